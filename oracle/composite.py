@@ -89,7 +89,7 @@ def composite_dense_bwd(surfs_rgb, surfs_alpha, rgb_bg, g_rgb, carry="f32"):
 
       rgb_c   = sum_k T_k a_k c_kc + T_K bg_c        (outer->inner, T_K = bgT)
       g_c_kc  = g_c * w_k
-      S_{K-1} = g . bg ;  S_{k-1} = a_k (g . c_k) + (1 - a_k) S_k
+      S_{K-1} = g . bg ;  S_{k-1} = a_k (g . c_k) + om_k S_k   (om_k = fp16(1 - a_k))
       g_a_k   = T_k * (g . c_k - S_k)
       g_bg_c  = g_c * bgT
     Returns (g_surfs_rgb [N,K,3], g_surfs_alpha [N,K], g_rgb_bg [N,3]) in
@@ -124,6 +124,6 @@ def composite_dense_bwd(surfs_rgb, surfs_alpha, rgb_bg, g_rgb, carry="f32"):
     g_a = np.empty((N, K), f32)
     for k in range(K - 1, -1, -1):
         g_a[:, k] = T[:, k] * (r[:, k] - S)
-        S = a[:, k] * r[:, k] + (f32(1.0) - a[:, k]) * S
+        S = a[:, k] * r[:, k] + om_h[:, k].astype(f32) * S
     g_bg = g_rgb * bgT[:, None]
     return g_c[:, ::-1].copy(), g_a[:, ::-1].copy(), g_bg

@@ -1,0 +1,70 @@
+"""Dense K-shell composite op (host side of SURVEY §8a row A7).
+
+Mirrors the tail of VolSurfs.render_rays
+(/root/reference/volsurfs_py/methods/volsurfs.py:601-640, 704-708, 728-748):
+same inputs (per-shell rgb / alpha, inner->outer; background colour), same
+outputs (keys of the `ray_traced` dict).  One HIP kernel forward, one backward.
+"""
+import torch
+
+from . import _lib
+
+
+class _CompositeDense(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, surfs_rgb, surfs_alpha, rgb_bg, carry_f16):
+        N, K, _ = surfs_rgb.shape
+        surfs_rgb = _lib.check_f32(surfs_rgb.contiguous(), N, K, 3)
+        surfs_alpha = _lib.check_f32(surfs_alpha.contiguous().view(N, K), N, K)
+        rgb_bg = rgb_bg.contiguous()
+        bcast = rgb_bg.shape[0] == 1 and N != 1
+        _lib.check_f32(rgb_bg, 1 if bcast else N, 3)
+        dev = surfs_rgb.device
+        out_rgb = torch.empty(N, 3, device=dev)
+        out_fg = torch.empty(N, 3, device=dev)
+        out_bgT = torch.empty(N, 1, device=dev)
+        out_w = torch.empty(N, K, 1, device=dev)
+        out_rgb_h = torch.empty(N, K, 3, device=dev)
+        out_alpha_h = torch.empty(N, K, 1, device=dev)
+        _lib.call("vsa_composite_dense_fwd", surfs_rgb, surfs_alpha, rgb_bg, bcast, out_rgb,
+                  out_fg, out_bgT, out_w, out_rgb_h, out_alpha_h, N, K, int(carry_f16),
+                  _lib.stream_ptr())
+        ctx.save_for_backward(surfs_rgb, surfs_alpha, rgb_bg)
+        ctx.bcast = bcast
+        ctx.carry_f16 = int(carry_f16)
+        ctx.mark_non_differentiable(out_fg, out_bgT, out_w, out_rgb_h, out_alpha_h)
+        return out_rgb, out_fg, out_bgT, out_w, out_rgb_h, out_alpha_h
+
+    @staticmethod
+    def backward(ctx, g_rgb, *unused):
+        surfs_rgb, surfs_alpha, rgb_bg = ctx.saved_tensors
+        N, K, _ = surfs_rgb.shape
+        g_rgb = _lib.check_f32(g_rgb.contiguous(), N, 3)
+        g_c = torch.empty_like(surfs_rgb)
+        g_a = torch.empty_like(surfs_alpha)
+        need_bg = ctx.needs_input_grad[2]
+        g_bg = torch.empty(N, 3, device=g_rgb.device) if need_bg else None
+        _lib.call("vsa_composite_dense_bwd", surfs_rgb, surfs_alpha, rgb_bg, ctx.bcast, g_rgb,
+                  g_c, g_a, g_bg, N, K, ctx.carry_f16, _lib.stream_ptr())
+        if need_bg and ctx.bcast:
+            g_bg = g_bg.sum(0, keepdim=True)
+        return g_c, g_a, g_bg, None
+
+
+def composite_dense(surfs_rgb, surfs_alpha, rgb_bg, carry_f16=False):
+    """surfs_rgb [N,K,3], surfs_alpha [N,K] or [N,K,1] (inner->outer, zero on
+    miss), rgb_bg [N,3] or [1,3].  Returns the dict of volsurfs.py:738-748
+    (minus the pass-through buffers).  Only `rgb` carries gradient, as in the
+    reference's training loss (volsurfs.py:791, 806)."""
+    N, K = surfs_rgb.shape[:2]
+    alpha2d = surfs_alpha.reshape(N, K)
+    rgb, fg, bgT, w, rgb_h, alpha_h = _CompositeDense.apply(surfs_rgb, alpha2d, rgb_bg, carry_f16)
+    return {
+        "rgb": rgb,
+        "rgb_fg": fg,
+        "rgb_bg": rgb_bg.expand(N, 3).half().float(),
+        "surfs_alpha": alpha_h,
+        "surfs_rgb": rgb_h,
+        "surfs_blending_weights": w,
+        "bg_transmittance": bgT,
+    }

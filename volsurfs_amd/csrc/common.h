@@ -1,0 +1,29 @@
+// Shared helpers for the volsurfs_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VSA_WAVE 64
+
+#include "../../include/volsurfs_hip.h"
+
+// Launch-status helper: every C-ABI entry point returns 0 or the hipError_t of
+// its launch (the reference only *prints* launch errors, src/VolumeRendering.cu:64-75;
+// this library surfaces them to the caller, which raises).
+#define VSA_RETURN_LAUNCH_STATUS()            \
+  do {                                        \
+    hipError_t e__ = hipGetLastError();       \
+    return e__ == hipSuccess ? VSA_OK : (int)e__; \
+  } while (0)
+
+#define VSA_HIP_TRY(expr)                     \
+  do {                                        \
+    hipError_t e__ = (expr);                  \
+    if (e__ != hipSuccess) return (int)e__;   \
+  } while (0)
+
+typedef _Float16 half_t;
+
+__device__ __forceinline__ float vsa_round_f16(float x) { return (float)(half_t)x; }
+
+static inline int vsa_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }

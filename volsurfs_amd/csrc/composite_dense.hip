@@ -1,0 +1,279 @@
+// Dense K-shell alpha composite, forward and backward.
+//
+// Replaces the ~15 PyTorch elementwise kernels of
+// volsurfs_py/methods/volsurfs.py:601-640 + :704-708 (and their autograd replay)
+// with one HBM-bound kernel per direction.  fp16 rounding points follow the
+// reference exactly (see oracle/composite.py for the list); I/O is fp32.
+//
+// Layout: surfs_rgb [N,K,3], surfs_alpha [N,K], inner->outer shell order, row
+// major fp32.  A workgroup owns a tile of 256 consecutive rays; the tile's
+// rgb/alpha slabs are contiguous in HBM, so they are streamed with 16-B/lane
+// coalesced loads into LDS (ray stride padded odd -> conflict-free per-ray
+// reads), one lane then composites one ray in registers, and results go back
+// through LDS as 16-B/lane coalesced stores.
+//
+// Algorithmic bytes (fp32 I/O): fwd 16K + 12 B/ray (+12 with per-ray bg),
+// bwd 16K + 12 read, 16K written  =>  24 + 48K B/ray fwd+bwd (264 @ K=5).
+#include "common.h"
+
+namespace {
+
+constexpr int TILE = 256;
+
+template <int K>
+struct Lds {
+  static constexpr int SC = (3 * K) | 1;  // odd ray stride (floats) for rgb
+  static constexpr int SA = K | 1;        // odd ray stride for alpha
+};
+
+// Coalesced slab copy HBM -> LDS (rows of W floats -> stride S floats).
+template <int W, int S>
+__device__ __forceinline__ void slab_load(const float* __restrict__ g, float* __restrict__ s,
+                                          int rows_valid) {
+  const int total = rows_valid * W;
+  const int nvec = total >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  for (int v = threadIdx.x; v < nvec; v += TILE) {
+    float4 x = g4[v];
+    int e = v << 2;
+    float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int r = (e + i) / W;
+      int j = (e + i) - r * W;
+      s[r * S + j] = xs[i];
+    }
+  }
+  for (int e = (nvec << 2) + threadIdx.x; e < total; e += TILE) {
+    int r = e / W;
+    s[r * S + (e - r * W)] = g[e];
+  }
+}
+
+template <int W, int S>
+__device__ __forceinline__ void slab_store(float* __restrict__ g, const float* __restrict__ s,
+                                           int rows_valid) {
+  const int total = rows_valid * W;
+  const int nvec = total >> 2;
+  float4* g4 = reinterpret_cast<float4*>(g);
+  for (int v = threadIdx.x; v < nvec; v += TILE) {
+    int e = v << 2;
+    float xs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int r = (e + i) / W;
+      int j = (e + i) - r * W;
+      xs[i] = s[r * S + j];
+    }
+    g4[v] = make_float4(xs[0], xs[1], xs[2], xs[3]);
+  }
+  for (int e = (nvec << 2) + threadIdx.x; e < total; e += TILE) {
+    int r = e / W;
+    g[e] = s[r * S + (e - r * W)];
+  }
+}
+
+// Per-ray forward in registers.  Index k runs inner->outer in memory; the
+// composite walks outer->inner (k = K-1 .. 0), volsurfs.py:602-603.
+template <int K, bool CARRY_F16>
+struct RayFwd {
+  float a[K], c[K][3], T[K], w[K], om[K];
+  float bgT, fg[3];
+  __device__ __forceinline__ void run(const float* sc, const float* sa) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      a[k] = vsa_round_f16(sa[k]);
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) c[k][ch] = vsa_round_f16(sc[3 * k + ch]);
+      om[k] = vsa_round_f16(1.0f - a[k]);
+    }
+    float acc = 1.0f, Tp = 1.0f;
+    fg[0] = fg[1] = fg[2] = 0.f;
+#pragma unroll
+    for (int k = K - 1; k >= 0; --k) {
+      T[k] = Tp;
+      if (CARRY_F16) {
+        Tp = vsa_round_f16(Tp * om[k]);
+      } else {
+        acc = acc * om[k];
+        Tp = vsa_round_f16(acc);
+      }
+      w[k] = vsa_round_f16(T[k] * a[k]);
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) fg[ch] += vsa_round_f16(c[k][ch] * w[k]);
+    }
+    bgT = Tp;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) fg[ch] = vsa_round_f16(fg[ch]);
+  }
+};
+
+template <int K, bool CARRY_F16>
+__global__ __launch_bounds__(TILE) void composite_dense_fwd_kernel(
+    const float* __restrict__ surfs_rgb, const float* __restrict__ surfs_alpha,
+    const float* __restrict__ rgb_bg, int bg_bcast, float* __restrict__ out_rgb,
+    float* __restrict__ out_rgb_fg, float* __restrict__ out_bgT, float* __restrict__ out_w,
+    float* __restrict__ out_rgb_h, float* __restrict__ out_alpha_h, int N) {
+  using L = Lds<K>;
+  __shared__ float s_c[TILE * L::SC];
+  __shared__ float s_a[TILE * L::SA];
+  __shared__ float s_o[TILE * 3];
+  const long long ray0 = (long long)blockIdx.x * TILE;
+  const int rows = min(TILE, (int)(N - ray0));
+  slab_load<3 * K, L::SC>(surfs_rgb + ray0 * 3 * K, s_c, rows);
+  slab_load<K, L::SA>(surfs_alpha + ray0 * K, s_a, rows);
+  if (!bg_bcast) slab_load<3, 3>(rgb_bg + ray0 * 3, s_o, rows);
+  __syncthreads();
+  const int r = threadIdx.x;
+  if (r < rows) {
+    RayFwd<K, CARRY_F16> f;
+    f.run(s_c + r * L::SC, s_a + r * L::SA);
+    float bg[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+      bg[ch] = vsa_round_f16(bg_bcast ? rgb_bg[ch] : s_o[r * 3 + ch]);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+      s_o[r * 3 + ch] = vsa_round_f16(f.fg[ch] + vsa_round_f16(f.bgT * bg[ch]));
+    const long long n = ray0 + r;
+    if (out_rgb_fg) {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) out_rgb_fg[n * 3 + ch] = f.fg[ch];
+    }
+    if (out_bgT) out_bgT[n] = f.bgT;
+    if (out_w) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) out_w[n * K + k] = f.w[k];
+    }
+    if (out_alpha_h) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) out_alpha_h[n * K + k] = f.a[k];
+    }
+    if (out_rgb_h) {
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) out_rgb_h[(n * K + k) * 3 + ch] = f.c[k][ch];
+    }
+  }
+  __syncthreads();
+  slab_store<3, 3>(out_rgb + ray0 * 3, s_o, rows);
+}
+
+template <int K, bool CARRY_F16>
+__global__ __launch_bounds__(TILE) void composite_dense_bwd_kernel(
+    const float* __restrict__ surfs_rgb, const float* __restrict__ surfs_alpha,
+    const float* __restrict__ rgb_bg, int bg_bcast, const float* __restrict__ g_rgb,
+    float* __restrict__ g_surfs_rgb, float* __restrict__ g_surfs_alpha,
+    float* __restrict__ g_rgb_bg, int N) {
+  using L = Lds<K>;
+  __shared__ float s_c[TILE * L::SC];
+  __shared__ float s_a[TILE * L::SA];
+  __shared__ float s_g[TILE * 3];
+  __shared__ float s_b[TILE * 3];
+  const long long ray0 = (long long)blockIdx.x * TILE;
+  const int rows = min(TILE, (int)(N - ray0));
+  slab_load<3 * K, L::SC>(surfs_rgb + ray0 * 3 * K, s_c, rows);
+  slab_load<K, L::SA>(surfs_alpha + ray0 * K, s_a, rows);
+  slab_load<3, 3>(g_rgb + ray0 * 3, s_g, rows);
+  if (!bg_bcast) slab_load<3, 3>(rgb_bg + ray0 * 3, s_b, rows);
+  __syncthreads();
+  const int r = threadIdx.x;
+  if (r < rows) {
+    RayFwd<K, CARRY_F16> f;
+    float* sc = s_c + r * L::SC;
+    float* sa = s_a + r * L::SA;
+    f.run(sc, sa);
+    float g[3], bg[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      g[ch] = s_g[r * 3 + ch];
+      bg[ch] = vsa_round_f16(bg_bcast ? rgb_bg[ch] : s_b[r * 3 + ch]);
+    }
+    // S_{K-1} = g.bg ; walk inner -> outer side (k = 0 is the innermost shell,
+    // i.e. the LAST one in composite order), oracle/composite.py.
+    float S = g[0] * bg[0] + g[1] * bg[1] + g[2] * bg[2];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float rk = g[0] * f.c[k][0] + g[1] * f.c[k][1] + g[2] * f.c[k][2];
+      sa[k] = f.T[k] * (rk - S);
+      S = f.a[k] * rk + f.om[k] * S;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) sc[3 * k + ch] = g[ch] * f.w[k];
+    }
+    if (g_rgb_bg) {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) s_b[r * 3 + ch] = g[ch] * f.bgT;
+    }
+  }
+  __syncthreads();
+  slab_store<3 * K, L::SC>(g_surfs_rgb + ray0 * 3 * K, s_c, rows);
+  slab_store<K, L::SA>(g_surfs_alpha + ray0 * K, s_a, rows);
+  if (g_rgb_bg) slab_store<3, 3>(g_rgb_bg + ray0 * 3, s_b, rows);
+}
+
+}  // namespace
+
+#define VSA_K_DISPATCH(K_, BODY)              \
+  switch (K_) {                               \
+    case 1: { constexpr int KK = 1; BODY; } break;   \
+    case 2: { constexpr int KK = 2; BODY; } break;   \
+    case 3: { constexpr int KK = 3; BODY; } break;   \
+    case 4: { constexpr int KK = 4; BODY; } break;   \
+    case 5: { constexpr int KK = 5; BODY; } break;   \
+    case 6: { constexpr int KK = 6; BODY; } break;   \
+    case 7: { constexpr int KK = 7; BODY; } break;   \
+    case 8: { constexpr int KK = 8; BODY; } break;   \
+    case 9: { constexpr int KK = 9; BODY; } break;   \
+    default: return VSA_ERR_UNSUPPORTED;      \
+  }
+
+extern "C" int vsa_composite_dense_fwd(const float* surfs_rgb, const float* surfs_alpha,
+                                       const float* rgb_bg, int bg_is_broadcast, float* out_rgb,
+                                       float* out_rgb_fg, float* out_bg_transmittance,
+                                       float* out_weights, float* out_surfs_rgb_h,
+                                       float* out_surfs_alpha_h, int nr_rays, int nr_shells,
+                                       int carry_f16, void* stream) {
+  if (nr_rays < 0 || !out_rgb) return VSA_ERR_ARG;
+  if (nr_rays == 0) return VSA_OK;
+  if (!surfs_rgb || !surfs_alpha || !rgb_bg) return VSA_ERR_ARG;
+  dim3 grid(vsa_div_up(nr_rays, TILE)), block(TILE);
+  hipStream_t st = (hipStream_t)stream;
+  VSA_K_DISPATCH(nr_shells, {
+    if (carry_f16)
+      hipLaunchKernelGGL((composite_dense_fwd_kernel<KK, true>), grid, block, 0, st, surfs_rgb,
+                         surfs_alpha, rgb_bg, bg_is_broadcast, out_rgb, out_rgb_fg,
+                         out_bg_transmittance, out_weights, out_surfs_rgb_h, out_surfs_alpha_h,
+                         nr_rays);
+    else
+      hipLaunchKernelGGL((composite_dense_fwd_kernel<KK, false>), grid, block, 0, st, surfs_rgb,
+                         surfs_alpha, rgb_bg, bg_is_broadcast, out_rgb, out_rgb_fg,
+                         out_bg_transmittance, out_weights, out_surfs_rgb_h, out_surfs_alpha_h,
+                         nr_rays);
+  });
+  VSA_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int vsa_composite_dense_bwd(const float* surfs_rgb, const float* surfs_alpha,
+                                       const float* rgb_bg, int bg_is_broadcast,
+                                       const float* g_rgb, float* g_surfs_rgb,
+                                       float* g_surfs_alpha, float* g_rgb_bg, int nr_rays,
+                                       int nr_shells, int carry_f16, void* stream) {
+  if (nr_rays < 0) return VSA_ERR_ARG;
+  if (nr_rays == 0) return VSA_OK;
+  if (!surfs_rgb || !surfs_alpha || !rgb_bg || !g_rgb || !g_surfs_rgb || !g_surfs_alpha)
+    return VSA_ERR_ARG;
+  dim3 grid(vsa_div_up(nr_rays, TILE)), block(TILE);
+  hipStream_t st = (hipStream_t)stream;
+  VSA_K_DISPATCH(nr_shells, {
+    if (carry_f16)
+      hipLaunchKernelGGL((composite_dense_bwd_kernel<KK, true>), grid, block, 0, st, surfs_rgb,
+                         surfs_alpha, rgb_bg, bg_is_broadcast, g_rgb, g_surfs_rgb, g_surfs_alpha,
+                         g_rgb_bg, nr_rays);
+    else
+      hipLaunchKernelGGL((composite_dense_bwd_kernel<KK, false>), grid, block, 0, st, surfs_rgb,
+                         surfs_alpha, rgb_bg, bg_is_broadcast, g_rgb, g_surfs_rgb, g_surfs_alpha,
+                         g_rgb_bg, nr_rays);
+  });
+  VSA_RETURN_LAUNCH_STATUS();
+}
