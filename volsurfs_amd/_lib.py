@@ -51,6 +51,10 @@ def lib():
             raise VolsurfsHipError(
                 f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C volsurfs_amd/csrc`. There is no CPU fallback.")
+        # torch ships its own libamdhip64; import it first so that this library
+        # binds to the SAME HIP runtime instance (two runtimes in one process do
+        # not share devices / streams).
+        import torch  # noqa: F401
         _lib = ctypes.CDLL(LIB_PATH)
         for name in declared_symbols():
             fn = getattr(_lib, name)  # AttributeError if the .so lacks a declared symbol

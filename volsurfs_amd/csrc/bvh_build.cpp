@@ -1,0 +1,274 @@
+// Host-side BVH builder for the K shell meshes (build half).
+//
+// Replaces `raytracelib.RayTracer(tensor_meshes)` (call site
+// /root/reference/volsurfs_py/methods/volsurfs.py:128); raytracelib's source is
+// not under /root/reference, so this is a from-scratch design: a binned-SAH
+// binary BVH whose 64-byte nodes carry BOTH children's boxes (one 64-B fetch =
+// two slab tests on the GPU), leaves of <= leaf_size triangles stored
+// contiguously in traversal order as (v0, e1, e2) float4 triples.
+//
+// Node (16 x 4 B):  c0.min.xyz c0.max.xyz c1.min.xyz c1.max.xyz ref0 ref1 cnt0 cnt1
+//   ref >= 0 : index of an inner node; cnt == 0
+//   ref <  0 : leaf, first triangle = ~ref, cnt triangles
+// Triangle (12 x 4 B): v0.xyz id | e1.xyz 0 | e2.xyz 0   (id = original face index)
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/volsurfs_hip.h"
+
+namespace {
+
+struct V3 {
+  float x, y, z;
+};
+inline V3 vmin(V3 a, V3 b) { return {std::min(a.x, b.x), std::min(a.y, b.y), std::min(a.z, b.z)}; }
+inline V3 vmax(V3 a, V3 b) { return {std::max(a.x, b.x), std::max(a.y, b.y), std::max(a.z, b.z)}; }
+inline float axis(const V3& v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
+
+struct Box {
+  V3 lo{INFINITY, INFINITY, INFINITY}, hi{-INFINITY, -INFINITY, -INFINITY};
+  void grow(const V3& p) { lo = vmin(lo, p); hi = vmax(hi, p); }
+  void grow(const Box& b) { lo = vmin(lo, b.lo); hi = vmax(hi, b.hi); }
+  float area() const {
+    float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+    if (dx < 0) return 0.f;
+    return 2.f * (dx * dy + dy * dz + dz * dx);
+  }
+};
+
+struct BuildNode {
+  Box box[2];
+  int32_t ref[2];
+  int32_t cnt[2];
+};
+
+}  // namespace
+
+struct vsa_bvh {
+  std::vector<BuildNode> nodes;
+  std::vector<float> tris;  // 12 floats per triangle, leaf order
+  int max_depth = 0;
+  Box root_box;
+};
+
+namespace {
+
+struct Builder {
+  const float* verts;
+  const int32_t* faces;
+  int leaf_size;
+  std::vector<Box> tbox;
+  std::vector<V3> tcen;
+  std::vector<int32_t> order;
+  vsa_bvh* out;
+  float pad;
+
+  static constexpr int NBINS = 16;
+
+  Box padded(Box b) const {
+    // conservative padding so that the fp32 slab test on the GPU never culls a
+    // triangle that the (exact-formula) triangle test would accept
+    V3 e{pad + 1e-6f * std::max(std::fabs(b.lo.x), std::fabs(b.hi.x)),
+         pad + 1e-6f * std::max(std::fabs(b.lo.y), std::fabs(b.hi.y)),
+         pad + 1e-6f * std::max(std::fabs(b.lo.z), std::fabs(b.hi.z))};
+    b.lo = {b.lo.x - e.x, b.lo.y - e.y, b.lo.z - e.z};
+    b.hi = {b.hi.x + e.x, b.hi.y + e.y, b.hi.z + e.z};
+    return b;
+  }
+
+  // Emits the subtree over order[begin,end); returns (ref, cnt, box).
+  void emit_leaf(int begin, int end, int32_t& ref, int32_t& cnt) {
+    int first = (int)(out->tris.size() / 12);
+    for (int i = begin; i < end; ++i) {
+      int f = order[i];
+      const float* a = verts + 3 * (size_t)faces[3 * (size_t)f + 0];
+      const float* b = verts + 3 * (size_t)faces[3 * (size_t)f + 1];
+      const float* c = verts + 3 * (size_t)faces[3 * (size_t)f + 2];
+      float idf;
+      int32_t id = f;
+      std::memcpy(&idf, &id, 4);
+      float t[12] = {a[0], a[1], a[2], idf, b[0] - a[0], b[1] - a[1], b[2] - a[2], 0.f,
+                     c[0] - a[0], c[1] - a[1], c[2] - a[2], 0.f};
+      out->tris.insert(out->tris.end(), t, t + 12);
+    }
+    ref = ~first;
+    cnt = end - begin;
+  }
+
+  void build(int begin, int end, int depth, int32_t& ref, int32_t& cnt, Box& box) {
+    box = Box();
+    Box cbox;
+    for (int i = begin; i < end; ++i) {
+      box.grow(tbox[order[i]]);
+      cbox.grow(tcen[order[i]]);
+    }
+    out->max_depth = std::max(out->max_depth, depth);
+    int n = end - begin;
+    if (n <= leaf_size) {
+      emit_leaf(begin, end, ref, cnt);
+      return;
+    }
+    // binned SAH over the widest centroid axis first, then the others
+    int best_axis = -1, best_bin = -1;
+    float best_cost = INFINITY;
+    for (int ax = 0; ax < 3; ++ax) {
+      float lo = axis(cbox.lo, ax), hi = axis(cbox.hi, ax);
+      if (!(hi > lo)) continue;
+      Box bb[NBINS];
+      int bc[NBINS] = {0};
+      float scale = NBINS / (hi - lo);
+      for (int i = begin; i < end; ++i) {
+        int t = order[i];
+        int b = std::min(NBINS - 1, (int)((axis(tcen[t], ax) - lo) * scale));
+        bb[b].grow(tbox[t]);
+        bc[b]++;
+      }
+      float ra[NBINS];
+      int rc[NBINS];
+      Box acc;
+      int c = 0;
+      for (int b = NBINS - 1; b > 0; --b) {
+        acc.grow(bb[b]);
+        c += bc[b];
+        ra[b] = acc.area();
+        rc[b] = c;
+      }
+      acc = Box();
+      c = 0;
+      for (int b = 0; b < NBINS - 1; ++b) {
+        acc.grow(bb[b]);
+        c += bc[b];
+        if (c == 0 || rc[b + 1] == 0) continue;
+        float cost = acc.area() * c + ra[b + 1] * rc[b + 1];
+        if (cost < best_cost) {
+          best_cost = cost;
+          best_axis = ax;
+          best_bin = b;
+        }
+      }
+    }
+    int mid;
+    if (best_axis < 0 || depth > 48) {
+      // degenerate centroids (or runaway depth): median split by index
+      if (best_axis < 0 && n <= 4 * leaf_size) {
+        // many coincident centroids: chop into leaves through a balanced chain
+      }
+      mid = begin + n / 2;
+      int ax = 0;
+      float ex = cbox.hi.x - cbox.lo.x, ey = cbox.hi.y - cbox.lo.y, ez = cbox.hi.z - cbox.lo.z;
+      if (ey > ex && ey >= ez) ax = 1;
+      else if (ez > ex && ez > ey) ax = 2;
+      std::nth_element(order.begin() + begin, order.begin() + mid, order.begin() + end,
+                       [&](int a, int b) { return axis(tcen[a], ax) < axis(tcen[b], ax); });
+    } else {
+      float lo = axis(cbox.lo, best_axis), hi = axis(cbox.hi, best_axis);
+      float scale = NBINS / (hi - lo);
+      auto it = std::partition(order.begin() + begin, order.begin() + end, [&](int t) {
+        int b = std::min(NBINS - 1, (int)((axis(tcen[t], best_axis) - lo) * scale));
+        return b <= best_bin;
+      });
+      mid = (int)(it - order.begin());
+      if (mid == begin || mid == end) mid = begin + n / 2;
+    }
+    int me = (int)out->nodes.size();
+    out->nodes.emplace_back();
+    BuildNode tmp;
+    Box b0, b1;
+    build(begin, mid, depth + 1, tmp.ref[0], tmp.cnt[0], b0);
+    build(mid, end, depth + 1, tmp.ref[1], tmp.cnt[1], b1);
+    tmp.box[0] = padded(b0);
+    tmp.box[1] = padded(b1);
+    out->nodes[me] = tmp;
+    ref = me;
+    cnt = 0;
+  }
+};
+
+}  // namespace
+
+extern "C" int vsa_bvh_build(const float* verts, const int32_t* faces, int nr_verts, int nr_faces,
+                             int leaf_size, vsa_bvh** out_bvh) {
+  if (!verts || !faces || !out_bvh || nr_verts <= 0 || nr_faces <= 0) return VSA_ERR_ARG;
+  if (leaf_size < 1) leaf_size = 4;
+  if (leaf_size > 8) leaf_size = 8;
+  for (size_t i = 0; i < (size_t)nr_faces * 3; ++i)
+    if (faces[i] < 0 || faces[i] >= nr_verts) return VSA_ERR_ARG;
+  vsa_bvh* bvh = new vsa_bvh();
+  Builder b;
+  b.verts = verts;
+  b.faces = faces;
+  b.leaf_size = leaf_size;
+  b.out = bvh;
+  b.tbox.resize(nr_faces);
+  b.tcen.resize(nr_faces);
+  b.order.resize(nr_faces);
+  Box all;
+  for (int f = 0; f < nr_faces; ++f) {
+    Box bx;
+    for (int k = 0; k < 3; ++k) {
+      const float* p = verts + 3 * (size_t)faces[3 * (size_t)f + k];
+      bx.grow(V3{p[0], p[1], p[2]});
+    }
+    b.tbox[f] = bx;
+    b.tcen[f] = {0.5f * (bx.lo.x + bx.hi.x), 0.5f * (bx.lo.y + bx.hi.y), 0.5f * (bx.lo.z + bx.hi.z)};
+    b.order[f] = f;
+    all.grow(bx);
+  }
+  float diag = std::sqrt((all.hi.x - all.lo.x) * (all.hi.x - all.lo.x) +
+                         (all.hi.y - all.lo.y) * (all.hi.y - all.lo.y) +
+                         (all.hi.z - all.lo.z) * (all.hi.z - all.lo.z));
+  b.pad = 1e-6f * diag;
+  bvh->root_box = b.padded(all);
+  bvh->nodes.reserve((size_t)nr_faces);
+  bvh->tris.reserve((size_t)nr_faces * 12);
+  int32_t ref, cnt;
+  Box box;
+  b.build(0, nr_faces, 0, ref, cnt, box);
+  if (bvh->nodes.empty()) {
+    // a single leaf: wrap it in a root whose second child is empty
+    BuildNode root;
+    root.box[0] = b.padded(box);
+    root.ref[0] = ref;
+    root.cnt[0] = cnt;
+    root.box[1] = Box();
+    root.box[1].lo = {1.f, 1.f, 1.f};
+    root.box[1].hi = {-1.f, -1.f, -1.f};  // inverted: never hit
+    root.ref[1] = ~0;
+    root.cnt[1] = 0;
+    bvh->nodes.push_back(root);
+  }
+  *out_bvh = bvh;
+  return VSA_OK;
+}
+
+extern "C" int vsa_bvh_sizes(const vsa_bvh* bvh, int* nr_nodes, int* nr_tris, int* max_depth) {
+  if (!bvh) return VSA_ERR_ARG;
+  if (nr_nodes) *nr_nodes = (int)bvh->nodes.size();
+  if (nr_tris) *nr_tris = (int)(bvh->tris.size() / 12);
+  if (max_depth) *max_depth = bvh->max_depth;
+  return VSA_OK;
+}
+
+extern "C" int vsa_bvh_export(const vsa_bvh* bvh, float* nodes_out, float* tris_out) {
+  if (!bvh || !nodes_out || !tris_out) return VSA_ERR_ARG;
+  for (size_t i = 0; i < bvh->nodes.size(); ++i) {
+    const BuildNode& n = bvh->nodes[i];
+    float* o = nodes_out + 16 * i;
+    o[0] = n.box[0].lo.x; o[1] = n.box[0].lo.y; o[2] = n.box[0].lo.z;
+    o[3] = n.box[0].hi.x; o[4] = n.box[0].hi.y; o[5] = n.box[0].hi.z;
+    o[6] = n.box[1].lo.x; o[7] = n.box[1].lo.y; o[8] = n.box[1].lo.z;
+    o[9] = n.box[1].hi.x; o[10] = n.box[1].hi.y; o[11] = n.box[1].hi.z;
+    int32_t tail[4] = {n.ref[0], n.ref[1], n.cnt[0], n.cnt[1]};
+    std::memcpy(o + 12, tail, 16);
+  }
+  std::memcpy(tris_out, bvh->tris.data(), bvh->tris.size() * sizeof(float));
+  return VSA_OK;
+}
+
+extern "C" int vsa_bvh_destroy(vsa_bvh* bvh) {
+  delete bvh;
+  return VSA_OK;
+}

@@ -26,4 +26,13 @@ typedef _Float16 half_t;
 
 __device__ __forceinline__ float vsa_round_f16(float x) { return (float)(half_t)x; }
 
+// Makes an fp32 value opaque to the optimiser.  hipcc folds
+// `(half)(f32_a * f32_b)` into v_fma_mixlo_f16, which rounds the exact product
+// ONCE to fp16; ATen rounds to fp32 first and then to fp16.  Where bit parity
+// with that double rounding matters, pin the fp32 intermediate with this.
+__device__ __forceinline__ float vsa_pin_f32(float x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
 static inline int vsa_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }

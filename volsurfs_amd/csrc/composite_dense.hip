@@ -95,7 +95,7 @@ struct RayFwd {
       if (CARRY_F16) {
         Tp = vsa_round_f16(Tp * om[k]);
       } else {
-        acc = acc * om[k];
+        acc = vsa_pin_f32(acc * om[k]);
         Tp = vsa_round_f16(acc);
       }
       w[k] = vsa_round_f16(T[k] * a[k]);
@@ -104,7 +104,7 @@ struct RayFwd {
     }
     bgT = Tp;
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) fg[ch] = vsa_round_f16(fg[ch]);
+    for (int ch = 0; ch < 3; ++ch) fg[ch] = vsa_round_f16(vsa_pin_f32(fg[ch]));
   }
 };
 
