@@ -33,6 +33,8 @@ extern "C" {
 #define VSA_ERR_ARG (-1)
 #define VSA_ERR_UNSUPPORTED (-2)
 
+#define VSA_MAX_SHELLS 16
+
 /* Library version / build info (sanity check used by the loader). */
 int vsa_version(void);
 
@@ -65,6 +67,54 @@ int vsa_composite_dense_bwd(const float* surfs_rgb, const float* surfs_alpha,
                             const float* rgb_bg, int bg_is_broadcast, const float* g_rgb,
                             float* g_surfs_rgb, float* g_surfs_alpha, float* g_rgb_bg,
                             int nr_rays, int nr_shells, int carry_f16, void* stream);
+
+/* ------------------------------------------------------------------------
+ * A2  BVH build (host) + K-shell closest-hit traversal (device).
+ * Replaces raytracelib.RayTracer(tensor_meshes) / .trace(rays_o, rays_d, mesh_id)
+ * at volsurfs_py/methods/volsurfs.py:128 and :476-485 (raytracelib is an
+ * un-vendored submodule, .gitmodules:14-17; a reference binding would wrap
+ * these in a class exposing `trace`).
+ *
+ * vsa_bvh_build  [host pointers]  verts [nv,3] f32, faces [nf,3] i32.
+ *   Binned-SAH binary BVH, leaves <= leaf_size (1..8) triangles.
+ * vsa_bvh_sizes  node / triangle counts and tree depth of a built BVH.
+ * vsa_bvh_export [host pointers]  nodes_out [nr_nodes,16] f32 (64-B nodes:
+ *   child0 box (6), child1 box (6), ref0, ref1, cnt0, cnt1 as i32 bits;
+ *   ref >= 0 inner node index, ref < 0 leaf with first triangle ~ref),
+ *   tris_out [nr_tris,12] f32 in leaf order: v0.xyz, original face id (i32
+ *   bits), e1.xyz, 0, e2.xyz, 0.  node_base / tri_base are added to the
+ *   references so that K meshes can be concatenated into one array pair.
+ */
+typedef struct vsa_bvh vsa_bvh;
+int vsa_bvh_build(const float* verts, const int32_t* faces, int nr_verts, int nr_faces,
+                  int leaf_size, vsa_bvh** out_bvh);
+int vsa_bvh_sizes(const vsa_bvh* bvh, int* nr_nodes, int* nr_tris, int* max_depth);
+int vsa_bvh_export(const vsa_bvh* bvh, float* nodes_out, float* tris_out, int node_base,
+                   int tri_base);
+int vsa_bvh_destroy(vsa_bvh* bvh);
+
+/* vsa_trace: closest hit of every ray against each of nr_meshes BVHs in ONE
+ * launch (grid.y = mesh).  mesh_roots [host, nr_meshes] = root node index of
+ * each mesh in `nodes`; max_depth = deepest tree (must be < 48).
+ *   rays_o, rays_d [N,3] f32 (rays_d need not be normalised; t is in units of
+ *   |rays_d|).  Hit iff t > t_min; closest = smallest t, ties -> smallest
+ *   original face id (order independent, bit-identical to the brute-force
+ *   oracle).  Outputs, mesh-major [nr_meshes, N]: hit_t (0 on miss),
+ *   hit_slot (index into `tris`, -1 on miss), hit_uv [.,.,2] = barycentric
+ *   weights of v1 and v2. */
+int vsa_trace(const float* nodes, const float* tris, const int32_t* mesh_roots, int nr_meshes,
+              int max_depth, const float* rays_o, const float* rays_d, int nr_rays, float t_min,
+              float* hit_t, int32_t* hit_slot, float* hit_uv, void* stream);
+
+/* vsa_hit_attributes: expands one mesh's hit records [N] into the dict
+ * raytracelib returns (volsurfs.py:496-501): is_hit [N] u8, triangles_id [N]
+ * i32 (original face index, -1 on miss), positions [N,3] = o + t d, normals
+ * [N,3] = unit geometric face normal (e1 x e2), barycentric [N,3] =
+ * (1-u-v, u, v).  Any output may be NULL. */
+int vsa_hit_attributes(const float* tris, const float* rays_o, const float* rays_d,
+                       const float* hit_t, const int32_t* hit_slot, const float* hit_uv,
+                       int nr_rays, uint8_t* is_hit, int32_t* tri_id, float* positions,
+                       float* normals, float* barycentric, void* stream);
 
 #ifdef __cplusplus
 }

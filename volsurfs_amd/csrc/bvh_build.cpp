@@ -151,11 +151,10 @@ struct Builder {
       }
     }
     int mid;
-    if (best_axis < 0 || depth > 48) {
-      // degenerate centroids (or runaway depth): median split by index
-      if (best_axis < 0 && n <= 4 * leaf_size) {
-        // many coincident centroids: chop into leaves through a balanced chain
-      }
+    if (best_axis < 0 || depth >= 24) {
+      // degenerate centroids, or SAH chain deeper than 24: balanced median
+      // splits from here on bound the depth by 24 + log2(n / leaf_size), which
+      // the traversal kernel's LDS stack (48 entries) relies on
       mid = begin + n / 2;
       int ax = 0;
       float ex = cbox.hi.x - cbox.lo.x, ey = cbox.hi.y - cbox.lo.y, ez = cbox.hi.z - cbox.lo.z;
@@ -252,8 +251,9 @@ extern "C" int vsa_bvh_sizes(const vsa_bvh* bvh, int* nr_nodes, int* nr_tris, in
   return VSA_OK;
 }
 
-extern "C" int vsa_bvh_export(const vsa_bvh* bvh, float* nodes_out, float* tris_out) {
-  if (!bvh || !nodes_out || !tris_out) return VSA_ERR_ARG;
+extern "C" int vsa_bvh_export(const vsa_bvh* bvh, float* nodes_out, float* tris_out,
+                              int node_base, int tri_base) {
+  if (!bvh || !nodes_out || !tris_out || node_base < 0 || tri_base < 0) return VSA_ERR_ARG;
   for (size_t i = 0; i < bvh->nodes.size(); ++i) {
     const BuildNode& n = bvh->nodes[i];
     float* o = nodes_out + 16 * i;
@@ -261,7 +261,10 @@ extern "C" int vsa_bvh_export(const vsa_bvh* bvh, float* nodes_out, float* tris_
     o[3] = n.box[0].hi.x; o[4] = n.box[0].hi.y; o[5] = n.box[0].hi.z;
     o[6] = n.box[1].lo.x; o[7] = n.box[1].lo.y; o[8] = n.box[1].lo.z;
     o[9] = n.box[1].hi.x; o[10] = n.box[1].hi.y; o[11] = n.box[1].hi.z;
-    int32_t tail[4] = {n.ref[0], n.ref[1], n.cnt[0], n.cnt[1]};
+    // rebase mesh-local references into the caller's concatenated arrays
+    int32_t tail[4] = {n.ref[0] >= 0 ? n.ref[0] + node_base : ~(~n.ref[0] + tri_base),
+                       n.ref[1] >= 0 ? n.ref[1] + node_base : ~(~n.ref[1] + tri_base),
+                       n.cnt[0], n.cnt[1]};
     std::memcpy(o + 12, tail, 16);
   }
   std::memcpy(tris_out, bvh->tris.data(), bvh->tris.size() * sizeof(float));

@@ -1,0 +1,227 @@
+// K-shell closest-hit ray / mesh intersection (trace half).
+//
+// Replaces the K sequential `self.raytracer.trace(rays_o, rays_d, mesh_id=i)`
+// calls and their K host syncs on `any_hit`
+// (/root/reference/volsurfs_py/methods/volsurfs.py:476-485; raytracelib itself
+// is not under /root/reference) with ONE launch over (ray tile, mesh):
+// grid.y = mesh, one lane per ray, per-lane traversal stack staged in LDS as
+// stack[depth][lane] (bank = lane -> conflict free), 64-byte nodes holding both
+// children's boxes (4 x dwordx4 per visit), leaf triangles as contiguous
+// (v0,e1,e2) float4 triples.
+//
+// Closest hit is defined order-independently (smallest t, ties -> smallest face
+// id) with the triangle test evaluated by one fixed fp32 formula, so the result
+// is bit-identical to the brute-force oracle (oracle/raytrace_ref.c).
+#include "common.h"
+
+namespace {
+
+constexpr int TRACE_BLOCK = 256;
+constexpr int TRACE_STACK = 48;
+
+struct Roots {
+  int root[VSA_MAX_SHELLS];
+};
+
+struct Hit {
+  float t, u, v;
+  int slot;  // index into the leaf-ordered triangle array, -1 = miss
+  int id;    // original face id (tie break)
+};
+
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+  return (ax * bx + ay * by) + az * bz;
+}
+
+// Moeller-Trumbore, two-sided, fixed evaluation order (mirrored by the oracle).
+__device__ __forceinline__ void tri_test(const float4 v0, const float4 e1, const float4 e2,
+                                         float ox, float oy, float oz, float dx, float dy,
+                                         float dz, float t_min, int slot, Hit& best) {
+  float px = dy * e2.z - dz * e2.y;
+  float py = dz * e2.x - dx * e2.z;
+  float pz = dx * e2.y - dy * e2.x;
+  float det = dot3(e1.x, e1.y, e1.z, px, py, pz);
+  if (fabsf(det) < 1e-20f) return;
+  float inv = 1.0f / det;
+  float tx = ox - v0.x, ty = oy - v0.y, tz = oz - v0.z;
+  float u = dot3(tx, ty, tz, px, py, pz) * inv;
+  if (!(u >= 0.0f && u <= 1.0f)) return;
+  float qx = ty * e1.z - tz * e1.y;
+  float qy = tz * e1.x - tx * e1.z;
+  float qz = tx * e1.y - ty * e1.x;
+  float v = dot3(dx, dy, dz, qx, qy, qz) * inv;
+  if (!(v >= 0.0f && u + v <= 1.0f)) return;
+  float t = dot3(e2.x, e2.y, e2.z, qx, qy, qz) * inv;
+  if (!(t > t_min)) return;
+  int id = __float_as_int(v0.w);
+  if (t < best.t || (t == best.t && id < best.id)) {
+    best.t = t;
+    best.u = u;
+    best.v = v;
+    best.slot = slot;
+    best.id = id;
+  }
+}
+
+__device__ __forceinline__ bool box_test(float lx, float ly, float lz, float hx, float hy,
+                                         float hz, float ox, float oy, float oz, float ix,
+                                         float iy, float iz, float t_min, float t_max,
+                                         float& t_near) {
+  float a = (lx - ox) * ix, b = (hx - ox) * ix;
+  float tn = fminf(a, b), tf = fmaxf(a, b);
+  a = (ly - oy) * iy;
+  b = (hy - oy) * iy;
+  tn = fmaxf(tn, fminf(a, b));
+  tf = fminf(tf, fmaxf(a, b));
+  a = (lz - oz) * iz;
+  b = (hz - oz) * iz;
+  tn = fmaxf(tn, fminf(a, b));
+  tf = fminf(tf, fmaxf(a, b));
+  t_near = tn;
+  // widen by a few ulps: the slab arithmetic is not the triangle arithmetic
+  return tn <= tf * 1.0000004f + 1e-30f && tf >= t_min && tn <= t_max;
+}
+
+__global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
+    const float4* __restrict__ nodes, const float4* __restrict__ tris, Roots roots,
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, int N, float t_min,
+    float* __restrict__ hit_t, int* __restrict__ hit_slot, float* __restrict__ hit_uv) {
+  __shared__ int s_stack[TRACE_STACK][TRACE_BLOCK];
+  const int lane = threadIdx.x;
+  const long long n = (long long)blockIdx.x * TRACE_BLOCK + lane;
+  const int mesh = blockIdx.y;
+  if (n >= N) return;
+  const float ox = rays_o[3 * n], oy = rays_o[3 * n + 1], oz = rays_o[3 * n + 2];
+  const float dx = rays_d[3 * n], dy = rays_d[3 * n + 1], dz = rays_d[3 * n + 2];
+  const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+
+  Hit best;
+  best.t = INFINITY;
+  best.u = best.v = 0.f;
+  best.slot = -1;
+  best.id = 0x7fffffff;
+
+  int cur = roots.root[mesh];
+  int sp = 0;
+  while (true) {
+    const float4 q0 = nodes[4 * (long long)cur + 0];
+    const float4 q1 = nodes[4 * (long long)cur + 1];
+    const float4 q2 = nodes[4 * (long long)cur + 2];
+    const float4 q3 = nodes[4 * (long long)cur + 3];
+    const int ref0 = __float_as_int(q3.x), ref1 = __float_as_int(q3.y);
+    const int cnt0 = __float_as_int(q3.z), cnt1 = __float_as_int(q3.w);
+    float tn0, tn1;
+    bool h0 = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ox, oy, oz, ix, iy, iz, t_min, best.t, tn0);
+    bool h1 = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ox, oy, oz, ix, iy, iz, t_min, best.t, tn1);
+    if (h0 && ref0 < 0) {
+      const int first = ~ref0;
+      for (int i = 0; i < cnt0; ++i) {
+        const long long s = first + i;
+        tri_test(tris[3 * s], tris[3 * s + 1], tris[3 * s + 2], ox, oy, oz, dx, dy, dz, t_min,
+                 (int)s, best);
+      }
+      h0 = false;
+    }
+    if (h1 && ref1 < 0) {
+      const int first = ~ref1;
+      for (int i = 0; i < cnt1; ++i) {
+        const long long s = first + i;
+        tri_test(tris[3 * s], tris[3 * s + 1], tris[3 * s + 2], ox, oy, oz, dx, dy, dz, t_min,
+                 (int)s, best);
+      }
+      h1 = false;
+    }
+    if (h0 && h1) {
+      const bool swap = tn1 < tn0;
+      const int near_ref = swap ? ref1 : ref0;
+      const int far_ref = swap ? ref0 : ref1;
+      s_stack[sp++][lane] = far_ref;
+      cur = near_ref;
+    } else if (h0) {
+      cur = ref0;
+    } else if (h1) {
+      cur = ref1;
+    } else {
+      if (sp == 0) break;
+      cur = s_stack[--sp][lane];
+    }
+  }
+  const long long o = (long long)mesh * N + n;
+  hit_t[o] = best.slot >= 0 ? best.t : 0.0f;
+  hit_slot[o] = best.slot;
+  hit_uv[2 * o] = best.u;
+  hit_uv[2 * o + 1] = best.v;
+}
+
+// Per-hit attributes in the shape raytracelib returns them
+// (volsurfs.py:496-501): positions, face normals, barycentrics, original ids.
+__global__ void hit_attributes_kernel(const float4* __restrict__ tris,
+                                      const float* __restrict__ rays_o,
+                                      const float* __restrict__ rays_d,
+                                      const float* __restrict__ hit_t,
+                                      const int* __restrict__ hit_slot,
+                                      const float* __restrict__ hit_uv, int N,
+                                      unsigned char* __restrict__ is_hit,
+                                      int* __restrict__ tri_id, float* __restrict__ positions,
+                                      float* __restrict__ normals, float* __restrict__ bary) {
+  const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int slot = hit_slot[n];
+  float p[3] = {0, 0, 0}, nn[3] = {0, 0, 0}, b[3] = {0, 0, 0};
+  int id = -1;
+  if (slot >= 0) {
+    const float t = hit_t[n];
+    for (int c = 0; c < 3; ++c) p[c] = rays_o[3 * n + c] + t * rays_d[3 * n + c];
+    const float4 v0 = tris[3 * (long long)slot], e1 = tris[3 * (long long)slot + 1],
+                 e2 = tris[3 * (long long)slot + 2];
+    id = __float_as_int(v0.w);
+    float cx = e1.y * e2.z - e1.z * e2.y, cy = e1.z * e2.x - e1.x * e2.z,
+          cz = e1.x * e2.y - e1.y * e2.x;
+    float len = sqrtf(dot3(cx, cy, cz, cx, cy, cz));
+    float inv = len > 0.f ? 1.0f / len : 0.f;
+    nn[0] = cx * inv; nn[1] = cy * inv; nn[2] = cz * inv;
+    const float u = hit_uv[2 * n], v = hit_uv[2 * n + 1];
+    b[0] = (1.0f - u) - v; b[1] = u; b[2] = v;
+  }
+  if (is_hit) is_hit[n] = slot >= 0;
+  if (tri_id) tri_id[n] = id;
+  for (int c = 0; c < 3; ++c) {
+    if (positions) positions[3 * n + c] = p[c];
+    if (normals) normals[3 * n + c] = nn[c];
+    if (bary) bary[3 * n + c] = b[c];
+  }
+}
+
+}  // namespace
+
+extern "C" int vsa_trace(const float* nodes, const float* tris, const int32_t* mesh_roots,
+                         int nr_meshes, int max_depth, const float* rays_o, const float* rays_d,
+                         int nr_rays, float t_min, float* hit_t, int32_t* hit_slot, float* hit_uv,
+                         void* stream) {
+  if (nr_meshes < 1 || nr_meshes > VSA_MAX_SHELLS || nr_rays < 0 || !mesh_roots) return VSA_ERR_ARG;
+  if (max_depth >= TRACE_STACK) return VSA_ERR_UNSUPPORTED;
+  if (nr_rays == 0) return VSA_OK;
+  if (!nodes || !tris || !rays_o || !rays_d || !hit_t || !hit_slot || !hit_uv) return VSA_ERR_ARG;
+  Roots r;
+  for (int i = 0; i < VSA_MAX_SHELLS; ++i) r.root[i] = i < nr_meshes ? mesh_roots[i] : 0;
+  dim3 grid(vsa_div_up(nr_rays, TRACE_BLOCK), nr_meshes), block(TRACE_BLOCK);
+  hipLaunchKernelGGL(trace_kernel, grid, block, 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(nodes), reinterpret_cast<const float4*>(tris),
+                     r, rays_o, rays_d, nr_rays, t_min, hit_t, hit_slot, hit_uv);
+  VSA_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int vsa_hit_attributes(const float* tris, const float* rays_o, const float* rays_d,
+                                  const float* hit_t, const int32_t* hit_slot,
+                                  const float* hit_uv, int nr_rays, uint8_t* is_hit,
+                                  int32_t* tri_id, float* positions, float* normals,
+                                  float* barycentric, void* stream) {
+  if (nr_rays < 0) return VSA_ERR_ARG;
+  if (nr_rays == 0) return VSA_OK;
+  if (!tris || !rays_o || !rays_d || !hit_t || !hit_slot || !hit_uv) return VSA_ERR_ARG;
+  hipLaunchKernelGGL(hit_attributes_kernel, dim3(vsa_div_up(nr_rays, 256)), dim3(256), 0,
+                     (hipStream_t)stream, reinterpret_cast<const float4*>(tris), rays_o, rays_d,
+                     hit_t, hit_slot, hit_uv, nr_rays, is_hit, tri_id, positions, normals,
+                     barycentric);
+  VSA_RETURN_LAUNCH_STATUS();
+}

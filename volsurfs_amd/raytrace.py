@@ -1,0 +1,107 @@
+"""RayTracer — raytracelib-shaped ray / K-shell intersector (SURVEY §8a A2, §8b
+"Secondary boundaries").
+
+Mirrors `raytracelib.RayTracer(list[TensorMesh])` / `.trace(rays_o, rays_d,
+mesh_id=int) -> dict` as called at
+/root/reference/volsurfs_py/methods/volsurfs.py:128 and :476-501, and adds
+`trace_all` (all K shells in one launch, no host sync) used by the fused path.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class RayTracer:
+    def __init__(self, tensor_meshes, leaf_size=4):
+        self.nr_meshes = len(tensor_meshes)
+        if not 1 <= self.nr_meshes <= 16:
+            raise _lib.VolsurfsHipError("RayTracer supports 1..16 meshes")
+        L = _lib.lib()
+        nodes_all, tris_all, roots = [], [], []
+        self.mesh_tri_offset, self.mesh_nr_tris = [], []
+        self.max_depth = 0
+        node_base = tri_base = 0
+        for m in tensor_meshes:
+            v = np.ascontiguousarray(m.vertices.detach().cpu().numpy(), np.float32)
+            f = np.ascontiguousarray(m.faces.detach().cpu().numpy(), np.int32)
+            h = ctypes.c_void_p()
+            rc = L.vsa_bvh_build(v.ctypes.data_as(ctypes.c_void_p), f.ctypes.data_as(ctypes.c_void_p),
+                                 ctypes.c_int(v.shape[0]), ctypes.c_int(f.shape[0]),
+                                 ctypes.c_int(leaf_size), ctypes.byref(h))
+            if rc != 0:
+                raise _lib.VolsurfsHipError(f"vsa_bvh_build failed with status {rc}")
+            nn, nt, md = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            L.vsa_bvh_sizes(h, ctypes.byref(nn), ctypes.byref(nt), ctypes.byref(md))
+            nodes = np.empty((nn.value, 16), np.float32)
+            tris = np.empty((nt.value, 12), np.float32)
+            rc = L.vsa_bvh_export(h, nodes.ctypes.data_as(ctypes.c_void_p),
+                                  tris.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(node_base),
+                                  ctypes.c_int(tri_base))
+            L.vsa_bvh_destroy(h)
+            if rc != 0:
+                raise _lib.VolsurfsHipError(f"vsa_bvh_export failed with status {rc}")
+            roots.append(node_base)
+            self.mesh_tri_offset.append(tri_base)
+            self.mesh_nr_tris.append(nt.value)
+            self.max_depth = max(self.max_depth, md.value)
+            node_base += nn.value
+            tri_base += nt.value
+            nodes_all.append(nodes)
+            tris_all.append(tris)
+        dev = tensor_meshes[0].vertices.device
+        self.device = dev
+        self.nodes = torch.from_numpy(np.concatenate(nodes_all, 0)).to(dev)
+        tris_np = np.concatenate(tris_all, 0)
+        self.tris = torch.from_numpy(tris_np).to(dev)
+        # original face id of every leaf-ordered triangle slot (for uv tables etc.)
+        self.slot_face_id = torch.from_numpy(tris_np[:, 3].copy().view(np.int32)).to(dev)
+        self._roots = (ctypes.c_int32 * self.nr_meshes)(*roots)
+        self.roots = roots
+
+    def trace_all(self, rays_o, rays_d, t_min=0.0):
+        """All K shells, one launch.  Returns hit_t [K,N] f32, hit_slot [K,N]
+        i32 (global index into self.tris, -1 = miss), hit_uv [K,N,2] f32."""
+        N = rays_o.shape[0]
+        rays_o = _lib.check_f32(rays_o.contiguous(), N, 3)
+        rays_d = _lib.check_f32(rays_d.contiguous(), N, 3)
+        K = self.nr_meshes
+        hit_t = torch.empty(K, N, device=rays_o.device)
+        hit_slot = torch.empty(K, N, dtype=torch.int32, device=rays_o.device)
+        hit_uv = torch.empty(K, N, 2, device=rays_o.device)
+        _lib.call("vsa_trace", self.nodes, self.tris, self._roots, K, self.max_depth, rays_o,
+                  rays_d, N, float(t_min), hit_t, hit_slot, hit_uv, _lib.stream_ptr())
+        return hit_t, hit_slot, hit_uv
+
+    def trace(self, rays_o, rays_d, mesh_id=0, t_min=0.0):
+        """raytracelib-shaped single-mesh trace (volsurfs.py:480-501)."""
+        N = rays_o.shape[0]
+        rays_o = _lib.check_f32(rays_o.contiguous(), N, 3)
+        rays_d = _lib.check_f32(rays_d.contiguous(), N, 3)
+        dev = rays_o.device
+        hit_t = torch.empty(1, N, device=dev)
+        hit_slot = torch.empty(1, N, dtype=torch.int32, device=dev)
+        hit_uv = torch.empty(1, N, 2, device=dev)
+        root = (ctypes.c_int32 * 1)(self.roots[mesh_id])
+        st = _lib.stream_ptr()
+        _lib.call("vsa_trace", self.nodes, self.tris, root, 1, self.max_depth, rays_o, rays_d, N,
+                  float(t_min), hit_t, hit_slot, hit_uv, st)
+        is_hit = torch.empty(N, dtype=torch.uint8, device=dev)
+        tri_id = torch.empty(N, dtype=torch.int32, device=dev)
+        pos = torch.empty(N, 3, device=dev)
+        nrm = torch.empty(N, 3, device=dev)
+        bary = torch.empty(N, 3, device=dev)
+        _lib.call("vsa_hit_attributes", self.tris, rays_o, rays_d, hit_t, hit_slot, hit_uv, N,
+                  is_hit, tri_id, pos, nrm, bary, st)
+        is_hit = is_hit.bool()
+        return {
+            "any_hit": bool(is_hit.any().item()),  # host sync, as in the reference (volsurfs.py:481)
+            "is_hit": is_hit,
+            "triangles_id": tri_id.long(),
+            "depth": hit_t[0],
+            "positions": pos,
+            "normals": nrm,
+            "barycentric": bary,
+        }
