@@ -1,0 +1,139 @@
+"""Oracle: 2-D multiresolution hash grid + fully-fused MLP, as configured at
+/root/reference/volsurfs_py/models/neural_texture.py:54-77.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+The reference gets both from `tinycudann` (NVlabs/tiny-cuda-nn master, pip dep
+with no version pin: README.md:45-46), which is absent.  This restates the
+published algorithm (Instant-NGP / tiny-cuda-nn `GridEncoding` with
+`GridType::Hash`, `InterpolationType::Linear`; `FullyFusedMLP`):
+  scale_l = 2^(l*log2(per_level_scale)) * base_resolution - 1
+  res_l   = ceil(scale_l) + 1
+  size_l  = min(round_up(res_l^D, 8), 2^log2_hashmap_size)
+  pos     = x*scale_l + 0.5 (rounded product, then rounded sum; tiny-cuda-nn uses one
+            fmaf — immaterial for an unpinned restatement) ; cell = floor(pos) ; frac = pos - cell
+  index   = dense (x + y*res_l) while the stride fits size_l, else
+            XOR_d(cell_d * prime_d), primes (1, 2654435761) ; index %= size_l
+  feature = sum_corners w_c * table[index_c]   (bilinear)
+  MLP     = bias-free, ReLU hidden, no output activation, fp16 weights and
+            activations (this restatement accumulates each layer in fp32 and
+            rounds the activations to fp16; tiny-cuda-nn accumulates in fp16 —
+            PARITY UNPINNED, and no bit-level claim is made against it).
+Negative cells follow CUDA's float->int->uint32 wrap of tiny-cuda-nn's
+`pos_fract` ((uint32_t)(int)floorf(pos)).
+"""
+import math
+
+import numpy as np
+import torch
+
+PRIME_Y = 2654435761
+
+
+class GridGeometry:
+    def __init__(self, n_levels=16, n_features_per_level=2, log2_hashmap_size=15,
+                 base_resolution=16, per_level_scale=1.5, n_dims=2):
+        assert n_features_per_level == 2 and n_dims == 2
+        self.n_levels = n_levels
+        self.n_features = n_features_per_level
+        self.hashmap_size = 1 << log2_hashmap_size
+        log2_pls = np.float32(math.log2(per_level_scale))
+        self.scale, self.res, self.size, self.offset = [], [], [], [0]
+        for l in range(n_levels):
+            s = np.float32(np.exp2(np.float32(l) * log2_pls)) * np.float32(base_resolution) - np.float32(1.0)
+            r = int(np.ceil(s)) + 1
+            n = r ** n_dims
+            n = (n + 7) // 8 * 8
+            n = min(n, self.hashmap_size)
+            self.scale.append(float(np.float32(s)))
+            self.res.append(r)
+            self.size.append(n)
+            self.offset.append(self.offset[-1] + n)
+        self.n_params = self.offset[-1] * self.n_features
+        self.n_output_dims = n_levels * n_features_per_level
+
+    def index(self, l, cx, cy):
+        """cx, cy int64 tensors holding uint32 values -> entry index in level l."""
+        res, size = self.res[l], self.size[l]
+        M = 0xFFFFFFFF
+        if res <= size:  # stride after dim 0 (= res) still fits: add the y term
+            idx = (cx + cy * res) & M
+            if res * res > size:  # stride overflowed the table -> hash instead
+                idx = (cx ^ ((cy * PRIME_Y) & M)) & M
+        else:
+            idx = cx
+            idx = (cx ^ ((cy * PRIME_Y) & M)) & M
+        return idx % size
+
+
+def hashgrid_forward(geom, table, x):
+    """table [n_entries, 2] (any float dtype; used as fp16 values), x [B,2] fp32.
+    Returns features [B, 32] fp16 (level-major)."""
+    tab = table.half().float()
+    outs = []
+    for l in range(geom.n_levels):
+        pos = x * np.float32(geom.scale[l]) + np.float32(0.5)
+        cell = torch.floor(pos)
+        frac = pos - cell
+        c = cell.to(torch.int64) & 0xFFFFFFFF
+        feat = torch.zeros(x.shape[0], 2, dtype=torch.float32)
+        for corner in range(4):
+            dx, dy = corner & 1, (corner >> 1) & 1
+            wx = frac[:, 0] if dx else 1 - frac[:, 0]
+            wy = frac[:, 1] if dy else 1 - frac[:, 1]
+            idx = geom.index(l, (c[:, 0] + dx) & 0xFFFFFFFF, (c[:, 1] + dy) & 0xFFFFFFFF)
+            feat = feat + (wx * wy)[:, None] * tab[geom.offset[l] + idx]
+        outs.append(feat)
+    return torch.cat(outs, dim=1).half()
+
+
+def mlp_forward(w1, w2, w3, x_h, n_out):
+    """w1 [64,32], w2 [64,64], w3 [P,64] (fp16 values), x_h [B,32] fp16.
+    fp32 accumulate, fp16 activations.  Returns [B, n_out] fp16."""
+    f = lambda t: t.half().float()
+    h = torch.relu(f(x_h) @ f(w1).t()).half()
+    h = torch.relu(f(h) @ f(w2).t()).half()
+    o = (f(h) @ f(w3).t()).half()
+    return o[:, :n_out]
+
+
+class Encoding(torch.nn.Module):
+    """tcnn.Encoding(n_input_dims=2, encoding_config) shaped."""
+
+    def __init__(self, n_input_dims, encoding_config, dtype=None, seed=1337):
+        super().__init__()
+        assert n_input_dims == 2 and encoding_config["otype"] == "HashGrid"
+        self.geom = GridGeometry(encoding_config["n_levels"], encoding_config["n_features_per_level"],
+                                 encoding_config["log2_hashmap_size"], encoding_config["base_resolution"],
+                                 encoding_config["per_level_scale"])
+        g = torch.Generator().manual_seed(seed)
+        self.params = torch.nn.Parameter(
+            (torch.rand(self.geom.offset[-1], 2, generator=g) * 2 - 1) * 1e-4)
+        self.n_output_dims = self.geom.n_output_dims
+
+    def forward(self, x):
+        return hashgrid_forward(self.geom, self.params, x.float())
+
+
+class Network(torch.nn.Module):
+    """tcnn.Network(n_input_dims, n_output_dims, network_config) shaped."""
+
+    def __init__(self, n_input_dims, n_output_dims, network_config, seed=1337):
+        super().__init__()
+        assert network_config["otype"] == "FullyFusedMLP" and network_config["activation"] == "ReLU"
+        assert network_config["n_neurons"] == 64 and network_config["n_hidden_layers"] == 2
+        assert n_input_dims == 32
+        self.n_output_dims = n_output_dims
+        pad = (n_output_dims + 15) // 16 * 16
+        g = torch.Generator().manual_seed(seed)
+
+        def xavier(o, i):
+            s = math.sqrt(6.0 / (i + o))
+            return (torch.rand(o, i, generator=g) * 2 - 1) * s
+
+        self.w1 = torch.nn.Parameter(xavier(64, 32))
+        self.w2 = torch.nn.Parameter(xavier(64, 64))
+        self.w3 = torch.nn.Parameter(xavier(pad, 64))
+
+    def forward(self, x):
+        return mlp_forward(self.w1, self.w2, self.w3, x, self.n_output_dims)

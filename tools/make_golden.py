@@ -129,7 +129,78 @@ def gen_composite():
               **{"out_" + k: v for k, v in out.items()})
 
 
-GENS = {"composite": gen_composite}
+# --------------------------------------------------------------------------
+# 2. SHNeuralTextures / NeuralTexture (models/sh_neural_textures.py:64-97,
+#    models/neural_texture.py:81-197) and SHEncoder (encodings/
+#    sphericalharmonics.py) run AS SHIPPED, with oracle.tcnn_like standing in
+#    for tinycudann and oracle.uv for mvdatasets.utils.images (both absent).
+#    Parameters are regenerated from seeds by tests (tables are MBs).
+# --------------------------------------------------------------------------
+def gen_nt():
+    from oracle import tcnn_like, uv as uvh
+    ref_import.install_placeholders({
+        "tinycudann": {"Encoding": tcnn_like.Encoding, "Network": tcnn_like.Network},
+        "mvdatasets.utils.images": {k: getattr(uvh, k) for k in [
+            "normalize_uv_coord", "non_normalize_uv_coord",
+            "non_normalized_uv_coords_to_interp_corners", "pix_to_texel_center_uv_coord",
+            "uv_coords_to_pix", "non_normalized_uv_coords_to_lerp_weights"]},
+    })
+    from volsurfs_py.models.sh_neural_textures import SHNeuralTextures
+    from volsurfs_py.encodings.sphericalharmonics import SHEncoder
+
+    for name, C, sh_deg, seed, M in [("rgb", 3, 3, 11, 256), ("alpha", 1, 3, 12, 256),
+                                     ("alpha_deg0", 1, 0, 13, 128)]:
+        model = SHNeuralTextures(sh_deg=sh_deg, nr_channels=C, sh_range=[15, 15, 15, 15],
+                                 anchor=False, lerp=True, deg_res=[2048, 1024, 512, 256],
+                                 quantize_output=True, squeeze_output=True, align_to_webgl=True)
+        from oracle.neural_texture import make_test_params
+        params = make_test_params(seed, C, sh_deg)
+        with torch.no_grad():
+            for deg, (table, w1, w2, w3) in enumerate(params):
+                nt = model.neural_textures[deg]
+                nt.encoding.params.copy_(table)
+                nt.network.w1.copy_(w1)
+                nt.network.w2.copy_(w2)
+                nt.network.w3.copy_(w3)
+        g = torch.Generator().manual_seed(seed)
+        uv = torch.rand(M, 2, generator=g)
+        uv[:4] = torch.tensor([[0.0, 0.0], [1.0, 1.0], [0.0001, 0.9999], [0.5, 0.5]])
+        dirs = torch.nn.functional.normalize(torch.randn(M, 3, generator=g), dim=-1)
+        out = model(uv_coords=uv, view_dirs=dirs)
+        coeffs = model(uv_coords=uv)                       # [M,C,(deg+1)^2] lerped SH coefficients
+        gt = torch.rand(M, C, generator=g)
+        loss = (gt - out).abs().mean()
+        loss.backward()
+        arrs = dict(uv=uv.numpy(), dirs=dirs.numpy(), out=out.detach().numpy(),
+                    coeffs=coeffs.detach().numpy(), gt=gt.numpy(), seed=np.array(seed),
+                    nr_channels=np.array(C), sh_deg=np.array(sh_deg))
+        for deg in range(sh_deg + 1):
+            nt = model.neural_textures[deg]
+            arrs[f"param_sum_{deg}"] = np.array([nt.encoding.params.double().sum().item(),
+                                                 nt.network.w3.double().sum().item()])
+            for wn in ("w1", "w2", "w3"):
+                arrs[f"g_{wn}_{deg}"] = getattr(nt.network, wn).grad.numpy()
+            gt_ = nt.encoding.params.grad
+            idx = gt_.abs().sum(1).topk(64).indices
+            arrs[f"g_table_top_idx_{deg}"] = idx.numpy()
+            arrs[f"g_table_top_val_{deg}"] = gt_[idx].numpy()
+            arrs[f"g_table_sums_{deg}"] = np.array([gt_.double().sum().item(),
+                                                    gt_.double().abs().sum().item()])
+        _save(f"sh_neural_textures_{name}.npz", **arrs)
+
+    # SHEncoder.__call__ / eval on their own (degrees 0..3)
+    g = torch.Generator().manual_seed(5)
+    dirs = torch.nn.functional.normalize(torch.randn(64, 3, generator=g), dim=-1)
+    arrs = dict(dirs=dirs.numpy())
+    for deg in range(4):
+        sh = (torch.randn(64, 3, (deg + 1) ** 2, generator=g)).half()
+        arrs[f"sh_{deg}"] = sh.float().numpy()
+        arrs[f"eval_{deg}"] = SHEncoder.eval(sh, dirs, deg).float().numpy()
+        arrs[f"enc_{deg}"] = SHEncoder(degree=deg)(dirs).numpy()
+    _save("sh_encoder.npz", **arrs)
+
+
+GENS = {"composite": gen_composite, "nt": gen_nt}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(GENS)
