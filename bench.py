@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s (fwd+bwd) of the K-shell render hot path on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (for N>1 launched by
+torch.distributed.run, one rank per GPU).  Rank 0 prints ONE JSON line.
+
+A step = one forward + backward pass of the hot path over one 800x800 frame of
+synthetic rays (BASELINE.json configs[1]: K=5 shells, neural-texture appearance),
+inputs resident in HBM before the timed region.  Rays shard across ranks by
+16 384-ray chunks, round-robin (tile-parallel, no data-path collective in the
+render) -> "scaling": "weak" is reported with a full frame PER RANK.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+MFMA_F16_PEAK_TFLOPS = 2500.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--res", type=int, default=800)
+    ap.add_argument("--shells", type=int, default=5)
+    ap.add_argument("--subdiv", type=int, default=6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rays", type=int, default=1024)
+    return ap.parse_args()
+
+
+def cpu_baseline(pipe, sample_rays):
+    """The oracle (oracle/: CPU restatement of the reference path) timed on this
+    box's host cores over a bounded sample of the same workload.  kind="port":
+    the reference has no CPU path of its own."""
+    from oracle import composite as ocomp, raytrace as ort
+    n = min(sample_rays, pipe.nr_rays)
+    idx = torch.linspace(0, pipe.nr_rays - 1, n, device=pipe.rays_o.device).long()
+    o = pipe.rays_o[idx].cpu().numpy()
+    d = pipe.rays_d[idx].cpu().numpy()
+    gt = pipe.gt[idx].cpu().numpy()
+    meshes = [(m.vertices.cpu().numpy(), m.faces.cpu().numpy()) for m in pipe.meshes]
+    rgb = pipe._rgb_raw[idx].cpu().numpy()
+    alpha = pipe._alpha_raw[idx].cpu().numpy()
+    t0 = time.perf_counter()
+    hits = [ort.trace_bruteforce(v, f, o, d) for v, f in meshes]
+    hit = np.stack([h["tri"] >= 0 for h in hits], 1)
+    c, a = rgb * hit[..., None], alpha * hit
+    out = ocomp.composite_dense_fwd(c, a, np.ones((1, 3), np.float32))
+    g = np.sign(out["rgb"] - gt).astype(np.float32) / (n * 3)
+    ocomp.composite_dense_bwd(c, a, np.ones((1, 3), np.float32), g)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+            "sample": f"{n} rays of the same frame, K={pipe.K}: brute-force closest hit "
+                      f"(oracle/raytrace_ref.c) + composite fwd+bwd (oracle/composite.py); "
+                      f"{dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.manual_seed(42 + rank)
+
+    from volsurfs_amd.pipeline import KShellPipeline
+    pipe = KShellPipeline.synthetic(K=args.shells, subdiv=args.subdiv, res=args.res, device=dev,
+                                    seed=42 + rank)
+    N = pipe.nr_rays
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        pipe.step()
+    pipe.reset_stage_timers()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pipe.step(record=True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    stages = pipe.stage_report()           # name -> dict(ms, bytes, flops)
+    if rank == 0:
+        total_rays = N * world * args.steps
+        value = total_rays / dt / 1e6
+        dom = max(stages.items(), key=lambda kv: kv[1]["ms"])
+        name, st = dom
+        if st.get("flops") and st.get("bound") == "mfma":
+            ach = st["flops"] / (st["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": MFMA_F16_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / MFMA_F16_PEAK_TFLOPS, "traffic": None}
+        else:
+            ach = st["bytes"] / (st["ms"] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
+        out = {
+            "metric": "Mrays/s (fwd+bwd) at 800x800, K=5 shells",
+            "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": pipe.dtype_desc, "data": "synthetic",
+            "config": pipe.config_desc(world),
+            "roofline": roof,
+            "stages_ms": {k: round(v["ms"], 4) for k, v in stages.items()},
+            "stage_roofline": {k: pipe.stage_roofline(v, HBM_PEAK_GBS, MFMA_F16_PEAK_TFLOPS)
+                               for k, v in stages.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(pipe, args.cpu_sample_rays)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
