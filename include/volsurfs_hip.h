@@ -116,6 +116,81 @@ int vsa_hit_attributes(const float* tris, const float* rays_o, const float* rays
                        int nr_rays, uint8_t* is_hit, int32_t* tri_id, float* positions,
                        float* normals, float* barycentric, void* stream);
 
+/* ------------------------------------------------------------------------
+ * A3/A4/A6  Neural-texture appearance of the K shells (the "shade" stage).
+ * Replaces, per shell and per model, SHNeuralTextures.forward
+ * (volsurfs_py/models/sh_neural_textures.py:64-97) -> NeuralTexture.forward
+ * (models/neural_texture.py:81-197) -> tcnn HashGrid + FullyFusedMLP
+ * (neural_texture.py:54-77; tiny-cuda-nn is a pip dependency, absent), plus the
+ * uv interpolation / alpha decay / scatter around it (methods/volsurfs.py:504-516,
+ * 539-596) and the autograd replay of all of it.
+ *
+ * MI355X design (DESIGN.md "Texel-deduplicated shading"): NeuralTexture only
+ * ever evaluates its network at TEXEL CENTRES (the 4 lerp corners), so the
+ * frame's hits are reduced to the set of unique touched texels per (shell,
+ * degree) first; hash encoding + MLP run once per unique texel ("slot") and
+ * write the 8-bit quantised texel (exactly the value the reference computes for
+ * every hit that touches it); hits then gather 4 corner rows per degree.  Hash
+ * levels are processed level-major with the whole level table resident in LDS
+ * (2^15 entries x half2 = 128 KiB <= 160 KiB), forward gathers and backward
+ * scatter-adds never touch HBM atomics.
+ *
+ * Indexing: texture x = (shell*2 + type)*4 + degree, type 0 = rgb, 1 = alpha.
+ * Texel domain of (shell, degree): (R_d+2)^2 texels (one-texel apron for
+ * corners outside [0,1]), padded to a multiple of 4096, concatenated:
+ * dom_off[shell*4 + degree].  Slots are numbered globally in domain order.
+ */
+#define VSA_NT_MAX_LEVELS 16
+#define VSA_NT_MAX_DEG 4
+#define VSA_NT_WEIGHTS_PER_TEX 8192 /* W1[64][32] W2[64][64] W3[32][64] (rows >= C' zero) */
+#define VSA_NT_ROW_BYTES 32         /* texel row: rgb bytes 0..20, alpha bytes 24..30 */
+
+typedef struct vsa_nt_plan {
+  int32_t nr_shells;                 /* K */
+  int32_t rgb_degrees;               /* sh_degree+1 of the rgb models, 1..4 */
+  int32_t alpha_degrees;             /* sh_degree+1 of the alpha models, 1..4 */
+  int32_t inner_solid;               /* 1: shell 0 has no alpha model (alpha = 1), volsurfs.py:181-183 */
+  int32_t with_alpha_decay;          /* volsurfs.py:585-594 */
+  int32_t n_levels;                  /* 16 */
+  int32_t tex_res[VSA_NT_MAX_DEG];   /* R_d (square textures) */
+  float sh_lo[VSA_NT_MAX_DEG];       /* val_range[0] = -sh_range[d] */
+  float sh_span[VSA_NT_MAX_DEG];     /* val_range[1]-val_range[0] */
+  float level_scale[VSA_NT_MAX_LEVELS];
+  int32_t level_res[VSA_NT_MAX_LEVELS];
+  int32_t level_size[VSA_NT_MAX_LEVELS];      /* entries */
+  int32_t level_offset[VSA_NT_MAX_LEVELS + 1]; /* entries */
+  int64_t dom_off[VSA_MAX_SHELLS * VSA_NT_MAX_DEG + 1];
+  int64_t slot_capacity;             /* rows allocated in every per-slot buffer */
+} vsa_nt_plan;
+
+/* Step 1 (per frame): per-hit texture uv + mark touched texels.
+ *   hit_slot [K,N] i32, hit_uv [K,N,2] f32 from vsa_trace; face_uvs [nr_tris,6]
+ *   f32 = per-corner uvs in leaf (slot) order.  Writes tex_uv [K,N,2] and sets
+ *   marks[dom_off[..] + texel] = 1 for the 4 lerp corners of every degree.
+ *   marks (u8 [dom_off[K*4]]) must be zero on entry. */
+int vsa_nt_mark(const vsa_nt_plan* plan, const int32_t* hit_slot, const float* hit_uv,
+                const float* face_uvs, int nr_rays, float* tex_uv, uint8_t* marks, void* stream);
+
+/* Step 2: compact marks into slots.  slot_of [dom total] i32 (-1 = untouched),
+ * texel_of_slot [slot_capacity] i32 (domain index), seg_start [K*4+1] i32 (first
+ * slot of each (shell,degree); last = total), block_scratch [dom total/4096 + 1] i32. */
+int vsa_nt_compact(const vsa_nt_plan* plan, const uint8_t* marks, int32_t* slot_of,
+                   int32_t* texel_of_slot, int32_t* seg_start, int32_t* block_scratch,
+                   void* stream);
+
+/* Step 3: hash-grid encode every slot of every texture, level-major with the
+ * level table in LDS.  tables_h: f16 [n_tex][level_offset[n]*2];
+ * features: f16x2 [2 types][n_levels][slot_capacity]. */
+int vsa_nt_encode_fwd(const vsa_nt_plan* plan, const void* tables_h, const int32_t* texel_of_slot,
+                      const int32_t* seg_start, void* features, void* stream);
+
+/* Backward of step 3: grad_tables (f32 [n_tex][level_offset[n]][2]) +=
+ * transpose-interpolation of dfeatures (f16x2, same layout as features, holding
+ * grad * grad_scale).  Accumulates (caller zeroes grad_tables per optimiser step). */
+int vsa_nt_encode_bwd(const vsa_nt_plan* plan, const void* dfeatures, float grad_scale,
+                      const int32_t* texel_of_slot, const int32_t* seg_start, float* grad_tables,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,185 @@
+// Neural-texture step 1 + 2: per-hit uv, touched-texel marking, slot compaction.
+//
+// The reference evaluates its texture network at the 4 lerp corners of every
+// hit (models/neural_texture.py:124-153); corners are texel centres, so hits
+// that share a texel share the evaluation.  These kernels build the set of
+// unique touched texels ("slots") per (shell, degree) without a sort and
+// without host syncs: byte marks (plain stores, benign races) + a 3-pass
+// exclusive scan that writes slot_of[texel] and texel_of_slot[slot].
+#include "nt_common.h"
+
+namespace {
+
+__global__ void nt_mark_kernel(vsa_nt_plan plan, const int* __restrict__ hit_slot,
+                               const float* __restrict__ hit_uv,
+                               const float* __restrict__ face_uvs, int N,
+                               float* __restrict__ tex_uv, unsigned char* __restrict__ marks) {
+  const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = blockIdx.y;
+  if (n >= N) return;
+  const long long o = (long long)s * N + n;
+  const int slot = hit_slot[o];
+  float2 uv = make_float2(0.f, 0.f);
+  if (slot >= 0) {
+    uv = nt_interp_uv(face_uvs + 6 * (long long)slot, hit_uv[2 * o], hit_uv[2 * o + 1]);
+    const int D = max(plan.rgb_degrees, plan.alpha_degrees);
+    for (int d = 0; d < D; ++d) {
+      const int R = plan.tex_res[d];
+      const int W = R + 2;
+      const NtFootprint f = nt_footprint(uv.x, uv.y, R);
+      unsigned char* m = marks + plan.dom_off[s * VSA_NT_MAX_DEG + d] +
+                         (long long)(f.j0 + 1) * W + (f.i0 + 1);
+      m[0] = 1;
+      m[1] = 1;
+      m[W] = 1;
+      m[W + 1] = 1;
+    }
+  }
+  tex_uv[2 * o] = uv.x;
+  tex_uv[2 * o + 1] = uv.y;
+}
+
+__device__ __forceinline__ int count16(const uint4 v) {
+  return __popc(v.x & 0x01010101u) + __popc(v.y & 0x01010101u) + __popc(v.z & 0x01010101u) +
+         __popc(v.w & 0x01010101u);
+}
+
+// pass A: number of marked texels per 4096-texel block
+__global__ __launch_bounds__(256) void nt_count_kernel(const uint4* __restrict__ marks,
+                                                       int* __restrict__ block_count) {
+  __shared__ int s_w[4];
+  const uint4 v = marks[(long long)blockIdx.x * 256 + threadIdx.x];
+  int c = count16(v);
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) block_count[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// pass B: exclusive scan of the block counts (single workgroup), segment starts
+__global__ __launch_bounds__(1024) void nt_scan_blocks_kernel(vsa_nt_plan plan,
+                                                              int* __restrict__ block_count,
+                                                              int nr_blocks,
+                                                              int* __restrict__ seg_start) {
+  __shared__ int s_part[1024];
+  const int t = threadIdx.x;
+  const int per = (nr_blocks + 1023) / 1024;
+  const int b0 = t * per, b1 = min(nr_blocks, b0 + per);
+  int sum = 0;
+  for (int b = b0; b < b1; ++b) sum += block_count[b];
+  s_part[t] = sum;
+  __syncthreads();
+  // Hillis-Steele inclusive scan over 1024 partials
+  for (int off = 1; off < 1024; off <<= 1) {
+    int v = t >= off ? s_part[t - off] : 0;
+    __syncthreads();
+    s_part[t] += v;
+    __syncthreads();
+  }
+  int run = s_part[t] - sum;  // exclusive
+  for (int b = b0; b < b1; ++b) {
+    int c = block_count[b];
+    block_count[b] = run;
+    run += c;
+  }
+  __syncthreads();
+  if (t == 0) block_count[nr_blocks] = s_part[1023];
+  __threadfence_block();
+  __syncthreads();
+  const int nseg = plan.nr_shells * VSA_NT_MAX_DEG;
+  for (int i = t; i <= nseg; i += 1024) {
+    // block_count[] was rewritten by other lanes of this workgroup: bypass this CU's L1
+    seg_start[i] = __hip_atomic_load(&block_count[(int)(plan.dom_off[i] / NT_DOM_BLOCK)],
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// pass C: slot_of[texel], texel_of_slot[slot]
+__global__ __launch_bounds__(256) void nt_assign_kernel(const uint4* __restrict__ marks,
+                                                        const int* __restrict__ block_prefix,
+                                                        int* __restrict__ slot_of,
+                                                        int* __restrict__ texel_of_slot,
+                                                        long long slot_capacity) {
+  __shared__ int s_w[4];
+  const long long vec = (long long)blockIdx.x * 256 + threadIdx.x;
+  const uint4 v = marks[vec];
+  const int c = count16(v);
+  // exclusive scan across the 256 threads
+  int incl = c;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int off = 1; off < 64; off <<= 1) {
+    int up = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += up;
+  }
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  int base = block_prefix[blockIdx.x];
+  for (int w = 0; w < wave; ++w) base += s_w[w];
+  int slot = base + incl - c;
+  const unsigned int words[4] = {v.x, v.y, v.z, v.w};
+  int out[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const bool m = (words[i >> 2] >> (8 * (i & 3))) & 1u;
+    out[i] = m ? slot : -1;
+    if (m) {
+      if (slot < slot_capacity) texel_of_slot[slot] = (int)(vec * 16 + i);
+      ++slot;
+    }
+  }
+  int4* so = reinterpret_cast<int4*>(slot_of + vec * 16);
+  so[0] = make_int4(out[0], out[1], out[2], out[3]);
+  so[1] = make_int4(out[4], out[5], out[6], out[7]);
+  so[2] = make_int4(out[8], out[9], out[10], out[11]);
+  so[3] = make_int4(out[12], out[13], out[14], out[15]);
+}
+
+}  // namespace
+
+static int plan_check(const vsa_nt_plan* p) {
+  if (!p) return VSA_ERR_ARG;
+  if (p->nr_shells < 1 || p->nr_shells > VSA_MAX_SHELLS) return VSA_ERR_ARG;
+  if (p->rgb_degrees < 1 || p->rgb_degrees > VSA_NT_MAX_DEG) return VSA_ERR_ARG;
+  if (p->alpha_degrees < 1 || p->alpha_degrees > VSA_NT_MAX_DEG) return VSA_ERR_ARG;
+  if (p->n_levels < 1 || p->n_levels > VSA_NT_MAX_LEVELS) return VSA_ERR_ARG;
+  const int nseg = p->nr_shells * VSA_NT_MAX_DEG;
+  for (int i = 0; i <= nseg; ++i)
+    if (p->dom_off[i] % NT_DOM_BLOCK != 0 || (i && p->dom_off[i] < p->dom_off[i - 1]))
+      return VSA_ERR_ARG;
+  if (p->dom_off[nseg] >= (1ll << 31)) return VSA_ERR_UNSUPPORTED;
+  return VSA_OK;
+}
+
+extern "C" int vsa_nt_mark(const vsa_nt_plan* plan, const int32_t* hit_slot, const float* hit_uv,
+                           const float* face_uvs, int nr_rays, float* tex_uv, uint8_t* marks,
+                           void* stream) {
+  int rc = plan_check(plan);
+  if (rc) return rc;
+  if (nr_rays < 0) return VSA_ERR_ARG;
+  if (nr_rays == 0) return VSA_OK;
+  if (!hit_slot || !hit_uv || !face_uvs || !tex_uv || !marks) return VSA_ERR_ARG;
+  dim3 grid(vsa_div_up(nr_rays, 256), plan->nr_shells);
+  hipLaunchKernelGGL(nt_mark_kernel, grid, dim3(256), 0, (hipStream_t)stream, *plan, hit_slot,
+                     hit_uv, face_uvs, nr_rays, tex_uv, marks);
+  VSA_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int vsa_nt_compact(const vsa_nt_plan* plan, const uint8_t* marks, int32_t* slot_of,
+                              int32_t* texel_of_slot, int32_t* seg_start, int32_t* block_scratch,
+                              void* stream) {
+  int rc = plan_check(plan);
+  if (rc) return rc;
+  if (!marks || !slot_of || !texel_of_slot || !seg_start || !block_scratch) return VSA_ERR_ARG;
+  const long long total = plan->dom_off[plan->nr_shells * VSA_NT_MAX_DEG];
+  const int nr_blocks = (int)(total / NT_DOM_BLOCK);
+  if (nr_blocks == 0) return VSA_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(nt_count_kernel, dim3(nr_blocks), dim3(256), 0, st,
+                     reinterpret_cast<const uint4*>(marks), block_scratch);
+  hipLaunchKernelGGL(nt_scan_blocks_kernel, dim3(1), dim3(1024), 0, st, *plan, block_scratch,
+                     nr_blocks, seg_start);
+  hipLaunchKernelGGL(nt_assign_kernel, dim3(nr_blocks), dim3(256), 0, st,
+                     reinterpret_cast<const uint4*>(marks), block_scratch, slot_of, texel_of_slot,
+                     (long long)plan->slot_capacity);
+  VSA_RETURN_LAUNCH_STATUS();
+}

@@ -1,0 +1,169 @@
+"""Neural-texture bank: parameters, plan and per-frame buffers of the K shells'
+SH neural textures, and the host side of the shade stage.
+
+Parameter shapes mirror what the reference instantiates per shell
+(/root/reference/volsurfs_py/methods/volsurfs.py:143-206): an rgb
+SHNeuralTextures (3 channels) and an alpha one (1 channel), each a ModuleList of
+sh_degree+1 NeuralTexture = tcnn HashGrid (16 levels x 2 features, 2^15 entries,
+base 16, x1.5; models/neural_texture.py:54-63) + FullyFusedMLP 32->64->64->C
+(:65-77).  Here all of them live in two stacked tensors so that one launch
+serves every texture:  tables [n_tex, E, 2],  weights [n_tex, 8192]
+(W1[64,32] | W2[64,64] | W3[32,64], rows >= C zero), texture index
+x = (shell*2 + type)*4 + degree.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+MAX_SHELLS, MAX_DEG, MAX_LEVELS = 16, 4, 16
+DOM_BLOCK = 4096
+WEIGHTS_PER_TEX = 8192
+
+
+class Plan(ctypes.Structure):
+    """Mirror of `vsa_nt_plan` (include/volsurfs_hip.h)."""
+    _fields_ = [
+        ("nr_shells", ctypes.c_int32), ("rgb_degrees", ctypes.c_int32),
+        ("alpha_degrees", ctypes.c_int32), ("inner_solid", ctypes.c_int32),
+        ("with_alpha_decay", ctypes.c_int32), ("n_levels", ctypes.c_int32),
+        ("tex_res", ctypes.c_int32 * MAX_DEG), ("sh_lo", ctypes.c_float * MAX_DEG),
+        ("sh_span", ctypes.c_float * MAX_DEG), ("level_scale", ctypes.c_float * MAX_LEVELS),
+        ("level_res", ctypes.c_int32 * MAX_LEVELS), ("level_size", ctypes.c_int32 * MAX_LEVELS),
+        ("level_offset", ctypes.c_int32 * (MAX_LEVELS + 1)),
+        ("dom_off", ctypes.c_int64 * (MAX_SHELLS * MAX_DEG + 1)),
+        ("slot_capacity", ctypes.c_int64),
+    ]
+
+
+def grid_geometry(n_levels=16, log2_hashmap_size=15, base_resolution=16, per_level_scale=1.5):
+    """Level geometry of tiny-cuda-nn's multiresolution grid (published formula;
+    neural_texture.py:54-61 fixes the arguments)."""
+    log2_pls = np.float32(math.log2(per_level_scale))
+    scale, res, size, offset = [], [], [], [0]
+    for l in range(n_levels):
+        s = np.float32(np.exp2(np.float32(l) * log2_pls)) * np.float32(base_resolution) - np.float32(1.0)
+        r = int(np.ceil(s)) + 1
+        n = min((r * r + 7) // 8 * 8, 1 << log2_hashmap_size)
+        scale.append(float(s))
+        res.append(r)
+        size.append(n)
+        offset.append(offset[-1] + n)
+    return scale, res, size, offset
+
+
+class NeuralTextureBank(torch.nn.Module):
+    def __init__(self, nr_shells, max_rays, sh_degree=3, alpha_sh_degree=3,
+                 sh_range=(15.0, 15.0, 15.0, 15.0), textures_res=(2048, 1024, 512, 256),
+                 inner_solid=False, with_alpha_decay=True, device="cuda", seed=42,
+                 training=True):
+        super().__init__()
+        K = nr_shells
+        self.K, self.max_rays = K, max_rays
+        self.rgb_degrees, self.alpha_degrees = sh_degree + 1, alpha_sh_degree + 1
+        self.D = max(self.rgb_degrees, self.alpha_degrees)
+        scale, res, size, offset = grid_geometry()
+        self.n_entries = offset[-1]
+        self.n_tex = K * 2 * MAX_DEG
+        p = Plan()
+        p.nr_shells, p.rgb_degrees, p.alpha_degrees = K, self.rgb_degrees, self.alpha_degrees
+        p.inner_solid, p.with_alpha_decay, p.n_levels = int(inner_solid), int(with_alpha_decay), 16
+        for d in range(MAX_DEG):
+            p.tex_res[d] = int(textures_res[d])
+            p.sh_lo[d] = -float(sh_range[d])
+            p.sh_span[d] = 2.0 * float(sh_range[d])
+        for l in range(16):
+            p.level_scale[l], p.level_res[l], p.level_size[l] = scale[l], res[l], size[l]
+        for l in range(17):
+            p.level_offset[l] = offset[l]
+        off, cap = 0, 0
+        for s in range(K):
+            for d in range(MAX_DEG):
+                p.dom_off[s * MAX_DEG + d] = off
+                if d < self.D:
+                    T = (textures_res[d] + 2) ** 2
+                    off += (T + DOM_BLOCK - 1) // DOM_BLOCK * DOM_BLOCK
+                    cap += min(4 * max_rays, T)
+        p.dom_off[K * MAX_DEG] = off
+        for i in range(K * MAX_DEG + 1, MAX_SHELLS * MAX_DEG + 1):
+            p.dom_off[i] = off
+        cap = (cap + 63) // 64 * 64 + 64
+        p.slot_capacity = cap
+        self.plan, self.dom_total, self.slot_capacity = p, off, cap
+        self.tex_res = tuple(int(r) for r in textures_res)
+
+        # ---- parameters (fp32 masters), tcnn-style init: U(-1e-4, 1e-4) tables,
+        # Xavier-uniform weights
+        g = torch.Generator().manual_seed(seed)
+        tables = (torch.rand(self.n_tex, self.n_entries, 2, generator=g) * 2 - 1) * 1e-4
+        weights = torch.zeros(self.n_tex, WEIGHTS_PER_TEX)
+        for x in range(self.n_tex):
+            C = self.tex_channels(x)
+            if C == 0:
+                continue
+
+            def xav(o, i):
+                s_ = math.sqrt(6.0 / (i + o))
+                return (torch.rand(o, i, generator=g) * 2 - 1) * s_
+            w3 = torch.zeros(32, 64)
+            pad = (C + 15) // 16 * 16
+            w3[:C] = xav(pad, 64)[:C]
+            weights[x] = torch.cat([xav(64, 32).flatten(), xav(64, 64).flatten(), w3.flatten()])
+        self.tables = torch.nn.Parameter(tables.to(device))
+        self.weights = torch.nn.Parameter(weights.to(device))
+        self._alloc(device, training)
+
+    # -- bookkeeping -------------------------------------------------------
+    def tex_channels(self, x):
+        deg, typ, shell = x % MAX_DEG, (x // MAX_DEG) & 1, x // (2 * MAX_DEG)
+        if typ == 0:
+            return 3 * (2 * deg + 1) if deg < self.rgb_degrees else 0
+        if self.plan.inner_solid and shell == 0:
+            return 0
+        return (2 * deg + 1) if deg < self.alpha_degrees else 0
+
+    @staticmethod
+    def tex_index(shell, typ, deg):
+        return (shell * 2 + typ) * MAX_DEG + deg
+
+    def _alloc(self, dev, training):
+        i32, u8 = torch.int32, torch.uint8
+        cap, K = self.slot_capacity, self.K
+        self.marks = torch.zeros(self.dom_total, dtype=u8, device=dev)
+        self.slot_of = torch.empty(self.dom_total, dtype=i32, device=dev)
+        self.texel_of_slot = torch.zeros(cap, dtype=i32, device=dev)
+        self.seg_start = torch.zeros(K * MAX_DEG + 1, dtype=i32, device=dev)
+        self.block_scratch = torch.zeros(self.dom_total // DOM_BLOCK + 1, dtype=i32, device=dev)
+        self.features = torch.empty(2, 16, cap, 2, dtype=torch.float16, device=dev)
+        self.tables_h = torch.empty(self.n_tex, self.n_entries, 2, dtype=torch.float16, device=dev)
+        self.weights_h = torch.empty(self.n_tex, WEIGHTS_PER_TEX, dtype=torch.float16, device=dev)
+        self.refresh_half_params()
+
+    @torch.no_grad()
+    def refresh_half_params(self):
+        """fp16 compute copies of the fp32 masters (tcnn keeps the same pair)."""
+        self.tables_h.copy_(self.tables)
+        self.weights_h.copy_(self.weights)
+
+    # -- stages --------------------------------------------------------------
+    def mark_and_compact(self, hit_slot, hit_uv, face_uvs):
+        """hit_slot [K,N] i32, hit_uv [K,N,2], face_uvs [nr_tris,6] (leaf order).
+        Returns tex_uv [K,N,2]."""
+        K, N = hit_slot.shape
+        assert K == self.K and N <= self.max_rays
+        st = _lib.stream_ptr()
+        tex_uv = torch.empty(K, N, 2, device=hit_slot.device)
+        self.marks.zero_()
+        _lib.call("vsa_nt_mark", ctypes.byref(self.plan), hit_slot, hit_uv, face_uvs, N, tex_uv,
+                  self.marks, st)
+        _lib.call("vsa_nt_compact", ctypes.byref(self.plan), self.marks, self.slot_of,
+                  self.texel_of_slot, self.seg_start, self.block_scratch, st)
+        return tex_uv
+
+    def encode(self):
+        _lib.call("vsa_nt_encode_fwd", ctypes.byref(self.plan), self.tables_h, self.texel_of_slot,
+                  self.seg_start, self.features, _lib.stream_ptr())
+        return self.features
