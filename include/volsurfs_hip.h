@@ -184,6 +184,15 @@ int vsa_nt_compact(const vsa_nt_plan* plan, const uint8_t* marks, int32_t* slot_
 int vsa_nt_encode_fwd(const vsa_nt_plan* plan, const void* tables_h, const int32_t* texel_of_slot,
                       const int32_t* seg_start, void* features, void* stream);
 
+/* Step 4: MLP 32->64->64->C' of every slot of every texture on MFMA, fused with
+ * sigmoid / x255 / round (neural_texture.py:156-169).  weights_h: f16
+ * [n_tex][VSA_NT_WEIGHTS_PER_TEX]; texels: u8 [slot_capacity][32] (quantised
+ * texel rows: rgb coefficient c at byte c, alpha coefficient c at byte 24+c).
+ * pre_out (optional, tests): f16 [slot_capacity][32], the network output before
+ * the sigmoid, same row layout. */
+int vsa_nt_mlp_fwd(const vsa_nt_plan* plan, const void* weights_h, const void* features,
+                   const int32_t* seg_start, uint8_t* texels, void* pre_out, void* stream);
+
 /* Backward of step 3: grad_tables (f32 [n_tex][level_offset[n]][2]) +=
  * transpose-interpolation of dfeatures (f16x2, same layout as features, holding
  * grad * grad_scale).  Accumulates (caller zeroes grad_tables per optimiser step). */

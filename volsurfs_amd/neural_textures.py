@@ -140,6 +140,7 @@ class NeuralTextureBank(torch.nn.Module):
         self.features = torch.empty(2, 16, cap, 2, dtype=torch.float16, device=dev)
         self.tables_h = torch.empty(self.n_tex, self.n_entries, 2, dtype=torch.float16, device=dev)
         self.weights_h = torch.empty(self.n_tex, WEIGHTS_PER_TEX, dtype=torch.float16, device=dev)
+        self.texels = torch.zeros(cap, 32, dtype=u8, device=dev)
         self.refresh_half_params()
 
     @torch.no_grad()
@@ -167,3 +168,11 @@ class NeuralTextureBank(torch.nn.Module):
         _lib.call("vsa_nt_encode_fwd", ctypes.byref(self.plan), self.tables_h, self.texel_of_slot,
                   self.seg_start, self.features, _lib.stream_ptr())
         return self.features
+
+    def mlp(self, want_pre=False):
+        pre = None
+        if want_pre:
+            pre = torch.zeros(self.slot_capacity, 32, dtype=torch.float16, device=self.texels.device)
+        _lib.call("vsa_nt_mlp_fwd", ctypes.byref(self.plan), self.weights_h, self.features,
+                  self.seg_start, self.texels, pre, _lib.stream_ptr())
+        return (self.texels, pre) if want_pre else self.texels
