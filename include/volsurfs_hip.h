@@ -193,6 +193,24 @@ int vsa_nt_encode_fwd(const vsa_nt_plan* plan, const void* tables_h, const int32
 int vsa_nt_mlp_fwd(const vsa_nt_plan* plan, const void* weights_h, const void* features,
                    const int32_t* seg_start, uint8_t* texels, void* pre_out, void* stream);
 
+/* Step 5: per-hit shading from the texel rows (expand LUT -> lerp -> fp16 SH
+ * coefficients -> SH eval -> sigmoid -> alpha decay), scattered dense:
+ * surfs_rgb [N,K,3], surfs_alpha [N,K] (zero on miss; inner->outer), optional
+ * surfs_normals [N,K,3] and coeffs_out [K,N,64] (tests: 48 rgb [ch][16] + 16
+ * alpha lerped fp16 SH coefficients).  tris = the tracer's triangle array. */
+int vsa_nt_shade_fwd(const vsa_nt_plan* plan, const int32_t* hit_slot, const float* tex_uv,
+                     const float* rays_d, const float* tris, const int32_t* slot_of,
+                     const uint8_t* texels, int nr_rays, float* surfs_rgb, float* surfs_alpha,
+                     float* surfs_normals, float* coeffs_out, void* stream);
+
+/* Backward of step 5: grad_rows (f32 [slot_capacity][32], same row layout as
+ * texels; zeroed by the caller / by vsa_nt_mlp_fwd) += grad_scale * dL/d(q/255)
+ * (round is a straight-through estimator, utils/math.py:5-18). */
+int vsa_nt_shade_bwd(const vsa_nt_plan* plan, const int32_t* hit_slot, const float* tex_uv,
+                     const float* rays_d, const float* tris, const int32_t* slot_of,
+                     const uint8_t* texels, int nr_rays, const float* g_surfs_rgb,
+                     const float* g_surfs_alpha, float grad_scale, float* grad_rows, void* stream);
+
 /* Backward of step 3: grad_tables (f32 [n_tex][level_offset[n]][2]) +=
  * transpose-interpolation of dfeatures (f16x2, same layout as features, holding
  * grad * grad_scale).  Accumulates (caller zeroes grad_tables per optimiser step). */

@@ -1,0 +1,348 @@
+// Neural-texture step 5: per-hit shading from the quantised texel rows, forward
+// and backward.
+//
+// Forward, per (ray, shell) hit — the reference's op sequence:
+//   4 corner rows per degree -> fp16 range expansion (neural_texture.py:177-185,
+//   a 256-entry LUT per degree) -> fp32 lerp (:188-191) -> fp16 SH coefficients
+//   (sh_neural_textures.py:88) -> SH evaluation with the view direction
+//   (encodings/sphericalharmonics.py:155-229) -> sigmoid (:92) -> alpha decay
+//   (methods/volsurfs.py:583-594) -> scatter into surfs_rgb / surfs_alpha
+//   (:550, :596).
+// Backward: the same chain reversed; gradients w.r.t. the quantised texel value
+// o = q/255 are accumulated per slot (f32 rows of 32) with wave-cooperative
+// atomics: lanes = the 64 (channel, SH coefficient) pairs of ONE hit, so each
+// wave instruction adds contiguous row segments instead of 64 scattered dwords.
+#include "nt_common.h"
+
+namespace {
+
+constexpr int SH_BLOCK = 256;
+
+constexpr float C0 = 0.28209479177387814f;
+constexpr float C1 = 0.4886025119029199f;
+constexpr float C2_0 = 1.0925484305920792f, C2_1 = -1.0925484305920792f,
+                C2_2 = 0.31539156525252005f, C2_3 = -1.0925484305920792f,
+                C2_4 = 0.5462742152960396f;
+constexpr float C3_0 = -0.5900435899266435f, C3_1 = 2.890611442640554f,
+                C3_2 = -0.4570457994644658f, C3_3 = 0.3731763325901154f,
+                C3_4 = -0.4570457994644658f, C3_5 = 1.445305721320277f,
+                C3_6 = -0.5900435899266435f;
+
+// SH basis factors exactly as SHEncoder.eval forms them (left-to-right fp32
+// products; index 0 is applied in fp16 and handled by the caller).
+__device__ __forceinline__ void sh_basis(float x, float y, float z, float b[16]) {
+  b[0] = C0;
+  b[1] = -(C1 * y);
+  b[2] = C1 * z;
+  b[3] = -(C1 * x);
+  const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+  b[4] = C2_0 * xy;
+  b[5] = C2_1 * yz;
+  b[6] = C2_2 * ((2.0f * zz - xx) - yy);
+  b[7] = C2_3 * xz;
+  b[8] = C2_4 * (xx - yy);
+  b[9] = (C3_0 * y) * (3.0f * xx - yy);
+  b[10] = (C3_1 * xy) * z;
+  b[11] = (C3_2 * y) * ((4.0f * zz - xx) - yy);
+  b[12] = (C3_3 * z) * ((2.0f * zz - 3.0f * xx) - 3.0f * yy);
+  b[13] = (C3_4 * x) * ((4.0f * zz - xx) - yy);
+  b[14] = (C3_5 * z) * (xx - yy);
+  b[15] = (C3_6 * x) * (xx - 3.0f * yy);
+}
+
+struct HitCtx {
+  bool hit;
+  float dir[3];
+  float decay;        // alpha decay factor (1 when disabled)
+  int slot[VSA_NT_MAX_DEG][4];
+  float w[VSA_NT_MAX_DEG][4];
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// Evaluate raw SH sum with the reference's exact order.  y, z, x come in through
+// the pre-multiplied basis b[] except for degree 1 where the reference
+// multiplies (C1*y)*sh — b[1..3] already carry the sign, so subtraction of
+// (C1*y)*sh1 is written as addition of b[1]*sh1 (bit-identical: a - p == a + (-p)).
+__device__ __forceinline__ float sh_raw(const float b[16], const float* sh, int degrees) {
+  float r = vsa_round_f16(C0 * sh[0]);
+  if (degrees > 1) {
+    r = r + b[1] * sh[1];
+    r = r + b[2] * sh[2];
+    r = r + b[3] * sh[3];
+    if (degrees > 2) {
+#pragma unroll
+      for (int m = 4; m < 9; ++m) r = r + b[m] * sh[m];
+      if (degrees > 3) {
+#pragma unroll
+        for (int m = 9; m < 16; ++m) r = r + b[m] * sh[m];
+      }
+    }
+  }
+  return r;
+}
+
+__device__ __forceinline__ void build_lut(const vsa_nt_plan& plan, float* s_lut) {
+  // expand_lut (oracle) : fp16(lo + fp16(span * fp16(q/255)))
+  for (int i = threadIdx.x; i < VSA_NT_MAX_DEG * 256; i += blockDim.x) {
+    const int d = i >> 8, q = i & 255;
+    const float o = vsa_round_f16((float)q / 255.0f);
+    const float t = vsa_round_f16(plan.sh_span[d] * o);
+    s_lut[i] = vsa_round_f16(plan.sh_lo[d] + t);
+  }
+}
+
+__device__ __forceinline__ bool load_ctx(const vsa_nt_plan& plan, int s, long long n, int N,
+                                         const int* hit_slot, const float* tex_uv,
+                                         const float* rays_d, const float4* tris,
+                                         const int* slot_of, HitCtx& c, float nrm[3]) {
+  const long long o = (long long)s * N + n;
+  const int tslot = hit_slot[o];
+  c.hit = tslot >= 0;
+  nrm[0] = nrm[1] = nrm[2] = 0.f;
+  if (!c.hit) return false;
+  c.dir[0] = rays_d[3 * n];
+  c.dir[1] = rays_d[3 * n + 1];
+  c.dir[2] = rays_d[3 * n + 2];
+  const float4 e1 = tris[3 * (long long)tslot + 1], e2 = tris[3 * (long long)tslot + 2];
+  const float cx = e1.y * e2.z - e1.z * e2.y, cy = e1.z * e2.x - e1.x * e2.z,
+              cz = e1.x * e2.y - e1.y * e2.x;
+  const float len = sqrtf((cx * cx + cy * cy) + cz * cz);
+  const float inv = len > 0.f ? 1.0f / len : 0.f;
+  nrm[0] = cx * inv;
+  nrm[1] = cy * inv;
+  nrm[2] = cz * inv;
+  c.decay = 1.0f;
+  if (plan.with_alpha_decay) {
+    float dot = ((-c.dir[0]) * nrm[0] + (-c.dir[1]) * nrm[1]) + (-c.dir[2]) * nrm[2];
+    dot = fminf(fmaxf(dot, 0.0f), 1.0f);
+    c.decay = sigmoidf_(10.0f * dot) * 2.0f - 1.0f;
+  }
+  const float u = tex_uv[2 * o], v = tex_uv[2 * o + 1];
+  const int D = max(plan.rgb_degrees, plan.alpha_degrees);
+  for (int d = 0; d < D; ++d) {
+    const int R = plan.tex_res[d], W = R + 2;
+    const NtFootprint f = nt_footprint(u, v, R);
+    const long long base = plan.dom_off[s * VSA_NT_MAX_DEG + d] + (long long)(f.j0 + 1) * W + (f.i0 + 1);
+    c.slot[d][0] = slot_of[base];
+    c.slot[d][1] = slot_of[base + 1];
+    c.slot[d][2] = slot_of[base + W];
+    c.slot[d][3] = slot_of[base + W + 1];
+    c.w[d][0] = (1.0f - f.fx) * (1.0f - f.fy);
+    c.w[d][1] = f.fx * (1.0f - f.fy);
+    c.w[d][2] = (1.0f - f.fx) * f.fy;
+    c.w[d][3] = f.fx * f.fy;
+  }
+  return true;
+}
+
+// SH coefficients (fp16-rounded, as floats): sh_rgb[ch][16], sh_a[16]
+__device__ __forceinline__ void gather_coeffs(const vsa_nt_plan& plan, const HitCtx& c,
+                                              const uint4* __restrict__ texels,
+                                              const float* s_lut, bool has_alpha,
+                                              float sh_rgb[3][16], float sh_a[16]) {
+#pragma unroll
+  for (int d = 0; d < VSA_NT_MAX_DEG; ++d) {
+    const int n = 2 * d + 1, m0 = d * d;
+    const bool do_rgb = d < plan.rgb_degrees, do_a = has_alpha && d < plan.alpha_degrees;
+    if (!do_rgb && !do_a) continue;
+    float acc[28];
+#pragma unroll
+    for (int i = 0; i < 28; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint4 lo = texels[2 * (long long)c.slot[d][k]];
+      const uint4 hi = texels[2 * (long long)c.slot[d][k] + 1];
+      const unsigned wds[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      const float wk = c.w[d][k];
+#pragma unroll
+      for (int i = 0; i < 3 * n; ++i) {
+        const unsigned q = (wds[i >> 2] >> (8 * (i & 3))) & 255u;
+        acc[i] = acc[i] + s_lut[d * 256 + q] * wk;
+      }
+#pragma unroll
+      for (int i = 0; i < n; ++i) {
+        const unsigned q = (wds[6 + (i >> 2)] >> (8 * (i & 3))) & 255u;
+        acc[21 + i] = acc[21 + i] + s_lut[d * 256 + q] * wk;
+      }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+      for (int i = 0; i < n; ++i) sh_rgb[ch][m0 + i] = do_rgb ? vsa_round_f16(acc[ch * n + i]) : 0.f;
+#pragma unroll
+    for (int i = 0; i < n; ++i) sh_a[m0 + i] = do_a ? vsa_round_f16(acc[21 + i]) : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(SH_BLOCK) void nt_shade_fwd_kernel(
+    vsa_nt_plan plan, const int* __restrict__ hit_slot, const float* __restrict__ tex_uv,
+    const float* __restrict__ rays_d, const float4* __restrict__ tris,
+    const int* __restrict__ slot_of, const uint4* __restrict__ texels, int N,
+    float* __restrict__ surfs_rgb, float* __restrict__ surfs_alpha,
+    float* __restrict__ surfs_normals, float* __restrict__ coeffs_out) {
+  __shared__ float s_lut[VSA_NT_MAX_DEG * 256];
+  build_lut(plan, s_lut);
+  __syncthreads();
+  const long long n = (long long)blockIdx.x * SH_BLOCK + threadIdx.x;
+  const int s = blockIdx.y, K = plan.nr_shells;
+  if (n >= N) return;
+  HitCtx c;
+  float nrm[3];
+  float rgb[3] = {0.f, 0.f, 0.f}, alpha = 0.f;
+  if (load_ctx(plan, s, n, N, hit_slot, tex_uv, rays_d, tris, slot_of, c, nrm)) {
+    const bool has_alpha = !(plan.inner_solid && s == 0);
+    float sh_rgb[3][16], sh_a[16];
+    gather_coeffs(plan, c, texels, s_lut, has_alpha, sh_rgb, sh_a);
+    float b[16];
+    sh_basis(c.dir[0], c.dir[1], c.dir[2], b);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float raw = sh_raw(b, sh_rgb[ch], plan.rgb_degrees);
+      rgb[ch] = plan.rgb_degrees > 1 ? sigmoidf_(raw) : vsa_round_f16(sigmoidf_(raw));
+    }
+    if (has_alpha) {
+      const float raw = sh_raw(b, sh_a, plan.alpha_degrees);
+      const float a = plan.alpha_degrees > 1 ? sigmoidf_(raw) : vsa_round_f16(sigmoidf_(raw));
+      alpha = a * c.decay;
+    } else {
+      alpha = 1.0f;
+    }
+    if (coeffs_out) {
+      float* co = coeffs_out + ((long long)s * N + n) * 64;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+        for (int m = 0; m < 16; ++m) co[ch * 16 + m] = sh_rgb[ch][m];
+#pragma unroll
+      for (int m = 0; m < 16; ++m) co[48 + m] = has_alpha ? sh_a[m] : 0.f;
+    }
+  } else if (coeffs_out) {
+    float* co = coeffs_out + ((long long)s * N + n) * 64;
+    for (int i = 0; i < 64; ++i) co[i] = 0.f;
+  }
+  const long long o = n * K + s;
+  surfs_rgb[3 * o] = rgb[0];
+  surfs_rgb[3 * o + 1] = rgb[1];
+  surfs_rgb[3 * o + 2] = rgb[2];
+  surfs_alpha[o] = alpha;
+  if (surfs_normals) {
+    surfs_normals[3 * o] = nrm[0];
+    surfs_normals[3 * o + 1] = nrm[1];
+    surfs_normals[3 * o + 2] = nrm[2];
+  }
+}
+
+// ---------------------------------------------------------------- backward
+// Per hit: g_raw[4] (3 rgb + alpha, through the output sigmoid and the decay) and
+// the 16 SH basis values; then lanes = 64 (channel, coefficient) pairs of one
+// hit at a time add  span_d * w_corner * g_raw[ch] * basis[m]  to the slot rows.
+__global__ __launch_bounds__(SH_BLOCK) void nt_shade_bwd_kernel(
+    vsa_nt_plan plan, const int* __restrict__ hit_slot, const float* __restrict__ tex_uv,
+    const float* __restrict__ rays_d, const float4* __restrict__ tris,
+    const int* __restrict__ slot_of, const uint4* __restrict__ texels, int N,
+    const float* __restrict__ g_surfs_rgb, const float* __restrict__ g_surfs_alpha,
+    float grad_scale, float* __restrict__ grad_rows) {
+  __shared__ float s_lut[VSA_NT_MAX_DEG * 256];
+  __shared__ float s_graw[SH_BLOCK][4];
+  __shared__ float s_basis[SH_BLOCK][17];
+  __shared__ int s_slot[SH_BLOCK][17];
+  __shared__ float s_w[SH_BLOCK][17];
+  build_lut(plan, s_lut);
+  __syncthreads();
+  const long long n = (long long)blockIdx.x * SH_BLOCK + threadIdx.x;
+  const int s = blockIdx.y, K = plan.nr_shells;
+  const int t = threadIdx.x;
+  HitCtx c;
+  c.hit = false;
+  float nrm[3];
+  const bool has_alpha = !(plan.inner_solid && s == 0);
+  if (n < N && load_ctx(plan, s, n, N, hit_slot, tex_uv, rays_d, tris, slot_of, c, nrm)) {
+    float sh_rgb[3][16], sh_a[16];
+    gather_coeffs(plan, c, texels, s_lut, has_alpha, sh_rgb, sh_a);
+    float b[16];
+    sh_basis(c.dir[0], c.dir[1], c.dir[2], b);
+    const long long o = n * K + s;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float sg = sigmoidf_(sh_raw(b, sh_rgb[ch], plan.rgb_degrees));
+      s_graw[t][ch] = g_surfs_rgb[3 * o + ch] * sg * (1.0f - sg) * grad_scale;
+    }
+    float ga = 0.f;
+    if (has_alpha) {
+      const float sg = sigmoidf_(sh_raw(b, sh_a, plan.alpha_degrees));
+      ga = g_surfs_alpha[o] * c.decay * sg * (1.0f - sg) * grad_scale;
+    }
+    s_graw[t][3] = ga;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) s_basis[t][m] = b[m];
+#pragma unroll
+    for (int d = 0; d < VSA_NT_MAX_DEG; ++d)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        s_slot[t][d * 4 + k] = c.slot[d][k];
+        s_w[t][d * 4 + k] = c.w[d][k] * plan.sh_span[d];
+      }
+  }
+  // per-wave cooperative scatter (no workgroup barrier needed: each wave reads
+  // only what its own lanes wrote)
+  const int lane = t & 63, wbase = t & ~63;
+  const unsigned long long hits = __ballot(c.hit);
+  const int ch = lane < 48 ? lane >> 4 : 3;
+  const int m = lane < 48 ? lane & 15 : lane - 48;
+  const int d = m >= 9 ? 3 : (m >= 4 ? 2 : (m >= 1 ? 1 : 0));
+  const int nn = 2 * d + 1;
+  const int fidx = ch < 3 ? ch * nn + (m - d * d) : 24 + (m - d * d);
+  const bool active = ch < 3 ? d < plan.rgb_degrees : (has_alpha && d < plan.alpha_degrees);
+  unsigned long long rem = hits;
+  while (rem) {
+    const int hl = __ffsll((long long)rem) - 1;
+    rem &= rem - 1;
+    const int ht = wbase + hl;
+    if (active) {
+      const float g = s_graw[ht][ch] * s_basis[ht][m];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int sl = s_slot[ht][d * 4 + k];
+        atomicAdd(&grad_rows[(long long)sl * 32 + fidx], s_w[ht][d * 4 + k] * g);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int vsa_nt_shade_fwd(const vsa_nt_plan* plan, const int32_t* hit_slot,
+                                const float* tex_uv, const float* rays_d, const float* tris,
+                                const int32_t* slot_of, const uint8_t* texels, int nr_rays,
+                                float* surfs_rgb, float* surfs_alpha, float* surfs_normals,
+                                float* coeffs_out, void* stream) {
+  if (!plan || nr_rays < 0) return VSA_ERR_ARG;
+  if (nr_rays == 0) return VSA_OK;
+  if (!hit_slot || !tex_uv || !rays_d || !tris || !slot_of || !texels || !surfs_rgb || !surfs_alpha)
+    return VSA_ERR_ARG;
+  dim3 grid(vsa_div_up(nr_rays, SH_BLOCK), plan->nr_shells);
+  hipLaunchKernelGGL(nt_shade_fwd_kernel, grid, dim3(SH_BLOCK), 0, (hipStream_t)stream, *plan,
+                     hit_slot, tex_uv, rays_d, reinterpret_cast<const float4*>(tris), slot_of,
+                     reinterpret_cast<const uint4*>(texels), nr_rays, surfs_rgb, surfs_alpha,
+                     surfs_normals, coeffs_out);
+  VSA_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int vsa_nt_shade_bwd(const vsa_nt_plan* plan, const int32_t* hit_slot,
+                                const float* tex_uv, const float* rays_d, const float* tris,
+                                const int32_t* slot_of, const uint8_t* texels, int nr_rays,
+                                const float* g_surfs_rgb, const float* g_surfs_alpha,
+                                float grad_scale, float* grad_rows, void* stream) {
+  if (!plan || nr_rays < 0) return VSA_ERR_ARG;
+  if (nr_rays == 0) return VSA_OK;
+  if (!hit_slot || !tex_uv || !rays_d || !tris || !slot_of || !texels || !g_surfs_rgb ||
+      !g_surfs_alpha || !grad_rows)
+    return VSA_ERR_ARG;
+  dim3 grid(vsa_div_up(nr_rays, SH_BLOCK), plan->nr_shells);
+  hipLaunchKernelGGL(nt_shade_bwd_kernel, grid, dim3(SH_BLOCK), 0, (hipStream_t)stream, *plan,
+                     hit_slot, tex_uv, rays_d, reinterpret_cast<const float4*>(tris), slot_of,
+                     reinterpret_cast<const uint4*>(texels), nr_rays, g_surfs_rgb, g_surfs_alpha,
+                     grad_scale, grad_rows);
+  VSA_RETURN_LAUNCH_STATUS();
+}

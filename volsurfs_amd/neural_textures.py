@@ -176,3 +176,14 @@ class NeuralTextureBank(torch.nn.Module):
         _lib.call("vsa_nt_mlp_fwd", ctypes.byref(self.plan), self.weights_h, self.features,
                   self.seg_start, self.texels, pre, _lib.stream_ptr())
         return (self.texels, pre) if want_pre else self.texels
+
+    def shade(self, hit_slot, tex_uv, rays_d, tris, want_coeffs=False, want_normals=False):
+        K, N = hit_slot.shape
+        dev = hit_slot.device
+        rgb = torch.empty(N, K, 3, device=dev)
+        alpha = torch.empty(N, K, device=dev)
+        normals = torch.empty(N, K, 3, device=dev) if want_normals else None
+        coeffs = torch.empty(K, N, 64, device=dev) if want_coeffs else None
+        _lib.call("vsa_nt_shade_fwd", ctypes.byref(self.plan), hit_slot, tex_uv, rays_d, tris,
+                  self.slot_of, self.texels, N, rgb, alpha, normals, coeffs, _lib.stream_ptr())
+        return rgb, alpha, normals, coeffs
