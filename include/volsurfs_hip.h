@@ -189,9 +189,21 @@ int vsa_nt_encode_fwd(const vsa_nt_plan* plan, const void* tables_h, const int32
  * [n_tex][VSA_NT_WEIGHTS_PER_TEX]; texels: u8 [slot_capacity][32] (quantised
  * texel rows: rgb coefficient c at byte c, alpha coefficient c at byte 24+c).
  * pre_out (optional, tests): f16 [slot_capacity][32], the network output before
- * the sigmoid, same row layout. */
+ * the sigmoid, same row layout.
+ * grad_rows (optional, training): f32 [slot_capacity][32]; the rows of every
+ * visited slot are zeroed here so that vsa_nt_shade_bwd can accumulate into them. */
 int vsa_nt_mlp_fwd(const vsa_nt_plan* plan, const void* weights_h, const void* features,
-                   const int32_t* seg_start, uint8_t* texels, void* pre_out, void* stream);
+                   const int32_t* seg_start, uint8_t* texels, void* pre_out, float* grad_rows,
+                   void* stream);
+
+/* Backward of step 4: recomputes the forward per 32-slot tile, back-propagates
+ * grad_rows (f32, already multiplied by grad_scale) through sigmoid (round = STE)
+ * and the three layers on MFMA.  Overwrites `features` IN PLACE with the feature
+ * gradients (f16x2, still scaled) and accumulates grad_weights (f32
+ * [n_tex][VSA_NT_WEIGHTS_PER_TEX], scaled) with one flush per wave. */
+int vsa_nt_mlp_bwd(const vsa_nt_plan* plan, const void* weights_h, void* features,
+                   const int32_t* seg_start, const float* grad_rows, float* grad_weights,
+                   void* stream);
 
 /* Step 5: per-hit shading from the texel rows (expand LUT -> lerp -> fp16 SH
  * coefficients -> SH eval -> sigmoid -> alpha decay), scattered dense:

@@ -1,0 +1,97 @@
+"""Backward of the whole shade stage (shade_bwd -> MLP bwd on MFMA -> LDS-resident
+hash-grid scatter) vs autograd through the oracle's SHNeuralTextures model."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import neural_texture as ONT
+
+from test_nt_mlp import unpack_weights
+from test_nt_shade import _scene
+
+
+def _oracle_grads(bank, s, hit_slot, tex_uv, rays_d, normals, g_rgb, g_alpha, decay_on):
+    hit = (hit_slot[s] >= 0).cpu()
+    uv, dirs = tex_uv[s].cpu()[hit], rays_d.cpu()[hit]
+    leaves = {}
+    loss = 0.0
+    for typ, C in ((0, 3), (1, 1)):
+        texs = []
+        for d in range(4):
+            x = bank.tex_index(s, typ, d)
+            w1, w2, w3 = unpack_weights(bank.weights_h[x].cpu().float())
+            ps = [t.clone().requires_grad_(True) for t in
+                  (bank.tables_h[x].cpu().float(), w1, w2, w3)]
+            leaves[x] = ps
+            texs.append(ONT.NeuralTextureOracle(bank.tex_res[d], C * (2 * d + 1), (-15, 15), *ps))
+        out = ONT.sh_neural_textures_forward(texs, uv, dirs, C, 3)
+        if typ == 0:
+            loss = loss + (out * g_rgb[:, s].cpu()[hit]).sum()
+        else:
+            a = out[:, 0]
+            if decay_on:
+                a = a * ONT.alpha_decay(dirs, normals[:, s].cpu()[hit])[:, 0]
+            loss = loss + (a * g_alpha[:, s].cpu()[hit]).sum()
+    loss.backward()
+    return leaves
+
+
+@pytest.mark.gpu
+def test_shade_stage_backward_vs_oracle_autograd():
+    K, N = 2, 2500
+    bank, face_uvs, hit_slot, hit_uv, tris, rays_d = _scene(K, N, 3)
+    tex_uv = bank.mark_and_compact(hit_slot, hit_uv, face_uvs)
+    bank.encode()
+    bank.mlp()
+    rgb, alpha, normals, _ = bank.shade(hit_slot, tex_uv, rays_d, tris, False, True)
+    g = torch.Generator().manual_seed(0)
+    g_rgb = (torch.randn(N, K, 3, generator=g) / N).cuda()
+    g_alpha = (torch.randn(N, K, generator=g) / N).cuda()
+    bank.backward(hit_slot, tex_uv, rays_d, tris, g_rgb, g_alpha, grad_scale=float(N))
+    torch.cuda.synchronize()
+    gw = bank.weights.grad.cpu()
+    gt = bank.tables.grad.cpu()
+    for s in range(K):
+        leaves = _oracle_grads(bank, s, hit_slot, tex_uv, rays_d, normals, g_rgb, g_alpha, True)
+        for x, (table, w1, w2, w3) in leaves.items():
+            ref_w = torch.cat([w1.grad.flatten(), w2.grad.flatten(), w3.grad.flatten()])
+            got_w = gw[x]
+            # reference: fp16 autograd; here: fp16 MFMA operands, fp32 accumulation.
+            # BASELINE north_star: grads within 1e-3 — stated here relative to the
+            # gradient scale of each tensor, plus fp16 noise on the small entries.
+            scale = ref_w.abs().max()
+            assert scale > 0
+            err = (got_w - ref_w).abs().max()
+            assert err <= 2e-2 * scale, (x, err, scale)
+            cos = torch.nn.functional.cosine_similarity(got_w, ref_w, dim=0)
+            assert cos > 0.9995, (x, cos)
+            ref_t, got_t = table.grad, gt[x]
+            tscale = ref_t.abs().max()
+            terr = (got_t - ref_t).abs().max()
+            assert terr <= 3e-2 * tscale, (x, terr, tscale)
+            cos = torch.nn.functional.cosine_similarity(got_t.flatten(), ref_t.flatten(), dim=0)
+            assert cos > 0.9995, (x, cos)
+            # same support up to fp16 underflow on either side (the reference's fp16
+            # autograd flushes tiny table gradients to zero; here dF is fp16 too)
+            assert ((ref_t != 0) ^ (got_t != 0)).float().mean() < 0.2
+
+
+@pytest.mark.gpu
+def test_backward_accumulates_and_is_linear():
+    K, N = 1, 1200
+    bank, face_uvs, hit_slot, hit_uv, tris, rays_d = _scene(K, N, 4, res=(256, 128, 64, 32))
+    tex_uv = bank.mark_and_compact(hit_slot, hit_uv, face_uvs)
+    bank.encode(); bank.mlp()
+    g = torch.Generator().manual_seed(1)
+    g_rgb = (torch.randn(N, K, 3, generator=g) / N).cuda()
+    g_alpha = (torch.randn(N, K, generator=g) / N).cuda()
+    bank.backward(hit_slot, tex_uv, rays_d, tris, g_rgb, g_alpha, grad_scale=float(N))
+    g1w, g1t = bank.weights.grad.clone(), bank.tables.grad.clone()
+    # second pass of the same frame accumulates (autograd semantics): need fresh features
+    bank.encode(); bank.mlp()
+    bank.backward(hit_slot, tex_uv, rays_d, tris, 2 * g_rgb, 2 * g_alpha, grad_scale=float(N))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(bank.weights.grad.cpu().numpy(), 3 * g1w.cpu().numpy(),
+                               rtol=2e-2, atol=2e-3 * g1w.abs().max().item())
+    np.testing.assert_allclose(bank.tables.grad.cpu().numpy(), 3 * g1t.cpu().numpy(),
+                               rtol=2e-2, atol=2e-3 * g1t.abs().max().item())

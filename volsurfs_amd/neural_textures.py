@@ -141,6 +141,7 @@ class NeuralTextureBank(torch.nn.Module):
         self.tables_h = torch.empty(self.n_tex, self.n_entries, 2, dtype=torch.float16, device=dev)
         self.weights_h = torch.empty(self.n_tex, WEIGHTS_PER_TEX, dtype=torch.float16, device=dev)
         self.texels = torch.zeros(cap, 32, dtype=u8, device=dev)
+        self.grad_rows = torch.zeros(cap, 32, device=dev) if training else None
         self.refresh_half_params()
 
     @torch.no_grad()
@@ -174,7 +175,7 @@ class NeuralTextureBank(torch.nn.Module):
         if want_pre:
             pre = torch.zeros(self.slot_capacity, 32, dtype=torch.float16, device=self.texels.device)
         _lib.call("vsa_nt_mlp_fwd", ctypes.byref(self.plan), self.weights_h, self.features,
-                  self.seg_start, self.texels, pre, _lib.stream_ptr())
+                  self.seg_start, self.texels, pre, self.grad_rows, _lib.stream_ptr())
         return (self.texels, pre) if want_pre else self.texels
 
     def shade(self, hit_slot, tex_uv, rays_d, tris, want_coeffs=False, want_normals=False):
@@ -187,3 +188,27 @@ class NeuralTextureBank(torch.nn.Module):
         _lib.call("vsa_nt_shade_fwd", ctypes.byref(self.plan), hit_slot, tex_uv, rays_d, tris,
                   self.slot_of, self.texels, N, rgb, alpha, normals, coeffs, _lib.stream_ptr())
         return rgb, alpha, normals, coeffs
+
+    def backward(self, hit_slot, tex_uv, rays_d, tris, g_surfs_rgb, g_surfs_alpha, grad_scale):
+        """Back-propagates d loss / d surfs_rgb [N,K,3], d surfs_alpha [N,K] to
+        self.tables.grad / self.weights.grad (accumulating, like autograd).
+        grad_scale keeps the fp16 intermediate gradients in range (the analogue of
+        tiny-cuda-nn's loss scale); it is divided out before accumulation."""
+        K, N = hit_slot.shape
+        st = _lib.stream_ptr()
+        if self.tables.grad is None:
+            self.tables.grad = torch.zeros_like(self.tables)
+        if self.weights.grad is None:
+            self.weights.grad = torch.zeros_like(self.weights)
+        if not hasattr(self, "_gw_scaled") or self._gw_scaled is None:
+            self._gw_scaled = torch.zeros_like(self.weights)
+        else:
+            self._gw_scaled.zero_()
+        _lib.call("vsa_nt_shade_bwd", ctypes.byref(self.plan), hit_slot, tex_uv, rays_d, tris,
+                  self.slot_of, self.texels, N, g_surfs_rgb.contiguous(),
+                  g_surfs_alpha.contiguous(), float(grad_scale), self.grad_rows, st)
+        _lib.call("vsa_nt_mlp_bwd", ctypes.byref(self.plan), self.weights_h, self.features,
+                  self.seg_start, self.grad_rows, self._gw_scaled, st)
+        _lib.call("vsa_nt_encode_bwd", ctypes.byref(self.plan), self.features, float(grad_scale),
+                  self.texel_of_slot, self.seg_start, self.tables.grad, st)
+        self.weights.grad.add_(self._gw_scaled, alpha=1.0 / float(grad_scale))
