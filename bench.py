@@ -35,35 +35,67 @@ def parse():
     ap.add_argument("--shells", type=int, default=5)
     ap.add_argument("--subdiv", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rays", type=int, default=1024)
+    ap.add_argument("--cpu-sample-rays", type=int, default=2048)
     return ap.parse_args()
 
 
 def cpu_baseline(pipe, sample_rays):
-    """The oracle (oracle/: CPU restatement of the reference path) timed on this
-    box's host cores over a bounded sample of the same workload.  kind="port":
-    the reference has no CPU path of its own."""
-    from oracle import composite as ocomp, raytrace as ort
+    """The oracle (oracle/: CPU restatement of the reference path, evaluated the
+    reference's way: 4 network evaluations per hit, degree and model) timed on this
+    box's host cores over a bounded sample of the same workload, forward +
+    backward.  kind="port": the reference has no CPU path of its own."""
+    from oracle import composite as ocomp, raytrace as ort, neural_texture as ONT
+    torch.set_num_threads(os.cpu_count())
     n = min(sample_rays, pipe.nr_rays)
     idx = torch.linspace(0, pipe.nr_rays - 1, n, device=pipe.rays_o.device).long()
     o = pipe.rays_o[idx].cpu().numpy()
     d = pipe.rays_d[idx].cpu().numpy()
-    gt = pipe.gt[idx].cpu().numpy()
-    meshes = [(m.vertices.cpu().numpy(), m.faces.cpu().numpy()) for m in pipe.meshes]
-    rgb = pipe._rgb_raw[idx].cpu().numpy()
-    alpha = pipe._alpha_raw[idx].cpu().numpy()
+    gt = pipe.gt[idx].cpu()
+    bank = pipe.bank
+    meshes = [(m.vertices.cpu().numpy(), m.faces.cpu().numpy(), m.faces_uvs.cpu()) for m in pipe.meshes]
+    tabs = bank.tables_h.cpu().float()
+    wts = bank.weights_h.cpu().float()
     t0 = time.perf_counter()
-    hits = [ort.trace_bruteforce(v, f, o, d) for v, f in meshes]
-    hit = np.stack([h["tri"] >= 0 for h in hits], 1)
-    c, a = rgb * hit[..., None], alpha * hit
-    out = ocomp.composite_dense_fwd(c, a, np.ones((1, 3), np.float32))
-    g = np.sign(out["rgb"] - gt).astype(np.float32) / (n * 3)
-    ocomp.composite_dense_bwd(c, a, np.ones((1, 3), np.float32), g)
+    K = pipe.K
+    surfs_rgb = torch.zeros(n, K, 3)
+    surfs_alpha = torch.zeros(n, K)
+    leaves = []
+    dirs_all = torch.from_numpy(d)
+    for s, (v, f, fuv) in enumerate(meshes):
+        h = ort.trace_bruteforce(v, f, o, d)
+        att = ort.hit_attributes(v, f, o, d, h)
+        hit = torch.from_numpy(att["is_hit"])
+        if not hit.any():
+            continue
+        uv = ONT.interp_uv(torch.from_numpy(att["barycentric"])[hit], fuv,
+                           torch.from_numpy(att["triangles_id"]).long()[hit])
+        dirs = dirs_all[hit]
+        for typ, C in ((0, 3), (1, 1)):
+            texs = []
+            for deg in range(4):
+                x = bank.tex_index(s, typ, deg)
+                w = wts[x]
+                ps = [t.clone().requires_grad_(True) for t in
+                      (tabs[x], w[:2048].view(64, 32), w[2048:6144].view(64, 64), w[6144:].view(32, 64))]
+                leaves += ps
+                texs.append(ONT.NeuralTextureOracle(bank.tex_res[deg], C * (2 * deg + 1), (-15, 15), *ps))
+            out = ONT.sh_neural_textures_forward(texs, uv, dirs, C, 3)
+            if typ == 0:
+                surfs_rgb = surfs_rgb.index_put((hit.nonzero()[:, 0], torch.tensor(s)), out)
+            else:
+                a = out[:, 0] * ONT.alpha_decay(dirs, torch.from_numpy(att["normals"])[hit])[:, 0]
+                surfs_alpha = surfs_alpha.index_put((hit.nonzero()[:, 0], torch.tensor(s)), a)
+    c_np, a_np = surfs_rgb.detach().numpy(), surfs_alpha.detach().numpy()
+    fwd = ocomp.composite_dense_fwd(c_np, a_np, np.ones((1, 3), np.float32))
+    g = np.sign(fwd["rgb"] - gt.numpy()).astype(np.float32) / (n * 3)
+    gc, ga, _ = ocomp.composite_dense_bwd(c_np, a_np, np.ones((1, 3), np.float32), g)
+    (surfs_rgb * torch.from_numpy(gc)).sum().add((surfs_alpha * torch.from_numpy(ga)).sum()).backward()
     dt = time.perf_counter() - t0
-    return {"value": n / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
-            "sample": f"{n} rays of the same frame, K={pipe.K}: brute-force closest hit "
-                      f"(oracle/raytrace_ref.c) + composite fwd+bwd (oracle/composite.py); "
-                      f"{dt:.1f} s"}
+    return {"value": n / dt / 1e6, "unit": "Mrays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} rays spread over the same frame, K={K}: brute-force closest hit "
+                      f"(oracle/raytrace_ref.c, 1 thread) + per-hit SH neural textures fwd+bwd "
+                      f"(oracle/neural_texture.py on torch-CPU, {torch.get_num_threads()} threads) + "
+                      f"composite fwd+bwd (oracle/composite.py); {dt:.1f} s"}
 
 
 def main():
@@ -92,8 +124,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(1, args.warmup)):
         pipe.step()
+    pipe.stats()                       # hit / unique-texel counts for the byte & flop accounting
     pipe.reset_stage_timers()
     barrier()
     t0 = time.perf_counter()

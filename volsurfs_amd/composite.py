@@ -68,3 +68,23 @@ def composite_dense(surfs_rgb, surfs_alpha, rgb_bg, carry_f16=False):
         "surfs_blending_weights": w,
         "bg_transmittance": bgT,
     }
+
+
+def composite_fwd_raw(surfs_rgb, surfs_alpha, rgb_bg, carry_f16=False):
+    """Forward only, rgb [N,3] only (the fused pipeline's call)."""
+    N, K, _ = surfs_rgb.shape
+    out = torch.empty(N, 3, device=surfs_rgb.device)
+    bcast = rgb_bg.shape[0] == 1 and N != 1
+    _lib.call("vsa_composite_dense_fwd", surfs_rgb, surfs_alpha, rgb_bg, bcast, out, None, None,
+              None, None, None, N, K, int(carry_f16), _lib.stream_ptr())
+    return out
+
+
+def composite_bwd_raw(surfs_rgb, surfs_alpha, rgb_bg, g_rgb, carry_f16=False):
+    N, K, _ = surfs_rgb.shape
+    g_c = torch.empty_like(surfs_rgb)
+    g_a = torch.empty_like(surfs_alpha)
+    bcast = rgb_bg.shape[0] == 1 and N != 1
+    _lib.call("vsa_composite_dense_bwd", surfs_rgb, surfs_alpha, rgb_bg, bcast, g_rgb, g_c, g_a,
+              None, N, K, int(carry_f16), _lib.stream_ptr())
+    return g_c, g_a

@@ -40,9 +40,11 @@ class StageTimer:
 
 
 class KShellPipeline:
-    dtype_desc = "f16 (composite / MLP compute as in the reference), f32 I/O"
+    dtype_desc = "f16 (hash features, MLP on MFMA, composite: as the reference), f32 accumulate and I/O"
 
-    def __init__(self, meshes, rays_o, rays_d, gt_rgb, bg_color=(1.0, 1.0, 1.0)):
+    def __init__(self, meshes, rays_o, rays_d, gt_rgb, bg_color=(1.0, 1.0, 1.0), seed=42,
+                 init="tcnn"):
+        from .neural_textures import NeuralTextureBank
         self.meshes = meshes
         self.K = len(meshes)
         self.tracer = RayTracer(meshes)
@@ -52,22 +54,31 @@ class KShellPipeline:
         self.bg = torch.tensor([bg_color], device=dev, dtype=torch.float32)
         self.timer = StageTimer()
         N, K = self.nr_rays, self.K
-        # PLACEHOLDER appearance until the neural-texture kernels land: fixed
-        # per-(ray,shell) colours/opacities, masked by the hit.  Flagged in
-        # config_desc() as a missing stage.
-        g = torch.Generator(device=dev).manual_seed(7)
-        self._rgb_raw = torch.rand(N, K, 3, device=dev, generator=g)
-        self._alpha_raw = torch.rand(N, K, device=dev, generator=g)
-        self.shading = "placeholder"
+        # per-corner uvs in the tracer's leaf (slot) order
+        fu = []
+        for m, off, n in zip(meshes, self.tracer.mesh_tri_offset, self.tracer.mesh_nr_tris):
+            ids = self.tracer.slot_face_id[off:off + n].long()
+            fu.append(m.faces_uvs.reshape(-1, 6)[ids])
+        self.face_uvs = torch.cat(fu, 0).contiguous()
+        self.bank = NeuralTextureBank(K, N, device=dev, seed=seed)
+        if init == "spread":
+            # larger parameters: textures with visible structure (parity tests)
+            g = torch.Generator().manual_seed(seed)
+            with torch.no_grad():
+                self.bank.tables.copy_((torch.rand(self.bank.tables.shape, generator=g) * 2 - 1).to(dev))
+            self.bank.refresh_half_params()
+        self.shading = "neural_textures"
+        self.grad_scale = float(N)
+        self.surfs_rgb = self.surfs_alpha = None
 
     @classmethod
-    def synthetic(cls, K=5, subdiv=6, res=800, device="cuda", seed=42):
+    def synthetic(cls, K=5, subdiv=6, res=800, device="cuda", seed=42, **kw):
         meshes = nested_shells(K=K, subdiv=subdiv, device=device)
         o, d = pinhole_rays(res, res, focal=1111.1 * res / 800.0, cam_pos=(0.0, 0.0, -1.5),
                             device=device)
         g = torch.Generator(device=device).manual_seed(seed)
         gt = torch.rand(o.shape[0], 3, device=device, generator=g)
-        p = cls(meshes, o, d, gt)
+        p = cls(meshes, o, d, gt, seed=seed, **kw)
         p.res = res
         p.subdiv = subdiv
         return p
@@ -94,36 +105,76 @@ class KShellPipeline:
         return {
             "workload": f"synthetic kitten-like: {self.res}x{self.res} rays, K={self.K} nested "
                         f"icospheres subdiv {self.subdiv} ({self.tracer.mesh_nr_tris[0]} tris each), "
-                        "white bg, L1 loss",
+                        "SH-degree-3 neural textures (rgb + alpha per shell, res 2048/1024/512/256, "
+                        "16-level 2-D hash grid + 32-64-64-C MLP, 8-bit quantised, lerp), alpha decay, "
+                        "white bg, L1 loss, gradients to all hash tables and MLP weights",
             "rays_per_gpu": self.nr_rays, "global_rays": self.nr_rays * world,
             "parallelism": f"tile-parallel x{world}",
-            "stages": ["trace", "shade:" + self.shading, "composite_fwd", "loss_l1",
-                       "composite_bwd"],
-            "missing_stages": (["neural-texture shading fwd/bwd (placeholder colours used)"]
-                               if self.shading == "placeholder" else []),
+            "hits_per_frame": getattr(self, "last_hits", None),
+            "unique_texels_per_frame": getattr(self, "last_slots", None),
         }
 
+    def stats(self):
+        """Host-side read-back of frame statistics (outside the timed region)."""
+        self.last_slots = int(self.bank.seg_start[self.K * 4].item())
+        self.last_hits = int((self._hit_slot >= 0).sum().item())
+        seg = self.bank.seg_start.cpu().tolist()
+        fl = 0
+        for s_ in range(self.K):
+            for d in range(4):
+                P_sd = seg[s_ * 4 + d + 1] - seg[s_ * 4 + d]
+                for typ in range(2):
+                    C = self.bank.tex_channels(self.bank.tex_index(s_, typ, d))
+                    if C:
+                        fl += P_sd * 2 * (32 * 64 + 64 * 64 + 64 * C)
+        self.mlp_flops_fwd = fl          # unpadded FLOPs of one forward over the unique texels
+        return self.last_hits, self.last_slots
+
     def step(self, record=False):
-        from .composite import composite_dense
+        """zero_grad -> forward -> L1 loss -> backward (trainer.py:118-264 without
+        the optimiser step).  Returns the predicted rgb [N,3]."""
+        from .composite import composite_fwd_raw, composite_bwd_raw
         N, K = self.nr_rays, self.K
-        T = self.timer
+        T, bank = self.timer, self.bank
+        M = getattr(self, "last_hits", None) or N * K          # hits (for byte/flop accounting)
+        P = getattr(self, "last_slots", None) or bank.slot_capacity
+        ntex = sum(1 for x in range(bank.n_tex) if bank.tex_channels(x))
         nodes_b = self.tracer.nodes.numel() * 4 + self.tracer.tris.numel() * 4
+
+        def zero_grad():
+            if bank.tables.grad is not None:
+                bank.tables.grad.zero_()
+                bank.weights.grad.zero_()
+        T.run("zero_grad", zero_grad, record, bytes=(bank.tables.numel() + bank.weights.numel()) * 4)
         hit_t, hit_slot, hit_uv = T.run(
             "trace", lambda: self.tracer.trace_all(self.rays_o, self.rays_d), record,
-            bytes=N * (24 + 16 * K) + nodes_b, bound="hbm")
+            bytes=N * (24 + 16 * K) + nodes_b)
+        self._hit_slot = hit_slot
+        tex_uv = T.run("nt_mark_compact",
+                       lambda: bank.mark_and_compact(hit_slot, hit_uv, self.face_uvs), record,
+                       bytes=N * K * 20 + bank.dom_total * (1 + 1 + 1 + 4) + P * 4)
+        T.run("nt_encode_fwd", bank.encode, record,
+              bytes=2 * 16 * P * (4 + 4) + ntex * bank.n_entries * 4)
+        mlp_flops = getattr(self, "mlp_flops_fwd", 0)
+        T.run("nt_mlp_fwd", bank.mlp, record, bytes=2 * P * (16 * 4) + P * (32 + 128),
+              flops=mlp_flops, bound="mfma")
+        rgb_k, alpha_k, _, _ = T.run(
+            "nt_shade_fwd", lambda: bank.shade(hit_slot, tex_uv, self.rays_d, self.tracer.tris),
+            record, bytes=M * (16 * 4 + 16 * 32 + 8 + 12 + 16) + N * K * 16)
+        self.surfs_rgb, self.surfs_alpha = rgb_k, alpha_k
+        rgb = T.run("composite_fwd", lambda: composite_fwd_raw(rgb_k, alpha_k, self.bg), record,
+                    bytes=N * (16 * K + 12))
 
-        def shade():
-            hit = (hit_slot >= 0).t()                       # [N,K]
-            rgb = (self._rgb_raw * hit[..., None]).requires_grad_(True)
-            alpha = (self._alpha_raw * hit).requires_grad_(True)
-            return rgb, alpha
-        rgb, alpha = T.run("shade_placeholder", shade, record, bytes=N * K * 40, bound="hbm")
-        out = T.run("composite_fwd", lambda: composite_dense(rgb, alpha, self.bg), record,
-                    bytes=N * (16 * K + 12 + 16 * K + 16 + 4 * K), bound="hbm")
-
-        def loss_fn():
-            return (self.gt - out["rgb"]).abs().mean()
-        loss = T.run("loss_l1", loss_fn, record, bytes=N * 24, bound="hbm")
-        T.run("backward(loss+composite_bwd)", lambda: loss.backward(), record,
-              bytes=N * (12 + 16 * K + 16 * K + 36), bound="hbm")
-        return loss
+        def loss_grad():
+            # d mean|gt - pred| / d pred  (utils/losses.py:14-19)
+            return torch.sign(rgb - self.gt) / (3.0 * N)
+        g_rgb = T.run("loss_l1_grad", loss_grad, record, bytes=N * 36)
+        g_c, g_a = T.run("composite_bwd",
+                         lambda: composite_bwd_raw(rgb_k, alpha_k, self.bg, g_rgb), record,
+                         bytes=N * (12 + 32 * K))
+        T.run("nt_backward(shade+mlp+hashgrad)",
+              lambda: bank.backward(hit_slot, tex_uv, self.rays_d, self.tracer.tris, g_c, g_a,
+                                    self.grad_scale), record,
+              bytes=M * (16 * 36 + 256 * 4) + 2 * P * 16 * 4 * 3 + P * 128,
+              flops=3 * mlp_flops, bound="mfma")
+        return rgb
