@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--shells", type=int, default=5)
     ap.add_argument("--subdiv", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rays", type=int, default=2048)
+    ap.add_argument("--cpu-sample-rays", type=int, default=4096)
     return ap.parse_args()
 
 
@@ -45,7 +45,9 @@ def cpu_baseline(pipe, sample_rays):
     box's host cores over a bounded sample of the same workload, forward +
     backward.  kind="port": the reference has no CPU path of its own."""
     from oracle import composite as ocomp, raytrace as ort, neural_texture as ONT
-    torch.set_num_threads(os.cpu_count())
+    # the reference's driver scripts assume 16 host threads (scripts/volsurfs.sh:47);
+    # many more than that makes torch-CPU's scatter backward crawl on big hosts
+    torch.set_num_threads(min(16, os.cpu_count()))
     n = min(sample_rays, pipe.nr_rays)
     idx = torch.linspace(0, pipe.nr_rays - 1, n, device=pipe.rays_o.device).long()
     o = pipe.rays_o[idx].cpu().numpy()
