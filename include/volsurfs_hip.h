@@ -161,6 +161,9 @@ typedef struct vsa_nt_plan {
   int32_t level_offset[VSA_NT_MAX_LEVELS + 1]; /* entries */
   int64_t dom_off[VSA_MAX_SHELLS * VSA_NT_MAX_DEG + 1];
   int64_t slot_capacity;             /* rows allocated in every per-slot buffer */
+  int32_t max_rays;                  /* N the buffers were sized for: a (shell,degree)
+                                        segment holds <= min(4*max_rays, (R_d+2)^2) slots */
+  int32_t reserved0;
 } vsa_nt_plan;
 
 /* Step 1 (per frame): per-hit texture uv + mark touched texels.
@@ -172,16 +175,18 @@ int vsa_nt_mark(const vsa_nt_plan* plan, const int32_t* hit_slot, const float* h
                 const float* face_uvs, int nr_rays, float* tex_uv, uint8_t* marks, void* stream);
 
 /* Step 2: compact marks into slots.  slot_of [dom total] i32 (-1 = untouched),
- * texel_of_slot [slot_capacity] i32 (domain index), seg_start [K*4+1] i32 (first
- * slot of each (shell,degree); last = total), block_scratch [dom total/4096 + 1] i32. */
+ * texel_of_slot [slot_capacity] i32 (domain index), slot_xy [slot_capacity,2] f32
+ * (normalised texel-centre coordinates = the network input of the slot),
+ * seg_start [K*4+1] i32 (first slot of each (shell,degree); last = total),
+ * block_scratch [dom total/4096 + 1] i32. */
 int vsa_nt_compact(const vsa_nt_plan* plan, const uint8_t* marks, int32_t* slot_of,
-                   int32_t* texel_of_slot, int32_t* seg_start, int32_t* block_scratch,
-                   void* stream);
+                   int32_t* texel_of_slot, float* slot_xy, int32_t* seg_start,
+                   int32_t* block_scratch, void* stream);
 
 /* Step 3: hash-grid encode every slot of every texture, level-major with the
  * level table in LDS.  tables_h: f16 [n_tex][level_offset[n]*2];
  * features: f16x2 [2 types][n_levels][slot_capacity]. */
-int vsa_nt_encode_fwd(const vsa_nt_plan* plan, const void* tables_h, const int32_t* texel_of_slot,
+int vsa_nt_encode_fwd(const vsa_nt_plan* plan, const void* tables_h, const float* slot_xy,
                       const int32_t* seg_start, void* features, void* stream);
 
 /* Step 4: MLP 32->64->64->C' of every slot of every texture on MFMA, fused with
@@ -227,7 +232,7 @@ int vsa_nt_shade_bwd(const vsa_nt_plan* plan, const int32_t* hit_slot, const flo
  * transpose-interpolation of dfeatures (f16x2, same layout as features, holding
  * grad * grad_scale).  Accumulates (caller zeroes grad_tables per optimiser step). */
 int vsa_nt_encode_bwd(const vsa_nt_plan* plan, const void* dfeatures, float grad_scale,
-                      const int32_t* texel_of_slot, const int32_t* seg_start, float* grad_tables,
+                      const float* slot_xy, const int32_t* seg_start, float* grad_tables,
                       void* stream);
 
 #ifdef __cplusplus

@@ -95,12 +95,22 @@ __global__ __launch_bounds__(1024) void nt_scan_blocks_kernel(vsa_nt_plan plan,
 }
 
 // pass C: slot_of[texel], texel_of_slot[slot]
-__global__ __launch_bounds__(256) void nt_assign_kernel(const uint4* __restrict__ marks,
+__global__ __launch_bounds__(256) void nt_assign_kernel(vsa_nt_plan plan,
+                                                        const uint4* __restrict__ marks,
                                                         const int* __restrict__ block_prefix,
                                                         int* __restrict__ slot_of,
                                                         int* __restrict__ texel_of_slot,
+                                                        float2* __restrict__ slot_xy,
                                                         long long slot_capacity) {
   __shared__ int s_w[4];
+  // the (shell, degree) domain this block lies in (domains are block aligned)
+  const long long blk0 = (long long)blockIdx.x * NT_DOM_BLOCK;
+  int sd = 0;
+  const int nseg = plan.nr_shells * VSA_NT_MAX_DEG;
+  while (sd + 1 < nseg && plan.dom_off[sd + 1] <= blk0) ++sd;
+  const int R = plan.tex_res[sd % VSA_NT_MAX_DEG], W = R + 2;
+  const float Rf = (float)R;
+  const long long dom0 = plan.dom_off[sd];
   const long long vec = (long long)blockIdx.x * 256 + threadIdx.x;
   const uint4 v = marks[vec];
   const int c = count16(v);
@@ -123,7 +133,14 @@ __global__ __launch_bounds__(256) void nt_assign_kernel(const uint4* __restrict_
     const bool m = (words[i >> 2] >> (8 * (i & 3))) & 1u;
     out[i] = m ? slot : -1;
     if (m) {
-      if (slot < slot_capacity) texel_of_slot[slot] = (int)(vec * 16 + i);
+      if (slot < slot_capacity) {
+        const long long texel = vec * 16 + i;
+        texel_of_slot[slot] = (int)texel;
+        const int local = (int)(texel - dom0);
+        const int iy = local / W, ix = local - iy * W;
+        // texel centre, normalised exactly like normalize_uv_coord(corner) in the reference
+        slot_xy[slot] = make_float2(((float)(ix - 1) + 0.5f) / Rf, ((float)(iy - 1) + 0.5f) / Rf);
+      }
       ++slot;
     }
   }
@@ -165,11 +182,12 @@ extern "C" int vsa_nt_mark(const vsa_nt_plan* plan, const int32_t* hit_slot, con
 }
 
 extern "C" int vsa_nt_compact(const vsa_nt_plan* plan, const uint8_t* marks, int32_t* slot_of,
-                              int32_t* texel_of_slot, int32_t* seg_start, int32_t* block_scratch,
-                              void* stream) {
+                              int32_t* texel_of_slot, float* slot_xy, int32_t* seg_start,
+                              int32_t* block_scratch, void* stream) {
   int rc = plan_check(plan);
   if (rc) return rc;
-  if (!marks || !slot_of || !texel_of_slot || !seg_start || !block_scratch) return VSA_ERR_ARG;
+  if (!marks || !slot_of || !texel_of_slot || !slot_xy || !seg_start || !block_scratch)
+    return VSA_ERR_ARG;
   const long long total = plan->dom_off[plan->nr_shells * VSA_NT_MAX_DEG];
   const int nr_blocks = (int)(total / NT_DOM_BLOCK);
   if (nr_blocks == 0) return VSA_OK;
@@ -178,8 +196,8 @@ extern "C" int vsa_nt_compact(const vsa_nt_plan* plan, const uint8_t* marks, int
                      reinterpret_cast<const uint4*>(marks), block_scratch);
   hipLaunchKernelGGL(nt_scan_blocks_kernel, dim3(1), dim3(1024), 0, st, *plan, block_scratch,
                      nr_blocks, seg_start);
-  hipLaunchKernelGGL(nt_assign_kernel, dim3(nr_blocks), dim3(256), 0, st,
+  hipLaunchKernelGGL(nt_assign_kernel, dim3(nr_blocks), dim3(256), 0, st, *plan,
                      reinterpret_cast<const uint4*>(marks), block_scratch, slot_of, texel_of_slot,
-                     (long long)plan->slot_capacity);
+                     reinterpret_cast<float2*>(slot_xy), (long long)plan->slot_capacity);
   VSA_RETURN_LAUNCH_STATUS();
 }

@@ -36,6 +36,7 @@ class Plan(ctypes.Structure):
         ("level_offset", ctypes.c_int32 * (MAX_LEVELS + 1)),
         ("dom_off", ctypes.c_int64 * (MAX_SHELLS * MAX_DEG + 1)),
         ("slot_capacity", ctypes.c_int64),
+        ("max_rays", ctypes.c_int32), ("reserved0", ctypes.c_int32),
     ]
 
 
@@ -92,6 +93,7 @@ class NeuralTextureBank(torch.nn.Module):
             p.dom_off[i] = off
         cap = (cap + 63) // 64 * 64 + 64
         p.slot_capacity = cap
+        p.max_rays = max_rays
         self.plan, self.dom_total, self.slot_capacity = p, off, cap
         self.tex_res = tuple(int(r) for r in textures_res)
 
@@ -135,6 +137,7 @@ class NeuralTextureBank(torch.nn.Module):
         self.marks = torch.zeros(self.dom_total, dtype=u8, device=dev)
         self.slot_of = torch.empty(self.dom_total, dtype=i32, device=dev)
         self.texel_of_slot = torch.zeros(cap, dtype=i32, device=dev)
+        self.slot_xy = torch.zeros(cap, 2, device=dev)
         self.seg_start = torch.zeros(K * MAX_DEG + 1, dtype=i32, device=dev)
         self.block_scratch = torch.zeros(self.dom_total // DOM_BLOCK + 1, dtype=i32, device=dev)
         self.features = torch.empty(2, 16, cap, 2, dtype=torch.float16, device=dev)
@@ -162,11 +165,11 @@ class NeuralTextureBank(torch.nn.Module):
         _lib.call("vsa_nt_mark", ctypes.byref(self.plan), hit_slot, hit_uv, face_uvs, N, tex_uv,
                   self.marks, st)
         _lib.call("vsa_nt_compact", ctypes.byref(self.plan), self.marks, self.slot_of,
-                  self.texel_of_slot, self.seg_start, self.block_scratch, st)
+                  self.texel_of_slot, self.slot_xy, self.seg_start, self.block_scratch, st)
         return tex_uv
 
     def encode(self):
-        _lib.call("vsa_nt_encode_fwd", ctypes.byref(self.plan), self.tables_h, self.texel_of_slot,
+        _lib.call("vsa_nt_encode_fwd", ctypes.byref(self.plan), self.tables_h, self.slot_xy,
                   self.seg_start, self.features, _lib.stream_ptr())
         return self.features
 
@@ -210,5 +213,5 @@ class NeuralTextureBank(torch.nn.Module):
         _lib.call("vsa_nt_mlp_bwd", ctypes.byref(self.plan), self.weights_h, self.features,
                   self.seg_start, self.grad_rows, self._gw_scaled, st)
         _lib.call("vsa_nt_encode_bwd", ctypes.byref(self.plan), self.features, float(grad_scale),
-                  self.texel_of_slot, self.seg_start, self.tables.grad, st)
+                  self.slot_xy, self.seg_start, self.tables.grad, st)
         self.weights.grad.add_(self._gw_scaled, alpha=1.0 / float(grad_scale))
