@@ -17,17 +17,27 @@
 
 namespace {
 
-constexpr int ENC_BLOCK = 1024;     // 16 waves: the 128 KiB level pins one workgroup per CU
+constexpr int ENC_BLOCK = 1024;     // 16 waves: a 128 KiB level pins one workgroup per CU
 constexpr int ENC_UNROLL = 4;       // slots in flight per lane
 constexpr int ENC_SPAN_FWD = 65536;   // slots per workgroup (forward)
 constexpr int ENC_SPAN_BWD = 262144;  // slots per workgroup before a flush (backward)
 constexpr unsigned PRIME_Y = 2654435761u;
-constexpr int SMALL_LEVEL_ENTRIES = 8192;  // levels up to this size run in the small-LDS launch
+constexpr int LDS_ENTRIES = 32768;    // 4-byte entries of LDS a workgroup may use (128 KiB)
+
+// Per-launch constants decoded on the host: which levels, and how blockIdx.x
+// enumerates (model = shell*2+type, degree, group).  The per-degree group count
+// comes from the segment capacity min(4*max_rays, (R_d+2)^2), so that small
+// textures do not launch the worst-case number of LDS-hungry workgroups.
+struct EncLaunch {
+  int level0;
+  int span;
+  int groups[VSA_NT_MAX_DEG];
+  int per_model;
+};
 
 struct LevelGeom {
   float scale;
   unsigned res, size, mask;
-  bool hashed;
 };
 
 __device__ __forceinline__ LevelGeom level_geom(const vsa_nt_plan& p, int l) {
@@ -35,16 +45,8 @@ __device__ __forceinline__ LevelGeom level_geom(const vsa_nt_plan& p, int l) {
   g.scale = p.level_scale[l];
   g.res = (unsigned)p.level_res[l];
   g.size = (unsigned)p.level_size[l];
-  // tiny-cuda-nn grid_index: dense while the running stride fits the table
-  g.hashed = !((long long)g.res <= (long long)g.size && (long long)g.res * g.res <= (long long)g.size);
-  g.mask = (g.size & (g.size - 1)) == 0 ? g.size - 1 : 0u;
+  g.mask = g.size - 1;   // used by hashed levels only (their size is a power of two)
   return g;
-}
-
-__device__ __forceinline__ unsigned level_index(const LevelGeom& g, unsigned cx, unsigned cy) {
-  unsigned idx = g.hashed ? (cx ^ (cy * PRIME_Y)) : (cx + cy * g.res);
-  if (g.mask) return idx & g.mask;           // power-of-two table: modulo is a mask
-  return idx < g.size ? idx : idx % g.size;  // dense level: in range except at the far edge
 }
 
 struct CellCorners {
@@ -53,20 +55,37 @@ struct CellCorners {
 };
 
 // normalised texel centre -> the 4 table entries and bilinear weights at level g
-// (oracle/tcnn_like.py hashgrid_forward, same fp32 operations in the same order)
+// (oracle/tcnn_like.py hashgrid_forward: same fp32 operations in the same order).
+// HASHED: tiny-cuda-nn's coherent prime hash, table size 2^k.  Dense: x + y*res,
+// wrapped only at the far edge / on the apron of tiny textures.
+template <bool HASHED>
 __device__ __forceinline__ CellCorners cell_corners(const LevelGeom& g, float x, float y) {
   const float px = x * g.scale + 0.5f, py = y * g.scale + 0.5f;
   const float flx = floorf(px), fly = floorf(py);
   const float fx = px - flx, fy = py - fly;
   const unsigned cx = (unsigned)(int)flx, cy = (unsigned)(int)fly;
+  const float gx = 1.0f - fx, gy = 1.0f - fy;
   CellCorners c;
+  c.w[0] = gx * gy;
+  c.w[1] = fx * gy;
+  c.w[2] = gx * fy;
+  c.w[3] = fx * fy;
+  if (HASHED) {
+    const unsigned h0 = cy * PRIME_Y, h1 = (cy + 1u) * PRIME_Y;
+    c.idx[0] = (cx ^ h0) & g.mask;
+    c.idx[1] = ((cx + 1u) ^ h0) & g.mask;
+    c.idx[2] = (cx ^ h1) & g.mask;
+    c.idx[3] = ((cx + 1u) ^ h1) & g.mask;
+  } else {
+    const unsigned r0 = cx + cy * g.res;
+    c.idx[0] = r0;
+    c.idx[1] = r0 + 1u;
+    c.idx[2] = r0 + g.res;
+    c.idx[3] = r0 + g.res + 1u;
+    if (c.idx[3] >= g.size || c.idx[0] > c.idx[3]) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int dx = k & 1, dy = k >> 1;
-    const float wx = dx ? fx : 1.0f - fx;
-    const float wy = dy ? fy : 1.0f - fy;
-    c.w[k] = wx * wy;
-    c.idx[k] = level_index(g, cx + dx, cy + dy);
+      for (int k = 0; k < 4; ++k) c.idx[k] %= g.size;
+    }
   }
   return c;
 }
@@ -80,53 +99,45 @@ __device__ __forceinline__ bool tex_active(const vsa_nt_plan& p, int tex) {
   return deg < p.alpha_degrees;
 }
 
-// Work decode.  blockIdx.x enumerates (shell*2+type, degree, group) with a
-// per-degree group count derived from the segment's capacity
-// min(4*max_rays, (R_d+2)^2), so that small textures do not launch the
-// worst-case number of (LDS-hungry) workgroups.
-__host__ __device__ inline int groups_of_degree(const vsa_nt_plan& p, int d, int span) {
-  const long long T = (long long)(p.tex_res[d] + 2) * (p.tex_res[d] + 2);
-  long long cap = 4ll * p.max_rays < T ? 4ll * p.max_rays : T;
-  if (cap < 1) cap = 1;
-  return (int)((cap + span - 1) / span);
-}
-
 struct Work {
-  int tex, group;
-  int begin, end;  // slot range of the (shell, degree) segment
+  int tex, first, last;  // slots [first, last) of texture tex
+  int seg_len;           // slots in the whole (shell, degree) segment
 };
 
-__device__ __forceinline__ bool decode_work(const vsa_nt_plan& p, const int* seg_start, int span,
-                                            int bx, Work& w) {
-  int per_model = 0;
-  for (int d = 0; d < VSA_NT_MAX_DEG; ++d) per_model += groups_of_degree(p, d, span);
-  const int model = bx / per_model;  // shell*2 + type
-  int r = bx - model * per_model;
+__device__ __forceinline__ bool decode_work(const vsa_nt_plan& p, const EncLaunch& L,
+                                            const int* seg_start, int bx, Work& w) {
+  const int model = bx / L.per_model;  // shell*2 + type
+  int r = bx - model * L.per_model;
   int d = 0;
-  for (; d < VSA_NT_MAX_DEG; ++d) {
-    const int g = groups_of_degree(p, d, span);
-    if (r < g) break;
-    r -= g;
-  }
+#pragma unroll
+  for (int i = 0; i < VSA_NT_MAX_DEG - 1; ++i)
+    if (d == i && r >= L.groups[i]) {
+      r -= L.groups[i];
+      d = i + 1;
+    }
   w.tex = model * VSA_NT_MAX_DEG + d;
-  w.group = r;
   if (!tex_active(p, w.tex)) return false;
   const int sd = (model >> 1) * VSA_NT_MAX_DEG + d;
-  w.begin = seg_start[sd];
-  w.end = seg_start[sd + 1];
-  return w.begin + (long long)r * span < w.end;
+  const int begin = seg_start[sd], end = seg_start[sd + 1];
+  w.seg_len = end - begin;
+  const long long first = begin + (long long)r * L.span;
+  if (first >= end) return false;
+  w.first = (int)first;
+  w.last = (int)(first + L.span < end ? first + L.span : end);
+  return true;
 }
 
+template <bool HASHED>
 __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
-    vsa_nt_plan plan, const half2_t* __restrict__ tables, const float2* __restrict__ slot_xy,
-    const int* __restrict__ seg_start, half2_t* __restrict__ features, int level0) {
+    vsa_nt_plan plan, EncLaunch L, const half2_t* __restrict__ tables,
+    const float2* __restrict__ slot_xy, const int* __restrict__ seg_start,
+    half2_t* __restrict__ features) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   half2_t* s_tab = reinterpret_cast<half2_t*>(s_raw);
-  const int level = level0 + blockIdx.y;
+  const int level = L.level0 + blockIdx.y;
   Work wk;
-  if (!decode_work(plan, seg_start, ENC_SPAN_FWD, blockIdx.x, wk)) return;
-  const int first = wk.begin + wk.group * ENC_SPAN_FWD;
-  const int last = min(wk.end, first + ENC_SPAN_FWD);
+  if (!decode_work(plan, L, seg_start, blockIdx.x, wk)) return;
+  const int last = wk.last;
   const LevelGeom g = level_geom(plan, level);
   const long long n_entries = plan.level_offset[plan.n_levels];
   const half2_t* tab = tables + (long long)wk.tex * n_entries + plan.level_offset[level];
@@ -138,7 +149,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
   __syncthreads();
   const int type = (wk.tex / VSA_NT_MAX_DEG) & 1;
   half2_t* out = features + ((long long)type * plan.n_levels + level) * plan.slot_capacity;
-  for (int base = first + threadIdx.x; base < last; base += ENC_BLOCK * ENC_UNROLL) {
+  for (int base = wk.first + threadIdx.x; base < last; base += ENC_BLOCK * ENC_UNROLL) {
     float2 xy[ENC_UNROLL];
 #pragma unroll
     for (int u = 0; u < ENC_UNROLL; ++u) {
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
     }
     CellCorners c[ENC_UNROLL];
 #pragma unroll
-    for (int u = 0; u < ENC_UNROLL; ++u) c[u] = cell_corners(g, xy[u].x, xy[u].y);
+    for (int u = 0; u < ENC_UNROLL; ++u) c[u] = cell_corners<HASHED>(g, xy[u].x, xy[u].y);
     half2_t v[ENC_UNROLL][4];
 #pragma unroll
     for (int u = 0; u < ENC_UNROLL; ++u)
@@ -175,25 +186,34 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
 // plane (size entries) in LDS.
 //
 // gfx950's LDS float atomic (ds_add_f32) retires ~0.4 lanes/clk/CU on random
-// addresses, the integer one >= 8x that (tools/ubench/lds_atomics.hip), so the
-// plane is accumulated in 32-bit FIXED POINT with a per-workgroup scale that
-// makes overflow impossible: S = 2^30 / sum_slots |dF| bounds every entry's
-// |sum| (bilinear weights of a slot sum to 1) below 2^30.  Resolution is
+// addresses, the integer one ~8.5 (tools/ubench/lds_atomics.hip), so the plane
+// is accumulated in 32-bit FIXED POINT with a per-workgroup scale that makes
+// overflow impossible: S = 2^30 / sum_slots |dF| bounds every entry's |sum|
+// (bilinear weights of a slot sum to 1) below 2^30.  Resolution is
 // sum|dF| / 2^30, i.e. <= span / 2^30 = 2.4e-4 of the MEAN |dF| per add.
+// Same-address adds serialise (16 lanes on one entry: 5x slower), and at the
+// coarse dense levels neighbouring texels share their cell; those small planes
+// are therefore replicated `copies` times in LDS (lane & (copies-1) picks one)
+// and summed at the flush.
+template <bool HASHED>
 __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
-    vsa_nt_plan plan, const half2_t* __restrict__ dfeatures, float dscale_inv,
+    vsa_nt_plan plan, EncLaunch L, const half2_t* __restrict__ dfeatures, float dscale_inv,
     const float2* __restrict__ slot_xy, const int* __restrict__ seg_start,
-    float* __restrict__ grad_tables, int level0) {
+    float* __restrict__ grad_tables) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   int* s_g = reinterpret_cast<int*>(s_raw);
   __shared__ float s_red[ENC_BLOCK / 64];
-  const int level = level0 + (blockIdx.y >> 1), feat = blockIdx.y & 1;
+  const int level = L.level0 + (blockIdx.y >> 1), feat = blockIdx.y & 1;
   Work wk;
-  if (!decode_work(plan, seg_start, ENC_SPAN_BWD, blockIdx.x, wk)) return;
-  const int first = wk.begin + wk.group * ENC_SPAN_BWD;
-  const int last = min(wk.end, first + ENC_SPAN_BWD);
+  if (!decode_work(plan, L, seg_start, blockIdx.x, wk)) return;
+  const int first = wk.first, last = wk.last;
   const LevelGeom g = level_geom(plan, level);
-  for (int i = threadIdx.x; i < (int)g.size; i += ENC_BLOCK) s_g[i] = 0;
+  int copies = 1;
+  if (!HASHED) {
+    while (copies < 32 && (long long)g.size * copies * 2 <= LDS_ENTRIES) copies *= 2;
+  }
+  for (int i = threadIdx.x; i < (int)g.size * copies; i += ENC_BLOCK) s_g[i] = 0;
+  int* my_g = s_g + (threadIdx.x & (copies - 1)) * g.size;
   const int type = (wk.tex / VSA_NT_MAX_DEG) & 1;
   const _Float16* dF = reinterpret_cast<const _Float16*>(
                            dfeatures + ((long long)type * plan.n_levels + level) * plan.slot_capacity) + feat;
@@ -207,10 +227,9 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
 #pragma unroll
   for (int i = 0; i < ENC_BLOCK / 64; ++i) total += s_red[i];
   if (!(total > 0.f)) return;   // nothing to add (uniform across the workgroup)
-  // power-of-two scale <= 2^30 / total  (exact scaling, exact un-scaling)
   int e;
   frexpf(total, &e);                       // total = m * 2^e, m in [0.5, 1)
-  const float S = ldexpf(1.0f, 30 - e);
+  const float S = ldexpf(1.0f, 30 - e);    // power of two: exact scaling and un-scaling
   const float S_inv = ldexpf(1.0f, e - 30) * dscale_inv;
   // pass 2: scatter
   for (int base = first + threadIdx.x; base < last; base += ENC_BLOCK * ENC_UNROLL) {
@@ -226,18 +245,19 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
 #pragma unroll
     for (int u = 0; u < ENC_UNROLL; ++u) {
       if (gv[u] != 0.f) {
-        const CellCorners c = cell_corners(g, xy[u].x, xy[u].y);
+        const CellCorners c = cell_corners<HASHED>(g, xy[u].x, xy[u].y);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) atomicAdd(&s_g[c.idx[k]], __float2int_rn(c.w[k] * gv[u]));
+        for (int k = 0; k < 4; ++k) atomicAdd(&my_g[c.idx[k]], __float2int_rn(c.w[k] * gv[u]));
       }
     }
   }
   __syncthreads();
   const long long n_entries = plan.level_offset[plan.n_levels];
   float* gt = grad_tables + ((long long)wk.tex * n_entries + plan.level_offset[level]) * 2 + feat;
-  const bool single = (wk.end - wk.begin) <= ENC_SPAN_BWD;
+  const bool single = wk.seg_len <= L.span;
   for (int i = threadIdx.x; i < (int)g.size; i += ENC_BLOCK) {
-    const int vi = s_g[i];
+    int vi = 0;
+    for (int cpy = 0; cpy < copies; ++cpy) vi += s_g[cpy * g.size + i];
     if (vi == 0) continue;
     const float v = (float)vi * S_inv;
     if (single) {
@@ -250,18 +270,44 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
 
 }  // namespace
 
-static int enc_grid_x(const vsa_nt_plan* p, int span) {
-  int per_model = 0;
-  for (int d = 0; d < VSA_NT_MAX_DEG; ++d) per_model += groups_of_degree(*p, d, span);
-  return per_model * p->nr_shells * 2;
+static EncLaunch enc_launch(const vsa_nt_plan* p, int level0, int span) {
+  EncLaunch L;
+  L.level0 = level0;
+  L.span = span;
+  L.per_model = 0;
+  for (int d = 0; d < VSA_NT_MAX_DEG; ++d) {
+    const long long T = (long long)(p->tex_res[d] + 2) * (p->tex_res[d] + 2);
+    long long cap = 4ll * p->max_rays < T ? 4ll * p->max_rays : T;
+    if (cap < 1) cap = 1;
+    L.groups[d] = (int)((cap + span - 1) / span);
+    L.per_model += L.groups[d];
+  }
+  return L;
 }
 
-// Levels are launched in two classes so that the many small (dense) levels do
-// not reserve the 128 KiB a full 2^15-entry level needs.
-static int split_level(const vsa_nt_plan* p) {
+static bool level_hashed(const vsa_nt_plan* p, int l) {
+  const long long res = p->level_res[l], size = p->level_size[l];
+  return !(res <= size && res * res <= size);  // tiny-cuda-nn grid_index
+}
+
+// Dense (coarse) levels first, hashed levels after: the multiresolution grid is
+// monotone, which the two-launch split relies on.
+static int first_hashed_level(const vsa_nt_plan* p) {
   int l = 0;
-  while (l < p->n_levels && p->level_size[l] <= SMALL_LEVEL_ENTRIES) ++l;
+  while (l < p->n_levels && !level_hashed(p, l)) ++l;
   return l;
+}
+
+static int check_levels(const vsa_nt_plan* p) {
+  const int lh = first_hashed_level(p);
+  for (int l = lh; l < p->n_levels; ++l) {
+    if (!level_hashed(p, l)) return VSA_ERR_UNSUPPORTED;
+    const int sz = p->level_size[l];
+    if ((sz & (sz - 1)) != 0 || sz > LDS_ENTRIES) return VSA_ERR_UNSUPPORTED;
+  }
+  for (int l = 0; l < lh; ++l)
+    if (p->level_size[l] > LDS_ENTRIES) return VSA_ERR_UNSUPPORTED;
+  return VSA_OK;
 }
 
 static int max_level_size(const vsa_nt_plan* p, int l0, int l1) {
@@ -270,28 +316,41 @@ static int max_level_size(const vsa_nt_plan* p, int l0, int l1) {
   return m;
 }
 
+template <typename K>
+static int set_lds_attr(K kernel) {
+  VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+  return VSA_OK;
+}
+
 extern "C" int vsa_nt_encode_fwd(const vsa_nt_plan* plan, const void* tables_h,
                                  const float* slot_xy, const int32_t* seg_start, void* features,
                                  void* stream) {
   if (!plan || !tables_h || !slot_xy || !seg_start || !features) return VSA_ERR_ARG;
-  if ((size_t)max_level_size(plan, 0, plan->n_levels) * 4 > 160 * 1024) return VSA_ERR_UNSUPPORTED;
+  int rc = check_levels(plan);
+  if (rc) return rc;
   static bool attr_set = false;
   if (!attr_set) {
-    VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(nt_encode_fwd_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+    if ((rc = set_lds_attr(nt_encode_fwd_kernel<false>))) return rc;
+    if ((rc = set_lds_attr(nt_encode_fwd_kernel<true>))) return rc;
     attr_set = true;
   }
-  const int ls = split_level(plan);
-  const int gx = enc_grid_x(plan, ENC_SPAN_FWD);
-  const int ranges[2][2] = {{0, ls}, {ls, plan->n_levels}};
-  for (int r = 0; r < 2; ++r) {
-    const int l0 = ranges[r][0], l1 = ranges[r][1];
-    if (l1 <= l0) continue;
-    const size_t lds = (size_t)max_level_size(plan, l0, l1) * 4;
-    hipLaunchKernelGGL(nt_encode_fwd_kernel, dim3(gx, l1 - l0), dim3(ENC_BLOCK), lds,
-                       (hipStream_t)stream, *plan, reinterpret_cast<const half2_t*>(tables_h),
-                       reinterpret_cast<const float2*>(slot_xy), seg_start,
-                       reinterpret_cast<half2_t*>(features), l0);
+  const int lh = first_hashed_level(plan);
+  const half2_t* tab = reinterpret_cast<const half2_t*>(tables_h);
+  const float2* xy = reinterpret_cast<const float2*>(slot_xy);
+  half2_t* out = reinterpret_cast<half2_t*>(features);
+  const int models = plan->nr_shells * 2;
+  if (lh > 0) {
+    const EncLaunch L = enc_launch(plan, 0, ENC_SPAN_FWD);
+    hipLaunchKernelGGL(nt_encode_fwd_kernel<false>, dim3(L.per_model * models, lh), dim3(ENC_BLOCK),
+                       (size_t)max_level_size(plan, 0, lh) * 4, (hipStream_t)stream, *plan, L, tab,
+                       xy, seg_start, out);
+  }
+  if (lh < plan->n_levels) {
+    const EncLaunch L = enc_launch(plan, lh, ENC_SPAN_FWD);
+    hipLaunchKernelGGL(nt_encode_fwd_kernel<true>, dim3(L.per_model * models, plan->n_levels - lh),
+                       dim3(ENC_BLOCK), (size_t)max_level_size(plan, lh, plan->n_levels) * 4,
+                       (hipStream_t)stream, *plan, L, tab, xy, seg_start, out);
   }
   VSA_RETURN_LAUNCH_STATUS();
 }
@@ -301,24 +360,30 @@ extern "C" int vsa_nt_encode_bwd(const vsa_nt_plan* plan, const void* dfeatures,
                                  float* grad_tables, void* stream) {
   if (!plan || !dfeatures || !slot_xy || !seg_start || !grad_tables) return VSA_ERR_ARG;
   if (!(grad_scale > 0.f)) return VSA_ERR_ARG;
-  if ((size_t)max_level_size(plan, 0, plan->n_levels) * 4 > 160 * 1024) return VSA_ERR_UNSUPPORTED;
+  int rc = check_levels(plan);
+  if (rc) return rc;
   static bool attr_set = false;
   if (!attr_set) {
-    VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(nt_encode_bwd_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+    if ((rc = set_lds_attr(nt_encode_bwd_kernel<false>))) return rc;
+    if ((rc = set_lds_attr(nt_encode_bwd_kernel<true>))) return rc;
     attr_set = true;
   }
-  const int ls = split_level(plan);
-  const int gx = enc_grid_x(plan, ENC_SPAN_BWD);
-  const int ranges[2][2] = {{0, ls}, {ls, plan->n_levels}};
-  for (int r = 0; r < 2; ++r) {
-    const int l0 = ranges[r][0], l1 = ranges[r][1];
-    if (l1 <= l0) continue;
-    const size_t lds = (size_t)max_level_size(plan, l0, l1) * 4;
-    hipLaunchKernelGGL(nt_encode_bwd_kernel, dim3(gx, 2 * (l1 - l0)), dim3(ENC_BLOCK), lds,
-                       (hipStream_t)stream, *plan, reinterpret_cast<const half2_t*>(dfeatures),
-                       1.0f / grad_scale, reinterpret_cast<const float2*>(slot_xy), seg_start,
-                       grad_tables, l0);
+  const int lh = first_hashed_level(plan);
+  const half2_t* dF = reinterpret_cast<const half2_t*>(dfeatures);
+  const float2* xy = reinterpret_cast<const float2*>(slot_xy);
+  const int models = plan->nr_shells * 2;
+  if (lh > 0) {
+    const EncLaunch L = enc_launch(plan, 0, ENC_SPAN_BWD);
+    hipLaunchKernelGGL(nt_encode_bwd_kernel<false>, dim3(L.per_model * models, 2 * lh),
+                       dim3(ENC_BLOCK), (size_t)LDS_ENTRIES * 4, (hipStream_t)stream, *plan, L, dF,
+                       1.0f / grad_scale, xy, seg_start, grad_tables);
+  }
+  if (lh < plan->n_levels) {
+    const EncLaunch L = enc_launch(plan, lh, ENC_SPAN_BWD);
+    hipLaunchKernelGGL(nt_encode_bwd_kernel<true>, dim3(L.per_model * models, 2 * (plan->n_levels - lh)),
+                       dim3(ENC_BLOCK), (size_t)max_level_size(plan, lh, plan->n_levels) * 4,
+                       (hipStream_t)stream, *plan, L, dF, 1.0f / grad_scale, xy, seg_start,
+                       grad_tables);
   }
   VSA_RETURN_LAUNCH_STATUS();
 }
