@@ -185,7 +185,8 @@ int vsa_nt_compact(const vsa_nt_plan* plan, const uint8_t* marks, int32_t* slot_
 
 /* Step 3: hash-grid encode every slot of every texture, level-major with the
  * level table in LDS.  tables_h: f16 [n_tex][level_offset[n]*2];
- * features: f16x2 [2 types][n_levels][slot_capacity]. */
+ * features: f16x2, blocked [2 types][slot_capacity/256][n_levels][256] (slot_capacity
+ * is a multiple of 256): a 32-slot MLP tile's 16 levels stay within 16 KiB. */
 int vsa_nt_encode_fwd(const vsa_nt_plan* plan, const void* tables_h, const float* slot_xy,
                       const int32_t* seg_start, void* features, void* stream);
 
@@ -194,20 +195,19 @@ int vsa_nt_encode_fwd(const vsa_nt_plan* plan, const void* tables_h, const float
  * [n_tex][VSA_NT_WEIGHTS_PER_TEX]; texels: u8 [slot_capacity][32] (quantised
  * texel rows: rgb coefficient c at byte c, alpha coefficient c at byte 24+c).
  * pre_out (optional, tests): f16 [slot_capacity][32], the network output before
- * the sigmoid, same row layout.
- * grad_rows (optional, training): f32 [slot_capacity][32]; the rows of every
- * visited slot are zeroed here so that vsa_nt_shade_bwd can accumulate into them. */
+ * the sigmoid, same row layout. */
 int vsa_nt_mlp_fwd(const vsa_nt_plan* plan, const void* weights_h, const void* features,
-                   const int32_t* seg_start, uint8_t* texels, void* pre_out, float* grad_rows,
-                   void* stream);
+                   const int32_t* seg_start, uint8_t* texels, void* pre_out, void* stream);
 
 /* Backward of step 4: recomputes the forward per 32-slot tile, back-propagates
  * grad_rows (f32, already multiplied by grad_scale) through sigmoid (round = STE)
  * and the three layers on MFMA.  Overwrites `features` IN PLACE with the feature
  * gradients (f16x2, still scaled) and accumulates grad_weights (f32
- * [n_tex][VSA_NT_WEIGHTS_PER_TEX], scaled) with one flush per wave. */
+ * [n_tex][VSA_NT_WEIGHTS_PER_TEX], scaled) with one flush per workgroup.
+ * grad_rows is CONSUMED: every row read is reset to zero, so the buffer (zero
+ * at allocation) is zero again outside a [vsa_nt_shade_bwd, vsa_nt_mlp_bwd] pair. */
 int vsa_nt_mlp_bwd(const vsa_nt_plan* plan, const void* weights_h, void* features,
-                   const int32_t* seg_start, const float* grad_rows, float* grad_weights,
+                   const int32_t* seg_start, float* grad_rows, float* grad_weights,
                    void* stream);
 
 /* Step 5: per-hit shading from the texel rows (expand LUT -> lerp -> fp16 SH
@@ -221,7 +221,7 @@ int vsa_nt_shade_fwd(const vsa_nt_plan* plan, const int32_t* hit_slot, const flo
                      float* surfs_normals, float* coeffs_out, void* stream);
 
 /* Backward of step 5: grad_rows (f32 [slot_capacity][32], same row layout as
- * texels; zeroed by the caller / by vsa_nt_mlp_fwd) += grad_scale * dL/d(q/255)
+ * texels; zero on entry, see vsa_nt_mlp_bwd) += grad_scale * dL/d(q/255)
  * (round is a straight-through estimator, utils/math.py:5-18). */
 int vsa_nt_shade_bwd(const vsa_nt_plan* plan, const int32_t* hit_slot, const float* tex_uv,
                      const float* rays_d, const float* tris, const int32_t* slot_of,

@@ -34,7 +34,8 @@ def unpack_weights(w):
 def test_mlp_fwd_matches_oracle():
     bank, face_uvs, hit_slot, hit_uv = _bank()
     bank.mark_and_compact(hit_slot, hit_uv, face_uvs)
-    feats = bank.encode()
+    bank.encode()
+    feats = bank.features_level_major()
     texels, pre = bank.mlp(want_pre=True)
     torch.cuda.synchronize()
     seg = bank.seg_start.cpu().numpy()
@@ -78,9 +79,11 @@ def test_mlp_fwd_asymmetric_weights_exact():
         bank.weights.copy_(w.cuda() * (bank.weights != 0))
     bank.refresh_half_params()
     bank.mark_and_compact(hit_slot, hit_uv, face_uvs)
-    feats = bank.encode()
+    bank.encode()
+    feats = bank.features_level_major()
     # make the features integers too (overwrite with small ints)
-    feats.copy_(torch.randint(-3, 4, feats.shape, generator=g).half())
+    bank.features.copy_(torch.randint(-3, 4, bank.features.shape, generator=g).half())
+    feats = bank.features_level_major()
     texels, pre = bank.mlp(want_pre=True)
     seg = bank.seg_start.cpu().numpy()
     for typ in range(2):

@@ -58,7 +58,8 @@ def test_mark_compact_encode_bit_exact():
     bank, face_uvs, hit_slot, hit_uv = _setup()
     K, N = hit_slot.shape
     tex_uv = bank.mark_and_compact(hit_slot.cuda(), hit_uv.cuda(), face_uvs.cuda())
-    feats = bank.encode()
+    bank.encode()
+    feats = bank.features_level_major()
     torch.cuda.synchronize()
     # --- uv (volsurfs.py:511-514)
     hit = hit_slot >= 0

@@ -9,6 +9,25 @@ typedef float float16_t __attribute__((ext_vector_type(16)));
 
 #define NT_DOM_BLOCK 4096  // texel domains are padded to this (one scan block)
 
+// Feature planes are blocked: [type][slot / 256][level][slot % 256] (f16x2 each),
+// so that the 16 levels of a 32-slot MLP tile sit within one 16 KiB block (a
+// level-major [type][level][slot] layout spreads a tile over 16 pages that are
+// ~80 MB apart and the MLP kernels become TLB-miss bound), while the encode
+// kernels still write / read 1 KiB contiguous runs per level.
+#define NT_FBLOCK 256
+__device__ __forceinline__ long long nt_feat_index(const vsa_nt_plan& p, int type, int level,
+                                                   int slot) {
+  const long long blocks = p.slot_capacity / NT_FBLOCK;
+  return (((long long)type * blocks + (slot >> 8)) * p.n_levels + level) * NT_FBLOCK + (slot & 255);
+}
+// (type, level) fixed: element offset = plane_base + (slot >> 8) * n_levels * 256 + (slot & 255)
+__device__ __forceinline__ long long nt_feat_plane_base(const vsa_nt_plan& p, int type, int level) {
+  return ((long long)type * (p.slot_capacity / NT_FBLOCK) * p.n_levels + level) * NT_FBLOCK;
+}
+__device__ __forceinline__ long long nt_feat_in_plane(int n_levels, int slot) {
+  return (long long)(slot >> 8) * (n_levels * NT_FBLOCK) + (slot & 255);
+}
+
 __host__ __device__ inline int nt_tex_index(int shell, int type, int deg) {
   return (shell * 2 + type) * VSA_NT_MAX_DEG + deg;
 }
@@ -46,3 +65,73 @@ __device__ __forceinline__ float2 nt_interp_uv(const float* __restrict__ fuv, fl
   r.y = (b0 * fuv[1] + bu * fuv[3]) + bv * fuv[5];
   return r;
 }
+
+// Per-launch constants decoded on the host: which levels, and how blockIdx.x
+// enumerates (model = shell*2+type, degree, group).  The per-degree group count
+// comes from the segment capacity min(4*max_rays, (R_d+2)^2), so that small
+// textures do not launch the worst-case number of LDS-hungry workgroups.
+struct EncLaunch {
+  int level0;
+  int span;
+  int groups[VSA_NT_MAX_DEG];
+  int per_model;
+};
+
+
+__device__ __forceinline__ bool tex_active(const vsa_nt_plan& p, int tex) {
+  const int deg = tex % VSA_NT_MAX_DEG;
+  const int type = (tex / VSA_NT_MAX_DEG) & 1;
+  const int shell = tex / (2 * VSA_NT_MAX_DEG);
+  if (type == 0) return deg < p.rgb_degrees;
+  if (p.inner_solid && shell == 0) return false;
+  return deg < p.alpha_degrees;
+}
+
+struct Work {
+  int tex, first, last;  // slots [first, last) of texture tex
+  int seg_len;           // slots in the whole (shell, degree) segment
+};
+
+__device__ __forceinline__ bool decode_work(const vsa_nt_plan& p, const EncLaunch& L,
+                                            const int* seg_start, int bx, Work& w) {
+  const int model = bx / L.per_model;  // shell*2 + type
+  int r = bx - model * L.per_model;
+  int d = 0;
+#pragma unroll
+  for (int i = 0; i < VSA_NT_MAX_DEG - 1; ++i)
+    if (d == i && r >= L.groups[i]) {
+      r -= L.groups[i];
+      d = i + 1;
+    }
+  w.tex = model * VSA_NT_MAX_DEG + d;
+  if (!tex_active(p, w.tex)) return false;
+  const int sd = (model >> 1) * VSA_NT_MAX_DEG + d;
+  const int begin = seg_start[sd], end = seg_start[sd + 1];
+  w.seg_len = end - begin;
+  // equal-sized groups: ceil(len / span) workgroups share the segment evenly
+  const int active = (w.seg_len + L.span - 1) / L.span;
+  if (r >= active) return false;
+  const int per = ((w.seg_len + active - 1) / active + 31) & ~31;   // whole 32-slot tiles
+  const long long first = begin + (long long)r * per;
+  if (first >= end) return false;
+  w.first = (int)first;
+  w.last = (int)(first + per < end ? first + per : end);
+  return true;
+}
+
+
+static inline EncLaunch enc_launch(const vsa_nt_plan* p, int level0, int span) {
+  EncLaunch L;
+  L.level0 = level0;
+  L.span = span;
+  L.per_model = 0;
+  for (int d = 0; d < VSA_NT_MAX_DEG; ++d) {
+    const long long T = (long long)(p->tex_res[d] + 2) * (p->tex_res[d] + 2);
+    long long cap = 4ll * p->max_rays < T ? 4ll * p->max_rays : T;
+    if (cap < 1) cap = 1;
+    L.groups[d] = (int)((cap + span - 1) / span);
+    L.per_model += L.groups[d];
+  }
+  return L;
+}
+

@@ -24,17 +24,6 @@ constexpr int ENC_SPAN_BWD = 262144;  // slots per workgroup before a flush (bac
 constexpr unsigned PRIME_Y = 2654435761u;
 constexpr int LDS_ENTRIES = 32768;    // 4-byte entries of LDS a workgroup may use (128 KiB)
 
-// Per-launch constants decoded on the host: which levels, and how blockIdx.x
-// enumerates (model = shell*2+type, degree, group).  The per-degree group count
-// comes from the segment capacity min(4*max_rays, (R_d+2)^2), so that small
-// textures do not launch the worst-case number of LDS-hungry workgroups.
-struct EncLaunch {
-  int level0;
-  int span;
-  int groups[VSA_NT_MAX_DEG];
-  int per_model;
-};
-
 struct LevelGeom {
   float scale;
   unsigned res, size, mask;
@@ -90,43 +79,6 @@ __device__ __forceinline__ CellCorners cell_corners(const LevelGeom& g, float x,
   return c;
 }
 
-__device__ __forceinline__ bool tex_active(const vsa_nt_plan& p, int tex) {
-  const int deg = tex % VSA_NT_MAX_DEG;
-  const int type = (tex / VSA_NT_MAX_DEG) & 1;
-  const int shell = tex / (2 * VSA_NT_MAX_DEG);
-  if (type == 0) return deg < p.rgb_degrees;
-  if (p.inner_solid && shell == 0) return false;
-  return deg < p.alpha_degrees;
-}
-
-struct Work {
-  int tex, first, last;  // slots [first, last) of texture tex
-  int seg_len;           // slots in the whole (shell, degree) segment
-};
-
-__device__ __forceinline__ bool decode_work(const vsa_nt_plan& p, const EncLaunch& L,
-                                            const int* seg_start, int bx, Work& w) {
-  const int model = bx / L.per_model;  // shell*2 + type
-  int r = bx - model * L.per_model;
-  int d = 0;
-#pragma unroll
-  for (int i = 0; i < VSA_NT_MAX_DEG - 1; ++i)
-    if (d == i && r >= L.groups[i]) {
-      r -= L.groups[i];
-      d = i + 1;
-    }
-  w.tex = model * VSA_NT_MAX_DEG + d;
-  if (!tex_active(p, w.tex)) return false;
-  const int sd = (model >> 1) * VSA_NT_MAX_DEG + d;
-  const int begin = seg_start[sd], end = seg_start[sd + 1];
-  w.seg_len = end - begin;
-  const long long first = begin + (long long)r * L.span;
-  if (first >= end) return false;
-  w.first = (int)first;
-  w.last = (int)(first + L.span < end ? first + L.span : end);
-  return true;
-}
-
 template <bool HASHED>
 __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
     vsa_nt_plan plan, EncLaunch L, const half2_t* __restrict__ tables,
@@ -148,7 +100,8 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
   }
   __syncthreads();
   const int type = (wk.tex / VSA_NT_MAX_DEG) & 1;
-  half2_t* out = features + ((long long)type * plan.n_levels + level) * plan.slot_capacity;
+  half2_t* out = features + nt_feat_plane_base(plan, type, level);
+  const int nl = plan.n_levels;
   for (int base = wk.first + threadIdx.x; base < last; base += ENC_BLOCK * ENC_UNROLL) {
     float2 xy[ENC_UNROLL];
 #pragma unroll
@@ -176,7 +129,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
       half2_t r;
       r.x = (_Float16)f0;
       r.y = (_Float16)f1;
-      if (slot < last) out[slot] = r;
+      if (slot < last) out[nt_feat_in_plane(nl, slot)] = r;
     }
   }
 }
@@ -215,11 +168,11 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
   for (int i = threadIdx.x; i < (int)g.size * copies; i += ENC_BLOCK) s_g[i] = 0;
   int* my_g = s_g + (threadIdx.x & (copies - 1)) * g.size;
   const int type = (wk.tex / VSA_NT_MAX_DEG) & 1;
-  const _Float16* dF = reinterpret_cast<const _Float16*>(
-                           dfeatures + ((long long)type * plan.n_levels + level) * plan.slot_capacity) + feat;
+  const _Float16* dF = reinterpret_cast<const _Float16*>(dfeatures + nt_feat_plane_base(plan, type, level)) + feat;
+  const int nl = plan.n_levels;
   // pass 1: sum |dF| over this workgroup's slots -> fixed-point scale
   float asum = 0.f;
-  for (int slot = first + threadIdx.x; slot < last; slot += ENC_BLOCK) asum += fabsf((float)dF[2 * (long long)slot]);
+  for (int slot = first + threadIdx.x; slot < last; slot += ENC_BLOCK) asum += fabsf((float)dF[2 * nt_feat_in_plane(nl, slot)]);
   for (int off = 32; off > 0; off >>= 1) asum += __shfl_down(asum, off, 64);
   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = asum;
   __syncthreads();
@@ -240,7 +193,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
       const int slot = base + u * ENC_BLOCK;
       const int sl = slot < last ? slot : last - 1;
       xy[u] = slot_xy[sl];
-      gv[u] = slot < last ? (float)dF[2 * (long long)sl] * S : 0.f;
+      gv[u] = slot < last ? (float)dF[2 * nt_feat_in_plane(nl, sl)] * S : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < ENC_UNROLL; ++u) {
@@ -269,21 +222,6 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
 }
 
 }  // namespace
-
-static EncLaunch enc_launch(const vsa_nt_plan* p, int level0, int span) {
-  EncLaunch L;
-  L.level0 = level0;
-  L.span = span;
-  L.per_model = 0;
-  for (int d = 0; d < VSA_NT_MAX_DEG; ++d) {
-    const long long T = (long long)(p->tex_res[d] + 2) * (p->tex_res[d] + 2);
-    long long cap = 4ll * p->max_rays < T ? 4ll * p->max_rays : T;
-    if (cap < 1) cap = 1;
-    L.groups[d] = (int)((cap + span - 1) / span);
-    L.per_model += L.groups[d];
-  }
-  return L;
-}
 
 static bool level_hashed(const vsa_nt_plan* p, int l) {
   const long long res = p->level_res[l], size = p->level_size[l];

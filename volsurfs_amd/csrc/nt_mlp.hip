@@ -79,10 +79,11 @@ __device__ __forceinline__ TexInfo tex_info(const vsa_nt_plan& p, const int* seg
 
 // Forward network on one 32-point tile.  Returns acc3 (rows = output channels)
 // and, when KEEP, the two hidden accumulators (pre-ReLU) for the backward pass.
-template <bool KEEP>
+// b2 / b3: the ReLU'd hidden activations as f16 B fragments (k-step q, element j
+// <-> accumulator register 8(q&1)+j of tile q>>1); the backward pass keeps these
+// instead of the fp32 accumulators (ReLU mask = value > 0).
 __device__ __forceinline__ void mlp_tile_fwd(const half8_t* s_frag, const half8_t bx[2],
-                                             float16_t acc1[2], float16_t acc2[2],
-                                             float16_t& acc3) {
+                                             half8_t b2[4], half8_t b3[4], float16_t& acc3) {
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
@@ -90,22 +91,18 @@ __device__ __forceinline__ void mlp_tile_fwd(const half8_t* s_frag, const half8_
 #pragma unroll
     for (int s = 0; s < 2; ++s)
       a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_frag[(m * 2 + s) * 64 + lane], bx[s], a, 0, 0, 0);
-    acc1[m] = a;
+    b2[2 * m] = relu_pack(a, 0);
+    b2[2 * m + 1] = relu_pack(a, 1);
   }
-  half8_t b2[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) b2[q] = relu_pack(acc1[q >> 1], q & 1);
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
     float16_t a = {0};
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_frag[(4 + m * 4 + q) * 64 + lane], b2[q], a, 0, 0, 0);
-    acc2[m] = a;
+    b3[2 * m] = relu_pack(a, 0);
+    b3[2 * m + 1] = relu_pack(a, 1);
   }
-  half8_t b3[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) b3[q] = relu_pack(acc2[q >> 1], q & 1);
   float16_t a = {0};
 #pragma unroll
   for (int q = 0; q < 4; ++q)
@@ -113,46 +110,61 @@ __device__ __forceinline__ void mlp_tile_fwd(const half8_t* s_frag, const half8_
   acc3 = a;
 }
 
-__device__ __forceinline__ void load_features(const unsigned* __restrict__ F, long long cap,
-                                              int type, int n_levels, int slot, int h,
+__device__ __forceinline__ void load_features(const unsigned* __restrict__ F,
+                                              const vsa_nt_plan& plan, int type, int slot, int h,
                                               half8_t bx[2]) {
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     unsigned w[4];
+    const unsigned* base = F + nt_feat_plane_base(plan, type, 8 * s + 4 * h) +
+                           nt_feat_in_plane(plan.n_levels, slot);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      w[i] = F[((long long)type * n_levels + (8 * s + 4 * h + i)) * cap + slot];
+    for (int i = 0; i < 4; ++i) w[i] = base[i * NT_FBLOCK];
     uint4 u = make_uint4(w[0], w[1], w[2], w[3]);
     bx[s] = __builtin_bit_cast(half8_t, u);
   }
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// sigmoid with the hardware exp2 / rcp (1 ulp each): the result is quantised to 8
+// bits (forward) or multiplies a gradient (backward), so exact division buys nothing
+__device__ __forceinline__ float sigmoidf_(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+
+constexpr int MLP_FWD_SPAN = MLP_WAVES * 16 * 32;   // slots per workgroup: 16 tiles per wave
 
 __global__ __launch_bounds__(MLP_BLOCK) void nt_mlp_fwd_kernel(
-    vsa_nt_plan plan, const _Float16* __restrict__ weights, const unsigned* __restrict__ features,
-    const int* __restrict__ seg_start, unsigned* __restrict__ texels, _Float16* __restrict__ pre_out,
-    float* __restrict__ grad_rows) {
+    vsa_nt_plan plan, EncLaunch L, const _Float16* __restrict__ weights,
+    const unsigned* __restrict__ features, const int* __restrict__ seg_start,
+    unsigned* __restrict__ texels, _Float16* __restrict__ pre_out) {
   __shared__ half8_t s_frag[16 * 64];
-  const int tex = blockIdx.y;
+  Work wk;
+  if (!decode_work(plan, L, seg_start, blockIdx.x, wk)) return;
+  const int tex = wk.tex;
   const TexInfo ti = tex_info(plan, seg_start, tex);
-  if (ti.channels == 0 || ti.begin >= ti.end) return;
-  const int ntiles = (ti.end - ti.begin + 31) >> 5;
-  if ((int)blockIdx.x * MLP_WAVES >= ntiles) return;
   stage_weights_fwd(weights + (long long)tex * VSA_NT_WEIGHTS_PER_TEX, s_frag);
   __syncthreads();
   const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
-  const int wave = blockIdx.x * MLP_WAVES + (threadIdx.x >> 6);
-  const int nwaves = gridDim.x * MLP_WAVES;
+  const int wave = threadIdx.x >> 6;
   const int dword_base = ti.type == 0 ? 0 : 6;   // rgb bytes 0..23, alpha bytes 24..31
-  for (int tile = wave; tile < ntiles; tile += nwaves) {
-    const int slot = ti.begin + tile * 32 + p;
-    const bool valid = slot < ti.end;
-    const int sl = valid ? slot : ti.end - 1;
-    half8_t bx[2];
-    load_features(features, plan.slot_capacity, ti.type, plan.n_levels, sl, h, bx);
-    float16_t acc1[2], acc2[2], acc3;
-    mlp_tile_fwd<false>(s_frag, bx, acc1, acc2, acc3);
+  const int ntiles = (wk.last - wk.first + 31) >> 5;
+  half8_t bx[2], bx_next[2];
+  if (wave < ntiles) {
+    const int s0 = wk.first + wave * 32 + p;
+    load_features(features, plan, ti.type, s0 < wk.last ? s0 : wk.last - 1, h, bx_next);
+  }
+  for (int tile = wave; tile < ntiles; tile += MLP_WAVES) {
+    const int slot = wk.first + tile * 32 + p;
+    const bool valid = slot < wk.last;
+    bx[0] = bx_next[0];
+    bx[1] = bx_next[1];
+    if (tile + MLP_WAVES < ntiles) {   // prefetch the next tile's features
+      const int sn = slot + MLP_WAVES * 32;
+      load_features(features, plan, ti.type, sn < wk.last ? sn : wk.last - 1, h, bx_next);
+    }
+    half8_t b2[4], b3[4];
+    float16_t acc3;
+    mlp_tile_fwd(s_frag, bx, b2, b3, acc3);
     if (!valid) continue;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -169,58 +181,88 @@ __global__ __launch_bounds__(MLP_BLOCK) void nt_mlp_fwd_kernel(
         packed |= qb << (8 * i);
       }
       texels[(long long)slot * 8 + dword_base + (row0 >> 2)] = packed;
-      if (grad_rows)
-        *reinterpret_cast<float4*>(grad_rows + (long long)slot * 32 + 4 * (dword_base + (row0 >> 2))) =
-            make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
 }
-
 
 // ------------------------------------------------------------------ backward
 // Fragment ids 16..31: the transposed weights for the data-gradient chain
 //   16..19 T3[m][s]  elem j = W3[perm_k(s,h,j)][32m + r]
 //   20..27 T2[m][q]  elem j = W2[perm_k(q,h,j)][32m + r]
 //   28..31 T1[q]     elem j = W1[perm_k(q,h,j)][r]
+constexpr int BWD_BLOCK = 256;                 // 4 waves, one per SIMD (the whole 512-register file each)
+constexpr int BWD_WAVES = BWD_BLOCK / 64;
+constexpr int BWD_TPW = 32;                    // tiles per wave
+constexpr int MLP_BWD_SPAN = BWD_WAVES * BWD_TPW * 32;
+
 __device__ void stage_weights_bwd(const _Float16* __restrict__ W, half8_t* s_frag) {
-  for (int idx = threadIdx.x; idx < 16 * 64; idx += MLP_BLOCK) {
+  for (int idx = threadIdx.x; idx < 16 * 64; idx += BWD_BLOCK) {
     const int frag = idx >> 6, lane = idx & 63, r = lane & 31, h = lane >> 5;
-    half8_t v;
+    half8_t v, f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      _Float16 x;
+      _Float16 x, y;
       if (frag < 4) {
         const int m = frag >> 1, s = frag & 1;
         x = W[W3_OFF + perm_k(s, h, j) * 64 + 32 * m + r];
+        y = W[W1_OFF + (32 * m + r) * 32 + 16 * s + 8 * h + j];
       } else if (frag < 12) {
-        const int f = frag - 4, m = f >> 2, q = f & 3;
+        const int f_ = frag - 4, m = f_ >> 2, q = f_ & 3;
         x = W[W2_OFF + perm_k(q, h, j) * 64 + 32 * m + r];
+        y = W[W2_OFF + (32 * m + r) * 64 + perm_k(q, h, j)];
       } else {
         x = W[W1_OFF + perm_k(frag - 12, h, j) * 32 + r];
+        y = W[W3_OFF + r * 64 + perm_k(frag - 12, h, j)];
       }
       v[j] = x;
+      f[j] = y;
     }
-    s_frag[16 * 64 + idx] = v;
+    s_frag[idx] = f;             // forward fragments (same ids as stage_weights_fwd)
+    s_frag[16 * 64 + idx] = v;   // transposed fragments
   }
 }
 
-constexpr int IMG_STRIDE = 40;                 // halfs per image row (32 points + 16-B pad)
-constexpr int IMG_ROWS = 320;                  // dOut 32 | H2 64 | dH2 64 | H1 64 | dH1 64 | X 32
-constexpr int ROW_DOUT = 0, ROW_H2 = 32, ROW_DH2 = 96, ROW_H1 = 160, ROW_DH1 = 224, ROW_X = 288;
+// Per-wave LDS scratch for the weight-gradient products, POINT-major:
+// img[point][channel] f16, written with 8-byte stores straight from the MFMA
+// accumulator layout (lane = point, 4 consecutive rows per register group) and
+// read back TRANSPOSED with ds_read_b64_tr_b16 as [channel][8 consecutive
+// points] = the A/B fragment of an MFMA that contracts over the tile's points.
+constexpr int IMG_STRIDE = 72;                 // halfs per point row (64 channels + 16 B pad)
+constexpr int IMG_HALFS = 32 * IMG_STRIDE;     // one region: 32 points x 64 channels
 
-template <bool RELU>
-__device__ __forceinline__ void store_image(_Float16* img, int row_base, const float16_t& acc,
-                                            int p, int h) {
+typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
+
+// Writes one 32-channel tile held as two f16 fragments (frag[s][j] <-> accumulator
+// register 8s+j, i.e. row (j&3) + 8(2s + (j>>2)) + 4h) to img[point][col_base + row].
+__device__ __forceinline__ void store_frags(_Float16* img, int col_base, const half8_t& f0,
+                                            const half8_t& f1, int p, int h) {
+  _Float16* row = img + p * IMG_STRIDE + col_base + 4 * h;
+  *reinterpret_cast<half4_t*>(row + 0) = __builtin_shufflevector(f0, f0, 0, 1, 2, 3);
+  *reinterpret_cast<half4_t*>(row + 8) = __builtin_shufflevector(f0, f0, 4, 5, 6, 7);
+  *reinterpret_cast<half4_t*>(row + 16) = __builtin_shufflevector(f1, f1, 0, 1, 2, 3);
+  *reinterpret_cast<half4_t*>(row + 24) = __builtin_shufflevector(f1, f1, 4, 5, 6, 7);
+}
+
+// accumulator -> two f16 fragments, zeroed where the forward activation was <= 0
+__device__ __forceinline__ void mask_pack(const float16_t& acc, const half8_t& act0,
+                                          const half8_t& act1, half8_t& o0, half8_t& o1) {
 #pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-    const float v = RELU ? fmaxf(acc[reg], 0.0f) : acc[reg];
-    img[(row_base + row) * IMG_STRIDE + p] = (_Float16)v;
+  for (int j = 0; j < 8; ++j) {
+    o0[j] = act0[j] > (_Float16)0 ? (_Float16)acc[j] : (_Float16)0;
+    o1[j] = act1[j] > (_Float16)0 ? (_Float16)acc[8 + j] : (_Float16)0;
   }
 }
 
-__device__ __forceinline__ half8_t read_frag(const _Float16* img, int row, int s, int h) {
-  return *reinterpret_cast<const half8_t*>(img + row * IMG_STRIDE + 16 * s + 8 * h);
+// fragment (A or B operand) for channels col_base + (lane & 31), points 16s + 8h + 0..7
+__device__ __forceinline__ half8_t read_tr(const _Float16* img, int col_base, int s, int lane) {
+  const int h = lane >> 5, li = lane & 15, q = li >> 2, pp = li & 3, grp = (lane >> 4) & 1;
+  const _Float16* a0 = img + (16 * s + 8 * h + q) * IMG_STRIDE + col_base + 16 * grp + 4 * pp;
+  typedef __attribute__((address_space(3))) short4v* lds_p;
+  const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0));
+  const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0 + 4 * IMG_STRIDE));
+  typedef short short8v __attribute__((__vector_size__(8 * sizeof(short))));
+  const short8v both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(half8_t, both);
 }
 
 __device__ __forceinline__ half8_t pack8(const float16_t& acc, int s) {
@@ -230,28 +272,32 @@ __device__ __forceinline__ half8_t pack8(const float16_t& acc, int s) {
   return b;
 }
 
-__global__ __launch_bounds__(MLP_BLOCK, 1) void nt_mlp_bwd_kernel(
-    vsa_nt_plan plan, const _Float16* __restrict__ weights, unsigned* __restrict__ features,
-    const int* __restrict__ seg_start, const float* __restrict__ grad_rows,
-    float* __restrict__ grad_weights) {
+__device__ __forceinline__ void prefetch_features(const vsa_nt_plan& plan,
+                                                  const unsigned* features, int type, int slot,
+                                                  int last, int h, half8_t bx[2]) {
+  load_features(features, plan, type, slot < last ? slot : last - 1, h, bx);
+}
+
+__global__ __launch_bounds__(BWD_BLOCK, 1) void nt_mlp_bwd_kernel(
+    vsa_nt_plan plan, EncLaunch L, const _Float16* __restrict__ weights,
+    unsigned* __restrict__ features, const int* __restrict__ seg_start,
+    float* __restrict__ grad_rows, float* __restrict__ grad_weights) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   half8_t* s_frag = reinterpret_cast<half8_t*>(s_raw);                       // 32 KiB
-  _Float16* s_img_all = reinterpret_cast<_Float16*>(s_raw + 32 * 64 * 16);   // 4 x 25.6 KB
-  const int tex = blockIdx.y;
+  _Float16* s_img_all = reinterpret_cast<_Float16*>(s_raw + 32 * 64 * 16);   // 8 x 2 regions
+  Work wk;
+  if (!decode_work(plan, L, seg_start, blockIdx.x, wk)) return;
+  const int tex = wk.tex;
   const TexInfo ti = tex_info(plan, seg_start, tex);
-  if (ti.channels == 0 || ti.begin >= ti.end) return;
-  const int ntiles = (ti.end - ti.begin + 31) >> 5;
-  if ((int)blockIdx.x * MLP_WAVES >= ntiles) return;
-  const _Float16* W = weights + (long long)tex * VSA_NT_WEIGHTS_PER_TEX;
-  stage_weights_fwd(W, s_frag);
-  stage_weights_bwd(W, s_frag);
+  stage_weights_bwd(weights + (long long)tex * VSA_NT_WEIGHTS_PER_TEX, s_frag);
   __syncthreads();
   const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
-  const int wave_in_wg = threadIdx.x >> 6;
-  _Float16* img = s_img_all + wave_in_wg * IMG_ROWS * IMG_STRIDE;
-  const int wave = blockIdx.x * MLP_WAVES + wave_in_wg;
-  const int nwaves = gridDim.x * MLP_WAVES;
+  const int wave = threadIdx.x >> 6;
+  _Float16* imgA = s_img_all + wave * 2 * IMG_HALFS;
+  _Float16* imgB = imgA + IMG_HALFS;
   const int float_base = ti.type == 0 ? 0 : 24;
+  const int ntiles = (wk.last - wk.first + 31) >> 5;
+  const int t0 = wave * BWD_TPW, t1 = min(ntiles, t0 + BWD_TPW);
 
   float16_t gW3[2], gW2[2][2], gW1[2];
 #pragma unroll
@@ -262,175 +308,194 @@ __global__ __launch_bounds__(MLP_BLOCK, 1) void nt_mlp_bwd_kernel(
     gW2[i][1] = float16_t{0};
   }
 
-  for (int tile = wave; tile < ntiles; tile += nwaves) {
-    const int slot = ti.begin + tile * 32 + p;
-    const bool valid = slot < ti.end;
-    const int sl = valid ? slot : ti.end - 1;
-    half8_t bx[2];
-    load_features(features, plan.slot_capacity, ti.type, plan.n_levels, sl, h, bx);
-    float16_t acc1[2], acc2[2], acc3;
-    mlp_tile_fwd<true>(s_frag, bx, acc1, acc2, acc3);
-
-    // dL/d(pre-sigmoid output): G * sig * (1 - sig)   (round = STE, x255 /255 cancel)
-    float16_t d3;
+  half8_t bx[2], bx_next[2];
+  if (t0 < t1) prefetch_features(plan, features, ti.type, wk.first + t0 * 32 + p, wk.last, h, bx_next);
+  for (int tile = t0; tile < t1; ++tile) {
+    const int slot = wk.first + tile * 32 + p;
+    const bool valid = slot < wk.last;
+    bx[0] = bx_next[0];
+    bx[1] = bx_next[1];
+    // this tile's gradient rows: consume-and-clear (zero again for the next frame)
+    float4 gr[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int row0 = 8 * g + 4 * h;
-      float4 gr = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (valid && row0 < ti.channels)
-        gr = *reinterpret_cast<const float4*>(grad_rows + (long long)slot * 32 + float_base + row0);
-      const float gv[4] = {gr.x, gr.y, gr.z, gr.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float sg = sigmoidf_((float)(_Float16)acc3[4 * g + i]);
-        d3[4 * g + i] = row0 + i < ti.channels ? gv[i] * sg * (1.0f - sg) : 0.0f;
+      gr[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (valid && row0 < ti.channels) {
+        float4* gp = reinterpret_cast<float4*>(grad_rows + (long long)slot * 32 + float_base + row0);
+        gr[g] = *gp;
+        *gp = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
-    // images for the weight-gradient products (points along k)
-    store_image<false>(img, ROW_DOUT, d3, p, h);
-    store_image<true>(img, ROW_H2, acc2[0], p, h);
-    store_image<true>(img, ROW_H2 + 32, acc2[1], p, h);
-    store_image<true>(img, ROW_H1, acc1[0], p, h);
-    store_image<true>(img, ROW_H1 + 32, acc1[1], p, h);
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) img[(ROW_X + 16 * s + 8 * h + j) * IMG_STRIDE + p] = bx[s][j];
+    if (tile + 1 < t1) prefetch_features(plan, features, ti.type, slot + 32, wk.last, h, bx_next);
 
-    // data gradients: dH2 = W3^T dOut ; dH1 = W2^T dH2 ; dX = W1^T dH1
-    float16_t dh2[2], dh1[2], dx;
+    half8_t b2[4], b3[4];   // H1, H2 (f16, ReLU'd)
+    half8_t d3h[2];
     {
-      half8_t b[2] = {pack8(d3, 0), pack8(d3, 1)};
+      float16_t acc3;
+      mlp_tile_fwd(s_frag, bx, b2, b3, acc3);
+      // dL/d(pre-sigmoid output): G * sig * (1 - sig)   (round = STE, x255 /255 cancel);
+      // G is zero for padding rows and invalid slots
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        float16_t a = {0};
+      for (int g = 0; g < 4; ++g) {
+        const float gv[4] = {gr[g].x, gr[g].y, gr[g].z, gr[g].w};
+        if (8 * g < ti.channels) {   // wave-uniform: skip the sigmoids of all-padding row groups
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-          a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_frag[(16 + m * 2 + s) * 64 + lane], b[s], a, 0, 0, 0);
+          for (int i = 0; i < 4; ++i) {
+            const float sg = sigmoidf_((float)(_Float16)acc3[4 * g + i]);
+            d3h[g >> 1][4 * (g & 1) + i] = (_Float16)(gv[i] * sg * (1.0f - sg));
+          }
+        } else {
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) a[reg] = acc2[m][reg] > 0.0f ? a[reg] : 0.0f;
-        dh2[m] = a;
+          for (int i = 0; i < 4; ++i) d3h[g >> 1][4 * (g & 1) + i] = (_Float16)0;
+        }
       }
     }
-    store_image<false>(img, ROW_DH2, dh2[0], p, h);
-    store_image<false>(img, ROW_DH2 + 32, dh2[1], p, h);
-    {
-      half8_t b[4] = {pack8(dh2[0], 0), pack8(dh2[0], 1), pack8(dh2[1], 0), pack8(dh2[1], 1)};
+    // ---- dW3 += dOut . H2^T
+    store_frags(imgA, 0, b3[0], b3[1], p, h);
+    store_frags(imgA, 32, b3[2], b3[3], p, h);
+    store_frags(imgB, 0, d3h[0], d3h[1], p, h);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const half8_t a3 = read_tr(imgB, 0, s, lane);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        gW3[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3, read_tr(imgA, 32 * m, s, lane), gW3[m], 0, 0, 0);
+    }
+    // ---- dH2 = W3^T dOut, masked by ReLU
+    half8_t dh2[4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float16_t a = {0};
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_frag[(16 + m * 2 + s) * 64 + lane], d3h[s], a, 0, 0, 0);
+      mask_pack(a, b3[2 * m], b3[2 * m + 1], dh2[2 * m], dh2[2 * m + 1]);
+    }
+    // ---- dW2 += dH2 . H1^T
+    store_frags(imgB, 0, dh2[0], dh2[1], p, h);
+    store_frags(imgB, 32, dh2[2], dh2[3], p, h);
+    store_frags(imgA, 0, b2[0], b2[1], p, h);
+    store_frags(imgA, 32, b2[2], b2[3], p, h);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const half8_t b1[2] = {read_tr(imgA, 0, s, lane), read_tr(imgA, 32, s, lane)};
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        float16_t a = {0};
+        const half8_t a2 = read_tr(imgB, 32 * m, s, lane);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_frag[(20 + m * 4 + q) * 64 + lane], b[q], a, 0, 0, 0);
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) a[reg] = acc1[m][reg] > 0.0f ? a[reg] : 0.0f;
-        dh1[m] = a;
+        for (int mj = 0; mj < 2; ++mj)
+          gW2[m][mj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b1[mj], gW2[m][mj], 0, 0, 0);
       }
     }
-    store_image<false>(img, ROW_DH1, dh1[0], p, h);
-    store_image<false>(img, ROW_DH1 + 32, dh1[1], p, h);
-    {
-      half8_t b[4] = {pack8(dh1[0], 0), pack8(dh1[0], 1), pack8(dh1[1], 0), pack8(dh1[1], 1)};
+    // ---- dH1 = W2^T dH2, masked by ReLU
+    half8_t dh1[4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
       float16_t a = {0};
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_frag[(28 + q) * 64 + lane], b[q], a, 0, 0, 0);
-      dx = a;
+        a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_frag[(20 + m * 4 + q) * 64 + lane], dh2[q], a, 0, 0, 0);
+      mask_pack(a, b2[2 * m], b2[2 * m + 1], dh1[2 * m], dh1[2 * m + 1]);
     }
-    // dF (in place over the features): rows = feature index, pairs -> one level
-    if (valid) {
+    // ---- dW1 += dH1 . X^T
+    store_frags(imgB, 0, dh1[0], dh1[1], p, h);
+    store_frags(imgB, 32, dh1[2], dh1[3], p, h);
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int level = 4 * g + 2 * h + i;
-          half2_t v;
-          v.x = (_Float16)dx[4 * g + 2 * i];
-          v.y = (_Float16)dx[4 * g + 2 * i + 1];
-          features[((long long)ti.type * plan.n_levels + level) * plan.slot_capacity + slot] =
-              __builtin_bit_cast(unsigned, v);
-        }
-    }
-    // weight gradients: sum over the tile's 32 points (2 k-steps of 16)
+    for (int s = 0; s < 2; ++s)
+      *reinterpret_cast<half8_t*>(imgA + p * IMG_STRIDE + 16 * s + 8 * h) = bx[s];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const half8_t a3 = read_frag(img, ROW_DOUT + p, s, h);
-      const half8_t a2[2] = {read_frag(img, ROW_DH2 + p, s, h), read_frag(img, ROW_DH2 + 32 + p, s, h)};
-      const half8_t a1[2] = {read_frag(img, ROW_DH1 + p, s, h), read_frag(img, ROW_DH1 + 32 + p, s, h)};
-      const half8_t bh2[2] = {read_frag(img, ROW_H2 + p, s, h), read_frag(img, ROW_H2 + 32 + p, s, h)};
-      const half8_t bh1[2] = {read_frag(img, ROW_H1 + p, s, h), read_frag(img, ROW_H1 + 32 + p, s, h)};
-      const half8_t bxx = read_frag(img, ROW_X + p, s, h);
+      const half8_t bxx = read_tr(imgA, 0, s, lane);
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        gW3[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3, bh2[m], gW3[m], 0, 0, 0);
-        gW1[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[m], bxx, gW1[m], 0, 0, 0);
+      for (int m = 0; m < 2; ++m)
+        gW1[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(read_tr(imgB, 32 * m, s, lane), bxx, gW1[m], 0, 0, 0);
+    }
+    // ---- dX = W1^T dH1 -> dF, in place over the features
+    {
+      float16_t dx = {0};
 #pragma unroll
-        for (int mj = 0; mj < 2; ++mj)
-          gW2[m][mj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[m], bh1[mj], gW2[m][mj], 0, 0, 0);
+      for (int q = 0; q < 4; ++q)
+        dx = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_frag[(28 + q) * 64 + lane], dh1[q], dx, 0, 0, 0);
+      if (valid) {
+        unsigned* base = features + nt_feat_plane_base(plan, ti.type, 2 * h) +
+                         nt_feat_in_plane(plan.n_levels, slot);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            half2_t v;
+            v.x = (_Float16)dx[4 * g + 2 * i];
+            v.y = (_Float16)dx[4 * g + 2 * i + 1];
+            base[(4 * g + i) * NT_FBLOCK] = __builtin_bit_cast(unsigned, v);
+          }
       }
     }
   }
 
-  // flush: accumulator (row = (reg&3)+8(reg>>2)+4h, col = p) -> grad_weights
-  float* gw = grad_weights + (long long)tex * VSA_NT_WEIGHTS_PER_TEX;
+  // ---- workgroup reduction of the weight gradients in LDS (waves take turns:
+  // LDS float atomics are slow on gfx950), then one global atomic per weight.
+  __syncthreads();
+  float* s_acc = reinterpret_cast<float*>(s_img_all);   // 8192 floats, aliases the images
+  for (int w = 0; w < BWD_WAVES; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      if (row < ti.channels) atomicAdd(&gw[W3_OFF + row * 64 + 32 * m + p], gW3[m][reg]);
-      atomicAdd(&gw[W1_OFF + (32 * m + row) * 32 + p], gW1[m][reg]);
+        for (int m = 0; m < 2; ++m) {
+          const int i3 = W3_OFF + row * 64 + 32 * m + p;
+          const int i1 = W1_OFF + (32 * m + row) * 32 + p;
+          s_acc[i3] = (w ? s_acc[i3] : 0.0f) + gW3[m][reg];
+          s_acc[i1] = (w ? s_acc[i1] : 0.0f) + gW1[m][reg];
 #pragma unroll
-      for (int mj = 0; mj < 2; ++mj)
-        atomicAdd(&gw[W2_OFF + (32 * m + row) * 64 + 32 * mj + p], gW2[m][mj][reg]);
+          for (int mj = 0; mj < 2; ++mj) {
+            const int i2 = W2_OFF + (32 * m + row) * 64 + 32 * mj + p;
+            s_acc[i2] = (w ? s_acc[i2] : 0.0f) + gW2[m][mj][reg];
+          }
+        }
+      }
     }
+    __syncthreads();
+  }
+  float* gw = grad_weights + (long long)tex * VSA_NT_WEIGHTS_PER_TEX;
+  const int w3_end = W3_OFF + ti.channels * 64;
+  for (int i = threadIdx.x; i < w3_end; i += BWD_BLOCK) {
+    const float v = s_acc[i];
+    if (v != 0.0f) atomicAdd(&gw[i], v);
   }
 }
 
 }  // namespace
 
-static int mlp_grid_x(const vsa_nt_plan* p) {
-  long long worst = 0;
-  for (int i = 0; i < p->nr_shells * VSA_NT_MAX_DEG; ++i) {
-    long long d = p->dom_off[i + 1] - p->dom_off[i];
-    worst = worst > d ? worst : d;
-  }
-  if (worst > p->slot_capacity) worst = p->slot_capacity;
-  long long tiles = (worst + 31) / 32;
-  long long wg = (tiles + MLP_WAVES - 1) / MLP_WAVES;
-  if (wg > 64) wg = 64;   // 256 waves per texture at most; tiles are strided over them
-  return wg < 1 ? 1 : (int)wg;
-}
-
 extern "C" int vsa_nt_mlp_fwd(const vsa_nt_plan* plan, const void* weights_h, const void* features,
                               const int32_t* seg_start, uint8_t* texels, void* pre_out,
-                              float* grad_rows, void* stream) {
+                              void* stream) {
   if (!plan || !weights_h || !features || !seg_start || !texels) return VSA_ERR_ARG;
-  dim3 grid(mlp_grid_x(plan), plan->nr_shells * 2 * VSA_NT_MAX_DEG);
-  hipLaunchKernelGGL(nt_mlp_fwd_kernel, grid, dim3(MLP_BLOCK), 0, (hipStream_t)stream, *plan,
+  const EncLaunch L = enc_launch(plan, 0, MLP_FWD_SPAN);
+  dim3 grid(L.per_model * plan->nr_shells * 2);
+  hipLaunchKernelGGL(nt_mlp_fwd_kernel, grid, dim3(MLP_BLOCK), 0, (hipStream_t)stream, *plan, L,
                      reinterpret_cast<const _Float16*>(weights_h),
                      reinterpret_cast<const unsigned*>(features), seg_start,
-                     reinterpret_cast<unsigned*>(texels), reinterpret_cast<_Float16*>(pre_out),
-                     grad_rows);
+                     reinterpret_cast<unsigned*>(texels), reinterpret_cast<_Float16*>(pre_out));
   VSA_RETURN_LAUNCH_STATUS();
 }
 
 extern "C" int vsa_nt_mlp_bwd(const vsa_nt_plan* plan, const void* weights_h, void* features,
-                              const int32_t* seg_start, const float* grad_rows,
-                              float* grad_weights, void* stream) {
+                              const int32_t* seg_start, float* grad_rows, float* grad_weights,
+                              void* stream) {
   if (!plan || !weights_h || !features || !seg_start || !grad_rows || !grad_weights)
     return VSA_ERR_ARG;
-  const size_t lds = 32 * 64 * 16 + (size_t)MLP_WAVES * IMG_ROWS * IMG_STRIDE * 2;
+  const size_t lds = 32 * 64 * 16 + (size_t)BWD_WAVES * 2 * IMG_HALFS * 2;
   static bool attr_set = false;
   if (!attr_set) {
     VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(nt_mlp_bwd_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
     attr_set = true;
   }
-  int gx = mlp_grid_x(plan);
-  if (gx > 16) gx = 16;  // fewer, longer-lived waves: one weight-gradient flush per wave
-  dim3 grid(gx, plan->nr_shells * 2 * VSA_NT_MAX_DEG);
-  hipLaunchKernelGGL(nt_mlp_bwd_kernel, grid, dim3(MLP_BLOCK), lds, (hipStream_t)stream, *plan,
+  const EncLaunch L = enc_launch(plan, 0, MLP_BWD_SPAN);
+  dim3 grid(L.per_model * plan->nr_shells * 2);
+  hipLaunchKernelGGL(nt_mlp_bwd_kernel, grid, dim3(BWD_BLOCK), lds, (hipStream_t)stream, *plan, L,
                      reinterpret_cast<const _Float16*>(weights_h),
                      reinterpret_cast<unsigned*>(features), seg_start, grad_rows, grad_weights);
   VSA_RETURN_LAUNCH_STATUS();

@@ -91,7 +91,7 @@ class NeuralTextureBank(torch.nn.Module):
         p.dom_off[K * MAX_DEG] = off
         for i in range(K * MAX_DEG + 1, MAX_SHELLS * MAX_DEG + 1):
             p.dom_off[i] = off
-        cap = (cap + 63) // 64 * 64 + 64
+        cap = (cap + 255) // 256 * 256 + 256      # feature planes are blocked by 256 slots
         p.slot_capacity = cap
         p.max_rays = max_rays
         self.plan, self.dom_total, self.slot_capacity = p, off, cap
@@ -140,7 +140,8 @@ class NeuralTextureBank(torch.nn.Module):
         self.slot_xy = torch.zeros(cap, 2, device=dev)
         self.seg_start = torch.zeros(K * MAX_DEG + 1, dtype=i32, device=dev)
         self.block_scratch = torch.zeros(self.dom_total // DOM_BLOCK + 1, dtype=i32, device=dev)
-        self.features = torch.empty(2, 16, cap, 2, dtype=torch.float16, device=dev)
+        # blocked layout [type][slot/256][level][slot%256][2]  (nt_common.h: nt_feat_index)
+        self.features = torch.empty(2, cap // 256, 16, 256, 2, dtype=torch.float16, device=dev)
         self.tables_h = torch.empty(self.n_tex, self.n_entries, 2, dtype=torch.float16, device=dev)
         self.weights_h = torch.empty(self.n_tex, WEIGHTS_PER_TEX, dtype=torch.float16, device=dev)
         self.texels = torch.zeros(cap, 32, dtype=u8, device=dev)
@@ -173,12 +174,17 @@ class NeuralTextureBank(torch.nn.Module):
                   self.seg_start, self.features, _lib.stream_ptr())
         return self.features
 
+    def features_level_major(self):
+        """[type, level, slot, 2] view-copy of the blocked feature planes (tests)."""
+        f = self.features.permute(0, 2, 1, 3, 4)            # [type, level, block, 256, 2]
+        return f.reshape(2, 16, self.slot_capacity, 2)
+
     def mlp(self, want_pre=False):
         pre = None
         if want_pre:
             pre = torch.zeros(self.slot_capacity, 32, dtype=torch.float16, device=self.texels.device)
         _lib.call("vsa_nt_mlp_fwd", ctypes.byref(self.plan), self.weights_h, self.features,
-                  self.seg_start, self.texels, pre, self.grad_rows, _lib.stream_ptr())
+                  self.seg_start, self.texels, pre, _lib.stream_ptr())
         return (self.texels, pre) if want_pre else self.texels
 
     def shade(self, hit_slot, tex_uv, rays_d, tris, want_coeffs=False, want_normals=False):
