@@ -1,0 +1,138 @@
+"""VolSurfs — host-side mirror of the reference's K-shell method for the hot path
+(SURVEY §8a row H): same entry points, argument meaning and output dict as
+/root/reference/volsurfs_py/methods/volsurfs.py (render_rays :423-761, forward
+:763-816) and base_method.py (render :366-541, chunking :407-418; optimiser
+:60-94), implemented on the HIP kernels of libvolsurfs_hip.so.  No CPU fallback.
+"""
+import torch
+
+from . import _lib
+from .composite import composite_dense
+from .neural_textures import NeuralTextureBank
+from .raytrace import RayTracer
+
+
+class _ShadeStage(torch.autograd.Function):
+    """tables, weights -> surfs_rgb [N,K,3], surfs_alpha [N,K] for the traced hits
+    (volsurfs.py:492-599), differentiable w.r.t. every texture's parameters."""
+
+    @staticmethod
+    def forward(ctx, tables, weights, method, hit_slot, hit_uv, rays_d):
+        bank = method.bank
+        tex_uv = bank.mark_and_compact(hit_slot, hit_uv, method.face_uvs)
+        bank.encode()
+        bank.mlp()
+        rgb, alpha, normals, _ = bank.shade(hit_slot, tex_uv, rays_d, method.raytracer.tris,
+                                            want_normals=True)
+        ctx.method, ctx.saved = method, (hit_slot, tex_uv, rays_d)
+        ctx.mark_non_differentiable(normals, tex_uv)
+        return rgb, alpha, normals, tex_uv
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_alpha, *unused):
+        method = ctx.method
+        bank = method.bank
+        hit_slot, tex_uv, rays_d = ctx.saved
+        gt_prev, gw_prev = bank.tables.grad, bank.weights.grad
+        bank.tables.grad = torch.zeros_like(bank.tables)
+        bank.weights.grad = torch.zeros_like(bank.weights)
+        bank.backward(hit_slot, tex_uv, rays_d, method.raytracer.tris, g_rgb.contiguous(),
+                      g_alpha.contiguous(), method.grad_scale)
+        g_t, g_w = bank.tables.grad, bank.weights.grad
+        bank.tables.grad, bank.weights.grad = gt_prev, gw_prev    # autograd accumulates itself
+        return g_t, g_w, None, None, None, None
+
+
+class VolSurfs(torch.nn.Module):
+    """K nested mesh shells with SH neural-texture appearance.
+
+    tensor_meshes: list (inner -> outer, utils/mesh_loaders.py:28-30) of objects with
+    .vertices [V,3], .faces [F,3], .get_faces_uvs() [F,3,2] (volsurfs.py:82-117, 511).
+    hyper-parameters follow config/volsurfs/base_5.cfg."""
+
+    def __init__(self, tensor_meshes, max_rays=16384, sh_degree=3, transp_view_dep=True,
+                 sh_range=(15, 15, 15, 15), textures_res=(2048, 1024, 512, 256),
+                 is_inner_mesh_solid=False, with_alpha_decay=True, bg_color=(1.0, 1.0, 1.0),
+                 lr=1e-3, seed=42):
+        super().__init__()
+        self.tensor_meshes = tensor_meshes
+        self.nr_meshes = len(tensor_meshes)
+        dev = tensor_meshes[0].vertices.device
+        self.raytracer = RayTracer(tensor_meshes)                      # volsurfs.py:128
+        fu = []
+        for m, off, n in zip(tensor_meshes, self.raytracer.mesh_tri_offset, self.raytracer.mesh_nr_tris):
+            ids = self.raytracer.slot_face_id[off:off + n].long()
+            fu.append(m.get_faces_uvs().reshape(-1, 6)[ids])
+        self.face_uvs = torch.cat(fu, 0).contiguous()
+        self.bank = NeuralTextureBank(self.nr_meshes, max_rays, sh_degree=sh_degree,
+                                      alpha_sh_degree=sh_degree if transp_view_dep else 0,
+                                      sh_range=sh_range, textures_res=textures_res,
+                                      inner_solid=is_inner_mesh_solid,
+                                      with_alpha_decay=with_alpha_decay, device=dev, seed=seed)
+        self.max_rays = max_rays
+        self.bg_color = torch.tensor([bg_color], device=dev, dtype=torch.float32)   # volsurfs.py:686-689
+        self.grad_scale = 16384.0
+        self.is_training = True
+        self.lr = lr
+        self.optimizer = None
+
+    # -- optimiser: apex FusedAdam(betas (0.9, 0.99), eps 1e-15, wd 0) of
+    # base_method.py:87-94 == Adam with the same hyper-parameters
+    def init_optim(self):
+        self.optimizer = torch.optim.Adam([self.bank.tables, self.bank.weights], lr=self.lr,
+                                          betas=(0.9, 0.99), eps=1e-15, weight_decay=0.0, fused=True)
+        return self.optimizer
+
+    def optim_step(self):
+        self.optimizer.step()
+        self.bank.refresh_half_params()
+
+    def render_rays(self, rays_o, rays_d, iter_nr=None, return_samples=True, **kwargs):
+        """volsurfs.py:423-761: returns {"renders": {"ray_traced": {...}}, "samples_3d",
+        "samples_grad"} with the reference's keys, shapes and dtypes."""
+        N, K = rays_o.shape[0], self.nr_meshes
+        if N > self.max_rays:
+            raise _lib.VolsurfsHipError(f"{N} rays > max_rays={self.max_rays}; use render()")
+        rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
+        hit_t, hit_slot, hit_uv = self.raytracer.trace_all(rays_o, rays_d)     # :476-485, one launch
+        rgb_k, alpha_k, normals, tex_uv = _ShadeStage.apply(self.bank.tables, self.bank.weights,
+                                                            self, hit_slot, hit_uv, rays_d)
+        out = composite_dense(rgb_k, alpha_k, self.bg_color)                   # :601-640, 704-708
+        renders = {
+            "rgb": out["rgb"], "rgb_fg": out["rgb_fg"], "rgb_bg": out["rgb_bg"],
+            "surfs_alpha": out["surfs_alpha"], "surfs_rgb": out["surfs_rgb"],
+            "surfs_normals": normals, "surfs_blending_weights": out["surfs_blending_weights"],
+            "bg_transmittance": out["bg_transmittance"],
+            "surfs_uvs": tex_uv.permute(1, 0, 2).contiguous(),                # [N,K,2], :509-516
+        }
+        res = {"renders": {"ray_traced": renders}, "samples_3d": None, "samples_grad": None}
+        if return_samples:       # :713-716 (boolean compaction = a host sync, as in the reference)
+            hits = (hit_slot >= 0).t()
+            pts = rays_o[:, None, :] + hit_t.t()[..., None] * rays_d[:, None, :]
+            res["samples_3d"] = pts[hits].reshape(-1, 3)
+            res["samples_grad"] = normals[hits].reshape(-1, 3)
+        return res
+
+    def forward(self, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first_iter=False,
+                is_training_masked=False):
+        """volsurfs.py:763-816: L1 rgb loss (utils/losses.py:14-19)."""
+        res = self.render_rays(rays_o=rays_o, rays_d=rays_d, iter_nr=iter_nr)
+        pred = res["renders"]["ray_traced"]["rgb"]
+        if is_training_masked and gt_mask is not None:
+            loss_rgb = ((gt_rgb - pred).abs() * gt_mask).mean()
+        else:
+            loss_rgb = (gt_rgb - pred).abs().mean()
+        return {"loss": loss_rgb, "rgb": loss_rgb}, {}, res["samples_3d"]
+
+    @torch.no_grad()
+    def render(self, rays_o, rays_d, nr_rays_per_pixel=1, chunk=16384):
+        """base_method.py:366-541: chunked full-frame render (test_rays_batch_size =
+        16384), supersample mean over nr_rays_per_pixel; buffers stay on the device."""
+        outs = []
+        for a in range(0, rays_o.shape[0], chunk):
+            r = self.render_rays(rays_o[a:a + chunk], rays_d[a:a + chunk], return_samples=False)
+            outs.append(r["renders"]["ray_traced"])
+        full = {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
+        if nr_rays_per_pixel > 1:
+            full = {k: v.reshape(-1, nr_rays_per_pixel, *v.shape[1:]).mean(1) for k, v in full.items()}
+        return full

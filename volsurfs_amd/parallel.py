@@ -1,0 +1,65 @@
+"""Tile-parallel data parallelism for the K-shell path (SURVEY §5 "Distributed
+communication backend", §8e).  The reference is single-GPU (G1); rays are
+independent end to end, so a frame / batch is sharded by contiguous ray chunks
+(16 384 = the reference's eval chunk, base_method.py:407-418) dealt round-robin
+to the ranks, meshes + BVH + textures are replicated, and the only collective is
+one all-reduce(sum) of the parameter gradients per training step (RCCL over xGMI
+on MI355X; gloo in the CPU tests)."""
+import torch
+
+
+def shard_chunks(nr_rays, rank, world, chunk=16384):
+    """[(start, end)] ray ranges owned by `rank`: chunk c goes to rank c % world.
+    Round-robin (not one contiguous block per rank) balances the load, because rays
+    that miss every shell are almost free."""
+    out = []
+    nchunks = (nr_rays + chunk - 1) // chunk
+    for c in range(rank, nchunks, world):
+        out.append((c * chunk, min(nr_rays, (c + 1) * chunk)))
+    return out
+
+
+def shard_indices(nr_rays, rank, world, chunk=16384, device="cpu"):
+    parts = [torch.arange(a, b, device=device) for a, b in shard_chunks(nr_rays, rank, world, chunk)]
+    return torch.cat(parts) if parts else torch.zeros(0, dtype=torch.long, device=device)
+
+
+def allreduce_gradients(params, world, group=None):
+    """Sum the gradients over ranks (each rank back-propagated its shard of a loss
+    normalised by the GLOBAL ray count, so the sum is the gradient of the global
+    mean loss; uneven shards stay exact — SURVEY §8e)."""
+    if world == 1:
+        return
+    import torch.distributed as dist
+    works = []
+    for p in params:
+        if p.grad is not None:
+            works.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=group, async_op=True))
+    for w in works:
+        w.wait()
+
+
+def gather_frame(local_rgb, nr_rays, rank, world, chunk=16384, group=None):
+    """Rank 0 receives the full [nr_rays,3] frame (rendering needs no other
+    collective: every rank writes its own tiles)."""
+    import torch.distributed as dist
+    if world == 1:
+        return local_rgb
+    sizes = [sum(b - a for a, b in shard_chunks(nr_rays, r, world, chunk)) for r in range(world)]
+    bufs = [torch.empty(s, 3, dtype=local_rgb.dtype, device=local_rgb.device) for s in sizes]
+    dist.all_gather(bufs, local_rgb.contiguous(), group=group) if len(set(sizes)) == 1 else \
+        _all_gather_uneven(bufs, local_rgb, rank, world, group)
+    if rank != 0:
+        return None
+    frame = torch.empty(nr_rays, 3, dtype=local_rgb.dtype, device=local_rgb.device)
+    for r in range(world):
+        frame[shard_indices(nr_rays, r, world, chunk, local_rgb.device)] = bufs[r]
+    return frame
+
+
+def _all_gather_uneven(bufs, local, rank, world, group):
+    import torch.distributed as dist
+    for r in range(world):
+        if r == rank:
+            bufs[r].copy_(local)
+        dist.broadcast(bufs[r], src=r, group=group)
