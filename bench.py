@@ -94,14 +94,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from volsurfs_amd.parallel import allreduce_gradients
+    params = [pipe.bank.tables, pipe.bank.weights]
+
+    def step(record=False):
+        pipe.step(record=record)
+        if world > 1:
+            # data-parallel training step: one all-reduce(sum) of the parameter
+            # gradients per step over RCCL / xGMI
+            pipe.timer.run("grad_allreduce", lambda: allreduce_gradients(params, world), record,
+                           bytes=sum(p.numel() for p in params) * 4)
+
     for _ in range(max(1, args.warmup)):
-        pipe.step()
+        step()
     pipe.stats()                       # hit / unique-texel counts for the byte & flop accounting
     pipe.reset_stage_timers()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        pipe.step(record=True)
+        step(record=True)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -113,16 +124,23 @@ def main():
     if rank == 0:
         total_rays = N * world * args.steps
         value = total_rays / dt / 1e6
-        dom = max(stages.items(), key=lambda kv: kv[1]["ms"])
+        dom = max(((k, v) for k, v in stages.items() if k != "grad_allreduce"),
+                  key=lambda kv: kv[1]["ms"])
         name, st = dom
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-measured HBM bytes per launch
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get(name)
         if st.get("flops") and st.get("bound") == "mfma":
+            # executed, unpadded FLOPs of the texels this launch evaluates
             ach = st["flops"] / (st["ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": MFMA_F16_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / MFMA_F16_PEAK_TFLOPS, "traffic": None}
+                    "unit": "TFLOP/s", "frac": ach / MFMA_F16_PEAK_TFLOPS, "traffic": traffic,
+                    "hbm_GB/s": st["bytes"] / (st["ms"] * 1e-3) / 1e9}
         else:
             ach = st["bytes"] / (st["ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
+                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic}
         out = {
             "metric": "Mrays/s (fwd+bwd) at 800x800, K=5 shells",
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,

@@ -203,21 +203,30 @@ class NeuralTextureBank(torch.nn.Module):
         self.tables.grad / self.weights.grad (accumulating, like autograd).
         grad_scale keeps the fp16 intermediate gradients in range (the analogue of
         tiny-cuda-nn's loss scale); it is divided out before accumulation."""
-        K, N = hit_slot.shape
-        st = _lib.stream_ptr()
+        self.backward_shade(hit_slot, tex_uv, rays_d, tris, g_surfs_rgb, g_surfs_alpha, grad_scale)
+        self.backward_mlp(grad_scale)
+        self.backward_encode(grad_scale)
+
+    def _ensure_grads(self):
         if self.tables.grad is None:
             self.tables.grad = torch.zeros_like(self.tables)
         if self.weights.grad is None:
             self.weights.grad = torch.zeros_like(self.weights)
-        if not hasattr(self, "_gw_scaled") or self._gw_scaled is None:
+        if getattr(self, "_gw_scaled", None) is None:
             self._gw_scaled = torch.zeros_like(self.weights)
-        else:
-            self._gw_scaled.zero_()
+
+    def backward_shade(self, hit_slot, tex_uv, rays_d, tris, g_surfs_rgb, g_surfs_alpha, grad_scale):
+        self._ensure_grads()
         _lib.call("vsa_nt_shade_bwd", ctypes.byref(self.plan), hit_slot, tex_uv, rays_d, tris,
-                  self.slot_of, self.texels, N, g_surfs_rgb.contiguous(),
-                  g_surfs_alpha.contiguous(), float(grad_scale), self.grad_rows, st)
+                  self.slot_of, self.texels, hit_slot.shape[1], g_surfs_rgb.contiguous(),
+                  g_surfs_alpha.contiguous(), float(grad_scale), self.grad_rows, _lib.stream_ptr())
+
+    def backward_mlp(self, grad_scale):
+        self._gw_scaled.zero_()
         _lib.call("vsa_nt_mlp_bwd", ctypes.byref(self.plan), self.weights_h, self.features,
-                  self.seg_start, self.grad_rows, self._gw_scaled, st)
-        _lib.call("vsa_nt_encode_bwd", ctypes.byref(self.plan), self.features, float(grad_scale),
-                  self.slot_xy, self.seg_start, self.tables.grad, st)
+                  self.seg_start, self.grad_rows, self._gw_scaled, _lib.stream_ptr())
         self.weights.grad.add_(self._gw_scaled, alpha=1.0 / float(grad_scale))
+
+    def backward_encode(self, grad_scale):
+        _lib.call("vsa_nt_encode_bwd", ctypes.byref(self.plan), self.features, float(grad_scale),
+                  self.slot_xy, self.seg_start, self.tables.grad, _lib.stream_ptr())

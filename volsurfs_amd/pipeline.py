@@ -154,7 +154,7 @@ class KShellPipeline:
                        lambda: bank.mark_and_compact(hit_slot, hit_uv, self.face_uvs), record,
                        bytes=N * K * 20 + bank.dom_total * (1 + 1 + 1 + 4) + P * 4)
         T.run("nt_encode_fwd", bank.encode, record,
-              bytes=2 * 16 * P * (4 + 4) + ntex * bank.n_entries * 4)
+              bytes=2 * 16 * P * 4 + 16 * P * 8 + ntex * bank.n_entries * 4)
         mlp_flops = getattr(self, "mlp_flops_fwd", 0)
         T.run("nt_mlp_fwd", bank.mlp, record, bytes=2 * P * (16 * 4) + P * (32 + 128),
               flops=mlp_flops, bound="mfma")
@@ -172,9 +172,12 @@ class KShellPipeline:
         g_c, g_a = T.run("composite_bwd",
                          lambda: composite_bwd_raw(rgb_k, alpha_k, self.bg, g_rgb), record,
                          bytes=N * (12 + 32 * K))
-        T.run("nt_backward(shade+mlp+hashgrad)",
-              lambda: bank.backward(hit_slot, tex_uv, self.rays_d, self.tracer.tris, g_c, g_a,
-                                    self.grad_scale), record,
-              bytes=M * (16 * 36 + 256 * 4) + 2 * P * 16 * 4 * 3 + P * 128,
-              flops=3 * mlp_flops, bound="mfma")
+        tris = self.tracer.tris
+        T.run("nt_shade_bwd", lambda: bank.backward_shade(hit_slot, tex_uv, self.rays_d, tris, g_c, g_a,
+                                                           self.grad_scale), record,
+              bytes=M * (16 * 36 + 8 + 12 + 16 + 256 * 4), bound="atomic")
+        T.run("nt_mlp_bwd", lambda: bank.backward_mlp(self.grad_scale), record,
+              bytes=2 * P * (64 + 64) + P * 128 * 2, flops=2 * mlp_flops, bound="mfma")
+        T.run("nt_encode_bwd", lambda: bank.backward_encode(self.grad_scale), record,
+              bytes=2 * 16 * P * 4 * 2 + 2 * 16 * P * 8 + ntex * bank.n_entries * 8)
         return rgb
