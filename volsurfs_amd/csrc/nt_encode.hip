@@ -18,7 +18,7 @@
 namespace {
 
 constexpr int ENC_BLOCK = 1024;     // 16 waves: a 128 KiB level pins one workgroup per CU
-constexpr int ENC_UNROLL = 4;       // slots in flight per lane
+constexpr int ENC_UNROLL = 8;       // slots in flight per lane
 constexpr int ENC_SPAN_FWD = 65536;   // slots per workgroup (forward)
 constexpr int ENC_SPAN_BWD = 262144;  // slots per workgroup before a flush (backward)
 constexpr unsigned PRIME_Y = 2654435761u;
@@ -166,13 +166,17 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
     while (copies < 32 && (long long)g.size * copies * 2 <= LDS_ENTRIES) copies *= 2;
   }
   for (int i = threadIdx.x; i < (int)g.size * copies; i += ENC_BLOCK) s_g[i] = 0;
-  int* my_g = s_g + (threadIdx.x & (copies - 1)) * g.size;
+  int* my_g = s_g + (threadIdx.x & (copies - 1)) * g.size;   // consecutive lanes -> different copies
   const int type = (wk.tex / VSA_NT_MAX_DEG) & 1;
-  const _Float16* dF = reinterpret_cast<const _Float16*>(dfeatures + nt_feat_plane_base(plan, type, level)) + feat;
   const int nl = plan.n_levels;
   // pass 1: sum |dF| over this workgroup's slots -> fixed-point scale
+  const unsigned* dFw = reinterpret_cast<const unsigned*>(dfeatures + nt_feat_plane_base(plan, type, level));
+  const int shift = 16 * feat;
   float asum = 0.f;
-  for (int slot = first + threadIdx.x; slot < last; slot += ENC_BLOCK) asum += fabsf((float)dF[2 * nt_feat_in_plane(nl, slot)]);
+  for (int slot = first + threadIdx.x; slot < last; slot += ENC_BLOCK) {
+    const unsigned wv = dFw[nt_feat_in_plane(nl, slot)] >> shift;
+    asum += fabsf((float)__builtin_bit_cast(_Float16, (unsigned short)wv));
+  }
   for (int off = 32; off > 0; off >>= 1) asum += __shfl_down(asum, off, 64);
   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = asum;
   __syncthreads();
@@ -184,23 +188,33 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
   frexpf(total, &e);                       // total = m * 2^e, m in [0.5, 1)
   const float S = ldexpf(1.0f, 30 - e);    // power of two: exact scaling and un-scaling
   const float S_inv = ldexpf(1.0f, e - 30) * dscale_inv;
-  // pass 2: scatter
-  for (int base = first + threadIdx.x; base < last; base += ENC_BLOCK * ENC_UNROLL) {
+  // pass 2: scatter.  Lanes are dealt in groups of 8: a group walks its own
+  // 1/128th of the slot range (64-byte coalesced loads per group), so that the
+  // 64 lanes of a wave touch 8 distant texture regions instead of 64 neighbouring
+  // texels that share one coarse cell (same-address LDS atomics serialise).
+  // (Hashed levels scatter pseudo-randomly anyway: they keep fully coalesced loads.)
+  constexpr int GW = HASHED ? ENC_BLOCK : 8;            // lanes that walk one sub-range together
+  const int grp = threadIdx.x / GW, j8 = threadIdx.x % GW;
+  const int sub = (((last - first) + (ENC_BLOCK / GW) - 1) / (ENC_BLOCK / GW) + GW - 1) / GW * GW;
+  const int g_first = first + grp * sub;
+  const int g_last = min(last, g_first + sub);
+  for (int base = g_first + j8; base < g_last; base += GW * ENC_UNROLL) {
     float2 xy[ENC_UNROLL];
-    float gv[ENC_UNROLL];
+    unsigned dw[ENC_UNROLL];
 #pragma unroll
     for (int u = 0; u < ENC_UNROLL; ++u) {
-      const int slot = base + u * ENC_BLOCK;
-      const int sl = slot < last ? slot : last - 1;
+      const int slot = base + u * GW;
+      const int sl = slot < g_last ? slot : first;
       xy[u] = slot_xy[sl];
-      gv[u] = slot < last ? (float)dF[2 * nt_feat_in_plane(nl, sl)] * S : 0.f;
+      dw[u] = slot < g_last ? dFw[nt_feat_in_plane(nl, sl)] >> shift : 0u;
     }
 #pragma unroll
     for (int u = 0; u < ENC_UNROLL; ++u) {
-      if (gv[u] != 0.f) {
+      const float gv = (float)__builtin_bit_cast(_Float16, (unsigned short)dw[u]) * S;
+      if (gv != 0.f) {
         const CellCorners c = cell_corners<HASHED>(g, xy[u].x, xy[u].y);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) atomicAdd(&my_g[c.idx[k]], __float2int_rn(c.w[k] * gv[u]));
+        for (int k = 0; k < 4; ++k) atomicAdd(&my_g[c.idx[k]], __float2int_rn(c.w[k] * gv));
       }
     }
   }
