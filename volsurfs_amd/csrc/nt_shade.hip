@@ -294,6 +294,12 @@ __global__ __launch_bounds__(SH_BLOCK) void nt_shade_bwd_kernel(
   const int nn = 2 * d + 1;
   const int fidx = ch < 3 ? ch * nn + (m - d * d) : 24 + (m - d * d);
   const bool active = ch < 3 ? d < plan.rgb_degrees : (has_alpha && d < plan.alpha_degrees);
+  // Consecutive hits of a wave are neighbouring pixels: at the coarse degrees
+  // (256^2, 512^2 textures) they often fall on the SAME corner texels.  Each lane
+  // therefore keeps a running sum per corner and only issues the atomic when the
+  // corner's slot changes (lanes of one degree take the same decisions).
+  int cur[4] = {-1, -1, -1, -1};
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
   unsigned long long rem = hits;
   while (rem) {
     const int hl = __ffsll((long long)rem) - 1;
@@ -304,9 +310,21 @@ __global__ __launch_bounds__(SH_BLOCK) void nt_shade_bwd_kernel(
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int sl = s_slot[ht][d * 4 + k];
-        atomicAdd(&grad_rows[(long long)sl * 32 + fidx], s_w[ht][d * 4 + k] * g);
+        const float v = s_w[ht][d * 4 + k] * g;
+        if (sl == cur[k]) {
+          acc[k] += v;
+        } else {
+          if (cur[k] >= 0) atomicAdd(&grad_rows[(long long)cur[k] * 32 + fidx], acc[k]);
+          cur[k] = sl;
+          acc[k] = v;
+        }
       }
     }
+  }
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (cur[k] >= 0) atomicAdd(&grad_rows[(long long)cur[k] * 32 + fidx], acc[k]);
   }
 }
 
