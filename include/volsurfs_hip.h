@@ -235,6 +235,54 @@ int vsa_nt_encode_bwd(const vsa_nt_plan* plan, const void* dfeatures, float grad
                       const float* slot_xy, const int32_t* seg_start, float* grad_tables,
                       void* stream);
 
+/* ------------------------------------------------------------------------
+ * A8 / A9 / A11  Packed (ragged) per-ray sample ops of the background path:
+ * what render_contracted_bg (volsurfs_py/utils/background.py:31-141) calls in the
+ * reference's pybind module `volsurfs` (src/PyBridge.cxx:70-138).  A pack is the
+ * SoA of include/volsurfs/RaySamplesPacked.cuh:7-80; here its tensors are passed
+ * individually: ray_start_end_idx [N,2] i32, per-sample [S,*] f32, per-ray [N,*] f32.
+ * A ray is owned by a 32-lane half-wave (lanes = consecutive samples).
+ */
+/* VolumeRendering::cumprod_one_minus_alpha_to_transmittance (src/VolumeRendering.cu:30-78):
+ * T_i = prod_{j<i} a_j, bg_T = T_{n-1}; caller pre-fills T with 0 and bg_T with 1. */
+int vsa_packed_cumprod_fwd(const int32_t* start_end, const float* one_minus_alpha,
+                           float* transmittance, float* bg_transmittance, int nr_rays,
+                           void* stream);
+/* ..._backward (:671-718): g_a_i = (cumsumLV_{i+1} + g_bgT*bgT)/max(a_i,1e-6), 0 for the last. */
+int vsa_packed_cumprod_bwd(const int32_t* start_end, const float* g_bg_transmittance,
+                           const float* one_minus_alpha, const float* bg_transmittance,
+                           const float* cumsum_lv, float* g_one_minus_alpha, int nr_rays,
+                           void* stream);
+/* VolumeRendering::cumsum_over_rays (:326-370), inverse = suffix sums. */
+int vsa_packed_cumsum(const int32_t* start_end, const float* values, int inverse, float* out,
+                      int nr_rays, void* stream);
+/* integrate_with_weights_{1d,3d} (:80-176) and their backward (:720-818); dim in {1,3};
+ * bug_compat=1 reproduces VolumeRenderingGPU.cuh:1021 (z lane reads column 1). */
+int vsa_packed_integrate_fwd(const int32_t* start_end, const float* values, const float* weights,
+                             float* out, int nr_rays, int dim, void* stream);
+int vsa_packed_integrate_bwd(const int32_t* start_end, const float* g_out, const float* values,
+                             const float* weights, float* g_values, float* g_weights,
+                             int nr_rays, int dim, int bug_compat, void* stream);
+/* median_depth_over_rays (:372-416); fallback_compat=1 reproduces VolumeRenderingGPU.cuh:407. */
+int vsa_packed_median_depth(const int32_t* start_end, const float* samples_z,
+                            const float* weights, float threshold, float* out, int nr_rays,
+                            int fallback_compat, void* stream);
+/* RaySamplesPacked::update_dt (src/RaySamplesPacked.cu:396-461). */
+int vsa_packed_update_dt(const int32_t* start_end, const float* ray_max_dt, const float* ray_exit,
+                         const float* samples_z, int is_background, float* samples_dt,
+                         int nr_rays, void* stream);
+/* RaySampler::compute_samples_bg (src/RaySampler.cu:70-156): n samples per ray at
+ * t = t_start + 1/(s+1e-6) - 1, s: 1 -> 0; jitter uses PCG32 (state, inc) exactly as the
+ * reference's by-value copy of m_rng (advance(ray) before every draw). */
+int vsa_sample_bg(const float* rays_o, const float* rays_d, const float* ray_t_start,
+                  float ray_t_far, int nr_samples_per_ray, int jitter, uint64_t rng_state,
+                  uint64_t rng_inc, float* ray_max_dt, float* samples_3d, float* samples_dirs,
+                  float* samples_z, int32_t* ray_start_end_idx, int nr_rays, void* stream);
+/* RaySampler::contract_samples kernel (src/RaySampler.cu:336-381; update_dt is a separate call). */
+int vsa_contract_samples(const float* ray_o, const int32_t* start_end, const float* samples_3d,
+                         const float* samples_z, float* out_samples_3d, float* out_samples_z,
+                         int nr_rays, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

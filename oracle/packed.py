@@ -1,0 +1,207 @@
+"""Oracle: packed (ragged) per-ray sample ops of the background path, restated
+from the reference's CUDA kernels with their serial per-ray loops.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Follows kernels/volsurfs/VolumeRenderingGPU.cuh:28-78 (cumprod), :80-177
+(integrate 1d/3d), :305-361 (cumsum), :364-409 (median depth), :896-1033
+(backwards); RaySamplerGPU.cuh:39-139 (compute_samples_bg), :528-592
+(contract_samples); RaySamplesPackedGPU.cuh:14-88 (update_dt); pcg32.h (PCG32,
+published generator).  These kernels cannot be compiled or imported here (CUDA
+only), and the reference has no tests: the only known-answer material is the
+worked example at VolumeRenderingGPU.cuh:60-62 -> PARITY UNPINNED beyond it.
+The autograd glue around them (volume_rendering_funcs.py:91-241) IS pinned:
+tests/golden/packed_glue.npz comes from the reference's own Function classes run
+on top of this module (tools/make_golden.py).
+Sums are accumulated serially in fp32 like the kernels (nvcc may contract a*b+c
+into FMA, which this restatement does not: differences are 1 ulp).
+"""
+import numpy as np
+
+f32 = np.float32
+
+
+def _rays(start_end):
+    for r in range(start_end.shape[0]):
+        a, b = int(start_end[r, 0]), int(start_end[r, 1])
+        yield r, a, b
+
+
+def cumprod_fwd(start_end, a):
+    a = np.asarray(a, f32).reshape(-1)
+    T = np.zeros_like(a)
+    bgT = np.ones(start_end.shape[0], f32)
+    for r, i0, i1 in _rays(start_end):
+        n = i1 - i0
+        if n == 0:
+            continue
+        t = f32(1.0)
+        for i in range(n):
+            T[i0 + i] = t
+            if i < n - 1:
+                t = f32(t * a[i0 + i])
+        bgT[r] = t
+    return T, bgT
+
+
+def cumsum(start_end, v, inverse):
+    v = np.asarray(v, f32).reshape(-1)
+    out = np.zeros_like(v)
+    for r, i0, i1 in _rays(start_end):
+        seg = v[i0:i1][::-1] if inverse else v[i0:i1]
+        c = np.cumsum(seg, dtype=f32)
+        out[i0:i1] = c[::-1] if inverse else c
+    return out
+
+
+def integrate_fwd(start_end, values, weights):
+    values = np.asarray(values, f32)
+    w = np.asarray(weights, f32).reshape(-1)
+    D = values.shape[1]
+    out = np.zeros((start_end.shape[0], D), f32)
+    for r, i0, i1 in _rays(start_end):
+        if i1 > i0:
+            out[r] = np.cumsum(w[i0:i1, None] * values[i0:i1], axis=0, dtype=f32)[-1]
+    return out
+
+
+def integrate_bwd(start_end, g_out, values, weights, bug_compat=False):
+    values = np.asarray(values, f32)
+    w = np.asarray(weights, f32).reshape(-1)
+    g_values = np.zeros_like(values)
+    g_w = np.zeros_like(w)
+    for r, i0, i1 in _rays(start_end):
+        g = np.asarray(g_out[r], f32)
+        g_values[i0:i1] = g[None] * w[i0:i1, None]
+        v = values[i0:i1]
+        if bug_compat and v.shape[1] == 3:
+            v = v[:, [0, 1, 1]]                      # VolumeRenderingGPU.cuh:1021
+        acc = np.zeros(i1 - i0, f32)
+        for d in range(values.shape[1]):
+            acc = acc + g[d] * v[:, d]
+        g_w[i0:i1] = acc
+    return g_values, g_w
+
+
+def cumprod_bwd(start_end, g_bgT, a, bgT, cumsum_lv):
+    a = np.asarray(a, f32).reshape(-1)
+    g = np.zeros_like(a)
+    for r, i0, i1 in _rays(start_end):
+        n = i1 - i0
+        for i in range(n - 1):
+            d = max(a[i0 + i], f32(1e-6))
+            x = f32(cumsum_lv[i0 + i + 1] / d)
+            g[i0 + i] = f32(x + f32(f32(g_bgT[r] * bgT[r]) / d))
+    return g
+
+
+def median_depth(start_end, z, w, thr, fallback_compat=False):
+    z = np.asarray(z, f32).reshape(-1)
+    w = np.asarray(w, f32).reshape(-1)
+    out = np.zeros(start_end.shape[0], f32)
+    for r, i0, i1 in _rays(start_end):
+        n = i1 - i0
+        if n == 0:
+            continue
+        c = np.cumsum(w[i0:i1], dtype=f32)
+        hit = np.nonzero(c >= f32(thr))[0]
+        if hit.size:
+            out[r] = z[i0 + hit[0]]
+        else:
+            out[r] = z[n - 1] if fallback_compat else z[i1 - 1]   # :407 reads without idx_start
+    return out
+
+
+def update_dt(start_end, ray_max_dt, ray_exit, z, is_background):
+    z = np.asarray(z, f32).reshape(-1)
+    dt = np.full_like(z, -1.0)
+    for r, i0, i1 in _rays(start_end):
+        n = i1 - i0
+        if n == 0:
+            continue
+        m = f32(ray_max_dt[r])
+        d = np.clip(z[i0 + 1:i1] - z[i0:i1 - 1], f32(0), m)
+        dt[i0:i1 - 1] = d
+        dt[i1 - 1] = f32(1e10) if is_background else np.clip(f32(ray_exit[r]) - z[i1 - 1], f32(0), m)
+    return dt
+
+
+class Pcg32:
+    MULT = 0x5851f42d4c957f2d
+    M64 = (1 << 64) - 1
+
+    def __init__(self, state=0x853c49e6748fea9b, inc=0xda3e39cb94b95bdb):
+        self.state, self.inc = state, inc
+
+    def next_uint(self):
+        old = self.state
+        self.state = (old * self.MULT + self.inc) & self.M64
+        xs = (((old >> 18) ^ old) >> 27) & 0xFFFFFFFF
+        rot = old >> 59
+        return ((xs >> rot) | (xs << ((-rot) & 31))) & 0xFFFFFFFF
+
+    def next_float(self):
+        u = (self.next_uint() >> 9) | 0x3f800000
+        return f32(np.array([u], np.uint32).view(f32)[0] - f32(1.0))
+
+    def advance(self, delta=1 << 32):
+        cur_mult, cur_plus, acc_mult, acc_plus = self.MULT, self.inc, 1, 0
+        delta &= self.M64
+        while delta > 0:
+            if delta & 1:
+                acc_mult = (acc_mult * cur_mult) & self.M64
+                acc_plus = (acc_plus * cur_mult + cur_plus) & self.M64
+            cur_plus = ((cur_mult + 1) * cur_plus) & self.M64
+            cur_mult = (cur_mult * cur_mult) & self.M64
+            delta >>= 1
+        self.state = (acc_mult * self.state + acc_plus) & self.M64
+
+    def copy(self):
+        return Pcg32(self.state, self.inc)
+
+
+def sample_bg(rays_o, rays_d, t_start, t_far, n, jitter=False, rng=None):
+    rays_o, rays_d = np.asarray(rays_o, f32), np.asarray(rays_d, f32)
+    N = rays_o.shape[0]
+    z = np.zeros((N, n), f32)
+    max_dt = np.zeros(N, f32)
+    eps = f32(1e-6)
+    delta_s = f32(1.0 / (n - 1))
+    for r in range(N):
+        s, t_prec, md = f32(1.0), f32(t_start[r]), f32(0.0)
+        g = rng.copy() if jitter else None
+        for i in range(n):
+            t = f32(1.0 / float(f32(s + eps)) - 1.0)
+            t = f32(t + f32(t_start[r]))
+            t = min(max(t, f32(t_start[r])), f32(t_far))
+            if jitter and i != 0 and i != n - 1:
+                g.advance(r)
+                u = g.next_float()
+                t = f32(t_prec + f32(u * f32(t - t_prec)))
+            z[r, i] = t
+            s = f32(s - delta_s)
+            md = max(md, f32(t - t_prec))
+            t_prec = t
+        max_dt[r] = md
+    s3d = (rays_o[:, None, :] + z[..., None] * rays_d[:, None, :]).astype(f32)
+    dirs = np.broadcast_to(rays_d[:, None, :], (N, n, 3)).copy()
+    se = np.stack([np.arange(N) * n, np.arange(N) * n + n], 1).astype(np.int32)
+    return {"samples_z": z.reshape(-1), "samples_3d": s3d.reshape(-1, 3), "samples_dirs": dirs.reshape(-1, 3),
+            "ray_max_dt": max_dt, "ray_start_end_idx": se}
+
+
+def contract(ray_o, start_end, s3d, sz):
+    s3d, sz = np.asarray(s3d, f32).copy(), np.asarray(sz, f32).reshape(-1).copy()
+    for r, i0, i1 in _rays(start_end):
+        p = s3d[i0:i1]
+        q = p * f32(2.0)
+        norm = np.sqrt((q[:, 0] * q[:, 0] + q[:, 1] * q[:, 1]) + q[:, 2] * q[:, 2]).astype(f32)
+        m = norm > 1.0
+        nz = np.where(m, norm, f32(1.0))
+        factor = (f32(2.0) - f32(1.0) / nz).astype(f32)
+        pc = ((factor[:, None] * p) / nz[:, None]).astype(f32)
+        e = pc - np.asarray(ray_o[r], f32)[None]
+        zc = np.sqrt((e[:, 0] * e[:, 0] + e[:, 1] * e[:, 1]) + e[:, 2] * e[:, 2]).astype(f32)
+        s3d[i0:i1] = np.where(m[:, None], pc, p)
+        sz[i0:i1] = np.where(m, zc, sz[i0:i1])
+    return s3d, sz

@@ -1,0 +1,181 @@
+"""Packed ops of the background path (A8/A9/A11): oracle known answers (CPU) and
+HIP kernels vs oracle + the reference-glue fixture (GPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import packed as OP
+
+
+def _ragged(n_rays, seed, max_n=70):
+    g = np.random.default_rng(seed)
+    counts = g.integers(0, max_n, n_rays)
+    counts[:4] = [0, 1, 32, 33]
+    ends = np.cumsum(counts)
+    return np.stack([ends - counts, ends], 1).astype(np.int32), int(ends[-1])
+
+
+def test_oracle_worked_example_and_pcg32():
+    se = np.array([[0, 3]], np.int32)
+    T, b = OP.cumprod_fwd(se, np.array([0.9, 0.5, 0.1], np.float32))
+    # kernels/volsurfs/VolumeRenderingGPU.cuh:60-62
+    np.testing.assert_allclose(T, [1.0, 0.9, 0.45], rtol=1e-6)
+    np.testing.assert_allclose(b, [0.45], rtol=1e-6)
+    # PCG32 reference stream (pcg-c demo, seed (42, 54)): published first outputs
+    r = OP.Pcg32(0, (54 << 1) | 1)
+    r.next_uint(); r.state = (r.state + 42) & r.M64; r.next_uint()
+    assert [r.next_uint() for _ in range(3)] == [0xa15c02b7, 0x7b47f409, 0xba1d3330]
+    # advance(k) == k steps
+    a, b2 = OP.Pcg32(), OP.Pcg32()
+    for _ in range(37):
+        a.next_uint()
+    b2.advance(37)
+    assert a.state == b2.state
+
+
+def test_oracle_cumprod_backward_is_the_gradient():
+    se, S = _ragged(20, 1, 12)
+    g = np.random.default_rng(2)
+    a = g.uniform(0.2, 0.99, S).astype(np.float32)
+    gT = g.standard_normal(S).astype(np.float32)
+    gb = g.standard_normal(20).astype(np.float32)
+    T, bgT = OP.cumprod_fwd(se, a)
+    lv = OP.cumsum(se, gT * T, True)
+    ga = OP.cumprod_bwd(se, gb, a, bgT, lv)
+    at = torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    loss = 0
+    for r in range(20):
+        i0, i1 = se[r]
+        if i1 > i0:
+            seg = at[i0:i1]
+            Tt = torch.cat([torch.ones(1, dtype=torch.float64), torch.cumprod(seg[:-1], 0)])
+            loss = loss + (Tt * torch.tensor(gT[i0:i1], dtype=torch.float64)).sum() + Tt[-1] * float(gb[r])
+    loss.backward()
+    np.testing.assert_allclose(ga, at.grad.numpy(), rtol=2e-4, atol=1e-5)
+
+
+def test_oracle_sampler_properties():
+    o = np.zeros((3, 3), np.float32)
+    d = np.tile(np.array([[0, 0, 1.0]], np.float32), (3, 1))
+    ts = np.array([0.5, 1.0, 2.0], np.float32)
+    s = OP.sample_bg(o, d, ts, 100.0, 32)
+    z = s["samples_z"].reshape(3, 32)
+    assert np.allclose(z[:, 0], ts) and np.all(np.diff(z, axis=1) >= 0) and np.all(z <= 100.0)
+    assert np.all(z[:, -1] == 100.0)             # s -> 0: 1/(0+1e-6) - 1 clamps to t_far
+    sj = OP.sample_bg(o, d, ts, 100.0, 32, jitter=True, rng=OP.Pcg32())
+    zj = sj["samples_z"].reshape(3, 32)
+    assert np.all(zj[:, 0] == z[:, 0]) and np.all(zj[:, -1] == z[:, -1]) and np.all(zj <= z + 1e-6)
+    c3d, cz = OP.contract(o, s["ray_start_end_idx"], s["samples_3d"], s["samples_z"])
+    assert np.all(np.linalg.norm(c3d * 2, axis=1) <= 2.0 + 1e-5)     # contracted into radius 1 (scale 2)
+
+
+# ------------------------------- GPU ---------------------------------------
+def _pack(se):
+    from volsurfs_amd.volsurfs import RaySamplesPacked
+    p = RaySamplesPacked(se.shape[0], int(se[-1, 1]))
+    p.ray_start_end_idx = torch.from_numpy(se).cuda()
+    return p
+
+
+@pytest.mark.gpu
+def test_hip_packed_ops_vs_oracle():
+    from volsurfs_amd.volsurfs import VolumeRendering as VR
+    se, S = _ragged(3000, 3)
+    g = np.random.default_rng(4)
+    a = g.uniform(0.0, 1.0, (S, 1)).astype(np.float32)
+    v3 = g.standard_normal((S, 3)).astype(np.float32)
+    w = g.uniform(0, 0.1, (S, 1)).astype(np.float32)
+    z = np.sort(g.uniform(0, 5, (S, 1)).astype(np.float32), axis=0)
+    p = _pack(se)
+    p.samples_z = torch.from_numpy(z).cuda()
+    cu = lambda x: torch.from_numpy(x).cuda()
+    T, bgT = VR.cumprod_one_minus_alpha_to_transmittance(p, cu(a))
+    Tr, br = OP.cumprod_fwd(se, a)
+    np.testing.assert_allclose(T.cpu().numpy()[:, 0], Tr, rtol=2e-6, atol=1e-30)
+    np.testing.assert_allclose(bgT.cpu().numpy()[:, 0], br, rtol=2e-6, atol=1e-30)
+    for inv in (False, True):
+        c = VR.cumsum_over_rays(p, cu(w), inv)
+        np.testing.assert_allclose(c.cpu().numpy()[:, 0], OP.cumsum(se, w, inv), rtol=2e-6, atol=1e-7)
+    o3 = VR.integrate_with_weights_3d(p, cu(v3), cu(w))
+    np.testing.assert_allclose(o3.cpu().numpy(), OP.integrate_fwd(se, v3, w), rtol=1e-5, atol=1e-6)
+    o1 = VR.integrate_with_weights_1d(p, cu(z), cu(w))
+    np.testing.assert_allclose(o1.cpu().numpy(), OP.integrate_fwd(se, z, w), rtol=1e-5, atol=1e-6)
+    gr = g.standard_normal((3000, 3)).astype(np.float32)
+    for compat in (False, True):
+        VR.bug_compat = compat
+        gv, gw = VR.integrate_with_weights_3d_backward(cu(gr), p, cu(v3), cu(w), o3)
+        rv, rw = OP.integrate_bwd(se, gr, v3, w, bug_compat=compat)
+        np.testing.assert_allclose(gv.cpu().numpy(), rv, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(gw.cpu().numpy()[:, 0], rw, rtol=1e-5, atol=1e-6)
+        md = VR.median_depth_over_rays(p, cu(w), 0.5)
+        # identical decisions except when the scanned cumsum straddles the threshold by 1 ulp
+        ref = OP.median_depth(se, z, w, 0.5, fallback_compat=compat)
+        assert (md.cpu().numpy()[:, 0] != ref).mean() < 2e-3
+    VR.bug_compat = False
+    gb = g.standard_normal((3000, 1)).astype(np.float32)
+    lv = OP.cumsum(se, (gr[:1].sum() * 0 + g.standard_normal(S).astype(np.float32)) * Tr, True)
+    ga = VR.cumprod_one_minus_alpha_to_transmittance_backward(cu(a), cu(gb), p, cu(a), T, bgT,
+                                                              cu(lv[:, None]))
+    np.testing.assert_allclose(ga.cpu().numpy()[:, 0], OP.cumprod_bwd(se, gb[:, 0], a, br, lv),
+                               rtol=1e-5, atol=1e-6)
+    # rays without samples: bg transmittance 1, zero colour
+    assert bgT[0].item() == 1.0 and (o3[0] == 0).all()
+
+
+@pytest.mark.gpu
+def test_hip_sampler_contract_update_dt_vs_oracle():
+    from volsurfs_amd.volsurfs import RaySampler
+    g = np.random.default_rng(5)
+    N = 777
+    o = (g.standard_normal((N, 3)) * 0.2).astype(np.float32)
+    d = g.standard_normal((N, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    ts = g.uniform(0.1, 2.0, (N, 1)).astype(np.float32)
+    for jitter in (False, True):
+        RaySampler.m_rng.__init__()
+        p = RaySampler.compute_samples_bg(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda(),
+                                          torch.from_numpy(ts).cuda(), 100.0, 32, jitter)
+        ref = OP.sample_bg(o, d, ts[:, 0], 100.0, 32, jitter=jitter, rng=OP.Pcg32())
+        assert np.array_equal(p.samples_z.cpu().numpy()[:, 0], ref["samples_z"])
+        assert np.array_equal(p.ray_start_end_idx.cpu().numpy(), ref["ray_start_end_idx"])
+        np.testing.assert_allclose(p.samples_3d.cpu().numpy(), ref["samples_3d"], rtol=0, atol=1e-6)
+        assert np.array_equal(p.samples_dirs.cpu().numpy(), ref["samples_dirs"])
+        np.testing.assert_allclose(p.ray_max_dt.cpu().numpy()[:, 0], ref["ray_max_dt"], rtol=1e-6)
+        assert p.get_total_nr_samples() == N * 32 and not p.is_empty()
+        c = RaySampler.contract_samples(p)
+        r3d, rz = OP.contract(o, ref["ray_start_end_idx"], p.samples_3d.cpu().numpy(),
+                              p.samples_z.cpu().numpy())
+        np.testing.assert_allclose(c.samples_3d.cpu().numpy(), r3d, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(c.samples_z.cpu().numpy()[:, 0], rz, rtol=1e-6, atol=1e-7)
+        rdt = OP.update_dt(ref["ray_start_end_idx"], p.ray_max_dt.cpu().numpy()[:, 0],
+                           np.full(N, 100.0, np.float32), c.samples_z.cpu().numpy(), True)
+        np.testing.assert_allclose(c.samples_dt.cpu().numpy()[:, 0], rdt, rtol=1e-6, atol=1e-7)
+    # after a jittered call the global RNG moved on by 2^32 (RaySampler.cu:139-142)
+    r = OP.Pcg32(); r.advance()
+    assert RaySampler.m_rng.state == r.state
+
+
+@pytest.mark.gpu
+def test_hip_glue_matches_reference_fixture(golden_dir):
+    from volsurfs_amd import volsurfs as V
+    z = np.load(os.path.join(golden_dir, "packed_glue.npz"))
+    p = _pack(z["start_end"])
+    V.VolumeRendering.bug_compat = True          # the fixture carries the reference's :1021 behaviour
+    try:
+        density = torch.from_numpy(z["density"]).cuda().requires_grad_(True)
+        rgb = torch.from_numpy(z["rgb"]).cuda().requires_grad_(True)
+        dt = torch.from_numpy(z["dt"]).cuda()
+        alpha = 1.0 - torch.exp(-density * dt)
+        T, bgT = V.CumprodOneMinusAlphaToTransmittanceFunc.apply(p, (1 - alpha) + 1e-6)
+        pred = V.IntegrateWithWeights3DFunc.apply(p, rgb, alpha * T)
+        loss = (torch.from_numpy(z["gt"]).cuda() - pred).abs().mean() + 0.1 * bgT.mean()
+        loss.backward()
+    finally:
+        V.VolumeRendering.bug_compat = False
+    np.testing.assert_allclose(T.detach().cpu().numpy(), z["T"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(bgT.detach().cpu().numpy(), z["bgT"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), z["pred"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rgb.grad.cpu().numpy(), z["g_rgb"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(density.grad.cpu().numpy(), z["g_density"], rtol=2e-3, atol=1e-6)

@@ -200,7 +200,73 @@ def gen_nt():
     _save("sh_encoder.npz", **arrs)
 
 
-GENS = {"composite": gen_composite, "nt": gen_nt}
+# --------------------------------------------------------------------------
+# 3. Autograd glue of the packed background composite
+#    (volume_rendering/volume_rendering_funcs.py:91-241 + the weight math of
+#    utils/background.py:93-111) run AS SHIPPED on top of oracle.packed (the
+#    native `volsurfs.VolumeRendering` is CUDA-only).
+# --------------------------------------------------------------------------
+def gen_glue():
+    from oracle import packed as OP
+
+    class _Pack:
+        def __init__(self, se):
+            self.ray_start_end_idx = se
+
+    class _VR:
+        @staticmethod
+        def cumprod_one_minus_alpha_to_transmittance(p, a):
+            T, b = OP.cumprod_fwd(p.ray_start_end_idx, a.detach().numpy())
+            return torch.from_numpy(T)[:, None], torch.from_numpy(b)[:, None]
+
+        @staticmethod
+        def cumsum_over_rays(p, v, inverse):
+            return torch.from_numpy(OP.cumsum(p.ray_start_end_idx, v.detach().numpy(), inverse))[:, None]
+
+        @staticmethod
+        def cumprod_one_minus_alpha_to_transmittance_backward(gT, gb, p, a, T, b, lv):
+            g = OP.cumprod_bwd(p.ray_start_end_idx, gb.numpy()[:, 0], a.detach().numpy(), b.numpy()[:, 0],
+                               lv.numpy()[:, 0])
+            return torch.from_numpy(g)[:, None]
+
+        @staticmethod
+        def integrate_with_weights_3d(p, v, w):
+            return torch.from_numpy(OP.integrate_fwd(p.ray_start_end_idx, v.detach().numpy(), w.detach().numpy()))
+
+        @staticmethod
+        def integrate_with_weights_3d_backward(g, p, v, w, res):
+            gv, gw = OP.integrate_bwd(p.ray_start_end_idx, g.numpy(), v.detach().numpy(), w.detach().numpy(),
+                                      bug_compat=True)
+            return torch.from_numpy(gv), torch.from_numpy(gw)[:, None]
+
+    ref_import.install_placeholders({"volsurfs": {"VolumeRendering": _VR}})
+    from volsurfs_py.volume_rendering.volume_rendering_funcs import (
+        CumprodOneMinusAlphaToTransmittanceFunc, IntegrateWithWeights3DFunc)
+
+    g = torch.Generator().manual_seed(21)
+    counts = torch.randint(0, 40, (50,), generator=g)
+    counts[:3] = torch.tensor([0, 1, 32])
+    ends = torch.cumsum(counts, 0)
+    se = torch.stack([ends - counts, ends], 1).int().numpy()
+    S = int(ends[-1])
+    density = (torch.rand(S, 1, generator=g) * 3).requires_grad_(True)
+    rgb = torch.rand(S, 3, generator=g).requires_grad_(True)
+    dt = torch.rand(S, 1, generator=g) * 0.3
+    pack = _Pack(se)
+    alpha = 1.0 - torch.exp(-density * dt)                       # background.py:93-95
+    one_minus_alpha = 1 - alpha
+    T, bgT = CumprodOneMinusAlphaToTransmittanceFunc.apply(pack, one_minus_alpha + 1e-6)   # :99-104
+    weights = alpha * T                                          # :105
+    pred = IntegrateWithWeights3DFunc.apply(pack, rgb, weights)  # :109-111
+    gt = torch.rand(50, 3, generator=g)
+    loss = ((gt - pred).abs().mean() + 0.1 * bgT.mean())
+    loss.backward()
+    _save("packed_glue.npz", start_end=se, density=density.detach().numpy(), rgb=rgb.detach().numpy(),
+          dt=dt.numpy(), gt=gt.numpy(), T=T.detach().numpy(), bgT=bgT.detach().numpy(),
+          pred=pred.detach().numpy(), g_density=density.grad.numpy(), g_rgb=rgb.grad.numpy())
+
+
+GENS = {"composite": gen_composite, "nt": gen_nt, "glue": gen_glue}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(GENS)

@@ -1,0 +1,426 @@
+// Packed (ragged) per-ray sample ops of the background path (SURVEY §8a rows A8,
+// A9, A11): the subset of the reference's `volsurfs` pybind module that
+// VolSurfs.render_rays reaches through render_contracted_bg
+// (volsurfs_py/utils/background.py:31-141).
+//
+// The reference runs ONE THREAD PER RAY with a serial loop over the ray's samples
+// (kernels/volsurfs/VolumeRenderingGPU.cuh, RaySamplerGPU.cuh,
+// RaySamplesPackedGPU.cuh; lane stride = samples_per_ray * 4 B, i.e. uncoalesced).
+// Here a ray is owned by a 32-lane half-wave: lanes = consecutive samples
+// (coalesced 128-B rows), segmented scans / reductions via DPP shuffles, chunks of
+// 32 samples with a carried running value for longer rays (the bg path has
+// exactly 32 samples per ray: background.py:51-58, hyper_params.py:65).
+#include "common.h"
+
+namespace {
+
+constexpr int PK_BLOCK = 256;
+constexpr int SUB = 32;  // lanes per ray
+
+__device__ __forceinline__ float sub_scan_mul(float v, int l) {
+#pragma unroll
+  for (int off = 1; off < SUB; off <<= 1) {
+    const float u = __shfl_up(v, off, SUB);
+    if (l >= off) v *= u;
+  }
+  return v;
+}
+__device__ __forceinline__ float sub_scan_add(float v, int l) {
+#pragma unroll
+  for (int off = 1; off < SUB; off <<= 1) {
+    const float u = __shfl_up(v, off, SUB);
+    if (l >= off) v += u;
+  }
+  return v;
+}
+__device__ __forceinline__ float sub_reduce_add(float v) {
+#pragma unroll
+  for (int off = SUB / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, SUB);
+  return v;
+}
+
+#define PK_RAY_PROLOGUE()                                                        \
+  const int l = threadIdx.x & (SUB - 1);                                         \
+  const long long ray = ((long long)blockIdx.x * PK_BLOCK + threadIdx.x) / SUB;  \
+  if (ray >= N) return;                                                          \
+  const int i0 = start_end[2 * ray], i1 = start_end[2 * ray + 1];                \
+  const int n = i1 - i0;
+
+// VolumeRenderingGPU.cuh:28-78: T_i = prod_{j<i} a_j ; bgT = T_{n-1} (the last
+// sample's factor is deliberately excluded); rays without samples keep bgT.
+__global__ void cumprod_fwd_kernel(const int* __restrict__ start_end, const float* __restrict__ a,
+                                   float* __restrict__ T, float* __restrict__ bgT, int N) {
+  PK_RAY_PROLOGUE();
+  if (n <= 0) return;
+  float carry = 1.0f;
+  for (int c = 0; c < n; c += SUB) {
+    const int i = c + l;
+    const float v = i < n ? a[i0 + i] : 1.0f;
+    const float incl = sub_scan_mul(v, l);
+    float excl = __shfl_up(incl, 1, SUB);
+    if (l == 0) excl = 1.0f;
+    const float t = carry * excl;
+    if (i < n) T[i0 + i] = t;
+    if (i == n - 1) bgT[ray] = t;
+    carry *= __shfl(incl, SUB - 1, SUB);
+  }
+}
+
+// VolumeRenderingGPU.cuh:305-361
+__global__ void cumsum_kernel(const int* __restrict__ start_end, const float* __restrict__ v,
+                              int inverse, float* __restrict__ out, int N) {
+  PK_RAY_PROLOGUE();
+  if (n <= 0) return;
+  float carry = 0.0f;
+  for (int c = 0; c < n; c += SUB) {
+    const int i = c + l;
+    const int idx = inverse ? i1 - 1 - i : i0 + i;
+    const float x = i < n ? v[idx] : 0.0f;
+    const float incl = sub_scan_add(x, l);
+    if (i < n) out[idx] = carry + incl;
+    carry += __shfl(incl, SUB - 1, SUB);
+  }
+}
+
+// VolumeRenderingGPU.cuh:80-177
+template <int D>
+__global__ void integrate_fwd_kernel(const int* __restrict__ start_end,
+                                     const float* __restrict__ values,
+                                     const float* __restrict__ weights, float* __restrict__ out,
+                                     int N) {
+  PK_RAY_PROLOGUE();
+  if (n <= 0) return;
+  float acc[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) acc[d] = 0.f;
+  for (int i = l; i < n; i += SUB) {
+    const float w = weights[i0 + i];
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc[d] += w * values[(long long)(i0 + i) * D + d];
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const float s = sub_reduce_add(acc[d]);
+    if (l == 0) out[ray * D + d] = s;
+  }
+}
+
+// VolumeRenderingGPU.cuh:945-1033.  bug_compat reproduces :1021 (the z lane of
+// `values` reads column 1), off by default.
+template <int D>
+__global__ void integrate_bwd_kernel(const int* __restrict__ start_end,
+                                     const float* __restrict__ g_out,
+                                     const float* __restrict__ values,
+                                     const float* __restrict__ weights,
+                                     float* __restrict__ g_values, float* __restrict__ g_weights,
+                                     int N, int bug_compat) {
+  PK_RAY_PROLOGUE();
+  if (n <= 0) return;
+  float g[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) g[d] = g_out[ray * D + d];
+  for (int i = l; i < n; i += SUB) {
+    const long long s = i0 + i;
+    const float w = weights[s];
+    float gw = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      g_values[s * D + d] = g[d] * w;
+      const int col = (bug_compat && D == 3 && d == 2) ? 1 : d;
+      gw += g[d] * values[s * D + col];
+    }
+    g_weights[s] = gw;
+  }
+}
+
+// VolumeRenderingGPU.cuh:896-943
+__global__ void cumprod_bwd_kernel(const int* __restrict__ start_end,
+                                   const float* __restrict__ g_bgT, const float* __restrict__ a,
+                                   const float* __restrict__ bgT,
+                                   const float* __restrict__ cumsumLV, float* __restrict__ g_a,
+                                   int N) {
+  PK_RAY_PROLOGUE();
+  if (n <= 0) return;
+  const float b = bgT[ray], gb = g_bgT[ray];
+  for (int i = l; i < n; i += SUB) {
+    float g = 0.f;
+    if (i < n - 1) {
+      const float d = fmaxf(a[i0 + i], 1e-6f);
+      g = cumsumLV[i0 + i + 1] / d;
+      g += gb * b / d;
+    }
+    g_a[i0 + i] = g;
+  }
+}
+
+// VolumeRenderingGPU.cuh:364-409.  fallback_compat reproduces :407
+// (samples_z[nr_samples-1] without idx_start); default is the ray's last sample.
+__global__ void median_depth_kernel(const int* __restrict__ start_end, const float* __restrict__ z,
+                                    const float* __restrict__ w, float thr,
+                                    float* __restrict__ out, int N, int fallback_compat) {
+  PK_RAY_PROLOGUE();
+  if (n <= 0) return;
+  float carry = 0.0f;
+  for (int c = 0; c < n; c += SUB) {
+    const int i = c + l;
+    const float incl = carry + sub_scan_add(i < n ? w[i0 + i] : 0.0f, l);
+    const unsigned long long m = __ballot(i < n && incl >= thr);
+    const unsigned int mine = (unsigned int)(m >> (threadIdx.x & 32));   // this half-wave's 32 bits
+    if (mine) {
+      const int first = __ffs(mine) - 1;
+      if (l == first) out[ray] = z[i0 + i];
+      return;
+    }
+    carry = __shfl(incl, SUB - 1, SUB);
+  }
+  if (l == 0) out[ray] = fallback_compat ? z[n - 1] : z[i1 - 1];
+}
+
+// RaySamplesPackedGPU.cuh:14-88
+__global__ void update_dt_kernel(const int* __restrict__ start_end,
+                                 const float* __restrict__ ray_max_dt,
+                                 const float* __restrict__ ray_exit, const float* __restrict__ z,
+                                 int is_background, float* __restrict__ dt, int N) {
+  PK_RAY_PROLOGUE();
+  if (n <= 0) return;
+  const float max_dt = ray_max_dt[ray];
+  for (int i = l; i < n; i += SUB) {
+    float v;
+    if (i < n - 1) {
+      v = fminf(fmaxf(z[i0 + i + 1] - z[i0 + i], 0.0f), max_dt);
+    } else if (is_background) {
+      v = 1e10f;
+    } else {
+      v = fminf(fmaxf(ray_exit[ray] - z[i0 + i], 0.0f), max_dt);
+    }
+    dt[i0 + i] = v;
+  }
+}
+
+// PCG32 (O'Neill 2014; the reference carries Wenzel Jakob's pcg32.h) — the
+// published generator restated: LCG state, XSH-RR output, log-time skip-ahead.
+struct Pcg32 {
+  unsigned long long state, inc;
+  __device__ unsigned int next_uint() {
+    const unsigned long long old = state;
+    state = old * 0x5851f42d4c957f2dULL + inc;
+    const unsigned int xs = (unsigned int)(((old >> 18u) ^ old) >> 27u);
+    const unsigned int rot = (unsigned int)(old >> 59u);
+    return (xs >> rot) | (xs << ((~rot + 1u) & 31));
+  }
+  __device__ float next_float() { return __uint_as_float((next_uint() >> 9) | 0x3f800000u) - 1.0f; }
+  __device__ void advance(unsigned long long delta) {
+    unsigned long long cur_mult = 0x5851f42d4c957f2dULL, cur_plus = inc, acc_mult = 1u, acc_plus = 0u;
+    while (delta > 0) {
+      if (delta & 1) {
+        acc_mult *= cur_mult;
+        acc_plus = acc_plus * cur_mult + cur_plus;
+      }
+      cur_plus = (cur_mult + 1) * cur_plus;
+      cur_mult *= cur_mult;
+      delta >>= 1;
+    }
+    state = acc_mult * state + acc_plus;
+  }
+};
+
+// RaySamplerGPU.cuh:39-139.  Without jitter every sample is independent: lanes =
+// samples.  With jitter t_i = lerp(t_{i-1}, t_i, u) chains through the ray, and the
+// reference's per-thread rng.advance(ray) + next_float() sequence is reproduced by
+// lane 0 serially (training-time only).
+__global__ void sample_bg_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                 const float* __restrict__ t_start_in, float t_far, int ns,
+                                 int jitter, unsigned long long rng_state,
+                                 unsigned long long rng_inc, float* __restrict__ ray_max_dt,
+                                 float* __restrict__ s3d, float* __restrict__ sdirs,
+                                 float* __restrict__ sz, int* __restrict__ start_end, int N) {
+  const int l = threadIdx.x & (SUB - 1);
+  const long long ray = ((long long)blockIdx.x * PK_BLOCK + threadIdx.x) / SUB;
+  if (ray >= N) return;
+  const float eps = 1e-6f;
+  const float t_start = t_start_in[ray];
+  const float ox = rays_o[3 * ray], oy = rays_o[3 * ray + 1], oz = rays_o[3 * ray + 2];
+  const float dx = rays_d[3 * ray], dy = rays_d[3 * ray + 1], dz = rays_d[3 * ray + 2];
+  // delta_s = 1.0 / (n - 1) is a double expression assigned to float; s -= delta_s in float
+  const float delta_s = (float)(1.0 / (double)(ns - 1));
+  const long long base = ray * ns;
+  if (!jitter) {
+    // s_i by the same serial float subtractions as the reference (i is small)
+    float max_dt = 0.f;
+    for (int c = 0; c < ns; c += SUB) {
+      const int i = c + l;
+      float s = 1.0f;
+      for (int k = 0; k < i && k < ns; ++k) s -= delta_s;
+      float t = (float)(1.0 / (double)(s + eps) - 1.0);
+      t += t_start;
+      t = fminf(fmaxf(t, t_start), t_far);
+      float tp = __shfl_up(t, 1, SUB);
+      if (l == 0) {
+        // previous chunk's last t (or t_start for the first sample)
+        float sp = 1.0f;
+        for (int k = 0; k < i - 1; ++k) sp -= delta_s;
+        float tq = (float)(1.0 / (double)(sp + eps) - 1.0) + t_start;
+        tp = i == 0 ? t_start : fminf(fmaxf(tq, t_start), t_far);
+      }
+      if (i < ns) {
+        sz[base + i] = t;
+        s3d[3 * (base + i)] = ox + t * dx;
+        s3d[3 * (base + i) + 1] = oy + t * dy;
+        s3d[3 * (base + i) + 2] = oz + t * dz;
+        sdirs[3 * (base + i)] = dx;
+        sdirs[3 * (base + i) + 1] = dy;
+        sdirs[3 * (base + i) + 2] = dz;
+        max_dt = fmaxf(max_dt, t - tp);
+      }
+    }
+#pragma unroll
+    for (int off = SUB / 2; off > 0; off >>= 1) max_dt = fmaxf(max_dt, __shfl_xor(max_dt, off, SUB));
+    if (l == 0) ray_max_dt[ray] = max_dt;
+  } else if (l == 0) {
+    Pcg32 rng{rng_state, rng_inc};
+    float s = 1.0f, t_prec = t_start, max_dt = 0.f;
+    for (int i = 0; i < ns; ++i) {
+      float t = (float)(1.0 / (double)(s + eps) - 1.0);
+      t += t_start;
+      t = fminf(fmaxf(t, t_start), t_far);
+      if (i != 0 && i != ns - 1) {
+        rng.advance((unsigned long long)ray);
+        const float u = rng.next_float();
+        t = t_prec + u * (t - t_prec);   // helper_math lerp: a + t*(b-a)
+      }
+      sz[base + i] = t;
+      s3d[3 * (base + i)] = ox + t * dx;
+      s3d[3 * (base + i) + 1] = oy + t * dy;
+      s3d[3 * (base + i) + 2] = oz + t * dz;
+      sdirs[3 * (base + i)] = dx;
+      sdirs[3 * (base + i) + 1] = dy;
+      sdirs[3 * (base + i) + 2] = dz;
+      s -= delta_s;
+      max_dt = fmaxf(max_dt, t - t_prec);
+      t_prec = t;
+    }
+    ray_max_dt[ray] = max_dt;
+  }
+  if (l == 0) {
+    start_end[2 * ray] = (int)base;
+    start_end[2 * ray + 1] = (int)(base + ns);
+  }
+}
+
+// RaySamplerGPU.cuh:528-592 (scale 2 contraction)
+__global__ void contract_kernel(const float* __restrict__ ray_o, const int* __restrict__ start_end,
+                                const float* __restrict__ s3d, const float* __restrict__ sz,
+                                float* __restrict__ o3d, float* __restrict__ oz, int N) {
+  PK_RAY_PROLOGUE();
+  if (n <= 0) return;
+  const float cx = ray_o[3 * ray], cy = ray_o[3 * ray + 1], cz = ray_o[3 * ray + 2];
+  for (int i = l; i < n; i += SUB) {
+    const long long s = i0 + i;
+    float px = s3d[3 * s], py = s3d[3 * s + 1], pz = s3d[3 * s + 2];
+    float z = sz[s];
+    const float sx = px * 2.0f, sy = py * 2.0f, sz2 = pz * 2.0f;
+    const float norm = sqrtf((sx * sx + sy * sy) + sz2 * sz2);
+    if (norm > 1.0f) {
+      const float factor = 2.0f - 1.0f / norm;
+      px = (factor * px) / norm;
+      py = (factor * py) / norm;
+      pz = (factor * pz) / norm;
+      const float ex = px - cx, ey = py - cy, ez = pz - cz;
+      z = sqrtf((ex * ex + ey * ey) + ez * ez);
+    }
+    o3d[3 * s] = px;
+    o3d[3 * s + 1] = py;
+    o3d[3 * s + 2] = pz;
+    oz[s] = z;
+  }
+}
+
+inline dim3 pk_grid(int N) { return dim3(vsa_div_up((long long)N * SUB, PK_BLOCK)); }
+
+}  // namespace
+
+#define PK_CHECK(cond) \
+  if (!(cond)) return VSA_ERR_ARG
+#define PK_LAUNCH(kernel, N, ...)                                                          \
+  if ((N) == 0) return VSA_OK;                                                             \
+  hipLaunchKernelGGL(kernel, pk_grid(N), dim3(PK_BLOCK), 0, (hipStream_t)stream, __VA_ARGS__); \
+  VSA_RETURN_LAUNCH_STATUS()
+
+extern "C" int vsa_packed_cumprod_fwd(const int32_t* start_end, const float* one_minus_alpha,
+                                      float* transmittance, float* bg_transmittance, int nr_rays,
+                                      void* stream) {
+  PK_CHECK(nr_rays >= 0 && start_end && one_minus_alpha && transmittance && bg_transmittance);
+  PK_LAUNCH(cumprod_fwd_kernel, nr_rays, start_end, one_minus_alpha, transmittance,
+            bg_transmittance, nr_rays);
+}
+extern "C" int vsa_packed_cumprod_bwd(const int32_t* start_end, const float* g_bg_transmittance,
+                                      const float* one_minus_alpha, const float* bg_transmittance,
+                                      const float* cumsum_lv, float* g_one_minus_alpha,
+                                      int nr_rays, void* stream) {
+  PK_CHECK(nr_rays >= 0 && start_end && g_bg_transmittance && one_minus_alpha && bg_transmittance &&
+           cumsum_lv && g_one_minus_alpha);
+  PK_LAUNCH(cumprod_bwd_kernel, nr_rays, start_end, g_bg_transmittance, one_minus_alpha,
+            bg_transmittance, cumsum_lv, g_one_minus_alpha, nr_rays);
+}
+extern "C" int vsa_packed_cumsum(const int32_t* start_end, const float* values, int inverse,
+                                 float* out, int nr_rays, void* stream) {
+  PK_CHECK(nr_rays >= 0 && start_end && values && out);
+  PK_LAUNCH(cumsum_kernel, nr_rays, start_end, values, inverse, out, nr_rays);
+}
+extern "C" int vsa_packed_integrate_fwd(const int32_t* start_end, const float* values,
+                                        const float* weights, float* out, int nr_rays, int dim,
+                                        void* stream) {
+  PK_CHECK(nr_rays >= 0 && start_end && values && weights && out && (dim == 1 || dim == 3));
+  if (dim == 1) {
+    PK_LAUNCH(integrate_fwd_kernel<1>, nr_rays, start_end, values, weights, out, nr_rays);
+  }
+  PK_LAUNCH(integrate_fwd_kernel<3>, nr_rays, start_end, values, weights, out, nr_rays);
+}
+extern "C" int vsa_packed_integrate_bwd(const int32_t* start_end, const float* g_out,
+                                        const float* values, const float* weights,
+                                        float* g_values, float* g_weights, int nr_rays, int dim,
+                                        int bug_compat, void* stream) {
+  PK_CHECK(nr_rays >= 0 && start_end && g_out && values && weights && g_values && g_weights &&
+           (dim == 1 || dim == 3));
+  if (dim == 1) {
+    PK_LAUNCH(integrate_bwd_kernel<1>, nr_rays, start_end, g_out, values, weights, g_values,
+              g_weights, nr_rays, bug_compat);
+  }
+  PK_LAUNCH(integrate_bwd_kernel<3>, nr_rays, start_end, g_out, values, weights, g_values,
+            g_weights, nr_rays, bug_compat);
+}
+extern "C" int vsa_packed_median_depth(const int32_t* start_end, const float* samples_z,
+                                       const float* weights, float threshold, float* out,
+                                       int nr_rays, int fallback_compat, void* stream) {
+  PK_CHECK(nr_rays >= 0 && start_end && samples_z && weights && out);
+  PK_LAUNCH(median_depth_kernel, nr_rays, start_end, samples_z, weights, threshold, out, nr_rays,
+            fallback_compat);
+}
+extern "C" int vsa_packed_update_dt(const int32_t* start_end, const float* ray_max_dt,
+                                    const float* ray_exit, const float* samples_z,
+                                    int is_background, float* samples_dt, int nr_rays,
+                                    void* stream) {
+  PK_CHECK(nr_rays >= 0 && start_end && ray_max_dt && ray_exit && samples_z && samples_dt);
+  PK_LAUNCH(update_dt_kernel, nr_rays, start_end, ray_max_dt, ray_exit, samples_z, is_background,
+            samples_dt, nr_rays);
+}
+extern "C" int vsa_sample_bg(const float* rays_o, const float* rays_d, const float* ray_t_start,
+                             float ray_t_far, int nr_samples_per_ray, int jitter,
+                             uint64_t rng_state, uint64_t rng_inc, float* ray_max_dt,
+                             float* samples_3d, float* samples_dirs, float* samples_z,
+                             int32_t* ray_start_end_idx, int nr_rays, void* stream) {
+  PK_CHECK(nr_rays >= 0 && nr_samples_per_ray >= 2 && rays_o && rays_d && ray_t_start &&
+           ray_max_dt && samples_3d && samples_dirs && samples_z && ray_start_end_idx);
+  PK_LAUNCH(sample_bg_kernel, nr_rays, rays_o, rays_d, ray_t_start, ray_t_far, nr_samples_per_ray,
+            jitter, (unsigned long long)rng_state, (unsigned long long)rng_inc, ray_max_dt,
+            samples_3d, samples_dirs, samples_z, ray_start_end_idx, nr_rays);
+}
+extern "C" int vsa_contract_samples(const float* ray_o, const int32_t* start_end,
+                                    const float* samples_3d, const float* samples_z,
+                                    float* out_samples_3d, float* out_samples_z, int nr_rays,
+                                    void* stream) {
+  PK_CHECK(nr_rays >= 0 && ray_o && start_end && samples_3d && samples_z && out_samples_3d &&
+           out_samples_z);
+  PK_LAUNCH(contract_kernel, nr_rays, ray_o, start_end, samples_3d, samples_z, out_samples_3d,
+            out_samples_z, nr_rays);
+}

@@ -1,0 +1,355 @@
+"""Mirror of the reference's pybind11 module `volsurfs` (src/PyBridge.cxx:19-139)
+for the classes the K-shell path reaches: RaySamplesPacked, VolumeRendering,
+RaySampler — same class / method names, argument order and return shapes, on the
+HIP kernels of libvolsurfs_hip.so.  Methods of the reference surface that only
+the sibling methods (nerf / surf / offsets_surfs) use raise NotImplementedError
+(SURVEY §8f row 4); OccupancyGrid is not executed by VolSurfs.render_rays (A12).
+
+Differences a caller can observe: contract violations raise (the reference CHECKs
+abort the process), kernels are asynchronous on the current stream.
+"""
+import torch
+
+from . import _lib
+
+
+def _dev():
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class RaySamplesPacked:
+    """include/volsurfs/RaySamplesPacked.cuh:7-80; ctor src/RaySamplesPacked.cu:13-48
+    (everything initialised to -1)."""
+
+    def __init__(self, nr_rays, max_nr_samples, first_sample_idx=0, values_dim=0):
+        d = _dev()
+        f = lambda *s: torch.full(s, -1.0, device=d)
+        self.samples_idx = torch.arange(first_sample_idx, max_nr_samples + first_sample_idx,
+                                        dtype=torch.int32, device=d).unsqueeze(1)
+        self.samples_3d, self.samples_dirs = f(max_nr_samples, 3), f(max_nr_samples, 3)
+        self.samples_z, self.samples_dt = f(max_nr_samples, 1), f(max_nr_samples, 1)
+        self.ray_start_end_idx = torch.full((nr_rays, 2), -1, dtype=torch.int32, device=d)
+        self.ray_o, self.ray_d = f(nr_rays, 3), f(nr_rays, 3)
+        self.ray_enter, self.ray_exit, self.ray_max_dt = f(nr_rays, 1), f(nr_rays, 1), f(nr_rays, 1)
+        self.samples_values = f(max_nr_samples, values_dim)
+        self.has_samples_values, self.has_dt, self.is_compacted = False, False, True
+        self._nr_rays, self._max_nr_samples, self._values_dim = nr_rays, max_nr_samples, values_dim
+
+    def get_nr_rays(self):
+        return self._nr_rays
+
+    def get_max_nr_samples(self):
+        return self._max_nr_samples
+
+    def get_values_dim(self):
+        return self._values_dim
+
+    def get_ray_start_end_idx(self):
+        return self.ray_start_end_idx
+
+    def get_ray_o(self):
+        return self.ray_o
+
+    def get_ray_d(self):
+        return self.ray_d
+
+    def get_ray_enter(self):
+        return self.ray_enter
+
+    def get_ray_exit(self):
+        return self.ray_exit
+
+    def get_ray_max_dt(self):
+        if not self.has_dt:
+            raise ValueError("ray_max_dt is not set")          # RaySamplesPacked.cu:58-61
+        return self.ray_max_dt
+
+    def get_nr_samples_per_ray(self):
+        return (self.ray_start_end_idx[:, 1] - self.ray_start_end_idx[:, 0]).unsqueeze(1)
+
+    def get_total_nr_samples(self):
+        if self._nr_rays == 0:
+            return 0
+        return int((self.ray_start_end_idx[:, 1] - self.ray_start_end_idx[:, 0]).sum().item())
+
+    def is_empty(self):
+        return self.get_total_nr_samples() == 0
+
+    def get_samples_values(self):
+        return self.samples_values
+
+    def are_samples_values_set(self):
+        return self.has_samples_values
+
+    def set_samples_values(self, v):
+        self.samples_values, self.has_samples_values, self._values_dim = v, True, v.shape[1]
+
+    def remove_samples_values(self):
+        self.samples_values = torch.full((self._max_nr_samples, 0), -1.0, device=_dev())
+        self.has_samples_values, self._values_dim = False, 0
+
+    def _ray_slice(self, t, ray_idx):
+        a, b = self.ray_start_end_idx[ray_idx].tolist()
+        return t[a:b]
+
+    def get_ray_samples_idx(self, i):
+        return self._ray_slice(self.samples_idx, i)
+
+    def get_ray_samples_3d(self, i):
+        return self._ray_slice(self.samples_3d, i)
+
+    def get_ray_samples_dirs(self, i):
+        return self._ray_slice(self.samples_dirs, i)
+
+    def get_ray_samples_z(self, i):
+        return self._ray_slice(self.samples_z, i)
+
+    def get_ray_samples_dt(self, i):
+        return self._ray_slice(self.samples_dt, i)
+
+    def get_ray_samples_values(self, i):
+        return self._ray_slice(self.samples_values, i)
+
+    def copy(self):
+        """RaySamplesPacked.cu:344-369 (deep clone)."""
+        c = RaySamplesPacked.__new__(RaySamplesPacked)
+        for k, v in self.__dict__.items():
+            setattr(c, k, v.clone() if isinstance(v, torch.Tensor) else v)
+        return c
+
+    def update_dt(self, is_background):
+        """RaySamplesPacked.cu:396-461."""
+        if not self.is_compacted:
+            raise _lib.VolsurfsHipError("RaySamplesPacked must be compacted before update_dt")
+        _lib.call("vsa_packed_update_dt", self.ray_start_end_idx, self.ray_max_dt, self.ray_exit,
+                  self.samples_z, bool(is_background), self.samples_dt, self._nr_rays,
+                  _lib.stream_ptr())
+        self.has_dt = True
+
+    def compact_to_valid_samples(self):
+        if self.is_compacted:
+            return self
+        raise NotImplementedError("compact_to_valid_samples: only produced by the fg samplers "
+                                  "(nerf/surf/offsets_surfs), SURVEY §8f row 4")
+
+
+def _check_pack(p, *tensors):
+    if not p.is_compacted:
+        raise _lib.VolsurfsHipError("RaySamplesPacked must be compacted")
+    for t, cols in tensors:
+        if t.dim() != 2 or t.shape[1] != cols or t.dtype != torch.float32 or not t.is_cuda:
+            raise _lib.VolsurfsHipError(f"expected a CUDA float32 [S,{cols}] tensor, got {tuple(t.shape)} {t.dtype}")
+
+
+class VolumeRendering:
+    """include/volsurfs/VolumeRendering.cuh:69-97: static methods, same order of arguments."""
+    bug_compat = False   # reproduce VolumeRenderingGPU.cuh:1021 / :407
+
+    @staticmethod
+    def cumprod_one_minus_alpha_to_transmittance(pack, one_minus_alpha):
+        _check_pack(pack, (one_minus_alpha, 1))
+        N, S = pack.get_nr_rays(), one_minus_alpha.shape[0]
+        T = torch.zeros(S, 1, device=one_minus_alpha.device)
+        bgT = torch.ones(N, 1, device=one_minus_alpha.device)
+        _lib.call("vsa_packed_cumprod_fwd", pack.ray_start_end_idx, one_minus_alpha.contiguous(), T,
+                  bgT, N, _lib.stream_ptr())
+        return T, bgT
+
+    @staticmethod
+    def cumprod_one_minus_alpha_to_transmittance_backward(grad_transmittance, grad_bg_transmittance,
+                                                          pack, alpha, transmittance,
+                                                          bg_transmittance, cumsumLV):
+        S = alpha.shape[0]
+        if grad_transmittance.shape[0] != S:
+            raise _lib.VolsurfsHipError("grad_transmittance should have size nr_samples_total x 1")
+        g = torch.zeros(S, 1, device=alpha.device)
+        _lib.call("vsa_packed_cumprod_bwd", pack.ray_start_end_idx, grad_bg_transmittance.contiguous(),
+                  alpha.contiguous(), bg_transmittance.contiguous(), cumsumLV.contiguous(), g,
+                  pack.get_nr_rays(), _lib.stream_ptr())
+        return g
+
+    @staticmethod
+    def cumsum_over_rays(pack, values, inverse):
+        _check_pack(pack, (values, 1))
+        out = torch.zeros_like(values)
+        _lib.call("vsa_packed_cumsum", pack.ray_start_end_idx, values.contiguous(), bool(inverse),
+                  out, pack.get_nr_rays(), _lib.stream_ptr())
+        return out
+
+    @staticmethod
+    def _integrate(pack, values, weights, dim):
+        _check_pack(pack, (values, dim), (weights, 1))
+        out = torch.zeros(pack.get_nr_rays(), dim, device=values.device)
+        _lib.call("vsa_packed_integrate_fwd", pack.ray_start_end_idx, values.contiguous(),
+                  weights.contiguous(), out, pack.get_nr_rays(), dim, _lib.stream_ptr())
+        return out
+
+    @staticmethod
+    def integrate_with_weights_1d(pack, values, weights):
+        return VolumeRendering._integrate(pack, values, weights, 1)
+
+    @staticmethod
+    def integrate_with_weights_3d(pack, values, weights):
+        return VolumeRendering._integrate(pack, values, weights, 3)
+
+    @staticmethod
+    def _integrate_backward(grad_result, pack, values, weights, dim):
+        if grad_result.shape != (pack.get_nr_rays(), dim):
+            raise _lib.VolsurfsHipError(f"grad_result should have size nr_rays x {dim}")
+        gv, gw = torch.zeros_like(values), torch.zeros_like(weights)
+        _lib.call("vsa_packed_integrate_bwd", pack.ray_start_end_idx, grad_result.contiguous(),
+                  values.contiguous(), weights.contiguous(), gv, gw, pack.get_nr_rays(), dim,
+                  bool(VolumeRendering.bug_compat), _lib.stream_ptr())
+        return gv, gw
+
+    @staticmethod
+    def integrate_with_weights_1d_backward(grad_result, pack, values, weights, result):
+        return VolumeRendering._integrate_backward(grad_result, pack, values, weights, 1)
+
+    @staticmethod
+    def integrate_with_weights_3d_backward(grad_result, pack, values, weights, result):
+        return VolumeRendering._integrate_backward(grad_result, pack, values, weights, 3)
+
+    @staticmethod
+    def median_depth_over_rays(pack, weights, threshold):
+        _check_pack(pack, (weights, 1))
+        out = torch.zeros(pack.get_nr_rays(), 1, device=weights.device)
+        _lib.call("vsa_packed_median_depth", pack.ray_start_end_idx, pack.samples_z,
+                  weights.contiguous(), float(threshold), out, pack.get_nr_rays(),
+                  bool(VolumeRendering.bug_compat), _lib.stream_ptr())
+        return out
+
+    @staticmethod
+    def _todo(name):
+        raise NotImplementedError(f"VolumeRendering.{name}: used only by nerf/surf/offsets_surfs "
+                                  "(SURVEY §8f row 4), not on the VolSurfs path")
+
+    sdf2alpha = staticmethod(lambda *a: VolumeRendering._todo("sdf2alpha"))
+    sum_over_rays = staticmethod(lambda *a: VolumeRendering._todo("sum_over_rays"))
+    compute_cdf = staticmethod(lambda *a: VolumeRendering._todo("compute_cdf"))
+    importance_sample = staticmethod(lambda *a: VolumeRendering._todo("importance_sample"))
+    combine_ray_samples_packets = staticmethod(lambda *a: VolumeRendering._todo("combine_ray_samples_packets"))
+
+
+class _Pcg32State:
+    """Process-global RNG of the reference's RaySampler (static pcg32 m_rng,
+    src/RaySampler.cu:19), advanced by 2^32 after every jittered call (:139-142)."""
+    MULT, M64 = 0x5851f42d4c957f2d, (1 << 64) - 1
+
+    def __init__(self):
+        self.state, self.inc = 0x853c49e6748fea9b, 0xda3e39cb94b95bdb
+
+    def advance(self, delta=1 << 32):
+        cur_mult, cur_plus, acc_mult, acc_plus = self.MULT, self.inc, 1, 0
+        while delta > 0:
+            if delta & 1:
+                acc_mult = (acc_mult * cur_mult) & self.M64
+                acc_plus = (acc_plus * cur_mult + cur_plus) & self.M64
+            cur_plus = ((cur_mult + 1) * cur_plus) & self.M64
+            cur_mult = (cur_mult * cur_mult) & self.M64
+            delta >>= 1
+        self.state = (acc_mult * self.state + acc_plus) & self.M64
+
+
+class RaySampler:
+    """include/volsurfs/RaySampler.cuh:15-58."""
+    m_rng = _Pcg32State()
+
+    @staticmethod
+    def compute_samples_bg(rays_o, rays_d, ray_t_start, ray_t_far, nr_samples_per_ray, jitter_samples):
+        """src/RaySampler.cu:70-156."""
+        import ctypes
+        if rays_o.dim() != 2 or rays_d.dim() != 2 or ray_t_start.dim() != 2:
+            raise _lib.VolsurfsHipError("rays_o/rays_d should be nr_rays x 3, ray_t_start nr_rays x 1")
+        N = rays_o.shape[0]
+        p = RaySamplesPacked(N, N * nr_samples_per_ray, 0, 0)
+        p.ray_o, p.ray_d = rays_o.clone().contiguous(), rays_d.clone().contiguous()
+        p.ray_enter = ray_t_start.clone().contiguous()
+        p.ray_exit = torch.full((N, 1), float(ray_t_far), device=rays_o.device)
+        p.is_compacted = True
+        rng = RaySampler.m_rng
+        _lib.call("vsa_sample_bg", p.ray_o, p.ray_d, p.ray_enter, float(ray_t_far),
+                  int(nr_samples_per_ray), bool(jitter_samples), ctypes.c_uint64(rng.state),
+                  ctypes.c_uint64(rng.inc), p.ray_max_dt, p.samples_3d, p.samples_dirs, p.samples_z,
+                  p.ray_start_end_idx, N, _lib.stream_ptr())
+        if jitter_samples:
+            rng.advance()
+        return p
+
+    @staticmethod
+    def contract_samples(pack):
+        """src/RaySampler.cu:336-381: copy, contract (scale 2), update_dt(True)."""
+        if not pack.is_compacted:
+            raise _lib.VolsurfsHipError("RaySamplesPacked should be compacted before contract_samples")
+        if pack.get_nr_rays() == 0:
+            raise _lib.VolsurfsHipError("RaySamplesPacked must not be empty before contract_samples")
+        c = pack.copy()
+        _lib.call("vsa_contract_samples", pack.ray_o, pack.ray_start_end_idx, pack.samples_3d,
+                  pack.samples_z, c.samples_3d, c.samples_z, pack.get_nr_rays(), _lib.stream_ptr())
+        c.update_dt(True)
+        return c
+
+    @staticmethod
+    def _todo(name):
+        raise NotImplementedError(f"RaySampler.{name}: used only by nerf/surf/offsets_surfs "
+                                  "(SURVEY §8f row 4)")
+
+    compute_samples_fg = staticmethod(lambda *a: RaySampler._todo("compute_samples_fg"))
+    compute_samples_fg_in_grid_occupied_regions = staticmethod(
+        lambda *a: RaySampler._todo("compute_samples_fg_in_grid_occupied_regions"))
+    init_with_one_sample_per_ray = staticmethod(lambda *a: RaySampler._todo("init_with_one_sample_per_ray"))
+    uncontract_samples = staticmethod(lambda *a: RaySampler._todo("uncontract_samples"))
+
+
+# ---- autograd glue, same classes as volume_rendering/volume_rendering_funcs.py:91-241
+class CumprodOneMinusAlphaToTransmittanceFunc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pack, alpha):
+        T, bgT = VolumeRendering.cumprod_one_minus_alpha_to_transmittance(pack, alpha)
+        ctx.save_for_backward(alpha, T, bgT)
+        ctx.pack = pack
+        return T, bgT
+
+    @staticmethod
+    def backward(ctx, g_T, g_bgT):
+        alpha, T, bgT = ctx.saved_tensors
+        lv = g_T * T
+        cumsum_lv = VolumeRendering.cumsum_over_rays(ctx.pack, lv, True)
+        g = VolumeRendering.cumprod_one_minus_alpha_to_transmittance_backward(
+            g_T, g_bgT, ctx.pack, alpha, T, bgT, cumsum_lv)
+        ctx.pack = None
+        return None, g
+
+
+class IntegrateWithWeights3DFunc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pack, values, weights):
+        out = VolumeRendering.integrate_with_weights_3d(pack, values, weights)
+        ctx.save_for_backward(values, weights, out)
+        ctx.pack = pack
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        values, weights, out = ctx.saved_tensors
+        gv, gw = VolumeRendering.integrate_with_weights_3d_backward(g.contiguous(), ctx.pack, values,
+                                                                    weights, out)
+        ctx.pack = None
+        return None, gv, gw
+
+
+class IntegrateWithWeights1DFunc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pack, values, weights):
+        out = VolumeRendering.integrate_with_weights_1d(pack, values, weights)
+        ctx.save_for_backward(values, weights, out)
+        ctx.pack = pack
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        values, weights, out = ctx.saved_tensors
+        gv, gw = VolumeRendering.integrate_with_weights_1d_backward(g.contiguous(), ctx.pack, values,
+                                                                    weights, out)
+        ctx.pack = None
+        return None, gv, gw
