@@ -67,3 +67,30 @@ def test_render_chunks_equal_one_shot():
         assert torch.equal(full[k], part[k]), k
     with pytest.raises(Exception):
         m.render_rays(torch.cat([o, o]), torch.cat([d, d]))    # more rays than the buffers hold
+
+
+@pytest.mark.gpu
+def test_learned_background_path():
+    """bg_color None -> render_contracted_bg through the packed ops (volsurfs.py:690-702)."""
+    from volsurfs_amd.background import BoundingBox
+    from volsurfs_amd.camera import pinhole_rays
+    from volsurfs_amd.mesh import nested_shells
+    from volsurfs_amd.methods import VolSurfs
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4)).cuda()
+
+    def bg(p, d, it):
+        y = net(torch.cat([p, d], 1))
+        return torch.sigmoid(y[:, :3]), torch.nn.functional.softplus(y[:, 3:])
+    m = VolSurfs(nested_shells(K=2, subdiv=2), max_rays=4096, textures_res=(128, 64, 32, 16),
+                 bg_color=None, bg_model=bg, bounding_primitive=BoundingBox(1.0))
+    m.is_training = False
+    o, d = pinhole_rays(32, 32, focal=50.0)
+    rt = m.render_rays(o, d)["renders"]["ray_traced"]
+    assert rt["rgb_bg"].shape == (1024, 3) and rt["rgb"].shape == (1024, 3)
+    miss = rt["surfs_alpha"].sum((1, 2)) == 0
+    # where no shell is hit the pixel is the (fp16-rounded) background colour
+    assert torch.equal(rt["rgb"][miss], rt["rgb_bg"][miss])
+    rt["rgb"].sum().backward()
+    assert all(p.grad is not None and p.grad.abs().sum() > 0 for p in net.parameters())
+    with pytest.raises(Exception):
+        VolSurfs(nested_shells(K=1, subdiv=1), bg_color=None)

@@ -179,3 +179,43 @@ def test_hip_glue_matches_reference_fixture(golden_dir):
     np.testing.assert_allclose(pred.detach().cpu().numpy(), z["pred"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(rgb.grad.cpu().numpy(), z["g_rgb"], rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(density.grad.cpu().numpy(), z["g_density"], rtol=2e-3, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_render_contracted_bg_end_to_end_vs_oracle():
+    """background.py:31-141 with a tiny stand-in radiance model: HIP packed path vs the
+    oracle's serial restatement, values and gradients."""
+    from volsurfs_amd.background import BoundingBox, intersect_bounding_primitive, render_contracted_bg
+    torch.manual_seed(0)
+    N = 500
+    o = torch.zeros(N, 3, device="cuda") + torch.tensor([0.0, 0.0, -0.2], device="cuda")
+    d = torch.nn.functional.normalize(torch.randn(N, 3, device="cuda"), dim=-1)
+    rc = intersect_bounding_primitive(BoundingBox(1.0), o, d)
+    assert rc["is_hit"].all() and (rc["t_far"] > 0).all()
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4)).cuda()
+
+    def model_bg(p, dirs, it):
+        y = net(torch.cat([p, dirs], 1))
+        return torch.sigmoid(y[:, :3]), torch.nn.functional.softplus(y[:, 3:])
+    res = render_contracted_bg(model_bg, rc, 32)
+    res["pred_rgb"].sum().backward()
+    g_hip = [p.grad.clone() for p in net.parameters()]
+    # oracle: same model on the CPU, packed ops from oracle/packed.py, autograd by torch
+    s = OP.sample_bg(o.cpu().numpy(), d.cpu().numpy(), rc["t_far"].cpu().numpy()[:, 0], 100.0, 32)
+    c3d, cz = OP.contract(o.cpu().numpy(), s["ray_start_end_idx"], s["samples_3d"], s["samples_z"])
+    dt = OP.update_dt(s["ray_start_end_idx"], s["ray_max_dt"], np.full(N, 100.0, np.float32), cz, True)
+    netc = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4))
+    netc.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    y = netc(torch.cat([torch.from_numpy(c3d), torch.from_numpy(s["samples_dirs"])], 1))
+    rgb, dens = torch.sigmoid(y[:, :3]), torch.nn.functional.softplus(y[:, 3:])
+    alpha = 1.0 - torch.exp(-dens * torch.from_numpy(dt)[:, None])
+    a = ((1 - alpha) + 1e-6).view(N, 32)
+    T = torch.cat([torch.ones(N, 1), torch.cumprod(a[:, :-1], 1)], 1).reshape(-1, 1)
+    pred = ((alpha * T) * rgb).view(N, 32, 3).sum(1)
+    np.testing.assert_allclose(res["pred_rgb"].detach().cpu().numpy(), pred.detach().numpy(),
+                               rtol=1e-4, atol=1e-5)
+    pred.sum().backward()
+    for gh, pc in zip(g_hip, netc.parameters()):
+        np.testing.assert_allclose(gh.cpu().numpy(), pc.grad.numpy(), rtol=2e-3, atol=2e-4)
+    md = OP.median_depth(s["ray_start_end_idx"], s["samples_z"], (alpha * T).detach().numpy(), 0.5)
+    assert (res["median_depth"].cpu().numpy()[:, 0] != md).mean() < 0.01

@@ -53,7 +53,7 @@ class VolSurfs(torch.nn.Module):
     def __init__(self, tensor_meshes, max_rays=16384, sh_degree=3, transp_view_dep=True,
                  sh_range=(15, 15, 15, 15), textures_res=(2048, 1024, 512, 256),
                  is_inner_mesh_solid=False, with_alpha_decay=True, bg_color=(1.0, 1.0, 1.0),
-                 lr=1e-3, seed=42):
+                 bg_model=None, bounding_primitive=None, nr_samples_bg=32, lr=1e-3, seed=42):
         super().__init__()
         self.tensor_meshes = tensor_meshes
         self.nr_meshes = len(tensor_meshes)
@@ -70,7 +70,13 @@ class VolSurfs(torch.nn.Module):
                                       inner_solid=is_inner_mesh_solid,
                                       with_alpha_decay=with_alpha_decay, device=dev, seed=seed)
         self.max_rays = max_rays
-        self.bg_color = torch.tensor([bg_color], device=dev, dtype=torch.float32)   # volsurfs.py:686-689
+        # volsurfs.py:686-702: constant colour, or (bg_color None) a learned contracted
+        # background model rendered through the packed ops (utils/background.py)
+        self.bg_color = None if bg_color is None else torch.tensor([bg_color], device=dev,
+                                                                   dtype=torch.float32)
+        self.bg_model, self.bounding_primitive, self.nr_samples_bg = bg_model, bounding_primitive, nr_samples_bg
+        if self.bg_color is None and (bg_model is None or bounding_primitive is None):
+            raise _lib.VolsurfsHipError("bg_color=None needs bg_model and bounding_primitive")
         self.grad_scale = 16384.0
         self.is_training = True
         self.lr = lr
@@ -97,7 +103,14 @@ class VolSurfs(torch.nn.Module):
         hit_t, hit_slot, hit_uv = self.raytracer.trace_all(rays_o, rays_d)     # :476-485, one launch
         rgb_k, alpha_k, normals, tex_uv = _ShadeStage.apply(self.bank.tables, self.bank.weights,
                                                             self, hit_slot, hit_uv, rays_d)
-        out = composite_dense(rgb_k, alpha_k, self.bg_color)                   # :601-640, 704-708
+        if self.bg_color is not None:
+            rgb_bg = self.bg_color
+        else:
+            from .background import intersect_bounding_primitive, render_contracted_bg
+            raycast = intersect_bounding_primitive(self.bounding_primitive, rays_o, rays_d)   # :434
+            rgb_bg = render_contracted_bg(self.bg_model, raycast, self.nr_samples_bg,
+                                          jitter_samples=self.is_training, iter_nr=iter_nr)["pred_rgb"]
+        out = composite_dense(rgb_k, alpha_k, rgb_bg)                          # :601-640, 704-708
         renders = {
             "rgb": out["rgb"], "rgb_fg": out["rgb_fg"], "rgb_bg": out["rgb_bg"],
             "surfs_alpha": out["surfs_alpha"], "surfs_rgb": out["surfs_rgb"],
