@@ -205,10 +205,12 @@ int vsa_nt_mlp_fwd(const vsa_nt_plan* plan, const void* weights_h, const void* f
  * gradients (f16x2, still scaled) and accumulates grad_weights (f32
  * [n_tex][VSA_NT_WEIGHTS_PER_TEX], scaled) with one flush per workgroup.
  * grad_rows is CONSUMED: every row read is reset to zero, so the buffer (zero
- * at allocation) is zero again outside a [vsa_nt_shade_bwd, vsa_nt_mlp_bwd] pair. */
+ * at allocation) is zero again outside a [vsa_nt_shade_bwd, vsa_nt_mlp_bwd] pair.
+ * dfeat_abs_sum (f32 [n_tex][32], zeroed by the caller) += sum over slots of |dF| per
+ * feature row: the overflow bound of vsa_nt_encode_bwd's fixed-point accumulation. */
 int vsa_nt_mlp_bwd(const vsa_nt_plan* plan, const void* weights_h, void* features,
                    const int32_t* seg_start, float* grad_rows, float* grad_weights,
-                   void* stream);
+                   float* dfeat_abs_sum, void* stream);
 
 /* Step 5: per-hit shading from the texel rows (expand LUT -> lerp -> fp16 SH
  * coefficients -> SH eval -> sigmoid -> alpha decay), scattered dense:
@@ -231,9 +233,9 @@ int vsa_nt_shade_bwd(const vsa_nt_plan* plan, const int32_t* hit_slot, const flo
 /* Backward of step 3: grad_tables (f32 [n_tex][level_offset[n]][2]) +=
  * transpose-interpolation of dfeatures (f16x2, same layout as features, holding
  * grad * grad_scale).  Accumulates (caller zeroes grad_tables per optimiser step). */
-int vsa_nt_encode_bwd(const vsa_nt_plan* plan, const void* dfeatures, float grad_scale,
-                      const float* slot_xy, const int32_t* seg_start, float* grad_tables,
-                      void* stream);
+int vsa_nt_encode_bwd(const vsa_nt_plan* plan, const void* dfeatures, const float* dfeat_abs_sum,
+                      float grad_scale, const float* slot_xy, const int32_t* seg_start,
+                      float* grad_tables, void* stream);
 
 /* ------------------------------------------------------------------------
  * A8 / A9 / A11  Packed (ragged) per-ray sample ops of the background path:

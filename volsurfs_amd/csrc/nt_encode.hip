@@ -19,7 +19,7 @@ namespace {
 
 constexpr int ENC_BLOCK = 1024;     // 16 waves: a 128 KiB level pins one workgroup per CU
 constexpr int ENC_UNROLL = 8;       // slots in flight per lane
-constexpr int ENC_SPAN_FWD = 65536;   // slots per workgroup (forward)
+constexpr int ENC_SPAN_FWD = 262144;  // slots per workgroup (forward): amortises staging the level
 constexpr int ENC_SPAN_BWD = 262144;  // slots per workgroup before a flush (backward)
 constexpr unsigned PRIME_Y = 2654435761u;
 constexpr int LDS_ENTRIES = 32768;    // 4-byte entries of LDS a workgroup may use (128 KiB)
@@ -150,12 +150,12 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
 // and summed at the flush.
 template <bool HASHED>
 __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
-    vsa_nt_plan plan, EncLaunch L, const half2_t* __restrict__ dfeatures, float dscale_inv,
+    vsa_nt_plan plan, EncLaunch L, const half2_t* __restrict__ dfeatures,
+    const float* __restrict__ dfeat_abs_sum, float dscale_inv,
     const float2* __restrict__ slot_xy, const int* __restrict__ seg_start,
     float* __restrict__ grad_tables) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   int* s_g = reinterpret_cast<int*>(s_raw);
-  __shared__ float s_red[ENC_BLOCK / 64];
   const int level = L.level0 + (blockIdx.y >> 1), feat = blockIdx.y & 1;
   Work wk;
   if (!decode_work(plan, L, seg_start, blockIdx.x, wk)) return;
@@ -169,20 +169,13 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
   int* my_g = s_g + (threadIdx.x & (copies - 1)) * g.size;   // consecutive lanes -> different copies
   const int type = (wk.tex / VSA_NT_MAX_DEG) & 1;
   const int nl = plan.n_levels;
-  // pass 1: sum |dF| over this workgroup's slots -> fixed-point scale
+  // fixed-point scale from sum |dF| over the WHOLE (texture, level, feature) plane,
+  // accumulated by the MLP backward kernel while it wrote dF (an upper bound for
+  // this workgroup's share; saves a second pass over dF)
   const unsigned* dFw = reinterpret_cast<const unsigned*>(dfeatures + nt_feat_plane_base(plan, type, level));
   const int shift = 16 * feat;
-  float asum = 0.f;
-  for (int slot = first + threadIdx.x; slot < last; slot += ENC_BLOCK) {
-    const unsigned wv = dFw[nt_feat_in_plane(nl, slot)] >> shift;
-    asum += fabsf((float)__builtin_bit_cast(_Float16, (unsigned short)wv));
-  }
-  for (int off = 32; off > 0; off >>= 1) asum += __shfl_down(asum, off, 64);
-  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = asum;
+  const float total = dfeat_abs_sum[wk.tex * 32 + 2 * level + feat] * 1.001f;
   __syncthreads();
-  float total = 0.f;
-#pragma unroll
-  for (int i = 0; i < ENC_BLOCK / 64; ++i) total += s_red[i];
   if (!(total > 0.f)) return;   // nothing to add (uniform across the workgroup)
   int e;
   frexpf(total, &e);                       // total = m * 2^e, m in [0.5, 1)
@@ -307,10 +300,12 @@ extern "C" int vsa_nt_encode_fwd(const vsa_nt_plan* plan, const void* tables_h,
   VSA_RETURN_LAUNCH_STATUS();
 }
 
-extern "C" int vsa_nt_encode_bwd(const vsa_nt_plan* plan, const void* dfeatures, float grad_scale,
+extern "C" int vsa_nt_encode_bwd(const vsa_nt_plan* plan, const void* dfeatures,
+                                 const float* dfeat_abs_sum, float grad_scale,
                                  const float* slot_xy, const int32_t* seg_start,
                                  float* grad_tables, void* stream) {
-  if (!plan || !dfeatures || !slot_xy || !seg_start || !grad_tables) return VSA_ERR_ARG;
+  if (!plan || !dfeatures || !dfeat_abs_sum || !slot_xy || !seg_start || !grad_tables)
+    return VSA_ERR_ARG;
   if (!(grad_scale > 0.f)) return VSA_ERR_ARG;
   int rc = check_levels(plan);
   if (rc) return rc;
@@ -328,14 +323,14 @@ extern "C" int vsa_nt_encode_bwd(const vsa_nt_plan* plan, const void* dfeatures,
     const EncLaunch L = enc_launch(plan, 0, ENC_SPAN_BWD);
     hipLaunchKernelGGL(nt_encode_bwd_kernel<false>, dim3(L.per_model * models, 2 * lh),
                        dim3(ENC_BLOCK), (size_t)LDS_ENTRIES * 4, (hipStream_t)stream, *plan, L, dF,
-                       1.0f / grad_scale, xy, seg_start, grad_tables);
+                       dfeat_abs_sum, 1.0f / grad_scale, xy, seg_start, grad_tables);
   }
   if (lh < plan->n_levels) {
     const EncLaunch L = enc_launch(plan, lh, ENC_SPAN_BWD);
     hipLaunchKernelGGL(nt_encode_bwd_kernel<true>, dim3(L.per_model * models, 2 * (plan->n_levels - lh)),
                        dim3(ENC_BLOCK), (size_t)max_level_size(plan, lh, plan->n_levels) * 4,
-                       (hipStream_t)stream, *plan, L, dF, 1.0f / grad_scale, xy, seg_start,
-                       grad_tables);
+                       (hipStream_t)stream, *plan, L, dF, dfeat_abs_sum, 1.0f / grad_scale, xy,
+                       seg_start, grad_tables);
   }
   VSA_RETURN_LAUNCH_STATUS();
 }

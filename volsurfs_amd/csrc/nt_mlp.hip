@@ -282,7 +282,8 @@ __device__ __forceinline__ void prefetch_features(const vsa_nt_plan& plan,
 __global__ __launch_bounds__(BWD_BLOCK, 1) void nt_mlp_bwd_kernel(
     vsa_nt_plan plan, EncLaunch L, const _Float16* __restrict__ weights,
     unsigned* __restrict__ features, const int* __restrict__ seg_start,
-    float* __restrict__ grad_rows, float* __restrict__ grad_weights) {
+    float* __restrict__ grad_rows, float* __restrict__ grad_weights,
+    float* __restrict__ dfeat_abs_sum) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   half8_t* s_frag = reinterpret_cast<half8_t*>(s_raw);                       // 32 KiB
   _Float16* s_img_all = reinterpret_cast<_Float16*>(s_raw + 32 * 64 * 16);   // 8 x 2 regions
@@ -309,6 +310,7 @@ __global__ __launch_bounds__(BWD_BLOCK, 1) void nt_mlp_bwd_kernel(
     gW2[i][1] = float16_t{0};
   }
 
+  float16_t dabs = {0};   // per-lane sum |dF| per feature row (for the hash-grad fixed point)
   half8_t bx[2], bx_next[2];
   if (t0 < t1) prefetch_features(plan, features, ti.type, wk.first + t0 * 32 + p, wk.last, h, bx_next);
   for (int tile = t0; tile < t1; ++tile) {
@@ -419,6 +421,8 @@ __global__ __launch_bounds__(BWD_BLOCK, 1) void nt_mlp_bwd_kernel(
       for (int q = 0; q < 4; ++q)
         dx = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_frag[(28 + q) * 64 + lane], dh1[q], dx, 0, 0, 0);
       if (valid) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) dabs[reg] += fabsf(dx[reg]);
         unsigned* base = features + nt_feat_plane_base(plan, ti.type, 2 * h) +
                          nt_feat_in_plane(plan.n_levels, slot);
 #pragma unroll
@@ -432,6 +436,16 @@ __global__ __launch_bounds__(BWD_BLOCK, 1) void nt_mlp_bwd_kernel(
           }
       }
     }
+  }
+
+  // ---- sum |dF| per feature row: reduce over the 32 lanes of each half, one atomic per row
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    float v = dabs[reg];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 32);
+    const int f = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    if (p == 0 && v != 0.0f) atomicAdd(&dfeat_abs_sum[tex * 32 + f], v);
   }
 
   // ---- workgroup reduction of the weight gradients in LDS (waves take turns:
@@ -484,8 +498,9 @@ extern "C" int vsa_nt_mlp_fwd(const vsa_nt_plan* plan, const void* weights_h, co
 
 extern "C" int vsa_nt_mlp_bwd(const vsa_nt_plan* plan, const void* weights_h, void* features,
                               const int32_t* seg_start, float* grad_rows, float* grad_weights,
-                              void* stream) {
-  if (!plan || !weights_h || !features || !seg_start || !grad_rows || !grad_weights)
+                              float* dfeat_abs_sum, void* stream) {
+  if (!plan || !weights_h || !features || !seg_start || !grad_rows || !grad_weights ||
+      !dfeat_abs_sum)
     return VSA_ERR_ARG;
   const size_t lds = 32 * 64 * 16 + (size_t)BWD_WAVES * 2 * IMG_HALFS * 2;
   static bool attr_set = false;
@@ -498,6 +513,7 @@ extern "C" int vsa_nt_mlp_bwd(const vsa_nt_plan* plan, const void* weights_h, vo
   dim3 grid(L.per_model * plan->nr_shells * 2);
   hipLaunchKernelGGL(nt_mlp_bwd_kernel, grid, dim3(BWD_BLOCK), lds, (hipStream_t)stream, *plan, L,
                      reinterpret_cast<const _Float16*>(weights_h),
-                     reinterpret_cast<unsigned*>(features), seg_start, grad_rows, grad_weights);
+                     reinterpret_cast<unsigned*>(features), seg_start, grad_rows, grad_weights,
+                     dfeat_abs_sum);
   VSA_RETURN_LAUNCH_STATUS();
 }

@@ -223,10 +223,15 @@ class NeuralTextureBank(torch.nn.Module):
 
     def backward_mlp(self, grad_scale):
         self._gw_scaled.zero_()
+        if getattr(self, "_dfsum", None) is None:
+            self._dfsum = torch.zeros(self.n_tex, 32, device=self.weights.device)
+        else:
+            self._dfsum.zero_()
         _lib.call("vsa_nt_mlp_bwd", ctypes.byref(self.plan), self.weights_h, self.features,
-                  self.seg_start, self.grad_rows, self._gw_scaled, _lib.stream_ptr())
+                  self.seg_start, self.grad_rows, self._gw_scaled, self._dfsum, _lib.stream_ptr())
         self.weights.grad.add_(self._gw_scaled, alpha=1.0 / float(grad_scale))
 
     def backward_encode(self, grad_scale):
-        _lib.call("vsa_nt_encode_bwd", ctypes.byref(self.plan), self.features, float(grad_scale),
-                  self.slot_xy, self.seg_start, self.tables.grad, _lib.stream_ptr())
+        _lib.call("vsa_nt_encode_bwd", ctypes.byref(self.plan), self.features, self._dfsum,
+                  float(grad_scale), self.slot_xy, self.seg_start, self.tables.grad,
+                  _lib.stream_ptr())
