@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--shells", type=int, default=5)
     ap.add_argument("--subdiv", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="time the eager path instead of the HIP-graph replay")
     ap.add_argument("--cpu-sample-rays", type=int, default=4096)
     return ap.parse_args()
 
@@ -108,11 +109,32 @@ def main():
     for _ in range(max(1, args.warmup)):
         step()
     pipe.stats()                       # hit / unique-texel counts for the byte & flop accounting
+    # per-kernel stage times: a few eager steps with events (outside the timed region)
     pipe.reset_stage_timers()
+    for _ in range(3):
+        step(record=True)
+    stages = pipe.stage_report()
+    use_graph = not args.no_graph
+    if use_graph:
+        try:
+            pipe.capture_graph()       # the step is ~25 launches on one stream with no host sync
+            for _ in range(2):
+                pipe.replay()
+        except Exception as e:         # fall back to the (equally fast) eager path
+            print(f"[bench] graph capture failed ({e}); timing the eager path", file=sys.stderr)
+            use_graph = False
+
+    def timed_step():
+        if use_graph:
+            pipe.replay()
+            if world > 1:
+                allreduce_gradients(params, world)
+        else:
+            step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(record=True)
+        timed_step()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -120,7 +142,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 
-    stages = pipe.stage_report()           # name -> dict(ms, bytes, flops)
     if rank == 0:
         total_rays = N * world * args.steps
         value = total_rays / dt / 1e6
@@ -149,7 +170,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": pipe.dtype_desc, "data": "synthetic",
-            "config": pipe.config_desc(world),
+            "config": dict(pipe.config_desc(world), launch="hip-graph replay" if use_graph else "eager"),
             "roofline": roof,
             "stages_ms": {k: round(v["ms"], 4) for k, v in stages.items()},
             "stage_roofline": {k: pipe.stage_roofline(v, HBM_PEAK_GBS, MFMA_F16_PEAK_TFLOPS)

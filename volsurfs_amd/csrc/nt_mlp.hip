@@ -83,15 +83,17 @@ __device__ __forceinline__ TexInfo tex_info(const vsa_nt_plan& p, const int* seg
 // b2 / b3: the ReLU'd hidden activations as f16 B fragments (k-step q, element j
 // <-> accumulator register 8(q&1)+j of tile q>>1); the backward pass keeps these
 // instead of the fp32 accumulators (ReLU mask = value > 0).
-__device__ __forceinline__ void mlp_tile_fwd(const half8_t* s_frag, const half8_t bx[2],
+// wf: the 16 forward weight fragments of this lane, register resident (loaded once
+// per workgroup task; re-reading them from LDS per MFMA exposes an LDS round trip
+// in front of every matrix instruction at one wave per SIMD).
+__device__ __forceinline__ void mlp_tile_fwd(const half8_t wf[16], const half8_t bx[2],
                                              half8_t b2[4], half8_t b3[4], float16_t& acc3) {
-  const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
     float16_t a = {0};
 #pragma unroll
     for (int s = 0; s < 2; ++s)
-      a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_frag[(m * 2 + s) * 64 + lane], bx[s], a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[m * 2 + s], bx[s], a, 0, 0, 0);
     b2[2 * m] = relu_pack(a, 0);
     b2[2 * m + 1] = relu_pack(a, 1);
   }
@@ -100,14 +102,14 @@ __device__ __forceinline__ void mlp_tile_fwd(const half8_t* s_frag, const half8_
     float16_t a = {0};
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_frag[(4 + m * 4 + q) * 64 + lane], b2[q], a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[4 + m * 4 + q], b2[q], a, 0, 0, 0);
     b3[2 * m] = relu_pack(a, 0);
     b3[2 * m + 1] = relu_pack(a, 1);
   }
   float16_t a = {0};
 #pragma unroll
   for (int q = 0; q < 4; ++q)
-    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_frag[(12 + q) * 64 + lane], b3[q], a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[12 + q], b3[q], a, 0, 0, 0);
   acc3 = a;
 }
 
@@ -147,6 +149,9 @@ __global__ __launch_bounds__(MLP_BLOCK) void nt_mlp_fwd_kernel(
   __syncthreads();
   const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
   const int wave = threadIdx.x >> 6;
+  half8_t wf[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) wf[i] = s_frag[i * 64 + lane];
   const int dword_base = ti.type == 0 ? 0 : 6;   // rgb bytes 0..23, alpha bytes 24..31
   const int ntiles = (wk.last - wk.first + 31) >> 5;
   half8_t bx[2], bx_next[2];
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(MLP_BLOCK) void nt_mlp_fwd_kernel(
     }
     half8_t b2[4], b3[4];
     float16_t acc3;
-    mlp_tile_fwd(s_frag, bx, b2, b3, acc3);
+    mlp_tile_fwd(wf, bx, b2, b3, acc3);
     if (!valid) continue;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -310,33 +315,48 @@ __global__ __launch_bounds__(BWD_BLOCK, 1) void nt_mlp_bwd_kernel(
     gW2[i][1] = float16_t{0};
   }
 
+  half8_t wf[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) wf[i] = s_frag[i * 64 + lane];
   float16_t dabs = {0};   // per-lane sum |dF| per feature row (for the hash-grad fixed point)
+  // software pipeline: the NEXT tile's features and gradient rows are in flight while
+  // this tile computes (one wave per SIMD: nothing else hides HBM latency)
+  auto load_grows = [&](int slot, float4 gr[4]) {
+    const bool ok = slot < wk.last;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int row0 = 8 * g + 4 * h;
+      gr[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok && row0 < ti.channels) {
+        float4* gp = reinterpret_cast<float4*>(grad_rows + (long long)slot * 32 + float_base + row0);
+        gr[g] = *gp;
+        *gp = make_float4(0.f, 0.f, 0.f, 0.f);   // consume-and-clear: zero again for the next frame
+      }
+    }
+  };
   half8_t bx[2], bx_next[2];
-  if (t0 < t1) prefetch_features(plan, features, ti.type, wk.first + t0 * 32 + p, wk.last, h, bx_next);
+  float4 gr[4], gr_next[4];
+  if (t0 < t1) {
+    prefetch_features(plan, features, ti.type, wk.first + t0 * 32 + p, wk.last, h, bx_next);
+    load_grows(wk.first + t0 * 32 + p, gr_next);
+  }
   for (int tile = t0; tile < t1; ++tile) {
     const int slot = wk.first + tile * 32 + p;
     const bool valid = slot < wk.last;
     bx[0] = bx_next[0];
     bx[1] = bx_next[1];
-    // this tile's gradient rows: consume-and-clear (zero again for the next frame)
-    float4 gr[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int row0 = 8 * g + 4 * h;
-      gr[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (valid && row0 < ti.channels) {
-        float4* gp = reinterpret_cast<float4*>(grad_rows + (long long)slot * 32 + float_base + row0);
-        gr[g] = *gp;
-        *gp = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+    for (int g = 0; g < 4; ++g) gr[g] = gr_next[g];
+    if (tile + 1 < t1) {
+      prefetch_features(plan, features, ti.type, slot + 32, wk.last, h, bx_next);
+      load_grows(slot + 32, gr_next);
     }
-    if (tile + 1 < t1) prefetch_features(plan, features, ti.type, slot + 32, wk.last, h, bx_next);
 
     half8_t b2[4], b3[4];   // H1, H2 (f16, ReLU'd)
     half8_t d3h[2];
     {
       float16_t acc3;
-      mlp_tile_fwd(s_frag, bx, b2, b3, acc3);
+      mlp_tile_fwd(wf, bx, b2, b3, acc3);
       // dL/d(pre-sigmoid output): G * sig * (1 - sig)   (round = STE, x255 /255 cancel);
       // G is zero for padding rows and invalid slots
 #pragma unroll

@@ -130,6 +130,26 @@ class KShellPipeline:
         self.mlp_flops_fwd = fl          # unpadded FLOPs of one forward over the unique texels
         return self.last_hits, self.last_slots
 
+    def capture_graph(self):
+        """Capture one whole step (zero_grad .. backward: ~25 launches on one stream, no
+        host sync) into a HIP graph; `replay()` then costs one graph launch instead of
+        the per-kernel host overhead of the eager path."""
+        self._static_rgb = None
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self.step()
+        torch.cuda.current_stream().wait_stream(s)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._static_rgb = self.step()
+        return self._graph
+
+    def replay(self):
+        self._graph.replay()
+        return self._static_rgb
+
     def step(self, record=False):
         """zero_grad -> forward -> L1 loss -> backward (trainer.py:118-264 without
         the optimiser step).  Returns the predicted rgb [N,3]."""
