@@ -13,6 +13,8 @@
 // half h), which is absorbed into the order in which the weight fragments are
 // staged.  16 MFMAs per 32 points; layer-1 B fragments are 4-byte coalesced
 // loads from the level-major feature planes.
+#include <stdlib.h>
+
 #include "nt_common.h"
 
 namespace {
@@ -501,6 +503,347 @@ __global__ __launch_bounds__(BWD_BLOCK, 1) void nt_mlp_bwd_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------- backward v4
+// Producer / consumer split.  The single-role kernel above needs 128 accumulator
+// registers for the weight gradients on top of the recompute + dgrad chain (~410
+// VGPRs -> one wave per SIMD, every MFMA result copied AGPR<->VGPR) and is bound by
+// the ISSUE rate of that one wave (in-kernel stamps: 7.6k cycles per tile, of which
+// 170 wait on memory).  Here the two waves that share a SIMD (w and w+4) split a
+// tile stream so that both issue streams are busy:
+//   PRODUCER  (t)   gradient rows + features (prefetched), forward recompute,
+//                   dOut = G * sigmoid' -> writes the point-major f16 images
+//                   {dOut, H2, H1, X} of tile t into LDS buffer t&1
+//   CONSUMER  (t-1) reads buffer (t-1)&1: dgrad chain dH2, dH1, dX (B operands by
+//                   16-B row reads, ReLU masks from the H images), the three weight
+//                   gradients (operands by ds_read_b64_tr_b16), dF stores, sum|dF|
+// Each role stays below 256 registers (MFMA results in plain VGPRs), hand-off is ONE
+// workgroup barrier per tile over a double-buffered image set.
+constexpr int PC_BLOCK = 512;
+constexpr int PC_PAIRS = 4;
+constexpr int PC_TPP = 32;                            // tiles per pair
+constexpr int MLP_PC_SPAN = PC_PAIRS * PC_TPP * 32;
+constexpr int S64 = 68, S32 = 40;   // row strides (halfs): 136 B (8-B aligned, bank-spread), 80 B (16-B aligned)
+constexpr int SET_DOUT = 0, SET_X = 32 * S32, SET_H2 = 2 * 32 * S32, SET_H1 = SET_H2 + 32 * S64;
+constexpr int SET_HALFS = SET_H1 + 32 * S64;          // one {dOut, X, H2, H1} set
+constexpr int PRIV_HALFS = 32 * S64;                  // consumer-private dH2 / dH1 image
+constexpr int PAIR_HALFS = 2 * SET_HALFS + PRIV_HALFS;
+constexpr int PC_FRAGS = 20;   // persistent in LDS: ids 16..31 transposed (perm k), 32..35 W3^T natural k
+                               // (ids 0..15, the forward set, are staged through the image area into registers)
+
+template <int STRIDE>
+__device__ __forceinline__ void store_frags_s(_Float16* img, int col_base, const half8_t& f0,
+                                              const half8_t& f1, int p, int h) {
+  _Float16* row = img + p * STRIDE + col_base + 4 * h;
+  *reinterpret_cast<half4_t*>(row + 0) = __builtin_shufflevector(f0, f0, 0, 1, 2, 3);
+  *reinterpret_cast<half4_t*>(row + 8) = __builtin_shufflevector(f0, f0, 4, 5, 6, 7);
+  *reinterpret_cast<half4_t*>(row + 16) = __builtin_shufflevector(f1, f1, 0, 1, 2, 3);
+  *reinterpret_cast<half4_t*>(row + 24) = __builtin_shufflevector(f1, f1, 4, 5, 6, 7);
+}
+
+// the two fragments (accumulator-register order) of a 32-channel tile of this lane's point
+template <int STRIDE>
+__device__ __forceinline__ void load_frags_s(const _Float16* img, int col_base, half8_t& f0,
+                                             half8_t& f1, int p, int h) {
+  const _Float16* row = img + p * STRIDE + col_base + 4 * h;
+  const half4_t a = *reinterpret_cast<const half4_t*>(row + 0);
+  const half4_t b = *reinterpret_cast<const half4_t*>(row + 8);
+  const half4_t c = *reinterpret_cast<const half4_t*>(row + 16);
+  const half4_t d = *reinterpret_cast<const half4_t*>(row + 24);
+  f0 = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  f1 = __builtin_shufflevector(c, d, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int STRIDE>
+__device__ __forceinline__ half8_t read_tr_s(const _Float16* img, int col_base, int s, int lane) {
+  const int h = lane >> 5, li = lane & 15, q = li >> 2, pp = li & 3, grp = (lane >> 4) & 1;
+  const _Float16* a0 = img + (16 * s + 8 * h + q) * STRIDE + col_base + 16 * grp + 4 * pp;
+  typedef __attribute__((address_space(3))) short4v* lds_p;
+  const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0));
+  const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0 + 4 * STRIDE));
+  typedef short short8v __attribute__((__vector_size__(8 * sizeof(short))));
+  const short8v both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(half8_t, both);
+}
+
+// LDS operations of this wave are done, then the workgroup barrier; does NOT drain the
+// vector-memory queue (prefetches and stores stay in flight across it)
+__device__ __forceinline__ void pc_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__global__ __launch_bounds__(PC_BLOCK, 2) void nt_mlp_bwd_pc_kernel(
+    vsa_nt_plan plan, EncLaunch L, const _Float16* __restrict__ weights,
+    unsigned* __restrict__ features, const int* __restrict__ seg_start,
+    float* __restrict__ grad_rows, float* __restrict__ grad_weights,
+    float* __restrict__ dfeat_abs_sum) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  half8_t* s_frag = reinterpret_cast<half8_t*>(s_raw) - 16 * 64;   // indexed by fragment id 16..35 (20 KiB)
+  _Float16* s_img_all = reinterpret_cast<_Float16*>(s_raw + PC_FRAGS * 64 * 16);
+  Work wk;
+  if (!decode_work(plan, L, seg_start, blockIdx.x, wk)) return;
+  const int tex = wk.tex;
+  const TexInfo ti = tex_info(plan, seg_start, tex);
+  {
+    const _Float16* W = weights + (long long)tex * VSA_NT_WEIGHTS_PER_TEX;
+    half8_t* s_tmp = reinterpret_cast<half8_t*>(s_img_all);   // forward fragments, until the images start
+    for (int idx = threadIdx.x; idx < 36 * 64; idx += PC_BLOCK) {
+      const int frag = idx >> 6, ln = idx & 63, r = ln & 31, hh = ln >> 5;
+      half8_t v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        _Float16 x;
+        if (frag < 4) {                      // forward W1
+          x = W[W1_OFF + (32 * (frag >> 1) + r) * 32 + 16 * (frag & 1) + 8 * hh + j];
+        } else if (frag < 12) {              // forward W2 (perm k)
+          const int f_ = frag - 4;
+          x = W[W2_OFF + (32 * (f_ >> 2) + r) * 64 + perm_k(f_ & 3, hh, j)];
+        } else if (frag < 16) {              // forward W3 (perm k)
+          x = W[W3_OFF + r * 64 + perm_k(frag - 12, hh, j)];
+        } else if (frag < 20) {              // W3^T, perm k (unused by v4, kept for id parity)
+          const int f_ = frag - 16;
+          x = W[W3_OFF + perm_k(f_ & 1, hh, j) * 64 + 32 * (f_ >> 1) + r];
+        } else if (frag < 28) {              // W2^T, perm k
+          const int f_ = frag - 20;
+          x = W[W2_OFF + perm_k(f_ & 3, hh, j) * 64 + 32 * (f_ >> 2) + r];
+        } else if (frag < 32) {              // W1^T, perm k
+          x = W[W1_OFF + perm_k(frag - 28, hh, j) * 32 + r];
+        } else {                             // W3^T, natural k (B operand comes from LDS rows)
+          const int f_ = frag - 32;
+          x = W[W3_OFF + (16 * (f_ & 1) + 8 * hh + j) * 64 + 32 * (f_ >> 1) + r];
+        }
+        v[j] = x;
+      }
+      if (frag < 16) s_tmp[idx] = v; else s_frag[idx] = v;
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
+  const int wave = threadIdx.x >> 6;
+  const bool producer = wave < PC_PAIRS;
+  half8_t wf[16];
+  if (producer) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wf[i] = reinterpret_cast<const half8_t*>(s_img_all)[i * 64 + lane];
+  }
+  __syncthreads();   // the image area may be overwritten from here on
+  const int pr = wave & (PC_PAIRS - 1);
+  _Float16* pair = s_img_all + pr * PAIR_HALFS;
+  _Float16* priv = pair + 2 * SET_HALFS;
+  const int float_base = ti.type == 0 ? 0 : 24;
+  const int ntiles = (wk.last - wk.first + 31) >> 5;
+  const int iters = (ntiles + PC_PAIRS - 1) / PC_PAIRS;     // same for every wave: barriers match
+
+  if (producer) {
+    auto load_grows = [&](int slot, float4 gr[4]) {
+      const bool ok = slot < wk.last;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row0 = 8 * g + 4 * h;
+        gr[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && row0 < ti.channels) {
+          float4* gp = reinterpret_cast<float4*>(grad_rows + (long long)slot * 32 + float_base + row0);
+          gr[g] = *gp;
+          *gp = make_float4(0.f, 0.f, 0.f, 0.f);   // consume-and-clear
+        }
+      }
+    };
+    half8_t bx[2], bx_next[2];
+    float4 gr[4], gr_next[4];
+    {
+      const int s0 = wk.first + pr * 32 + p;
+      prefetch_features(plan, features, ti.type, s0, wk.last, h, bx_next);
+      load_grows(s0, gr_next);
+    }
+    for (int it = 0; it <= iters; ++it) {
+      if (it < iters) {
+        const int slot = wk.first + (pr + it * PC_PAIRS) * 32 + p;
+        _Float16* set = pair + (it & 1) * SET_HALFS;
+        bx[0] = bx_next[0];
+        bx[1] = bx_next[1];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gr[g] = gr_next[g];
+        if (it + 1 < iters) {
+          prefetch_features(plan, features, ti.type, slot + PC_PAIRS * 32, wk.last, h, bx_next);
+          load_grows(slot + PC_PAIRS * 32, gr_next);
+        }
+        half8_t b2[4], b3[4], d3h[2];
+        float16_t acc3;
+        mlp_tile_fwd(wf, bx, b2, b3, acc3);
+        // dL/d(pre-sigmoid output): G * sig * (1 - sig) (round = STE); G is zero for
+        // padding rows and slots past the end
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float gv[4] = {gr[g].x, gr[g].y, gr[g].z, gr[g].w};
+          if (8 * g < ti.channels) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float sg = sigmoidf_((float)(_Float16)acc3[4 * g + i]);
+              d3h[g >> 1][4 * (g & 1) + i] = (_Float16)(gv[i] * sg * (1.0f - sg));
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d3h[g >> 1][4 * (g & 1) + i] = (_Float16)0;
+          }
+        }
+        store_frags_s<S32>(set + SET_DOUT, 0, d3h[0], d3h[1], p, h);
+        store_frags_s<S64>(set + SET_H2, 0, b3[0], b3[1], p, h);
+        store_frags_s<S64>(set + SET_H2, 32, b3[2], b3[3], p, h);
+        store_frags_s<S64>(set + SET_H1, 0, b2[0], b2[1], p, h);
+        store_frags_s<S64>(set + SET_H1, 32, b2[2], b2[3], p, h);
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx)
+          *reinterpret_cast<half8_t*>(set + SET_X + p * S32 + 16 * sx + 8 * h) = bx[sx];
+      }
+      pc_barrier();
+    }
+    // join the consumers' reduction barriers
+    __syncthreads();
+    for (int w = 0; w < PC_PAIRS; ++w) __syncthreads();
+  } else {
+    float16_t gW3[2], gW2[2][2], gW1[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      gW3[i] = float16_t{0};
+      gW1[i] = float16_t{0};
+      gW2[i][0] = float16_t{0};
+      gW2[i][1] = float16_t{0};
+    }
+    float16_t dabs = {0};   // per-lane sum |dF| per feature row (hash-grad fixed-point bound)
+    for (int it = 0; it <= iters; ++it) {
+      if (it > 0) {
+        const int t = it - 1;
+        const int slot = wk.first + (pr + t * PC_PAIRS) * 32 + p;
+        const bool valid = slot < wk.last;
+        const _Float16* set = pair + (t & 1) * SET_HALFS;
+        // ---- dW3 += dOut . H2^T
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+          const half8_t a3 = read_tr_s<S32>(set + SET_DOUT, 0, sx, lane);
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+            gW3[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3, read_tr_s<S64>(set + SET_H2, 32 * m, sx, lane), gW3[m], 0, 0, 0);
+        }
+        // ---- dH2 = W3^T dOut (B operand: this point's dOut row, natural channel order)
+        half8_t dh2[4];
+        {
+          const half8_t d0 = *reinterpret_cast<const half8_t*>(set + SET_DOUT + p * S32 + 8 * h);
+          const half8_t d1 = *reinterpret_cast<const half8_t*>(set + SET_DOUT + p * S32 + 16 + 8 * h);
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            float16_t a = {0};
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_frag[(32 + m * 2 + 0) * 64 + lane], d0, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_frag[(32 + m * 2 + 1) * 64 + lane], d1, a, 0, 0, 0);
+            half8_t h0, h1;
+            load_frags_s<S64>(set + SET_H2, 32 * m, h0, h1, p, h);
+            mask_pack(a, h0, h1, dh2[2 * m], dh2[2 * m + 1]);
+          }
+        }
+        // ---- dW2 += dH2 . H1^T
+        store_frags_s<S64>(priv, 0, dh2[0], dh2[1], p, h);
+        store_frags_s<S64>(priv, 32, dh2[2], dh2[3], p, h);
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+          const half8_t b1[2] = {read_tr_s<S64>(set + SET_H1, 0, sx, lane), read_tr_s<S64>(set + SET_H1, 32, sx, lane)};
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const half8_t a2 = read_tr_s<S64>(priv, 32 * m, sx, lane);
+#pragma unroll
+            for (int mj = 0; mj < 2; ++mj)
+              gW2[m][mj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b1[mj], gW2[m][mj], 0, 0, 0);
+          }
+        }
+        // ---- dH1 = W2^T dH2, masked
+        half8_t dh1[4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          float16_t a = {0};
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_frag[(20 + m * 4 + q) * 64 + lane], dh2[q], a, 0, 0, 0);
+          half8_t h0, h1;
+          load_frags_s<S64>(set + SET_H1, 32 * m, h0, h1, p, h);
+          mask_pack(a, h0, h1, dh1[2 * m], dh1[2 * m + 1]);
+        }
+        // ---- dW1 += dH1 . X^T   (the private image is reused: dW2's reads are done)
+        store_frags_s<S64>(priv, 0, dh1[0], dh1[1], p, h);
+        store_frags_s<S64>(priv, 32, dh1[2], dh1[3], p, h);
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+          const half8_t bxx = read_tr_s<S32>(set + SET_X, 0, sx, lane);
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+            gW1[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(read_tr_s<S64>(priv, 32 * m, sx, lane), bxx, gW1[m], 0, 0, 0);
+        }
+        // ---- dX = W1^T dH1 -> dF, in place over the features
+        float16_t dx = {0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          dx = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_frag[(28 + q) * 64 + lane], dh1[q], dx, 0, 0, 0);
+        if (valid) {
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) dabs[reg] += fabsf(dx[reg]);
+          unsigned* base = features + nt_feat_plane_base(plan, ti.type, 2 * h) +
+                           nt_feat_in_plane(plan.n_levels, slot);
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              half2_t v;
+              v.x = (_Float16)dx[4 * g + 2 * i];
+              v.y = (_Float16)dx[4 * g + 2 * i + 1];
+              base[(4 * g + i) * NT_FBLOCK] = __builtin_bit_cast(unsigned, v);
+            }
+        }
+      }
+      pc_barrier();
+    }
+    // sum |dF| per feature row: reduce over the 32 lanes of each half, one atomic per row
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      float v = dabs[reg];
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 32);
+      const int f = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if (p == 0 && v != 0.0f) atomicAdd(&dfeat_abs_sum[tex * 32 + f], v);
+    }
+    // workgroup reduction of the weight gradients (consumer waves take turns: LDS
+    // float atomics are slow on gfx950), then one global atomic per weight
+    __syncthreads();
+    float* s_acc = reinterpret_cast<float*>(s_img_all);   // 8192 floats, aliases the images
+    for (int w = 0; w < PC_PAIRS; ++w) {
+      if (pr == w) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const int i3 = W3_OFF + row * 64 + 32 * m + p;
+            const int i1 = W1_OFF + (32 * m + row) * 32 + p;
+            s_acc[i3] = (w ? s_acc[i3] : 0.0f) + gW3[m][reg];
+            s_acc[i1] = (w ? s_acc[i1] : 0.0f) + gW1[m][reg];
+#pragma unroll
+            for (int mj = 0; mj < 2; ++mj) {
+              const int i2 = W2_OFF + (32 * m + row) * 64 + 32 * mj + p;
+              s_acc[i2] = (w ? s_acc[i2] : 0.0f) + gW2[m][mj][reg];
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  {
+    const float* s_acc = reinterpret_cast<const float*>(s_img_all);
+    float* gw = grad_weights + (long long)tex * VSA_NT_WEIGHTS_PER_TEX;
+    const int w3_end = W3_OFF + ti.channels * 64;
+    for (int i = threadIdx.x; i < w3_end; i += PC_BLOCK) {
+      const float v = s_acc[i];
+      if (v != 0.0f) atomicAdd(&gw[i], v);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int vsa_nt_mlp_fwd(const vsa_nt_plan* plan, const void* weights_h, const void* features,
@@ -522,18 +865,35 @@ extern "C" int vsa_nt_mlp_bwd(const vsa_nt_plan* plan, const void* weights_h, vo
   if (!plan || !weights_h || !features || !seg_start || !grad_rows || !grad_weights ||
       !dfeat_abs_sum)
     return VSA_ERR_ARG;
-  const size_t lds = 32 * 64 * 16 + (size_t)BWD_WAVES * 2 * IMG_HALFS * 2;
+  static int variant = -1;   // VSA_MLP_BWD=single selects the one-role kernel (A/B runs)
+  if (variant < 0) {
+    const char* e = getenv("VSA_MLP_BWD");
+    variant = (e && e[0] == 's') ? 0 : 1;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(nt_mlp_bwd_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+    VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(nt_mlp_bwd_pc_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
     attr_set = true;
   }
-  const EncLaunch L = enc_launch(plan, 0, MLP_BWD_SPAN);
-  dim3 grid(L.per_model * plan->nr_shells * 2);
-  hipLaunchKernelGGL(nt_mlp_bwd_kernel, grid, dim3(BWD_BLOCK), lds, (hipStream_t)stream, *plan, L,
-                     reinterpret_cast<const _Float16*>(weights_h),
-                     reinterpret_cast<unsigned*>(features), seg_start, grad_rows, grad_weights,
-                     dfeat_abs_sum);
+  if (variant == 0) {
+    const size_t lds = 32 * 64 * 16 + (size_t)BWD_WAVES * 2 * IMG_HALFS * 2;
+    const EncLaunch L = enc_launch(plan, 0, MLP_BWD_SPAN);
+    dim3 grid(L.per_model * plan->nr_shells * 2);
+    hipLaunchKernelGGL(nt_mlp_bwd_kernel, grid, dim3(BWD_BLOCK), lds, (hipStream_t)stream, *plan, L,
+                       reinterpret_cast<const _Float16*>(weights_h),
+                       reinterpret_cast<unsigned*>(features), seg_start, grad_rows, grad_weights,
+                       dfeat_abs_sum);
+  } else {
+    const size_t lds = (size_t)PC_FRAGS * 64 * 16 + (size_t)PC_PAIRS * PAIR_HALFS * 2;   // >= frags + 32 KiB reduction buffer
+    const EncLaunch L = enc_launch(plan, 0, MLP_PC_SPAN);
+    dim3 grid(L.per_model * plan->nr_shells * 2);
+    hipLaunchKernelGGL(nt_mlp_bwd_pc_kernel, grid, dim3(PC_BLOCK), lds, (hipStream_t)stream, *plan,
+                       L, reinterpret_cast<const _Float16*>(weights_h),
+                       reinterpret_cast<unsigned*>(features), seg_start, grad_rows, grad_weights,
+                       dfeat_abs_sum);
+  }
   VSA_RETURN_LAUNCH_STATUS();
 }
