@@ -566,6 +566,17 @@ __device__ __forceinline__ half8_t read_tr_s(const _Float16* img, int col_base, 
   return __builtin_bit_cast(half8_t, both);
 }
 
+#ifdef NT_STAMP   // diagnostic build only (tools: make EXTRA=-DNT_STAMP): per-role cycles per tile
+#define STAMP(var)                                                               \
+  {                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");   \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+  }
+#else
+#define STAMP(var)
+#endif
+
 // LDS operations of this wave are done, then the workgroup barrier; does NOT drain the
 // vector-memory queue (prefetches and stores stay in flight across it)
 __device__ __forceinline__ void pc_barrier() {
@@ -648,6 +659,7 @@ __global__ __launch_bounds__(PC_BLOCK, 2) void nt_mlp_bwd_pc_kernel(
         }
       }
     };
+    float16_t gW3[2] = {float16_t{0}, float16_t{0}};   // the producer has slack: it also owns dW3
     half8_t bx[2], bx_next[2];
     float4 gr[4], gr_next[4];
     {
@@ -655,7 +667,11 @@ __global__ __launch_bounds__(PC_BLOCK, 2) void nt_mlp_bwd_pc_kernel(
       prefetch_features(plan, features, ti.type, s0, wk.last, h, bx_next);
       load_grows(s0, gr_next);
     }
+#ifdef NT_STAMP
+    unsigned long long tw_ = 0, tb_ = 0, q0, q1, q2;
+#endif
     for (int it = 0; it <= iters; ++it) {
+      STAMP(q0);
       if (it < iters) {
         const int slot = wk.first + (pr + it * PC_PAIRS) * 32 + p;
         _Float16* set = pair + (it & 1) * SET_HALFS;
@@ -694,29 +710,7 @@ __global__ __launch_bounds__(PC_BLOCK, 2) void nt_mlp_bwd_pc_kernel(
 #pragma unroll
         for (int sx = 0; sx < 2; ++sx)
           *reinterpret_cast<half8_t*>(set + SET_X + p * S32 + 16 * sx + 8 * h) = bx[sx];
-      }
-      pc_barrier();
-    }
-    // join the consumers' reduction barriers
-    __syncthreads();
-    for (int w = 0; w < PC_PAIRS; ++w) __syncthreads();
-  } else {
-    float16_t gW3[2], gW2[2][2], gW1[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      gW3[i] = float16_t{0};
-      gW1[i] = float16_t{0};
-      gW2[i][0] = float16_t{0};
-      gW2[i][1] = float16_t{0};
-    }
-    float16_t dabs = {0};   // per-lane sum |dF| per feature row (hash-grad fixed-point bound)
-    for (int it = 0; it <= iters; ++it) {
-      if (it > 0) {
-        const int t = it - 1;
-        const int slot = wk.first + (pr + t * PC_PAIRS) * 32 + p;
-        const bool valid = slot < wk.last;
-        const _Float16* set = pair + (t & 1) * SET_HALFS;
-        // ---- dW3 += dOut . H2^T
+        // ---- dW3 += dOut . H2^T  (transposed reads of this wave's own, just-written images)
 #pragma unroll
         for (int sx = 0; sx < 2; ++sx) {
           const half8_t a3 = read_tr_s<S32>(set + SET_DOUT, 0, sx, lane);
@@ -724,6 +718,55 @@ __global__ __launch_bounds__(PC_BLOCK, 2) void nt_mlp_bwd_pc_kernel(
           for (int m = 0; m < 2; ++m)
             gW3[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3, read_tr_s<S64>(set + SET_H2, 32 * m, sx, lane), gW3[m], 0, 0, 0);
         }
+      }
+      STAMP(q1);
+      pc_barrier();
+      STAMP(q2);
+#ifdef NT_STAMP
+      tw_ += q1 - q0; tb_ += q2 - q1;
+#endif
+    }
+#ifdef NT_STAMP
+    if (blockIdx.x == 3 && lane == 0) printf("P wave %d: work %llu barrier-wait %llu cycles/tile\n", wave, tw_ / iters, tb_ / iters);
+#endif
+    // weight-gradient reduction: the consumers go first (they initialise the buffer),
+    // then the producers add their dW3
+    __syncthreads();
+    for (int w = 0; w < PC_PAIRS; ++w) __syncthreads();
+    float* s_acc = reinterpret_cast<float*>(s_img_all);
+    for (int w = 0; w < PC_PAIRS; ++w) {
+      if (pr == w) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+#pragma unroll
+          for (int m = 0; m < 2; ++m) s_acc[W3_OFF + row * 64 + 32 * m + p] += gW3[m][reg];
+        }
+      }
+      __syncthreads();
+    }
+  } else {
+    float16_t gW2[2][2], gW1[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      gW1[i] = float16_t{0};
+      gW2[i][0] = float16_t{0};
+      gW2[i][1] = float16_t{0};
+    }
+    float16_t dabs = {0};   // per-lane sum |dF| per feature row (hash-grad fixed-point bound)
+    // the consumer is the longer stream AND the later-dispatched wave of its SIMD (the
+    // arbitration loser at equal priority): raise it once, statically
+    __builtin_amdgcn_s_setprio(1);
+#ifdef NT_STAMP
+    unsigned long long tw_ = 0, tb_ = 0, q0, q1, q2;
+#endif
+    for (int it = 0; it <= iters; ++it) {
+      STAMP(q0);
+      if (it > 0) {
+        const int t = it - 1;
+        const int slot = wk.first + (pr + t * PC_PAIRS) * 32 + p;
+        const bool valid = slot < wk.last;
+        const _Float16* set = pair + (t & 1) * SET_HALFS;
         // ---- dH2 = W3^T dOut (B operand: this point's dOut row, natural channel order)
         half8_t dh2[4];
         {
@@ -796,8 +839,16 @@ __global__ __launch_bounds__(PC_BLOCK, 2) void nt_mlp_bwd_pc_kernel(
             }
         }
       }
+      STAMP(q1);
       pc_barrier();
+      STAMP(q2);
+#ifdef NT_STAMP
+      tw_ += q1 - q0; tb_ += q2 - q1;
+#endif
     }
+#ifdef NT_STAMP
+    if (blockIdx.x == 3 && lane == 0) printf("C wave %d: work %llu barrier-wait %llu cycles/tile\n", wave, tw_ / iters, tb_ / iters);
+#endif
     // sum |dF| per feature row: reduce over the 32 lanes of each half, one atomic per row
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
@@ -820,7 +871,7 @@ __global__ __launch_bounds__(PC_BLOCK, 2) void nt_mlp_bwd_pc_kernel(
           for (int m = 0; m < 2; ++m) {
             const int i3 = W3_OFF + row * 64 + 32 * m + p;
             const int i1 = W1_OFF + (32 * m + row) * 32 + p;
-            s_acc[i3] = (w ? s_acc[i3] : 0.0f) + gW3[m][reg];
+            if (w == 0) s_acc[i3] = 0.0f;                      // the producers add dW3 afterwards
             s_acc[i1] = (w ? s_acc[i1] : 0.0f) + gW1[m][reg];
 #pragma unroll
             for (int mj = 0; mj < 2; ++mj) {
@@ -832,6 +883,7 @@ __global__ __launch_bounds__(PC_BLOCK, 2) void nt_mlp_bwd_pc_kernel(
       }
       __syncthreads();
     }
+    for (int w = 0; w < PC_PAIRS; ++w) __syncthreads();   // the producers' dW3 rounds
   }
   {
     const float* s_acc = reinterpret_cast<const float*>(s_img_all);
