@@ -143,7 +143,14 @@ int vsa_hit_attributes(const float* tris, const float* rays_o, const float* rays
 #define VSA_NT_MAX_LEVELS 16
 #define VSA_NT_MAX_DEG 4
 #define VSA_NT_WEIGHTS_PER_TEX 8192 /* W1[64][32] W2[64][64] W3[32][64] (rows >= C' zero) */
-#define VSA_NT_ROW_BYTES 32         /* texel row: rgb bytes 0..20, alpha bytes 24..30 */
+/* Texel rows (u8) and gradient rows (f32) share one per-degree layout, counted in QUADS
+ * (4 elements: 4 bytes of a texel row, 4 floats of a gradient row).  A slot of SH band d
+ * (n = 2d+1 coefficients) owns VSA_NT_ROW_QUADS(d) quads: rgb coefficient c (0..3n-1) at
+ * element c, alpha coefficient c (0..n-1) at element 4*VSA_NT_ALPHA_QUAD(d) + c; the rest
+ * is zero padding.  The row of slot i of segment (shell, d) starts at quad
+ * row_base[shell*4+d] + (i - seg_start[shell*4+d]) * VSA_NT_ROW_QUADS(d). */
+#define VSA_NT_ROW_QUADS(d) ((d) == 0 ? 2 : ((d) == 1 ? 4 : 8))
+#define VSA_NT_ALPHA_QUAD(d) ((d) == 0 ? 1 : ((d) == 1 ? 3 : ((d) == 2 ? 4 : 6)))
 
 typedef struct vsa_nt_plan {
   int32_t nr_shells;                 /* K */
@@ -164,6 +171,9 @@ typedef struct vsa_nt_plan {
   int32_t max_rays;                  /* N the buffers were sized for: a (shell,degree)
                                         segment holds <= min(4*max_rays, (R_d+2)^2) slots */
   int32_t reserved0;
+  int64_t row_base[VSA_MAX_SHELLS * VSA_NT_MAX_DEG + 1]; /* quads; multiples of 8; segment sd
+                                        reserves min(4*max_rays,(R_d+2)^2)*VSA_NT_ROW_QUADS(d);
+                                        the last entry is the allocation size */
 } vsa_nt_plan;
 
 /* Step 1 (per frame): per-hit texture uv + mark touched texels.
@@ -192,10 +202,9 @@ int vsa_nt_encode_fwd(const vsa_nt_plan* plan, const void* tables_h, const float
 
 /* Step 4: MLP 32->64->64->C' of every slot of every texture on MFMA, fused with
  * sigmoid / x255 / round (neural_texture.py:156-169).  weights_h: f16
- * [n_tex][VSA_NT_WEIGHTS_PER_TEX]; texels: u8 [slot_capacity][32] (quantised
- * texel rows: rgb coefficient c at byte c, alpha coefficient c at byte 24+c).
- * pre_out (optional, tests): f16 [slot_capacity][32], the network output before
- * the sigmoid, same row layout. */
+ * [n_tex][VSA_NT_WEIGHTS_PER_TEX]; texels: u8 [row_base[last]*4] (quantised texel rows,
+ * layout above).  pre_out (optional, tests): f16 [slot_capacity][32], the network output
+ * before the sigmoid: rgb channel c at [slot][c], alpha channel c at [slot][24+c]. */
 int vsa_nt_mlp_fwd(const vsa_nt_plan* plan, const void* weights_h, const void* features,
                    const int32_t* seg_start, uint8_t* texels, void* pre_out, void* stream);
 
@@ -219,15 +228,17 @@ int vsa_nt_mlp_bwd(const vsa_nt_plan* plan, const void* weights_h, void* feature
  * alpha lerped fp16 SH coefficients).  tris = the tracer's triangle array. */
 int vsa_nt_shade_fwd(const vsa_nt_plan* plan, const int32_t* hit_slot, const float* tex_uv,
                      const float* rays_d, const float* tris, const int32_t* slot_of,
-                     const uint8_t* texels, int nr_rays, float* surfs_rgb, float* surfs_alpha,
+                     const int32_t* seg_start, const uint8_t* texels, int nr_rays,
+                     float* surfs_rgb, float* surfs_alpha,
                      float* surfs_normals, float* coeffs_out, void* stream);
 
-/* Backward of step 5: grad_rows (f32 [slot_capacity][32], same row layout as
+/* Backward of step 5: grad_rows (f32 [row_base[last]*4], same row layout as
  * texels; zero on entry, see vsa_nt_mlp_bwd) += grad_scale * dL/d(q/255)
  * (round is a straight-through estimator, utils/math.py:5-18). */
 int vsa_nt_shade_bwd(const vsa_nt_plan* plan, const int32_t* hit_slot, const float* tex_uv,
                      const float* rays_d, const float* tris, const int32_t* slot_of,
-                     const uint8_t* texels, int nr_rays, const float* g_surfs_rgb,
+                     const int32_t* seg_start, const uint8_t* texels, int nr_rays,
+                     const float* g_surfs_rgb,
                      const float* g_surfs_alpha, float grad_scale, float* grad_rows, void* stream);
 
 /* Backward of step 3: grad_tables (f32 [n_tex][level_offset[n]][2]) +=

@@ -57,7 +57,7 @@ def test_shade_fwd_from_texels(cfg):
     bank.mlp()
     rgb, alpha, normals, coeffs = bank.shade(hit_slot, tex_uv, rays_d, tris, True, True)
     torch.cuda.synchronize()
-    texels, slot_of = bank.texels.cpu(), bank.slot_of.cpu()
+    texels, slot_of = bank.rows_dense(bank.texels).cpu(), bank.slot_of.cpu()
     K, N = hit_slot.shape
     for s in range(K):
         hit = (hit_slot[s] >= 0).cpu()

@@ -20,7 +20,7 @@ def test_plan_struct_matches_header_layout():
     import ctypes, os, subprocess, tempfile
     from volsurfs_amd.neural_textures import Plan
     from volsurfs_amd import _lib
-    src = '#include <stdio.h>\n#include <stddef.h>\n#include "volsurfs_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n",sizeof(vsa_nt_plan),offsetof(vsa_nt_plan,level_scale),offsetof(vsa_nt_plan,dom_off),offsetof(vsa_nt_plan,slot_capacity),offsetof(vsa_nt_plan,max_rays));return 0;}'
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "volsurfs_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",sizeof(vsa_nt_plan),offsetof(vsa_nt_plan,level_scale),offsetof(vsa_nt_plan,dom_off),offsetof(vsa_nt_plan,slot_capacity),offsetof(vsa_nt_plan,max_rays),offsetof(vsa_nt_plan,row_base));return 0;}'
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "p.c")
         open(c, "w").write(src)
@@ -29,7 +29,7 @@ def test_plan_struct_matches_header_layout():
         out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()
     assert [int(x) for x in out] == [ctypes.sizeof(Plan), Plan.level_scale.offset,
                                      Plan.dom_off.offset, Plan.slot_capacity.offset,
-                                     Plan.max_rays.offset]
+                                     Plan.max_rays.offset, Plan.row_base.offset]
 
 
 def _setup(K=2, N=3000, seed=0):

@@ -32,6 +32,10 @@ __host__ __device__ inline int nt_tex_index(int shell, int type, int deg) {
   return (shell * 2 + type) * VSA_NT_MAX_DEG + deg;
 }
 
+// Per-degree row layout of texels / grad_rows (include/volsurfs_hip.h: VSA_NT_ROW_QUADS)
+__host__ __device__ inline int nt_row_quads(int d) { return VSA_NT_ROW_QUADS(d); }
+__host__ __device__ inline int nt_alpha_quad(int d) { return VSA_NT_ALPHA_QUAD(d); }
+
 // The 2x2 texel footprint of a uv sample in a texture of resolution R
 // (models/neural_texture.py:107-138 with align_to_webgl; oracle/neural_texture.py
 // texel_corners).  (i0, j0) is the lower corner in texel units, may be -1;

@@ -61,6 +61,8 @@ __device__ __forceinline__ half8_t relu_pack(const float16_t& acc, int s) {
 
 struct TexInfo {
   int begin, end, type, channels;
+  int row_quads;        // quads per slot row of this degree
+  long long row_first;  // quad of slot `begin`'s first channel of THIS texture (rgb: 0, alpha: +alpha quad)
 };
 
 __device__ __forceinline__ TexInfo tex_info(const vsa_nt_plan& p, const int* seg_start, int tex) {
@@ -77,6 +79,8 @@ __device__ __forceinline__ TexInfo tex_info(const vsa_nt_plan& p, const int* seg
   }
   t.begin = seg_start[shell * VSA_NT_MAX_DEG + deg];
   t.end = seg_start[shell * VSA_NT_MAX_DEG + deg + 1];
+  t.row_quads = nt_row_quads(deg);
+  t.row_first = p.row_base[shell * VSA_NT_MAX_DEG + deg] + (type ? nt_alpha_quad(deg) : 0);
   return t;
 }
 
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(MLP_BLOCK) void nt_mlp_fwd_kernel(
   half8_t wf[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) wf[i] = s_frag[i * 64 + lane];
-  const int dword_base = ti.type == 0 ? 0 : 6;   // rgb bytes 0..23, alpha bytes 24..31
+  const int pre_base = ti.type == 0 ? 0 : 24;    // pre_out keeps the fixed 32-wide test layout
   const int ntiles = (wk.last - wk.first + 31) >> 5;
   half8_t bx[2], bx_next[2];
   if (wave < ntiles) {
@@ -183,12 +187,12 @@ __global__ __launch_bounds__(MLP_BLOCK) void nt_mlp_fwd_kernel(
       for (int i = 0; i < 4; ++i) {
         const _Float16 o_h = (_Float16)acc3[4 * g + i];
         if (pre_out && row0 + i < ti.channels)
-          pre_out[(long long)slot * 32 + 4 * dword_base + row0 + i] = o_h;
+          pre_out[(long long)slot * 32 + pre_base + row0 + i] = o_h;
         float q = rintf(sigmoidf_((float)o_h) * 255.0f);
         unsigned qb = row0 + i < ti.channels ? (unsigned)q : 0u;
         packed |= qb << (8 * i);
       }
-      texels[(long long)slot * 8 + dword_base + (row0 >> 2)] = packed;
+      texels[ti.row_first + (long long)(slot - ti.begin) * ti.row_quads + (row0 >> 2)] = packed;
     }
   }
 }
@@ -304,7 +308,6 @@ __global__ __launch_bounds__(BWD_BLOCK, 1) void nt_mlp_bwd_kernel(
   const int wave = threadIdx.x >> 6;
   _Float16* imgA = s_img_all + wave * 2 * IMG_HALFS;
   _Float16* imgB = imgA + IMG_HALFS;
-  const int float_base = ti.type == 0 ? 0 : 24;
   const int ntiles = (wk.last - wk.first + 31) >> 5;
   const int t0 = wave * BWD_TPW, t1 = min(ntiles, t0 + BWD_TPW);
 
@@ -330,7 +333,8 @@ __global__ __launch_bounds__(BWD_BLOCK, 1) void nt_mlp_bwd_kernel(
       const int row0 = 8 * g + 4 * h;
       gr[g] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ok && row0 < ti.channels) {
-        float4* gp = reinterpret_cast<float4*>(grad_rows + (long long)slot * 32 + float_base + row0);
+        float4* gp = reinterpret_cast<float4*>(grad_rows) + ti.row_first +
+                     (long long)(slot - ti.begin) * ti.row_quads + (row0 >> 2);
         gr[g] = *gp;
         *gp = make_float4(0.f, 0.f, 0.f, 0.f);   // consume-and-clear: zero again for the next frame
       }
@@ -641,7 +645,6 @@ __global__ __launch_bounds__(PC_BLOCK, 2) void nt_mlp_bwd_pc_kernel(
   const int pr = wave & (PC_PAIRS - 1);
   _Float16* pair = s_img_all + pr * PAIR_HALFS;
   _Float16* priv = pair + 2 * SET_HALFS;
-  const int float_base = ti.type == 0 ? 0 : 24;
   const int ntiles = (wk.last - wk.first + 31) >> 5;
   const int iters = (ntiles + PC_PAIRS - 1) / PC_PAIRS;     // same for every wave: barriers match
 
@@ -653,7 +656,8 @@ __global__ __launch_bounds__(PC_BLOCK, 2) void nt_mlp_bwd_pc_kernel(
         const int row0 = 8 * g + 4 * h;
         gr[g] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ok && row0 < ti.channels) {
-          float4* gp = reinterpret_cast<float4*>(grad_rows + (long long)slot * 32 + float_base + row0);
+          float4* gp = reinterpret_cast<float4*>(grad_rows) + ti.row_first +
+                     (long long)(slot - ti.begin) * ti.row_quads + (row0 >> 2);
           gr[g] = *gp;
           *gp = make_float4(0.f, 0.f, 0.f, 0.f);   // consume-and-clear
         }

@@ -9,7 +9,7 @@
 //   (methods/volsurfs.py:583-594) -> scatter into surfs_rgb / surfs_alpha
 //   (:550, :596).
 // Backward: the same chain reversed; gradients w.r.t. the quantised texel value
-// o = q/255 are accumulated per slot (f32 rows of 32) with wave-cooperative
+// o = q/255 are accumulated per slot (f32 rows, per-degree width) with wave-cooperative
 // atomics: lanes = the 64 (channel, SH coefficient) pairs of ONE hit, so each
 // wave instruction adds contiguous row segments instead of 64 scattered dwords.
 #include "nt_common.h"
@@ -54,7 +54,7 @@ struct HitCtx {
   bool hit;
   float dir[3];
   float decay;        // alpha decay factor (1 when disabled)
-  int slot[VSA_NT_MAX_DEG][4];
+  int row[VSA_NT_MAX_DEG][4];   // first quad of each corner's texel / gradient row
   float w[VSA_NT_MAX_DEG][4];
 };
 
@@ -95,7 +95,8 @@ __device__ __forceinline__ void build_lut(const vsa_nt_plan& plan, float* s_lut)
 __device__ __forceinline__ bool load_ctx(const vsa_nt_plan& plan, int s, long long n, int N,
                                          const int* hit_slot, const float* tex_uv,
                                          const float* rays_d, const float4* tris,
-                                         const int* slot_of, HitCtx& c, float nrm[3]) {
+                                         const int* slot_of, const int* seg_start, HitCtx& c,
+                                         float nrm[3]) {
   const long long o = (long long)s * N + n;
   const int tslot = hit_slot[o];
   c.hit = tslot >= 0;
@@ -124,10 +125,12 @@ __device__ __forceinline__ bool load_ctx(const vsa_nt_plan& plan, int s, long lo
     const int R = plan.tex_res[d], W = R + 2;
     const NtFootprint f = nt_footprint(u, v, R);
     const long long base = plan.dom_off[s * VSA_NT_MAX_DEG + d] + (long long)(f.j0 + 1) * W + (f.i0 + 1);
-    c.slot[d][0] = slot_of[base];
-    c.slot[d][1] = slot_of[base + 1];
-    c.slot[d][2] = slot_of[base + W];
-    c.slot[d][3] = slot_of[base + W + 1];
+    const int sd = s * VSA_NT_MAX_DEG + d;
+    const int rb = (int)plan.row_base[sd] - seg_start[sd] * nt_row_quads(d);
+    c.row[d][0] = rb + slot_of[base] * nt_row_quads(d);
+    c.row[d][1] = rb + slot_of[base + 1] * nt_row_quads(d);
+    c.row[d][2] = rb + slot_of[base + W] * nt_row_quads(d);
+    c.row[d][3] = rb + slot_of[base + W + 1] * nt_row_quads(d);
     c.w[d][0] = (1.0f - f.fx) * (1.0f - f.fy);
     c.w[d][1] = f.fx * (1.0f - f.fy);
     c.w[d][2] = (1.0f - f.fx) * f.fy;
@@ -138,7 +141,7 @@ __device__ __forceinline__ bool load_ctx(const vsa_nt_plan& plan, int s, long lo
 
 // SH coefficients (fp16-rounded, as floats): sh_rgb[ch][16], sh_a[16]
 __device__ __forceinline__ void gather_coeffs(const vsa_nt_plan& plan, const HitCtx& c,
-                                              const uint4* __restrict__ texels,
+                                              const unsigned* __restrict__ texels,
                                               const float* s_lut, bool has_alpha,
                                               float sh_rgb[3][16], float sh_a[16]) {
 #pragma unroll
@@ -151,9 +154,19 @@ __device__ __forceinline__ void gather_coeffs(const vsa_nt_plan& plan, const Hit
     for (int i = 0; i < 28; ++i) acc[i] = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const uint4 lo = texels[2 * (long long)c.slot[d][k]];
-      const uint4 hi = texels[2 * (long long)c.slot[d][k] + 1];
-      const unsigned wds[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      unsigned wds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      const unsigned* rp = texels + c.row[d][k];
+      if (d == 0) {
+        const uint2 v = *reinterpret_cast<const uint2*>(rp);
+        wds[0] = v.x, wds[1] = v.y;
+      } else {
+        const uint4 lo = *reinterpret_cast<const uint4*>(rp);
+        wds[0] = lo.x, wds[1] = lo.y, wds[2] = lo.z, wds[3] = lo.w;
+        if (d >= 2) {
+          const uint4 hi = *reinterpret_cast<const uint4*>(rp + 4);
+          wds[4] = hi.x, wds[5] = hi.y, wds[6] = hi.z, wds[7] = hi.w;
+        }
+      }
       const float wk = c.w[d][k];
 #pragma unroll
       for (int i = 0; i < 3 * n; ++i) {
@@ -162,7 +175,7 @@ __device__ __forceinline__ void gather_coeffs(const vsa_nt_plan& plan, const Hit
       }
 #pragma unroll
       for (int i = 0; i < n; ++i) {
-        const unsigned q = (wds[6 + (i >> 2)] >> (8 * (i & 3))) & 255u;
+        const unsigned q = (wds[nt_alpha_quad(d) + (i >> 2)] >> (8 * (i & 3))) & 255u;
         acc[21 + i] = acc[21 + i] + s_lut[d * 256 + q] * wk;
       }
     }
@@ -178,8 +191,8 @@ __device__ __forceinline__ void gather_coeffs(const vsa_nt_plan& plan, const Hit
 __global__ __launch_bounds__(SH_BLOCK) void nt_shade_fwd_kernel(
     vsa_nt_plan plan, const int* __restrict__ hit_slot, const float* __restrict__ tex_uv,
     const float* __restrict__ rays_d, const float4* __restrict__ tris,
-    const int* __restrict__ slot_of, const uint4* __restrict__ texels, int N,
-    float* __restrict__ surfs_rgb, float* __restrict__ surfs_alpha,
+    const int* __restrict__ slot_of, const int* __restrict__ seg_start,
+    const unsigned* __restrict__ texels, int N, float* __restrict__ surfs_rgb, float* __restrict__ surfs_alpha,
     float* __restrict__ surfs_normals, float* __restrict__ coeffs_out) {
   __shared__ float s_lut[VSA_NT_MAX_DEG * 256];
   build_lut(plan, s_lut);
@@ -190,7 +203,7 @@ __global__ __launch_bounds__(SH_BLOCK) void nt_shade_fwd_kernel(
   HitCtx c;
   float nrm[3];
   float rgb[3] = {0.f, 0.f, 0.f}, alpha = 0.f;
-  if (load_ctx(plan, s, n, N, hit_slot, tex_uv, rays_d, tris, slot_of, c, nrm)) {
+  if (load_ctx(plan, s, n, N, hit_slot, tex_uv, rays_d, tris, slot_of, seg_start, c, nrm)) {
     const bool has_alpha = !(plan.inner_solid && s == 0);
     float sh_rgb[3][16], sh_a[16];
     gather_coeffs(plan, c, texels, s_lut, has_alpha, sh_rgb, sh_a);
@@ -240,13 +253,13 @@ __global__ __launch_bounds__(SH_BLOCK) void nt_shade_fwd_kernel(
 __global__ __launch_bounds__(SH_BLOCK) void nt_shade_bwd_kernel(
     vsa_nt_plan plan, const int* __restrict__ hit_slot, const float* __restrict__ tex_uv,
     const float* __restrict__ rays_d, const float4* __restrict__ tris,
-    const int* __restrict__ slot_of, const uint4* __restrict__ texels, int N,
-    const float* __restrict__ g_surfs_rgb, const float* __restrict__ g_surfs_alpha,
+    const int* __restrict__ slot_of, const int* __restrict__ seg_start,
+    const unsigned* __restrict__ texels, int N, const float* __restrict__ g_surfs_rgb, const float* __restrict__ g_surfs_alpha,
     float grad_scale, float* __restrict__ grad_rows) {
   __shared__ float s_lut[VSA_NT_MAX_DEG * 256];
   __shared__ float s_graw[SH_BLOCK][4];
   __shared__ float s_basis[SH_BLOCK][17];
-  __shared__ int s_slot[SH_BLOCK][17];
+  __shared__ int s_row[SH_BLOCK][17];
   __shared__ float s_w[SH_BLOCK][17];
   build_lut(plan, s_lut);
   __syncthreads();
@@ -257,7 +270,7 @@ __global__ __launch_bounds__(SH_BLOCK) void nt_shade_bwd_kernel(
   c.hit = false;
   float nrm[3];
   const bool has_alpha = !(plan.inner_solid && s == 0);
-  if (n < N && load_ctx(plan, s, n, N, hit_slot, tex_uv, rays_d, tris, slot_of, c, nrm)) {
+  if (n < N && load_ctx(plan, s, n, N, hit_slot, tex_uv, rays_d, tris, slot_of, seg_start, c, nrm)) {
     float sh_rgb[3][16], sh_a[16];
     gather_coeffs(plan, c, texels, s_lut, has_alpha, sh_rgb, sh_a);
     float b[16];
@@ -280,7 +293,7 @@ __global__ __launch_bounds__(SH_BLOCK) void nt_shade_bwd_kernel(
     for (int d = 0; d < VSA_NT_MAX_DEG; ++d)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        s_slot[t][d * 4 + k] = c.slot[d][k];
+        s_row[t][d * 4 + k] = c.row[d][k];
         s_w[t][d * 4 + k] = c.w[d][k] * plan.sh_span[d];
       }
   }
@@ -292,7 +305,7 @@ __global__ __launch_bounds__(SH_BLOCK) void nt_shade_bwd_kernel(
   const int m = lane < 48 ? lane & 15 : lane - 48;
   const int d = m >= 9 ? 3 : (m >= 4 ? 2 : (m >= 1 ? 1 : 0));
   const int nn = 2 * d + 1;
-  const int fidx = ch < 3 ? ch * nn + (m - d * d) : 24 + (m - d * d);
+  const int fidx = ch < 3 ? ch * nn + (m - d * d) : 4 * nt_alpha_quad(d) + (m - d * d);
   const bool active = ch < 3 ? d < plan.rgb_degrees : (has_alpha && d < plan.alpha_degrees);
   // Consecutive hits of a wave are neighbouring pixels: at the coarse degrees
   // (256^2, 512^2 textures) they often fall on the SAME corner texels.  Each lane
@@ -309,12 +322,12 @@ __global__ __launch_bounds__(SH_BLOCK) void nt_shade_bwd_kernel(
       const float g = s_graw[ht][ch] * s_basis[ht][m];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int sl = s_slot[ht][d * 4 + k];
+        const int sl = s_row[ht][d * 4 + k];
         const float v = s_w[ht][d * 4 + k] * g;
         if (sl == cur[k]) {
           acc[k] += v;
         } else {
-          if (cur[k] >= 0) atomicAdd(&grad_rows[(long long)cur[k] * 32 + fidx], acc[k]);
+          if (cur[k] >= 0) atomicAdd(&grad_rows[(long long)cur[k] * 4 + fidx], acc[k]);
           cur[k] = sl;
           acc[k] = v;
         }
@@ -324,7 +337,7 @@ __global__ __launch_bounds__(SH_BLOCK) void nt_shade_bwd_kernel(
   if (active) {
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (cur[k] >= 0) atomicAdd(&grad_rows[(long long)cur[k] * 32 + fidx], acc[k]);
+      if (cur[k] >= 0) atomicAdd(&grad_rows[(long long)cur[k] * 4 + fidx], acc[k]);
   }
 }
 
@@ -332,35 +345,38 @@ __global__ __launch_bounds__(SH_BLOCK) void nt_shade_bwd_kernel(
 
 extern "C" int vsa_nt_shade_fwd(const vsa_nt_plan* plan, const int32_t* hit_slot,
                                 const float* tex_uv, const float* rays_d, const float* tris,
-                                const int32_t* slot_of, const uint8_t* texels, int nr_rays,
-                                float* surfs_rgb, float* surfs_alpha, float* surfs_normals,
+                                const int32_t* slot_of, const int32_t* seg_start,
+                                const uint8_t* texels, int nr_rays, float* surfs_rgb, float* surfs_alpha, float* surfs_normals,
                                 float* coeffs_out, void* stream) {
   if (!plan || nr_rays < 0) return VSA_ERR_ARG;
   if (nr_rays == 0) return VSA_OK;
-  if (!hit_slot || !tex_uv || !rays_d || !tris || !slot_of || !texels || !surfs_rgb || !surfs_alpha)
+  if (!hit_slot || !tex_uv || !rays_d || !tris || !slot_of || !seg_start || !texels || !surfs_rgb ||
+      !surfs_alpha)
     return VSA_ERR_ARG;
   dim3 grid(vsa_div_up(nr_rays, SH_BLOCK), plan->nr_shells);
   hipLaunchKernelGGL(nt_shade_fwd_kernel, grid, dim3(SH_BLOCK), 0, (hipStream_t)stream, *plan,
                      hit_slot, tex_uv, rays_d, reinterpret_cast<const float4*>(tris), slot_of,
-                     reinterpret_cast<const uint4*>(texels), nr_rays, surfs_rgb, surfs_alpha,
+                     seg_start, reinterpret_cast<const unsigned*>(texels), nr_rays, surfs_rgb,
+                     surfs_alpha,
                      surfs_normals, coeffs_out);
   VSA_RETURN_LAUNCH_STATUS();
 }
 
 extern "C" int vsa_nt_shade_bwd(const vsa_nt_plan* plan, const int32_t* hit_slot,
                                 const float* tex_uv, const float* rays_d, const float* tris,
-                                const int32_t* slot_of, const uint8_t* texels, int nr_rays,
-                                const float* g_surfs_rgb, const float* g_surfs_alpha,
+                                const int32_t* slot_of, const int32_t* seg_start,
+                                const uint8_t* texels, int nr_rays, const float* g_surfs_rgb, const float* g_surfs_alpha,
                                 float grad_scale, float* grad_rows, void* stream) {
   if (!plan || nr_rays < 0) return VSA_ERR_ARG;
   if (nr_rays == 0) return VSA_OK;
-  if (!hit_slot || !tex_uv || !rays_d || !tris || !slot_of || !texels || !g_surfs_rgb ||
+  if (!hit_slot || !tex_uv || !rays_d || !tris || !slot_of || !seg_start || !texels || !g_surfs_rgb ||
       !g_surfs_alpha || !grad_rows)
     return VSA_ERR_ARG;
   dim3 grid(vsa_div_up(nr_rays, SH_BLOCK), plan->nr_shells);
   hipLaunchKernelGGL(nt_shade_bwd_kernel, grid, dim3(SH_BLOCK), 0, (hipStream_t)stream, *plan,
                      hit_slot, tex_uv, rays_d, reinterpret_cast<const float4*>(tris), slot_of,
-                     reinterpret_cast<const uint4*>(texels), nr_rays, g_surfs_rgb, g_surfs_alpha,
+                     seg_start, reinterpret_cast<const unsigned*>(texels), nr_rays, g_surfs_rgb,
+                     g_surfs_alpha,
                      grad_scale, grad_rows);
   VSA_RETURN_LAUNCH_STATUS();
 }

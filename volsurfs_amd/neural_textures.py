@@ -37,7 +37,12 @@ class Plan(ctypes.Structure):
         ("dom_off", ctypes.c_int64 * (MAX_SHELLS * MAX_DEG + 1)),
         ("slot_capacity", ctypes.c_int64),
         ("max_rays", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("row_base", ctypes.c_int64 * (MAX_SHELLS * MAX_DEG + 1)),
     ]
+
+
+ROW_QUADS = (2, 4, 8, 8)      # VSA_NT_ROW_QUADS(d): quads (4 elements) per texel / gradient row
+ALPHA_QUAD = (1, 3, 4, 6)     # VSA_NT_ALPHA_QUAD(d): first alpha quad of a row
 
 
 def grid_geometry(n_levels=16, log2_hashmap_size=15, base_resolution=16, per_level_scale=1.5):
@@ -80,17 +85,20 @@ class NeuralTextureBank(torch.nn.Module):
             p.level_scale[l], p.level_res[l], p.level_size[l] = scale[l], res[l], size[l]
         for l in range(17):
             p.level_offset[l] = offset[l]
-        off, cap = 0, 0
+        off, cap, quads = 0, 0, 0
         for s in range(K):
             for d in range(MAX_DEG):
                 p.dom_off[s * MAX_DEG + d] = off
+                p.row_base[s * MAX_DEG + d] = quads
                 if d < self.D:
                     T = (textures_res[d] + 2) ** 2
                     off += (T + DOM_BLOCK - 1) // DOM_BLOCK * DOM_BLOCK
                     cap += min(4 * max_rays, T)
-        p.dom_off[K * MAX_DEG] = off
-        for i in range(K * MAX_DEG + 1, MAX_SHELLS * MAX_DEG + 1):
+                    quads += (min(4 * max_rays, T) * ROW_QUADS[d] + 7) // 8 * 8
+        for i in range(K * MAX_DEG, MAX_SHELLS * MAX_DEG + 1):
             p.dom_off[i] = off
+            p.row_base[i] = quads
+        self.row_quads_total = quads
         cap = (cap + 255) // 256 * 256 + 256      # feature planes are blocked by 256 slots
         p.slot_capacity = cap
         p.max_rays = max_rays
@@ -144,8 +152,9 @@ class NeuralTextureBank(torch.nn.Module):
         self.features = torch.empty(2, cap // 256, 16, 256, 2, dtype=torch.float16, device=dev)
         self.tables_h = torch.empty(self.n_tex, self.n_entries, 2, dtype=torch.float16, device=dev)
         self.weights_h = torch.empty(self.n_tex, WEIGHTS_PER_TEX, dtype=torch.float16, device=dev)
-        self.texels = torch.zeros(cap, 32, dtype=u8, device=dev)
-        self.grad_rows = torch.zeros(cap, 32, device=dev) if training else None
+        # per-degree row widths (include/volsurfs_hip.h: VSA_NT_ROW_QUADS), 4 elements per quad
+        self.texels = torch.zeros(self.row_quads_total * 4, dtype=u8, device=dev)
+        self.grad_rows = torch.zeros(self.row_quads_total * 4, device=dev) if training else None
         self.refresh_half_params()
 
     @torch.no_grad()
@@ -185,7 +194,22 @@ class NeuralTextureBank(torch.nn.Module):
             pre = torch.zeros(self.slot_capacity, 32, dtype=torch.float16, device=self.texels.device)
         _lib.call("vsa_nt_mlp_fwd", ctypes.byref(self.plan), self.weights_h, self.features,
                   self.seg_start, self.texels, pre, _lib.stream_ptr())
-        return (self.texels, pre) if want_pre else self.texels
+        return (self.rows_dense(self.texels), pre) if want_pre else self.texels
+
+    def rows_dense(self, buf):
+        """Tests / export: the per-degree rows of `texels` or `grad_rows` re-laid as
+        [slot_capacity, 32] with rgb coefficient c at column c and alpha coefficient c at 24+c."""
+        seg = self.seg_start.cpu().tolist()
+        dense = torch.zeros(self.slot_capacity, 32, dtype=buf.dtype, device=buf.device)
+        for s in range(self.K):
+            for d in range(self.D):
+                sd, n, q = s * MAX_DEG + d, 2 * d + 1, ROW_QUADS[d]
+                a, b = seg[sd], seg[sd + 1]
+                r0 = int(self.plan.row_base[sd]) * 4
+                rows = buf[r0:r0 + (b - a) * q * 4].view(b - a, q * 4)
+                dense[a:b, :3 * n] = rows[:, :3 * n]
+                dense[a:b, 24:24 + n] = rows[:, 4 * ALPHA_QUAD[d]:4 * ALPHA_QUAD[d] + n]
+        return dense
 
     def shade(self, hit_slot, tex_uv, rays_d, tris, want_coeffs=False, want_normals=False):
         K, N = hit_slot.shape
@@ -195,7 +219,8 @@ class NeuralTextureBank(torch.nn.Module):
         normals = torch.empty(N, K, 3, device=dev) if want_normals else None
         coeffs = torch.empty(K, N, 64, device=dev) if want_coeffs else None
         _lib.call("vsa_nt_shade_fwd", ctypes.byref(self.plan), hit_slot, tex_uv, rays_d, tris,
-                  self.slot_of, self.texels, N, rgb, alpha, normals, coeffs, _lib.stream_ptr())
+                  self.slot_of, self.seg_start, self.texels, N, rgb, alpha, normals, coeffs,
+                  _lib.stream_ptr())
         return rgb, alpha, normals, coeffs
 
     def backward(self, hit_slot, tex_uv, rays_d, tris, g_surfs_rgb, g_surfs_alpha, grad_scale):
@@ -218,7 +243,8 @@ class NeuralTextureBank(torch.nn.Module):
     def backward_shade(self, hit_slot, tex_uv, rays_d, tris, g_surfs_rgb, g_surfs_alpha, grad_scale):
         self._ensure_grads()
         _lib.call("vsa_nt_shade_bwd", ctypes.byref(self.plan), hit_slot, tex_uv, rays_d, tris,
-                  self.slot_of, self.texels, hit_slot.shape[1], g_surfs_rgb.contiguous(),
+                  self.slot_of, self.seg_start, self.texels, hit_slot.shape[1],
+                  g_surfs_rgb.contiguous(),
                   g_surfs_alpha.contiguous(), float(grad_scale), self.grad_rows, _lib.stream_ptr())
 
     def backward_mlp(self, grad_scale):
