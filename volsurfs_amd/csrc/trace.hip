@@ -7,7 +7,9 @@
 // grid.y = mesh, one lane per ray, per-lane traversal stack staged in LDS as
 // stack[depth][lane] (bank = lane -> conflict free), 64-byte nodes holding both
 // children's boxes (4 x dwordx4 per visit), leaf triangles as contiguous
-// (v0,e1,e2) float4 triples.
+// (v0,e1,e2) float4 triples; "while-while" control flow (inner-node walk until the
+// whole wave holds leaves, then one converged triangle phase): 0.90 -> 0.45 ms
+// against testing leaves inline at every node visit.
 //
 // Closest hit is defined order-independently (smallest t, ties -> smallest face
 // id) with the triangle test evaluated by one fixed fp32 formula, so the result
@@ -82,12 +84,19 @@ __device__ __forceinline__ bool box_test(float lx, float ly, float lz, float hx,
   return tn <= tf * 1.0000004f + 1e-30f && tf >= t_min && tn <= t_max;
 }
 
+// Traversal state per lane: an inner node index (>= 0), a leaf code (< 0:
+// ~((first << 4) | count)), or TRACE_EMPTY.  "while-while": the wave first walks
+// inner nodes until every lane holds a leaf (or is done), then all lanes test their
+// leaf triangles together -- lanes no longer sit idle through other lanes' triangle
+// loops at every node visit.
+constexpr int TRACE_EMPTY = 0x7fffffff;
+
 template <int STACK>
-__global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
+__global__ __launch_bounds__(TRACE_BLOCK) void trace_ww_kernel(
     const float4* __restrict__ nodes, const float4* __restrict__ tris, Roots roots,
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, int N, float t_min,
     float* __restrict__ hit_t, int* __restrict__ hit_slot, float* __restrict__ hit_uv) {
-  __shared__ int s_stack[STACK][TRACE_BLOCK];   // [depth][lane]: bank = lane, conflict free
+  __shared__ int s_stack[STACK][TRACE_BLOCK];
   const int lane = threadIdx.x;
   const long long n = (long long)blockIdx.x * TRACE_BLOCK + lane;
   const int mesh = blockIdx.y;
@@ -104,47 +113,42 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
 
   int cur = roots.root[mesh];
   int sp = 0;
-  while (true) {
-    const float4 q0 = nodes[4 * (long long)cur + 0];
-    const float4 q1 = nodes[4 * (long long)cur + 1];
-    const float4 q2 = nodes[4 * (long long)cur + 2];
-    const float4 q3 = nodes[4 * (long long)cur + 3];
-    const int ref0 = __float_as_int(q3.x), ref1 = __float_as_int(q3.y);
-    const int cnt0 = __float_as_int(q3.z), cnt1 = __float_as_int(q3.w);
-    float tn0, tn1;
-    bool h0 = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ox, oy, oz, ix, iy, iz, t_min, best.t, tn0);
-    bool h1 = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ox, oy, oz, ix, iy, iz, t_min, best.t, tn1);
-    if (h0 && ref0 < 0) {
-      const int first = ~ref0;
-      for (int i = 0; i < cnt0; ++i) {
+  while (cur != TRACE_EMPTY) {
+    while ((unsigned)cur < (unsigned)TRACE_EMPTY) {
+      const float4 q0 = nodes[4 * (long long)cur + 0];
+      const float4 q1 = nodes[4 * (long long)cur + 1];
+      const float4 q2 = nodes[4 * (long long)cur + 2];
+      const float4 q3 = nodes[4 * (long long)cur + 3];
+      const int ref0 = __float_as_int(q3.x), ref1 = __float_as_int(q3.y);
+      const int cnt0 = __float_as_int(q3.z), cnt1 = __float_as_int(q3.w);
+      float tn0, tn1;
+      bool h0 = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ox, oy, oz, ix, iy, iz, t_min, best.t, tn0);
+      bool h1 = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ox, oy, oz, ix, iy, iz, t_min, best.t, tn1);
+      const int c0 = ref0 < 0 ? ~(((~ref0) << 4) | cnt0) : ref0;
+      const int c1 = ref1 < 0 ? ~(((~ref1) << 4) | cnt1) : ref1;
+      h0 = h0 && !(ref0 < 0 && cnt0 == 0);
+      h1 = h1 && !(ref1 < 0 && cnt1 == 0);
+      if (h0 && h1) {
+        const bool swap = tn1 < tn0;
+        s_stack[sp++][lane] = swap ? c0 : c1;
+        cur = swap ? c1 : c0;
+      } else if (h0) {
+        cur = c0;
+      } else if (h1) {
+        cur = c1;
+      } else {
+        cur = sp ? s_stack[--sp][lane] : TRACE_EMPTY;
+      }
+    }
+    if (cur != TRACE_EMPTY) {
+      const int code = ~cur;
+      const int first = code >> 4, cnt = code & 15;
+      for (int i = 0; i < cnt; ++i) {
         const long long s = first + i;
         tri_test(tris[3 * s], tris[3 * s + 1], tris[3 * s + 2], ox, oy, oz, dx, dy, dz, t_min,
                  (int)s, best);
       }
-      h0 = false;
-    }
-    if (h1 && ref1 < 0) {
-      const int first = ~ref1;
-      for (int i = 0; i < cnt1; ++i) {
-        const long long s = first + i;
-        tri_test(tris[3 * s], tris[3 * s + 1], tris[3 * s + 2], ox, oy, oz, dx, dy, dz, t_min,
-                 (int)s, best);
-      }
-      h1 = false;
-    }
-    if (h0 && h1) {
-      const bool swap = tn1 < tn0;
-      const int near_ref = swap ? ref1 : ref0;
-      const int far_ref = swap ? ref0 : ref1;
-      s_stack[sp++][lane] = far_ref;
-      cur = near_ref;
-    } else if (h0) {
-      cur = ref0;
-    } else if (h1) {
-      cur = ref1;
-    } else {
-      if (sp == 0) break;
-      cur = s_stack[--sp][lane];
+      cur = sp ? s_stack[--sp][lane] : TRACE_EMPTY;
     }
   }
   const long long o = (long long)mesh * N + n;
@@ -210,11 +214,11 @@ extern "C" int vsa_trace(const float* nodes, const float* tris, const int32_t* m
   // case: depth 16 for 82k-triangle shells) take a 24-entry stack = 24 KiB of LDS
   // per workgroup -> 6 workgroups per CU instead of 3
   if (max_depth < 24)
-    hipLaunchKernelGGL(trace_kernel<24>, grid, block, 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(trace_ww_kernel<24>, grid, block, 0, (hipStream_t)stream,
                        reinterpret_cast<const float4*>(nodes), reinterpret_cast<const float4*>(tris),
                        r, rays_o, rays_d, nr_rays, t_min, hit_t, hit_slot, hit_uv);
   else
-    hipLaunchKernelGGL(trace_kernel<TRACE_STACK>, grid, block, 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(trace_ww_kernel<TRACE_STACK>, grid, block, 0, (hipStream_t)stream,
                        reinterpret_cast<const float4*>(nodes), reinterpret_cast<const float4*>(tris),
                        r, rays_o, rays_d, nr_rays, t_min, hit_t, hit_slot, hit_uv);
   VSA_RETURN_LAUNCH_STATUS();
