@@ -525,8 +525,6 @@ __global__ __launch_bounds__(BWD_BLOCK, 1) void nt_mlp_bwd_kernel(
 // workgroup barrier per tile over a double-buffered image set.
 constexpr int PC_BLOCK = 512;
 constexpr int PC_PAIRS = 4;
-constexpr int PC_TPP = 32;                            // tiles per pair
-constexpr int MLP_PC_SPAN = PC_PAIRS * PC_TPP * 32;
 constexpr int S64 = 68, S32 = 40;   // row strides (halfs): 136 B (8-B aligned, bank-spread), 80 B (16-B aligned)
 constexpr int SET_DOUT = 0, SET_X = 32 * S32, SET_H2 = 2 * 32 * S32, SET_H1 = SET_H2 + 32 * S64;
 constexpr int SET_HALFS = SET_H1 + 32 * S64;          // one {dOut, X, H2, H1} set
@@ -570,6 +568,9 @@ __device__ __forceinline__ half8_t read_tr_s(const _Float16* img, int col_base, 
   return __builtin_bit_cast(half8_t, both);
 }
 
+#ifdef NT_STAMP
+__device__ unsigned long long g_dbg[16384 * 8];   // per-workgroup timeline of the last pc launch
+#endif
 #ifdef NT_STAMP   // diagnostic build only (tools: make EXTRA=-DNT_STAMP): per-role cycles per tile
 #define STAMP(var)                                                               \
   {                                                                              \
@@ -587,16 +588,21 @@ __device__ __forceinline__ void pc_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-__global__ __launch_bounds__(PC_BLOCK, 2) void nt_mlp_bwd_pc_kernel(
-    vsa_nt_plan plan, EncLaunch L, const _Float16* __restrict__ weights,
-    unsigned* __restrict__ features, const int* __restrict__ seg_start,
-    float* __restrict__ grad_rows, float* __restrict__ grad_weights,
-    float* __restrict__ dfeat_abs_sum) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+// One run = a contiguous slot range [wk.first, wk.last) of ONE texture: stage the weight
+// fragments, stream the tiles through the producer/consumer pairs, reduce and flush the
+// weight gradients.
+__device__ __forceinline__ void pc_run(
+    const vsa_nt_plan& plan, const Work wk, unsigned char* s_raw,
+    const _Float16* __restrict__ weights, unsigned* __restrict__ features,
+    const int* __restrict__ seg_start, float* __restrict__ grad_rows,
+    float* __restrict__ grad_weights, float* __restrict__ dfeat_abs_sum) {
   half8_t* s_frag = reinterpret_cast<half8_t*>(s_raw) - 16 * 64;   // indexed by fragment id 16..35 (20 KiB)
   _Float16* s_img_all = reinterpret_cast<_Float16*>(s_raw + PC_FRAGS * 64 * 16);
-  Work wk;
-  if (!decode_work(plan, L, seg_start, blockIdx.x, wk)) return;
+#ifdef NT_STAMP
+  unsigned long long ph0, ph1, ph2, ph3, rt0, rt1;
+  STAMP(ph0);
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");
+#endif
   const int tex = wk.tex;
   const TexInfo ti = tex_info(plan, seg_start, tex);
   {
@@ -647,6 +653,9 @@ __global__ __launch_bounds__(PC_BLOCK, 2) void nt_mlp_bwd_pc_kernel(
   _Float16* priv = pair + 2 * SET_HALFS;
   const int ntiles = (wk.last - wk.first + 31) >> 5;
   const int iters = (ntiles + PC_PAIRS - 1) / PC_PAIRS;     // same for every wave: barriers match
+#ifdef NT_STAMP
+  STAMP(ph1);
+#endif
 
   if (producer) {
     auto load_grows = [&](int slot, float4 gr[4]) {
@@ -731,7 +740,10 @@ __global__ __launch_bounds__(PC_BLOCK, 2) void nt_mlp_bwd_pc_kernel(
 #endif
     }
 #ifdef NT_STAMP
-    if (blockIdx.x == 3 && lane == 0) printf("P wave %d: work %llu barrier-wait %llu cycles/tile\n", wave, tw_ / iters, tb_ / iters);
+    if (blockIdx.x == 0x7fffffff && lane == 0) printf("P wave %d: work %llu barrier-wait %llu cycles/tile\n", wave, tw_ / iters, tb_ / iters);
+#endif
+#ifdef NT_STAMP
+    STAMP(ph2);
 #endif
     // weight-gradient reduction: the consumers go first (they initialise the buffer),
     // then the producers add their dW3
@@ -851,7 +863,10 @@ __global__ __launch_bounds__(PC_BLOCK, 2) void nt_mlp_bwd_pc_kernel(
 #endif
     }
 #ifdef NT_STAMP
-    if (blockIdx.x == 3 && lane == 0) printf("C wave %d: work %llu barrier-wait %llu cycles/tile\n", wave, tw_ / iters, tb_ / iters);
+    if (blockIdx.x == 0x7fffffff && lane == 0) printf("C wave %d: work %llu barrier-wait %llu cycles/tile\n", wave, tw_ / iters, tb_ / iters);
+#endif
+#ifdef NT_STAMP
+    STAMP(ph2);
 #endif
     // sum |dF| per feature row: reduce over the 32 lanes of each half, one atomic per row
 #pragma unroll
@@ -898,9 +913,76 @@ __global__ __launch_bounds__(PC_BLOCK, 2) void nt_mlp_bwd_pc_kernel(
       if (v != 0.0f) atomicAdd(&gw[i], v);
     }
   }
+#ifdef NT_STAMP
+  STAMP(ph3);
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1)::"memory");
+  if (threadIdx.x == 0 && blockIdx.x < 16384) {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* d = g_dbg + 8 * blockIdx.x;
+    d[0] = rt0; d[1] = rt1; d[2] = ((unsigned long long)xcc << 32) | hwid; d[3] = iters;
+    d[4] = ph1 - ph0; d[5] = ph2 - ph1; d[6] = ph3 - ph2; d[7] = 1;
+  }
+#endif
+}
+
+// Persistent launch: gridDim.x workgroups (one per CU; the LDS footprint allows no more)
+// split the frame's tiles evenly.  Work is laid out on a cost axis: every active texture
+// contributes PC_RUN_COST units of spacing (a run's staging + reduction, measured ~11 loop
+// iterations) followed by one unit per 32-slot tile; workgroup w owns the tiles whose
+// coordinate falls in [w*C/G, (w+1)*C/G).  Replaces one workgroup per 4096 slots of the
+// worst-case capacity (70 % of them empty at the bench frame, each still needing the whole
+// CU's LDS to launch and exit; in-kernel timeline: 196 of 256 CUs busy on average, 26 %
+// of a workgroup's cycles in staging + reduction): 1.35 -> 0.88 ms.
+constexpr int PC_RUN_COST = 44;
+
+__global__ __launch_bounds__(PC_BLOCK, 2) void nt_mlp_bwd_pc_kernel(
+    vsa_nt_plan plan, const _Float16* __restrict__ weights,
+    unsigned* __restrict__ features, const int* __restrict__ seg_start,
+    float* __restrict__ grad_rows, float* __restrict__ grad_weights,
+    float* __restrict__ dfeat_abs_sum) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  const int n_tex = plan.nr_shells * 2 * VSA_NT_MAX_DEG;
+  long long total = 0;
+  for (int tex = 0; tex < n_tex; ++tex) {
+    if (!tex_active(plan, tex)) continue;
+    const int sd = (tex / (2 * VSA_NT_MAX_DEG)) * VSA_NT_MAX_DEG + tex % VSA_NT_MAX_DEG;
+    const int len = seg_start[sd + 1] - seg_start[sd];
+    if (len > 0) total += PC_RUN_COST + ((len + 31) >> 5);
+  }
+  const long long lo = total * blockIdx.x / gridDim.x, hi = total * (blockIdx.x + 1) / gridDim.x;
+  long long c0 = 0;
+  for (int tex = 0; tex < n_tex; ++tex) {
+    if (!tex_active(plan, tex)) continue;
+    const int sd = (tex / (2 * VSA_NT_MAX_DEG)) * VSA_NT_MAX_DEG + tex % VSA_NT_MAX_DEG;
+    const int begin = seg_start[sd], end = seg_start[sd + 1];
+    if (end <= begin) continue;
+    const int ntiles = (end - begin + 31) >> 5;
+    const long long t0 = c0 + PC_RUN_COST;     // coordinate of this texture's tile 0
+    c0 = t0 + ntiles;
+    if (t0 >= hi) break;
+    const long long a = lo > t0 ? lo - t0 : 0, b = hi - t0 < ntiles ? hi - t0 : ntiles;
+    if (b <= a) continue;
+    Work wk;
+    wk.tex = tex;
+    wk.seg_len = end - begin;
+    wk.first = begin + (int)a * 32;
+    wk.last = min(end, begin + (int)b * 32);
+    pc_run(plan, wk, s_raw, weights, features, seg_start, grad_rows, grad_weights, dfeat_abs_sum);
+    __syncthreads();   // the next run re-stages the fragments
+  }
 }
 
 }  // namespace
+
+#ifdef NT_STAMP
+extern "C" int vsa_debug_read(void* dst) {
+  VSA_HIP_TRY(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * 16384 * 8));
+  VSA_HIP_TRY(hipMemset(nullptr, 0, 0));
+  return 0;
+}
+#endif
 
 extern "C" int vsa_nt_mlp_fwd(const vsa_nt_plan* plan, const void* weights_h, const void* features,
                               const int32_t* seg_start, uint8_t* texels, void* pre_out,
@@ -944,10 +1026,15 @@ extern "C" int vsa_nt_mlp_bwd(const vsa_nt_plan* plan, const void* weights_h, vo
                        dfeat_abs_sum);
   } else {
     const size_t lds = (size_t)PC_FRAGS * 64 * 16 + (size_t)PC_PAIRS * PAIR_HALFS * 2;   // >= frags + 32 KiB reduction buffer
-    const EncLaunch L = enc_launch(plan, 0, MLP_PC_SPAN);
-    dim3 grid(L.per_model * plan->nr_shells * 2);
-    hipLaunchKernelGGL(nt_mlp_bwd_pc_kernel, grid, dim3(PC_BLOCK), lds, (hipStream_t)stream, *plan,
-                       L, reinterpret_cast<const _Float16*>(weights_h),
+    static int nr_cus = 0;
+    if (!nr_cus) {
+      int dev = 0;
+      VSA_HIP_TRY(hipGetDevice(&dev));
+      VSA_HIP_TRY(hipDeviceGetAttribute(&nr_cus, hipDeviceAttributeMultiprocessorCount, dev));
+      if (nr_cus < 1) nr_cus = 256;
+    }
+    hipLaunchKernelGGL(nt_mlp_bwd_pc_kernel, dim3(nr_cus), dim3(PC_BLOCK), lds, (hipStream_t)stream,
+                       *plan, reinterpret_cast<const _Float16*>(weights_h),
                        reinterpret_cast<unsigned*>(features), seg_start, grad_rows, grad_weights,
                        dfeat_abs_sum);
   }
