@@ -36,3 +36,16 @@ __device__ __forceinline__ float vsa_pin_f32(float x) {
 }
 
 static inline int vsa_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Compute units of the current device (grid size of the persistent kernels).
+static inline int vsa_cu_count(int* out) {
+  static int cached = 0;
+  if (!cached) {
+    int dev = 0, n = 0;
+    VSA_HIP_TRY(hipGetDevice(&dev));
+    VSA_HIP_TRY(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    cached = n > 0 ? n : 256;
+  }
+  *out = cached;
+  return VSA_OK;
+}

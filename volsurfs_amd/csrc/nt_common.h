@@ -124,6 +124,52 @@ __device__ __forceinline__ bool decode_work(const vsa_nt_plan& p, const EncLaunc
 }
 
 
+// Persistent work split (one workgroup per CU for the LDS-hungry kernels).  The launch's
+// work = n_planes x (every active texture's slots), laid out on one cost axis in units of
+// UNIT slots: plane-major, and within a plane each non-empty texture contributes `ovh`
+// units of spacing (the per-piece setup: staging / zeroing / flushing LDS) followed by
+// ceil(len / UNIT) units.  Workgroup w owns the units whose coordinate lies in
+// [w*C/G, (w+1)*C/G) and calls body(plane, tex, first_slot, last_slot, seg_begin, seg_end)
+// once per (plane, texture) it overlaps.  All of it is wave-uniform scalar code.
+// Replaces grids sized for the worst-case slot capacity, where ~2/3 of the workgroups
+// found nothing to do yet each needed a whole CU's LDS to launch and exit.
+template <int UNIT, typename Body>
+__device__ __forceinline__ void nt_for_each_piece(const vsa_nt_plan& plan,
+                                                  const int* __restrict__ seg_start, int n_planes,
+                                                  int ovh, Body&& body) {
+  const int n_tex = plan.nr_shells * 2 * VSA_NT_MAX_DEG;
+  long long T = 0;
+  for (int tex = 0; tex < n_tex; ++tex) {
+    if (!tex_active(plan, tex)) continue;
+    const int sd = (tex / (2 * VSA_NT_MAX_DEG)) * VSA_NT_MAX_DEG + tex % VSA_NT_MAX_DEG;
+    const int len = seg_start[sd + 1] - seg_start[sd];
+    if (len > 0) T += ovh + (len + UNIT - 1) / UNIT;
+  }
+  if (T == 0) return;
+  const long long total = T * n_planes;
+  const long long lo = total * blockIdx.x / gridDim.x, hi = total * (blockIdx.x + 1) / gridDim.x;
+  if (hi <= lo) return;
+  const int pl0 = (int)(lo / T), pl1 = (int)((hi - 1) / T);
+  for (int pl = pl0; pl <= pl1; ++pl) {
+    long long c0 = (long long)pl * T;
+    for (int tex = 0; tex < n_tex; ++tex) {
+      if (!tex_active(plan, tex)) continue;
+      const int sd = (tex / (2 * VSA_NT_MAX_DEG)) * VSA_NT_MAX_DEG + tex % VSA_NT_MAX_DEG;
+      const int begin = seg_start[sd], end = seg_start[sd + 1];
+      if (end <= begin) continue;
+      const int units = (end - begin + UNIT - 1) / UNIT;
+      const long long t0 = c0 + ovh;
+      c0 = t0 + units;
+      if (t0 >= hi) break;
+      const long long a = lo > t0 ? lo - t0 : 0, b = hi - t0 < units ? hi - t0 : units;
+      if (b <= a) continue;
+      const int first = begin + (int)a * UNIT;
+      const long long lastl = (long long)begin + b * UNIT;
+      body(pl, tex, first, lastl < end ? (int)lastl : end, begin, end);
+    }
+  }
+}
+
 static inline EncLaunch enc_launch(const vsa_nt_plan* p, int level0, int span) {
   EncLaunch L;
   L.level0 = level0;

@@ -19,8 +19,7 @@ namespace {
 
 constexpr int ENC_BLOCK = 1024;     // 16 waves: a 128 KiB level pins one workgroup per CU
 constexpr int ENC_UNROLL = 8;       // slots in flight per lane
-constexpr int ENC_SPAN_FWD = 262144;  // slots per workgroup (forward): amortises staging the level
-constexpr int ENC_SPAN_BWD = 262144;  // slots per workgroup before a flush (backward)
+constexpr int ENC_UNIT = 256;       // slot granularity of the persistent work split (nt_common.h)
 constexpr unsigned PRIME_Y = 2654435761u;
 constexpr int LDS_ENTRIES = 32768;    // 4-byte entries of LDS a workgroup may use (128 KiB)
 
@@ -43,95 +42,117 @@ struct CellCorners {
   float w[4];
 };
 
-// normalised texel centre -> the 4 table entries and bilinear weights at level g
+// normalised texel centre -> grid cell and bilinear weights at level g
 // (oracle/tcnn_like.py hashgrid_forward: same fp32 operations in the same order).
-// HASHED: tiny-cuda-nn's coherent prime hash, table size 2^k.  Dense: x + y*res,
-// wrapped only at the far edge / on the apron of tiny textures.
-template <bool HASHED>
-__device__ __forceinline__ CellCorners cell_corners(const LevelGeom& g, float x, float y) {
+struct CellRef {
+  unsigned cx, cy;
+  float w[4];
+};
+
+__device__ __forceinline__ CellRef cell_ref(const LevelGeom& g, float x, float y) {
   const float px = x * g.scale + 0.5f, py = y * g.scale + 0.5f;
   const float flx = floorf(px), fly = floorf(py);
   const float fx = px - flx, fy = py - fly;
-  const unsigned cx = (unsigned)(int)flx, cy = (unsigned)(int)fly;
   const float gx = 1.0f - fx, gy = 1.0f - fy;
-  CellCorners c;
+  CellRef c;
+  c.cx = (unsigned)(int)flx;
+  c.cy = (unsigned)(int)fly;
   c.w[0] = gx * gy;
   c.w[1] = fx * gy;
   c.w[2] = gx * fy;
   c.w[3] = fx * fy;
+  return c;
+}
+
+// the 4 table entries of a cell.  HASHED: tiny-cuda-nn's coherent prime hash, table
+// size 2^k.  Dense: x + y*res, wrapped only at the far edge / on the apron of tiny
+// textures.
+template <bool HASHED>
+__device__ __forceinline__ void cell_indices(const LevelGeom& g, unsigned cx, unsigned cy,
+                                             unsigned idx[4]) {
   if (HASHED) {
     const unsigned h0 = cy * PRIME_Y, h1 = (cy + 1u) * PRIME_Y;
-    c.idx[0] = (cx ^ h0) & g.mask;
-    c.idx[1] = ((cx + 1u) ^ h0) & g.mask;
-    c.idx[2] = (cx ^ h1) & g.mask;
-    c.idx[3] = ((cx + 1u) ^ h1) & g.mask;
+    idx[0] = (cx ^ h0) & g.mask;
+    idx[1] = ((cx + 1u) ^ h0) & g.mask;
+    idx[2] = (cx ^ h1) & g.mask;
+    idx[3] = ((cx + 1u) ^ h1) & g.mask;
   } else {
     const unsigned r0 = cx + cy * g.res;
-    c.idx[0] = r0;
-    c.idx[1] = r0 + 1u;
-    c.idx[2] = r0 + g.res;
-    c.idx[3] = r0 + g.res + 1u;
-    if (c.idx[3] >= g.size || c.idx[0] > c.idx[3]) {
+    idx[0] = r0;
+    idx[1] = r0 + 1u;
+    idx[2] = r0 + g.res;
+    idx[3] = r0 + g.res + 1u;
+    if (idx[3] >= g.size || idx[0] > idx[3]) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) c.idx[k] %= g.size;
+      for (int k = 0; k < 4; ++k) idx[k] %= g.size;
     }
   }
+}
+
+template <bool HASHED>
+__device__ __forceinline__ CellCorners cell_corners(const LevelGeom& g, float x, float y) {
+  const CellRef r = cell_ref(g, x, y);
+  CellCorners c;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) c.w[k] = r.w[k];
+  cell_indices<HASHED>(g, r.cx, r.cy, c.idx);
   return c;
 }
 
 template <bool HASHED>
 __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
-    vsa_nt_plan plan, EncLaunch L, const half2_t* __restrict__ tables,
+    vsa_nt_plan plan, int level0, int n_levels, const half2_t* __restrict__ tables,
     const float2* __restrict__ slot_xy, const int* __restrict__ seg_start,
     half2_t* __restrict__ features) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   half2_t* s_tab = reinterpret_cast<half2_t*>(s_raw);
-  const int level = L.level0 + blockIdx.y;
-  Work wk;
-  if (!decode_work(plan, L, seg_start, blockIdx.x, wk)) return;
-  const int last = wk.last;
-  const LevelGeom g = level_geom(plan, level);
   const long long n_entries = plan.level_offset[plan.n_levels];
-  const half2_t* tab = tables + (long long)wk.tex * n_entries + plan.level_offset[level];
-  {  // stage the level (size is a multiple of 8 entries = 32 B)
-    const uint4* src = reinterpret_cast<const uint4*>(tab);
-    uint4* dst = reinterpret_cast<uint4*>(s_tab);
-    for (int i = threadIdx.x; i < (int)(g.size / 4); i += ENC_BLOCK) dst[i] = src[i];
-  }
-  __syncthreads();
-  const int type = (wk.tex / VSA_NT_MAX_DEG) & 1;
-  half2_t* out = features + nt_feat_plane_base(plan, type, level);
   const int nl = plan.n_levels;
-  for (int base = wk.first + threadIdx.x; base < last; base += ENC_BLOCK * ENC_UNROLL) {
-    float2 xy[ENC_UNROLL];
-#pragma unroll
-    for (int u = 0; u < ENC_UNROLL; ++u) {
-      const int slot = base + u * ENC_BLOCK;
-      xy[u] = slot_xy[slot < last ? slot : last - 1];
+  nt_for_each_piece<ENC_UNIT>(plan, seg_start, n_levels, HASHED ? 32 : 8,
+                              [&](int pl, int tex, int first, int last, int, int) {
+    const int level = level0 + pl;
+    const LevelGeom g = level_geom(plan, level);
+    const half2_t* tab = tables + (long long)tex * n_entries + plan.level_offset[level];
+    __syncthreads();   // the previous piece is done with the table
+    {  // stage the level (size is a multiple of 8 entries = 32 B)
+      const uint4* src = reinterpret_cast<const uint4*>(tab);
+      uint4* dst = reinterpret_cast<uint4*>(s_tab);
+      for (int i = threadIdx.x; i < (int)(g.size / 4); i += ENC_BLOCK) dst[i] = src[i];
     }
-    CellCorners c[ENC_UNROLL];
+    __syncthreads();
+    const int type = (tex / VSA_NT_MAX_DEG) & 1;
+    half2_t* out = features + nt_feat_plane_base(plan, type, level);
+    for (int base = first + threadIdx.x; base < last; base += ENC_BLOCK * ENC_UNROLL) {
+      float2 xy[ENC_UNROLL];
 #pragma unroll
-    for (int u = 0; u < ENC_UNROLL; ++u) c[u] = cell_corners<HASHED>(g, xy[u].x, xy[u].y);
-    half2_t v[ENC_UNROLL][4];
-#pragma unroll
-    for (int u = 0; u < ENC_UNROLL; ++u)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[u][k] = s_tab[c[u].idx[k]];
-#pragma unroll
-    for (int u = 0; u < ENC_UNROLL; ++u) {
-      const int slot = base + u * ENC_BLOCK;
-      float f0 = 0.f, f1 = 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        f0 = f0 + c[u].w[k] * (float)v[u][k].x;
-        f1 = f1 + c[u].w[k] * (float)v[u][k].y;
+      for (int u = 0; u < ENC_UNROLL; ++u) {
+        const int slot = base + u * ENC_BLOCK;
+        xy[u] = slot_xy[slot < last ? slot : last - 1];
       }
-      half2_t r;
-      r.x = (_Float16)f0;
-      r.y = (_Float16)f1;
-      if (slot < last) out[nt_feat_in_plane(nl, slot)] = r;
+      CellCorners c[ENC_UNROLL];
+#pragma unroll
+      for (int u = 0; u < ENC_UNROLL; ++u) c[u] = cell_corners<HASHED>(g, xy[u].x, xy[u].y);
+      half2_t v[ENC_UNROLL][4];
+#pragma unroll
+      for (int u = 0; u < ENC_UNROLL; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[u][k] = s_tab[c[u].idx[k]];
+#pragma unroll
+      for (int u = 0; u < ENC_UNROLL; ++u) {
+        const int slot = base + u * ENC_BLOCK;
+        float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          f0 = f0 + c[u].w[k] * (float)v[u][k].x;
+          f1 = f1 + c[u].w[k] * (float)v[u][k].y;
+        }
+        half2_t r;
+        r.x = (_Float16)f0;
+        r.y = (_Float16)f1;
+        if (slot < last) out[nt_feat_in_plane(nl, slot)] = r;
+      }
     }
-  }
+  });
 }
 
 // Backward: grad_table[tex][level entries][feature] += w * dF[slot]; one
@@ -150,82 +171,105 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
 // and summed at the flush.
 template <bool HASHED>
 __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
-    vsa_nt_plan plan, EncLaunch L, const half2_t* __restrict__ dfeatures,
+    vsa_nt_plan plan, int level0, int n_levels, const half2_t* __restrict__ dfeatures,
     const float* __restrict__ dfeat_abs_sum, float dscale_inv,
     const float2* __restrict__ slot_xy, const int* __restrict__ seg_start,
     float* __restrict__ grad_tables) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   int* s_g = reinterpret_cast<int*>(s_raw);
-  const int level = L.level0 + (blockIdx.y >> 1), feat = blockIdx.y & 1;
-  Work wk;
-  if (!decode_work(plan, L, seg_start, blockIdx.x, wk)) return;
-  const int first = wk.first, last = wk.last;
-  const LevelGeom g = level_geom(plan, level);
-  int copies = 1;
-  if (!HASHED) {
-    while (copies < 32 && (long long)g.size * copies * 2 <= LDS_ENTRIES) copies *= 2;
-  }
-  for (int i = threadIdx.x; i < (int)g.size * copies; i += ENC_BLOCK) s_g[i] = 0;
-  int* my_g = s_g + (threadIdx.x & (copies - 1)) * g.size;   // consecutive lanes -> different copies
-  const int type = (wk.tex / VSA_NT_MAX_DEG) & 1;
   const int nl = plan.n_levels;
-  // fixed-point scale from sum |dF| over the WHOLE (texture, level, feature) plane,
-  // accumulated by the MLP backward kernel while it wrote dF (an upper bound for
-  // this workgroup's share; saves a second pass over dF)
-  const unsigned* dFw = reinterpret_cast<const unsigned*>(dfeatures + nt_feat_plane_base(plan, type, level));
-  const int shift = 16 * feat;
-  const float total = dfeat_abs_sum[wk.tex * 32 + 2 * level + feat] * 1.001f;
-  __syncthreads();
-  if (!(total > 0.f)) return;   // nothing to add (uniform across the workgroup)
-  int e;
-  frexpf(total, &e);                       // total = m * 2^e, m in [0.5, 1)
-  const float S = ldexpf(1.0f, 30 - e);    // power of two: exact scaling and un-scaling
-  const float S_inv = ldexpf(1.0f, e - 30) * dscale_inv;
-  // pass 2: scatter.  Lanes are dealt in groups of 8: a group walks its own
-  // 1/128th of the slot range (64-byte coalesced loads per group), so that the
-  // 64 lanes of a wave touch 8 distant texture regions instead of 64 neighbouring
-  // texels that share one coarse cell (same-address LDS atomics serialise).
-  // (Hashed levels scatter pseudo-randomly anyway: they keep fully coalesced loads.)
-  constexpr int GW = HASHED ? ENC_BLOCK : 8;            // lanes that walk one sub-range together
-  const int grp = threadIdx.x / GW, j8 = threadIdx.x % GW;
-  const int sub = (((last - first) + (ENC_BLOCK / GW) - 1) / (ENC_BLOCK / GW) + GW - 1) / GW * GW;
-  const int g_first = first + grp * sub;
-  const int g_last = min(last, g_first + sub);
-  for (int base = g_first + j8; base < g_last; base += GW * ENC_UNROLL) {
-    float2 xy[ENC_UNROLL];
-    unsigned dw[ENC_UNROLL];
-#pragma unroll
-    for (int u = 0; u < ENC_UNROLL; ++u) {
-      const int slot = base + u * GW;
-      const int sl = slot < g_last ? slot : first;
-      xy[u] = slot_xy[sl];
-      dw[u] = slot < g_last ? dFw[nt_feat_in_plane(nl, sl)] >> shift : 0u;
+  const long long n_entries = plan.level_offset[plan.n_levels];
+  nt_for_each_piece<ENC_UNIT>(plan, seg_start, 2 * n_levels, 64,
+                              [&](int pl, int tex, int first, int last, int seg_begin, int seg_end) {
+    const int level = level0 + (pl >> 1), feat = pl & 1;
+    const LevelGeom g = level_geom(plan, level);
+    // fixed-point scale from sum |dF| over the WHOLE (texture, level, feature) plane,
+    // accumulated by the MLP backward kernel while it wrote dF (an upper bound for
+    // this piece's share; saves a second pass over dF)
+    const float total = dfeat_abs_sum[tex * 32 + 2 * level + feat] * 1.001f;
+    if (!(total > 0.f)) return;   // nothing to add (uniform across the workgroup)
+    int copies = 1;
+    if (!HASHED) {
+      while (copies < 32 && (long long)g.size * copies * 2 <= LDS_ENTRIES) copies *= 2;
     }
+    __syncthreads();   // the previous piece's flush has read the plane
+    for (int i = threadIdx.x; i < (int)g.size * copies; i += ENC_BLOCK) s_g[i] = 0;
+    int* my_g = s_g + (threadIdx.x & (copies - 1)) * g.size;   // consecutive lanes -> different copies
+    const int type = (tex / VSA_NT_MAX_DEG) & 1;
+    const unsigned* dFw = reinterpret_cast<const unsigned*>(dfeatures + nt_feat_plane_base(plan, type, level));
+    const int shift = 16 * feat;
+    __syncthreads();
+    int e;
+    frexpf(total, &e);                       // total = m * 2^e, m in [0.5, 1)
+    const float S = ldexpf(1.0f, 30 - e);    // power of two: exact scaling and un-scaling
+    const float S_inv = ldexpf(1.0f, e - 30) * dscale_inv;
+    // scatter.  A lane owns ENC_UNROLL = 8 CONSECUTIVE slots (= neighbouring texels of one
+    // texture row): 64 B of texel centres and 32 B of dF per lane come in as dwordx4
+    // loads; the 64 lanes of a wave are 8 texels apart, so they share a grid cell only at
+    // the coarsest levels (same-address LDS atomics serialise; those small planes are
+    // replicated, see `copies`); and while consecutive slots of a lane stay in one cell
+    // their four corner contributions are summed in registers and added once.  The sums
+    // are integers, so the result is independent of this grouping.
+    const int a_first = first & ~(ENC_UNROLL - 1);
+    for (int s0 = a_first + threadIdx.x * ENC_UNROLL; s0 < last; s0 += ENC_BLOCK * ENC_UNROLL) {
+      float4 xyv[ENC_UNROLL / 2];
+      uint4 dv[ENC_UNROLL / 4];
+      const float4* xp = reinterpret_cast<const float4*>(slot_xy + s0);
+      const uint4* dp = reinterpret_cast<const uint4*>(dFw + nt_feat_in_plane(nl, s0));
 #pragma unroll
-    for (int u = 0; u < ENC_UNROLL; ++u) {
-      const float gv = (float)__builtin_bit_cast(_Float16, (unsigned short)dw[u]) * S;
-      if (gv != 0.f) {
-        const CellCorners c = cell_corners<HASHED>(g, xy[u].x, xy[u].y);
+      for (int i = 0; i < ENC_UNROLL / 2; ++i) xyv[i] = xp[i];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) atomicAdd(&my_g[c.idx[k]], __float2int_rn(c.w[k] * gv));
+      for (int i = 0; i < ENC_UNROLL / 4; ++i) dv[i] = dp[i];
+      const unsigned dws[ENC_UNROLL] = {dv[0].x, dv[0].y, dv[0].z, dv[0].w,
+                                        dv[1].x, dv[1].y, dv[1].z, dv[1].w};
+      unsigned cur_idx[4] = {0, 0, 0, 0};
+      int acc[4] = {0, 0, 0, 0};
+      unsigned cur_cx = 0xffffffffu, cur_cy = 0xffffffffu;
+#pragma unroll
+      for (int u = 0; u < ENC_UNROLL; ++u) {
+        const int slot = s0 + u;
+        const float x = (u & 1) ? xyv[u >> 1].z : xyv[u >> 1].x;
+        const float y = (u & 1) ? xyv[u >> 1].w : xyv[u >> 1].y;
+        const float gv = (float)__builtin_bit_cast(_Float16, (unsigned short)(dws[u] >> shift)) * S;
+        if (slot >= first && slot < last && gv != 0.f) {
+          const CellRef cr = cell_ref(g, x, y);
+          const int v0 = __float2int_rn(cr.w[0] * gv), v1 = __float2int_rn(cr.w[1] * gv),
+                    v2 = __float2int_rn(cr.w[2] * gv), v3 = __float2int_rn(cr.w[3] * gv);
+          if (cr.cx == cur_cx && cr.cy == cur_cy) {
+            acc[0] += v0, acc[1] += v1, acc[2] += v2, acc[3] += v3;
+          } else {
+            if (cur_cx != 0xffffffffu) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                if (acc[k]) atomicAdd(&my_g[cur_idx[k]], acc[k]);
+            }
+            cur_cx = cr.cx, cur_cy = cr.cy;
+            cell_indices<HASHED>(g, cr.cx, cr.cy, cur_idx);
+            acc[0] = v0, acc[1] = v1, acc[2] = v2, acc[3] = v3;
+          }
+        }
+      }
+      if (cur_cx != 0xffffffffu) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (acc[k]) atomicAdd(&my_g[cur_idx[k]], acc[k]);
       }
     }
-  }
-  __syncthreads();
-  const long long n_entries = plan.level_offset[plan.n_levels];
-  float* gt = grad_tables + ((long long)wk.tex * n_entries + plan.level_offset[level]) * 2 + feat;
-  const bool single = wk.seg_len <= L.span;
-  for (int i = threadIdx.x; i < (int)g.size; i += ENC_BLOCK) {
-    int vi = 0;
-    for (int cpy = 0; cpy < copies; ++cpy) vi += s_g[cpy * g.size + i];
-    if (vi == 0) continue;
-    const float v = (float)vi * S_inv;
-    if (single) {
-      gt[2 * (long long)i] += v;  // sole writer of this (texture, level, feature) plane
-    } else {
-      atomicAdd(&gt[2 * (long long)i], v);
+    __syncthreads();
+    float* gt = grad_tables + ((long long)tex * n_entries + plan.level_offset[level]) * 2 + feat;
+    const bool single = first == seg_begin && last == seg_end;
+    for (int i = threadIdx.x; i < (int)g.size; i += ENC_BLOCK) {
+      int vi = 0;
+      for (int cpy = 0; cpy < copies; ++cpy) vi += s_g[cpy * g.size + i];
+      if (vi == 0) continue;
+      const float v = (float)vi * S_inv;
+      if (single) {
+        gt[2 * (long long)i] += v;  // sole writer of this (texture, level, feature) plane
+      } else {
+        atomicAdd(&gt[2 * (long long)i], v);
+      }
     }
-  }
+  });
 }
 
 }  // namespace
@@ -284,19 +328,16 @@ extern "C" int vsa_nt_encode_fwd(const vsa_nt_plan* plan, const void* tables_h,
   const half2_t* tab = reinterpret_cast<const half2_t*>(tables_h);
   const float2* xy = reinterpret_cast<const float2*>(slot_xy);
   half2_t* out = reinterpret_cast<half2_t*>(features);
-  const int models = plan->nr_shells * 2;
-  if (lh > 0) {
-    const EncLaunch L = enc_launch(plan, 0, ENC_SPAN_FWD);
-    hipLaunchKernelGGL(nt_encode_fwd_kernel<false>, dim3(L.per_model * models, lh), dim3(ENC_BLOCK),
-                       (size_t)max_level_size(plan, 0, lh) * 4, (hipStream_t)stream, *plan, L, tab,
-                       xy, seg_start, out);
-  }
-  if (lh < plan->n_levels) {
-    const EncLaunch L = enc_launch(plan, lh, ENC_SPAN_FWD);
-    hipLaunchKernelGGL(nt_encode_fwd_kernel<true>, dim3(L.per_model * models, plan->n_levels - lh),
-                       dim3(ENC_BLOCK), (size_t)max_level_size(plan, lh, plan->n_levels) * 4,
-                       (hipStream_t)stream, *plan, L, tab, xy, seg_start, out);
-  }
+  int nr_cus = 0;
+  if ((rc = vsa_cu_count(&nr_cus))) return rc;
+  if (lh > 0)
+    hipLaunchKernelGGL(nt_encode_fwd_kernel<false>, dim3(nr_cus), dim3(ENC_BLOCK),
+                       (size_t)LDS_ENTRIES * 4, (hipStream_t)stream, *plan, 0, lh, tab, xy,
+                       seg_start, out);
+  if (lh < plan->n_levels)
+    hipLaunchKernelGGL(nt_encode_fwd_kernel<true>, dim3(nr_cus), dim3(ENC_BLOCK),
+                       (size_t)LDS_ENTRIES * 4, (hipStream_t)stream, *plan, lh, plan->n_levels - lh,
+                       tab, xy, seg_start, out);
   VSA_RETURN_LAUNCH_STATUS();
 }
 
@@ -318,19 +359,15 @@ extern "C" int vsa_nt_encode_bwd(const vsa_nt_plan* plan, const void* dfeatures,
   const int lh = first_hashed_level(plan);
   const half2_t* dF = reinterpret_cast<const half2_t*>(dfeatures);
   const float2* xy = reinterpret_cast<const float2*>(slot_xy);
-  const int models = plan->nr_shells * 2;
-  if (lh > 0) {
-    const EncLaunch L = enc_launch(plan, 0, ENC_SPAN_BWD);
-    hipLaunchKernelGGL(nt_encode_bwd_kernel<false>, dim3(L.per_model * models, 2 * lh),
-                       dim3(ENC_BLOCK), (size_t)LDS_ENTRIES * 4, (hipStream_t)stream, *plan, L, dF,
-                       dfeat_abs_sum, 1.0f / grad_scale, xy, seg_start, grad_tables);
-  }
-  if (lh < plan->n_levels) {
-    const EncLaunch L = enc_launch(plan, lh, ENC_SPAN_BWD);
-    hipLaunchKernelGGL(nt_encode_bwd_kernel<true>, dim3(L.per_model * models, 2 * (plan->n_levels - lh)),
-                       dim3(ENC_BLOCK), (size_t)max_level_size(plan, lh, plan->n_levels) * 4,
-                       (hipStream_t)stream, *plan, L, dF, dfeat_abs_sum, 1.0f / grad_scale, xy,
-                       seg_start, grad_tables);
-  }
+  int nr_cus = 0;
+  if ((rc = vsa_cu_count(&nr_cus))) return rc;
+  if (lh > 0)
+    hipLaunchKernelGGL(nt_encode_bwd_kernel<false>, dim3(nr_cus), dim3(ENC_BLOCK),
+                       (size_t)LDS_ENTRIES * 4, (hipStream_t)stream, *plan, 0, lh, dF, dfeat_abs_sum,
+                       1.0f / grad_scale, xy, seg_start, grad_tables);
+  if (lh < plan->n_levels)
+    hipLaunchKernelGGL(nt_encode_bwd_kernel<true>, dim3(nr_cus), dim3(ENC_BLOCK),
+                       (size_t)LDS_ENTRIES * 4, (hipStream_t)stream, *plan, lh, plan->n_levels - lh,
+                       dF, dfeat_abs_sum, 1.0f / grad_scale, xy, seg_start, grad_tables);
   VSA_RETURN_LAUNCH_STATUS();
 }

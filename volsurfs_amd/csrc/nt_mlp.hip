@@ -1026,13 +1026,8 @@ extern "C" int vsa_nt_mlp_bwd(const vsa_nt_plan* plan, const void* weights_h, vo
                        dfeat_abs_sum);
   } else {
     const size_t lds = (size_t)PC_FRAGS * 64 * 16 + (size_t)PC_PAIRS * PAIR_HALFS * 2;   // >= frags + 32 KiB reduction buffer
-    static int nr_cus = 0;
-    if (!nr_cus) {
-      int dev = 0;
-      VSA_HIP_TRY(hipGetDevice(&dev));
-      VSA_HIP_TRY(hipDeviceGetAttribute(&nr_cus, hipDeviceAttributeMultiprocessorCount, dev));
-      if (nr_cus < 1) nr_cus = 256;
-    }
+    int nr_cus = 0;
+    { const int rc = vsa_cu_count(&nr_cus); if (rc) return rc; }
     hipLaunchKernelGGL(nt_mlp_bwd_pc_kernel, dim3(nr_cus), dim3(PC_BLOCK), lds, (hipStream_t)stream,
                        *plan, reinterpret_cast<const _Float16*>(weights_h),
                        reinterpret_cast<unsigned*>(features), seg_start, grad_rows, grad_weights,
