@@ -122,34 +122,61 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
     __syncthreads();
     const int type = (tex / VSA_NT_MAX_DEG) & 1;
     half2_t* out = features + nt_feat_plane_base(plan, type, level);
-    for (int base = first + threadIdx.x; base < last; base += ENC_BLOCK * ENC_UNROLL) {
-      float2 xy[ENC_UNROLL];
+    // A lane owns ENC_UNROLL = 8 consecutive slots (neighbouring texels of one texture
+    // row): 64 B of texel centres in, 32 B of features out per lane as dwordx4 accesses,
+    // and the 4 LDS gathers are skipped while consecutive slots stay in one grid cell.
+    const int a_first = first & ~(ENC_UNROLL - 1);
+    for (int s0 = a_first + threadIdx.x * ENC_UNROLL; s0 < last; s0 += ENC_BLOCK * ENC_UNROLL) {
+      float4 xyv[ENC_UNROLL / 2];
+      const float4* xp = reinterpret_cast<const float4*>(slot_xy + s0);
+#pragma unroll
+      for (int i = 0; i < ENC_UNROLL / 2; ++i) xyv[i] = xp[i];
+      CellRef cr[ENC_UNROLL];
+      bool fresh[ENC_UNROLL];
 #pragma unroll
       for (int u = 0; u < ENC_UNROLL; ++u) {
-        const int slot = base + u * ENC_BLOCK;
-        xy[u] = slot_xy[slot < last ? slot : last - 1];
+        const float x = (u & 1) ? xyv[u >> 1].z : xyv[u >> 1].x;
+        const float y = (u & 1) ? xyv[u >> 1].w : xyv[u >> 1].y;
+        cr[u] = cell_ref(g, x, y);
+        fresh[u] = u == 0 || cr[u].cx != cr[u - 1].cx || cr[u].cy != cr[u - 1].cy;
       }
-      CellCorners c[ENC_UNROLL];
-#pragma unroll
-      for (int u = 0; u < ENC_UNROLL; ++u) c[u] = cell_corners<HASHED>(g, xy[u].x, xy[u].y);
       half2_t v[ENC_UNROLL][4];
 #pragma unroll
-      for (int u = 0; u < ENC_UNROLL; ++u)
+      for (int u = 0; u < ENC_UNROLL; ++u) {
+        if (fresh[u]) {
+          unsigned idx[4];
+          cell_indices<HASHED>(g, cr[u].cx, cr[u].cy, idx);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[u][k] = s_tab[c[u].idx[k]];
+          for (int k = 0; k < 4; ++k) v[u][k] = s_tab[idx[k]];
+        }
+      }
+      unsigned outw[ENC_UNROLL];
 #pragma unroll
       for (int u = 0; u < ENC_UNROLL; ++u) {
-        const int slot = base + u * ENC_BLOCK;
+        if (u > 0 && !fresh[u]) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[u][k] = v[u - 1][k];
+        }
         float f0 = 0.f, f1 = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          f0 = f0 + c[u].w[k] * (float)v[u][k].x;
-          f1 = f1 + c[u].w[k] * (float)v[u][k].y;
+          f0 = f0 + cr[u].w[k] * (float)v[u][k].x;
+          f1 = f1 + cr[u].w[k] * (float)v[u][k].y;
         }
         half2_t r;
         r.x = (_Float16)f0;
         r.y = (_Float16)f1;
-        if (slot < last) out[nt_feat_in_plane(nl, slot)] = r;
+        outw[u] = __builtin_bit_cast(unsigned, r);
+      }
+      unsigned* op = reinterpret_cast<unsigned*>(out) + nt_feat_in_plane(nl, s0);
+      if (s0 >= first && s0 + ENC_UNROLL <= last) {
+        uint4* o4 = reinterpret_cast<uint4*>(op);
+        o4[0] = make_uint4(outw[0], outw[1], outw[2], outw[3]);
+        o4[1] = make_uint4(outw[4], outw[5], outw[6], outw[7]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < ENC_UNROLL; ++u)
+          if (s0 + u >= first && s0 + u < last) op[u] = outw[u];
       }
     }
   });

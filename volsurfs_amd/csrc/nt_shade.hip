@@ -308,9 +308,12 @@ __global__ __launch_bounds__(SH_BLOCK) void nt_shade_bwd_kernel(
   const int fidx = ch < 3 ? ch * nn + (m - d * d) : 4 * nt_alpha_quad(d) + (m - d * d);
   const bool active = ch < 3 ? d < plan.rgb_degrees : (has_alpha && d < plan.alpha_degrees);
   // Consecutive hits of a wave are neighbouring pixels: at the coarse degrees
-  // (256^2, 512^2 textures) they often fall on the SAME corner texels.  Each lane
-  // therefore keeps a running sum per corner and only issues the atomic when the
-  // corner's slot changes (lanes of one degree take the same decisions).
+  // (256^2, 512^2 textures) they fall on the SAME or on overlapping 2x2 footprints.
+  // Each lane keeps the previous hit's four corner rows open with a running sum; a
+  // corner of the new hit that matches any open row (its own position or, after a
+  // one-texel step, a neighbouring one) inherits that sum, and only the rows the new
+  // footprint no longer covers are flushed with an atomic (lanes of one degree take
+  // the same decisions).
   int cur[4] = {-1, -1, -1, -1};
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   unsigned long long rem = hits;
@@ -320,17 +323,28 @@ __global__ __launch_bounds__(SH_BLOCK) void nt_shade_bwd_kernel(
     const int ht = wbase + hl;
     if (active) {
       const float g = s_graw[ht][ch] * s_basis[ht][m];
+      int sl[4];
+      float v[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int sl = s_row[ht][d * 4 + k];
-        const float v = s_w[ht][d * 4 + k] * g;
-        if (sl == cur[k]) {
-          acc[k] += v;
-        } else {
-          if (cur[k] >= 0) atomicAdd(&grad_rows[(long long)cur[k] * 4 + fidx], acc[k]);
-          cur[k] = sl;
-          acc[k] = v;
+        sl[k] = s_row[ht][d * 4 + k];
+        v[k] = s_w[ht][d * 4 + k] * g;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bool kept = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const bool same = cur[j] == sl[k];
+          v[k] += same ? acc[j] : 0.f;
+          kept |= same;
         }
+        if (!kept && cur[j] >= 0) atomicAdd(&grad_rows[(long long)cur[j] * 4 + fidx], acc[j]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        cur[k] = sl[k];
+        acc[k] = v[k];
       }
     }
   }
