@@ -140,61 +140,77 @@ __device__ __forceinline__ float sigmoidf_(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 
-constexpr int MLP_FWD_SPAN = MLP_WAVES * 16 * 32;   // slots per workgroup: 16 tiles per wave
+// Persistent: gridDim.x workgroups split the frame's 32-slot tiles evenly
+// (nt_for_each_piece: cost axis with the weight staging of a run priced at 8 tiles).
+constexpr int MLP_FWD_DEPTH = 1;        // feature tiles in flight per wave (3 measured slower: PMC shows the
+                                        // SIMDs 39 % VALU + 28 % MFMA busy, not waiting on HBM)
+constexpr int MLP_FWD_WGS_PER_CU = 3;   // 148 VGPRs -> 3 waves per SIMD, one per workgroup
 
-__global__ __launch_bounds__(MLP_BLOCK) void nt_mlp_fwd_kernel(
-    vsa_nt_plan plan, EncLaunch L, const _Float16* __restrict__ weights,
+__global__ __launch_bounds__(MLP_BLOCK, MLP_FWD_WGS_PER_CU) void nt_mlp_fwd_kernel(
+    vsa_nt_plan plan, const _Float16* __restrict__ weights,
     const unsigned* __restrict__ features, const int* __restrict__ seg_start,
     unsigned* __restrict__ texels, _Float16* __restrict__ pre_out) {
   __shared__ half8_t s_frag[16 * 64];
-  Work wk;
-  if (!decode_work(plan, L, seg_start, blockIdx.x, wk)) return;
-  const int tex = wk.tex;
-  const TexInfo ti = tex_info(plan, seg_start, tex);
-  stage_weights_fwd(weights + (long long)tex * VSA_NT_WEIGHTS_PER_TEX, s_frag);
-  __syncthreads();
   const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
   const int wave = threadIdx.x >> 6;
-  half8_t wf[16];
+  nt_for_each_piece<32>(plan, seg_start, 1, 8,
+                        [&](int, int tex, int first, int last, int, int) {
+    const TexInfo ti = tex_info(plan, seg_start, tex);
+    __syncthreads();   // the previous run's fragments have been read
+    stage_weights_fwd(weights + (long long)tex * VSA_NT_WEIGHTS_PER_TEX, s_frag);
+    __syncthreads();
+    half8_t wf[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) wf[i] = s_frag[i * 64 + lane];
-  const int pre_base = ti.type == 0 ? 0 : 24;    // pre_out keeps the fixed 32-wide test layout
-  const int ntiles = (wk.last - wk.first + 31) >> 5;
-  half8_t bx[2], bx_next[2];
-  if (wave < ntiles) {
-    const int s0 = wk.first + wave * 32 + p;
-    load_features(features, plan, ti.type, s0 < wk.last ? s0 : wk.last - 1, h, bx_next);
-  }
-  for (int tile = wave; tile < ntiles; tile += MLP_WAVES) {
-    const int slot = wk.first + tile * 32 + p;
-    const bool valid = slot < wk.last;
-    bx[0] = bx_next[0];
-    bx[1] = bx_next[1];
-    if (tile + MLP_WAVES < ntiles) {   // prefetch the next tile's features
-      const int sn = slot + MLP_WAVES * 32;
-      load_features(features, plan, ti.type, sn < wk.last ? sn : wk.last - 1, h, bx_next);
-    }
-    half8_t b2[4], b3[4];
-    float16_t acc3;
-    mlp_tile_fwd(wf, bx, b2, b3, acc3);
-    if (!valid) continue;
+    for (int i = 0; i < 16; ++i) wf[i] = s_frag[i * 64 + lane];
+    const int pre_base = ti.type == 0 ? 0 : 24;    // pre_out keeps the fixed 32-wide test layout
+    const int ntiles = (last - first + 31) >> 5;
+    // MLP_FWD_DEPTH tiles of features are in flight per wave (a static ring)
+    half8_t q[MLP_FWD_DEPTH][2];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int row0 = 8 * g + 4 * h;
-      if (row0 >= ti.channels) continue;
-      unsigned packed = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const _Float16 o_h = (_Float16)acc3[4 * g + i];
-        if (pre_out && row0 + i < ti.channels)
-          pre_out[(long long)slot * 32 + pre_base + row0 + i] = o_h;
-        float q = rintf(sigmoidf_((float)o_h) * 255.0f);
-        unsigned qb = row0 + i < ti.channels ? (unsigned)q : 0u;
-        packed |= qb << (8 * i);
+    for (int j = 0; j < MLP_FWD_DEPTH; ++j) {
+      const int t = wave + j * MLP_WAVES;
+      if (t < ntiles) {
+        const int s0 = first + t * 32 + p;
+        load_features(features, plan, ti.type, s0 < last ? s0 : last - 1, h, q[j]);
       }
-      texels[ti.row_first + (long long)(slot - ti.begin) * ti.row_quads + (row0 >> 2)] = packed;
     }
-  }
+    for (int tile0 = wave; tile0 < ntiles; tile0 += MLP_WAVES * MLP_FWD_DEPTH) {
+#pragma unroll
+    for (int j = 0; j < MLP_FWD_DEPTH; ++j) {
+      const int tile = tile0 + j * MLP_WAVES;
+      if (tile >= ntiles) break;
+      const int slot = first + tile * 32 + p;
+      const bool valid = slot < last;
+      half8_t bx[2];
+      bx[0] = q[j][0];
+      bx[1] = q[j][1];
+      if (tile + MLP_WAVES * MLP_FWD_DEPTH < ntiles) {   // refill this stage
+        const int sn = slot + MLP_WAVES * MLP_FWD_DEPTH * 32;
+        load_features(features, plan, ti.type, sn < last ? sn : last - 1, h, q[j]);
+      }
+      half8_t b2[4], b3[4];
+      float16_t acc3;
+      mlp_tile_fwd(wf, bx, b2, b3, acc3);
+      if (!valid) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row0 = 8 * g + 4 * h;
+        if (row0 >= ti.channels) continue;
+        unsigned packed = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const _Float16 o_h = (_Float16)acc3[4 * g + i];
+          if (pre_out && row0 + i < ti.channels)
+            pre_out[(long long)slot * 32 + pre_base + row0 + i] = o_h;
+          float q = rintf(sigmoidf_((float)o_h) * 255.0f);
+          unsigned qb = row0 + i < ti.channels ? (unsigned)q : 0u;
+          packed |= qb << (8 * i);
+        }
+        texels[ti.row_first + (long long)(slot - ti.begin) * ti.row_quads + (row0 >> 2)] = packed;
+      }
+    }
+    }
+  });
 }
 
 // ------------------------------------------------------------------ backward
@@ -988,10 +1004,10 @@ extern "C" int vsa_nt_mlp_fwd(const vsa_nt_plan* plan, const void* weights_h, co
                               const int32_t* seg_start, uint8_t* texels, void* pre_out,
                               void* stream) {
   if (!plan || !weights_h || !features || !seg_start || !texels) return VSA_ERR_ARG;
-  const EncLaunch L = enc_launch(plan, 0, MLP_FWD_SPAN);
-  dim3 grid(L.per_model * plan->nr_shells * 2);
-  hipLaunchKernelGGL(nt_mlp_fwd_kernel, grid, dim3(MLP_BLOCK), 0, (hipStream_t)stream, *plan, L,
-                     reinterpret_cast<const _Float16*>(weights_h),
+  int nr_cus = 0;
+  { const int rc = vsa_cu_count(&nr_cus); if (rc) return rc; }
+  hipLaunchKernelGGL(nt_mlp_fwd_kernel, dim3(nr_cus * MLP_FWD_WGS_PER_CU), dim3(MLP_BLOCK), 0,
+                     (hipStream_t)stream, *plan, reinterpret_cast<const _Float16*>(weights_h),
                      reinterpret_cast<const unsigned*>(features), seg_start,
                      reinterpret_cast<unsigned*>(texels), reinterpret_cast<_Float16*>(pre_out));
   VSA_RETURN_LAUNCH_STATUS();
