@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--subdiv", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time the eager path instead of the HIP-graph replay")
+    ap.add_argument("--by-shell", action="store_true",
+                    help="1 GPU: run the multi-GPU schedule (shell-by-shell hash-grid backward, eager) "
+                         "without the collectives, to price it")
     ap.add_argument("--cpu-sample-rays", type=int, default=4096)
     return ap.parse_args()
 
@@ -95,16 +98,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    from volsurfs_amd.parallel import allreduce_gradients
+    from volsurfs_amd.parallel import GradientOverlap
     params = [pipe.bank.tables, pipe.bank.weights]
+    overlap = GradientOverlap(world)
 
     def step(record=False):
-        pipe.step(record=record)
-        if world > 1:
-            # data-parallel training step: one all-reduce(sum) of the parameter
-            # gradients per step over RCCL / xGMI
-            pipe.timer.run("grad_allreduce", lambda: allreduce_gradients(params, world), record,
-                           bytes=sum(p.numel() for p in params) * 4)
+        if world == 1:
+            pipe.step(record=record, grad_ready=(lambda t: None) if args.by_shell else None)
+            return
+        # data-parallel training step: the parameter gradients are all-reduced (sum) over
+        # RCCL / xGMI shell by shell while the rest of backward still runs;
+        # what is left exposed after the last kernel is the "grad_allreduce" stage
+        pipe.step(record=record, grad_ready=overlap.reduce_async)
+        pipe.timer.run("grad_allreduce", overlap.wait, record,
+                       bytes=sum(p.numel() for p in params) * 4)
 
     for _ in range(max(1, args.warmup)):
         step()
@@ -114,7 +121,7 @@ def main():
     for _ in range(3):
         step(record=True)
     stages = pipe.stage_report()
-    use_graph = not args.no_graph
+    use_graph = not args.no_graph and world == 1 and not args.by_shell   # collectives interleave with the backward kernels
     if use_graph:
         try:
             pipe.capture_graph()       # the step is ~25 launches on one stream with no host sync
@@ -127,8 +134,6 @@ def main():
     def timed_step():
         if use_graph:
             pipe.replay()
-            if world > 1:
-                allreduce_gradients(params, world)
         else:
             step()
     barrier()

@@ -248,6 +248,14 @@ int vsa_nt_encode_bwd(const vsa_nt_plan* plan, const void* dfeatures, const floa
                       float grad_scale, const float* slot_xy, const int32_t* seg_start,
                       float* grad_tables, void* stream);
 
+/* The same, restricted to the textures of shells [shell_begin, shell_end): lets a
+ * data-parallel caller start the all-reduce of one shell's table gradients (a contiguous
+ * slice of grad_tables) while the next shell's are still being accumulated. */
+int vsa_nt_encode_bwd_range(const vsa_nt_plan* plan, const void* dfeatures,
+                            const float* dfeat_abs_sum, float grad_scale, const float* slot_xy,
+                            const int32_t* seg_start, float* grad_tables, int shell_begin,
+                            int shell_end, void* stream);
+
 /* ------------------------------------------------------------------------
  * A8 / A9 / A11  Packed (ragged) per-ray sample ops of the background path:
  * what render_contracted_bg (volsurfs_py/utils/background.py:31-141) calls in the

@@ -95,3 +95,38 @@ def test_backward_accumulates_and_is_linear():
                                rtol=2e-2, atol=2e-3 * g1w.abs().max().item())
     np.testing.assert_allclose(bank.tables.grad.cpu().numpy(), 3 * g1t.cpu().numpy(),
                                rtol=2e-2, atol=2e-3 * g1t.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_encode_backward_by_shell_equals_one_launch():
+    """vsa_nt_encode_bwd_range over each shell in turn (the multi-GPU overlap path)
+    accumulates the same table gradients as the single launch; shells outside the
+    range are untouched."""
+    K, N = 3, 2500
+    bank, face_uvs, hit_slot, hit_uv, tris, rays_d = _scene(K, N, 7, res=(256, 128, 64, 32))
+    tex_uv = bank.mark_and_compact(hit_slot, hit_uv, face_uvs)
+    g = torch.Generator().manual_seed(3)
+    g_rgb = (torch.randn(N, K, 3, generator=g) / N).cuda()
+    g_alpha = (torch.randn(N, K, generator=g) / N).cuda()
+
+    def upto_mlp():
+        bank.encode(); bank.mlp()
+        bank.tables.grad = None
+        bank.weights.grad = None
+        bank.backward_shade(hit_slot, tex_uv, rays_d, tris, g_rgb, g_alpha, float(N))
+        bank.backward_mlp(float(N))
+    upto_mlp()
+    # the hash-grid backward only READS dF, so both schedules can run on the same dF
+    # (re-running shade_bwd would differ in the last bits: its float atomics are unordered)
+    bank.backward_encode(float(N))
+    ref = bank.tables.grad.clone()
+    bank.tables.grad.zero_()
+    bank.backward_encode(float(N), shells=(1, 2))
+    part = bank.tables.grad.clone()
+    assert torch.equal(part[:8], torch.zeros_like(part[:8])) and torch.equal(part[16:], torch.zeros_like(part[16:]))
+    bank.backward_encode(float(N), shells=(0, 1))
+    bank.backward_encode(float(N), shells=(2, 3))
+    torch.cuda.synchronize()
+    assert ref.abs().max() > 0
+    np.testing.assert_allclose(bank.tables.grad.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5,
+                               atol=1e-6 * ref.abs().max().item())

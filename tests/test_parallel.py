@@ -7,7 +7,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from volsurfs_amd.parallel import allreduce_gradients, gather_frame, shard_chunks, shard_indices
+from volsurfs_amd.parallel import (GradientOverlap, allreduce_gradients, gather_frame, shard_chunks,
+                                   shard_indices)
 
 
 def test_shards_partition_the_frame():
@@ -74,3 +75,37 @@ def test_two_ranks_equal_one_rank():
     ((gt - pred).abs().mean()).backward()
     torch.testing.assert_close(grad, w.grad, rtol=1e-5, atol=1e-7)
     torch.testing.assert_close(frame, pred.detach())
+
+
+def _overlap_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # the bench's pattern: slices of one gradient tensor are reduced as they become final
+    g = torch.arange(40 * 6, dtype=torch.float32).view(40, 6) * (rank + 1)
+    w = torch.full((5,), float(rank + 1))
+    ov = GradientOverlap(world)
+    ov.reduce_async(w)
+    for s in range(5):
+        ov.reduce_async(g[s * 8:(s + 1) * 8])      # contiguous slice, reduced in place
+    ov.wait()
+    assert ov.works == []
+    if rank == 0:
+        q.put((g.clone(), w.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_overlap_slices_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    g, w = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    torch.testing.assert_close(g, torch.arange(40 * 6, dtype=torch.float32).view(40, 6) * 3)
+    torch.testing.assert_close(w, torch.full((5,), 3.0))

@@ -136,10 +136,12 @@ __device__ __forceinline__ bool decode_work(const vsa_nt_plan& p, const EncLaunc
 template <int UNIT, typename Body>
 __device__ __forceinline__ void nt_for_each_piece(const vsa_nt_plan& plan,
                                                   const int* __restrict__ seg_start, int n_planes,
-                                                  int ovh, Body&& body) {
-  const int n_tex = plan.nr_shells * 2 * VSA_NT_MAX_DEG;
+                                                  int ovh, Body&& body, int tex_begin = 0,
+                                                  int tex_end = 1 << 30) {
+  const int n_all = plan.nr_shells * 2 * VSA_NT_MAX_DEG;
+  const int n_tex = tex_end < n_all ? tex_end : n_all;   // textures [tex_begin, n_tex) only
   long long T = 0;
-  for (int tex = 0; tex < n_tex; ++tex) {
+  for (int tex = tex_begin; tex < n_tex; ++tex) {
     if (!tex_active(plan, tex)) continue;
     const int sd = (tex / (2 * VSA_NT_MAX_DEG)) * VSA_NT_MAX_DEG + tex % VSA_NT_MAX_DEG;
     const int len = seg_start[sd + 1] - seg_start[sd];
@@ -152,7 +154,7 @@ __device__ __forceinline__ void nt_for_each_piece(const vsa_nt_plan& plan,
   const int pl0 = (int)(lo / T), pl1 = (int)((hi - 1) / T);
   for (int pl = pl0; pl <= pl1; ++pl) {
     long long c0 = (long long)pl * T;
-    for (int tex = 0; tex < n_tex; ++tex) {
+    for (int tex = tex_begin; tex < n_tex; ++tex) {
       if (!tex_active(plan, tex)) continue;
       const int sd = (tex / (2 * VSA_NT_MAX_DEG)) * VSA_NT_MAX_DEG + tex % VSA_NT_MAX_DEG;
       const int begin = seg_start[sd], end = seg_start[sd + 1];

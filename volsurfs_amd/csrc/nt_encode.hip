@@ -201,7 +201,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
     vsa_nt_plan plan, int level0, int n_levels, const half2_t* __restrict__ dfeatures,
     const float* __restrict__ dfeat_abs_sum, float dscale_inv,
     const float2* __restrict__ slot_xy, const int* __restrict__ seg_start,
-    float* __restrict__ grad_tables) {
+    float* __restrict__ grad_tables, int tex_begin, int tex_end) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   int* s_g = reinterpret_cast<int*>(s_raw);
   const int nl = plan.n_levels;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
         atomicAdd(&gt[2 * (long long)i], v);
       }
     }
-  });
+  }, tex_begin, tex_end);
 }
 
 }  // namespace
@@ -372,8 +372,21 @@ extern "C" int vsa_nt_encode_bwd(const vsa_nt_plan* plan, const void* dfeatures,
                                  const float* dfeat_abs_sum, float grad_scale,
                                  const float* slot_xy, const int32_t* seg_start,
                                  float* grad_tables, void* stream) {
+  if (!plan) return VSA_ERR_ARG;
+  return vsa_nt_encode_bwd_range(plan, dfeatures, dfeat_abs_sum, grad_scale, slot_xy, seg_start,
+                                 grad_tables, 0, plan->nr_shells, stream);
+}
+
+extern "C" int vsa_nt_encode_bwd_range(const vsa_nt_plan* plan, const void* dfeatures,
+                                       const float* dfeat_abs_sum, float grad_scale,
+                                       const float* slot_xy, const int32_t* seg_start,
+                                       float* grad_tables, int shell_begin, int shell_end,
+                                       void* stream) {
   if (!plan || !dfeatures || !dfeat_abs_sum || !slot_xy || !seg_start || !grad_tables)
     return VSA_ERR_ARG;
+  if (shell_begin < 0 || shell_end > plan->nr_shells || shell_begin > shell_end) return VSA_ERR_ARG;
+  if (shell_begin == shell_end) return VSA_OK;
+  const int tex_begin = shell_begin * 2 * VSA_NT_MAX_DEG, tex_end = shell_end * 2 * VSA_NT_MAX_DEG;
   if (!(grad_scale > 0.f)) return VSA_ERR_ARG;
   int rc = check_levels(plan);
   if (rc) return rc;
@@ -391,10 +404,11 @@ extern "C" int vsa_nt_encode_bwd(const vsa_nt_plan* plan, const void* dfeatures,
   if (lh > 0)
     hipLaunchKernelGGL(nt_encode_bwd_kernel<false>, dim3(nr_cus), dim3(ENC_BLOCK),
                        (size_t)LDS_ENTRIES * 4, (hipStream_t)stream, *plan, 0, lh, dF, dfeat_abs_sum,
-                       1.0f / grad_scale, xy, seg_start, grad_tables);
+                       1.0f / grad_scale, xy, seg_start, grad_tables, tex_begin, tex_end);
   if (lh < plan->n_levels)
     hipLaunchKernelGGL(nt_encode_bwd_kernel<true>, dim3(nr_cus), dim3(ENC_BLOCK),
                        (size_t)LDS_ENTRIES * 4, (hipStream_t)stream, *plan, lh, plan->n_levels - lh,
-                       dF, dfeat_abs_sum, 1.0f / grad_scale, xy, seg_start, grad_tables);
+                       dF, dfeat_abs_sum, 1.0f / grad_scale, xy, seg_start, grad_tables, tex_begin,
+                       tex_end);
   VSA_RETURN_LAUNCH_STATUS();
 }

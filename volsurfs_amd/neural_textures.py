@@ -257,7 +257,14 @@ class NeuralTextureBank(torch.nn.Module):
                   self.seg_start, self.grad_rows, self._gw_scaled, self._dfsum, _lib.stream_ptr())
         self.weights.grad.add_(self._gw_scaled, alpha=1.0 / float(grad_scale))
 
-    def backward_encode(self, grad_scale):
-        _lib.call("vsa_nt_encode_bwd", ctypes.byref(self.plan), self.features, self._dfsum,
-                  float(grad_scale), self.slot_xy, self.seg_start, self.tables.grad,
-                  _lib.stream_ptr())
+    def backward_encode(self, grad_scale, shells=None):
+        """shells=(begin, end) restricts the launch to those shells' textures (their table
+        gradients are the contiguous slice tables.grad[begin*8:end*8])."""
+        if shells is None:
+            _lib.call("vsa_nt_encode_bwd", ctypes.byref(self.plan), self.features, self._dfsum,
+                      float(grad_scale), self.slot_xy, self.seg_start, self.tables.grad,
+                      _lib.stream_ptr())
+        else:
+            _lib.call("vsa_nt_encode_bwd_range", ctypes.byref(self.plan), self.features,
+                      self._dfsum, float(grad_scale), self.slot_xy, self.seg_start,
+                      self.tables.grad, int(shells[0]), int(shells[1]), _lib.stream_ptr())

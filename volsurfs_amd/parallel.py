@@ -39,6 +39,27 @@ def allreduce_gradients(params, world, group=None):
         w.wait()
 
 
+class GradientOverlap:
+    """All-reduce gradient tensors as they become final, overlapped with the rest of
+    backward: `reduce_async(t)` enqueues an asynchronous all-reduce(sum) of `t` (ordered
+    after the work already queued on the current stream), `wait()` makes the current
+    stream wait for all of them.  One instance per training loop."""
+
+    def __init__(self, world, group=None):
+        self.world, self.group, self.works = world, group, []
+
+    def reduce_async(self, t):
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        self.works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
 def gather_frame(local_rgb, nr_rays, rank, world, chunk=16384, group=None):
     """Rank 0 receives the full [nr_rays,3] frame (rendering needs no other
     collective: every rank writes its own tiles)."""

@@ -150,9 +150,14 @@ class KShellPipeline:
         self._graph.replay()
         return self._static_rgb
 
-    def step(self, record=False):
+    def step(self, record=False, grad_ready=None):
         """zero_grad -> forward -> L1 loss -> backward (trainer.py:118-264 without
-        the optimiser step).  Returns the predicted rgb [N,3]."""
+        the optimiser step).  Returns the predicted rgb [N,3].
+
+        grad_ready(tensor), if given, is called as soon as a gradient tensor is final on
+        the current stream: once with weights.grad, then once per shell with that shell's
+        contiguous slice of tables.grad (the hash-grid backward then runs shell by shell),
+        so a data-parallel caller can overlap its all-reduce with the rest of backward."""
         from .composite import composite_fwd_raw, composite_bwd_raw
         N, K = self.nr_rays, self.K
         T, bank = self.timer, self.bank
@@ -198,6 +203,16 @@ class KShellPipeline:
               bytes=M * (16 * 36 + 8 + 12 + 16 + 256 * 4), bound="atomic")
         T.run("nt_mlp_bwd", lambda: bank.backward_mlp(self.grad_scale), record,
               bytes=2 * P * (64 + 64) + P * 128 * 2, flops=2 * mlp_flops, bound="mfma")
-        T.run("nt_encode_bwd", lambda: bank.backward_encode(self.grad_scale), record,
-              bytes=2 * 16 * P * 4 * 2 + 2 * 16 * P * 8 + ntex * bank.n_entries * 8)
+        enc_bytes = 2 * 16 * P * 4 * 2 + 2 * 16 * P * 8 + ntex * bank.n_entries * 8
+        if grad_ready is None:
+            T.run("nt_encode_bwd", lambda: bank.backward_encode(self.grad_scale), record,
+                  bytes=enc_bytes)
+        else:
+            grad_ready(bank.weights.grad)
+
+            def by_shell():
+                for s in range(K):
+                    bank.backward_encode(self.grad_scale, shells=(s, s + 1))
+                    grad_ready(bank.tables.grad[s * 8:(s + 1) * 8])
+            T.run("nt_encode_bwd", by_shell, record, bytes=enc_bytes)
         return rgb
