@@ -115,19 +115,40 @@ class KShellPipeline:
         }
 
     def stats(self):
-        """Host-side read-back of frame statistics (outside the timed region)."""
-        self.last_slots = int(self.bank.seg_start[self.K * 4].item())
-        self.last_hits = int((self._hit_slot >= 0).sum().item())
-        seg = self.bank.seg_start.cpu().tolist()
-        fl = 0
-        for s_ in range(self.K):
+        """Host-side read-back of frame statistics (outside the timed region) and the
+        ALGORITHMIC bytes / FLOPs of every stage for this frame: each
+        operand counted once per stage at its stored width, gathers per hit."""
+        from .neural_textures import ROW_QUADS
+        bank, N, K = self.bank, self.nr_rays, self.K
+        self.last_slots = P = int(bank.seg_start[K * 4].item())
+        self.last_hits = M = int((self._hit_slot >= 0).sum().item())
+        seg = bank.seg_start.cpu().tolist()
+        fl, row_quads, slot_models = 0, 0, 0
+        for s_ in range(K):
             for d in range(4):
                 P_sd = seg[s_ * 4 + d + 1] - seg[s_ * 4 + d]
+                row_quads += P_sd * ROW_QUADS[d]
                 for typ in range(2):
-                    C = self.bank.tex_channels(self.bank.tex_index(s_, typ, d))
+                    C = bank.tex_channels(bank.tex_index(s_, typ, d))
                     if C:
                         fl += P_sd * 2 * (32 * 64 + 64 * 64 + 64 * C)
+                        slot_models += P_sd
         self.mlp_flops_fwd = fl          # unpadded FLOPs of one forward over the unique texels
+        ntex = sum(1 for x in range(bank.n_tex) if bank.tex_channels(x))
+        rows_u8, rows_f32 = row_quads * 4, row_quads * 16
+        feats = slot_models * 64                      # 16 levels x f16x2 per (slot, model)
+        gathers = M * (16 * 4 + 4 * sum(ROW_QUADS) * 4 + 8) + N * 12   # slot ids + 16 texel rows + uv, dirs
+        nodes_b = self.tracer.nodes.numel() * 4 + self.tracer.tris.numel() * 4
+        self.acct = {
+            "trace": N * (24 + 16 * K) + nodes_b,
+            "nt_mark_compact": N * K * 20 + bank.dom_total * (1 + 1 + 1 + 4) + P * 12,
+            "nt_encode_fwd": P * 8 + feats + ntex * bank.n_entries * 4,
+            "nt_mlp_fwd": feats + rows_u8 + ntex * 8192 * 2,
+            "nt_shade_fwd": gathers + N * K * 16,
+            "nt_shade_bwd": gathers + N * K * 16 + rows_f32,
+            "nt_mlp_bwd": 2 * feats + 2 * rows_f32 + ntex * 8192 * (2 + 4),
+            "nt_encode_bwd": feats + P * 8 + ntex * bank.n_entries * 8,
+        }
         return self.last_hits, self.last_slots
 
     def capture_graph(self):
@@ -161,10 +182,7 @@ class KShellPipeline:
         from .composite import composite_fwd_raw, composite_bwd_raw
         N, K = self.nr_rays, self.K
         T, bank = self.timer, self.bank
-        M = getattr(self, "last_hits", None) or N * K          # hits (for byte/flop accounting)
-        P = getattr(self, "last_slots", None) or bank.slot_capacity
-        ntex = sum(1 for x in range(bank.n_tex) if bank.tex_channels(x))
-        nodes_b = self.tracer.nodes.numel() * 4 + self.tracer.tris.numel() * 4
+        acct = getattr(self, "acct", None) or {}     # algorithmic bytes per stage (stats())
 
         def zero_grad():
             if bank.tables.grad is not None:
@@ -173,19 +191,18 @@ class KShellPipeline:
         T.run("zero_grad", zero_grad, record, bytes=(bank.tables.numel() + bank.weights.numel()) * 4)
         hit_t, hit_slot, hit_uv = T.run(
             "trace", lambda: self.tracer.trace_all(self.rays_o, self.rays_d), record,
-            bytes=N * (24 + 16 * K) + nodes_b)
+            bytes=acct.get("trace", 0))
         self._hit_slot = hit_slot
         tex_uv = T.run("nt_mark_compact",
                        lambda: bank.mark_and_compact(hit_slot, hit_uv, self.face_uvs), record,
-                       bytes=N * K * 20 + bank.dom_total * (1 + 1 + 1 + 4) + P * 4)
-        T.run("nt_encode_fwd", bank.encode, record,
-              bytes=2 * 16 * P * 4 + 16 * P * 8 + ntex * bank.n_entries * 4)
+                       bytes=acct.get("nt_mark_compact", 0))
+        T.run("nt_encode_fwd", bank.encode, record, bytes=acct.get("nt_encode_fwd", 0))
         mlp_flops = getattr(self, "mlp_flops_fwd", 0)
-        T.run("nt_mlp_fwd", bank.mlp, record, bytes=2 * P * (16 * 4) + P * (32 + 128),
-              flops=mlp_flops, bound="mfma")
+        T.run("nt_mlp_fwd", bank.mlp, record, bytes=acct.get("nt_mlp_fwd", 0), flops=mlp_flops,
+              bound="mfma")
         rgb_k, alpha_k, _, _ = T.run(
             "nt_shade_fwd", lambda: bank.shade(hit_slot, tex_uv, self.rays_d, self.tracer.tris),
-            record, bytes=M * (16 * 4 + 16 * 32 + 8 + 12 + 16) + N * K * 16)
+            record, bytes=acct.get("nt_shade_fwd", 0))
         self.surfs_rgb, self.surfs_alpha = rgb_k, alpha_k
         rgb = T.run("composite_fwd", lambda: composite_fwd_raw(rgb_k, alpha_k, self.bg), record,
                     bytes=N * (16 * K + 12))
@@ -200,10 +217,10 @@ class KShellPipeline:
         tris = self.tracer.tris
         T.run("nt_shade_bwd", lambda: bank.backward_shade(hit_slot, tex_uv, self.rays_d, tris, g_c, g_a,
                                                            self.grad_scale), record,
-              bytes=M * (16 * 36 + 8 + 12 + 16 + 256 * 4), bound="atomic")
+              bytes=acct.get("nt_shade_bwd", 0), bound="atomic")
         T.run("nt_mlp_bwd", lambda: bank.backward_mlp(self.grad_scale), record,
-              bytes=2 * P * (64 + 64) + P * 128 * 2, flops=2 * mlp_flops, bound="mfma")
-        enc_bytes = 2 * 16 * P * 4 * 2 + 2 * 16 * P * 8 + ntex * bank.n_entries * 8
+              bytes=acct.get("nt_mlp_bwd", 0), flops=2 * mlp_flops, bound="mfma")
+        enc_bytes = acct.get("nt_encode_bwd", 0)
         if grad_ready is None:
             T.run("nt_encode_bwd", lambda: bank.backward_encode(self.grad_scale), record,
                   bytes=enc_bytes)
