@@ -222,105 +222,170 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
 // coarse dense levels neighbouring texels share their cell; those small planes
 // are therefore replicated `copies` times in LDS (lane & (copies-1) picks one)
 // and summed at the flush.
+// One piece of the backward: slots [first, last) of `tex` scattered into the LDS plane(s)
+// of `level`.  NF = 1: feature `feat` only (the plane fills the LDS); NF = 2: both
+// features in one pass over the slots (two planes; levels of <= 16384 entries), which
+// shares the loads, the cell arithmetic and the indices between the features.
+template <bool HASHED, int NF>
+__device__ __forceinline__ void enc_bwd_piece(
+    const vsa_nt_plan& plan, int* s_g, int level, int feat, int tex, int first, int last,
+    bool single, const half2_t* __restrict__ dfeatures, const float* __restrict__ dfeat_abs_sum,
+    float dscale_inv, const float2* __restrict__ slot_xy, float* __restrict__ grad_tables) {
+  const int nl = plan.n_levels;
+  const long long n_entries = plan.level_offset[plan.n_levels];
+  const LevelGeom g = level_geom(plan, level);
+  // fixed-point scale from sum |dF| over the WHOLE (texture, level, feature) plane,
+  // accumulated by the MLP backward kernel while it wrote dF (an upper bound for
+  // this piece's share; saves a second pass over dF)
+  float S[NF], S_inv[NF];
+  bool any = false;
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    const float total = dfeat_abs_sum[tex * 32 + 2 * level + feat + f] * 1.001f;
+    S[f] = 0.f, S_inv[f] = 0.f;
+    if (total > 0.f) {
+      int e;
+      frexpf(total, &e);                    // total = m * 2^e, m in [0.5, 1)
+      S[f] = ldexpf(1.0f, 30 - e);          // power of two: exact scaling and un-scaling
+      S_inv[f] = ldexpf(1.0f, e - 30) * dscale_inv;
+      any = true;
+    }
+  }
+  if (!any) return;   // nothing to add (uniform across the workgroup)
+  int copies = 1;
+  if (!HASHED) {
+    while (copies < 32 && (long long)g.size * copies * 2 * NF <= LDS_ENTRIES) copies *= 2;
+  }
+  const int plane = (int)g.size * copies;   // LDS entries per feature
+  __syncthreads();   // the previous piece's flush has read the planes
+  for (int i = threadIdx.x; i < plane * NF; i += ENC_BLOCK) s_g[i] = 0;
+  int* my_g = s_g + (threadIdx.x & (copies - 1)) * g.size;   // consecutive lanes -> different copies
+  const int type = (tex / VSA_NT_MAX_DEG) & 1;
+  const unsigned* dFw = reinterpret_cast<const unsigned*>(dfeatures + nt_feat_plane_base(plan, type, level));
+  __syncthreads();
+  // scatter.  A lane owns ENC_UNROLL = 8 CONSECUTIVE slots (= neighbouring texels of one
+  // texture row): 64 B of texel centres and 32 B of dF per lane come in as dwordx4
+  // loads; the 64 lanes of a wave are 8 texels apart, so they share a grid cell only at
+  // the coarsest levels (same-address LDS atomics serialise; those small planes are
+  // replicated, see `copies`); and while consecutive slots of a lane stay in one cell
+  // their four corner contributions are summed in registers and added once.  The sums
+  // are integers, so the result is independent of this grouping.
+  const int a_first = first & ~(ENC_UNROLL - 1);
+  for (int s0 = a_first + threadIdx.x * ENC_UNROLL; s0 < last; s0 += ENC_BLOCK * ENC_UNROLL) {
+    float4 xyv[ENC_UNROLL / 2];
+    uint4 dv[ENC_UNROLL / 4];
+    const float4* xp = reinterpret_cast<const float4*>(slot_xy + s0);
+    const uint4* dp = reinterpret_cast<const uint4*>(dFw + nt_feat_in_plane(nl, s0));
+#pragma unroll
+    for (int i = 0; i < ENC_UNROLL / 2; ++i) xyv[i] = xp[i];
+#pragma unroll
+    for (int i = 0; i < ENC_UNROLL / 4; ++i) dv[i] = dp[i];
+    const unsigned dws[ENC_UNROLL] = {dv[0].x, dv[0].y, dv[0].z, dv[0].w,
+                                      dv[1].x, dv[1].y, dv[1].z, dv[1].w};
+    unsigned cur_idx[4] = {0, 0, 0, 0};
+    int acc[NF][4];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) acc[f][0] = acc[f][1] = acc[f][2] = acc[f][3] = 0;
+    unsigned cur_cx = 0xffffffffu, cur_cy = 0xffffffffu;
+#pragma unroll
+    for (int u = 0; u < ENC_UNROLL; ++u) {
+      const int slot = s0 + u;
+      const float x = (u & 1) ? xyv[u >> 1].z : xyv[u >> 1].x;
+      const float y = (u & 1) ? xyv[u >> 1].w : xyv[u >> 1].y;
+      float gv[NF];
+      bool nz = false;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const unsigned short hb = (unsigned short)(dws[u] >> (16 * (feat + f)));
+        gv[f] = (float)__builtin_bit_cast(_Float16, hb) * S[f];
+        nz |= gv[f] != 0.f;
+      }
+      if (slot >= first && slot < last && nz) {
+        const CellRef cr = cell_ref(g, x, y);
+        int v[NF][4];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const f32x2 p01 = cr.w01 * gv[f], p23 = cr.w23 * gv[f];
+          v[f][0] = __float2int_rn(p01.x), v[f][1] = __float2int_rn(p01.y);
+          v[f][2] = __float2int_rn(p23.x), v[f][3] = __float2int_rn(p23.y);
+        }
+        if (cr.cx == cur_cx && cr.cy == cur_cy) {
+#pragma unroll
+          for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[f][k] += v[f][k];
+        } else {
+          if (cur_cx != 0xffffffffu) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+              for (int k = 0; k < 4; ++k) atomicAdd(&my_g[f * plane + cur_idx[k]], acc[f][k]);
+          }
+          cur_cx = cr.cx, cur_cy = cr.cy;
+          cell_indices<HASHED>(g, cr.cx, cr.cy, cur_idx);
+#pragma unroll
+          for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[f][k] = v[f][k];
+        }
+      }
+    }
+    if (cur_cx != 0xffffffffu) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(&my_g[f * plane + cur_idx[k]], acc[f][k]);
+    }
+  }
+  __syncthreads();
+  float* gt = grad_tables + ((long long)tex * n_entries + plan.level_offset[level]) * 2 + feat;
+  for (int i = threadIdx.x; i < (int)g.size; i += ENC_BLOCK) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      int vi = 0;
+      for (int cpy = 0; cpy < copies; ++cpy) vi += s_g[f * plane + cpy * g.size + i];
+      if (vi == 0) continue;
+      const float v = (float)vi * S_inv[f];
+      if (single) {
+        gt[2 * (long long)i + f] += v;  // sole writer of this (texture, level, feature) plane
+      } else {
+        atomicAdd(&gt[2 * (long long)i + f], v);
+      }
+    }
+  }
+}
+
+// Planes of a launch over levels [level0, level0 + n_levels): a dense level whose two
+// feature planes fit the LDS together is ONE plane (both features per pass), any other
+// level is two (one per feature).
+__device__ __host__ inline bool enc_both_features(const vsa_nt_plan& p, int level, bool hashed) {
+  return !hashed && (long long)p.level_size[level] * 2 <= LDS_ENTRIES;
+}
+
 template <bool HASHED>
 __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
-    vsa_nt_plan plan, int level0, int n_levels, const half2_t* __restrict__ dfeatures,
-    const float* __restrict__ dfeat_abs_sum, float dscale_inv,
-    const float2* __restrict__ slot_xy, const int* __restrict__ seg_start,
+    vsa_nt_plan plan, int level0, int n_levels, int n_planes,
+    const half2_t* __restrict__ dfeatures, const float* __restrict__ dfeat_abs_sum,
+    float dscale_inv, const float2* __restrict__ slot_xy, const int* __restrict__ seg_start,
     float* __restrict__ grad_tables, int tex_begin, int tex_end) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   int* s_g = reinterpret_cast<int*>(s_raw);
-  const int nl = plan.n_levels;
-  const long long n_entries = plan.level_offset[plan.n_levels];
-  nt_for_each_piece<ENC_UNIT>(plan, seg_start, 2 * n_levels, 64,
+  nt_for_each_piece<ENC_UNIT>(plan, seg_start, n_planes, 64,
                               [&](int pl, int tex, int first, int last, int seg_begin, int seg_end) {
-    const int level = level0 + (pl >> 1), feat = pl & 1;
-    const LevelGeom g = level_geom(plan, level);
-    // fixed-point scale from sum |dF| over the WHOLE (texture, level, feature) plane,
-    // accumulated by the MLP backward kernel while it wrote dF (an upper bound for
-    // this piece's share; saves a second pass over dF)
-    const float total = dfeat_abs_sum[tex * 32 + 2 * level + feat] * 1.001f;
-    if (!(total > 0.f)) return;   // nothing to add (uniform across the workgroup)
-    int copies = 1;
-    if (!HASHED) {
-      while (copies < 32 && (long long)g.size * copies * 2 <= LDS_ENTRIES) copies *= 2;
+    int level = level0, r = pl;
+    bool both = enc_both_features(plan, level, HASHED);
+    while (r >= (both ? 1 : 2)) {
+      r -= both ? 1 : 2;
+      ++level;
+      both = enc_both_features(plan, level, HASHED);
     }
-    __syncthreads();   // the previous piece's flush has read the plane
-    for (int i = threadIdx.x; i < (int)g.size * copies; i += ENC_BLOCK) s_g[i] = 0;
-    int* my_g = s_g + (threadIdx.x & (copies - 1)) * g.size;   // consecutive lanes -> different copies
-    const int type = (tex / VSA_NT_MAX_DEG) & 1;
-    const unsigned* dFw = reinterpret_cast<const unsigned*>(dfeatures + nt_feat_plane_base(plan, type, level));
-    const int shift = 16 * feat;
-    __syncthreads();
-    int e;
-    frexpf(total, &e);                       // total = m * 2^e, m in [0.5, 1)
-    const float S = ldexpf(1.0f, 30 - e);    // power of two: exact scaling and un-scaling
-    const float S_inv = ldexpf(1.0f, e - 30) * dscale_inv;
-    // scatter.  A lane owns ENC_UNROLL = 8 CONSECUTIVE slots (= neighbouring texels of one
-    // texture row): 64 B of texel centres and 32 B of dF per lane come in as dwordx4
-    // loads; the 64 lanes of a wave are 8 texels apart, so they share a grid cell only at
-    // the coarsest levels (same-address LDS atomics serialise; those small planes are
-    // replicated, see `copies`); and while consecutive slots of a lane stay in one cell
-    // their four corner contributions are summed in registers and added once.  The sums
-    // are integers, so the result is independent of this grouping.
-    const int a_first = first & ~(ENC_UNROLL - 1);
-    for (int s0 = a_first + threadIdx.x * ENC_UNROLL; s0 < last; s0 += ENC_BLOCK * ENC_UNROLL) {
-      float4 xyv[ENC_UNROLL / 2];
-      uint4 dv[ENC_UNROLL / 4];
-      const float4* xp = reinterpret_cast<const float4*>(slot_xy + s0);
-      const uint4* dp = reinterpret_cast<const uint4*>(dFw + nt_feat_in_plane(nl, s0));
-#pragma unroll
-      for (int i = 0; i < ENC_UNROLL / 2; ++i) xyv[i] = xp[i];
-#pragma unroll
-      for (int i = 0; i < ENC_UNROLL / 4; ++i) dv[i] = dp[i];
-      const unsigned dws[ENC_UNROLL] = {dv[0].x, dv[0].y, dv[0].z, dv[0].w,
-                                        dv[1].x, dv[1].y, dv[1].z, dv[1].w};
-      unsigned cur_idx[4] = {0, 0, 0, 0};
-      int acc[4] = {0, 0, 0, 0};
-      unsigned cur_cx = 0xffffffffu, cur_cy = 0xffffffffu;
-#pragma unroll
-      for (int u = 0; u < ENC_UNROLL; ++u) {
-        const int slot = s0 + u;
-        const float x = (u & 1) ? xyv[u >> 1].z : xyv[u >> 1].x;
-        const float y = (u & 1) ? xyv[u >> 1].w : xyv[u >> 1].y;
-        const float gv = (float)__builtin_bit_cast(_Float16, (unsigned short)(dws[u] >> shift)) * S;
-        if (slot >= first && slot < last && gv != 0.f) {
-          const CellRef cr = cell_ref(g, x, y);
-          const f32x2 p01 = cr.w01 * gv, p23 = cr.w23 * gv;
-          const int v0 = __float2int_rn(p01.x), v1 = __float2int_rn(p01.y),
-                    v2 = __float2int_rn(p23.x), v3 = __float2int_rn(p23.y);
-          if (cr.cx == cur_cx && cr.cy == cur_cy) {
-            acc[0] += v0, acc[1] += v1, acc[2] += v2, acc[3] += v3;
-          } else {
-            if (cur_cx != 0xffffffffu) {
-#pragma unroll
-              for (int k = 0; k < 4; ++k) atomicAdd(&my_g[cur_idx[k]], acc[k]);
-            }
-            cur_cx = cr.cx, cur_cy = cr.cy;
-            cell_indices<HASHED>(g, cr.cx, cr.cy, cur_idx);
-            acc[0] = v0, acc[1] = v1, acc[2] = v2, acc[3] = v3;
-          }
-        }
-      }
-      if (cur_cx != 0xffffffffu) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) atomicAdd(&my_g[cur_idx[k]], acc[k]);
-      }
-    }
-    __syncthreads();
-    float* gt = grad_tables + ((long long)tex * n_entries + plan.level_offset[level]) * 2 + feat;
     const bool single = first == seg_begin && last == seg_end;
-    for (int i = threadIdx.x; i < (int)g.size; i += ENC_BLOCK) {
-      int vi = 0;
-      for (int cpy = 0; cpy < copies; ++cpy) vi += s_g[cpy * g.size + i];
-      if (vi == 0) continue;
-      const float v = (float)vi * S_inv;
-      if (single) {
-        gt[2 * (long long)i] += v;  // sole writer of this (texture, level, feature) plane
-      } else {
-        atomicAdd(&gt[2 * (long long)i], v);
-      }
-    }
+    if (both)
+      enc_bwd_piece<HASHED, 2>(plan, s_g, level, 0, tex, first, last, single, dfeatures,
+                               dfeat_abs_sum, dscale_inv, slot_xy, grad_tables);
+    else
+      enc_bwd_piece<HASHED, 1>(plan, s_g, level, r, tex, first, last, single, dfeatures,
+                               dfeat_abs_sum, dscale_inv, slot_xy, grad_tables);
   }, tex_begin, tex_end);
 }
 
@@ -426,14 +491,18 @@ extern "C" int vsa_nt_encode_bwd_range(const vsa_nt_plan* plan, const void* dfea
   const float2* xy = reinterpret_cast<const float2*>(slot_xy);
   int nr_cus = 0;
   if ((rc = vsa_cu_count(&nr_cus))) return rc;
-  if (lh > 0)
+  if (lh > 0) {
+    int n_planes = 0;
+    for (int l = 0; l < lh; ++l) n_planes += enc_both_features(*plan, l, false) ? 1 : 2;
     hipLaunchKernelGGL(nt_encode_bwd_kernel<false>, dim3(nr_cus), dim3(ENC_BLOCK),
-                       (size_t)LDS_ENTRIES * 4, (hipStream_t)stream, *plan, 0, lh, dF, dfeat_abs_sum,
-                       1.0f / grad_scale, xy, seg_start, grad_tables, tex_begin, tex_end);
+                       (size_t)LDS_ENTRIES * 4, (hipStream_t)stream, *plan, 0, lh, n_planes, dF,
+                       dfeat_abs_sum, 1.0f / grad_scale, xy, seg_start, grad_tables, tex_begin,
+                       tex_end);
+  }
   if (lh < plan->n_levels)
     hipLaunchKernelGGL(nt_encode_bwd_kernel<true>, dim3(nr_cus), dim3(ENC_BLOCK),
                        (size_t)LDS_ENTRIES * 4, (hipStream_t)stream, *plan, lh, plan->n_levels - lh,
-                       dF, dfeat_abs_sum, 1.0f / grad_scale, xy, seg_start, grad_tables, tex_begin,
-                       tex_end);
+                       2 * (plan->n_levels - lh), dF, dfeat_abs_sum, 1.0f / grad_scale, xy,
+                       seg_start, grad_tables, tex_begin, tex_end);
   VSA_RETURN_LAUNCH_STATUS();
 }
