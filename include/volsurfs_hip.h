@@ -225,21 +225,26 @@ int vsa_nt_mlp_bwd(const vsa_nt_plan* plan, const void* weights_h, void* feature
  * coefficients -> SH eval -> sigmoid -> alpha decay), scattered dense:
  * surfs_rgb [N,K,3], surfs_alpha [N,K] (zero on miss; inner->outer), optional
  * surfs_normals [N,K,3] and coeffs_out [K,N,64] (tests: 48 rgb [ch][16] + 16
- * alpha lerped fp16 SH coefficients).  tris = the tracer's triangle array. */
+ * alpha lerped fp16 SH coefficients).  tris = the tracer's triangle array.
+ * act_out (optional, [K,N,4] f32): the three rgb sigmoids and the alpha sigmoid (before
+ * the decay) of every hit, which vsa_nt_shade_bwd can take back as act_in instead of
+ * re-gathering the texel rows and re-evaluating the SH sums. */
 int vsa_nt_shade_fwd(const vsa_nt_plan* plan, const int32_t* hit_slot, const float* tex_uv,
                      const float* rays_d, const float* tris, const int32_t* slot_of,
                      const int32_t* seg_start, const uint8_t* texels, int nr_rays,
                      float* surfs_rgb, float* surfs_alpha,
-                     float* surfs_normals, float* coeffs_out, void* stream);
+                     float* surfs_normals, float* coeffs_out, float* act_out, void* stream);
 
 /* Backward of step 5: grad_rows (f32 [row_base[last]*4], same row layout as
  * texels; zero on entry, see vsa_nt_mlp_bwd) += grad_scale * dL/d(q/255)
- * (round is a straight-through estimator, utils/math.py:5-18). */
+ * (round is a straight-through estimator, utils/math.py:5-18).  act_in: NULL, or the
+ * act_out of the forward call on the SAME frame and parameters. */
 int vsa_nt_shade_bwd(const vsa_nt_plan* plan, const int32_t* hit_slot, const float* tex_uv,
                      const float* rays_d, const float* tris, const int32_t* slot_of,
                      const int32_t* seg_start, const uint8_t* texels, int nr_rays,
                      const float* g_surfs_rgb,
-                     const float* g_surfs_alpha, float grad_scale, float* grad_rows, void* stream);
+                     const float* g_surfs_alpha, float grad_scale, float* grad_rows,
+                     const float* act_in, void* stream);
 
 /* Backward of step 3: grad_tables (f32 [n_tex][level_offset[n]][2]) +=
  * transpose-interpolation of dfeatures (f16x2, same layout as features, holding

@@ -37,17 +37,25 @@ def _oracle_grads(bank, s, hit_slot, tex_uv, rays_d, normals, g_rgb, g_alpha, de
 
 
 @pytest.mark.gpu
-def test_shade_stage_backward_vs_oracle_autograd():
+@pytest.mark.parametrize("keep_act", [False, True])
+def test_shade_stage_backward_vs_oracle_autograd(keep_act):
+    """keep_act: shade_bwd takes the forward pass's output sigmoids (act_out -> act_in)
+    instead of re-gathering the texel rows; both routes are held to the same bar."""
     K, N = 2, 2500
     bank, face_uvs, hit_slot, hit_uv, tris, rays_d = _scene(K, N, 3)
     tex_uv = bank.mark_and_compact(hit_slot, hit_uv, face_uvs)
     bank.encode()
     bank.mlp()
-    rgb, alpha, normals, _ = bank.shade(hit_slot, tex_uv, rays_d, tris, False, True)
+    act = torch.full((K, N, 4), float("nan"), device="cuda") if keep_act else None
+    rgb, alpha, normals, _ = bank.shade(hit_slot, tex_uv, rays_d, tris, False, True, act_out=act)
+    if keep_act:     # every hit's entry was written: (sigmoid rgb x3, sigmoid alpha)
+        hit = hit_slot >= 0
+        assert torch.isfinite(act[hit]).all()
+        torch.testing.assert_close(act[hit][:, :3], rgb.permute(1, 0, 2)[hit])
     g = torch.Generator().manual_seed(0)
     g_rgb = (torch.randn(N, K, 3, generator=g) / N).cuda()
     g_alpha = (torch.randn(N, K, generator=g) / N).cuda()
-    bank.backward(hit_slot, tex_uv, rays_d, tris, g_rgb, g_alpha, grad_scale=float(N))
+    bank.backward(hit_slot, tex_uv, rays_d, tris, g_rgb, g_alpha, grad_scale=float(N), act=act)
     torch.cuda.synchronize()
     gw = bank.weights.grad.cpu()
     gt = bank.tables.grad.cpu()

@@ -193,7 +193,8 @@ __global__ __launch_bounds__(SH_BLOCK) void nt_shade_fwd_kernel(
     const float* __restrict__ rays_d, const float4* __restrict__ tris,
     const int* __restrict__ slot_of, const int* __restrict__ seg_start,
     const unsigned* __restrict__ texels, int N, float* __restrict__ surfs_rgb, float* __restrict__ surfs_alpha,
-    float* __restrict__ surfs_normals, float* __restrict__ coeffs_out) {
+    float* __restrict__ surfs_normals, float* __restrict__ coeffs_out,
+    float4* __restrict__ act_out) {
   __shared__ float s_lut[VSA_NT_MAX_DEG * 256];
   build_lut(plan, s_lut);
   __syncthreads();
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(SH_BLOCK) void nt_shade_fwd_kernel(
   HitCtx c;
   float nrm[3];
   float rgb[3] = {0.f, 0.f, 0.f}, alpha = 0.f;
+  float4 act = make_float4(0.f, 0.f, 0.f, 0.f);   // the four sigmoids, for the backward pass
   if (load_ctx(plan, s, n, N, hit_slot, tex_uv, rays_d, tris, slot_of, seg_start, c, nrm)) {
     const bool has_alpha = !(plan.inner_solid && s == 0);
     float sh_rgb[3][16], sh_a[16];
@@ -212,11 +214,15 @@ __global__ __launch_bounds__(SH_BLOCK) void nt_shade_fwd_kernel(
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
       const float raw = sh_raw(b, sh_rgb[ch], plan.rgb_degrees);
-      rgb[ch] = plan.rgb_degrees > 1 ? sigmoidf_(raw) : vsa_round_f16(sigmoidf_(raw));
+      const float sg = sigmoidf_(raw);
+      (ch == 0 ? act.x : ch == 1 ? act.y : act.z) = sg;
+      rgb[ch] = plan.rgb_degrees > 1 ? sg : vsa_round_f16(sg);
     }
     if (has_alpha) {
       const float raw = sh_raw(b, sh_a, plan.alpha_degrees);
-      const float a = plan.alpha_degrees > 1 ? sigmoidf_(raw) : vsa_round_f16(sigmoidf_(raw));
+      const float sg = sigmoidf_(raw);
+      act.w = sg;
+      const float a = plan.alpha_degrees > 1 ? sg : vsa_round_f16(sg);
       alpha = a * c.decay;
     } else {
       alpha = 1.0f;
@@ -234,6 +240,7 @@ __global__ __launch_bounds__(SH_BLOCK) void nt_shade_fwd_kernel(
     float* co = coeffs_out + ((long long)s * N + n) * 64;
     for (int i = 0; i < 64; ++i) co[i] = 0.f;
   }
+  if (act_out) act_out[(long long)s * N + n] = act;
   const long long o = n * K + s;
   surfs_rgb[3 * o] = rgb[0];
   surfs_rgb[3 * o + 1] = rgb[1];
@@ -254,8 +261,9 @@ __global__ __launch_bounds__(SH_BLOCK) void nt_shade_bwd_kernel(
     vsa_nt_plan plan, const int* __restrict__ hit_slot, const float* __restrict__ tex_uv,
     const float* __restrict__ rays_d, const float4* __restrict__ tris,
     const int* __restrict__ slot_of, const int* __restrict__ seg_start,
-    const unsigned* __restrict__ texels, int N, const float* __restrict__ g_surfs_rgb, const float* __restrict__ g_surfs_alpha,
-    float grad_scale, float* __restrict__ grad_rows) {
+    const unsigned* __restrict__ texels, int N, const float* __restrict__ g_surfs_rgb,
+    const float* __restrict__ g_surfs_alpha, float grad_scale, float* __restrict__ grad_rows,
+    const float4* __restrict__ act_in) {
   __shared__ float s_lut[VSA_NT_MAX_DEG * 256];
   __shared__ float s_graw[SH_BLOCK][4];
   __shared__ float s_basis[SH_BLOCK][17];
@@ -271,19 +279,28 @@ __global__ __launch_bounds__(SH_BLOCK) void nt_shade_bwd_kernel(
   float nrm[3];
   const bool has_alpha = !(plan.inner_solid && s == 0);
   if (n < N && load_ctx(plan, s, n, N, hit_slot, tex_uv, rays_d, tris, slot_of, seg_start, c, nrm)) {
-    float sh_rgb[3][16], sh_a[16];
-    gather_coeffs(plan, c, texels, s_lut, has_alpha, sh_rgb, sh_a);
     float b[16];
     sh_basis(c.dir[0], c.dir[1], c.dir[2], b);
     const long long o = n * K + s;
+    float sg4[4];
+    if (act_in) {   // the forward pass kept its four sigmoids: no texel gather, no SH sums
+      const float4 a = act_in[(long long)s * N + n];
+      sg4[0] = a.x, sg4[1] = a.y, sg4[2] = a.z, sg4[3] = a.w;
+    } else {
+      float sh_rgb[3][16], sh_a[16];
+      gather_coeffs(plan, c, texels, s_lut, has_alpha, sh_rgb, sh_a);
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) sg4[ch] = sigmoidf_(sh_raw(b, sh_rgb[ch], plan.rgb_degrees));
+      sg4[3] = has_alpha ? sigmoidf_(sh_raw(b, sh_a, plan.alpha_degrees)) : 0.f;
+    }
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-      const float sg = sigmoidf_(sh_raw(b, sh_rgb[ch], plan.rgb_degrees));
+      const float sg = sg4[ch];
       s_graw[t][ch] = g_surfs_rgb[3 * o + ch] * sg * (1.0f - sg) * grad_scale;
     }
     float ga = 0.f;
     if (has_alpha) {
-      const float sg = sigmoidf_(sh_raw(b, sh_a, plan.alpha_degrees));
+      const float sg = sg4[3];
       ga = g_surfs_alpha[o] * c.decay * sg * (1.0f - sg) * grad_scale;
     }
     s_graw[t][3] = ga;
@@ -360,8 +377,9 @@ __global__ __launch_bounds__(SH_BLOCK) void nt_shade_bwd_kernel(
 extern "C" int vsa_nt_shade_fwd(const vsa_nt_plan* plan, const int32_t* hit_slot,
                                 const float* tex_uv, const float* rays_d, const float* tris,
                                 const int32_t* slot_of, const int32_t* seg_start,
-                                const uint8_t* texels, int nr_rays, float* surfs_rgb, float* surfs_alpha, float* surfs_normals,
-                                float* coeffs_out, void* stream) {
+                                const uint8_t* texels, int nr_rays, float* surfs_rgb,
+                                float* surfs_alpha, float* surfs_normals, float* coeffs_out,
+                                float* act_out, void* stream) {
   if (!plan || nr_rays < 0) return VSA_ERR_ARG;
   if (nr_rays == 0) return VSA_OK;
   if (!hit_slot || !tex_uv || !rays_d || !tris || !slot_of || !seg_start || !texels || !surfs_rgb ||
@@ -371,16 +389,16 @@ extern "C" int vsa_nt_shade_fwd(const vsa_nt_plan* plan, const int32_t* hit_slot
   hipLaunchKernelGGL(nt_shade_fwd_kernel, grid, dim3(SH_BLOCK), 0, (hipStream_t)stream, *plan,
                      hit_slot, tex_uv, rays_d, reinterpret_cast<const float4*>(tris), slot_of,
                      seg_start, reinterpret_cast<const unsigned*>(texels), nr_rays, surfs_rgb,
-                     surfs_alpha,
-                     surfs_normals, coeffs_out);
+                     surfs_alpha, surfs_normals, coeffs_out, reinterpret_cast<float4*>(act_out));
   VSA_RETURN_LAUNCH_STATUS();
 }
 
 extern "C" int vsa_nt_shade_bwd(const vsa_nt_plan* plan, const int32_t* hit_slot,
                                 const float* tex_uv, const float* rays_d, const float* tris,
                                 const int32_t* slot_of, const int32_t* seg_start,
-                                const uint8_t* texels, int nr_rays, const float* g_surfs_rgb, const float* g_surfs_alpha,
-                                float grad_scale, float* grad_rows, void* stream) {
+                                const uint8_t* texels, int nr_rays, const float* g_surfs_rgb,
+                                const float* g_surfs_alpha, float grad_scale, float* grad_rows,
+                                const float* act_in, void* stream) {
   if (!plan || nr_rays < 0) return VSA_ERR_ARG;
   if (nr_rays == 0) return VSA_OK;
   if (!hit_slot || !tex_uv || !rays_d || !tris || !slot_of || !seg_start || !texels || !g_surfs_rgb ||
@@ -390,7 +408,6 @@ extern "C" int vsa_nt_shade_bwd(const vsa_nt_plan* plan, const int32_t* hit_slot
   hipLaunchKernelGGL(nt_shade_bwd_kernel, grid, dim3(SH_BLOCK), 0, (hipStream_t)stream, *plan,
                      hit_slot, tex_uv, rays_d, reinterpret_cast<const float4*>(tris), slot_of,
                      seg_start, reinterpret_cast<const unsigned*>(texels), nr_rays, g_surfs_rgb,
-                     g_surfs_alpha,
-                     grad_scale, grad_rows);
+                     g_surfs_alpha, grad_scale, grad_rows, reinterpret_cast<const float4*>(act_in));
   VSA_RETURN_LAUNCH_STATUS();
 }

@@ -22,9 +22,11 @@ class _ShadeStage(torch.autograd.Function):
         tex_uv = bank.mark_and_compact(hit_slot, hit_uv, method.face_uvs)
         bank.encode()
         bank.mlp()
+        act = torch.empty(hit_slot.shape[0], hit_slot.shape[1], 4, device=hit_slot.device) \
+            if torch.is_grad_enabled() else None
         rgb, alpha, normals, _ = bank.shade(hit_slot, tex_uv, rays_d, method.raytracer.tris,
-                                            want_normals=True)
-        ctx.method, ctx.saved = method, (hit_slot, tex_uv, rays_d)
+                                            want_normals=True, act_out=act)
+        ctx.method, ctx.saved = method, (hit_slot, tex_uv, rays_d, act)
         ctx.mark_non_differentiable(normals, tex_uv)
         return rgb, alpha, normals, tex_uv
 
@@ -32,12 +34,12 @@ class _ShadeStage(torch.autograd.Function):
     def backward(ctx, g_rgb, g_alpha, *unused):
         method = ctx.method
         bank = method.bank
-        hit_slot, tex_uv, rays_d = ctx.saved
+        hit_slot, tex_uv, rays_d, act = ctx.saved
         gt_prev, gw_prev = bank.tables.grad, bank.weights.grad
         bank.tables.grad = torch.zeros_like(bank.tables)
         bank.weights.grad = torch.zeros_like(bank.weights)
         bank.backward(hit_slot, tex_uv, rays_d, method.raytracer.tris, g_rgb.contiguous(),
-                      g_alpha.contiguous(), method.grad_scale)
+                      g_alpha.contiguous(), method.grad_scale, act)
         g_t, g_w = bank.tables.grad, bank.weights.grad
         bank.tables.grad, bank.weights.grad = gt_prev, gw_prev    # autograd accumulates itself
         return g_t, g_w, None, None, None, None

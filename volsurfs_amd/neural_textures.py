@@ -211,7 +211,10 @@ class NeuralTextureBank(torch.nn.Module):
                 dense[a:b, 24:24 + n] = rows[:, 4 * ALPHA_QUAD[d]:4 * ALPHA_QUAD[d] + n]
         return dense
 
-    def shade(self, hit_slot, tex_uv, rays_d, tris, want_coeffs=False, want_normals=False):
+    def shade(self, hit_slot, tex_uv, rays_d, tris, want_coeffs=False, want_normals=False,
+              act_out=None):
+        """act_out: optional [K,N,4] f32 buffer that receives the per-hit output sigmoids;
+        pass it to backward_shade(act=...) of the same frame to skip the re-gather."""
         K, N = hit_slot.shape
         dev = hit_slot.device
         rgb = torch.empty(N, K, 3, device=dev)
@@ -220,15 +223,17 @@ class NeuralTextureBank(torch.nn.Module):
         coeffs = torch.empty(K, N, 64, device=dev) if want_coeffs else None
         _lib.call("vsa_nt_shade_fwd", ctypes.byref(self.plan), hit_slot, tex_uv, rays_d, tris,
                   self.slot_of, self.seg_start, self.texels, N, rgb, alpha, normals, coeffs,
-                  _lib.stream_ptr())
+                  act_out, _lib.stream_ptr())
         return rgb, alpha, normals, coeffs
 
-    def backward(self, hit_slot, tex_uv, rays_d, tris, g_surfs_rgb, g_surfs_alpha, grad_scale):
+    def backward(self, hit_slot, tex_uv, rays_d, tris, g_surfs_rgb, g_surfs_alpha, grad_scale,
+                 act=None):
         """Back-propagates d loss / d surfs_rgb [N,K,3], d surfs_alpha [N,K] to
         self.tables.grad / self.weights.grad (accumulating, like autograd).
         grad_scale keeps the fp16 intermediate gradients in range (the analogue of
         tiny-cuda-nn's loss scale); it is divided out before accumulation."""
-        self.backward_shade(hit_slot, tex_uv, rays_d, tris, g_surfs_rgb, g_surfs_alpha, grad_scale)
+        self.backward_shade(hit_slot, tex_uv, rays_d, tris, g_surfs_rgb, g_surfs_alpha, grad_scale,
+                            act)
         self.backward_mlp(grad_scale)
         self.backward_encode(grad_scale)
 
@@ -240,12 +245,16 @@ class NeuralTextureBank(torch.nn.Module):
         if getattr(self, "_gw_scaled", None) is None:
             self._gw_scaled = torch.zeros_like(self.weights)
 
-    def backward_shade(self, hit_slot, tex_uv, rays_d, tris, g_surfs_rgb, g_surfs_alpha, grad_scale):
+    def backward_shade(self, hit_slot, tex_uv, rays_d, tris, g_surfs_rgb, g_surfs_alpha, grad_scale,
+                       act=None):
         self._ensure_grads()
+        if act is not None:
+            _lib.check_f32(act, hit_slot.shape[0], hit_slot.shape[1], 4)
         _lib.call("vsa_nt_shade_bwd", ctypes.byref(self.plan), hit_slot, tex_uv, rays_d, tris,
                   self.slot_of, self.seg_start, self.texels, hit_slot.shape[1],
                   g_surfs_rgb.contiguous(),
-                  g_surfs_alpha.contiguous(), float(grad_scale), self.grad_rows, _lib.stream_ptr())
+                  g_surfs_alpha.contiguous(), float(grad_scale), self.grad_rows, act,
+                  _lib.stream_ptr())
 
     def backward_mlp(self, grad_scale):
         self._gw_scaled.zero_()

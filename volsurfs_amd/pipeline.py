@@ -70,6 +70,8 @@ class KShellPipeline:
         self.shading = "neural_textures"
         self.grad_scale = float(N)
         self.surfs_rgb = self.surfs_alpha = None
+        # per-hit output sigmoids kept from shade_fwd for shade_bwd of the same frame
+        self._act = torch.empty(K, N, 4, device=dev)
 
     @classmethod
     def synthetic(cls, K=5, subdiv=6, res=800, device="cuda", seed=42, **kw):
@@ -201,7 +203,8 @@ class KShellPipeline:
         T.run("nt_mlp_fwd", bank.mlp, record, bytes=acct.get("nt_mlp_fwd", 0), flops=mlp_flops,
               bound="mfma")
         rgb_k, alpha_k, _, _ = T.run(
-            "nt_shade_fwd", lambda: bank.shade(hit_slot, tex_uv, self.rays_d, self.tracer.tris),
+            "nt_shade_fwd", lambda: bank.shade(hit_slot, tex_uv, self.rays_d, self.tracer.tris,
+                                               act_out=self._act),
             record, bytes=acct.get("nt_shade_fwd", 0))
         self.surfs_rgb, self.surfs_alpha = rgb_k, alpha_k
         rgb = T.run("composite_fwd", lambda: composite_fwd_raw(rgb_k, alpha_k, self.bg), record,
@@ -216,7 +219,7 @@ class KShellPipeline:
                          bytes=N * (12 + 32 * K))
         tris = self.tracer.tris
         T.run("nt_shade_bwd", lambda: bank.backward_shade(hit_slot, tex_uv, self.rays_d, tris, g_c, g_a,
-                                                           self.grad_scale), record,
+                                                           self.grad_scale, self._act), record,
               bytes=acct.get("nt_shade_bwd", 0), bound="atomic")
         T.run("nt_mlp_bwd", lambda: bank.backward_mlp(self.grad_scale), record,
               bytes=acct.get("nt_mlp_bwd", 0), flops=2 * mlp_flops, bound="mfma")
