@@ -94,15 +94,18 @@ __global__ __launch_bounds__(1024) void nt_scan_blocks_kernel(vsa_nt_plan plan,
   }
 }
 
-// pass C: slot_of[texel], texel_of_slot[slot]
-__global__ __launch_bounds__(256) void nt_assign_kernel(vsa_nt_plan plan,
-                                                        const uint4* __restrict__ marks,
-                                                        const int* __restrict__ block_prefix,
-                                                        int* __restrict__ slot_of,
-                                                        int* __restrict__ texel_of_slot,
-                                                        float2* __restrict__ slot_xy,
-                                                        long long slot_capacity) {
-  __shared__ int s_w[4];
+// pass C: slot_of[texel], texel_of_slot[slot], slot_xy[slot].  One thread per 4 texels
+// (1024 threads = one 4096-texel domain block): the marks come in as one dword and
+// slot_of goes out as one int4 per lane, i.e. every wave instruction moves a contiguous
+// 256 B / 1 KiB (16 texels per thread made each store touch 64 lines at 16 B).
+__global__ __launch_bounds__(1024) void nt_assign_kernel(vsa_nt_plan plan,
+                                                         const unsigned* __restrict__ marks,
+                                                         const int* __restrict__ block_prefix,
+                                                         int4* __restrict__ slot_of,
+                                                         int* __restrict__ texel_of_slot,
+                                                         float2* __restrict__ slot_xy,
+                                                         long long slot_capacity) {
+  __shared__ int s_w[16];
   // the (shell, degree) domain this block lies in (domains are block aligned)
   const long long blk0 = (long long)blockIdx.x * NT_DOM_BLOCK;
   int sd = 0;
@@ -111,10 +114,10 @@ __global__ __launch_bounds__(256) void nt_assign_kernel(vsa_nt_plan plan,
   const int R = plan.tex_res[sd % VSA_NT_MAX_DEG], W = R + 2;
   const float Rf = (float)R;
   const long long dom0 = plan.dom_off[sd];
-  const long long vec = (long long)blockIdx.x * 256 + threadIdx.x;
-  const uint4 v = marks[vec];
-  const int c = count16(v);
-  // exclusive scan across the 256 threads
+  const long long vec = (long long)blockIdx.x * 1024 + threadIdx.x;   // 4-texel group
+  const unsigned word = marks[vec] & 0x01010101u;
+  const int c = __popc(word);
+  // exclusive scan across the 1024 threads
   int incl = c;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int off = 1; off < 64; off <<= 1) {
@@ -123,32 +126,29 @@ __global__ __launch_bounds__(256) void nt_assign_kernel(vsa_nt_plan plan,
   }
   if (lane == 63) s_w[wave] = incl;
   __syncthreads();
-  int base = block_prefix[blockIdx.x];
-  for (int w = 0; w < wave; ++w) base += s_w[w];
-  int slot = base + incl - c;
-  const unsigned int words[4] = {v.x, v.y, v.z, v.w};
-  int out[16];
+  int slot = block_prefix[blockIdx.x] + incl - c;
+  for (int w = 0; w < wave; ++w) slot += s_w[w];
+  int out[4];
+  const int local0 = (int)(vec * 4 - dom0);
+  int iy = local0 / W, ix = local0 - iy * W;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const bool m = (words[i >> 2] >> (8 * (i & 3))) & 1u;
+  for (int i = 0; i < 4; ++i) {
+    const bool m = (word >> (8 * i)) & 1u;
     out[i] = m ? slot : -1;
     if (m) {
       if (slot < slot_capacity) {
-        const long long texel = vec * 16 + i;
-        texel_of_slot[slot] = (int)texel;
-        const int local = (int)(texel - dom0);
-        const int iy = local / W, ix = local - iy * W;
+        texel_of_slot[slot] = (int)(vec * 4 + i);
         // texel centre, normalised exactly like normalize_uv_coord(corner) in the reference
         slot_xy[slot] = make_float2(((float)(ix - 1) + 0.5f) / Rf, ((float)(iy - 1) + 0.5f) / Rf);
       }
       ++slot;
     }
+    if (++ix == W) {
+      ix = 0;
+      ++iy;
+    }
   }
-  int4* so = reinterpret_cast<int4*>(slot_of + vec * 16);
-  so[0] = make_int4(out[0], out[1], out[2], out[3]);
-  so[1] = make_int4(out[4], out[5], out[6], out[7]);
-  so[2] = make_int4(out[8], out[9], out[10], out[11]);
-  so[3] = make_int4(out[12], out[13], out[14], out[15]);
+  slot_of[vec] = make_int4(out[0], out[1], out[2], out[3]);
 }
 
 }  // namespace
@@ -196,8 +196,9 @@ extern "C" int vsa_nt_compact(const vsa_nt_plan* plan, const uint8_t* marks, int
                      reinterpret_cast<const uint4*>(marks), block_scratch);
   hipLaunchKernelGGL(nt_scan_blocks_kernel, dim3(1), dim3(1024), 0, st, *plan, block_scratch,
                      nr_blocks, seg_start);
-  hipLaunchKernelGGL(nt_assign_kernel, dim3(nr_blocks), dim3(256), 0, st, *plan,
-                     reinterpret_cast<const uint4*>(marks), block_scratch, slot_of, texel_of_slot,
+  hipLaunchKernelGGL(nt_assign_kernel, dim3(nr_blocks), dim3(1024), 0, st, *plan,
+                     reinterpret_cast<const unsigned*>(marks), block_scratch,
+                     reinterpret_cast<int4*>(slot_of), texel_of_slot,
                      reinterpret_cast<float2*>(slot_xy), (long long)plan->slot_capacity);
   VSA_RETURN_LAUNCH_STATUS();
 }
