@@ -262,6 +262,34 @@ int vsa_nt_encode_bwd_range(const vsa_nt_plan* plan, const void* dfeatures,
                             int shell_end, void* stream);
 
 /* ------------------------------------------------------------------------
+ * A5 / A10  Encoders of the legacy appearance branch and of the background field:
+ * the 2-D / 3-D multiresolution hash grid behind GridHashEncoder
+ * (volsurfs_py/encodings/gridhash.py:12-92: tcnn.Encoding "Grid"/"Hash", fp32) and
+ * SHEncoder.__call__ (volsurfs_py/encodings/sphericalharmonics.py:84-153).
+ * tables: fp32 [level_offset[n_levels]][2]; x: fp32 [nr_points][n_dims] in [0,1];
+ * out / g_out: fp32 [nr_points][n_levels*2] (level-major, as tcnn returns it).
+ */
+#define VSA_GRID_MAX_LEVELS 32
+typedef struct vsa_grid_plan {
+  int32_t n_dims;      /* 2 or 3 */
+  int32_t n_levels;
+  int32_t n_features;  /* 2 */
+  int32_t reserved0;
+  float level_scale[VSA_GRID_MAX_LEVELS];
+  int32_t level_res[VSA_GRID_MAX_LEVELS];
+  int32_t level_size[VSA_GRID_MAX_LEVELS];        /* entries */
+  int32_t level_offset[VSA_GRID_MAX_LEVELS + 1];  /* entries */
+} vsa_grid_plan;
+
+int vsa_grid_encode_fwd(const vsa_grid_plan* plan, const float* tables, const float* x,
+                        int nr_points, float* out, void* stream);
+/* grad_tables (fp32, same shape as tables) += transpose-interpolation of g_out. */
+int vsa_grid_encode_bwd(const vsa_grid_plan* plan, const float* x, const float* g_out,
+                        int nr_points, float* grad_tables, void* stream);
+/* out [nr_dirs][(degree+1)^2]: SH basis of each direction, degree 0..4. */
+int vsa_sh_encode(const float* dirs, int nr_dirs, int degree, float* out, void* stream);
+
+/* ------------------------------------------------------------------------
  * A8 / A9 / A11  Packed (ragged) per-ray sample ops of the background path:
  * what render_contracted_bg (volsurfs_py/utils/background.py:31-141) calls in the
  * reference's pybind module `volsurfs` (src/PyBridge.cxx:70-138).  A pack is the

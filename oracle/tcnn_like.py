@@ -97,6 +97,75 @@ def mlp_forward(w1, w2, w3, x_h, n_out):
     return o[:, :n_out]
 
 
+PRIMES = (1, 2654435761, 805459861)
+
+
+class GridGeometryND:
+    """tiny-cuda-nn GridEncoding geometry for n_dims in {2, 3} (the fp32 "Grid"/"Hash"
+    encoder of /root/reference/volsurfs_py/encodings/gridhash.py:23-37: 24 levels,
+    2 features, 2^18 entries, base 16, growth 2)."""
+
+    def __init__(self, n_dims=3, n_levels=24, log2_hashmap_size=18, base_resolution=16,
+                 per_level_scale=2.0):
+        self.n_dims, self.n_levels, self.n_features = n_dims, n_levels, 2
+        hashmap = 1 << log2_hashmap_size
+        log2_pls = np.float32(math.log2(per_level_scale))
+        self.scale, self.res, self.size, self.offset = [], [], [], [0]
+        for l in range(n_levels):
+            s = np.float32(np.exp2(np.float32(l) * log2_pls)) * np.float32(base_resolution) - np.float32(1.0)
+            r = int(np.ceil(s)) + 1
+            n = min(r ** n_dims, 1 << 62)
+            n = min((n + 7) // 8 * 8, hashmap)
+            self.scale.append(float(np.float32(s)))
+            self.res.append(r)
+            self.size.append(n)
+            self.offset.append(self.offset[-1] + n)
+        self.n_output_dims = 2 * n_levels
+
+    def index(self, l, c):
+        """c: list of n_dims int64 tensors holding uint32 values."""
+        M = 0xFFFFFFFF
+        res, size = self.res[l], self.size[l]
+        # tiny-cuda-nn keeps `stride` in a uint32: at res = 2^16 .. 2^18 (levels 12-14 of the
+        # 24-level, growth-2 grid) res^2 wraps to 0, the loop runs on with stride 0 and the
+        # level falls back to the dense x + y*res index instead of the hash.  Restated as is.
+        stride, idx = 1, torch.zeros_like(c[0])
+        for d in range(self.n_dims):
+            if stride <= size:
+                idx = (idx + c[d] * stride) & M
+                stride = (stride * res) & M
+        if size < stride:
+            idx = torch.zeros_like(c[0])
+            for d in range(self.n_dims):
+                idx = idx ^ ((c[d] * PRIMES[d]) & M)
+        return idx % size
+
+
+def grid_forward_f32(geom, table, x):
+    """table [n_entries, 2] fp32, x [B, n_dims] fp32 in [0,1] -> [B, 2*n_levels] fp32.
+    Per level: pos = x*scale + 0.5 (two roundings), cell = floor, D-linear interpolation
+    with the corner weight formed as ((w0*w1)*w2) and the corners summed in index order."""
+    D = geom.n_dims
+    outs = []
+    for l in range(geom.n_levels):
+        pos = x * np.float32(geom.scale[l]) + np.float32(0.5)
+        cell = torch.floor(pos)
+        frac = pos - cell
+        c = cell.to(torch.int64) & 0xFFFFFFFF
+        feat = torch.zeros(x.shape[0], 2, dtype=torch.float32)
+        for corner in range(1 << D):
+            w = None
+            cc = []
+            for d in range(D):
+                bit = (corner >> d) & 1
+                wd = frac[:, d] if bit else 1 - frac[:, d]
+                w = wd if w is None else w * wd
+                cc.append((c[:, d] + bit) & 0xFFFFFFFF)
+            feat = feat + w[:, None] * table[geom.offset[l] + geom.index(l, cc)]
+        outs.append(feat)
+    return torch.cat(outs, dim=1)
+
+
 class Encoding(torch.nn.Module):
     """tcnn.Encoding(n_input_dims=2, encoding_config) shaped."""
 
@@ -113,6 +182,27 @@ class Encoding(torch.nn.Module):
 
     def forward(self, x):
         return hashgrid_forward(self.geom, self.params, x.float())
+
+
+class GridEncoding(torch.nn.Module):
+    """tcnn.Encoding(n_input_dims, {"otype": "Grid", "type": "Hash", ...}, dtype=float32)
+    shaped (gridhash.py:23-37): fp32 parameters and output."""
+
+    def __init__(self, n_input_dims, encoding_config, dtype=None, seed=1337):
+        super().__init__()
+        assert encoding_config["otype"] == "Grid" and encoding_config["type"] == "Hash"
+        assert encoding_config["n_features_per_level"] == 2
+        self.geom = GridGeometryND(n_input_dims, encoding_config["n_levels"],
+                                   encoding_config["log2_hashmap_size"],
+                                   encoding_config["base_resolution"],
+                                   encoding_config["per_level_scale"])
+        g = torch.Generator().manual_seed(seed)
+        self.params = torch.nn.Parameter(
+            (torch.rand(self.geom.offset[-1], 2, generator=g) * 2 - 1) * 1e-4)
+        self.n_output_dims = self.geom.n_output_dims
+
+    def forward(self, x):
+        return grid_forward_f32(self.geom, self.params, x.float())
 
 
 class Network(torch.nn.Module):

@@ -94,3 +94,74 @@ def test_learned_background_path():
     assert all(p.grad is not None and p.grad.abs().sum() > 0 for p in net.parameters())
     with pytest.raises(Exception):
         VolSurfs(nested_shells(K=1, subdiv=1), bg_color=None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sh_coeffs", [False, True])
+def test_legacy_appearance_branch_matches_oracle_and_trains(sh_coeffs):
+    """using_neural_textures=False (config C3's branch, volsurfs.py:208-300, 548-580): per-shell
+    RGB / ColorSH models on hit points, dirs, normals.  Checked against the oracle's
+    restatement (hash grid + MLP on torch-CPU + oracle composite) from the same hits."""
+    from oracle import composite as OC
+    from oracle import legacy_models as OL
+    from oracle import tcnn_like
+    from oracle.neural_texture import sh_basis_values, sh_eval
+    from volsurfs_amd.camera import pinhole_rays
+    from volsurfs_amd.mesh import nested_shells
+    from volsurfs_amd.methods import VolSurfs
+    K = 2
+    m = VolSurfs(nested_shells(K=K, subdiv=3), max_rays=4096, using_neural_textures=False,
+                 appearance_predict_sh_coeffs=sh_coeffs, rgb_normal_dep=not sh_coeffs,
+                 rgb_mlp_layers_dims=(64, 32), bb_sides=1.0, sh_degree=3)
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for mod in m.models.values():
+            p = mod.pos_encoder.encoder.params
+            p.copy_((torch.rand(p.shape, generator=g) * 2 - 1).cuda())
+    o, d = pinhole_rays(40, 40, focal=70.0)
+    res = m.render_rays(o, d, iter_nr=None)
+    rt = res["renders"]["ray_traced"]
+    assert rt["surfs_uvs"] is None and torch.isfinite(rt["rgb"]).all()
+    # ---- oracle from the same hits
+    hit_t, hit_slot, _ = m.raytracer.trace_all(o, d)
+    N = o.shape[0]
+    geom = tcnn_like.GridGeometryND(3, 24, 18, 16, 2)
+    s_rgb, s_a = torch.zeros(N, K, 3), torch.zeros(N, K)
+    for i in range(K):
+        hits = (hit_slot[i] >= 0).cpu()
+        tri = m.raytracer.tris[hit_slot[i][hit_slot[i] >= 0].long()].cpu()
+        nrm = torch.nn.functional.normalize(torch.cross(tri[:, 4:7], tri[:, 8:11], dim=1), dim=1)
+        dd = d.cpu()[hits]
+        pts = o.cpu()[hits] + hit_t[i].cpu()[hits][:, None] * dd
+        outs = []
+        for key in (f"rgb_{i}", f"alpha_{i}"):
+            mod = m.models[key]
+            layers = [(l.weight.detach().cpu(), l.bias.detach().cpu()) for l in mod.mlp.layers
+                      if isinstance(l, torch.nn.Linear)]
+            table = mod.pos_encoder.encoder.params.detach().cpu()
+            if sh_coeffs:       # ColorSH: the encoder gets no bounding box (color_sh.py:62-69)
+                feats = OL.gridhash_encode(geom, table, pts, None)
+                coeffs = OL.mlp_forward(layers, feats).reshape(pts.shape[0], -1, 16)
+                outs.append(torch.sigmoid(sh_eval(coeffs, dd, 3)))
+            else:
+                bb = torch.tensor([1.0, 1.0, 1.0])
+                nrm_in = nrm if mod.normal_dep else None
+                outs.append(OL.rgb_forward(geom, table, layers, pts, dd, nrm_in, bb, 3))
+        dot = torch.sum(-dd * nrm, dim=1).clamp(0.0, 1.0)
+        s_rgb[hits, i] = outs[0]
+        s_a[hits, i] = outs[1][:, 0] * (torch.sigmoid(10.0 * dot) * 2.0 - 1.0)
+    ref = OC.composite_dense_fwd(s_rgb.numpy(), s_a.numpy(), np.ones((1, 3), np.float32))
+    ref_rgb = ref["rgb"] if isinstance(ref, dict) else ref[0]
+    err = np.abs(rt["rgb"].detach().cpu().numpy() - np.asarray(ref_rgb))
+    assert err.max() < 2e-3 and np.median(err) < 1e-4, (err.max(), np.median(err))   # fp16 composite
+    # ---- trains
+    opt = m.init_optim()
+    gt = torch.rand(N, 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)) * 0.2
+    losses = []
+    for it in range(8):
+        opt.zero_grad()
+        l, _, _ = m(o, d, gt, None, it)
+        l["loss"].backward()
+        m.optim_step()
+        losses.append(l["loss"].item())
+    assert losses[-1] < losses[0], losses

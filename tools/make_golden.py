@@ -266,7 +266,91 @@ def gen_glue():
           pred=pred.detach().numpy(), g_density=density.grad.numpy(), g_rgb=rgb.grad.numpy())
 
 
-GENS = {"composite": gen_composite, "nt": gen_nt, "glue": gen_glue}
+# --------------------------------------------------------------------------
+# 4. Legacy appearance branch + background field: the reference's own MLP, RGB, ColorSH and
+#    NerfHash classes (models/{mlp,rgb,color_sh,nerfhash}.py) and GridHashEncoder
+#    (encodings/gridhash.py), with oracle.tcnn_like.GridEncoding standing in for the absent
+#    tinycudann grid and the restated Coarse2Fine for permutohedral_encoding's.  The classes
+#    hard-code .to("cuda") for their bounding boxes; that one call is redirected to the CPU.
+# --------------------------------------------------------------------------
+def gen_legacy():
+    from oracle import tcnn_like
+
+    class _C2F:
+        def __init__(self, n):
+            self.n = n
+
+        def __call__(self, t):
+            import math
+            a = float(t) * self.n
+            i = torch.arange(self.n, dtype=torch.float32)
+            return 0.5 * (1.0 - torch.cos(math.pi * torch.clamp(a - i, 0.0, 1.0)))
+
+    ref_import.install_placeholders({
+        "tinycudann": {"Encoding": tcnn_like.GridEncoding},
+        "permutohedral_encoding": {"Coarse2Fine": _C2F},
+    })
+    orig_to = torch.Tensor.to
+
+    def to_cpu(self, *a, **k):
+        a = tuple("cpu" if (isinstance(x, str) and x.startswith("cuda")) else x for x in a)
+        return orig_to(self, *a, **k)
+    torch.Tensor.to = to_cpu
+    try:
+        from volsurfs_py.models.nerfhash import NerfHash
+        from volsurfs_py.models.rgb import RGB
+        from volsurfs_py.models.color_sh import ColorSH
+        torch.manual_seed(5)
+        g = torch.Generator().manual_seed(6)
+        arrs = {}
+
+        def dump(prefix, model):     # the 48 MB hash tables are re-created from the seed by the test
+            for k, v in model.state_dict().items():
+                if not k.endswith("encoder.params"):
+                    arrs[f"{prefix}/{k}"] = v.detach().numpy()
+
+        def spread(model):     # visible structure instead of U(-1e-4, 1e-4)
+            with torch.no_grad():
+                model.pos_encoder.encoder.params.copy_(
+                    torch.rand(model.pos_encoder.encoder.params.shape, generator=g) * 2 - 1)
+
+        M = 96
+        pts = (torch.rand(M, 3, generator=g) * 2 - 1) * 0.9
+        dirs = torch.nn.functional.normalize(torch.randn(M, 3, generator=g), dim=-1)
+        nrm = torch.nn.functional.normalize(torch.randn(M, 3, generator=g), dim=-1)
+        arrs.update(points=pts.numpy(), dirs=dirs.numpy(), normals=nrm.numpy())
+
+        nh = NerfHash(3, "gridhash", "spherical_harmonics")
+        spread(nh)
+        rgb, dens = nh(pts, dirs, iter_nr=None)
+        dump("nerfhash", nh)
+        arrs.update(nerfhash_rgb=rgb.detach().numpy(), nerfhash_density=dens.detach().numpy())
+        loss = (rgb * torch.linspace(0.5, 1.5, 3)).sum() + 0.3 * dens.sum()
+        loss.backward()
+        gt = nh.pos_encoder.encoder.params.grad
+        nz = torch.nonzero(gt.abs().sum(1)).flatten()
+        arrs["nerfhash_grad/table_idx"] = nz.numpy()
+        arrs["nerfhash_grad/table_val"] = gt[nz].numpy()
+        arrs["nerfhash_grad/mlp_rgb0"] = nh.mlp_rgb.layers[0].weight.grad.numpy()
+
+        m = RGB(3, [128, 128, 64], "gridhash", "spherical_harmonics", sh_deg=3, normal_dep=True,
+                bb_sides=1.0)
+        spread(m)
+        out = m(points=pts * 0.5, samples_dirs=dirs, normals=nrm, iter_nr=None)
+        dump("rgb", m)
+        arrs["rgb_out"] = out.detach().numpy()
+
+        c = ColorSH(3, [128, 128, 64], "gridhash", sh_deg=3, bb_sides=1.0)
+        spread(c)
+        arrs["colorsh_out"] = c(pts * 0.45, samples_dirs=dirs).detach().numpy()
+        arrs["colorsh_coeffs"] = c(pts * 0.45).detach().numpy()
+        dump("colorsh", c)
+    finally:
+        torch.Tensor.to = orig_to
+    _save("legacy_models.npz", **arrs)
+
+
+GENS = {"composite": gen_composite, "nt": gen_nt, "glue": gen_glue, "legacy": gen_legacy}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(GENS)

@@ -1,0 +1,233 @@
+// 2-D / 3-D multiresolution hash-grid encoding with fp32 tables and fp32 output, and
+// the SH direction encoding (the legacy appearance branch's
+// GridHashEncoder, encodings/gridhash.py:12-92, and NerfHash's position / direction
+// encoders, models/nerfhash.py:26-38).
+//
+// The reference gets the grid from tinycudann (absent: tcnn.Encoding(input_dim, {"otype":
+// "Grid", "type": "Hash", 24 levels, 2 features, 2^18 entries, base 16, growth 2, linear
+// interpolation}, dtype=float32)); this follows the published tiny-cuda-nn definition
+// restated in oracle/tcnn_like.py (grid_forward_f32).  Unlike the 2-D texture grids of
+// nt_encode.hip (2^15 entries: a level fits the LDS), a level here is 2 MiB of fp32, so
+// the tables are gathered from L2 / the 256 MiB MALL (24 levels = 48 MiB): one thread per
+// (sample, level), 2^D float2 gathers, D-linear weights formed in the oracle's order.
+#include "common.h"
+
+namespace {
+
+constexpr unsigned GRID_PRIMES[3] = {1u, 2654435761u, 805459861u};
+
+struct GridLevel {
+  float scale;
+  unsigned res, size, offset;
+};
+
+__device__ __forceinline__ GridLevel grid_level(const vsa_grid_plan& p, int l) {
+  GridLevel g;
+  g.scale = p.level_scale[l];
+  g.res = (unsigned)p.level_res[l];
+  g.size = (unsigned)p.level_size[l];
+  g.offset = (unsigned)p.level_offset[l];
+  return g;
+}
+
+// tiny-cuda-nn grid_index: dense strides while they fit the level, otherwise the XOR-prime hash
+template <int D>
+__device__ __forceinline__ unsigned grid_index(const GridLevel& g, const unsigned c[D]) {
+  unsigned stride = 1, index = 0;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    if (stride <= g.size) {
+      index += c[d] * stride;
+      stride *= g.res;
+    }
+  }
+  if (g.size < stride) {
+    index = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) index ^= c[d] * GRID_PRIMES[d];
+  }
+  return index % g.size;
+}
+
+template <int D>
+struct GridCell {
+  unsigned c[D];
+  float f[D];
+};
+
+template <int D>
+__device__ __forceinline__ GridCell<D> grid_cell(const GridLevel& g, const float* __restrict__ x) {
+  GridCell<D> r;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const float pos = x[d] * g.scale + 0.5f;
+    const float fl = floorf(pos);
+    r.f[d] = pos - fl;
+    r.c[d] = (unsigned)(int)fl;
+  }
+  return r;
+}
+
+// corner weight in the oracle's order: ((w_0 * w_1) * w_2), w_d = f_d or 1 - f_d
+template <int D>
+__device__ __forceinline__ float corner_weight(const GridCell<D>& cell, int corner) {
+  float w = 1.0f;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const float wd = ((corner >> d) & 1) ? cell.f[d] : 1.0f - cell.f[d];
+    w = d == 0 ? wd : w * wd;
+  }
+  return w;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void grid_encode_fwd_kernel(vsa_grid_plan plan,
+                                                              const float2* __restrict__ tables,
+                                                              const float* __restrict__ x, int B,
+                                                              float2* __restrict__ out) {
+  const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int l = blockIdx.y;
+  if (b >= B) return;
+  const GridLevel g = grid_level(plan, l);
+  const GridCell<D> cell = grid_cell<D>(g, x + b * D);
+  float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+  for (int corner = 0; corner < (1 << D); ++corner) {
+    unsigned c[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) c[d] = cell.c[d] + ((corner >> d) & 1);
+    const float w = corner_weight<D>(cell, corner);
+    const float2 v = tables[g.offset + grid_index<D>(g, c)];
+    f0 = f0 + w * v.x;
+    f1 = f1 + w * v.y;
+  }
+  out[b * plan.n_levels + l] = make_float2(f0, f1);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void grid_encode_bwd_kernel(vsa_grid_plan plan,
+                                                              const float* __restrict__ x,
+                                                              const float2* __restrict__ g_out,
+                                                              int B, float* __restrict__ g_tables) {
+  const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int l = blockIdx.y;
+  if (b >= B) return;
+  const float2 go = g_out[b * plan.n_levels + l];
+  if (go.x == 0.f && go.y == 0.f) return;
+  const GridLevel g = grid_level(plan, l);
+  const GridCell<D> cell = grid_cell<D>(g, x + b * D);
+#pragma unroll
+  for (int corner = 0; corner < (1 << D); ++corner) {
+    unsigned c[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) c[d] = cell.c[d] + ((corner >> d) & 1);
+    const float w = corner_weight<D>(cell, corner);
+    float* dst = g_tables + 2 * (long long)(g.offset + grid_index<D>(g, c));
+    atomicAdd(dst, w * go.x);
+    atomicAdd(dst + 1, w * go.y);
+  }
+}
+
+// SHEncoder.__call__ (encodings/sphericalharmonics.py:84-153): the SH basis of a direction,
+// degree 0..4, fp32, products formed left to right as the reference writes them.
+__global__ void sh_encode_kernel(const float* __restrict__ dirs, int B, int degree,
+                                 float* __restrict__ out) {
+  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float x = dirs[3 * b], y = dirs[3 * b + 1], z = dirs[3 * b + 2];
+  const int n = (degree + 1) * (degree + 1);
+  float r[25];
+  r[0] = 0.28209479177387814f;
+  if (degree > 0) {
+    const float C1 = 0.4886025119029199f;
+    r[1] = -C1 * y;
+    r[2] = C1 * z;
+    r[3] = -C1 * x;
+    if (degree > 1) {
+      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      r[4] = 1.0925484305920792f * xy;
+      r[5] = -1.0925484305920792f * yz;
+      r[6] = 0.31539156525252005f * ((2.0f * zz - xx) - yy);
+      r[7] = -1.0925484305920792f * xz;
+      r[8] = 0.5462742152960396f * (xx - yy);
+      if (degree > 2) {
+        r[9] = (-0.5900435899266435f * y) * (3.0f * xx - yy);
+        r[10] = (2.890611442640554f * xy) * z;
+        r[11] = (-0.4570457994644658f * y) * ((4.0f * zz - xx) - yy);
+        r[12] = (0.3731763325901154f * z) * ((2.0f * zz - 3.0f * xx) - 3.0f * yy);
+        r[13] = (-0.4570457994644658f * x) * ((4.0f * zz - xx) - yy);
+        r[14] = (1.445305721320277f * z) * (xx - yy);
+        r[15] = (-0.5900435899266435f * x) * (xx - 3.0f * yy);
+        if (degree > 3) {
+          r[16] = (2.5033429417967046f * xy) * (xx - yy);
+          r[17] = (-1.7701307697799304f * yz) * (3.0f * xx - yy);
+          r[18] = (0.9461746957575601f * xy) * (7.0f * zz - 1.0f);
+          r[19] = (-0.6690465435572892f * yz) * (7.0f * zz - 3.0f);
+          r[20] = 0.10578554691520431f * (zz * (35.0f * zz - 30.0f) + 3.0f);
+          r[21] = (-0.6690465435572892f * xz) * (7.0f * zz - 3.0f);
+          r[22] = (0.47308734787878004f * (xx - yy)) * (7.0f * zz - 1.0f);
+          r[23] = (-1.7701307697799304f * xz) * (xx - 3.0f * yy);
+          r[24] = 0.6258357354491761f * (xx * (xx - 3.0f * yy) - yy * (3.0f * xx - yy));
+        }
+      }
+    }
+  }
+  for (int i = 0; i < n; ++i) out[b * n + i] = r[i];
+}
+
+int plan_ok(const vsa_grid_plan* p) {
+  if (!p) return VSA_ERR_ARG;
+  if (p->n_dims != 2 && p->n_dims != 3) return VSA_ERR_UNSUPPORTED;
+  if (p->n_features != 2) return VSA_ERR_UNSUPPORTED;
+  if (p->n_levels < 1 || p->n_levels > VSA_GRID_MAX_LEVELS) return VSA_ERR_ARG;
+  for (int l = 0; l < p->n_levels; ++l)
+    if (p->level_size[l] < 1 || p->level_res[l] < 1) return VSA_ERR_ARG;
+  return VSA_OK;
+}
+
+}  // namespace
+
+extern "C" int vsa_grid_encode_fwd(const vsa_grid_plan* plan, const float* tables, const float* x,
+                                   int nr_points, float* out, void* stream) {
+  int rc = plan_ok(plan);
+  if (rc) return rc;
+  if (nr_points < 0) return VSA_ERR_ARG;
+  if (nr_points == 0) return VSA_OK;
+  if (!tables || !x || !out) return VSA_ERR_ARG;
+  dim3 grid(vsa_div_up(nr_points, 256), plan->n_levels);
+  if (plan->n_dims == 2)
+    hipLaunchKernelGGL(grid_encode_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, *plan,
+                       reinterpret_cast<const float2*>(tables), x, nr_points,
+                       reinterpret_cast<float2*>(out));
+  else
+    hipLaunchKernelGGL(grid_encode_fwd_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, *plan,
+                       reinterpret_cast<const float2*>(tables), x, nr_points,
+                       reinterpret_cast<float2*>(out));
+  VSA_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int vsa_grid_encode_bwd(const vsa_grid_plan* plan, const float* x, const float* g_out,
+                                   int nr_points, float* grad_tables, void* stream) {
+  int rc = plan_ok(plan);
+  if (rc) return rc;
+  if (nr_points < 0) return VSA_ERR_ARG;
+  if (nr_points == 0) return VSA_OK;
+  if (!x || !g_out || !grad_tables) return VSA_ERR_ARG;
+  dim3 grid(vsa_div_up(nr_points, 256), plan->n_levels);
+  if (plan->n_dims == 2)
+    hipLaunchKernelGGL(grid_encode_bwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, *plan, x,
+                       reinterpret_cast<const float2*>(g_out), nr_points, grad_tables);
+  else
+    hipLaunchKernelGGL(grid_encode_bwd_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, *plan, x,
+                       reinterpret_cast<const float2*>(g_out), nr_points, grad_tables);
+  VSA_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int vsa_sh_encode(const float* dirs, int nr_dirs, int degree, float* out, void* stream) {
+  if (nr_dirs < 0 || degree < 0 || degree > 4) return VSA_ERR_ARG;
+  if (nr_dirs == 0) return VSA_OK;
+  if (!dirs || !out) return VSA_ERR_ARG;
+  hipLaunchKernelGGL(sh_encode_kernel, dim3(vsa_div_up(nr_dirs, 256)), dim3(256), 0,
+                     (hipStream_t)stream, dirs, nr_dirs, degree, out);
+  VSA_RETURN_LAUNCH_STATUS();
+}

@@ -55,8 +55,15 @@ class VolSurfs(torch.nn.Module):
     def __init__(self, tensor_meshes, max_rays=16384, sh_degree=3, transp_view_dep=True,
                  sh_range=(15, 15, 15, 15), textures_res=(2048, 1024, 512, 256),
                  is_inner_mesh_solid=False, with_alpha_decay=True, bg_color=(1.0, 1.0, 1.0),
-                 bg_model=None, bounding_primitive=None, nr_samples_bg=32, lr=1e-3, seed=42):
+                 bg_model=None, bounding_primitive=None, nr_samples_bg=32, lr=1e-3, seed=42,
+                 using_neural_textures=True, appearance_predict_sh_coeffs=False,
+                 rgb_mlp_layers_dims=(128, 128, 64), rgb_pos_encoder_type="gridhash",
+                 rgb_dir_encoder_type="spherical_harmonics", rgb_view_dep=True,
+                 rgb_normal_dep=False, transp_normal_dep=False, rgb_nr_iters_for_c2f=0,
+                 are_volsurfs_colors_indep=True, are_volsurfs_alphas_indep=True, bb_sides=2.0):
         super().__init__()
+        self.using_neural_textures = using_neural_textures
+        self.with_alpha_decay = with_alpha_decay
         self.tensor_meshes = tensor_meshes
         self.nr_meshes = len(tensor_meshes)
         dev = tensor_meshes[0].vertices.device
@@ -66,11 +73,44 @@ class VolSurfs(torch.nn.Module):
             ids = self.raytracer.slot_face_id[off:off + n].long()
             fu.append(m.get_faces_uvs().reshape(-1, 6)[ids])
         self.face_uvs = torch.cat(fu, 0).contiguous()
-        self.bank = NeuralTextureBank(self.nr_meshes, max_rays, sh_degree=sh_degree,
-                                      alpha_sh_degree=sh_degree if transp_view_dep else 0,
-                                      sh_range=sh_range, textures_res=textures_res,
-                                      inner_solid=is_inner_mesh_solid,
-                                      with_alpha_decay=with_alpha_decay, device=dev, seed=seed)
+        self.bank, self.models = None, torch.nn.ModuleDict()
+        if using_neural_textures:
+            self.bank = NeuralTextureBank(self.nr_meshes, max_rays, sh_degree=sh_degree,
+                                          alpha_sh_degree=sh_degree if transp_view_dep else 0,
+                                          sh_range=sh_range, textures_res=textures_res,
+                                          inner_solid=is_inner_mesh_solid,
+                                          with_alpha_decay=with_alpha_decay, device=dev, seed=seed)
+        else:
+            # legacy appearance branch (volsurfs.py:208-300): one RGB / ColorSH per shell (or one
+            # for all shells), alpha model None for a solid inner mesh
+            from .models import ColorSH, RGB
+
+            def make(out_channels, view_dep, normal_dep):
+                if appearance_predict_sh_coeffs:
+                    return ColorSH(in_channels=3, out_channels=out_channels,
+                                   mlp_layers_dims=list(rgb_mlp_layers_dims),
+                                   pos_encoder_type=rgb_pos_encoder_type, sh_deg=sh_degree,
+                                   normal_dep=normal_dep, nr_iters_for_c2f=rgb_nr_iters_for_c2f,
+                                   bb_sides=bb_sides, device=dev)
+                return RGB(in_channels=3, out_channels=out_channels,
+                           mlp_layers_dims=list(rgb_mlp_layers_dims),
+                           pos_encoder_type=rgb_pos_encoder_type,
+                           dir_encoder_type=rgb_dir_encoder_type, sh_deg=sh_degree,
+                           view_dep=view_dep, normal_dep=normal_dep,
+                           nr_iters_for_c2f=rgb_nr_iters_for_c2f, bb_sides=bb_sides, device=dev)
+            for i in range(self.nr_meshes):
+                self.models[f"rgb_{i}" if are_volsurfs_colors_indep else "rgb"] = \
+                    make(3, rgb_view_dep, rgb_normal_dep)
+                if not are_volsurfs_colors_indep:
+                    break
+            self.solid_inner = is_inner_mesh_solid
+            for i in range(self.nr_meshes):
+                key = f"alpha_{i}" if are_volsurfs_alphas_indep else "alpha"
+                if not (is_inner_mesh_solid and i == 0):
+                    self.models[key] = make(1, transp_view_dep, transp_normal_dep)
+                if not are_volsurfs_alphas_indep:
+                    break
+            self.colors_indep, self.alphas_indep = are_volsurfs_colors_indep, are_volsurfs_alphas_indep
         self.max_rays = max_rays
         # volsurfs.py:686-702: constant colour, or (bg_color None) a learned contracted
         # background model rendered through the packed ops (utils/background.py)
@@ -87,13 +127,52 @@ class VolSurfs(torch.nn.Module):
     # -- optimiser: apex FusedAdam(betas (0.9, 0.99), eps 1e-15, wd 0) of
     # base_method.py:87-94 == Adam with the same hyper-parameters
     def init_optim(self):
-        self.optimizer = torch.optim.Adam([self.bank.tables, self.bank.weights], lr=self.lr,
-                                          betas=(0.9, 0.99), eps=1e-15, weight_decay=0.0, fused=True)
+        params = [self.bank.tables, self.bank.weights] if self.bank is not None else \
+            list(self.models.parameters())
+        if isinstance(self.bg_model, torch.nn.Module):
+            params += list(self.bg_model.parameters())
+        self.optimizer = torch.optim.Adam(params, lr=self.lr, betas=(0.9, 0.99), eps=1e-15,
+                                          weight_decay=0.0, fused=True)
         return self.optimizer
 
     def optim_step(self):
         self.optimizer.step()
-        self.bank.refresh_half_params()
+        if self.bank is not None:
+            self.bank.refresh_half_params()
+
+    def _shade_legacy(self, rays_o, rays_d, hit_t, hit_slot, iter_nr):
+        """volsurfs.py:486-599, legacy branch: per shell, the hit points / view directions /
+        face normals go through that shell's RGB (or ColorSH) models; alpha decay; dense scatter."""
+        N, K = rays_o.shape[0], self.nr_meshes
+        dev = rays_o.device
+        surfs_rgb = torch.zeros(N, K, 3, device=dev)
+        surfs_alpha = torch.zeros(N, K, device=dev)
+        surfs_normals = torch.zeros(N, K, 3, device=dev)
+        for i in range(K):
+            hits = hit_slot[i] >= 0
+            if not bool(hits.any()):            # volsurfs.py:481 (the reference's host sync)
+                continue
+            slots = hit_slot[i][hits].long()
+            tri = self.raytracer.tris[slots]                                    # [M,12]: v0+id, e1, e2
+            nrm = torch.nn.functional.normalize(torch.cross(tri[:, 4:7], tri[:, 8:11], dim=1), dim=1)
+            d = rays_d[hits]
+            pts = rays_o[hits] + hit_t[i][hits][:, None] * d
+            m_rgb = self.models[f"rgb_{i}" if self.colors_indep else "rgb"]
+            pred = m_rgb(points=pts, samples_dirs=d, normals=nrm, iter_nr=iter_nr)
+            surfs_rgb[hits, i] = pred[:, :3]
+            key = f"alpha_{i}" if self.alphas_indep else "alpha"
+            if key not in self.models or (self.solid_inner and i == 0):
+                a = torch.ones(pts.shape[0], device=dev)
+            else:
+                a = self.models[key](points=pts, samples_dirs=d, normals=nrm, iter_nr=iter_nr)[:, 0]
+                if self.with_alpha_decay:
+                    with torch.no_grad():
+                        dot = torch.sum(-d * nrm, dim=1).clamp(0.0, 1.0)
+                        decay = torch.sigmoid(10.0 * dot) * 2.0 - 1.0
+                    a = a * decay
+            surfs_alpha[hits, i] = a
+            surfs_normals[hits, i] = nrm
+        return surfs_rgb, surfs_alpha, surfs_normals
 
     def render_rays(self, rays_o, rays_d, iter_nr=None, return_samples=True, **kwargs):
         """volsurfs.py:423-761: returns {"renders": {"ray_traced": {...}}, "samples_3d",
@@ -103,8 +182,12 @@ class VolSurfs(torch.nn.Module):
             raise _lib.VolsurfsHipError(f"{N} rays > max_rays={self.max_rays}; use render()")
         rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
         hit_t, hit_slot, hit_uv = self.raytracer.trace_all(rays_o, rays_d)     # :476-485, one launch
-        rgb_k, alpha_k, normals, tex_uv = _ShadeStage.apply(self.bank.tables, self.bank.weights,
-                                                            self, hit_slot, hit_uv, rays_d)
+        if self.using_neural_textures:
+            rgb_k, alpha_k, normals, tex_uv = _ShadeStage.apply(self.bank.tables, self.bank.weights,
+                                                                self, hit_slot, hit_uv, rays_d)
+        else:
+            rgb_k, alpha_k, normals = self._shade_legacy(rays_o, rays_d, hit_t, hit_slot, iter_nr)
+            tex_uv = None
         if self.bg_color is not None:
             rgb_bg = self.bg_color
         else:
@@ -118,7 +201,7 @@ class VolSurfs(torch.nn.Module):
             "surfs_alpha": out["surfs_alpha"], "surfs_rgb": out["surfs_rgb"],
             "surfs_normals": normals, "surfs_blending_weights": out["surfs_blending_weights"],
             "bg_transmittance": out["bg_transmittance"],
-            "surfs_uvs": tex_uv.permute(1, 0, 2).contiguous(),                # [N,K,2], :509-516
+            "surfs_uvs": None if tex_uv is None else tex_uv.permute(1, 0, 2).contiguous(),  # [N,K,2], :509-516
         }
         res = {"renders": {"ray_traced": renders}, "samples_3d": None, "samples_grad": None}
         if return_samples:       # :713-716 (boolean compaction = a host sync, as in the reference)

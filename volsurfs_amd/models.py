@@ -1,0 +1,205 @@
+"""Models of the legacy appearance branch and the background field (SURVEY §8a rows A5,
+A10): `MLP`, `RGB`, `ColorSH`, `NerfHash` with the reference's constructor arguments,
+forward signatures and module layout (`mlp.layers.<i>.weight/bias` state-dict keys match
+/root/reference/volsurfs_py/models/{mlp,rgb,color_sh,nerfhash}.py, so the reference's
+checkpoints load).
+
+The encoders run on the HIP kernels of csrc/grid_encode.hip (volsurfs_amd/encodings.py).
+The MLPs are the reference's own op sequence — fp32 `torch.nn.Linear` (+bias) and exact
+GELU — i.e. plain library GEMMs (rocBLAS/hipBLASLt through torch), which is where the
+prompt's MI355X rules put un-fused fp32 GEMMs; they are not on the headline path
+(neural-texture shading never calls them).
+"""
+import copy
+
+import numpy as np
+import torch
+
+from .encodings import SHEncoder, get_encoder
+from .neural_textures import MAX_DEG  # noqa: F401  (re-exported for symmetry)
+
+
+class MLP(torch.nn.Module):
+    """models/mlp.py:8-69: Linear + GELU stack, optional linear last layer."""
+
+    def __init__(self, in_channels, nr_out_channels_per_layer, last_layer_linear, bias=True):
+        super().__init__()
+        self.last_layer_linear = last_layer_linear
+        self.in_channels = in_channels
+        self.nr_out_channels_per_layer = nr_out_channels_per_layer
+        self.bias = bias
+        in_channels_ = in_channels
+        modules = []
+        for i, cur in enumerate(nr_out_channels_per_layer):
+            modules.append(torch.nn.Linear(in_channels_, cur, bias=bias))
+            is_last = i == len(nr_out_channels_per_layer) - 1
+            if is_last and last_layer_linear:
+                continue
+            modules.append(torch.nn.GELU())
+            in_channels_ = cur
+        self.layers = torch.nn.Sequential(*modules)
+
+    def forward(self, x):
+        return self.layers(x)
+
+    def reset(self):
+        for layer in self.layers:
+            if isinstance(layer, torch.nn.Linear):
+                layer.reset_parameters()
+
+
+def _bb_sides(bb_sides, in_channels, device):
+    if isinstance(bb_sides, float):
+        bb_sides = np.array([bb_sides] * in_channels)
+    if isinstance(bb_sides, np.ndarray):
+        bb_sides = torch.tensor(bb_sides, dtype=torch.float32)
+    return bb_sides.to(device) if bb_sides is not None else None
+
+
+class RGB(torch.nn.Module):
+    """models/rgb.py:13-149 (use_lipshitz_mlp is not built: raises)."""
+
+    def __init__(self, in_channels, mlp_layers_dims, pos_encoder_type, dir_encoder_type,
+                 out_channels=3, pos_dep=True, view_dep=True, geom_feat_dep=False,
+                 normal_dep=False, sh_deg=5, in_geom_feat_size=32, nr_iters_for_c2f=0,
+                 use_lipshitz_mlp=False, bb_sides=2.0, device="cuda"):
+        super().__init__()
+        assert (pos_dep and in_channels > 0) or (not pos_dep and in_channels == 0), \
+            "pos_dep and in_channels must be consistent"
+        if use_lipshitz_mlp:
+            raise NotImplementedError("LipshitzMLP (models/lipshitz_mlp.py) is outside SURVEY §8")
+        self.in_channels = in_channels
+        self.mlp_layers_dims = copy.deepcopy(mlp_layers_dims)
+        self.out_channels = out_channels
+        self.pos_encoder_type, self.dir_encoder_type = pos_encoder_type, dir_encoder_type
+        self.sh_deg = sh_deg
+        self.pos_dep, self.view_dep = pos_dep, view_dep
+        self.normal_dep, self.geom_feat_dep = normal_dep, geom_feat_dep
+        self.in_geom_feat_size = in_geom_feat_size
+        self.bb_sides = _bb_sides(bb_sides, in_channels, device)
+        mlp_in = 0
+        if pos_dep:
+            self.pos_encoder = get_encoder(pos_encoder_type, input_dim=in_channels, nr_levels=24,
+                                           nr_iters_for_c2f=nr_iters_for_c2f, multires=6,
+                                           bb_sides=self.bb_sides)
+            mlp_in += self.pos_encoder.output_dim
+        if view_dep:
+            self.dir_encoder = get_encoder(dir_encoder_type, input_dim=3, degree=sh_deg)
+            mlp_in += self.dir_encoder.output_dim
+        if normal_dep:
+            mlp_in += 3
+        if geom_feat_dep:
+            mlp_in += in_geom_feat_size
+        self.mlp = MLP(mlp_in, self.mlp_layers_dims + [out_channels], last_layer_linear=True).to(device)
+        self.sigmoid = torch.nn.Sigmoid()
+
+    def forward(self, points=None, samples_dirs=None, normals=None, iter_nr=None, geom_feat=None):
+        parts = []
+        if self.pos_dep:
+            feats = self.pos_encoder(points, iter_nr=iter_nr)
+            parts.append(feats[0] if isinstance(feats, tuple) else feats)
+        if self.view_dep:
+            with torch.no_grad():
+                parts.append(self.dir_encoder(samples_dirs, iter_nr=iter_nr))
+        if self.normal_dep:
+            parts.append(normals)
+        if self.geom_feat_dep and self.in_geom_feat_size > 0:
+            if geom_feat is None:
+                raise ValueError("geom_feat is required")     # the reference prints and exit(1)s
+            parts.append(geom_feat)
+        return self.sigmoid(self.mlp(torch.cat(parts, 1)))
+
+
+def sh_eval(sh, dirs, degree):
+    """SHEncoder.eval (encodings/sphericalharmonics.py:155-229): sh [M, C, (deg+1)^2],
+    dirs [M, 3] -> [M, C]; band 0 first, then the basis-weighted sum in index order."""
+    basis = SHEncoder(3, degree)(dirs)                     # [M, n]
+    result = basis[:, None, 0] * sh[..., 0]
+    for i in range(1, (degree + 1) ** 2):
+        result = result + basis[:, None, i] * sh[..., i]
+    return result
+
+
+class ColorSH(torch.nn.Module):
+    """models/color_sh.py:15-143: position -> SH coefficients -> view-dependent colour."""
+
+    def __init__(self, in_channels, mlp_layers_dims, pos_encoder_type, out_channels=3, sh_deg=3,
+                 geom_feat_dep=False, normal_dep=False, in_geom_feat_size=0, nr_iters_for_c2f=0,
+                 bb_sides=2.0, device="cuda"):
+        super().__init__()
+        self.in_channels, self.sh_deg = in_channels, sh_deg
+        self.mlp_layers_dims = copy.deepcopy(mlp_layers_dims)
+        self.nr_coeffs = (sh_deg + 1) ** 2
+        self.color_channels = out_channels
+        self.out_channels = self.nr_coeffs * out_channels
+        self.pos_encoder_type = pos_encoder_type
+        self.pos_dep, self.normal_dep, self.geom_feat_dep = True, normal_dep, geom_feat_dep
+        self.in_geom_feat_size = in_geom_feat_size
+        self.bb_sides = _bb_sides(bb_sides, in_channels, device)
+        # the reference passes `points_scaling=` here, which get_encoder ignores: bb_sides=None
+        self.pos_encoder = get_encoder(pos_encoder_type, input_dim=in_channels, nr_levels=24,
+                                       nr_iters_for_c2f=nr_iters_for_c2f, multires=6)
+        mlp_in = self.pos_encoder.output_dim + (3 if normal_dep else 0) + \
+            (in_geom_feat_size if geom_feat_dep else 0)
+        self.mlp = MLP(mlp_in, self.mlp_layers_dims + [self.out_channels], last_layer_linear=True).to(device)
+        self.sigmoid = torch.nn.Sigmoid()
+
+    def forward(self, points, samples_dirs=None, normals=None, geom_feat=None, iter_nr=None):
+        feats = self.pos_encoder(points, iter_nr=iter_nr)
+        data = feats[0] if isinstance(feats, tuple) else feats
+        if self.normal_dep:
+            if normals is None:
+                raise ValueError("normals are required for normal dependent model")
+            data = torch.cat([data, normals], 1)
+        if self.geom_feat_dep and self.in_geom_feat_size > 0:
+            if geom_feat is None:
+                raise ValueError("geom_feat is required")
+            data = torch.cat([data, geom_feat], 1)
+        pred = self.mlp(data)
+        if samples_dirs is None:
+            return pred
+        sh = pred.reshape(-1, self.color_channels, self.nr_coeffs)
+        return self.sigmoid(sh_eval(sh, samples_dirs, self.sh_deg))
+
+
+class NerfHash(torch.nn.Module):
+    """models/nerfhash.py:11-91: the background radiance field render_contracted_bg evaluates
+    at 32 contracted samples per ray (utils/background.py:72-80)."""
+
+    def __init__(self, in_channels, pos_encoder_type, dir_encoder_type, nr_iters_for_c2f=0,
+                 device="cuda"):
+        super().__init__()
+        self.in_channels = in_channels
+        self.pos_encoder_type, self.dir_encoder_type = pos_encoder_type, dir_encoder_type
+        self.pos_encoder = get_encoder(pos_encoder_type, input_dim=in_channels, nr_levels=24,
+                                       nr_iters_for_c2f=nr_iters_for_c2f, multires=6, bb_sides=2.0)
+        self.pos_encoder_output_dims = self.pos_encoder.output_dim
+        self.dir_encoder = get_encoder(dir_encoder_type, input_dim=3, degree=3)
+        self.dir_encoder_output_dims = self.dir_encoder.output_dim
+        self.nr_feat_for_rgb = 64
+        self.mlp_feat_and_density = MLP(self.pos_encoder_output_dims,
+                                        [64, 64, 64, self.nr_feat_for_rgb + 1],
+                                        last_layer_linear=True).to(device)
+        self.mlp_rgb = MLP(self.nr_feat_for_rgb + self.dir_encoder_output_dims, [64, 64, 3],
+                           last_layer_linear=True).to(device)
+        self.softplus, self.sigmoid, self.gelu = torch.nn.Softplus(), torch.nn.Sigmoid(), torch.nn.GELU()
+
+    def _features(self, points, iter_nr):
+        feats = self.pos_encoder(points, iter_nr=iter_nr)
+        return feats[0] if isinstance(feats, tuple) else feats
+
+    def forward(self, samples_3d, samples_dirs, iter_nr=None):
+        assert samples_3d.shape[1] == self.in_channels, "points should be N x in_channels"
+        point_features = self._features(samples_3d, iter_nr)
+        with torch.no_grad():
+            dirs_enc = self.dir_encoder(samples_dirs)
+        feat_and_density = self.mlp_feat_and_density(point_features)
+        density = feat_and_density[:, 0:1]
+        feat_rgb = feat_and_density[:, 1:self.nr_feat_for_rgb + 1]
+        rgb = self.mlp_rgb(torch.cat([self.gelu(feat_rgb), dirs_enc], 1))
+        return self.sigmoid(rgb), self.softplus(density)
+
+    def get_only_density(self, ray_samples, iter_nr=None):
+        points = ray_samples.view(-1, ray_samples.shape[-1])
+        feat_and_density = self.mlp_feat_and_density(self._features(points, iter_nr))
+        return self.softplus(feat_and_density[:, 0:1])

@@ -7,6 +7,7 @@ mesh_id=int) -> dict` as called at
 `trace_all` (all K shells in one launch, no host sync) used by the fused path.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -15,7 +16,7 @@ from . import _lib
 
 
 class RayTracer:
-    def __init__(self, tensor_meshes, leaf_size=4):
+    def __init__(self, tensor_meshes, leaf_size=None):
         self.nr_meshes = len(tensor_meshes)
         if not 1 <= self.nr_meshes <= 16:
             raise _lib.VolsurfsHipError("RayTracer supports 1..16 meshes")
@@ -25,6 +26,8 @@ class RayTracer:
         self.max_depth = 0
         node_base = tri_base = 0
         for m in tensor_meshes:
+            if leaf_size is None:
+                leaf_size = int(os.environ.get("VSA_LEAF_SIZE", "4"))
             v = np.ascontiguousarray(m.vertices.detach().cpu().numpy(), np.float32)
             f = np.ascontiguousarray(m.faces.detach().cpu().numpy(), np.int32)
             h = ctypes.c_void_p()
