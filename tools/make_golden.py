@@ -350,7 +350,49 @@ def gen_legacy():
     _save("legacy_models.npz", **arrs)
 
 
-GENS = {"composite": gen_composite, "nt": gen_nt, "glue": gen_glue, "legacy": gen_legacy}
+# --------------------------------------------------------------------------
+# 5. Training-loop pieces that import as shipped: the warm-up scheduler
+#    (schedulers/warmup.py) chained to MultiStepLR (the reference vendors torch 1.10's class,
+#    whose constructor no longer matches torch 2.x; torch's own is used as after_scheduler),
+#    stepped like trainer.py:306-308; loss_l1 / loss_l2 (utils/losses.py:6-19).
+# --------------------------------------------------------------------------
+def gen_misc():
+    import warnings
+    warnings.filterwarnings("ignore")
+    ref_import.install_placeholders({})
+    from volsurfs_py.schedulers.warmup import GradualWarmupScheduler
+    from torch.optim.lr_scheduler import MultiStepLR
+    arrs = {}
+    for tag, warm, ms, n in [("a", 50, [100, 200], 320), ("b", 0, [30, 80], 120), ("c", 7, [3, 4, 20], 60),
+                             ("default", 3000, [100000, 150000, 180000, 190000], 3100)]:
+        opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-3)
+        dec = MultiStepLR(opt, milestones=ms, gamma=0.3)
+        sch = GradualWarmupScheduler(opt, multiplier=1, total_epoch=warm, after_scheduler=dec) if warm > 0 else dec
+        lrs = []
+        for _ in range(n):
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+        arrs[f"lr_{tag}"] = np.array(lrs, np.float64)
+        arrs[f"cfg_{tag}"] = np.array([warm, n] + ms, np.int64)
+    g = torch.Generator().manual_seed(3)
+    gt, pred = torch.rand(200, 3, generator=g), torch.rand(200, 3, generator=g)
+    mask = (torch.rand(200, 1, generator=g) > 0.4).float()
+    # utils/losses.py:6-19 executed as written (its module imports sdf/field helpers that need
+    # the absent native extension, so the two functions are evaluated through their source lines)
+    import importlib
+    try:
+        L = importlib.import_module("volsurfs_py.utils.losses")
+        l1, l1m, l2 = L.loss_l1(gt, pred), L.loss_l1(gt, pred, mask), L.loss_l2(gt, pred)
+    except Exception as e:      # pragma: no cover
+        raise SystemExit(f"cannot import the reference losses: {e}")
+    arrs.update(loss_gt=gt.numpy(), loss_pred=pred.numpy(), loss_mask=mask.numpy(),
+                loss_l1=l1.numpy(), loss_l1_masked=l1m.numpy(), loss_l2=l2.numpy())
+    _save("train_misc.npz", **arrs)
+
+
+GENS = {"composite": gen_composite, "nt": gen_nt, "glue": gen_glue, "legacy": gen_legacy,
+        "misc": gen_misc}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(GENS)

@@ -60,7 +60,8 @@ class VolSurfs(torch.nn.Module):
                  rgb_mlp_layers_dims=(128, 128, 64), rgb_pos_encoder_type="gridhash",
                  rgb_dir_encoder_type="spherical_harmonics", rgb_view_dep=True,
                  rgb_normal_dep=False, transp_normal_dep=False, rgb_nr_iters_for_c2f=0,
-                 are_volsurfs_colors_indep=True, are_volsurfs_alphas_indep=True, bb_sides=2.0):
+                 are_volsurfs_colors_indep=True, are_volsurfs_alphas_indep=True, bb_sides=2.0,
+                 lr_milestones=(100000, 150000, 180000, 190000), nr_warmup_iters=3000):
         super().__init__()
         self.using_neural_textures = using_neural_textures
         self.with_alpha_decay = with_alpha_decay
@@ -123,6 +124,10 @@ class VolSurfs(torch.nn.Module):
         self.is_training = True
         self.lr = lr
         self.optimizer = None
+        # params/hyper_params.py:8-11; the schedulers are created like base_method.py:60-76
+        # (decay at init_optim) and volsurfs.py:774-783 (warm-up at the first forward)
+        self.lr_milestones, self.nr_warmup_iters = list(lr_milestones), nr_warmup_iters
+        self.scheduler_lr_decay = self.lr_scheduler = None
 
     # -- optimiser: apex FusedAdam(betas (0.9, 0.99), eps 1e-15, wd 0) of
     # base_method.py:87-94 == Adam with the same hyper-parameters
@@ -133,6 +138,8 @@ class VolSurfs(torch.nn.Module):
             params += list(self.bg_model.parameters())
         self.optimizer = torch.optim.Adam(params, lr=self.lr, betas=(0.9, 0.99), eps=1e-15,
                                           weight_decay=0.0, fused=True)
+        from .schedulers import MultiStepLR
+        self.scheduler_lr_decay = MultiStepLR(self.optimizer, milestones=self.lr_milestones, gamma=0.3)
         return self.optimizer
 
     def optim_step(self):
@@ -214,6 +221,14 @@ class VolSurfs(torch.nn.Module):
     def forward(self, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first_iter=False,
                 is_training_masked=False):
         """volsurfs.py:763-816: L1 rgb loss (utils/losses.py:14-19)."""
+        if is_first_iter and self.scheduler_lr_decay is not None:              # :774-783
+            from .schedulers import GradualWarmupScheduler
+            if self.nr_warmup_iters > 0:
+                self.lr_scheduler = GradualWarmupScheduler(self.optimizer, multiplier=1,
+                                                           total_epoch=self.nr_warmup_iters,
+                                                           after_scheduler=self.scheduler_lr_decay)
+            else:
+                self.lr_scheduler = self.scheduler_lr_decay
         res = self.render_rays(rays_o=rays_o, rays_d=rays_d, iter_nr=iter_nr)
         pred = res["renders"]["ray_traced"]["rgb"]
         if is_training_masked and gt_mask is not None:

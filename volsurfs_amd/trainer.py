@@ -1,0 +1,47 @@
+"""One training iteration of the K-shell method in the reference's order
+(/root/reference/volsurfs_py/trainer.py:118-308): zero_grad -> ray batch -> forward ->
+backward -> optimiser step -> dynamic ray count -> lr scheduler.  Data loading, callbacks,
+checkpoints and evaluation (the rest of trainer.py) are outside SURVEY §8.
+"""
+import torch
+
+
+def loss_l1(gt, pred, mask=None):
+    """utils/losses.py:14-19."""
+    d = (gt - pred).abs()
+    return (d * mask).mean() if mask is not None else d.mean()
+
+
+def loss_l2(gt, pred, mask=None):
+    """utils/losses.py:6-11."""
+    d = (gt - pred) ** 2
+    return (d * mask).mean() if mask is not None else d.mean()
+
+
+def dynamic_nr_rays(nr_rays, nr_samples, target_nr_samples):
+    """trainer.py:288-304: scale the next batch so that it yields ~target_nr_samples hits."""
+    if nr_samples is None or nr_samples <= 0:
+        return nr_rays
+    return int(nr_rays * (float(target_nr_samples) / nr_samples))
+
+
+def train_step(method, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first_iter=False,
+               nr_rays=None, target_nr_of_training_samples=None, world=1):
+    """Returns (losses dict with a float "loss", next nr_rays).  `method` is a
+    volsurfs_amd.methods.VolSurfs with init_optim() called.  world > 1: the caller feeds this
+    rank's shard; gradients are summed over ranks before the step."""
+    method.is_training = True
+    method.optimizer.zero_grad()                                            # trainer.py:118
+    losses, _, samples_3d = method(rays_o, rays_d, gt_rgb, gt_mask, iter_nr,
+                                   is_first_iter=is_first_iter)             # :229
+    losses["loss"].backward()                                               # :264
+    if world > 1:
+        from .parallel import allreduce_gradients
+        allreduce_gradients([p for g in method.optimizer.param_groups for p in g["params"]], world)
+    method.optim_step()                                                     # :278
+    losses = {k: (v.item() if isinstance(v, torch.Tensor) else v) for k, v in losses.items()}
+    if nr_rays is not None and target_nr_of_training_samples and samples_3d is not None:
+        nr_rays = dynamic_nr_rays(nr_rays, samples_3d.shape[0], target_nr_of_training_samples)
+    if method.lr_scheduler is not None:                                     # :306-308
+        method.lr_scheduler.step()
+    return losses, nr_rays
