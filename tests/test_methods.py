@@ -165,3 +165,45 @@ def test_legacy_appearance_branch_matches_oracle_and_trains(sh_coeffs):
         m.optim_step()
         losses.append(l["loss"].item())
     assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.gpu
+def test_baked_textures_render_identically_and_match_the_oracle():
+    """bake every texel once, render from the 8-bit textures only.  The
+    baked render equals the live render bit for bit (same texel values), and the baked texels
+    are the oracle's network output at the texel centres."""
+    from oracle import neural_texture as ONT
+    from oracle import tcnn_like
+    from volsurfs_amd.camera import pinhole_rays
+    from volsurfs_amd.mesh import nested_shells
+    from volsurfs_amd.methods import VolSurfs
+    from test_nt_mlp import unpack_weights
+    res = (64, 32, 16, 8)
+    m = VolSurfs(nested_shells(K=2, subdiv=3), max_rays=4096, textures_res=res)
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        m.bank.tables.copy_((torch.rand(m.bank.tables.shape, generator=g) * 2 - 1).cuda())
+    m.bank.refresh_half_params()
+    o, d = pinhole_rays(56, 56, focal=90.0)
+    live = m.render(o, d)
+    baked = m.bake()
+    out = m.render_baked(o, d)
+    assert (live["surfs_alpha"].sum((1, 2)) > 0).sum() > 200
+    assert torch.equal(out["rgb"], live["rgb"]) and torch.equal(out["surfs_rgb"], live["surfs_rgb"])
+    assert torch.equal(out["surfs_alpha"], live["surfs_alpha"])
+    tex = baked.baked_textures()
+    assert set(tex) == {(s, t, dg) for s in range(2) for t in range(2) for dg in range(4)}
+    geom = tcnn_like.GridGeometry()
+    for (s, typ, dg) in [(0, 0, 3), (1, 1, 2), (1, 0, 0)]:
+        R, n = res[dg], 2 * dg + 1
+        C = (3 if typ == 0 else 1) * n
+        img = tex[(s, typ, dg)]
+        assert img.shape == (R, R, C) and img.dtype == torch.uint8
+        iy, ix = torch.meshgrid(torch.arange(R), torch.arange(R), indexing="ij")
+        xy = torch.stack([(ix.flatten() + 0.5) / R, (iy.flatten() + 0.5) / R], 1).float()
+        x = baked.tex_index(s, typ, dg)
+        feats = tcnn_like.hashgrid_forward(geom, baked.tables_h[x].cpu(), xy)
+        w1, w2, w3 = unpack_weights(baked.weights_h[x].cpu())
+        _, q_ref = ONT.quantise(tcnn_like.mlp_forward(w1, w2, w3, feats, C))
+        dq = (img.cpu().reshape(-1, C).int() - q_ref.int()).abs()
+        assert dq.max() <= 1 and (dq > 0).float().mean() < 2e-3, (s, typ, dg, dq.max())

@@ -218,6 +218,44 @@ class VolSurfs(torch.nn.Module):
             res["samples_grad"] = normals[hits].reshape(-1, 3)
         return res
 
+    # -- baked-texture inference (renderers/mesh_renderer.py:113-201 extended
+    # to K shells: 8-bit SH-coefficient textures -> bilinear fetch -> SH eval -> composite)
+    @torch.no_grad()
+    def bake(self):
+        """Evaluate all texels of all 2K neural textures once into 8-bit texel rows."""
+        b = self.bank
+        full = NeuralTextureBank.full_capacity_rays(b.tex_res)
+        baked = NeuralTextureBank(self.nr_meshes, full, sh_degree=b.rgb_degrees - 1,
+                                  alpha_sh_degree=b.alpha_degrees - 1,
+                                  sh_range=[-float(b.plan.sh_lo[d]) for d in range(4)],
+                                  textures_res=b.tex_res, inner_solid=bool(b.plan.inner_solid),
+                                  with_alpha_decay=bool(b.plan.with_alpha_decay),
+                                  device=b.tables.device, training=False)
+        baked.tables.copy_(b.tables)
+        baked.weights.copy_(b.weights)
+        baked.refresh_half_params()
+        baked.bake_all()
+        baked.features = None            # 128 B per (texel, model): only the 8-bit rows are kept
+        self.baked = baked
+        return baked
+
+    @torch.no_grad()
+    def render_baked(self, rays_o, rays_d, chunk=1 << 20):
+        """Render from the baked textures: trace -> per-hit uv -> shade -> composite (no hash
+        grid, no MLP).  Returns the `ray_traced` dict of render()."""
+        outs = []
+        for a in range(0, rays_o.shape[0], chunk):
+            o, d = rays_o[a:a + chunk].contiguous(), rays_d[a:a + chunk].contiguous()
+            hit_t, hit_slot, hit_uv = self.raytracer.trace_all(o, d)
+            tex_uv = self.baked.tex_uv_only(hit_slot, hit_uv, self.face_uvs)
+            rgb_k, alpha_k, normals, _ = self.baked.shade(hit_slot, tex_uv, d, self.raytracer.tris,
+                                                          want_normals=True)
+            bg = self.bg_color if self.bg_color is not None else torch.ones(1, 3, device=o.device)
+            out = composite_dense(rgb_k, alpha_k, bg)
+            out["surfs_normals"] = normals
+            outs.append(out)
+        return {k: torch.cat([o_[k] for o_ in outs], 0) for k in outs[0]}
+
     def forward(self, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first_iter=False,
                 is_training_masked=False):
         """volsurfs.py:763-816: L1 rgb loss (utils/losses.py:14-19)."""

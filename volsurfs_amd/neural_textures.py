@@ -169,6 +169,8 @@ class NeuralTextureBank(torch.nn.Module):
         Returns tex_uv [K,N,2]."""
         K, N = hit_slot.shape
         assert K == self.K and N <= self.max_rays
+        if getattr(self, "baked", False):
+            raise _lib.VolsurfsHipError("this bank holds baked textures: use tex_uv_only + shade")
         st = _lib.stream_ptr()
         tex_uv = torch.empty(K, N, 2, device=hit_slot.device)
         self.marks.zero_()
@@ -176,6 +178,64 @@ class NeuralTextureBank(torch.nn.Module):
                   self.marks, st)
         _lib.call("vsa_nt_compact", ctypes.byref(self.plan), self.marks, self.slot_of,
                   self.texel_of_slot, self.slot_xy, self.seg_start, self.block_scratch, st)
+        return tex_uv
+
+    # -- baking (the deploy format, sh_neural_textures.py:99-114 /
+    # neural_texture.py:200-251 evaluate every texel once and store it as an 8-bit texture)
+    @staticmethod
+    def full_capacity_rays(textures_res):
+        """max_rays for which every (shell, degree) segment can hold ALL its texels."""
+        return ((max(int(r) for r in textures_res) + 2) ** 2 + 3) // 4
+
+    @torch.no_grad()
+    def bake_all(self):
+        """Evaluate EVERY texel of every texture (instead of the texels a frame touches): after
+        this, `shade` works for any ray without mark/compact/encode/mlp.  Needs a bank built
+        with max_rays >= full_capacity_rays(textures_res)."""
+        self.marks.zero_()
+        for s in range(self.K):
+            for d in range(self.D):
+                R = self.tex_res[d]
+                W = R + 2
+                if min(4 * self.max_rays, W * W) < W * W:
+                    raise _lib.VolsurfsHipError("bake_all needs a full-capacity bank "
+                                                "(max_rays >= NeuralTextureBank.full_capacity_rays)")
+                off = int(self.plan.dom_off[s * MAX_DEG + d])
+                self.marks[off:off + W * W].view(W, W).fill_(1)   # interior + the one-texel apron
+        _lib.call("vsa_nt_compact", ctypes.byref(self.plan), self.marks, self.slot_of,
+                  self.texel_of_slot, self.slot_xy, self.seg_start, self.block_scratch,
+                  _lib.stream_ptr())
+        self.encode()
+        self.mlp()
+        self.baked = True
+        return self
+
+    @torch.no_grad()
+    def baked_textures(self):
+        """{(shell, type, degree): uint8 [R, R, C]} indexed [iy, ix] in the network's texel
+        coordinates (texel centre = ((ix + 0.5) / R, (iy + 0.5) / R), see nt_footprint: the
+        reference's 90-degree-rotated uv, neural_texture.py:114-121); C = channels x (2d+1)."""
+        dense = self.rows_dense(self.texels)
+        out = {}
+        for s in range(self.K):
+            for d in range(self.D):
+                R = self.tex_res[d]
+                W, n = R + 2, 2 * d + 1
+                off = int(self.plan.dom_off[s * MAX_DEG + d])
+                slots = self.slot_of[off:off + W * W].view(W, W)[1:R + 1, 1:R + 1].long()
+                rows = dense[slots]                                  # [R, R, 32]
+                if self.tex_channels(self.tex_index(s, 0, d)):
+                    out[(s, 0, d)] = rows[..., :3 * n].contiguous()
+                if self.tex_channels(self.tex_index(s, 1, d)):
+                    out[(s, 1, d)] = rows[..., 24:24 + n].contiguous()
+        return out
+
+    def tex_uv_only(self, hit_slot, hit_uv, face_uvs):
+        """Per-hit texture uv without touching the compaction (inference from a baked bank)."""
+        K, N = hit_slot.shape
+        tex_uv = torch.empty(K, N, 2, device=hit_slot.device)
+        _lib.call("vsa_nt_mark", ctypes.byref(self.plan), hit_slot, hit_uv, face_uvs, N, tex_uv,
+                  self.marks, _lib.stream_ptr())
         return tex_uv
 
     def encode(self):
