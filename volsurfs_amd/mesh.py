@@ -79,3 +79,91 @@ def nested_shells(K=5, subdiv=6, r0=0.30, dr=0.01, noise=0.0, seed=0, device="cu
         uv = octahedral_uv(base_v.astype(np.float64))[f].astype(np.float32)  # [F,3,2]
         meshes.append(TensorMesh(vv, f, uv, device=device))
     return meshes
+
+
+# ---------------------------------------------------------------------------
+# Mesh I/O: the baked shells of a run are
+# `<run>/meshes_simplified_uvs/<isolevel>.obj` with per-face-corner UVs from xatlas
+# (baker.py:123,151); the reference loads them through mvdatasets.utils.mesh.Mesh (absent)
+# in filename order (utils/mesh_loaders.py:22-110) and wraps them as TensorMesh
+# (volsurfs.py:82-117).
+def load_obj(path, device="cuda"):
+    """Wavefront OBJ -> TensorMesh.  `v x y z`, `vt u v`, `f a/at[/an] b/bt[/bn] ...`
+    (polygons are fan-triangulated, negative indices are relative).  Faces without `vt`
+    indices get uv 0."""
+    verts, uvs, faces, face_uvs = [], [], [], []
+    with open(path) as f:
+        for line in f:
+            if line.startswith("v "):
+                verts.append([float(x) for x in line.split()[1:4]])
+            elif line.startswith("vt "):
+                uvs.append([float(x) for x in line.split()[1:3]])
+            elif line.startswith("f "):
+                vi, ti = [], []
+                for tok in line.split()[1:]:
+                    parts = tok.split("/")
+                    i = int(parts[0])
+                    vi.append(i - 1 if i > 0 else len(verts) + i)
+                    if len(parts) > 1 and parts[1]:
+                        t = int(parts[1])
+                        ti.append(t - 1 if t > 0 else len(uvs) + t)
+                    else:
+                        ti.append(-1)
+                for k in range(1, len(vi) - 1):
+                    faces.append([vi[0], vi[k], vi[k + 1]])
+                    face_uvs.append([ti[0], ti[k], ti[k + 1]])
+    if not verts or not faces:
+        raise ValueError(f"{path}: no geometry")
+    v = torch.tensor(verts, dtype=torch.float32)
+    fa = torch.tensor(faces, dtype=torch.int32)
+    uv_tab = torch.tensor(uvs if uvs else [[0.0, 0.0]], dtype=torch.float32)
+    ft = torch.tensor(face_uvs, dtype=torch.long)
+    fuv = uv_tab[ft.clamp(min=0)]
+    fuv[ft < 0] = 0.0
+    mesh = TensorMesh(v, fa, fuv, device=device)
+    mesh.has_uvs = bool(uvs) and bool((ft >= 0).all())
+    return mesh
+
+
+def save_obj(path, mesh):
+    """TensorMesh -> OBJ with one `vt` per face corner (round-trips through load_obj)."""
+    v = mesh.vertices.detach().cpu()
+    f = mesh.faces.detach().cpu().long()
+    fuv = mesh.get_faces_uvs().detach().cpu().reshape(-1, 3, 2)
+    with open(path, "w") as out:
+        for p in v.tolist():
+            out.write("v %.9g %.9g %.9g\n" % tuple(p))
+        for t in fuv.reshape(-1, 2).tolist():
+            out.write("vt %.9g %.9g\n" % tuple(t))
+        for i, tri in enumerate(f.tolist()):
+            out.write("f %d/%d %d/%d %d/%d\n" % (tri[0] + 1, 3 * i + 1, tri[1] + 1, 3 * i + 2,
+                                                  tri[2] + 1, 3 * i + 3))
+
+
+def load_meshes_indexed_from_path(meshes_indices, meshes_path, require_uvs=False, return_paths=False,
+                                  device="cuda"):
+    """utils/mesh_loaders.py:35-110: the .obj files of a directory sorted by the isolevel in
+    their name (inner -> outer), optionally a subset by index.  Errors raise (the reference
+    prints and exit(1)s)."""
+    import os
+    if not os.path.exists(meshes_path):
+        raise FileNotFoundError(f"mesh path {meshes_path} does not exist")
+    names = [n for n in os.listdir(meshes_path) if n.endswith(".obj")]
+    names.sort(key=lambda x: float(x[:-4]))
+    if not names:
+        raise FileNotFoundError(f"no meshes found in {meshes_path}")
+    if meshes_indices is not None:
+        idx = sorted(int(i) for i in meshes_indices)
+        if not idx:
+            raise ValueError("no meshes indices set")
+        for i in idx:
+            if i < 0 or i >= len(names):
+                raise IndexError(f"mesh index {i} out of range")
+        names = [names[i] for i in idx]
+    paths = [os.path.join(meshes_path, n) for n in names]
+    meshes = [load_obj(p, device=device) for p in paths]
+    if require_uvs:
+        for n, m in zip(names, meshes):
+            if not m.has_uvs:
+                raise ValueError(f"mesh {n} does not have UVs")
+    return (meshes, paths) if return_paths else meshes
