@@ -91,6 +91,12 @@ int vsa_bvh_build(const float* verts, const int32_t* faces, int nr_verts, int nr
 int vsa_bvh_sizes(const vsa_bvh* bvh, int* nr_nodes, int* nr_tris, int* max_depth);
 int vsa_bvh_export(const vsa_bvh* bvh, float* nodes_out, float* tris_out, int node_base,
                    int tri_base);
+/* Quantised export for vsa_trace_q: qnodes_out [nr_nodes,8] u32 (32-B nodes: per child three
+ * dwords of 6 x u16 box coordinates on the mesh's grid, rounded outward; dwords 6, 7 = the
+ * children: node index >= 0, leaf code ~((first_tri << 4) | count), or 0x7fffffff = none),
+ * frame_out [6] = grid origin xyz and step xyz, tris_out as vsa_bvh_export. */
+int vsa_bvh_export_q(const vsa_bvh* bvh, uint32_t* qnodes_out, float* tris_out, int node_base,
+                     int tri_base, float* frame_out);
 int vsa_bvh_destroy(vsa_bvh* bvh);
 
 /* vsa_trace: closest hit of every ray against each of nr_meshes BVHs in ONE
@@ -105,6 +111,15 @@ int vsa_bvh_destroy(vsa_bvh* bvh);
 int vsa_trace(const float* nodes, const float* tris, const int32_t* mesh_roots, int nr_meshes,
               int max_depth, const float* rays_o, const float* rays_d, int nr_rays, float t_min,
               float* hit_t, int32_t* hit_slot, float* hit_uv, void* stream);
+
+/* vsa_trace on the quantised nodes of vsa_bvh_export_q (half the node bytes; identical
+ * results).  mesh_frames [host, nr_meshes*6].  Valid while ray origins stay within ~60 mesh
+ * extents of the mesh (fp32 error of the origin in grid units < the boxes' outward margin);
+ * beyond that use vsa_trace. */
+int vsa_trace_q(const uint32_t* qnodes, const float* tris, const int32_t* mesh_roots,
+                const float* mesh_frames, int nr_meshes, int max_depth, const float* rays_o,
+                const float* rays_d, int nr_rays, float t_min, float* hit_t, int32_t* hit_slot,
+                float* hit_uv, void* stream);
 
 /* vsa_hit_attributes: expands one mesh's hit records [N] into the dict
  * raytracelib returns (volsurfs.py:496-501): is_hit [N] u8, triangles_id [N]

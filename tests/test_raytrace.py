@@ -67,8 +67,10 @@ def test_bvh_build_host_side():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["q16", "f32"])
 @pytest.mark.parametrize("subdiv,n", [(0, 1000), (2, 4096), (4, 4096), (5, 2000)])
-def test_trace_bit_exact_vs_bruteforce(subdiv, n):
+def test_trace_bit_exact_vs_bruteforce(subdiv, n, fmt):
+    """fmt: 32-byte quantised nodes (default) / 64-byte fp32 nodes — identical hits."""
     from volsurfs_amd.mesh import TensorMesh
     from volsurfs_amd.raytrace import RayTracer
     meshes_np = [icosphere(subdiv, 0.3 + 0.02 * k) for k in range(3)]
@@ -76,7 +78,7 @@ def test_trace_bit_exact_vs_bruteforce(subdiv, n):
     g = np.random.default_rng(subdiv)
     meshes_np = [((v * (1 + 0.05 * g.standard_normal((v.shape[0], 1)))).astype(np.float32), f)
                  for v, f in meshes_np]
-    rt = RayTracer([TensorMesh(v, f) for v, f in meshes_np])
+    rt = RayTracer([TensorMesh(v, f) for v, f in meshes_np], node_format=fmt)
     o, d = _rays(n, subdiv)
     hit_t, hit_slot, hit_uv = rt.trace_all(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda())
     face_id = torch.where(hit_slot >= 0, rt.slot_face_id[hit_slot.clamp(min=0).long()],
@@ -105,6 +107,7 @@ def test_trace_edge_cases():
     from volsurfs_amd.raytrace import RayTracer
     v, f = icosphere(1, 0.3)
     rt = RayTracer([TensorMesh(v, f)])
+    assert rt.node_format == "q16"
     # empty batch
     t, s, uv = rt.trace_all(torch.zeros(0, 3, device="cuda"), torch.zeros(0, 3, device="cuda"))
     assert t.shape == (1, 0)

@@ -271,6 +271,70 @@ extern "C" int vsa_bvh_export(const vsa_bvh* bvh, float* nodes_out, float* tris_
   return VSA_OK;
 }
 
+// Quantised export: 32-byte nodes.  Each child box is 6 x u16 on a per-mesh grid
+// (frame: lo[3], step[3] with step = extent / 65533), rounded OUTWARD and widened by one
+// more grid unit per side, which covers the fp32 error of the traversal's box test in grid
+// coordinates; the boxes only prune, so closest hits stay bit-identical.  Dwords 6, 7 are
+// the children: inner node index (>= 0), leaf code ~((first_tri << 4) | count), or
+// 0x7fffffff for an empty child.
+extern "C" int vsa_bvh_export_q(const vsa_bvh* bvh, uint32_t* qnodes_out, float* tris_out,
+                                int node_base, int tri_base, float* frame_out) {
+  if (!bvh || !qnodes_out || !tris_out || !frame_out || node_base < 0 || tri_base < 0)
+    return VSA_ERR_ARG;
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (const BuildNode& n : bvh->nodes)
+    for (int c = 0; c < 2; ++c) {
+      if (n.ref[c] < 0 && n.cnt[c] == 0) continue;
+      const float l[3] = {n.box[c].lo.x, n.box[c].lo.y, n.box[c].lo.z};
+      const float h[3] = {n.box[c].hi.x, n.box[c].hi.y, n.box[c].hi.z};
+      for (int a = 0; a < 3; ++a) {
+        lo[a] = std::min(lo[a], l[a]);
+        hi[a] = std::max(hi[a], h[a]);
+      }
+    }
+  double step[3];
+  for (int a = 0; a < 3; ++a) {
+    if (!(hi[a] >= lo[a])) lo[a] = hi[a] = 0.f;   // empty mesh
+    step[a] = std::max((double)hi[a] - (double)lo[a], 1e-30) / 65533.0;
+    frame_out[a] = lo[a];
+    frame_out[3 + a] = (float)step[a];
+    step[a] = (double)frame_out[3 + a];            // quantise against the step the device uses
+  }
+  auto qlo = [&](float x, int a) {
+    const double q = std::floor(((double)x - (double)lo[a]) / step[a]) - 1.0 + 1.0;   // grid is offset by +1
+    return (uint32_t)std::min(std::max(q, 0.0), 65535.0);
+  };
+  auto qhi = [&](float x, int a) {
+    const double q = std::ceil(((double)x - (double)lo[a]) / step[a]) + 1.0 + 1.0;
+    return (uint32_t)std::min(std::max(q, 0.0), 65535.0);
+  };
+  for (size_t i = 0; i < bvh->nodes.size(); ++i) {
+    const BuildNode& n = bvh->nodes[i];
+    uint32_t* o = qnodes_out + 8 * i;
+    for (int c = 0; c < 2; ++c) {
+      uint32_t q[6];
+      const bool empty = n.ref[c] < 0 && n.cnt[c] == 0;
+      if (empty) {
+        q[0] = q[1] = q[2] = 65535u;   // inverted box: never hit
+        q[3] = q[4] = q[5] = 0u;
+      } else {
+        q[0] = qlo(n.box[c].lo.x, 0); q[1] = qlo(n.box[c].lo.y, 1); q[2] = qlo(n.box[c].lo.z, 2);
+        q[3] = qhi(n.box[c].hi.x, 0); q[4] = qhi(n.box[c].hi.y, 1); q[5] = qhi(n.box[c].hi.z, 2);
+      }
+      o[3 * c + 0] = q[0] | (q[1] << 16);
+      o[3 * c + 1] = q[2] | (q[3] << 16);
+      o[3 * c + 2] = q[4] | (q[5] << 16);
+      int32_t ref;
+      if (empty) ref = 0x7fffffff;
+      else if (n.ref[c] >= 0) ref = n.ref[c] + node_base;
+      else ref = ~(((~n.ref[c] + tri_base) << 4) | n.cnt[c]);
+      o[6 + c] = (uint32_t)ref;
+    }
+  }
+  std::memcpy(tris_out, bvh->tris.data(), bvh->tris.size() * sizeof(float));
+  return VSA_OK;
+}
+
 extern "C" int vsa_bvh_destroy(vsa_bvh* bvh) {
   delete bvh;
   return VSA_OK;

@@ -169,6 +169,122 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_ww_kernel(
   hit_uv[2 * o + 1] = best.v;
 }
 
+// ---- quantised nodes (vsa_bvh_export_q): 32 B per node instead of 64.  The inner-node walk
+// is bound by the texture-address path (every lane fetches its own node: 64 lanes x 64 B per
+// visit), so halving the node halves that traffic.  The ray is moved into each mesh's
+// 16-bit grid once (o_g = (o - lo) / step + 1, d_g = d / step: the slab parameter t is
+// unchanged), child boxes are tested directly on their u16 coordinates; the boxes were
+// rounded outward by more than the fp32 error of that test, and triangles are still tested
+// with the original ray, so the closest hit is bit-identical to the fp32-node kernel.
+struct Frames {
+  float f[VSA_MAX_SHELLS][6];   // lo.xyz, step.xyz
+};
+
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// Slab test on grid coordinates, ~20 VALU ops per box (the fp32-node test is ~40 and PMC
+// showed the traversal VALU-bound: 68 % VALU-busy at 37 % lane utilisation): per axis ONE
+// packed FMA gives both plane parameters, t = q * (1/d_g) - o_g/d_g.  The different rounding
+// (and the NaN an axis-parallel ray produces, which min/max then ignore, i.e. that axis's
+// constraint is dropped) can only make the test pass more often; the boxes carry a one-unit
+// outward margin, so nothing reachable is pruned.
+struct QRay {
+  f32x2_t ix, iy, iz;   // (1/d_g, 1/d_g) per axis
+  f32x2_t cx, cy, cz;   // (-o_g/d_g, -o_g/d_g)
+};
+
+__device__ __forceinline__ bool qbox_test(unsigned w0, unsigned w1, unsigned w2, const QRay& r,
+                                          float t_min, float t_max, float& t_near) {
+  const f32x2_t qx = {(float)(w0 & 0xffffu), (float)(w1 >> 16)};
+  const f32x2_t qy = {(float)(w0 >> 16), (float)(w2 & 0xffffu)};
+  const f32x2_t qz = {(float)(w1 & 0xffffu), (float)(w2 >> 16)};
+  const f32x2_t tx = __builtin_elementwise_fma(qx, r.ix, r.cx);
+  const f32x2_t ty = __builtin_elementwise_fma(qy, r.iy, r.cy);
+  const f32x2_t tz = __builtin_elementwise_fma(qz, r.iz, r.cz);
+  const float tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fminf(tz.x, tz.y));
+  const float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fmaxf(tz.x, tz.y));
+  t_near = tn;
+  return tn <= tf && tf >= t_min && tn <= t_max;
+}
+
+template <int STACK>
+__global__ __launch_bounds__(TRACE_BLOCK) void trace_q_kernel(
+    const uint4* __restrict__ qnodes, const float4* __restrict__ tris, Roots roots, Frames frames,
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, int N, float t_min,
+    float* __restrict__ hit_t, int* __restrict__ hit_slot, float* __restrict__ hit_uv) {
+  __shared__ int s_stack[STACK][TRACE_BLOCK];
+  const int lane = threadIdx.x;
+  const long long n = (long long)blockIdx.x * TRACE_BLOCK + lane;
+  const int mesh = blockIdx.y;
+  if (n >= N) return;
+  const float ox = rays_o[3 * n], oy = rays_o[3 * n + 1], oz = rays_o[3 * n + 2];
+  const float dx = rays_d[3 * n], dy = rays_d[3 * n + 1], dz = rays_d[3 * n + 2];
+  const float* fr = frames.f[mesh];
+  QRay qr;
+  {
+    const float gx = (ox - fr[0]) / fr[3] + 1.0f, gy = (oy - fr[1]) / fr[4] + 1.0f,
+                gz = (oz - fr[2]) / fr[5] + 1.0f;
+    const float ix = 1.0f / (dx / fr[3]), iy = 1.0f / (dy / fr[4]), iz = 1.0f / (dz / fr[5]);
+    qr.ix = f32x2_t{ix, ix}, qr.iy = f32x2_t{iy, iy}, qr.iz = f32x2_t{iz, iz};
+    qr.cx = f32x2_t{-(gx * ix), -(gx * ix)};
+    qr.cy = f32x2_t{-(gy * iy), -(gy * iy)};
+    qr.cz = f32x2_t{-(gz * iz), -(gz * iz)};
+  }
+
+  Hit best;
+  best.t = INFINITY;
+  best.u = best.v = 0.f;
+  best.slot = -1;
+  best.id = 0x7fffffff;
+
+  int cur = roots.root[mesh];
+  int sp = 0;
+  while (cur != TRACE_EMPTY) {
+    while ((unsigned)cur < (unsigned)TRACE_EMPTY) {
+      const uint4 a = qnodes[2 * (long long)cur], b = qnodes[2 * (long long)cur + 1];
+      float tn0, tn1;
+      const bool h0 = qbox_test(a.x, a.y, a.z, qr, t_min, best.t, tn0);
+      const bool h1 = qbox_test(a.w, b.x, b.y, qr, t_min, best.t, tn1);
+      const int c0 = (int)b.z, c1 = (int)b.w;
+      if (h0 && h1) {
+        const bool swap = tn1 < tn0;
+        s_stack[sp++][lane] = swap ? c0 : c1;
+        cur = swap ? c1 : c0;
+      } else if (h0) {
+        cur = c0;
+      } else if (h1) {
+        cur = c1;
+      } else {
+        cur = sp ? s_stack[--sp][lane] : TRACE_EMPTY;
+      }
+    }
+    if (cur != TRACE_EMPTY) {
+      const int code = ~cur;
+      const int first = code >> 4, cnt = code & 15;
+      for (int i0 = 0; i0 < cnt; i0 += 4) {
+        float4 tv[4][3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const long long s = first + min(i0 + i, cnt - 1);
+          tv[i][0] = tris[3 * s];
+          tv[i][1] = tris[3 * s + 1];
+          tv[i][2] = tris[3 * s + 2];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i0 + i < cnt)
+            tri_test(tv[i][0], tv[i][1], tv[i][2], ox, oy, oz, dx, dy, dz, t_min, first + i0 + i, best);
+      }
+      cur = sp ? s_stack[--sp][lane] : TRACE_EMPTY;
+    }
+  }
+  const long long o = (long long)mesh * N + n;
+  hit_t[o] = best.slot >= 0 ? best.t : 0.0f;
+  hit_slot[o] = best.slot;
+  hit_uv[2 * o] = best.u;
+  hit_uv[2 * o + 1] = best.v;
+}
+
 // Per-hit attributes in the shape raytracelib returns them
 // (volsurfs.py:496-501): positions, face normals, barycentrics, original ids.
 __global__ void hit_attributes_kernel(const float4* __restrict__ tris,
@@ -231,6 +347,33 @@ extern "C" int vsa_trace(const float* nodes, const float* tris, const int32_t* m
     hipLaunchKernelGGL(trace_ww_kernel<TRACE_STACK>, grid, block, 0, (hipStream_t)stream,
                        reinterpret_cast<const float4*>(nodes), reinterpret_cast<const float4*>(tris),
                        r, rays_o, rays_d, nr_rays, t_min, hit_t, hit_slot, hit_uv);
+  VSA_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int vsa_trace_q(const uint32_t* qnodes, const float* tris, const int32_t* mesh_roots,
+                           const float* mesh_frames, int nr_meshes, int max_depth,
+                           const float* rays_o, const float* rays_d, int nr_rays, float t_min,
+                           float* hit_t, int32_t* hit_slot, float* hit_uv, void* stream) {
+  if (nr_meshes < 1 || nr_meshes > VSA_MAX_SHELLS || nr_rays < 0 || !mesh_roots || !mesh_frames)
+    return VSA_ERR_ARG;
+  if (max_depth >= TRACE_STACK) return VSA_ERR_UNSUPPORTED;
+  if (nr_rays == 0) return VSA_OK;
+  if (!qnodes || !tris || !rays_o || !rays_d || !hit_t || !hit_slot || !hit_uv) return VSA_ERR_ARG;
+  Roots r;
+  Frames fr;
+  for (int i = 0; i < VSA_MAX_SHELLS; ++i) {
+    r.root[i] = i < nr_meshes ? mesh_roots[i] : 0;
+    for (int j = 0; j < 6; ++j) fr.f[i][j] = i < nr_meshes ? mesh_frames[6 * i + j] : 1.0f;
+  }
+  dim3 grid(vsa_div_up(nr_rays, TRACE_BLOCK), nr_meshes), block(TRACE_BLOCK);
+  if (max_depth < 24)
+    hipLaunchKernelGGL(trace_q_kernel<24>, grid, block, 0, (hipStream_t)stream,
+                       reinterpret_cast<const uint4*>(qnodes), reinterpret_cast<const float4*>(tris),
+                       r, fr, rays_o, rays_d, nr_rays, t_min, hit_t, hit_slot, hit_uv);
+  else
+    hipLaunchKernelGGL(trace_q_kernel<TRACE_STACK>, grid, block, 0, (hipStream_t)stream,
+                       reinterpret_cast<const uint4*>(qnodes), reinterpret_cast<const float4*>(tris),
+                       r, fr, rays_o, rays_d, nr_rays, t_min, hit_t, hit_slot, hit_uv);
   VSA_RETURN_LAUNCH_STATUS();
 }
 

@@ -16,12 +16,18 @@ from . import _lib
 
 
 class RayTracer:
-    def __init__(self, tensor_meshes, leaf_size=None):
+    def __init__(self, tensor_meshes, leaf_size=None, node_format=None):
+        """node_format: "q16" (default; 32-byte quantised nodes, vsa_trace_q) or "f32" (64-byte
+        nodes, vsa_trace; also selected by VSA_TRACE_NODES=f32).  Both give identical hits; q16
+        assumes ray origins within ~60 mesh extents of the mesh (include/volsurfs_hip.h)."""
+        self.node_format = node_format or os.environ.get("VSA_TRACE_NODES", "q16")
+        if self.node_format not in ("q16", "f32"):
+            raise _lib.VolsurfsHipError(f"unknown node_format {self.node_format}")
         self.nr_meshes = len(tensor_meshes)
         if not 1 <= self.nr_meshes <= 16:
             raise _lib.VolsurfsHipError("RayTracer supports 1..16 meshes")
         L = _lib.lib()
-        nodes_all, tris_all, roots = [], [], []
+        nodes_all, tris_all, roots, qnodes_all, frames = [], [], [], [], []
         self.mesh_tri_offset, self.mesh_nr_tris = [], []
         self.max_depth = 0
         node_base = tri_base = 0
@@ -43,9 +49,16 @@ class RayTracer:
             rc = L.vsa_bvh_export(h, nodes.ctypes.data_as(ctypes.c_void_p),
                                   tris.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(node_base),
                                   ctypes.c_int(tri_base))
+            qnodes = np.empty((nn.value, 8), np.uint32)
+            frame = np.empty(6, np.float32)
+            rc2 = L.vsa_bvh_export_q(h, qnodes.ctypes.data_as(ctypes.c_void_p),
+                                     tris.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(node_base),
+                                     ctypes.c_int(tri_base), frame.ctypes.data_as(ctypes.c_void_p))
             L.vsa_bvh_destroy(h)
-            if rc != 0:
-                raise _lib.VolsurfsHipError(f"vsa_bvh_export failed with status {rc}")
+            if rc != 0 or rc2 != 0:
+                raise _lib.VolsurfsHipError(f"vsa_bvh_export failed with status {rc} / {rc2}")
+            qnodes_all.append(qnodes)
+            frames.append(frame)
             roots.append(node_base)
             self.mesh_tri_offset.append(tri_base)
             self.mesh_nr_tris.append(nt.value)
@@ -57,6 +70,8 @@ class RayTracer:
         dev = tensor_meshes[0].vertices.device
         self.device = dev
         self.nodes = torch.from_numpy(np.concatenate(nodes_all, 0)).to(dev)
+        self.qnodes = torch.from_numpy(np.concatenate(qnodes_all, 0).view(np.int32)).to(dev)
+        self._frames = (ctypes.c_float * (6 * self.nr_meshes))(*np.concatenate(frames).tolist())
         tris_np = np.concatenate(tris_all, 0)
         self.tris = torch.from_numpy(tris_np).to(dev)
         # original face id of every leaf-ordered triangle slot (for uv tables etc.)
@@ -74,8 +89,13 @@ class RayTracer:
         hit_t = torch.empty(K, N, device=rays_o.device)
         hit_slot = torch.empty(K, N, dtype=torch.int32, device=rays_o.device)
         hit_uv = torch.empty(K, N, 2, device=rays_o.device)
-        _lib.call("vsa_trace", self.nodes, self.tris, self._roots, K, self.max_depth, rays_o,
-                  rays_d, N, float(t_min), hit_t, hit_slot, hit_uv, _lib.stream_ptr())
+        if self.node_format == "q16":
+            _lib.call("vsa_trace_q", self.qnodes, self.tris, self._roots, self._frames, K,
+                      self.max_depth, rays_o, rays_d, N, float(t_min), hit_t, hit_slot, hit_uv,
+                      _lib.stream_ptr())
+        else:
+            _lib.call("vsa_trace", self.nodes, self.tris, self._roots, K, self.max_depth, rays_o,
+                      rays_d, N, float(t_min), hit_t, hit_slot, hit_uv, _lib.stream_ptr())
         return hit_t, hit_slot, hit_uv
 
     def trace(self, rays_o, rays_d, mesh_id=0, t_min=0.0):
