@@ -68,6 +68,15 @@ int vsa_composite_dense_bwd(const float* surfs_rgb, const float* surfs_alpha,
                             float* g_surfs_rgb, float* g_surfs_alpha, float* g_rgb_bg,
                             int nr_rays, int nr_shells, int carry_f16, void* stream);
 
+/* The same with the L1 image loss of utils/losses.py:14-19 fused in: the upstream gradient
+ * is formed in the kernel as loss_scale * sign(pred_rgb - gt_rgb) (loss_scale = 1 / (3 N_global)
+ * for the mean), saving three elementwise passes over [N,3]. */
+int vsa_composite_dense_bwd_l1(const float* surfs_rgb, const float* surfs_alpha,
+                               const float* rgb_bg, int bg_is_broadcast, const float* pred_rgb,
+                               const float* gt_rgb, float loss_scale, float* g_surfs_rgb,
+                               float* g_surfs_alpha, int nr_rays, int nr_shells, int carry_f16,
+                               void* stream);
+
 /* ------------------------------------------------------------------------
  * A2  BVH build (host) + K-shell closest-hit traversal (device).
  * Replaces raytracelib.RayTracer(tensor_meshes) / .trace(rays_o, rays_d, mesh_id)

@@ -174,3 +174,24 @@ def test_hip_full_frame_properties():
     # tile independence: first chunk of 16384 rays equals the same rays alone
     out4 = composite_dense(c[:16384].contiguous(), a[:16384].contiguous(), bg)
     assert torch.equal(out4["rgb"], out["rgb"][:16384])
+
+
+@pytest.mark.gpu
+def test_fused_l1_backward_equals_explicit_gradient():
+    """vsa_composite_dense_bwd_l1 forms d mean|gt - pred| / d pred = sign(pred - gt) / (3N)
+    (utils/losses.py:14-19 through autograd) inside the kernel: identical to handing the
+    explicit gradient to vsa_composite_dense_bwd."""
+    from volsurfs_amd.composite import composite_bwd_l1_raw, composite_bwd_raw, composite_fwd_raw
+    g = torch.Generator().manual_seed(3)
+    N, K = 5000, 5
+    c = torch.rand(N, K, 3, generator=g).cuda()
+    a = torch.rand(N, K, generator=g).cuda()
+    bg = torch.ones(1, 3).cuda()
+    gt = torch.rand(N, 3, generator=g).cuda()
+    pred = composite_fwd_raw(c, a, bg)
+    gt[:7] = pred[:7]                                   # exact ties -> zero gradient, like torch.sign
+    g_rgb = torch.sign(pred - gt) / (3.0 * N)
+    ref_c, ref_a = composite_bwd_raw(c, a, bg, g_rgb)
+    got_c, got_a = composite_bwd_l1_raw(c, a, bg, pred, gt, 1.0 / (3.0 * N))
+    assert torch.equal(got_c, ref_c) and torch.equal(got_a, ref_a)
+    assert got_c[:7].abs().sum() == 0

@@ -88,3 +88,15 @@ def composite_bwd_raw(surfs_rgb, surfs_alpha, rgb_bg, g_rgb, carry_f16=False):
     _lib.call("vsa_composite_dense_bwd", surfs_rgb, surfs_alpha, rgb_bg, bcast, g_rgb, g_c, g_a,
               None, N, K, int(carry_f16), _lib.stream_ptr())
     return g_c, g_a
+
+
+def composite_bwd_l1_raw(surfs_rgb, surfs_alpha, rgb_bg, pred_rgb, gt_rgb, loss_scale, carry_f16=False):
+    """composite_bwd_raw with d mean|gt - pred| / d pred formed inside the kernel
+    (loss_scale = 1 / (3 * N_global))."""
+    N, K, _ = surfs_rgb.shape
+    g_c = torch.empty_like(surfs_rgb)
+    g_a = torch.empty_like(surfs_alpha)
+    bcast = rgb_bg.shape[0] == 1 and N != 1
+    _lib.call("vsa_composite_dense_bwd_l1", surfs_rgb, surfs_alpha, rgb_bg, bcast, pred_rgb, gt_rgb,
+              float(loss_scale), g_c, g_a, N, K, int(carry_f16), _lib.stream_ptr())
+    return g_c, g_a

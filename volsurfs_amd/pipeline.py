@@ -210,13 +210,13 @@ class KShellPipeline:
         rgb = T.run("composite_fwd", lambda: composite_fwd_raw(rgb_k, alpha_k, self.bg), record,
                     bytes=N * (16 * K + 12))
 
-        def loss_grad():
-            # d mean|gt - pred| / d pred  (utils/losses.py:14-19)
-            return torch.sign(rgb - self.gt) / (3.0 * N)
-        g_rgb = T.run("loss_l1_grad", loss_grad, record, bytes=N * 36)
+        # d mean|gt - pred| / d pred (utils/losses.py:14-19) is formed inside the composite
+        # backward kernel (vsa_composite_dense_bwd_l1)
+        from .composite import composite_bwd_l1_raw
         g_c, g_a = T.run("composite_bwd",
-                         lambda: composite_bwd_raw(rgb_k, alpha_k, self.bg, g_rgb), record,
-                         bytes=N * (12 + 32 * K))
+                         lambda: composite_bwd_l1_raw(rgb_k, alpha_k, self.bg, rgb, self.gt,
+                                                      1.0 / (3.0 * N)), record,
+                         bytes=N * (24 + 32 * K))
         tris = self.tracer.tris
         T.run("nt_shade_bwd", lambda: bank.backward_shade(hit_slot, tex_uv, self.rays_d, tris, g_c, g_a,
                                                            self.grad_scale, self._act), record,
