@@ -70,18 +70,6 @@ __device__ __forceinline__ float2 nt_interp_uv(const float* __restrict__ fuv, fl
   return r;
 }
 
-// Per-launch constants decoded on the host: which levels, and how blockIdx.x
-// enumerates (model = shell*2+type, degree, group).  The per-degree group count
-// comes from the segment capacity min(4*max_rays, (R_d+2)^2), so that small
-// textures do not launch the worst-case number of LDS-hungry workgroups.
-struct EncLaunch {
-  int level0;
-  int span;
-  int groups[VSA_NT_MAX_DEG];
-  int per_model;
-};
-
-
 __device__ __forceinline__ bool tex_active(const vsa_nt_plan& p, int tex) {
   const int deg = tex % VSA_NT_MAX_DEG;
   const int type = (tex / VSA_NT_MAX_DEG) & 1;
@@ -95,34 +83,6 @@ struct Work {
   int tex, first, last;  // slots [first, last) of texture tex
   int seg_len;           // slots in the whole (shell, degree) segment
 };
-
-__device__ __forceinline__ bool decode_work(const vsa_nt_plan& p, const EncLaunch& L,
-                                            const int* seg_start, int bx, Work& w) {
-  const int model = bx / L.per_model;  // shell*2 + type
-  int r = bx - model * L.per_model;
-  int d = 0;
-#pragma unroll
-  for (int i = 0; i < VSA_NT_MAX_DEG - 1; ++i)
-    if (d == i && r >= L.groups[i]) {
-      r -= L.groups[i];
-      d = i + 1;
-    }
-  w.tex = model * VSA_NT_MAX_DEG + d;
-  if (!tex_active(p, w.tex)) return false;
-  const int sd = (model >> 1) * VSA_NT_MAX_DEG + d;
-  const int begin = seg_start[sd], end = seg_start[sd + 1];
-  w.seg_len = end - begin;
-  // equal-sized groups: ceil(len / span) workgroups share the segment evenly
-  const int active = (w.seg_len + L.span - 1) / L.span;
-  if (r >= active) return false;
-  const int per = ((w.seg_len + active - 1) / active + 31) & ~31;   // whole 32-slot tiles
-  const long long first = begin + (long long)r * per;
-  if (first >= end) return false;
-  w.first = (int)first;
-  w.last = (int)(first + per < end ? first + per : end);
-  return true;
-}
-
 
 // Persistent work split (one workgroup per CU for the LDS-hungry kernels).  The launch's
 // work = n_planes x (every active texture's slots), laid out on one cost axis in units of
@@ -172,18 +132,4 @@ __device__ __forceinline__ void nt_for_each_piece(const vsa_nt_plan& plan,
   }
 }
 
-static inline EncLaunch enc_launch(const vsa_nt_plan* p, int level0, int span) {
-  EncLaunch L;
-  L.level0 = level0;
-  L.span = span;
-  L.per_model = 0;
-  for (int d = 0; d < VSA_NT_MAX_DEG; ++d) {
-    const long long T = (long long)(p->tex_res[d] + 2) * (p->tex_res[d] + 2);
-    long long cap = 4ll * p->max_rays < T ? 4ll * p->max_rays : T;
-    if (cap < 1) cap = 1;
-    L.groups[d] = (int)((cap + span - 1) / span);
-    L.per_model += L.groups[d];
-  }
-  return L;
-}
 

@@ -218,58 +218,8 @@ __global__ __launch_bounds__(MLP_BLOCK, MLP_FWD_WGS_PER_CU) void nt_mlp_fwd_kern
 //   16..19 T3[m][s]  elem j = W3[perm_k(s,h,j)][32m + r]
 //   20..27 T2[m][q]  elem j = W2[perm_k(q,h,j)][32m + r]
 //   28..31 T1[q]     elem j = W1[perm_k(q,h,j)][r]
-constexpr int BWD_BLOCK = 256;                 // 4 waves, one per SIMD (the whole 512-register file each)
-constexpr int BWD_WAVES = BWD_BLOCK / 64;
-constexpr int BWD_TPW = 32;                    // tiles per wave
-constexpr int MLP_BWD_SPAN = BWD_WAVES * BWD_TPW * 32;
-
-__device__ void stage_weights_bwd(const _Float16* __restrict__ W, half8_t* s_frag) {
-  for (int idx = threadIdx.x; idx < 16 * 64; idx += BWD_BLOCK) {
-    const int frag = idx >> 6, lane = idx & 63, r = lane & 31, h = lane >> 5;
-    half8_t v, f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      _Float16 x, y;
-      if (frag < 4) {
-        const int m = frag >> 1, s = frag & 1;
-        x = W[W3_OFF + perm_k(s, h, j) * 64 + 32 * m + r];
-        y = W[W1_OFF + (32 * m + r) * 32 + 16 * s + 8 * h + j];
-      } else if (frag < 12) {
-        const int f_ = frag - 4, m = f_ >> 2, q = f_ & 3;
-        x = W[W2_OFF + perm_k(q, h, j) * 64 + 32 * m + r];
-        y = W[W2_OFF + (32 * m + r) * 64 + perm_k(q, h, j)];
-      } else {
-        x = W[W1_OFF + perm_k(frag - 12, h, j) * 32 + r];
-        y = W[W3_OFF + r * 64 + perm_k(frag - 12, h, j)];
-      }
-      v[j] = x;
-      f[j] = y;
-    }
-    s_frag[idx] = f;             // forward fragments (same ids as stage_weights_fwd)
-    s_frag[16 * 64 + idx] = v;   // transposed fragments
-  }
-}
-
-// Per-wave LDS scratch for the weight-gradient products, POINT-major:
-// img[point][channel] f16, written with 8-byte stores straight from the MFMA
-// accumulator layout (lane = point, 4 consecutive rows per register group) and
-// read back TRANSPOSED with ds_read_b64_tr_b16 as [channel][8 consecutive
-// points] = the A/B fragment of an MFMA that contracts over the tile's points.
-constexpr int IMG_STRIDE = 72;                 // halfs per point row (64 channels + 16 B pad)
-constexpr int IMG_HALFS = 32 * IMG_STRIDE;     // one region: 32 points x 64 channels
 
 typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
-
-// Writes one 32-channel tile held as two f16 fragments (frag[s][j] <-> accumulator
-// register 8s+j, i.e. row (j&3) + 8(2s + (j>>2)) + 4h) to img[point][col_base + row].
-__device__ __forceinline__ void store_frags(_Float16* img, int col_base, const half8_t& f0,
-                                            const half8_t& f1, int p, int h) {
-  _Float16* row = img + p * IMG_STRIDE + col_base + 4 * h;
-  *reinterpret_cast<half4_t*>(row + 0) = __builtin_shufflevector(f0, f0, 0, 1, 2, 3);
-  *reinterpret_cast<half4_t*>(row + 8) = __builtin_shufflevector(f0, f0, 4, 5, 6, 7);
-  *reinterpret_cast<half4_t*>(row + 16) = __builtin_shufflevector(f1, f1, 0, 1, 2, 3);
-  *reinterpret_cast<half4_t*>(row + 24) = __builtin_shufflevector(f1, f1, 4, 5, 6, 7);
-}
 
 // accumulator -> two f16 fragments, zeroed where the forward activation was <= 0.
 // Packed integer form, 5 VALU ops per f16 pair (the element-wise select compiled to ~12):
@@ -297,24 +247,6 @@ __device__ __forceinline__ void mask_pack(const float16_t& acc, const half8_t& a
   o1 = __builtin_bit_cast(half8_t, r1);
 }
 
-// fragment (A or B operand) for channels col_base + (lane & 31), points 16s + 8h + 0..7
-__device__ __forceinline__ half8_t read_tr(const _Float16* img, int col_base, int s, int lane) {
-  const int h = lane >> 5, li = lane & 15, q = li >> 2, pp = li & 3, grp = (lane >> 4) & 1;
-  const _Float16* a0 = img + (16 * s + 8 * h + q) * IMG_STRIDE + col_base + 16 * grp + 4 * pp;
-  typedef __attribute__((address_space(3))) short4v* lds_p;
-  const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0));
-  const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0 + 4 * IMG_STRIDE));
-  typedef short short8v __attribute__((__vector_size__(8 * sizeof(short))));
-  const short8v both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-  return __builtin_bit_cast(half8_t, both);
-}
-
-__device__ __forceinline__ half8_t pack8(const float16_t& acc, int s) {
-  half8_t b;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) b[j] = (_Float16)acc[8 * s + j];
-  return b;
-}
 
 __device__ __forceinline__ void prefetch_features(const vsa_nt_plan& plan,
                                                   const unsigned* features, int type, int slot,
@@ -322,226 +254,8 @@ __device__ __forceinline__ void prefetch_features(const vsa_nt_plan& plan,
   load_features(features, plan, type, slot < last ? slot : last - 1, h, bx);
 }
 
-__global__ __launch_bounds__(BWD_BLOCK, 1) void nt_mlp_bwd_kernel(
-    vsa_nt_plan plan, EncLaunch L, const _Float16* __restrict__ weights,
-    unsigned* __restrict__ features, const int* __restrict__ seg_start,
-    float* __restrict__ grad_rows, float* __restrict__ grad_weights,
-    float* __restrict__ dfeat_abs_sum) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-  half8_t* s_frag = reinterpret_cast<half8_t*>(s_raw);                       // 32 KiB
-  _Float16* s_img_all = reinterpret_cast<_Float16*>(s_raw + 32 * 64 * 16);   // 8 x 2 regions
-  Work wk;
-  if (!decode_work(plan, L, seg_start, blockIdx.x, wk)) return;
-  const int tex = wk.tex;
-  const TexInfo ti = tex_info(plan, seg_start, tex);
-  stage_weights_bwd(weights + (long long)tex * VSA_NT_WEIGHTS_PER_TEX, s_frag);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
-  const int wave = threadIdx.x >> 6;
-  _Float16* imgA = s_img_all + wave * 2 * IMG_HALFS;
-  _Float16* imgB = imgA + IMG_HALFS;
-  const int ntiles = (wk.last - wk.first + 31) >> 5;
-  const int t0 = wave * BWD_TPW, t1 = min(ntiles, t0 + BWD_TPW);
-
-  float16_t gW3[2], gW2[2][2], gW1[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    gW3[i] = float16_t{0};
-    gW1[i] = float16_t{0};
-    gW2[i][0] = float16_t{0};
-    gW2[i][1] = float16_t{0};
-  }
-
-  half8_t wf[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) wf[i] = s_frag[i * 64 + lane];
-  float16_t dabs = {0};   // per-lane sum |dF| per feature row (for the hash-grad fixed point)
-  // software pipeline: the NEXT tile's features and gradient rows are in flight while
-  // this tile computes (one wave per SIMD: nothing else hides HBM latency)
-  auto load_grows = [&](int slot, float4 gr[4]) {
-    const bool ok = slot < wk.last;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int row0 = 8 * g + 4 * h;
-      gr[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok && row0 < ti.channels) {
-        float4* gp = reinterpret_cast<float4*>(grad_rows) + ti.row_first +
-                     (long long)(slot - ti.begin) * ti.row_quads + (row0 >> 2);
-        gr[g] = *gp;
-        *gp = make_float4(0.f, 0.f, 0.f, 0.f);   // consume-and-clear: zero again for the next frame
-      }
-    }
-  };
-  half8_t bx[2], bx_next[2];
-  float4 gr[4], gr_next[4];
-  if (t0 < t1) {
-    prefetch_features(plan, features, ti.type, wk.first + t0 * 32 + p, wk.last, h, bx_next);
-    load_grows(wk.first + t0 * 32 + p, gr_next);
-  }
-  for (int tile = t0; tile < t1; ++tile) {
-    const int slot = wk.first + tile * 32 + p;
-    const bool valid = slot < wk.last;
-    bx[0] = bx_next[0];
-    bx[1] = bx_next[1];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) gr[g] = gr_next[g];
-    if (tile + 1 < t1) {
-      prefetch_features(plan, features, ti.type, slot + 32, wk.last, h, bx_next);
-      load_grows(slot + 32, gr_next);
-    }
-
-    half8_t b2[4], b3[4];   // H1, H2 (f16, ReLU'd)
-    half8_t d3h[2];
-    {
-      float16_t acc3;
-      mlp_tile_fwd(wf, bx, b2, b3, acc3);
-      // dL/d(pre-sigmoid output): G * sig * (1 - sig)   (round = STE, x255 /255 cancel);
-      // G is zero for padding rows and invalid slots
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float gv[4] = {gr[g].x, gr[g].y, gr[g].z, gr[g].w};
-        if (8 * g < ti.channels) {   // wave-uniform: skip the sigmoids of all-padding row groups
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float sg = sigmoidf_((float)(_Float16)acc3[4 * g + i]);
-            d3h[g >> 1][4 * (g & 1) + i] = (_Float16)(gv[i] * sg * (1.0f - sg));
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) d3h[g >> 1][4 * (g & 1) + i] = (_Float16)0;
-        }
-      }
-    }
-    // ---- dW3 += dOut . H2^T
-    store_frags(imgA, 0, b3[0], b3[1], p, h);
-    store_frags(imgA, 32, b3[2], b3[3], p, h);
-    store_frags(imgB, 0, d3h[0], d3h[1], p, h);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const half8_t a3 = read_tr(imgB, 0, s, lane);
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-        gW3[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3, read_tr(imgA, 32 * m, s, lane), gW3[m], 0, 0, 0);
-    }
-    // ---- dH2 = W3^T dOut, masked by ReLU
-    half8_t dh2[4];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      float16_t a = {0};
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-        a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_frag[(16 + m * 2 + s) * 64 + lane], d3h[s], a, 0, 0, 0);
-      mask_pack(a, b3[2 * m], b3[2 * m + 1], dh2[2 * m], dh2[2 * m + 1]);
-    }
-    // ---- dW2 += dH2 . H1^T
-    store_frags(imgB, 0, dh2[0], dh2[1], p, h);
-    store_frags(imgB, 32, dh2[2], dh2[3], p, h);
-    store_frags(imgA, 0, b2[0], b2[1], p, h);
-    store_frags(imgA, 32, b2[2], b2[3], p, h);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const half8_t b1[2] = {read_tr(imgA, 0, s, lane), read_tr(imgA, 32, s, lane)};
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const half8_t a2 = read_tr(imgB, 32 * m, s, lane);
-#pragma unroll
-        for (int mj = 0; mj < 2; ++mj)
-          gW2[m][mj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b1[mj], gW2[m][mj], 0, 0, 0);
-      }
-    }
-    // ---- dH1 = W2^T dH2, masked by ReLU
-    half8_t dh1[4];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      float16_t a = {0};
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_frag[(20 + m * 4 + q) * 64 + lane], dh2[q], a, 0, 0, 0);
-      mask_pack(a, b2[2 * m], b2[2 * m + 1], dh1[2 * m], dh1[2 * m + 1]);
-    }
-    // ---- dW1 += dH1 . X^T
-    store_frags(imgB, 0, dh1[0], dh1[1], p, h);
-    store_frags(imgB, 32, dh1[2], dh1[3], p, h);
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-      *reinterpret_cast<half8_t*>(imgA + p * IMG_STRIDE + 16 * s + 8 * h) = bx[s];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const half8_t bxx = read_tr(imgA, 0, s, lane);
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-        gW1[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(read_tr(imgB, 32 * m, s, lane), bxx, gW1[m], 0, 0, 0);
-    }
-    // ---- dX = W1^T dH1 -> dF, in place over the features
-    {
-      float16_t dx = {0};
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        dx = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_frag[(28 + q) * 64 + lane], dh1[q], dx, 0, 0, 0);
-      if (valid) {
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) dabs[reg] += fabsf(dx[reg]);
-        unsigned* base = features + nt_feat_plane_base(plan, ti.type, 2 * h) +
-                         nt_feat_in_plane(plan.n_levels, slot);
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            half2_t v;
-            v.x = (_Float16)dx[4 * g + 2 * i];
-            v.y = (_Float16)dx[4 * g + 2 * i + 1];
-            base[(4 * g + i) * NT_FBLOCK] = __builtin_bit_cast(unsigned, v);
-          }
-      }
-    }
-  }
-
-  // ---- sum |dF| per feature row: reduce over the 32 lanes of each half, one atomic per row
-#pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    float v = dabs[reg];
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 32);
-    const int f = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-    if (p == 0 && v != 0.0f) atomicAdd(&dfeat_abs_sum[tex * 32 + f], v);
-  }
-
-  // ---- workgroup reduction of the weight gradients in LDS (waves take turns:
-  // LDS float atomics are slow on gfx950), then one global atomic per weight.
-  __syncthreads();
-  float* s_acc = reinterpret_cast<float*>(s_img_all);   // 8192 floats, aliases the images
-  for (int w = 0; w < BWD_WAVES; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const int i3 = W3_OFF + row * 64 + 32 * m + p;
-          const int i1 = W1_OFF + (32 * m + row) * 32 + p;
-          s_acc[i3] = (w ? s_acc[i3] : 0.0f) + gW3[m][reg];
-          s_acc[i1] = (w ? s_acc[i1] : 0.0f) + gW1[m][reg];
-#pragma unroll
-          for (int mj = 0; mj < 2; ++mj) {
-            const int i2 = W2_OFF + (32 * m + row) * 64 + 32 * mj + p;
-            s_acc[i2] = (w ? s_acc[i2] : 0.0f) + gW2[m][mj][reg];
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-  float* gw = grad_weights + (long long)tex * VSA_NT_WEIGHTS_PER_TEX;
-  const int w3_end = W3_OFF + ti.channels * 64;
-  for (int i = threadIdx.x; i < w3_end; i += BWD_BLOCK) {
-    const float v = s_acc[i];
-    if (v != 0.0f) atomicAdd(&gw[i], v);
-  }
-}
-
-
 // ---------------------------------------------------------------- backward v4
-// Producer / consumer split.  The single-role kernel above needs 128 accumulator
+// Producer / consumer split.  A single-role kernel (one wave doing everything) needs 128 accumulator
 // registers for the weight gradients on top of the recompute + dgrad chain (~410
 // VGPRs -> one wave per SIMD, every MFMA result copied AGPR<->VGPR) and is bound by
 // the ISSUE rate of that one wave (in-kernel stamps: 7.6k cycles per tile, of which
@@ -960,7 +674,7 @@ __device__ __forceinline__ void pc_run(
 }
 
 // Persistent launch: gridDim.x workgroups (one per CU; the LDS footprint allows no more)
-// split the frame's tiles evenly.  Work is laid out on a cost axis: every active texture
+// split the frame's tiles evenly (nt_for_each_piece, nt_common.h): every active texture
 // contributes PC_RUN_COST units of spacing (a run's staging + reduction, measured ~11 loop
 // iterations) followed by one unit per 32-slot tile; workgroup w owns the tiles whose
 // coordinate falls in [w*C/G, (w+1)*C/G).  Replaces one workgroup per 4096 slots of the
@@ -975,35 +689,16 @@ __global__ __launch_bounds__(PC_BLOCK, 2) void nt_mlp_bwd_pc_kernel(
     float* __restrict__ grad_rows, float* __restrict__ grad_weights,
     float* __restrict__ dfeat_abs_sum) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-  const int n_tex = plan.nr_shells * 2 * VSA_NT_MAX_DEG;
-  long long total = 0;
-  for (int tex = 0; tex < n_tex; ++tex) {
-    if (!tex_active(plan, tex)) continue;
-    const int sd = (tex / (2 * VSA_NT_MAX_DEG)) * VSA_NT_MAX_DEG + tex % VSA_NT_MAX_DEG;
-    const int len = seg_start[sd + 1] - seg_start[sd];
-    if (len > 0) total += PC_RUN_COST + ((len + 31) >> 5);
-  }
-  const long long lo = total * blockIdx.x / gridDim.x, hi = total * (blockIdx.x + 1) / gridDim.x;
-  long long c0 = 0;
-  for (int tex = 0; tex < n_tex; ++tex) {
-    if (!tex_active(plan, tex)) continue;
-    const int sd = (tex / (2 * VSA_NT_MAX_DEG)) * VSA_NT_MAX_DEG + tex % VSA_NT_MAX_DEG;
-    const int begin = seg_start[sd], end = seg_start[sd + 1];
-    if (end <= begin) continue;
-    const int ntiles = (end - begin + 31) >> 5;
-    const long long t0 = c0 + PC_RUN_COST;     // coordinate of this texture's tile 0
-    c0 = t0 + ntiles;
-    if (t0 >= hi) break;
-    const long long a = lo > t0 ? lo - t0 : 0, b = hi - t0 < ntiles ? hi - t0 : ntiles;
-    if (b <= a) continue;
+  nt_for_each_piece<32>(plan, seg_start, 1, PC_RUN_COST,
+                        [&](int, int tex, int first, int last, int seg_begin, int seg_end) {
     Work wk;
     wk.tex = tex;
-    wk.seg_len = end - begin;
-    wk.first = begin + (int)a * 32;
-    wk.last = min(end, begin + (int)b * 32);
+    wk.seg_len = seg_end - seg_begin;
+    wk.first = first;
+    wk.last = last;
     pc_run(plan, wk, s_raw, weights, features, seg_start, grad_rows, grad_weights, dfeat_abs_sum);
     __syncthreads();   // the next run re-stages the fragments
-  }
+  });
 }
 
 }  // namespace
@@ -1035,35 +730,18 @@ extern "C" int vsa_nt_mlp_bwd(const vsa_nt_plan* plan, const void* weights_h, vo
   if (!plan || !weights_h || !features || !seg_start || !grad_rows || !grad_weights ||
       !dfeat_abs_sum)
     return VSA_ERR_ARG;
-  static int variant = -1;   // VSA_MLP_BWD=single selects the one-role kernel (A/B runs)
-  if (variant < 0) {
-    const char* e = getenv("VSA_MLP_BWD");
-    variant = (e && e[0] == 's') ? 0 : 1;
-  }
   static bool attr_set = false;
   if (!attr_set) {
-    VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(nt_mlp_bwd_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
     VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(nt_mlp_bwd_pc_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
     attr_set = true;
   }
-  if (variant == 0) {
-    const size_t lds = 32 * 64 * 16 + (size_t)BWD_WAVES * 2 * IMG_HALFS * 2;
-    const EncLaunch L = enc_launch(plan, 0, MLP_BWD_SPAN);
-    dim3 grid(L.per_model * plan->nr_shells * 2);
-    hipLaunchKernelGGL(nt_mlp_bwd_kernel, grid, dim3(BWD_BLOCK), lds, (hipStream_t)stream, *plan, L,
-                       reinterpret_cast<const _Float16*>(weights_h),
-                       reinterpret_cast<unsigned*>(features), seg_start, grad_rows, grad_weights,
-                       dfeat_abs_sum);
-  } else {
-    const size_t lds = (size_t)PC_FRAGS * 64 * 16 + (size_t)PC_PAIRS * PAIR_HALFS * 2;   // >= frags + 32 KiB reduction buffer
-    int nr_cus = 0;
-    { const int rc = vsa_cu_count(&nr_cus); if (rc) return rc; }
-    hipLaunchKernelGGL(nt_mlp_bwd_pc_kernel, dim3(nr_cus), dim3(PC_BLOCK), lds, (hipStream_t)stream,
-                       *plan, reinterpret_cast<const _Float16*>(weights_h),
-                       reinterpret_cast<unsigned*>(features), seg_start, grad_rows, grad_weights,
-                       dfeat_abs_sum);
-  }
+  const size_t lds = (size_t)PC_FRAGS * 64 * 16 + (size_t)PC_PAIRS * PAIR_HALFS * 2;   // >= frags + 32 KiB reduction buffer
+  int nr_cus = 0;
+  { const int rc = vsa_cu_count(&nr_cus); if (rc) return rc; }
+  hipLaunchKernelGGL(nt_mlp_bwd_pc_kernel, dim3(nr_cus), dim3(PC_BLOCK), lds, (hipStream_t)stream,
+                     *plan, reinterpret_cast<const _Float16*>(weights_h),
+                     reinterpret_cast<unsigned*>(features), seg_start, grad_rows, grad_weights,
+                     dfeat_abs_sum);
   VSA_RETURN_LAUNCH_STATUS();
 }
