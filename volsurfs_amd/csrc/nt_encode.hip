@@ -226,7 +226,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
 // of `level`.  NF = 1: feature `feat` only (the plane fills the LDS); NF = 2: both
 // features in one pass over the slots (two planes; levels of <= 16384 entries), which
 // shares the loads, the cell arithmetic and the indices between the features.
-template <bool HASHED, int NF>
+template <bool HASHED, int NF, bool MERGE>
 __device__ __forceinline__ void enc_bwd_piece(
     const vsa_nt_plan& plan, int* s_g, int level, int feat, int tex, int first, int last,
     bool single, const half2_t* __restrict__ dfeatures, const float* __restrict__ dfeat_abs_sum,
@@ -309,7 +309,14 @@ __device__ __forceinline__ void enc_bwd_piece(
           v[f][0] = __float2int_rn(p01.x), v[f][1] = __float2int_rn(p01.y);
           v[f][2] = __float2int_rn(p23.x), v[f][3] = __float2int_rn(p23.y);
         }
-        if (cr.cx == cur_cx && cr.cy == cur_cy) {
+        if (!MERGE) {   // cells are finer than texels: every slot has its own cell
+          unsigned idx[4];
+          cell_indices<HASHED>(g, cr.cx, cr.cy, idx);
+#pragma unroll
+          for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) atomicAdd(&my_g[f * plane + idx[k]], v[f][k]);
+        } else if (cr.cx == cur_cx && cr.cy == cur_cy) {
 #pragma unroll
           for (int f = 0; f < NF; ++f)
 #pragma unroll
@@ -330,7 +337,7 @@ __device__ __forceinline__ void enc_bwd_piece(
         }
       }
     }
-    if (cur_cx != 0xffffffffu) {
+    if (MERGE && cur_cx != 0xffffffffu) {
 #pragma unroll
       for (int f = 0; f < NF; ++f)
 #pragma unroll
@@ -380,12 +387,18 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
       both = enc_both_features(plan, level, HASHED);
     }
     const bool single = first == seg_begin && last == seg_end;
+    // neighbouring texels are scale / R cells apart: from one cell per texel on, the
+    // in-register merging of same-cell slots cannot fire and its bookkeeping is skipped
+    const bool merge = plan.level_scale[level] < (float)plan.tex_res[tex % VSA_NT_MAX_DEG];
     if (both)
-      enc_bwd_piece<HASHED, 2>(plan, s_g, level, 0, tex, first, last, single, dfeatures,
-                               dfeat_abs_sum, dscale_inv, slot_xy, grad_tables);
+      enc_bwd_piece<HASHED, 2, true>(plan, s_g, level, 0, tex, first, last, single, dfeatures,
+                                     dfeat_abs_sum, dscale_inv, slot_xy, grad_tables);
+    else if (merge)
+      enc_bwd_piece<HASHED, 1, true>(plan, s_g, level, r, tex, first, last, single, dfeatures,
+                                     dfeat_abs_sum, dscale_inv, slot_xy, grad_tables);
     else
-      enc_bwd_piece<HASHED, 1>(plan, s_g, level, r, tex, first, last, single, dfeatures,
-                               dfeat_abs_sum, dscale_inv, slot_xy, grad_tables);
+      enc_bwd_piece<HASHED, 1, false>(plan, s_g, level, r, tex, first, last, single, dfeatures,
+                                      dfeat_abs_sum, dscale_inv, slot_xy, grad_tables);
   }, tex_begin, tex_end);
 }
 
