@@ -56,6 +56,7 @@ struct HitCtx {
   float decay;        // alpha decay factor (1 when disabled)
   int row[VSA_NT_MAX_DEG][4];   // first quad of each corner's texel / gradient row
   float w[VSA_NT_MAX_DEG][4];
+  float fx[VSA_NT_MAX_DEG], fy[VSA_NT_MAX_DEG];   // lerp fractions (w = products of these)
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -121,7 +122,14 @@ __device__ __forceinline__ bool load_ctx(const vsa_nt_plan& plan, int s, long lo
   }
   const float u = tex_uv[2 * o], v = tex_uv[2 * o + 1];
   const int D = max(plan.rgb_degrees, plan.alpha_degrees);
-  for (int d = 0; d < D; ++d) {
+#pragma unroll
+  for (int d = 0; d < VSA_NT_MAX_DEG; ++d) {   // static indices: the arrays stay in registers
+    if (d >= D) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) c.row[d][k] = 0, c.w[d][k] = 0.f;
+      c.fx[d] = c.fy[d] = 0.f;
+      continue;
+    }
     const int R = plan.tex_res[d], W = R + 2;
     const NtFootprint f = nt_footprint(u, v, R);
     const long long base = plan.dom_off[s * VSA_NT_MAX_DEG + d] + (long long)(f.j0 + 1) * W + (f.i0 + 1);
@@ -131,6 +139,8 @@ __device__ __forceinline__ bool load_ctx(const vsa_nt_plan& plan, int s, long lo
     c.row[d][1] = rb + slot_of[base + 1] * nt_row_quads(d);
     c.row[d][2] = rb + slot_of[base + W] * nt_row_quads(d);
     c.row[d][3] = rb + slot_of[base + W + 1] * nt_row_quads(d);
+    c.fx[d] = f.fx;
+    c.fy[d] = f.fy;
     c.w[d][0] = (1.0f - f.fx) * (1.0f - f.fy);
     c.w[d][1] = f.fx * (1.0f - f.fy);
     c.w[d][2] = (1.0f - f.fx) * f.fy;
@@ -188,7 +198,73 @@ __device__ __forceinline__ void gather_coeffs(const vsa_nt_plan& plan, const Hit
   }
 }
 
-__global__ __launch_bounds__(SH_BLOCK) void nt_shade_fwd_kernel(
+// Forward of one hit, one SH band at a time: the band's 4 corner rows are expanded, lerped and
+// rounded to fp16 (gather_coeffs's arithmetic), then added to the raw SH sums in coefficient
+// order — the same additions sh_raw performs, so the result is bit-identical, but only one
+// band's coefficients are live (the all-bands-first form needed 197 VGPRs = two waves per
+// SIMD on a kernel that PMC shows waiting on gathers: 16 % VALU-busy).
+__device__ __forceinline__ void shade_hit(const vsa_nt_plan& plan, const HitCtx& c,
+                                          const unsigned* __restrict__ texels, const float* s_lut,
+                                          bool has_alpha, const float b[16], float raw[4],
+                                          float* __restrict__ coeffs_out) {
+  raw[0] = raw[1] = raw[2] = raw[3] = 0.f;
+#pragma unroll
+  for (int d = 0; d < VSA_NT_MAX_DEG; ++d) {
+    const int n = 2 * d + 1, m0 = d * d;
+    const bool do_rgb = d < plan.rgb_degrees, do_a = has_alpha && d < plan.alpha_degrees;
+    if (!do_rgb && !do_a) {
+      if (coeffs_out) {
+#pragma unroll
+        for (int i = 0; i < n; ++i)
+          coeffs_out[m0 + i] = coeffs_out[16 + m0 + i] = coeffs_out[32 + m0 + i] = coeffs_out[48 + m0 + i] = 0.f;
+      }
+      continue;
+    }
+    float acc[28];
+#pragma unroll
+    for (int i = 0; i < 28; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      unsigned wds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      const unsigned* rp = texels + c.row[d][k];
+      if (d == 0) {
+        const uint2 v = *reinterpret_cast<const uint2*>(rp);
+        wds[0] = v.x, wds[1] = v.y;
+      } else {
+        const uint4 lo = *reinterpret_cast<const uint4*>(rp);
+        wds[0] = lo.x, wds[1] = lo.y, wds[2] = lo.z, wds[3] = lo.w;
+        if (d >= 2) {
+          const uint4 hi = *reinterpret_cast<const uint4*>(rp + 4);
+          wds[4] = hi.x, wds[5] = hi.y, wds[6] = hi.z, wds[7] = hi.w;
+        }
+      }
+      const float wk = c.w[d][k];
+#pragma unroll
+      for (int i = 0; i < 3 * n; ++i) {
+        const unsigned q = (wds[i >> 2] >> (8 * (i & 3))) & 255u;
+        acc[i] = acc[i] + s_lut[d * 256 + q] * wk;
+      }
+#pragma unroll
+      for (int i = 0; i < n; ++i) {
+        const unsigned q = (wds[nt_alpha_quad(d) + (i >> 2)] >> (8 * (i & 3))) & 255u;
+        acc[21 + i] = acc[21 + i] + s_lut[d * 256 + q] * wk;
+      }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+      const bool on = ch < 3 ? do_rgb : do_a;
+#pragma unroll
+      for (int i = 0; i < n; ++i) {
+        const int m = m0 + i;
+        const float shv = on ? vsa_round_f16(ch < 3 ? acc[ch * n + i] : acc[21 + i]) : 0.f;
+        if (coeffs_out) coeffs_out[ch * 16 + m] = shv;
+        if (on) raw[ch] = m == 0 ? vsa_round_f16(C0 * shv) : raw[ch] + b[m] * shv;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(SH_BLOCK, 3) void nt_shade_fwd_kernel(
     vsa_nt_plan plan, const int* __restrict__ hit_slot, const float* __restrict__ tex_uv,
     const float* __restrict__ rays_d, const float4* __restrict__ tris,
     const int* __restrict__ slot_of, const int* __restrict__ seg_start,
@@ -207,34 +283,23 @@ __global__ __launch_bounds__(SH_BLOCK) void nt_shade_fwd_kernel(
   float4 act = make_float4(0.f, 0.f, 0.f, 0.f);   // the four sigmoids, for the backward pass
   if (load_ctx(plan, s, n, N, hit_slot, tex_uv, rays_d, tris, slot_of, seg_start, c, nrm)) {
     const bool has_alpha = !(plan.inner_solid && s == 0);
-    float sh_rgb[3][16], sh_a[16];
-    gather_coeffs(plan, c, texels, s_lut, has_alpha, sh_rgb, sh_a);
-    float b[16];
+    float b[16], raw[4];
     sh_basis(c.dir[0], c.dir[1], c.dir[2], b);
+    shade_hit(plan, c, texels, s_lut, has_alpha, b, raw,
+              coeffs_out ? coeffs_out + ((long long)s * N + n) * 64 : nullptr);
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-      const float raw = sh_raw(b, sh_rgb[ch], plan.rgb_degrees);
-      const float sg = sigmoidf_(raw);
+      const float sg = sigmoidf_(raw[ch]);
       (ch == 0 ? act.x : ch == 1 ? act.y : act.z) = sg;
       rgb[ch] = plan.rgb_degrees > 1 ? sg : vsa_round_f16(sg);
     }
     if (has_alpha) {
-      const float raw = sh_raw(b, sh_a, plan.alpha_degrees);
-      const float sg = sigmoidf_(raw);
+      const float sg = sigmoidf_(raw[3]);
       act.w = sg;
       const float a = plan.alpha_degrees > 1 ? sg : vsa_round_f16(sg);
       alpha = a * c.decay;
     } else {
       alpha = 1.0f;
-    }
-    if (coeffs_out) {
-      float* co = coeffs_out + ((long long)s * N + n) * 64;
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch)
-#pragma unroll
-        for (int m = 0; m < 16; ++m) co[ch * 16 + m] = sh_rgb[ch][m];
-#pragma unroll
-      for (int m = 0; m < 16; ++m) co[48 + m] = has_alpha ? sh_a[m] : 0.f;
     }
   } else if (coeffs_out) {
     float* co = coeffs_out + ((long long)s * N + n) * 64;
@@ -257,21 +322,31 @@ __global__ __launch_bounds__(SH_BLOCK) void nt_shade_fwd_kernel(
 // Per hit: g_raw[4] (3 rgb + alpha, through the output sigmoid and the decay) and
 // the 16 SH basis values; then lanes = 64 (channel, coefficient) pairs of one
 // hit at a time add  span_d * w_corner * g_raw[ch] * basis[m]  to the slot rows.
-__global__ __launch_bounds__(SH_BLOCK) void nt_shade_bwd_kernel(
+// RECOMPUTE = false: the caller hands back the forward pass's sigmoids (act_in) and phase 1
+// is a handful of loads; RECOMPUTE = true re-gathers the texel rows.  The per-hit record
+// that phase 2 reads is 47 dwords (4 g_raw, 16 basis, 16 row ids, 2 lerp fractions per band)
+// so that a 128-thread workgroup needs 24 KiB of LDS and 12 waves fit a CU: halving the
+// occupancy of this atomic-bound kernel cost 27 % (measured), i.e. it is latency-sensitive.
+constexpr int SHB_BLOCK = 128;
+
+template <bool RECOMPUTE>
+__global__ __launch_bounds__(SHB_BLOCK, RECOMPUTE ? 2 : 3) void nt_shade_bwd_kernel(
     vsa_nt_plan plan, const int* __restrict__ hit_slot, const float* __restrict__ tex_uv,
     const float* __restrict__ rays_d, const float4* __restrict__ tris,
     const int* __restrict__ slot_of, const int* __restrict__ seg_start,
     const unsigned* __restrict__ texels, int N, const float* __restrict__ g_surfs_rgb,
     const float* __restrict__ g_surfs_alpha, float grad_scale, float* __restrict__ grad_rows,
     const float4* __restrict__ act_in) {
-  __shared__ float s_lut[VSA_NT_MAX_DEG * 256];
-  __shared__ float s_graw[SH_BLOCK][4];
-  __shared__ float s_basis[SH_BLOCK][17];
-  __shared__ int s_row[SH_BLOCK][17];
-  __shared__ float s_w[SH_BLOCK][17];
-  build_lut(plan, s_lut);
-  __syncthreads();
-  const long long n = (long long)blockIdx.x * SH_BLOCK + threadIdx.x;
+  __shared__ float s_lut[RECOMPUTE ? VSA_NT_MAX_DEG * 256 : 1];
+  __shared__ float s_graw[SHB_BLOCK][4];
+  __shared__ float s_basis[SHB_BLOCK][17];
+  __shared__ int s_row[SHB_BLOCK][17];
+  __shared__ float s_f[SHB_BLOCK][9];
+  if (RECOMPUTE) {
+    build_lut(plan, s_lut);
+    __syncthreads();
+  }
+  const long long n = (long long)blockIdx.x * SHB_BLOCK + threadIdx.x;
   const int s = blockIdx.y, K = plan.nr_shells;
   const int t = threadIdx.x;
   HitCtx c;
@@ -283,7 +358,7 @@ __global__ __launch_bounds__(SH_BLOCK) void nt_shade_bwd_kernel(
     sh_basis(c.dir[0], c.dir[1], c.dir[2], b);
     const long long o = n * K + s;
     float sg4[4];
-    if (act_in) {   // the forward pass kept its four sigmoids: no texel gather, no SH sums
+    if (!RECOMPUTE) {   // the forward pass kept its four sigmoids: no texel gather, no SH sums
       const float4 a = act_in[(long long)s * N + n];
       sg4[0] = a.x, sg4[1] = a.y, sg4[2] = a.z, sg4[3] = a.w;
     } else {
@@ -307,12 +382,12 @@ __global__ __launch_bounds__(SH_BLOCK) void nt_shade_bwd_kernel(
 #pragma unroll
     for (int m = 0; m < 16; ++m) s_basis[t][m] = b[m];
 #pragma unroll
-    for (int d = 0; d < VSA_NT_MAX_DEG; ++d)
+    for (int d = 0; d < VSA_NT_MAX_DEG; ++d) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        s_row[t][d * 4 + k] = c.row[d][k];
-        s_w[t][d * 4 + k] = c.w[d][k] * plan.sh_span[d];
-      }
+      for (int k = 0; k < 4; ++k) s_row[t][d * 4 + k] = c.row[d][k];
+      s_f[t][2 * d] = c.fx[d];
+      s_f[t][2 * d + 1] = c.fy[d];
+    }
   }
   // per-wave cooperative scatter (no workgroup barrier needed: each wave reads
   // only what its own lanes wrote)
@@ -324,6 +399,7 @@ __global__ __launch_bounds__(SH_BLOCK) void nt_shade_bwd_kernel(
   const int nn = 2 * d + 1;
   const int fidx = ch < 3 ? ch * nn + (m - d * d) : 4 * nt_alpha_quad(d) + (m - d * d);
   const bool active = ch < 3 ? d < plan.rgb_degrees : (has_alpha && d < plan.alpha_degrees);
+  const float span = plan.sh_span[d];
   // Consecutive hits of a wave are neighbouring pixels: at the coarse degrees
   // (256^2, 512^2 textures) they fall on the SAME or on overlapping 2x2 footprints.
   // Each lane keeps the previous hit's four corner rows open with a running sum; a
@@ -340,12 +416,15 @@ __global__ __launch_bounds__(SH_BLOCK) void nt_shade_bwd_kernel(
     const int ht = wbase + hl;
     if (active) {
       const float g = s_graw[ht][ch] * s_basis[ht][m];
+      const float fx = s_f[ht][2 * d], fy = s_f[ht][2 * d + 1];
+      // the lerp weights exactly as load_ctx forms them, then x span, then x g
+      const float w[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
       int sl[4];
       float v[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         sl[k] = s_row[ht][d * 4 + k];
-        v[k] = s_w[ht][d * 4 + k] * g;
+        v[k] = (w[k] * span) * g;
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -404,10 +483,16 @@ extern "C" int vsa_nt_shade_bwd(const vsa_nt_plan* plan, const int32_t* hit_slot
   if (!hit_slot || !tex_uv || !rays_d || !tris || !slot_of || !seg_start || !texels || !g_surfs_rgb ||
       !g_surfs_alpha || !grad_rows)
     return VSA_ERR_ARG;
-  dim3 grid(vsa_div_up(nr_rays, SH_BLOCK), plan->nr_shells);
-  hipLaunchKernelGGL(nt_shade_bwd_kernel, grid, dim3(SH_BLOCK), 0, (hipStream_t)stream, *plan,
-                     hit_slot, tex_uv, rays_d, reinterpret_cast<const float4*>(tris), slot_of,
-                     seg_start, reinterpret_cast<const unsigned*>(texels), nr_rays, g_surfs_rgb,
-                     g_surfs_alpha, grad_scale, grad_rows, reinterpret_cast<const float4*>(act_in));
+  dim3 grid(vsa_div_up(nr_rays, SHB_BLOCK), plan->nr_shells);
+  if (act_in)
+    hipLaunchKernelGGL(nt_shade_bwd_kernel<false>, grid, dim3(SHB_BLOCK), 0, (hipStream_t)stream, *plan,
+                       hit_slot, tex_uv, rays_d, reinterpret_cast<const float4*>(tris), slot_of,
+                       seg_start, reinterpret_cast<const unsigned*>(texels), nr_rays, g_surfs_rgb,
+                       g_surfs_alpha, grad_scale, grad_rows, reinterpret_cast<const float4*>(act_in));
+  else
+    hipLaunchKernelGGL(nt_shade_bwd_kernel<true>, grid, dim3(SHB_BLOCK), 0, (hipStream_t)stream, *plan,
+                       hit_slot, tex_uv, rays_d, reinterpret_cast<const float4*>(tris), slot_of,
+                       seg_start, reinterpret_cast<const unsigned*>(texels), nr_rays, g_surfs_rgb,
+                       g_surfs_alpha, grad_scale, grad_rows, nullptr);
   VSA_RETURN_LAUNCH_STATUS();
 }
