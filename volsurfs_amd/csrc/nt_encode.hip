@@ -18,7 +18,11 @@
 namespace {
 
 constexpr int ENC_BLOCK = 1024;     // 16 waves: a 128 KiB level pins one workgroup per CU
-constexpr int ENC_UNROLL = 8;       // slots in flight per lane
+constexpr int ENC_UNROLL = 8;       // slots in flight per lane (backward)
+#ifndef ENC_UNROLL_FWD_N
+#define ENC_UNROLL_FWD_N 4
+#endif
+constexpr int ENC_UNROLL_FWD = ENC_UNROLL_FWD_N;   // forward
 constexpr int ENC_UNIT = 256;       // slot granularity of the persistent work split (nt_common.h)
 constexpr unsigned PRIME_Y = 2654435761u;
 constexpr int LDS_ENTRIES = 32768;    // 4-byte entries of LDS a workgroup may use (128 KiB)
@@ -148,27 +152,27 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
     __syncthreads();
     const int type = (tex / VSA_NT_MAX_DEG) & 1;
     half2_t* out = features + nt_feat_plane_base(plan, type, level);
-    // A lane owns ENC_UNROLL = 8 consecutive slots (neighbouring texels of one texture
+    // A lane owns ENC_UNROLL_FWD consecutive slots (neighbouring texels of one texture
     // row): 64 B of texel centres in, 32 B of features out per lane as dwordx4 accesses,
     // and the 4 LDS gathers are skipped while consecutive slots stay in one grid cell.
-    const int a_first = first & ~(ENC_UNROLL - 1);
-    for (int s0 = a_first + threadIdx.x * ENC_UNROLL; s0 < last; s0 += ENC_BLOCK * ENC_UNROLL) {
-      float4 xyv[ENC_UNROLL / 2];
+    const int a_first = first & ~(ENC_UNROLL_FWD - 1);
+    for (int s0 = a_first + threadIdx.x * ENC_UNROLL_FWD; s0 < last; s0 += ENC_BLOCK * ENC_UNROLL_FWD) {
+      float4 xyv[ENC_UNROLL_FWD / 2];
       const float4* xp = reinterpret_cast<const float4*>(slot_xy + s0);
 #pragma unroll
-      for (int i = 0; i < ENC_UNROLL / 2; ++i) xyv[i] = xp[i];
-      CellRefS cr[ENC_UNROLL];
-      bool fresh[ENC_UNROLL];
+      for (int i = 0; i < ENC_UNROLL_FWD / 2; ++i) xyv[i] = xp[i];
+      CellRefS cr[ENC_UNROLL_FWD];
+      bool fresh[ENC_UNROLL_FWD];
 #pragma unroll
-      for (int u = 0; u < ENC_UNROLL; ++u) {
+      for (int u = 0; u < ENC_UNROLL_FWD; ++u) {
         const float x = (u & 1) ? xyv[u >> 1].z : xyv[u >> 1].x;
         const float y = (u & 1) ? xyv[u >> 1].w : xyv[u >> 1].y;
         cr[u] = cell_ref_s(g, x, y);
         fresh[u] = u == 0 || cr[u].cx != cr[u - 1].cx || cr[u].cy != cr[u - 1].cy;
       }
-      half2_t v[ENC_UNROLL][4];
+      half2_t v[ENC_UNROLL_FWD][4];
 #pragma unroll
-      for (int u = 0; u < ENC_UNROLL; ++u) {
+      for (int u = 0; u < ENC_UNROLL_FWD; ++u) {
         if (fresh[u]) {
           unsigned idx[4];
           cell_indices<HASHED>(g, cr[u].cx, cr[u].cy, idx);
@@ -176,9 +180,9 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
           for (int k = 0; k < 4; ++k) v[u][k] = s_tab[idx[k]];
         }
       }
-      unsigned outw[ENC_UNROLL];
+      unsigned outw[ENC_UNROLL_FWD];
 #pragma unroll
-      for (int u = 0; u < ENC_UNROLL; ++u) {
+      for (int u = 0; u < ENC_UNROLL_FWD; ++u) {
         if (u > 0 && !fresh[u]) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) v[u][k] = v[u - 1][k];
@@ -195,13 +199,14 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
         outw[u] = __builtin_bit_cast(unsigned, r);
       }
       unsigned* op = reinterpret_cast<unsigned*>(out) + nt_feat_in_plane(nl, s0);
-      if (s0 >= first && s0 + ENC_UNROLL <= last) {
+      if (s0 >= first && s0 + ENC_UNROLL_FWD <= last) {
         uint4* o4 = reinterpret_cast<uint4*>(op);
-        o4[0] = make_uint4(outw[0], outw[1], outw[2], outw[3]);
-        o4[1] = make_uint4(outw[4], outw[5], outw[6], outw[7]);
+#pragma unroll
+        for (int i = 0; i < ENC_UNROLL_FWD / 4; ++i)
+          o4[i] = make_uint4(outw[4 * i], outw[4 * i + 1], outw[4 * i + 2], outw[4 * i + 3]);
       } else {
 #pragma unroll
-        for (int u = 0; u < ENC_UNROLL; ++u)
+        for (int u = 0; u < ENC_UNROLL_FWD; ++u)
           if (s0 + u >= first && s0 + u < last) op[u] = outw[u];
       }
     }
