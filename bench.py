@@ -40,6 +40,10 @@ def parse():
                     help="1 GPU: run the multi-GPU schedule (shell-by-shell hash-grid backward, eager) "
                          "without the collectives, to price it")
     ap.add_argument("--cpu-sample-rays", type=int, default=4096)
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="functional tests of the multi-rank path on one GPU: gloo + --single-device")
+    ap.add_argument("--single-device", action="store_true",
+                    help="all ranks use cuda:0 (testing only; RCCL refuses two ranks on one GPU)")
     return ap.parse_args()
 
 
@@ -77,14 +81,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev_index = local_rank if (world > 1 and not args.single_device) else 0
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.dist_backend)
     else:
         dist = None
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
     torch.manual_seed(42 + rank)
 
     from volsurfs_amd.pipeline import KShellPipeline
