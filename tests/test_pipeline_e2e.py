@@ -137,3 +137,34 @@ def test_full_size_frame_properties():
         assert s > 0 and (g1 - g2).abs().max().item() < 2e-2 * s
         cos = torch.nn.functional.cosine_similarity(g1.flatten(), g2.flatten(), dim=0)
         assert cos > 0.999
+
+
+@pytest.mark.gpu
+def test_degenerate_frames():
+    """Edge cases of the whole step: a frame in which every ray misses every shell (zero
+    slots: the persistent kernels have no work), and a one-ray frame."""
+    from volsurfs_amd.camera import pinhole_rays
+    from volsurfs_amd.pipeline import KShellPipeline
+    pipe = KShellPipeline.synthetic(K=2, subdiv=2, res=16, init="spread", seed=1)
+    # look away from the shells: no hits at all
+    pipe.rays_d = (-pipe.rays_d).contiguous()
+    rgb = pipe.step()
+    torch.cuda.synchronize()
+    hits, slots = pipe.stats()
+    assert hits == 0 and slots == 0
+    assert torch.equal(rgb, torch.ones_like(rgb))                     # white background
+    assert pipe.bank.tables.grad.abs().sum() == 0 and pipe.bank.weights.grad.abs().sum() == 0
+    # the same pipeline renders normally afterwards
+    pipe.rays_d = (-pipe.rays_d).contiguous()
+    rgb = pipe.step()
+    hits, slots = pipe.stats()
+    assert hits > 0 and slots > 0 and pipe.bank.tables.grad.abs().sum() > 0
+    # a single ray through the centre
+    one = KShellPipeline(pipe.meshes, torch.tensor([[0.0, 0.0, -1.5]]).cuda(),
+                         torch.tensor([[0.0, 0.0, 1.0]]).cuda(), torch.rand(1, 3).cuda(), seed=1,
+                         init="spread")
+    r = one.step()
+    torch.cuda.synchronize()
+    h, sl = one.stats()
+    assert r.shape == (1, 3) and h == 2 and 8 <= sl <= 32 and torch.isfinite(r).all()
+    assert one.bank.weights.grad.abs().sum() > 0
