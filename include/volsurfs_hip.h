@@ -361,6 +361,25 @@ int vsa_contract_samples(const float* ray_o, const int32_t* start_end, const flo
                          const float* samples_z, float* out_samples_3d, float* out_samples_z,
                          int nr_rays, void* stream);
 
+/* Ops of the sibling methods reached through the same pybind module.
+ * VolumeRendering::sum_over_rays (src/VolumeRendering.cu:231-324): values [S,dim], dim in
+ * {1,2,3,32} -> sum_per_ray [N,dim] and the same sum repeated per sample [S,dim]; backward
+ * g_values = g_sum_per_ray[ray] + g_sum_per_sample (kernels/volsurfs/VolumeRenderingGPU.cuh:1036-1077). */
+int vsa_packed_sum_over_rays(const int32_t* start_end, const float* values, float* sum_per_ray,
+                             float* sum_per_sample, int nr_rays, int dim, void* stream);
+int vsa_packed_sum_over_rays_bwd(const int32_t* start_end, const float* g_sum_per_ray,
+                                 const float* g_sum_per_sample, float* g_values, int nr_rays,
+                                 int dim, void* stream);
+/* VolumeRendering::sdf2alpha (src/VolumeRendering.cu:178-229): alpha [S,1] (zero-initialised by
+ * the caller; the last sample of a ray is not written) from samples_dt, samples_sdf and the
+ * per-sample logistic beta. */
+int vsa_packed_sdf2alpha(const int32_t* start_end, const float* samples_dt, const float* samples_sdf,
+                         const float* logistic_beta, float* alpha, int nr_rays, void* stream);
+/* VolumeRendering::compute_cdf (src/VolumeRendering.cu:418-465): cdf [S,1], zero-initialised by
+ * the caller. */
+int vsa_packed_compute_cdf(const int32_t* start_end, const float* weights, float* cdf, int nr_rays,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

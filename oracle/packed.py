@@ -205,3 +205,67 @@ def contract(ray_o, start_end, s3d, sz):
         s3d[i0:i1] = np.where(m[:, None], pc, p)
         sz[i0:i1] = np.where(m, zc, sz[i0:i1])
     return s3d, sz
+
+
+# ---- ops of the sibling methods, same serial per-ray loops
+def sum_over_rays(start_end, values):
+    """VolumeRenderingGPU.cuh:246-303."""
+    v = np.asarray(values, f32)
+    per_ray = np.zeros((start_end.shape[0], v.shape[1]), f32)
+    per_sample = np.zeros_like(v)
+    for r, i0, i1 in _rays(start_end):
+        acc = np.zeros(v.shape[1], f32)
+        for i in range(i0, i1):
+            acc = (acc + v[i]).astype(f32)
+        if i1 > i0:
+            per_ray[r] = acc
+            per_sample[i0:i1] = acc
+    return per_ray, per_sample
+
+
+def sum_over_rays_bwd(start_end, g_ray, g_sample):
+    """VolumeRenderingGPU.cuh:1036-1077."""
+    g = np.zeros_like(np.asarray(g_sample, f32))
+    for r, i0, i1 in _rays(start_end):
+        g[i0:i1] = (np.asarray(g_ray, f32)[r][None, :] + np.asarray(g_sample, f32)[i0:i1]).astype(f32)
+    return g
+
+
+def _sigmoid_ref(x):
+    """:179-183  float res = 1.0 / (1.0 + exp(-x)) with a float argument."""
+    with np.errstate(over="ignore"):          # exp overflows to inf like expf does: 1/(1+inf) = 0
+        return f32(1.0 / (1.0 + np.float64(np.exp(f32(-x), dtype=f32))))
+
+
+def sdf2alpha(start_end, dt, sdf, beta):
+    """VolumeRenderingGPU.cuh:185-244; double literals promote the marked intermediates."""
+    dt, sdf, beta = (np.asarray(a, f32).reshape(-1) for a in (dt, sdf, beta))
+    alpha = np.zeros_like(sdf)
+    for r, i0, i1 in _rays(start_end):
+        for i in range(i0, i1 - 1):
+            d, prev, nxt = dt[i], sdf[i], sdf[i + 1]
+            mid = f32(np.float64(f32(prev + nxt)) * 0.5)
+            cosv = f32(np.float64(f32(nxt - prev)) / (np.float64(d) + 1e-6))
+            cosv = f32(min(max(cosv, f32(-1e3)), f32(0.0)))
+            half = np.float64(f32(cosv * d)) * 0.5
+            prev_e, next_e = f32(np.float64(mid) - half), f32(np.float64(mid) + half)
+            pc, nc = _sigmoid_ref(f32(prev_e * beta[i])), _sigmoid_ref(f32(next_e * beta[i]))
+            alpha[i] = f32((np.float64(f32(pc - nc)) + 1e-6) / (np.float64(pc) + 1e-6))
+    return alpha
+
+
+def compute_cdf(start_end, weights):
+    """VolumeRenderingGPU.cuh:412-460."""
+    w = np.asarray(weights, f32).reshape(-1)
+    cdf = np.zeros_like(w)
+    for r, i0, i1 in _rays(start_end):
+        if i1 - i0 < 2:
+            continue
+        c, tot = f32(0.0), f32(0.0)
+        for i in range(i0, i1):
+            cdf[i] = c
+            tot = f32(tot + w[i])
+            c = f32(c + w[i])
+        if abs(np.float64(tot) - 1.0) < 1e-3 and abs(np.float64(cdf[i1 - 1]) - 1.0) > 1e-3:
+            cdf[i1 - 1] = f32(1.0)
+    return cdf

@@ -219,3 +219,68 @@ def test_render_contracted_bg_end_to_end_vs_oracle():
         np.testing.assert_allclose(gh.cpu().numpy(), pc.grad.numpy(), rtol=2e-3, atol=2e-4)
     md = OP.median_depth(s["ray_start_end_idx"], s["samples_z"], (alpha * T).detach().numpy(), 0.5)
     assert (res["median_depth"].cpu().numpy()[:, 0] != md).mean() < 0.01
+
+
+def test_oracle_sibling_ops_known_answers():
+    """SURVEY §8f row 4 ops: hand-checkable cases of the restated kernels."""
+    se = np.array([[0, 3], [3, 3], [3, 5], [5, 6]], np.int32)
+    v = np.arange(12, dtype=np.float32).reshape(6, 2)
+    per_ray, per_sample = OP.sum_over_rays(se, v)
+    assert per_ray.tolist() == [[6.0, 9.0], [0.0, 0.0], [14.0, 16.0], [10.0, 11.0]]
+    assert per_sample[:3].tolist() == [[6.0, 9.0]] * 3 and per_sample[5].tolist() == [10.0, 11.0]
+    g = OP.sum_over_rays_bwd(se, np.ones((4, 2), np.float32), v)
+    assert np.array_equal(g, v + 1)
+    # cdf: exclusive running sum; a ray whose weights sum to 1 keeps cdf[-1] = 1 - w_last,
+    # snapped to exactly 1 only if it is more than 1e-3 away
+    w = np.array([0.25, 0.25, 0.5, 0.3, 0.7, 1.0], np.float32)
+    cdf = OP.compute_cdf(se, w)
+    assert cdf.tolist() == [0.0, 0.25, 1.0, 0.0, 1.0, 0.0]      # last entries snapped; 1-sample ray untouched
+    # sdf2alpha: a surface crossing gives alpha in (0, 1), the last sample of each ray stays 0
+    a = OP.sdf2alpha(se, np.full(6, 0.1, np.float32), np.array([0.2, 0.1, -0.1, 0.3, 0.25, 0.0], np.float32),
+                     np.full(6, 50.0, np.float32))
+    assert a[2] == 0 and a[4] == 0 and a[5] == 0 and 0 < a[0] < a[1] < 1
+
+
+@pytest.mark.gpu
+def test_hip_sibling_ops_vs_oracle():
+    from volsurfs_amd.volsurfs import SumOverRaysFunc, VolumeRendering as VR
+    se, S = _ragged(2500, 11)
+    g = np.random.default_rng(12)
+    cu = lambda x: torch.from_numpy(x).cuda()
+    p = _pack(se)
+    for D in (1, 2, 3, 32):
+        v = g.standard_normal((S, D)).astype(np.float32)
+        per_ray, per_sample = VR.sum_over_rays(p, cu(v))
+        rr, rs = OP.sum_over_rays(se, v)
+        np.testing.assert_allclose(per_ray.cpu().numpy(), rr, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(per_sample.cpu().numpy(), rs, rtol=1e-5, atol=1e-5)
+        gr, gs = g.standard_normal((2500, D)).astype(np.float32), g.standard_normal((S, D)).astype(np.float32)
+        gv = VR.sum_over_rays_backward(cu(gr), cu(gs), p, cu(v))
+        assert np.array_equal(gv.cpu().numpy(), OP.sum_over_rays_bwd(se, gr, gs))
+    # autograd glue (volume_rendering_funcs.py:244-272)
+    vt = cu(g.standard_normal((S, 3)).astype(np.float32)).requires_grad_(True)
+    pr, ps = SumOverRaysFunc.apply(p, vt)
+    (pr.sum() + (ps * 2).sum()).backward()
+    # the reference's backward (VolumeRenderingGPU.cuh:1036-1077) adds the ray's gradient to the
+    # sample's OWN per-sample gradient (it does not sum the per-sample gradients over the ray)
+    torch.testing.assert_close(vt.grad, torch.full_like(vt.grad, 3.0))
+    # cdf
+    w = g.uniform(0, 0.1, (S, 1)).astype(np.float32)
+    for r in range(0, 2500, 7):                       # some rays normalised to sum 1
+        i0, i1 = se[r]
+        if i1 - i0 >= 2:
+            w[i0:i1] /= w[i0:i1].sum()
+    cdf = VR.compute_cdf(p, cu(w)).cpu().numpy()[:, 0]
+    ref = OP.compute_cdf(se, w)
+    np.testing.assert_allclose(cdf, ref, rtol=1e-5, atol=1e-6)
+    assert (cdf == 1.0).sum() == (ref == 1.0).sum() > 50
+    # sdf2alpha (needs dt on the pack)
+    p.samples_dt = cu(g.uniform(0.01, 0.2, (S, 1)).astype(np.float32))
+    p.has_dt = True
+    sdf = g.standard_normal((S, 1)).astype(np.float32) * 0.2
+    beta = g.uniform(5, 200, (S, 1)).astype(np.float32)
+    al = VR.sdf2alpha(p, cu(sdf), cu(beta)).cpu().numpy()[:, 0]
+    ref = OP.sdf2alpha(se, p.samples_dt.cpu().numpy(), sdf, beta)
+    np.testing.assert_allclose(al, ref, rtol=2e-5, atol=2e-6)   # expf implementations differ by an ulp
+    last = se[se[:, 1] > se[:, 0], 1] - 1
+    assert (al[last] == 0).all()

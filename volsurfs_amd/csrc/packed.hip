@@ -337,6 +337,96 @@ __global__ void contract_kernel(const float* __restrict__ ray_o, const int* __re
 
 inline dim3 pk_grid(int N) { return dim3(vsa_div_up((long long)N * SUB, PK_BLOCK)); }
 
+
+// ---- ops of the sibling methods: sum_over_rays, sdf2alpha, compute_cdf
+// VolumeRenderingGPU.cuh:246-303 / :1036-1077: per-ray sum of D-wide sample values, also
+// broadcast back to the ray's samples; backward g_v[i] = g_sum[ray] + g_per_sample[i].
+template <int D>
+__global__ void sum_over_rays_kernel(const int* __restrict__ start_end, const float* __restrict__ v,
+                                     float* __restrict__ sum_ray, float* __restrict__ sum_sample,
+                                     int N) {
+  PK_RAY_PROLOGUE();
+  if (n <= 0) return;
+  float acc[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) acc[d] = 0.f;
+  for (int c = 0; c < n; c += SUB) {
+    const int i = c + l;
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc[d] += sub_reduce_add(i < n ? v[(long long)(i0 + i) * D + d] : 0.f);
+  }
+  if (l == 0) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) sum_ray[ray * D + d] = acc[d];
+  }
+  for (int i = l; i < n; i += SUB) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) sum_sample[(long long)(i0 + i) * D + d] = acc[d];
+  }
+}
+
+template <int D>
+__global__ void sum_over_rays_bwd_kernel(const int* __restrict__ start_end,
+                                         const float* __restrict__ g_ray,
+                                         const float* __restrict__ g_sample,
+                                         float* __restrict__ g_v, int N) {
+  PK_RAY_PROLOGUE();
+  for (int i = l; i < n; i += SUB) {
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      g_v[(long long)(i0 + i) * D + d] = g_ray[ray * D + d] + g_sample[(long long)(i0 + i) * D + d];
+  }
+}
+
+// VolumeRenderingGPU.cuh:185-244 (NeuS alpha from consecutive SDF samples).  The reference
+// mixes float variables with double literals, so several intermediate results are formed in
+// double and rounded to float on assignment; reproduced operation by operation.
+__device__ __forceinline__ float sigmoid_ref(float x) {   // :179-183: float res = 1.0 / (1.0 + exp(-x))
+  return (float)(1.0 / (1.0 + (double)expf(-x)));
+}
+
+__global__ void sdf2alpha_kernel(const int* __restrict__ start_end, const float* __restrict__ dt,
+                                 const float* __restrict__ sdf, const float* __restrict__ beta,
+                                 float* __restrict__ alpha, int N) {
+  PK_RAY_PROLOGUE();
+  for (int i = l; i < n - 1; i += SUB) {
+    const float d = dt[i0 + i];
+    const float prev = sdf[i0 + i], next = sdf[i0 + i + 1];
+    const float mid = (float)((double)(prev + next) * 0.5);
+    float cosv = (float)((double)(next - prev) / ((double)d + 1e-6));
+    cosv = fminf(fmaxf(cosv, -1e3f), 0.0f);
+    const float prev_esti = (float)((double)mid - (double)(cosv * d) * 0.5);
+    const float next_esti = (float)((double)mid + (double)(cosv * d) * 0.5);
+    const float b = beta[i0 + i];
+    const float prev_cdf = sigmoid_ref(prev_esti * b), next_cdf = sigmoid_ref(next_esti * b);
+    alpha[i0 + i] = (float)(((double)(prev_cdf - next_cdf) + 1e-6) / ((double)prev_cdf + 1e-6));
+  }
+}
+
+// VolumeRenderingGPU.cuh:412-460: exclusive running sum of the weights per ray; if the
+// weights sum to ~1 the last entry is snapped to 1.  Rays with fewer than 2 samples are left
+// at zero (the reference prints and returns).
+__global__ void compute_cdf_kernel(const int* __restrict__ start_end, const float* __restrict__ w,
+                                   float* __restrict__ cdf, int N) {
+  PK_RAY_PROLOGUE();
+  if (n < 2) return;
+  float carry = 0.0f;
+  float last_cdf = 0.0f;
+  for (int c = 0; c < n; c += SUB) {
+    const int i = c + l;
+    const float x = i < n ? w[i0 + i] : 0.0f;
+    const float incl = sub_scan_add(x, l);
+    const float excl = carry + (incl - x);
+    if (i < n) cdf[i0 + i] = excl;
+    if (i == n - 1) last_cdf = excl;
+    carry += __shfl(incl, SUB - 1, SUB);
+  }
+  // carry = sum of all weights; the lane that owns the last sample applies the snap
+  const int owner = (n - 1) & (SUB - 1);
+  if (l == owner && fabs((double)carry - 1.0) < 1e-3 && fabs((double)last_cdf - 1.0) > 1e-3)
+    cdf[i1 - 1] = 1.0f;
+}
+
 }  // namespace
 
 #define PK_CHECK(cond) \
@@ -423,4 +513,48 @@ extern "C" int vsa_contract_samples(const float* ray_o, const int32_t* start_end
            out_samples_z);
   PK_LAUNCH(contract_kernel, nr_rays, ray_o, start_end, samples_3d, samples_z, out_samples_3d,
             out_samples_z, nr_rays);
+}
+
+extern "C" int vsa_packed_sum_over_rays(const int32_t* start_end, const float* values,
+                                        float* sum_per_ray, float* sum_per_sample, int nr_rays,
+                                        int dim, void* stream) {
+  PK_CHECK(nr_rays >= 0 && start_end && values && sum_per_ray && sum_per_sample &&
+           (dim == 1 || dim == 2 || dim == 3 || dim == 32));
+  if (dim == 1) {
+    PK_LAUNCH(sum_over_rays_kernel<1>, nr_rays, start_end, values, sum_per_ray, sum_per_sample, nr_rays);
+  }
+  if (dim == 2) {
+    PK_LAUNCH(sum_over_rays_kernel<2>, nr_rays, start_end, values, sum_per_ray, sum_per_sample, nr_rays);
+  }
+  if (dim == 3) {
+    PK_LAUNCH(sum_over_rays_kernel<3>, nr_rays, start_end, values, sum_per_ray, sum_per_sample, nr_rays);
+  }
+  PK_LAUNCH(sum_over_rays_kernel<32>, nr_rays, start_end, values, sum_per_ray, sum_per_sample, nr_rays);
+}
+extern "C" int vsa_packed_sum_over_rays_bwd(const int32_t* start_end, const float* g_sum_per_ray,
+                                            const float* g_sum_per_sample, float* g_values,
+                                            int nr_rays, int dim, void* stream) {
+  PK_CHECK(nr_rays >= 0 && start_end && g_sum_per_ray && g_sum_per_sample && g_values &&
+           (dim == 1 || dim == 2 || dim == 3 || dim == 32));
+  if (dim == 1) {
+    PK_LAUNCH(sum_over_rays_bwd_kernel<1>, nr_rays, start_end, g_sum_per_ray, g_sum_per_sample, g_values, nr_rays);
+  }
+  if (dim == 2) {
+    PK_LAUNCH(sum_over_rays_bwd_kernel<2>, nr_rays, start_end, g_sum_per_ray, g_sum_per_sample, g_values, nr_rays);
+  }
+  if (dim == 3) {
+    PK_LAUNCH(sum_over_rays_bwd_kernel<3>, nr_rays, start_end, g_sum_per_ray, g_sum_per_sample, g_values, nr_rays);
+  }
+  PK_LAUNCH(sum_over_rays_bwd_kernel<32>, nr_rays, start_end, g_sum_per_ray, g_sum_per_sample, g_values, nr_rays);
+}
+extern "C" int vsa_packed_sdf2alpha(const int32_t* start_end, const float* samples_dt,
+                                    const float* samples_sdf, const float* logistic_beta,
+                                    float* alpha, int nr_rays, void* stream) {
+  PK_CHECK(nr_rays >= 0 && start_end && samples_dt && samples_sdf && logistic_beta && alpha);
+  PK_LAUNCH(sdf2alpha_kernel, nr_rays, start_end, samples_dt, samples_sdf, logistic_beta, alpha, nr_rays);
+}
+extern "C" int vsa_packed_compute_cdf(const int32_t* start_end, const float* weights, float* cdf,
+                                      int nr_rays, void* stream) {
+  PK_CHECK(nr_rays >= 0 && start_end && weights && cdf);
+  PK_LAUNCH(compute_cdf_kernel, nr_rays, start_end, weights, cdf, nr_rays);
 }

@@ -224,9 +224,48 @@ class VolumeRendering:
         raise NotImplementedError(f"VolumeRendering.{name}: used only by nerf/surf/offsets_surfs "
                                   "(SURVEY §8f row 4), not on the VolSurfs path")
 
-    sdf2alpha = staticmethod(lambda *a: VolumeRendering._todo("sdf2alpha"))
-    sum_over_rays = staticmethod(lambda *a: VolumeRendering._todo("sum_over_rays"))
-    compute_cdf = staticmethod(lambda *a: VolumeRendering._todo("compute_cdf"))
+    @staticmethod
+    def sdf2alpha(pack, samples_sdf, logistic_beta):
+        """src/VolumeRendering.cu:178-229 (NeuS alpha; needs pack.samples_dt)."""
+        _check_pack(pack, (samples_sdf, 1), (logistic_beta, 1))
+        if not pack.has_dt:
+            raise _lib.VolsurfsHipError("ray_samples_packed should have dt")
+        alpha = torch.zeros_like(samples_sdf)
+        _lib.call("vsa_packed_sdf2alpha", pack.ray_start_end_idx, pack.samples_dt,
+                  samples_sdf.contiguous(), logistic_beta.contiguous(), alpha, pack.get_nr_rays(),
+                  _lib.stream_ptr())
+        return alpha
+
+    @staticmethod
+    def sum_over_rays(pack, samples_values):
+        """src/VolumeRendering.cu:231-324 -> (sum_per_ray [N,D], sum_per_sample [S,D]), D in 1,2,3,32."""
+        D = samples_values.shape[1]
+        if D not in (1, 2, 3, 32):
+            raise _lib.VolsurfsHipError(f"sum_over_rays: value dim {D} not supported (1, 2, 3, 32)")
+        _check_pack(pack, (samples_values, D))
+        per_ray = torch.zeros(pack.get_nr_rays(), D, device=samples_values.device)
+        per_sample = torch.zeros_like(samples_values)
+        _lib.call("vsa_packed_sum_over_rays", pack.ray_start_end_idx, samples_values.contiguous(),
+                  per_ray, per_sample, pack.get_nr_rays(), D, _lib.stream_ptr())
+        return per_ray, per_sample
+
+    @staticmethod
+    def sum_over_rays_backward(grad_per_ray, grad_per_sample, pack, samples_values):
+        D = samples_values.shape[1]
+        g = torch.zeros_like(samples_values)
+        _lib.call("vsa_packed_sum_over_rays_bwd", pack.ray_start_end_idx, grad_per_ray.contiguous(),
+                  grad_per_sample.contiguous(), g, pack.get_nr_rays(), D, _lib.stream_ptr())
+        return g
+
+    @staticmethod
+    def compute_cdf(pack, samples_weights):
+        """src/VolumeRendering.cu:418-465."""
+        _check_pack(pack, (samples_weights, 1))
+        cdf = torch.zeros_like(samples_weights)
+        _lib.call("vsa_packed_compute_cdf", pack.ray_start_end_idx, samples_weights.contiguous(), cdf,
+                  pack.get_nr_rays(), _lib.stream_ptr())
+        return cdf
+
     importance_sample = staticmethod(lambda *a: VolumeRendering._todo("importance_sample"))
     combine_ray_samples_packets = staticmethod(lambda *a: VolumeRendering._todo("combine_ray_samples_packets"))
 
@@ -353,3 +392,22 @@ class IntegrateWithWeights1DFunc(torch.autograd.Function):
                                                                     weights, out)
         ctx.pack = None
         return None, gv, gw
+
+
+class SumOverRaysFunc(torch.autograd.Function):
+    """volume_rendering_funcs.py:244-272."""
+
+    @staticmethod
+    def forward(ctx, ray_samples_packed, sample_values):
+        per_ray, per_sample = VolumeRendering.sum_over_rays(ray_samples_packed, sample_values)
+        ctx.save_for_backward(sample_values)
+        ctx.ray_samples_packed = ray_samples_packed
+        return per_ray, per_sample
+
+    @staticmethod
+    def backward(ctx, grad_per_ray, grad_per_sample):
+        (sample_values,) = ctx.saved_tensors
+        g = VolumeRendering.sum_over_rays_backward(grad_per_ray, grad_per_sample,
+                                                   ctx.ray_samples_packed, sample_values)
+        ctx.ray_samples_packed = None
+        return None, g
