@@ -13,6 +13,8 @@
 //
 // Arithmetic is the oracle's (oracle/tcnn_like.py hashgrid_forward), fp32, in
 // the same order, so features are bit-identical.
+#include <type_traits>
+
 #include "nt_common.h"
 
 namespace {
@@ -153,63 +155,72 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
     const int type = (tex / VSA_NT_MAX_DEG) & 1;
     half2_t* out = features + nt_feat_plane_base(plan, type, level);
     // A lane owns ENC_UNROLL_FWD consecutive slots (neighbouring texels of one texture
-    // row): 64 B of texel centres in, 32 B of features out per lane as dwordx4 accesses,
-    // and the 4 LDS gathers are skipped while consecutive slots stay in one grid cell.
+    // row): 32 B of texel centres in, 16 B of features out per lane as dwordx4 accesses.
+    // REUSE (levels coarser than the texture): the 4 LDS gathers are skipped while
+    // consecutive slots stay in one grid cell; at finer levels that never happens and the
+    // bookkeeping (11 moves + 3 branches per slot in the ISA) is left out.
     const int a_first = first & ~(ENC_UNROLL_FWD - 1);
-    for (int s0 = a_first + threadIdx.x * ENC_UNROLL_FWD; s0 < last; s0 += ENC_BLOCK * ENC_UNROLL_FWD) {
-      float4 xyv[ENC_UNROLL_FWD / 2];
-      const float4* xp = reinterpret_cast<const float4*>(slot_xy + s0);
+    auto run = [&](auto reuse_tag) {
+      constexpr bool REUSE = decltype(reuse_tag)::value;
+      for (int s0 = a_first + threadIdx.x * ENC_UNROLL_FWD; s0 < last; s0 += ENC_BLOCK * ENC_UNROLL_FWD) {
+        float4 xyv[ENC_UNROLL_FWD / 2];
+        const float4* xp = reinterpret_cast<const float4*>(slot_xy + s0);
 #pragma unroll
-      for (int i = 0; i < ENC_UNROLL_FWD / 2; ++i) xyv[i] = xp[i];
-      CellRefS cr[ENC_UNROLL_FWD];
-      bool fresh[ENC_UNROLL_FWD];
+        for (int i = 0; i < ENC_UNROLL_FWD / 2; ++i) xyv[i] = xp[i];
+        CellRefS cr[ENC_UNROLL_FWD];
+        bool fresh[ENC_UNROLL_FWD];
 #pragma unroll
-      for (int u = 0; u < ENC_UNROLL_FWD; ++u) {
-        const float x = (u & 1) ? xyv[u >> 1].z : xyv[u >> 1].x;
-        const float y = (u & 1) ? xyv[u >> 1].w : xyv[u >> 1].y;
-        cr[u] = cell_ref_s(g, x, y);
-        fresh[u] = u == 0 || cr[u].cx != cr[u - 1].cx || cr[u].cy != cr[u - 1].cy;
-      }
-      half2_t v[ENC_UNROLL_FWD][4];
+        for (int u = 0; u < ENC_UNROLL_FWD; ++u) {
+          const float x = (u & 1) ? xyv[u >> 1].z : xyv[u >> 1].x;
+          const float y = (u & 1) ? xyv[u >> 1].w : xyv[u >> 1].y;
+          cr[u] = cell_ref_s(g, x, y);
+          fresh[u] = !REUSE || u == 0 || cr[u].cx != cr[u - 1].cx || cr[u].cy != cr[u - 1].cy;
+        }
+        half2_t v[ENC_UNROLL_FWD][4];
 #pragma unroll
-      for (int u = 0; u < ENC_UNROLL_FWD; ++u) {
-        if (fresh[u]) {
-          unsigned idx[4];
-          cell_indices<HASHED>(g, cr[u].cx, cr[u].cy, idx);
+        for (int u = 0; u < ENC_UNROLL_FWD; ++u) {
+          if (fresh[u]) {
+            unsigned idx[4];
+            cell_indices<HASHED>(g, cr[u].cx, cr[u].cy, idx);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[u][k] = s_tab[idx[k]];
+            for (int k = 0; k < 4; ++k) v[u][k] = s_tab[idx[k]];
+          }
+        }
+        unsigned outw[ENC_UNROLL_FWD];
+#pragma unroll
+        for (int u = 0; u < ENC_UNROLL_FWD; ++u) {
+          if (REUSE && u > 0 && !fresh[u]) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[u][k] = v[u - 1][k];
+          }
+          float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            f0 = f0 + cr[u].w[k] * (float)v[u][k].x;
+            f1 = f1 + cr[u].w[k] * (float)v[u][k].y;
+          }
+          half2_t r;
+          r.x = (_Float16)f0;
+          r.y = (_Float16)f1;
+          outw[u] = __builtin_bit_cast(unsigned, r);
+        }
+        unsigned* op = reinterpret_cast<unsigned*>(out) + nt_feat_in_plane(nl, s0);
+        if (s0 >= first && s0 + ENC_UNROLL_FWD <= last) {
+          uint4* o4 = reinterpret_cast<uint4*>(op);
+#pragma unroll
+          for (int i = 0; i < ENC_UNROLL_FWD / 4; ++i)
+            o4[i] = make_uint4(outw[4 * i], outw[4 * i + 1], outw[4 * i + 2], outw[4 * i + 3]);
+        } else {
+#pragma unroll
+          for (int u = 0; u < ENC_UNROLL_FWD; ++u)
+            if (s0 + u >= first && s0 + u < last) op[u] = outw[u];
         }
       }
-      unsigned outw[ENC_UNROLL_FWD];
-#pragma unroll
-      for (int u = 0; u < ENC_UNROLL_FWD; ++u) {
-        if (u > 0 && !fresh[u]) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[u][k] = v[u - 1][k];
-        }
-        float f0 = 0.f, f1 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          f0 = f0 + cr[u].w[k] * (float)v[u][k].x;
-          f1 = f1 + cr[u].w[k] * (float)v[u][k].y;
-        }
-        half2_t r;
-        r.x = (_Float16)f0;
-        r.y = (_Float16)f1;
-        outw[u] = __builtin_bit_cast(unsigned, r);
-      }
-      unsigned* op = reinterpret_cast<unsigned*>(out) + nt_feat_in_plane(nl, s0);
-      if (s0 >= first && s0 + ENC_UNROLL_FWD <= last) {
-        uint4* o4 = reinterpret_cast<uint4*>(op);
-#pragma unroll
-        for (int i = 0; i < ENC_UNROLL_FWD / 4; ++i)
-          o4[i] = make_uint4(outw[4 * i], outw[4 * i + 1], outw[4 * i + 2], outw[4 * i + 3]);
-      } else {
-#pragma unroll
-        for (int u = 0; u < ENC_UNROLL_FWD; ++u)
-          if (s0 + u >= first && s0 + u < last) op[u] = outw[u];
-      }
-    }
+    };
+    if (g.scale < (float)plan.tex_res[tex % VSA_NT_MAX_DEG])
+      run(std::true_type{});
+    else
+      run(std::false_type{});
   });
 }
 
