@@ -23,3 +23,33 @@ def test_exported_symbols_are_c_linkage():
     exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
     for n in _lib.declared_symbols():
         assert n in exported
+
+
+def test_argument_errors_are_reported_not_ignored():
+    """Every entry point validates its arguments before touching the device and returns a
+    negative VSA_ERR_* status (SURVEY §8b "Errors": never continue silently); checked here
+    without a GPU, through the paths that return before any launch."""
+    import pytest
+    L = _lib.lib()
+    null = ctypes.c_void_p(0)
+    ERR_ARG, ERR_UNSUPPORTED = -1, -2
+    hdr = open(_lib.HEADER_PATH).read()
+    assert "#define VSA_ERR_ARG (-1)" in hdr and "#define VSA_ERR_UNSUPPORTED (-2)" in hdr
+    assert L.vsa_composite_dense_fwd(null, null, null, 0, null, null, null, null, null, null, 10, 5, 0, null) == ERR_ARG
+    assert L.vsa_composite_dense_bwd_l1(null, null, null, 0, null, null, ctypes.c_float(1.0), null, null, 10, 5, 0, null) == ERR_ARG
+    assert L.vsa_trace(null, null, null, 1, 10, null, null, 10, ctypes.c_float(0), null, null, null, null) == ERR_ARG
+    roots = (ctypes.c_int32 * 1)(0)
+    assert L.vsa_trace(null, null, roots, 1, 99, null, null, 10, ctypes.c_float(0), null, null, null, null) == ERR_UNSUPPORTED   # tree deeper than the stack
+    assert L.vsa_trace(null, null, roots, 1, 10, null, null, 0, ctypes.c_float(0), null, null, null, null) == 0                 # empty batch is fine
+    assert L.vsa_trace(null, null, roots, 17, 10, null, null, 10, ctypes.c_float(0), null, null, null, null) == ERR_ARG        # > VSA_MAX_SHELLS
+    assert L.vsa_nt_encode_fwd(null, null, null, null, null, null) == ERR_ARG
+    assert L.vsa_nt_mlp_bwd(null, null, null, null, null, null, null, null) == ERR_ARG
+    assert L.vsa_nt_shade_fwd(null, null, null, null, null, null, null, null, 10, null, null, null, null, null, null) == ERR_ARG
+    assert L.vsa_grid_encode_fwd(null, null, null, 10, null, null) == ERR_ARG
+    assert L.vsa_sh_encode(null, 10, 7, null, null) == ERR_ARG                                   # degree > 4
+    assert L.vsa_packed_sum_over_rays(null, null, null, null, 10, 1, null) == ERR_ARG
+    h = ctypes.c_void_p()
+    assert L.vsa_bvh_build(null, null, 0, 0, 4, ctypes.byref(h)) != 0
+    # the Python layer turns any non-zero status into an exception
+    with pytest.raises(_lib.VolsurfsHipError):
+        _lib.call("vsa_sh_encode", None, 10, 7, None, None)
