@@ -104,16 +104,22 @@ __global__ __launch_bounds__(256) void grid_encode_fwd_kernel(vsa_grid_plan plan
   out[b * plan.n_levels + l] = make_float2(f0, f1);
 }
 
+// Two lanes per (sample, level), one per feature: the two float atomics of an entry sit in
+// adjacent lanes and leave the wave as ONE 64-byte request instead of two instructions'
+// worth (the kernel is bound by the L2 atomic request rate: 53 ms for 2.1 M samples x 24
+// levels before, see tools/bench_bg.py).
 template <int D>
 __global__ __launch_bounds__(256) void grid_encode_bwd_kernel(vsa_grid_plan plan,
                                                               const float* __restrict__ x,
-                                                              const float2* __restrict__ g_out,
+                                                              const float* __restrict__ g_out,
                                                               int B, float* __restrict__ g_tables) {
-  const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long b = t >> 1;
+  const int f = (int)(t & 1);
   const int l = blockIdx.y;
   if (b >= B) return;
-  const float2 go = g_out[b * plan.n_levels + l];
-  if (go.x == 0.f && go.y == 0.f) return;
+  const float go = g_out[(b * plan.n_levels + l) * 2 + f];
+  if (go == 0.f) return;
   const GridLevel g = grid_level(plan, l);
   const GridCell<D> cell = grid_cell<D>(g, x + b * D);
 #pragma unroll
@@ -122,9 +128,7 @@ __global__ __launch_bounds__(256) void grid_encode_bwd_kernel(vsa_grid_plan plan
 #pragma unroll
     for (int d = 0; d < D; ++d) c[d] = cell.c[d] + ((corner >> d) & 1);
     const float w = corner_weight<D>(cell, corner);
-    float* dst = g_tables + 2 * (long long)(g.offset + grid_index<D>(g, c));
-    atomicAdd(dst, w * go.x);
-    atomicAdd(dst + 1, w * go.y);
+    atomicAdd(g_tables + 2 * (long long)(g.offset + grid_index<D>(g, c)) + f, w * go);
   }
 }
 
@@ -213,13 +217,13 @@ extern "C" int vsa_grid_encode_bwd(const vsa_grid_plan* plan, const float* x, co
   if (nr_points < 0) return VSA_ERR_ARG;
   if (nr_points == 0) return VSA_OK;
   if (!x || !g_out || !grad_tables) return VSA_ERR_ARG;
-  dim3 grid(vsa_div_up(nr_points, 256), plan->n_levels);
+  dim3 grid(vsa_div_up(2ll * nr_points, 256), plan->n_levels);
   if (plan->n_dims == 2)
     hipLaunchKernelGGL(grid_encode_bwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, *plan, x,
-                       reinterpret_cast<const float2*>(g_out), nr_points, grad_tables);
+                       g_out, nr_points, grad_tables);
   else
     hipLaunchKernelGGL(grid_encode_bwd_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, *plan, x,
-                       reinterpret_cast<const float2*>(g_out), nr_points, grad_tables);
+                       g_out, nr_points, grad_tables);
   VSA_RETURN_LAUNCH_STATUS();
 }
 

@@ -19,6 +19,27 @@ from .encodings import SHEncoder, get_encoder
 from .neural_textures import MAX_DEG  # noqa: F401  (re-exported for symmetry)
 
 
+class _LinearBiasByGemv(torch.autograd.Function):
+    """y = x W^T + b with the bias gradient formed as ones[1,B] @ g (a rocBLAS GEMV).  ATen's
+    column-sum reduction took 6.6 ms per layer on the background path's [2.1 M, 64] gradients
+    (27 % of that step, tools/bench_bg.py); forward and the other gradients are F.linear's."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = g @ weight if ctx.needs_input_grad[0] else None
+        gw = g.t() @ x if ctx.needs_input_grad[1] else None
+        gb = (torch.ones(1, g.shape[0], device=g.device, dtype=g.dtype) @ g)[0] \
+            if ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
 class MLP(torch.nn.Module):
     """models/mlp.py:8-69: Linear + GELU stack, optional linear last layer."""
 
@@ -40,7 +61,13 @@ class MLP(torch.nn.Module):
         self.layers = torch.nn.Sequential(*modules)
 
     def forward(self, x):
-        return self.layers(x)
+        for layer in self.layers:
+            if isinstance(layer, torch.nn.Linear) and layer.bias is not None and x.dim() == 2 \
+                    and torch.is_grad_enabled():
+                x = _LinearBiasByGemv.apply(x, layer.weight, layer.bias)
+            else:
+                x = layer(x)
+        return x
 
     def reset(self):
         for layer in self.layers:
