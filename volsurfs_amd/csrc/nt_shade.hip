@@ -324,13 +324,13 @@ __global__ __launch_bounds__(SH_BLOCK, 3) void nt_shade_fwd_kernel(
 // hit at a time add  span_d * w_corner * g_raw[ch] * basis[m]  to the slot rows.
 // RECOMPUTE = false: the caller hands back the forward pass's sigmoids (act_in) and phase 1
 // is a handful of loads; RECOMPUTE = true re-gathers the texel rows.  The per-hit record
-// that phase 2 reads is 47 dwords (4 g_raw, 16 basis, 16 row ids, 2 lerp fractions per band)
-// so that a 128-thread workgroup needs 24 KiB of LDS and 12 waves fit a CU: halving the
+// that phase 2 reads is 39 dwords (4 g_raw, 16 basis, 2 row ids + 2 lerp fractions per band)
+// so that a 128-thread workgroup needs 20 KiB of LDS and 16 waves fit a CU: halving the
 // occupancy of this atomic-bound kernel cost 27 % (measured), i.e. it is latency-sensitive.
 constexpr int SHB_BLOCK = 128;
 
 template <bool RECOMPUTE>
-__global__ __launch_bounds__(SHB_BLOCK, RECOMPUTE ? 2 : 3) void nt_shade_bwd_kernel(
+__global__ __launch_bounds__(SHB_BLOCK, RECOMPUTE ? 2 : 4) void nt_shade_bwd_kernel(
     vsa_nt_plan plan, const int* __restrict__ hit_slot, const float* __restrict__ tex_uv,
     const float* __restrict__ rays_d, const float4* __restrict__ tris,
     const int* __restrict__ slot_of, const int* __restrict__ seg_start,
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(SHB_BLOCK, RECOMPUTE ? 2 : 3) void nt_shade_bwd_ker
   __shared__ float s_lut[RECOMPUTE ? VSA_NT_MAX_DEG * 256 : 1];
   __shared__ float s_graw[SHB_BLOCK][4];
   __shared__ float s_basis[SHB_BLOCK][17];
-  __shared__ int s_row[SHB_BLOCK][17];
+  __shared__ int s_row[SHB_BLOCK][9];    // corners (x0,y0) and (x0,y1) per band; x1 = the next slot's row
   __shared__ float s_f[SHB_BLOCK][9];
   if (RECOMPUTE) {
     build_lut(plan, s_lut);
@@ -383,8 +383,10 @@ __global__ __launch_bounds__(SHB_BLOCK, RECOMPUTE ? 2 : 3) void nt_shade_bwd_ker
     for (int m = 0; m < 16; ++m) s_basis[t][m] = b[m];
 #pragma unroll
     for (int d = 0; d < VSA_NT_MAX_DEG; ++d) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) s_row[t][d * 4 + k] = c.row[d][k];
+      // slots are numbered in domain order and all four corners are marked, so the x1
+      // corner is always the slot right after the x0 corner
+      s_row[t][2 * d] = c.row[d][0];
+      s_row[t][2 * d + 1] = c.row[d][2];
       s_f[t][2 * d] = c.fx[d];
       s_f[t][2 * d + 1] = c.fy[d];
     }
@@ -421,11 +423,10 @@ __global__ __launch_bounds__(SHB_BLOCK, RECOMPUTE ? 2 : 3) void nt_shade_bwd_ker
       const float w[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
       int sl[4];
       float v[4];
+      const int r0 = s_row[ht][2 * d], r2 = s_row[ht][2 * d + 1], qd = nt_row_quads(d);
+      sl[0] = r0, sl[1] = r0 + qd, sl[2] = r2, sl[3] = r2 + qd;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        sl[k] = s_row[ht][d * 4 + k];
-        v[k] = (w[k] * span) * g;
-      }
+      for (int k = 0; k < 4; ++k) v[k] = (w[k] * span) * g;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         bool kept = false;
