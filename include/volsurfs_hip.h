@@ -380,6 +380,31 @@ int vsa_packed_sdf2alpha(const int32_t* start_end, const float* samples_dt, cons
 int vsa_packed_compute_cdf(const int32_t* start_end, const float* weights, float* cdf, int nr_rays,
                            void* stream);
 
+/* RaySampler::compute_samples_fg (src/RaySampler.cu:158-240, kernels/volsurfs/RaySamplerGPU.cuh:141-270):
+ * uniform steps >= min_dist between t_entry and t_exit, at most max_n per ray, rays with fewer
+ * than min_n samples get none; ray i writes slots [i*max_n, ...).  Outputs as the
+ * RaySamplesPacked fields (caller-initialised to the constructor's values); compact afterwards. */
+int vsa_sample_fg(const float* rays_o, const float* rays_d, const float* ray_t_entry,
+                  const float* ray_t_exit, float min_dist_between_samples,
+                  int min_nr_samples_per_ray, int max_nr_samples_per_ray, int jitter,
+                  uint64_t rng_state, uint64_t rng_inc, float* ray_max_dt, int32_t* samples_idx,
+                  float* samples_3d, float* samples_dirs, float* samples_z,
+                  int32_t* ray_start_end_idx, int nr_rays, void* stream);
+/* RaySamplesPacked::compact_to_valid_samples (src/RaySamplesPacked.cu:188-273): out_start [N] =
+ * exclusive scan of the per-ray sample counts (caller). */
+int vsa_pack_compact(const int32_t* start_end, const int32_t* out_start, const int32_t* samples_idx,
+                     const float* samples_3d, const float* samples_dirs, const float* samples_z,
+                     const float* samples_dt, const float* samples_values, int values_dim,
+                     int32_t* out_idx, float* out_3d, float* out_dirs, float* out_z, float* out_dt,
+                     float* out_values, int32_t* out_start_end, int nr_rays, void* stream);
+/* VolumeRendering::importance_sample (src/VolumeRendering.cu:467-560): nr_importance_samples new
+ * depths per ray by inverting the ray's cdf; ray i writes slots [i*n, (i+1)*n). */
+int vsa_importance_sample(const float* rays_o, const float* rays_d, const int32_t* start_end,
+                          const float* samples_z, const float* samples_cdf,
+                          int nr_importance_samples, int jitter, uint64_t rng_state,
+                          uint64_t rng_inc, float* out_3d, float* out_dirs, float* out_z,
+                          int32_t* out_start_end, int nr_rays, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -269,3 +269,99 @@ def compute_cdf(start_end, weights):
         if abs(np.float64(tot) - 1.0) < 1e-3 and abs(np.float64(cdf[i1 - 1]) - 1.0) > 1e-3:
             cdf[i1 - 1] = f32(1.0)
     return cdf
+
+
+def sample_fg(rays_o, rays_d, t_entry, t_exit, min_dist, min_n, max_n, jitter=False, rng=None):
+    """RaySamplerGPU.cuh:141-270 followed by the compaction of RaySamplesPacked.cu:188-273:
+    returns the compacted z / 3d / dirs / start_end / ray_max_dt."""
+    rays_o, rays_d = np.asarray(rays_o, f32), np.asarray(rays_d, f32)
+    N = rays_o.shape[0]
+    zs, se, max_dt = [], np.zeros((N, 2), np.int32), np.full(N, -1.0, f32)
+    cursor = 0
+    for r in range(N):
+        t_start, t_end = f32(t_entry[r]), f32(t_exit[r])
+        dist = f32(t_end - t_start)
+        to_create, step = 0, f32(0.0)
+        if dist > 0:
+            if dist > f32(min_dist):
+                to_create = int(f32(dist / f32(min_dist)))
+                to_create = min(max(to_create, 0), max_n)
+                step = f32(dist / f32(to_create))
+            else:
+                to_create, step = 1, dist
+        out = []
+        if to_create > 0 and to_create >= min_n:
+            t = t_start
+            if jitter:
+                g = rng.copy()
+                g.advance(r)
+                t = f32(t + f32(step * g.next_float()))
+            while t < t_end:
+                t = min(max(t, t_start), t_end)
+                if len(out) >= to_create:
+                    break
+                out.append(t)
+                t = f32(t + step)
+        if len(out) < min_n:
+            out = []
+        else:
+            max_dt[r] = step
+        # rays without samples keep the constructor's (-1, -1) (RaySamplesPacked.cu:27-28)
+        se[r] = (cursor, cursor + len(out)) if out else (-1, -1)
+        cursor += len(out)
+        zs.append((r, out))
+    z = np.zeros(cursor, f32)
+    s3d, dirs = np.zeros((cursor, 3), f32), np.zeros((cursor, 3), f32)
+    for r, out in zs:
+        for k, t in enumerate(out):
+            i = se[r, 0] + k
+            z[i] = t
+            s3d[i] = (rays_o[r] + f32(t) * rays_d[r]).astype(f32)
+            dirs[i] = rays_d[r]
+    return {"samples_z": z, "samples_3d": s3d, "samples_dirs": dirs, "ray_start_end_idx": se,
+            "ray_max_dt": max_dt}
+
+
+def _map_range_val(v, i0, i1, o0, o1):
+    """VolumeRenderingGPU.cuh:15-21 (all float)."""
+    c = max(f32(i0), min(f32(i1), f32(v)))
+    if i0 >= i1:
+        return f32(o1)
+    return f32(f32(o0) + f32(f32(f32(o1) - f32(o0)) / f32(f32(i1) - f32(i0))) * f32(c - f32(i0)))
+
+
+def importance_sample(rays_o, rays_d, start_end, z, cdf, n_imp, jitter=False, rng=None):
+    """VolumeRenderingGPU.cuh:462-678 (+ compaction): every ray with samples gets n_imp new ones."""
+    rays_o, rays_d = np.asarray(rays_o, f32), np.asarray(rays_d, f32)
+    z, cdf = np.asarray(z, f32).reshape(-1), np.asarray(cdf, f32).reshape(-1)
+    out_z, out_se, cursor = [], np.zeros((start_end.shape[0], 2), np.int32), 0
+    for r, u0, u1 in _rays(start_end):
+        if u1 - u0 == 0:
+            out_se[r] = (-1, -1)
+            continue
+        g = rng.copy() if jitter else None
+        dist = f32(1.0 / (n_imp + 1))
+        for i in range(n_imp):
+            ur = f32(dist + f32(i * dist))
+            if jitter:
+                g.advance(r)
+                rand = g.next_float()
+                mov = f32(np.float64(dist) / 2.0)
+                ur = f32(ur + _map_range_val(rand, 0.0, 1.0, -mov, mov))
+            ur = min(max(ur, f32(0.0 + 1e-6)), f32(1.0 - 1e-6))
+            imin, imax = u0, u1 - 1
+            while imax >= imin:
+                imid = imin + (imax - imin) // 2
+                if cdf[imid] > ur:
+                    imax = imid
+                else:
+                    imin = imid
+                if imax - imin == 1 or imax == imin:
+                    break
+            lo = max(imax - 1, 0)
+            out_z.append((r, _map_range_val(ur, cdf[lo], cdf[imax], z[lo], z[imax])))
+        out_se[r] = (cursor, cursor + n_imp)
+        cursor += n_imp
+    zz = np.array([t for _, t in out_z], f32)
+    s3d = np.stack([(rays_o[r] + f32(t) * rays_d[r]).astype(f32) for r, t in out_z]) if out_z else np.zeros((0, 3), f32)
+    return {"samples_z": zz, "samples_3d": s3d, "ray_start_end_idx": out_se}

@@ -284,3 +284,55 @@ def test_hip_sibling_ops_vs_oracle():
     np.testing.assert_allclose(al, ref, rtol=2e-5, atol=2e-6)   # expf implementations differ by an ulp
     last = se[se[:, 1] > se[:, 0], 1] - 1
     assert (al[last] == 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("jitter", [False, True])
+def test_hip_fg_sampler_compaction_importance_sampling_vs_oracle(jitter):
+    """RaySampler.compute_samples_fg -> compact_to_valid_samples -> compute_cdf ->
+    VolumeRendering.importance_sample (the NeRF / NeuS sampling chain of the sibling methods)."""
+    from volsurfs_amd.volsurfs import RaySampler, VolumeRendering as VR, _Pcg32State
+    g = np.random.default_rng(21)
+    N = 700
+    o = g.standard_normal((N, 3)).astype(np.float32) * 0.1
+    d = g.standard_normal((N, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    t0 = g.uniform(0.1, 0.5, (N, 1)).astype(np.float32)
+    t1 = (t0 + g.uniform(-0.1, 1.2, (N, 1))).astype(np.float32)     # some rays exit before they enter
+    t1[:3] = t0[:3] + np.array([[0.0], [0.004], [5.0]], np.float32)    # empty, one sample, clamped to max_n
+    cu = lambda x: torch.from_numpy(x).cuda()
+    RaySampler.m_rng = _Pcg32State()
+    VR.m_rng = _Pcg32State()
+    rng0 = OP.Pcg32(RaySampler.m_rng.state, RaySampler.m_rng.inc)
+    pack = RaySampler.compute_samples_fg(cu(o), cu(d), cu(t0), cu(t1), 0.01, 1, 64, jitter, 0)
+    ref = OP.sample_fg(o, d, t0[:, 0], t1[:, 0], 0.01, 1, 64, jitter=jitter, rng=rng0)
+    assert pack.is_compacted and pack.get_total_nr_samples() == ref["samples_z"].shape[0] > 5000
+    assert np.array_equal(pack.ray_start_end_idx.cpu().numpy(), ref["ray_start_end_idx"])
+    assert np.array_equal(pack.samples_z.cpu().numpy()[:, 0], ref["samples_z"])
+    np.testing.assert_allclose(pack.samples_3d.cpu().numpy(), ref["samples_3d"], rtol=0, atol=2e-7)
+    assert np.array_equal(pack.samples_dirs.cpu().numpy(), ref["samples_dirs"])
+    has = ref["ray_max_dt"] >= 0
+    assert np.array_equal(pack.ray_max_dt.cpu().numpy()[has, 0], ref["ray_max_dt"][has])
+    se = ref["ray_start_end_idx"]
+    assert se[0, 1] - se[0, 0] == 0 and se[1, 1] - se[1, 0] == 1 and se[2, 1] - se[2, 0] == 64
+    # importance sampling from a cdf over those samples
+    S = pack.get_total_nr_samples()
+    w = g.uniform(0, 1, (S, 1)).astype(np.float32)
+    for r in range(N):
+        a, b = se[r]
+        if b - a >= 2:
+            w[a:b] /= w[a:b].sum()
+    cdf = VR.compute_cdf(pack, cu(w))
+    multi = (se[:, 1] - se[:, 0]) >= 2                 # the reference never importance-samples 1-sample rays
+    keep = np.repeat(multi, se[:, 1] - se[:, 0])
+    rng1 = OP.Pcg32(VR.m_rng.state, VR.m_rng.inc)
+    imp = VR.importance_sample(pack, cdf, 16, jitter)
+    ref_i = OP.importance_sample(o, d, se, ref["samples_z"], cdf.cpu().numpy(), 16, jitter=jitter, rng=rng1)
+    got_se, ref_se = imp.ray_start_end_idx.cpu().numpy(), ref_i["ray_start_end_idx"]
+    assert np.array_equal(got_se[:, 1] - got_se[:, 0], ref_se[:, 1] - ref_se[:, 0])
+    zi, zr = imp.samples_z.cpu().numpy()[:, 0], ref_i["samples_z"]
+    rows = np.repeat(multi, ref_se[:, 1] - ref_se[:, 0])
+    assert rows.sum() > 5000 and np.array_equal(zi[rows], zr[rows])
+    assert (np.diff(zi.reshape(-1, 16)[multi[(ref_se[:, 1] - ref_se[:, 0]) > 0]], axis=1) >= 0).all()   # sorted per ray
+    if jitter:      # the static generators were advanced like the reference's m_rng
+        assert RaySampler.m_rng.state != rng0.state and VR.m_rng.state != rng1.state

@@ -427,6 +427,159 @@ __global__ void compute_cdf_kernel(const int* __restrict__ start_end, const floa
     cdf[i1 - 1] = 1.0f;
 }
 
+
+// ---- foreground sampling chain of the sibling methods
+// RaySamplerGPU.cuh:141-270 compute_samples_fg: uniform steps of >= min_dist between the
+// ray's entry and exit.  One thread per ray: the sample depths come from the serial
+// accumulation t += step, which is part of the result; the slot layout is the reference's
+// (ray i owns slots [i*max_n, (i+1)*max_n)), compacted afterwards.
+__global__ void sample_fg_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                 const float* __restrict__ t_entry, const float* __restrict__ t_exit_in,
+                                 float min_dist, int min_n, int max_n, int jitter,
+                                 unsigned long long rng_state, unsigned long long rng_inc,
+                                 float* __restrict__ ray_max_dt, int* __restrict__ samples_idx,
+                                 float* __restrict__ s3d, float* __restrict__ sdirs,
+                                 float* __restrict__ sz, int* __restrict__ start_end, int N) {
+  const long long ray = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ray >= N) return;
+  const float t_start = t_entry[ray], t_exit = t_exit_in[ray];
+  const float ox = rays_o[3 * ray], oy = rays_o[3 * ray + 1], oz = rays_o[3 * ray + 2];
+  const float dx = rays_d[3 * ray], dy = rays_d[3 * ray + 1], dz = rays_d[3 * ray + 2];
+  const float dist = t_exit - t_start;
+  int to_create = 0;
+  float step = 0.0f;
+  if (dist > 0.0f) {
+    if (dist > min_dist) {
+      to_create = (int)(dist / min_dist);
+      to_create = min(max(to_create, 0), max_n);
+      step = dist / to_create;
+    } else {
+      to_create = 1;
+      step = dist;
+    }
+  }
+  int created = 0;
+  const long long s0 = ray * max_n;
+  if (to_create > 0 && to_create >= min_n) {
+    float t = t_start;
+    if (jitter) {
+      Pcg32 rng{rng_state, rng_inc};
+      rng.advance((unsigned long long)ray);
+      t = t + step * rng.next_float();
+    }
+    while (t < t_exit) {
+      t = fminf(fmaxf(t, t_start), t_exit);
+      if (created >= to_create) break;
+      const long long o = s0 + created;
+      s3d[3 * o] = ox + t * dx;
+      s3d[3 * o + 1] = oy + t * dy;
+      s3d[3 * o + 2] = oz + t * dz;
+      sdirs[3 * o] = dx;
+      sdirs[3 * o + 1] = dy;
+      sdirs[3 * o + 2] = dz;
+      sz[o] = t;
+      t += step;
+      created += 1;
+    }
+  }
+  if (created < min_n) {
+    created = 0;
+  } else {
+    ray_max_dt[ray] = step;
+    start_end[2 * ray] = (int)s0;
+    start_end[2 * ray + 1] = (int)s0 + created;
+  }
+  for (int i = created; i < max_n; ++i) samples_idx[s0 + i] = -1;
+}
+
+// RaySamplesPackedGPU.cuh:172-257 compact_to_valid_samples: copy every ray's samples to its
+// offset in the compacted pack (out_start = exclusive scan of the per-ray counts, computed
+// by the caller).  Half-wave per ray, lanes = samples.
+__global__ void pack_compact_kernel(const int* __restrict__ start_end, const int* __restrict__ out_start,
+                                    const int* __restrict__ idx, const float* __restrict__ s3d,
+                                    const float* __restrict__ sdirs, const float* __restrict__ sz,
+                                    const float* __restrict__ sdt, const float* __restrict__ sval,
+                                    int V, int* __restrict__ o_idx, float* __restrict__ o_3d,
+                                    float* __restrict__ o_dirs, float* __restrict__ o_z,
+                                    float* __restrict__ o_dt, float* __restrict__ o_val,
+                                    int* __restrict__ o_start_end, int N) {
+  PK_RAY_PROLOGUE();
+  if (n <= 0) return;
+  const int o0 = out_start[ray];
+  for (int i = l; i < n; i += SUB) {
+    const long long a = i0 + i, b = o0 + i;
+    o_idx[b] = idx[a];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      o_3d[3 * b + c] = s3d[3 * a + c];
+      o_dirs[3 * b + c] = sdirs[3 * a + c];
+    }
+    o_z[b] = sz[a];
+    o_dt[b] = sdt[a];
+    for (int j = 0; j < V; ++j) o_val[b * V + j] = sval[a * V + j];
+  }
+  if (l == 0) {
+    o_start_end[2 * ray] = o0;
+    o_start_end[2 * ray + 1] = o0 + n;
+  }
+}
+
+// VolumeRenderingGPU.cuh:15-21
+__device__ __forceinline__ float map_range_val_ref(float v, float i0, float i1, float o0, float o1) {
+  const float c = fmaxf(i0, fminf(i1, v));
+  if (i0 >= i1) return o1;
+  return o0 + ((o1 - o0) / (i1 - i0)) * (c - i0);
+}
+
+// VolumeRenderingGPU.cuh:462-505 (binary search in a ray's cdf) and :507-678
+// importance_sample: one thread per (ray, new sample); the jittered variant replays the
+// reference's per-thread stream (advance(ray) + one draw per sample) by skipping ahead.
+__global__ void importance_sample_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                         const int* __restrict__ start_end, const float* __restrict__ sz,
+                                         const float* __restrict__ cdf, int n_imp, int jitter,
+                                         unsigned long long rng_state, unsigned long long rng_inc,
+                                         float* __restrict__ o_3d, float* __restrict__ o_dirs,
+                                         float* __restrict__ o_z, int* __restrict__ o_start_end, int N) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long ray = t / n_imp;
+  const int i = (int)(t - ray * n_imp);
+  if (ray >= N) return;
+  const int u0 = start_end[2 * ray], u1 = start_end[2 * ray + 1];
+  if (u1 - u0 == 0) return;
+  const float dist = (float)(1.0 / (double)(n_imp + 1));
+  float ur = dist + i * dist;
+  if (jitter) {
+    Pcg32 rng{rng_state, rng_inc};
+    rng.advance((unsigned long long)(i + 1) * (unsigned long long)ray + (unsigned long long)i);
+    const float r = rng.next_float();
+    const float mov = (float)((double)dist / 2.0);
+    ur += map_range_val_ref(r, 0.0f, 1.0f, -mov, mov);
+  }
+  ur = fminf(fmaxf(ur, (float)(0.0 + 1e-6)), (float)(1.0 - 1e-6));
+  int imin = u0, imax = u1 - 1;
+  while (imax >= imin) {   // binary_search (:466-489)
+    const int imid = imin + (imax - imin) / 2;
+    if (cdf[imid] > ur) imax = imid; else imin = imid;
+    if (imax - imin == 1) break;
+    if (imax == imin) break;   // single-sample ray: the reference would spin; it never calls this with < 2
+  }
+  const int hi = imax, lo = max(imax - 1, 0);
+  const float z = map_range_val_ref(ur, cdf[lo], cdf[hi], sz[lo], sz[hi]);
+  const long long o = ray * n_imp + i;
+  const float dx = rays_d[3 * ray], dy = rays_d[3 * ray + 1], dz = rays_d[3 * ray + 2];
+  o_3d[3 * o] = rays_o[3 * ray] + z * dx;
+  o_3d[3 * o + 1] = rays_o[3 * ray + 1] + z * dy;
+  o_3d[3 * o + 2] = rays_o[3 * ray + 2] + z * dz;
+  o_dirs[3 * o] = dx;
+  o_dirs[3 * o + 1] = dy;
+  o_dirs[3 * o + 2] = dz;
+  o_z[o] = z;
+  if (i == 0) {
+    o_start_end[2 * ray] = (int)(ray * n_imp);
+    o_start_end[2 * ray + 1] = (int)(ray * n_imp) + n_imp;
+  }
+}
+
 }  // namespace
 
 #define PK_CHECK(cond) \
@@ -557,4 +710,52 @@ extern "C" int vsa_packed_compute_cdf(const int32_t* start_end, const float* wei
                                       int nr_rays, void* stream) {
   PK_CHECK(nr_rays >= 0 && start_end && weights && cdf);
   PK_LAUNCH(compute_cdf_kernel, nr_rays, start_end, weights, cdf, nr_rays);
+}
+
+extern "C" int vsa_sample_fg(const float* rays_o, const float* rays_d, const float* ray_t_entry,
+                             const float* ray_t_exit, float min_dist_between_samples,
+                             int min_nr_samples_per_ray, int max_nr_samples_per_ray, int jitter,
+                             uint64_t rng_state, uint64_t rng_inc, float* ray_max_dt,
+                             int32_t* samples_idx, float* samples_3d, float* samples_dirs,
+                             float* samples_z, int32_t* ray_start_end_idx, int nr_rays, void* stream) {
+  PK_CHECK(nr_rays >= 0 && max_nr_samples_per_ray >= 1 && min_dist_between_samples > 0.f && rays_o &&
+           rays_d && ray_t_entry && ray_t_exit && ray_max_dt && samples_idx && samples_3d &&
+           samples_dirs && samples_z && ray_start_end_idx);
+  if (nr_rays == 0) return VSA_OK;
+  hipLaunchKernelGGL(sample_fg_kernel, dim3(vsa_div_up(nr_rays, 256)), dim3(256), 0,
+                     (hipStream_t)stream, rays_o, rays_d, ray_t_entry, ray_t_exit,
+                     min_dist_between_samples, min_nr_samples_per_ray, max_nr_samples_per_ray, jitter,
+                     (unsigned long long)rng_state, (unsigned long long)rng_inc, ray_max_dt,
+                     samples_idx, samples_3d, samples_dirs, samples_z, ray_start_end_idx, nr_rays);
+  VSA_RETURN_LAUNCH_STATUS();
+}
+extern "C" int vsa_pack_compact(const int32_t* start_end, const int32_t* out_start,
+                                const int32_t* samples_idx, const float* samples_3d,
+                                const float* samples_dirs, const float* samples_z,
+                                const float* samples_dt, const float* samples_values, int values_dim,
+                                int32_t* out_idx, float* out_3d, float* out_dirs, float* out_z,
+                                float* out_dt, float* out_values, int32_t* out_start_end,
+                                int nr_rays, void* stream) {
+  PK_CHECK(nr_rays >= 0 && values_dim >= 0 && start_end && out_start && samples_idx && samples_3d &&
+           samples_dirs && samples_z && samples_dt && out_idx && out_3d && out_dirs && out_z &&
+           out_dt && out_start_end && (values_dim == 0 || (samples_values && out_values)));
+  PK_LAUNCH(pack_compact_kernel, nr_rays, start_end, out_start, samples_idx, samples_3d, samples_dirs,
+            samples_z, samples_dt, samples_values, values_dim, out_idx, out_3d, out_dirs, out_z,
+            out_dt, out_values, out_start_end, nr_rays);
+}
+extern "C" int vsa_importance_sample(const float* rays_o, const float* rays_d,
+                                     const int32_t* start_end, const float* samples_z,
+                                     const float* samples_cdf, int nr_importance_samples, int jitter,
+                                     uint64_t rng_state, uint64_t rng_inc, float* out_3d,
+                                     float* out_dirs, float* out_z, int32_t* out_start_end,
+                                     int nr_rays, void* stream) {
+  PK_CHECK(nr_rays >= 0 && nr_importance_samples >= 1 && rays_o && rays_d && start_end && samples_z &&
+           samples_cdf && out_3d && out_dirs && out_z && out_start_end);
+  if (nr_rays == 0) return VSA_OK;
+  hipLaunchKernelGGL(importance_sample_kernel,
+                     dim3(vsa_div_up((long long)nr_rays * nr_importance_samples, 256)), dim3(256), 0,
+                     (hipStream_t)stream, rays_o, rays_d, start_end, samples_z, samples_cdf,
+                     nr_importance_samples, jitter, (unsigned long long)rng_state,
+                     (unsigned long long)rng_inc, out_3d, out_dirs, out_z, out_start_end, nr_rays);
+  VSA_RETURN_LAUNCH_STATUS();
 }

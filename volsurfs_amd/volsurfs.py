@@ -127,10 +127,28 @@ class RaySamplesPacked:
         self.has_dt = True
 
     def compact_to_valid_samples(self):
+        """src/RaySamplesPacked.cu:188-273: drop the unused slots of an uncompacted pack (one
+        host read of the sample count, as in the reference)."""
         if self.is_compacted:
-            return self
-        raise NotImplementedError("compact_to_valid_samples: only produced by the fg samplers "
-                                  "(nerf/surf/offsets_surfs), SURVEY §8f row 4")
+            raise _lib.VolsurfsHipError("RaySamplesPacked must not be compacted before compact_to_valid_samples")
+        N, V = self._nr_rays, self._values_dim
+        counts = (self.ray_start_end_idx[:, 1] - self.ray_start_end_idx[:, 0])
+        total = int(counts.sum().item()) if N else 0
+        c = RaySamplesPacked(N, total, 0, V)
+        c.ray_o, c.ray_d = self.ray_o.clone(), self.ray_d.clone()
+        c.ray_enter, c.ray_exit = self.ray_enter.clone(), self.ray_exit.clone()
+        c.has_samples_values, c.has_dt = self.has_samples_values, self.has_dt
+        c.ray_max_dt = self.ray_max_dt.clone()
+        c.is_compacted = True
+        if total == 0:
+            return c
+        out_start = (torch.cumsum(counts, 0) - counts).to(torch.int32).contiguous()
+        _lib.call("vsa_pack_compact", self.ray_start_end_idx, out_start, self.samples_idx,
+                  self.samples_3d, self.samples_dirs, self.samples_z, self.samples_dt,
+                  self.samples_values if V else None, V, c.samples_idx, c.samples_3d, c.samples_dirs,
+                  c.samples_z, c.samples_dt, c.samples_values if V else None, c.ray_start_end_idx, N,
+                  _lib.stream_ptr())
+        return c
 
 
 def _check_pack(p, *tensors):
@@ -266,7 +284,30 @@ class VolumeRendering:
                   pack.get_nr_rays(), _lib.stream_ptr())
         return cdf
 
-    importance_sample = staticmethod(lambda *a: VolumeRendering._todo("importance_sample"))
+    m_rng = None   # static pcg32 m_rng of src/VolumeRendering.cu:19 (set below)
+
+    @staticmethod
+    def importance_sample(pack, samples_cdf, nr_importance_samples, jitter_samples):
+        """src/VolumeRendering.cu:467-560: a new pack with nr_importance_samples per ray."""
+        import ctypes
+        if pack.is_empty():
+            raise _lib.VolsurfsHipError("RaySamplesPacked should not be empty")
+        _check_pack(pack, (samples_cdf, 1))
+        N, n = pack.get_nr_rays(), int(nr_importance_samples)
+        imp = RaySamplesPacked(N, N * n, pack.get_max_nr_samples(), pack.get_values_dim())
+        imp.has_samples_values = imp.has_dt = imp.is_compacted = False
+        rng = VolumeRendering.m_rng
+        _lib.call("vsa_importance_sample", pack.ray_o, pack.ray_d, pack.ray_start_end_idx,
+                  pack.samples_z, samples_cdf.contiguous(), n, bool(jitter_samples),
+                  ctypes.c_uint64(rng.state), ctypes.c_uint64(rng.inc), imp.samples_3d,
+                  imp.samples_dirs, imp.samples_z, imp.ray_start_end_idx, N, _lib.stream_ptr())
+        if jitter_samples:
+            rng.advance()
+        imp = imp.compact_to_valid_samples()
+        if imp.get_total_nr_samples() <= 0:
+            raise _lib.VolsurfsHipError("nr_samples_imp should be > 0")
+        return imp
+
     combine_ray_samples_packets = staticmethod(lambda *a: VolumeRendering._todo("combine_ray_samples_packets"))
 
 
@@ -290,9 +331,35 @@ class _Pcg32State:
         self.state = (acc_mult * self.state + acc_plus) & self.M64
 
 
+VolumeRendering.m_rng = _Pcg32State()
+
+
 class RaySampler:
     """include/volsurfs/RaySampler.cuh:15-58."""
     m_rng = _Pcg32State()
+
+    @staticmethod
+    def compute_samples_fg(rays_o, rays_d, ray_t_entry, ray_t_exit, min_dist_between_samples,
+                           min_nr_samples_per_ray, max_nr_samples_per_ray, jitter_samples, values_dim):
+        """src/RaySampler.cu:158-240: uniform foreground samples, compacted."""
+        import ctypes
+        for t, n in ((rays_o, "rays_o"), (rays_d, "rays_d"), (ray_t_entry, "ray_t_entry"), (ray_t_exit, "ray_t_exit")):
+            if t.dim() != 2:
+                raise _lib.VolsurfsHipError(f"{n} should be 2-D, it has sizes {tuple(t.shape)}")
+        N = rays_o.shape[0]
+        p = RaySamplesPacked(N, N * int(max_nr_samples_per_ray), 0, int(values_dim))
+        p.ray_o, p.ray_d = rays_o.clone().contiguous(), rays_d.clone().contiguous()
+        p.ray_enter, p.ray_exit = ray_t_entry.clone().contiguous(), ray_t_exit.clone().contiguous()
+        p.is_compacted = False
+        rng = RaySampler.m_rng
+        _lib.call("vsa_sample_fg", p.ray_o, p.ray_d, p.ray_enter, p.ray_exit,
+                  float(min_dist_between_samples), int(min_nr_samples_per_ray),
+                  int(max_nr_samples_per_ray), bool(jitter_samples), ctypes.c_uint64(rng.state),
+                  ctypes.c_uint64(rng.inc), p.ray_max_dt, p.samples_idx, p.samples_3d, p.samples_dirs,
+                  p.samples_z, p.ray_start_end_idx, N, _lib.stream_ptr())
+        if jitter_samples:
+            rng.advance()
+        return p.compact_to_valid_samples()
 
     @staticmethod
     def compute_samples_bg(rays_o, rays_d, ray_t_start, ray_t_far, nr_samples_per_ray, jitter_samples):
@@ -333,7 +400,6 @@ class RaySampler:
         raise NotImplementedError(f"RaySampler.{name}: used only by nerf/surf/offsets_surfs "
                                   "(SURVEY §8f row 4)")
 
-    compute_samples_fg = staticmethod(lambda *a: RaySampler._todo("compute_samples_fg"))
     compute_samples_fg_in_grid_occupied_regions = staticmethod(
         lambda *a: RaySampler._todo("compute_samples_fg_in_grid_occupied_regions"))
     init_with_one_sample_per_ray = staticmethod(lambda *a: RaySampler._todo("init_with_one_sample_per_ray"))
