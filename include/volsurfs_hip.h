@@ -405,6 +405,11 @@ int vsa_importance_sample(const float* rays_o, const float* rays_d, const int32_
                           uint64_t rng_inc, float* out_3d, float* out_dirs, float* out_z,
                           int32_t* out_start_end, int nr_rays, void* stream);
 
+/* RaySampler::uncontract_samples (src/RaySampler.cu:383-428): inverse of vsa_contract_samples. */
+int vsa_uncontract_samples(const float* ray_o, const int32_t* start_end, const float* samples_3d,
+                           const float* samples_z, float* out_samples_3d, float* out_samples_z,
+                           int nr_rays, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

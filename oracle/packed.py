@@ -365,3 +365,20 @@ def importance_sample(rays_o, rays_d, start_end, z, cdf, n_imp, jitter=False, rn
     zz = np.array([t for _, t in out_z], f32)
     s3d = np.stack([(rays_o[r] + f32(t) * rays_d[r]).astype(f32) for r, t in out_z]) if out_z else np.zeros((0, 3), f32)
     return {"samples_z": zz, "samples_3d": s3d, "ray_start_end_idx": out_se}
+
+
+def uncontract(ray_o, start_end, s3d, sz):
+    """RaySamplerGPU.cuh:595-650."""
+    s3d, sz = np.asarray(s3d, f32).copy(), np.asarray(sz, f32).reshape(-1).copy()
+    for r, i0, i1 in _rays(start_end):
+        for i in range(i0, i1):
+            p = s3d[i]
+            q = (p * f32(2.0)).astype(f32)
+            norm = f32(np.sqrt(f32(f32(q[0] * q[0] + q[1] * q[1]) + q[2] * q[2])))
+            if norm > 1.0:
+                factor = f32(f32(1.0) / f32(f32(2.0) - norm))
+                p = ((factor * p).astype(f32) / norm).astype(f32)
+                e = (p - np.asarray(ray_o, f32)[r]).astype(f32)
+                sz[i] = f32(np.sqrt(f32(f32(e[0] * e[0] + e[1] * e[1]) + e[2] * e[2])))
+                s3d[i] = p
+    return s3d, sz

@@ -336,3 +336,31 @@ def test_hip_fg_sampler_compaction_importance_sampling_vs_oracle(jitter):
     assert (np.diff(zi.reshape(-1, 16)[multi[(ref_se[:, 1] - ref_se[:, 0]) > 0]], axis=1) >= 0).all()   # sorted per ray
     if jitter:      # the static generators were advanced like the reference's m_rng
         assert RaySampler.m_rng.state != rng0.state and VR.m_rng.state != rng1.state
+
+
+@pytest.mark.gpu
+def test_hip_uncontract_inverts_contract_and_one_sample_packs():
+    from volsurfs_amd.volsurfs import RaySampler
+    g = np.random.default_rng(31)
+    N = 400
+    o = g.standard_normal((N, 3)).astype(np.float32) * 0.05
+    d = g.standard_normal((N, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    cu = lambda x: torch.from_numpy(x).cuda()
+    pack = RaySampler.compute_samples_bg(cu(o), cu(d), cu(np.full((N, 1), 0.4, np.float32)), 100.0, 32, False)
+    cp = RaySampler.contract_samples(pack)
+    up = RaySampler.uncontract_samples(cp)
+    ref3, refz = OP.uncontract(o, cp.ray_start_end_idx.cpu().numpy(), cp.samples_3d.cpu().numpy(),
+                               cp.samples_z.cpu().numpy())
+    np.testing.assert_allclose(up.samples_3d.cpu().numpy(), ref3, rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(up.samples_z.cpu().numpy()[:, 0], refz, rtol=2e-6, atol=1e-7)
+    # un-contracting the contracted samples gives the original positions back (up to fp32
+    # conditioning near the boundary of the contracted ball, where 1 / (2 - norm) blows up)
+    p0, p1 = pack.samples_3d.cpu().numpy(), up.samples_3d.cpu().numpy()
+    near = np.linalg.norm(p0, axis=1) < 20
+    np.testing.assert_allclose(p1[near], p0[near], rtol=2e-3, atol=1e-4)
+    assert up.has_dt and up.is_compacted
+    one = RaySampler.init_with_one_sample_per_ray(cu(o), cu(d))
+    assert one.get_total_nr_samples() == N and one.get_values_dim() == 1
+    assert torch.equal(one.samples_3d.cpu(), torch.from_numpy(o)) and (one.samples_z == 0).all()
+    assert one.ray_start_end_idx[5].tolist() == [5, 6]

@@ -580,6 +580,35 @@ __global__ void importance_sample_kernel(const float* __restrict__ rays_o, const
   }
 }
 
+
+// RaySamplerGPU.cuh:595-650 uncontract_samples (inverse of the scene contraction, scale 2)
+__global__ void uncontract_kernel(const float* __restrict__ ray_o, const int* __restrict__ start_end,
+                                  const float* __restrict__ s3d, const float* __restrict__ sz,
+                                  float* __restrict__ o3d, float* __restrict__ oz, int N) {
+  PK_RAY_PROLOGUE();
+  if (n <= 0) return;
+  const float cx = ray_o[3 * ray], cy = ray_o[3 * ray + 1], cz = ray_o[3 * ray + 2];
+  for (int i = l; i < n; i += SUB) {
+    const long long s = i0 + i;
+    float px = s3d[3 * s], py = s3d[3 * s + 1], pz = s3d[3 * s + 2];
+    float z = sz[s];
+    const float sx = px * 2.0f, sy = py * 2.0f, sz2 = pz * 2.0f;
+    const float norm = sqrtf((sx * sx + sy * sy) + sz2 * sz2);
+    if (norm > 1.0f) {
+      const float factor = 1.0f / (2.0f - norm);
+      px = (factor * px) / norm;
+      py = (factor * py) / norm;
+      pz = (factor * pz) / norm;
+      const float ex = px - cx, ey = py - cy, ez = pz - cz;
+      z = sqrtf((ex * ex + ey * ey) + ez * ez);
+    }
+    o3d[3 * s] = px;
+    o3d[3 * s + 1] = py;
+    o3d[3 * s + 2] = pz;
+    oz[s] = z;
+  }
+}
+
 }  // namespace
 
 #define PK_CHECK(cond) \
@@ -758,4 +787,14 @@ extern "C" int vsa_importance_sample(const float* rays_o, const float* rays_d,
                      nr_importance_samples, jitter, (unsigned long long)rng_state,
                      (unsigned long long)rng_inc, out_3d, out_dirs, out_z, out_start_end, nr_rays);
   VSA_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int vsa_uncontract_samples(const float* ray_o, const int32_t* start_end,
+                                      const float* samples_3d, const float* samples_z,
+                                      float* out_samples_3d, float* out_samples_z, int nr_rays,
+                                      void* stream) {
+  PK_CHECK(nr_rays >= 0 && ray_o && start_end && samples_3d && samples_z && out_samples_3d &&
+           out_samples_z);
+  PK_LAUNCH(uncontract_kernel, nr_rays, ray_o, start_end, samples_3d, samples_z, out_samples_3d,
+            out_samples_z, nr_rays);
 }

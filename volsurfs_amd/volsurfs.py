@@ -402,8 +402,29 @@ class RaySampler:
 
     compute_samples_fg_in_grid_occupied_regions = staticmethod(
         lambda *a: RaySampler._todo("compute_samples_fg_in_grid_occupied_regions"))
-    init_with_one_sample_per_ray = staticmethod(lambda *a: RaySampler._todo("init_with_one_sample_per_ray"))
-    uncontract_samples = staticmethod(lambda *a: RaySampler._todo("uncontract_samples"))
+    @staticmethod
+    def init_with_one_sample_per_ray(samples_3d, samples_dir):
+        """src/RaySampler.cu:30-68: a pack with exactly one sample per ray (z = dt = 0)."""
+        N = samples_3d.shape[0]
+        p = RaySamplesPacked(N, N, 0, 1)
+        p.samples_3d, p.samples_dirs = samples_3d.clone().contiguous(), samples_dir.clone().contiguous()
+        p.samples_z, p.samples_dt = torch.zeros(N, 1, device=samples_3d.device), torch.zeros(N, 1, device=samples_3d.device)
+        i = torch.arange(N, dtype=torch.int32, device=samples_3d.device)
+        p.ray_start_end_idx = torch.stack([i, i + 1], 1).contiguous()
+        return p
+
+    @staticmethod
+    def uncontract_samples(pack):
+        """src/RaySampler.cu:383-428: copy, un-contract (scale 2), update_dt(True)."""
+        if not pack.is_compacted:
+            raise _lib.VolsurfsHipError("RaySamplesPacked should be compacted before uncontract_samples")
+        if pack.is_empty():
+            raise _lib.VolsurfsHipError("RaySamplesPacked must not be empty before uncontract_samples")
+        c = pack.copy()
+        _lib.call("vsa_uncontract_samples", pack.ray_o, pack.ray_start_end_idx, pack.samples_3d,
+                  pack.samples_z, c.samples_3d, c.samples_z, pack.get_nr_rays(), _lib.stream_ptr())
+        c.update_dt(True)
+        return c
 
 
 # ---- autograd glue, same classes as volume_rendering/volume_rendering_funcs.py:91-241
