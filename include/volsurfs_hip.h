@@ -410,6 +410,17 @@ int vsa_uncontract_samples(const float* ray_o, const int32_t* start_end, const f
                            const float* samples_z, float* out_samples_3d, float* out_samples_z,
                            int nr_rays, void* stream);
 
+/* VolumeRendering::combine_ray_samples_packets (src/VolumeRendering.cu:562-670): depth-ordered
+ * merge of two compacted packs over the same rays, dropping samples closer than min_dist to the
+ * previous kept one.  out_start [N] = exclusive scan of (count_1 + count_2); compact afterwards. */
+int vsa_combine_packs(const int32_t* start_end_1, const int32_t* idx_1, const float* s3d_1,
+                      const float* dirs_1, const float* z_1, const float* values_1,
+                      const int32_t* start_end_2, const int32_t* idx_2, const float* s3d_2,
+                      const float* dirs_2, const float* z_2, const float* values_2,
+                      const int32_t* out_start, float min_dist_between_samples, int values_dim,
+                      int32_t* out_idx, float* out_3d, float* out_dirs, float* out_z,
+                      float* out_values, int32_t* out_start_end, int nr_rays, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -382,3 +382,45 @@ def uncontract(ray_o, start_end, s3d, sz):
                 sz[i] = f32(np.sqrt(f32(f32(e[0] * e[0] + e[1] * e[1]) + e[2] * e[2])))
                 s3d[i] = p
     return s3d, sz
+
+
+def combine_packs(se1, z1, se2, z2, min_dist):
+    """VolumeRenderingGPU.cuh:680-895 + compaction: returns (start_end, z, source) where source
+    gives (pack, sample index) of every kept sample.  A pack without samples for a ray counts
+    as exhausted from the start."""
+    z1, z2 = np.asarray(z1, f32).reshape(-1), np.asarray(z2, f32).reshape(-1)
+    out_se, out_z, src, cursor = np.full((se1.shape[0], 2), -1, np.int32), [], [], 0
+    for r in range(se1.shape[0]):
+        a0, na = int(se1[r, 0]), int(se1[r, 1] - se1[r, 0])
+        b0, nb = int(se2[r, 0]), int(se2[r, 1] - se2[r, 0])
+        if na == 0 and nb == 0:
+            continue
+        ca = cb = 0
+        fa, fb = na == 0, nb == 0
+        prec, written = f32(0.0), 0
+        for _ in range(na + nb):
+            if fa and fb:
+                break
+            za = f32(1e10) if fa else z1[a0 + ca]
+            zb = f32(1e10) if fb else z2[b0 + cb]
+            take_a = za < zb
+            z = za if take_a else zb
+            if not (f32(z - prec) < f32(min_dist)):
+                out_z.append(z)
+                src.append((0, a0 + ca) if take_a else (1, b0 + cb))
+                prec = z
+                written += 1
+            if take_a:
+                if ca + 1 >= na:
+                    fa = True
+                else:
+                    ca += 1
+            else:
+                if cb + 1 >= nb:
+                    fb = True
+                else:
+                    cb += 1
+        if written:
+            out_se[r] = (cursor, cursor + written)
+        cursor += written
+    return out_se, np.array(out_z, f32), src

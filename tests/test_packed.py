@@ -364,3 +364,43 @@ def test_hip_uncontract_inverts_contract_and_one_sample_packs():
     assert one.get_total_nr_samples() == N and one.get_values_dim() == 1
     assert torch.equal(one.samples_3d.cpu(), torch.from_numpy(o)) and (one.samples_z == 0).all()
     assert one.ray_start_end_idx[5].tolist() == [5, 6]
+
+
+@pytest.mark.gpu
+def test_hip_combine_ray_samples_packets_vs_oracle():
+    """Uniform + importance packs merged in depth order with a minimum spacing (the NeuS
+    up-sampling step of the sibling methods)."""
+    from volsurfs_amd.volsurfs import RaySampler, VolumeRendering as VR, _Pcg32State
+    g = np.random.default_rng(41)
+    N = 500
+    o = g.standard_normal((N, 3)).astype(np.float32) * 0.1
+    d = g.standard_normal((N, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    t0 = g.uniform(0.1, 0.5, (N, 1)).astype(np.float32)
+    t1 = (t0 + g.uniform(0.05, 1.0, (N, 1))).astype(np.float32)
+    cu = lambda x: torch.from_numpy(x).cuda()
+    RaySampler.m_rng, VR.m_rng = _Pcg32State(), _Pcg32State()
+    uni = RaySampler.compute_samples_fg(cu(o), cu(d), cu(t0), cu(t1), 0.02, 2, 48, False, 0)
+    S = uni.get_total_nr_samples()
+    w = g.uniform(0, 1, (S, 1)).astype(np.float32)
+    se_u = uni.ray_start_end_idx.cpu().numpy()
+    for r in range(N):
+        a, b = se_u[r]
+        if b - a >= 2:
+            w[a:b] /= w[a:b].sum()
+    imp = VR.importance_sample(uni, VR.compute_cdf(uni, cu(w)), 8, False)
+    comb = VR.combine_ray_samples_packets(uni, imp, 0.004)
+    se_i = imp.ray_start_end_idx.cpu().numpy()
+    ref_se, ref_z, src = OP.combine_packs(se_u, uni.samples_z.cpu().numpy(), se_i, imp.samples_z.cpu().numpy(), 0.004)
+    assert comb.is_compacted and not comb.has_dt
+    assert np.array_equal(comb.ray_start_end_idx.cpu().numpy(), ref_se)
+    assert np.array_equal(comb.samples_z.cpu().numpy()[:, 0], ref_z)
+    pos = [uni.samples_3d.cpu().numpy(), imp.samples_3d.cpu().numpy()]
+    ref_pos = np.stack([pos[k][i] for k, i in src])
+    assert np.array_equal(comb.samples_3d.cpu().numpy(), ref_pos)
+    z = comb.samples_z.cpu().numpy()[:, 0]
+    for r in range(0, N, 37):                     # per ray: sorted, spaced by at least min_dist
+        a, b = ref_se[r]
+        if b - a > 1:
+            assert (np.diff(z[a:b]) >= 0.004 - 1e-7).all()
+    assert S < comb.get_total_nr_samples() < S + imp.get_total_nr_samples()

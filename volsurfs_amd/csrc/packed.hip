@@ -609,6 +609,66 @@ __global__ void uncontract_kernel(const float* __restrict__ ray_o, const int* __
   }
 }
 
+
+// VolumeRenderingGPU.cuh:680-895 combine_ray_samples_packets: per ray, merge the two packs'
+// samples in increasing depth and drop a sample that lies closer than min_dist to the last one
+// kept.  One thread per ray: which samples survive depends on the serial scan.  (A pack without
+// samples for this ray counts as exhausted from the start; the reference would read one
+// element before the ray's range there.)
+struct PackView {
+  const int* start_end;
+  const int* idx;
+  const float* s3d;
+  const float* sdirs;
+  const float* sz;
+  const float* sval;
+};
+
+__global__ void combine_packs_kernel(PackView a, PackView b, const int* __restrict__ out_start,
+                                     float min_dist, int V, int* __restrict__ o_idx,
+                                     float* __restrict__ o_3d, float* __restrict__ o_dirs,
+                                     float* __restrict__ o_z, float* __restrict__ o_val,
+                                     int* __restrict__ o_start_end, int N) {
+  const long long ray = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ray >= N) return;
+  const int a0 = a.start_end[2 * ray], na = a.start_end[2 * ray + 1] - a0;
+  const int b0 = b.start_end[2 * ray], nb = b.start_end[2 * ray + 1] - b0;
+  if (na == 0 && nb == 0) return;
+  const int o0 = out_start[ray];
+  int ca = 0, cb = 0, written = 0;
+  bool fa = na == 0, fb = nb == 0;
+  float prec_z = 0.0f;
+  for (int i = 0; i < na + nb; ++i) {
+    if (fa && fb) break;
+    const float za = fa ? 1e10f : a.sz[a0 + ca];
+    const float zb = fb ? 1e10f : b.sz[b0 + cb];
+    const bool take_a = za < zb;
+    const PackView& p = take_a ? a : b;
+    const long long src = take_a ? a0 + ca : b0 + cb;
+    const float z = take_a ? za : zb;
+    if (!(z - prec_z < min_dist)) {
+      const long long dst = o0 + written;
+      o_idx[dst] = p.idx[src];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        o_3d[3 * dst + c] = p.s3d[3 * src + c];
+        o_dirs[3 * dst + c] = p.sdirs[3 * src + c];
+      }
+      o_z[dst] = z;
+      prec_z = z;
+      for (int v = 0; v < V; ++v) o_val[dst * V + v] = p.sval[src * V + v];
+      written += 1;
+    }
+    if (take_a) {
+      if (ca + 1 >= na) fa = true; else ca += 1;
+    } else {
+      if (cb + 1 >= nb) fb = true; else cb += 1;
+    }
+  }
+  o_start_end[2 * ray] = o0;
+  o_start_end[2 * ray + 1] = o0 + written;
+}
+
 }  // namespace
 
 #define PK_CHECK(cond) \
@@ -797,4 +857,25 @@ extern "C" int vsa_uncontract_samples(const float* ray_o, const int32_t* start_e
            out_samples_z);
   PK_LAUNCH(uncontract_kernel, nr_rays, ray_o, start_end, samples_3d, samples_z, out_samples_3d,
             out_samples_z, nr_rays);
+}
+
+extern "C" int vsa_combine_packs(const int32_t* start_end_1, const int32_t* idx_1, const float* s3d_1,
+                                 const float* dirs_1, const float* z_1, const float* values_1,
+                                 const int32_t* start_end_2, const int32_t* idx_2, const float* s3d_2,
+                                 const float* dirs_2, const float* z_2, const float* values_2,
+                                 const int32_t* out_start, float min_dist_between_samples,
+                                 int values_dim, int32_t* out_idx, float* out_3d, float* out_dirs,
+                                 float* out_z, float* out_values, int32_t* out_start_end,
+                                 int nr_rays, void* stream) {
+  PK_CHECK(nr_rays >= 0 && values_dim >= 0 && start_end_1 && idx_1 && s3d_1 && dirs_1 && z_1 &&
+           start_end_2 && idx_2 && s3d_2 && dirs_2 && z_2 && out_start && out_idx && out_3d &&
+           out_dirs && out_z && out_start_end &&
+           (values_dim == 0 || (values_1 && values_2 && out_values)));
+  if (nr_rays == 0) return VSA_OK;
+  const PackView a{start_end_1, idx_1, s3d_1, dirs_1, z_1, values_1};
+  const PackView b{start_end_2, idx_2, s3d_2, dirs_2, z_2, values_2};
+  hipLaunchKernelGGL(combine_packs_kernel, dim3(vsa_div_up(nr_rays, 256)), dim3(256), 0,
+                     (hipStream_t)stream, a, b, out_start, min_dist_between_samples, values_dim,
+                     out_idx, out_3d, out_dirs, out_z, out_values, out_start_end, nr_rays);
+  VSA_RETURN_LAUNCH_STATUS();
 }

@@ -308,7 +308,45 @@ class VolumeRendering:
             raise _lib.VolsurfsHipError("nr_samples_imp should be > 0")
         return imp
 
-    combine_ray_samples_packets = staticmethod(lambda *a: VolumeRendering._todo("combine_ray_samples_packets"))
+    @staticmethod
+    def combine_ray_samples_packets(pack_1, pack_2, min_dist_between_samples):
+        """src/VolumeRendering.cu:562-670."""
+        for p_ in (pack_1, pack_2):
+            if not p_.is_compacted:
+                raise _lib.VolsurfsHipError("RaySamplesPacked must be compacted before combine_ray_samples_packets")
+        if pack_1.has_samples_values != pack_2.has_samples_values or \
+                pack_1.get_values_dim() != pack_2.get_values_dim() or \
+                pack_1.get_nr_rays() != pack_2.get_nr_rays():
+            raise _lib.VolsurfsHipError("the two packs must agree in rays, values and values_dim")
+        e1, e2 = pack_1.is_empty(), pack_2.is_empty()
+        if e1 and e2:
+            raise _lib.VolsurfsHipError("Both ray_samples_packed are empty")
+        if e1:
+            return pack_2
+        if e2:
+            return pack_1
+        N, V = pack_1.get_nr_rays(), pack_1.get_values_dim()
+        total = pack_1.get_total_nr_samples() + pack_2.get_total_nr_samples()
+        c = RaySamplesPacked(N, total, 0, V)
+        c.ray_o, c.ray_d = pack_1.ray_o.clone(), pack_1.ray_d.clone()
+        c.ray_enter, c.ray_exit = pack_1.ray_enter.clone(), pack_1.ray_exit.clone()
+        c.has_samples_values, c.has_dt = pack_1.has_samples_values, False
+        c.ray_max_dt = pack_1.ray_max_dt.clone()
+        c.is_compacted = False
+        counts = (pack_1.get_nr_samples_per_ray() + pack_2.get_nr_samples_per_ray())[:, 0]
+        out_start = (torch.cumsum(counts, 0) - counts).to(torch.int32).contiguous()
+        v1 = pack_1.samples_values if V else None
+        v2 = pack_2.samples_values if V else None
+        _lib.call("vsa_combine_packs", pack_1.ray_start_end_idx, pack_1.samples_idx, pack_1.samples_3d,
+                  pack_1.samples_dirs, pack_1.samples_z, v1, pack_2.ray_start_end_idx,
+                  pack_2.samples_idx, pack_2.samples_3d, pack_2.samples_dirs, pack_2.samples_z, v2,
+                  out_start, float(min_dist_between_samples), V, c.samples_idx, c.samples_3d,
+                  c.samples_dirs, c.samples_z, c.samples_values if V else None, c.ray_start_end_idx,
+                  N, _lib.stream_ptr())
+        c = c.compact_to_valid_samples()
+        if c.get_total_nr_samples() <= 0:
+            raise _lib.VolsurfsHipError("total_nr_samples should be > 0")
+        return c
 
 
 class _Pcg32State:
