@@ -421,6 +421,29 @@ int vsa_combine_packs(const int32_t* start_end_1, const int32_t* idx_1, const fl
                       int32_t* out_idx, float* out_3d, float* out_dirs, float* out_z,
                       float* out_values, int32_t* out_start_end, int nr_rays, void* stream);
 
+/* ---- ray generation (mvdatasets is an empty submodule: parity unpinned) ----
+ * Pinhole rays of one camera, replacing mvdatasets.utils.raycasting.get_camera_rays as called at
+ * methods/base_method.py:389-394 and renderers/base_renderer.py:59.  c2w [3,4] and
+ * intrinsics_inv [3,3] are DEVICE arrays, row-major.  Ray i = (row * width + col) *
+ * nr_rays_per_pixel + s goes through (col + jx, row + jy), (jx, jy) = (0.5, 0.5) or two PCG32
+ * draws of the stream (rng_state, rng_inc) advanced by 2 i.  rays_o / rays_d [n,3], points_2d
+ * [n,2] (may be NULL). */
+int vsa_camera_rays(const float* c2w, const float* intrinsics_inv, int height, int width,
+                    int nr_rays_per_pixel, int jitter_pixels, uint64_t rng_state, uint64_t rng_inc,
+                    float* rays_o, float* rays_d, float* points_2d, void* stream);
+
+/* Training batch, replacing TensorReel.get_next_rays_batch as called at trainer.py:176-190:
+ * batch_size uniformly drawn (camera, pixel) pairs of a resident stack of nr_cameras equally
+ * sized views (c2w_all [C,3,4], intrinsics_inv_all [C,3,3], rgb_all [C,H,W,3], mask_all [C,H,W]
+ * or NULL), nr_rays_per_pixel rays each.  camera_idx [B], rays_o / rays_d [B*R,3], gt_rgb [B,3]
+ * and gt_mask [B] (each may be NULL), points_2d [B*R,2] (may be NULL). */
+int vsa_reel_next_rays_batch(const float* c2w_all, const float* intrinsics_inv_all,
+                             const float* rgb_all, const float* mask_all, int nr_cameras, int height,
+                             int width, int batch_size, int nr_rays_per_pixel, int jitter_pixels,
+                             uint64_t rng_state, uint64_t rng_inc, int32_t* camera_idx,
+                             float* rays_o, float* rays_d, float* gt_rgb, float* gt_mask,
+                             float* points_2d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,12 @@ def test_argument_errors_are_reported_not_ignored():
     assert L.vsa_grid_encode_fwd(null, null, null, 10, null, null) == ERR_ARG
     assert L.vsa_sh_encode(null, 10, 7, null, null) == ERR_ARG                                   # degree > 4
     assert L.vsa_packed_sum_over_rays(null, null, null, null, 10, 1, null) == ERR_ARG
+    u64 = ctypes.c_uint64(1)
+    assert L.vsa_camera_rays(null, null, 4, 4, 1, 0, u64, u64, null, null, null, null) == ERR_ARG
+    assert L.vsa_camera_rays(null, null, 0, 4, 1, 0, u64, u64, null, null, null, null) == 0      # no pixels
+    assert L.vsa_camera_rays(null, null, 4, 4, 0, 0, u64, u64, null, null, null, null) == ERR_ARG  # R < 1
+    assert L.vsa_reel_next_rays_batch(null, null, null, null, 0, 4, 4, 8, 1, 0, u64, u64, null, null, null,
+                                      null, null, null, null) == ERR_ARG                             # no cameras
     h = ctypes.c_void_p()
     assert L.vsa_bvh_build(null, null, 0, 0, 4, ctypes.byref(h)) != 0
     # the Python layer turns any non-zero status into an exception

@@ -1,0 +1,135 @@
+// Ray generation and the training-ray sampler: the step before the
+// traversal in both entry points — `get_camera_rays(camera, nr_rays_per_pixel, jitter_pixels)`
+// for full views (methods/base_method.py:389-394, renderers/base_renderer.py:59) and
+// `TensorReel.get_next_rays_batch(batch_size, jitter_pixels, nr_rays_per_pixel)` for training
+// batches (trainer.py:176-190).  Both live in mvdatasets, an empty submodule in the reference
+// checkout (.gitmodules:10-13): PARITY UNPINNED.  The call shapes are the reference's; the
+// arithmetic is this library's own pinhole definition, restated in oracle/raygen.py:
+//   point (x, y) in pixels, pixel centre = +0.5 (or + two PCG32 draws when jittered)
+//   d_cam = Kinv (x, y, 1);  d = normalise(R d_cam);  o = t           (c2w = [R | t], 3x4)
+// Every ray is independent and the camera is wave-uniform (scalar loads): one thread per ray
+// (camera rays) or per sampled pixel (reel), writes coalesced, 40 B of output per ray — an
+// HBM-write-bound kernel that costs microseconds next to the 3 ms render step.
+#include "common.h"
+#include "pcg32.h"
+
+namespace {
+
+struct RayOut {
+  float ox, oy, oz, dx, dy, dz;
+};
+
+__device__ __forceinline__ RayOut pinhole_ray(const float* __restrict__ c2w,
+                                              const float* __restrict__ kinv, float x, float y) {
+  float dc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) dc[i] = (kinv[3 * i] * x + kinv[3 * i + 1] * y) + kinv[3 * i + 2];
+  float d[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    d[i] = (c2w[4 * i] * dc[0] + c2w[4 * i + 1] * dc[1]) + c2w[4 * i + 2] * dc[2];
+  const float n = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+  return RayOut{c2w[3], c2w[7], c2w[11], d[0] / n, d[1] / n, d[2] / n};
+}
+
+__device__ __forceinline__ void store_ray(const RayOut& r, float x, float y, long long i,
+                                          float* __restrict__ rays_o, float* __restrict__ rays_d,
+                                          float* __restrict__ points_2d) {
+  rays_o[3 * i] = r.ox, rays_o[3 * i + 1] = r.oy, rays_o[3 * i + 2] = r.oz;
+  rays_d[3 * i] = r.dx, rays_d[3 * i + 1] = r.dy, rays_d[3 * i + 2] = r.dz;
+  if (points_2d) points_2d[2 * i] = x, points_2d[2 * i + 1] = y;
+}
+
+// ray i = pixel * R + s, pixel = row * W + col (the order BaseMethod.render averages
+// nr_rays_per_pixel consecutive rays in)
+__global__ __launch_bounds__(256) void camera_rays_kernel(
+    const float* __restrict__ c2w, const float* __restrict__ kinv, int W, int R, int jitter,
+    unsigned long long rng_state, unsigned long long rng_inc, long long n_rays,
+    float* __restrict__ rays_o, float* __restrict__ rays_d, float* __restrict__ points_2d) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_rays) return;
+  const long long pixel = i / R;
+  const int row = (int)(pixel / W), col = (int)(pixel % W);
+  float jx = 0.5f, jy = 0.5f;
+  if (jitter) {
+    Pcg32 rng{rng_state, rng_inc};
+    rng.advance(2ull * (unsigned long long)i);
+    jx = rng.next_float();
+    jy = rng.next_float();
+  }
+  const float x = (float)col + jx, y = (float)row + jy;
+  store_ray(pinhole_ray(c2w, kinv, x, y), x, y, i, rays_o, rays_d, points_2d);
+}
+
+// sample b: three draws pick (camera, col, row) uniformly; its R rays follow (jittered: two
+// more draws each).  Ground truth is the picked pixel's value whatever the jitter.
+__global__ __launch_bounds__(256) void reel_rays_kernel(
+    const float* __restrict__ c2w_all, const float* __restrict__ kinv_all,
+    const float* __restrict__ rgb_all, const float* __restrict__ mask_all, int C, int H, int W,
+    int B, int R, int jitter, unsigned long long rng_state, unsigned long long rng_inc,
+    int* __restrict__ camera_idx, float* __restrict__ rays_o, float* __restrict__ rays_d,
+    float* __restrict__ gt_rgb, float* __restrict__ gt_mask, float* __restrict__ points_2d) {
+  const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  Pcg32 rng{rng_state, rng_inc};
+  rng.advance((unsigned long long)b * (unsigned long long)(3 + (jitter ? 2 * R : 0)));
+  const int cam = min((int)(rng.next_float() * (float)C), C - 1);
+  const int col = min((int)(rng.next_float() * (float)W), W - 1);
+  const int row = min((int)(rng.next_float() * (float)H), H - 1);
+  camera_idx[b] = cam;
+  const long long px = ((long long)cam * H + row) * W + col;
+  if (gt_rgb) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gt_rgb[3 * b + c] = rgb_all[3 * px + c];
+  }
+  if (gt_mask) gt_mask[b] = mask_all[px];
+  const float* c2w = c2w_all + 12ll * cam;
+  const float* kinv = kinv_all + 9ll * cam;
+  for (int s = 0; s < R; ++s) {
+    float jx = 0.5f, jy = 0.5f;
+    if (jitter) {
+      jx = rng.next_float();
+      jy = rng.next_float();
+    }
+    const float x = (float)col + jx, y = (float)row + jy;
+    store_ray(pinhole_ray(c2w, kinv, x, y), x, y, b * R + s, rays_o, rays_d, points_2d);
+  }
+}
+
+}  // namespace
+
+extern "C" int vsa_camera_rays(const float* c2w, const float* intrinsics_inv, int height, int width,
+                               int nr_rays_per_pixel, int jitter_pixels, uint64_t rng_state,
+                               uint64_t rng_inc, float* rays_o, float* rays_d, float* points_2d,
+                               void* stream) {
+  if (height < 0 || width < 0 || nr_rays_per_pixel < 1) return VSA_ERR_ARG;
+  const long long n = (long long)height * width * nr_rays_per_pixel;
+  if (n == 0) return VSA_OK;
+  if (!c2w || !intrinsics_inv || !rays_o || !rays_d) return VSA_ERR_ARG;
+  if (n > 0x7fffffffll * 256) return VSA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(camera_rays_kernel, dim3(vsa_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     c2w, intrinsics_inv, width, nr_rays_per_pixel, jitter_pixels,
+                     (unsigned long long)rng_state, (unsigned long long)rng_inc, n, rays_o, rays_d,
+                     points_2d);
+  VSA_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int vsa_reel_next_rays_batch(const float* c2w_all, const float* intrinsics_inv_all,
+                                        const float* rgb_all, const float* mask_all, int nr_cameras,
+                                        int height, int width, int batch_size, int nr_rays_per_pixel,
+                                        int jitter_pixels, uint64_t rng_state, uint64_t rng_inc,
+                                        int32_t* camera_idx, float* rays_o, float* rays_d,
+                                        float* gt_rgb, float* gt_mask, float* points_2d,
+                                        void* stream) {
+  if (batch_size < 0 || nr_rays_per_pixel < 1) return VSA_ERR_ARG;
+  if (batch_size == 0) return VSA_OK;
+  if (nr_cameras < 1 || height < 1 || width < 1) return VSA_ERR_ARG;
+  if (!c2w_all || !intrinsics_inv_all || !camera_idx || !rays_o || !rays_d) return VSA_ERR_ARG;
+  if ((gt_rgb && !rgb_all) || (gt_mask && !mask_all)) return VSA_ERR_ARG;
+  hipLaunchKernelGGL(reel_rays_kernel, dim3(vsa_div_up(batch_size, 256)), dim3(256), 0,
+                     (hipStream_t)stream, c2w_all, intrinsics_inv_all, rgb_all, mask_all, nr_cameras,
+                     height, width, batch_size, nr_rays_per_pixel, jitter_pixels,
+                     (unsigned long long)rng_state, (unsigned long long)rng_inc, camera_idx, rays_o,
+                     rays_d, gt_rgb, gt_mask, points_2d);
+  VSA_RETURN_LAUNCH_STATUS();
+}

@@ -276,6 +276,15 @@ class VolSurfs(torch.nn.Module):
         return {"loss": loss_rgb, "rgb": loss_rgb}, {}, res["samples_3d"]
 
     @torch.no_grad()
+    def render_camera(self, camera, nr_rays_per_pixel=1, jitter_pixels=False, chunk=16384):
+        """base_method.py:366-541 from the camera down: device ray generation (`ray_gen`,
+        :386-402) then the chunked render, reshaped to [H, W, C] images."""
+        from .camera import get_camera_rays
+        rays_o, rays_d, _ = get_camera_rays(camera, nr_rays_per_pixel, jitter_pixels)
+        full = self.render(rays_o, rays_d, nr_rays_per_pixel, chunk)
+        return {k: v.reshape(camera.height, camera.width, *v.shape[1:]) for k, v in full.items()}
+
+    @torch.no_grad()
     def render(self, rays_o, rays_d, nr_rays_per_pixel=1, chunk=16384):
         """base_method.py:366-541: chunked full-frame render (test_rays_batch_size =
         16384), supersample mean over nr_rays_per_pixel; buffers stay on the device."""

@@ -45,3 +45,21 @@ def train_step(method, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first
     if method.lr_scheduler is not None:                                     # :306-308
         method.lr_scheduler.step()
     return losses, nr_rays
+
+
+def train_step_from_reel(method, reel, nr_rays, jitter_pixels=True, nr_rays_per_pixel=1, iter_nr=0,
+                         is_training_masked=False, **kw):
+    """trainer.py:176-235: draw the batch on the device (TensorReel.get_next_rays_batch), apply
+    the mask to the ground truth as :203-207 does, and step.  With nr_rays_per_pixel > 1 each
+    ray is compared with its pixel's value."""
+    _, rays_o, rays_d, vals, _ = reel.get_next_rays_batch(nr_rays, jitter_pixels, nr_rays_per_pixel)
+    gt_rgb = vals["rgb"]
+    gt_mask = vals["mask"] if "mask" in vals else torch.ones_like(gt_rgb[:, :1])
+    if is_training_masked:
+        gt_rgb = gt_rgb * gt_mask
+        if method.bg_color is not None:
+            gt_rgb = gt_rgb + (1 - gt_mask) * method.bg_color.reshape(1, 3).to(gt_rgb)
+    if nr_rays_per_pixel > 1:
+        gt_rgb = gt_rgb.repeat_interleave(nr_rays_per_pixel, 0)
+        gt_mask = gt_mask.repeat_interleave(nr_rays_per_pixel, 0)
+    return train_step(method, rays_o, rays_d, gt_rgb, gt_mask, iter_nr, nr_rays=nr_rays, **kw)
