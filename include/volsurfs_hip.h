@@ -233,7 +233,7 @@ int vsa_nt_mlp_fwd(const vsa_nt_plan* plan, const void* weights_h, const void* f
                    const int32_t* seg_start, uint8_t* texels, void* pre_out, void* stream);
 
 /* Backward of step 4: recomputes the forward per 32-slot tile, back-propagates
- * grad_rows (f32, already multiplied by grad_scale) through sigmoid (round = STE)
+ * grad_rows (f16, already multiplied by grad_scale) through sigmoid (round = STE)
  * and the three layers on MFMA.  Overwrites `features` IN PLACE with the feature
  * gradients (f16x2, still scaled) and accumulates grad_weights (f32
  * [n_tex][VSA_NT_WEIGHTS_PER_TEX], scaled) with one flush per workgroup.
@@ -242,7 +242,7 @@ int vsa_nt_mlp_fwd(const vsa_nt_plan* plan, const void* weights_h, const void* f
  * dfeat_abs_sum (f32 [n_tex][32], zeroed by the caller) += sum over slots of |dF| per
  * feature row: the overflow bound of vsa_nt_encode_bwd's fixed-point accumulation. */
 int vsa_nt_mlp_bwd(const vsa_nt_plan* plan, const void* weights_h, void* features,
-                   const int32_t* seg_start, float* grad_rows, float* grad_weights,
+                   const int32_t* seg_start, uint16_t* grad_rows, float* grad_weights,
                    float* dfeat_abs_sum, void* stream);
 
 /* Step 5: per-hit shading from the texel rows (expand LUT -> lerp -> fp16 SH
@@ -259,7 +259,7 @@ int vsa_nt_shade_fwd(const vsa_nt_plan* plan, const int32_t* hit_slot, const flo
                      float* surfs_rgb, float* surfs_alpha,
                      float* surfs_normals, float* coeffs_out, float* act_out, void* stream);
 
-/* Backward of step 5: grad_rows (f32 [row_base[last]*4], same row layout as
+/* Backward of step 5: grad_rows (f16 [row_base[last]*4], same row layout as
  * texels; zero on entry, see vsa_nt_mlp_bwd) += grad_scale * dL/d(q/255)
  * (round is a straight-through estimator, utils/math.py:5-18).  act_in: NULL, or the
  * act_out of the forward call on the SAME frame and parameters. */
@@ -267,7 +267,7 @@ int vsa_nt_shade_bwd(const vsa_nt_plan* plan, const int32_t* hit_slot, const flo
                      const float* rays_d, const float* tris, const int32_t* slot_of,
                      const int32_t* seg_start, const uint8_t* texels, int nr_rays,
                      const float* g_surfs_rgb,
-                     const float* g_surfs_alpha, float grad_scale, float* grad_rows,
+                     const float* g_surfs_alpha, float grad_scale, uint16_t* grad_rows,
                      const float* act_in, void* stream);
 
 /* Backward of step 3: grad_tables (f32 [n_tex][level_offset[n]][2]) +=

@@ -63,6 +63,7 @@ struct TexInfo {
   int begin, end, type, channels;
   int row_quads;        // quads per slot row of this degree
   long long row_first;  // quad of slot `begin`'s first channel of THIS texture (rgb: 0, alpha: +alpha quad)
+  int own_quads;        // quads of a slot row that belong to THIS texture (rgb: up to the alpha quad)
 };
 
 __device__ __forceinline__ TexInfo tex_info(const vsa_nt_plan& p, const int* seg_start, int tex) {
@@ -81,6 +82,7 @@ __device__ __forceinline__ TexInfo tex_info(const vsa_nt_plan& p, const int* seg
   t.end = seg_start[shell * VSA_NT_MAX_DEG + deg + 1];
   t.row_quads = nt_row_quads(deg);
   t.row_first = p.row_base[shell * VSA_NT_MAX_DEG + deg] + (type ? nt_alpha_quad(deg) : 0);
+  t.own_quads = type ? t.row_quads - nt_alpha_quad(deg) : nt_alpha_quad(deg);
   return t;
 }
 
@@ -340,7 +342,7 @@ __device__ __forceinline__ void pc_barrier() {
 __device__ __forceinline__ void pc_run(
     const vsa_nt_plan& plan, const Work wk, unsigned char* s_raw,
     const _Float16* __restrict__ weights, unsigned* __restrict__ features,
-    const int* __restrict__ seg_start, float* __restrict__ grad_rows,
+    const int* __restrict__ seg_start, _Float16* __restrict__ grad_rows,
     float* __restrict__ grad_weights, float* __restrict__ dfeat_abs_sum) {
   half8_t* s_frag = reinterpret_cast<half8_t*>(s_raw) - 16 * 64;   // indexed by fragment id 16..35 (20 KiB)
   _Float16* s_img_all = reinterpret_cast<_Float16*>(s_raw + PC_FRAGS * 64 * 16);
@@ -404,23 +406,21 @@ __device__ __forceinline__ void pc_run(
 #endif
 
   if (producer) {
-    auto load_grows = [&](int slot, float4 gr[4]) {
+    auto load_grows = [&](int slot, half4_t gr[4]) {   // raw f16: converting here would wait for the prefetch
       const bool ok = slot < wk.last;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int row0 = 8 * g + 4 * h;
-        gr[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gr[g] = half4_t{0, 0, 0, 0};
         if (ok && row0 < ti.channels) {
-          float4* gp = reinterpret_cast<float4*>(grad_rows) + ti.row_first +
-                     (long long)(slot - ti.begin) * ti.row_quads + (row0 >> 2);
-          gr[g] = *gp;
-          *gp = make_float4(0.f, 0.f, 0.f, 0.f);   // consume-and-clear
+          gr[g] = reinterpret_cast<const half4_t*>(grad_rows)[ti.row_first +
+                      (long long)(slot - ti.begin) * ti.row_quads + (row0 >> 2)];
         }
       }
     };
     float16_t gW3[2] = {float16_t{0}, float16_t{0}};   // the producer has slack: it also owns dW3
     half8_t bx[2], bx_next[2];
-    float4 gr[4], gr_next[4];
+    half4_t gr[4], gr_next[4];
     {
       const int s0 = wk.first + pr * 32 + p;
       prefetch_features(plan, features, ti.type, s0, wk.last, h, bx_next);
@@ -449,7 +449,7 @@ __device__ __forceinline__ void pc_run(
         // padding rows and slots past the end
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const float gv[4] = {gr[g].x, gr[g].y, gr[g].z, gr[g].w};
+          const float gv[4] = {(float)gr[g][0], (float)gr[g][1], (float)gr[g][2], (float)gr[g][3]};
           if (8 * g < ti.channels) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -459,6 +459,19 @@ __device__ __forceinline__ void pc_run(
           } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) d3h[g >> 1][4 * (g & 1) + i] = (_Float16)0;
+          }
+        }
+        // consume-and-clear.  Lanes run over (slot, own quad) pairs in memory order, so a
+        // store instruction covers whole stretches of a few lines (one 8-byte store per lane at
+        // its own row stride touched 32 lines per instruction and cost 180 us a frame).  The
+        // rows' loads have returned (d3h above); a wave's memory operations complete in order.
+        if (ti.channels > 0) {
+          const int s0 = slot - p, nq = min(32, wk.last - s0) * ti.own_quads;
+          half4_t* rows = reinterpret_cast<half4_t*>(grad_rows) + ti.row_first +
+                          (long long)(s0 - ti.begin) * ti.row_quads;
+          for (int i = lane; i < nq; i += 64) {
+            const int sl = i / ti.own_quads;
+            rows[sl * ti.row_quads + (i - sl * ti.own_quads)] = half4_t{0, 0, 0, 0};
           }
         }
         store_frags_s<S32>(set + SET_DOUT, 0, d3h[0], d3h[1], p, h);
@@ -686,7 +699,7 @@ constexpr int PC_RUN_COST = 44;
 __global__ __launch_bounds__(PC_BLOCK, 2) void nt_mlp_bwd_pc_kernel(
     vsa_nt_plan plan, const _Float16* __restrict__ weights,
     unsigned* __restrict__ features, const int* __restrict__ seg_start,
-    float* __restrict__ grad_rows, float* __restrict__ grad_weights,
+    _Float16* __restrict__ grad_rows, float* __restrict__ grad_weights,
     float* __restrict__ dfeat_abs_sum) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   nt_for_each_piece<32>(plan, seg_start, 1, PC_RUN_COST,
@@ -725,7 +738,7 @@ extern "C" int vsa_nt_mlp_fwd(const vsa_nt_plan* plan, const void* weights_h, co
 }
 
 extern "C" int vsa_nt_mlp_bwd(const vsa_nt_plan* plan, const void* weights_h, void* features,
-                              const int32_t* seg_start, float* grad_rows, float* grad_weights,
+                              const int32_t* seg_start, uint16_t* grad_rows, float* grad_weights,
                               float* dfeat_abs_sum, void* stream) {
   if (!plan || !weights_h || !features || !seg_start || !grad_rows || !grad_weights ||
       !dfeat_abs_sum)
@@ -741,7 +754,8 @@ extern "C" int vsa_nt_mlp_bwd(const vsa_nt_plan* plan, const void* weights_h, vo
   { const int rc = vsa_cu_count(&nr_cus); if (rc) return rc; }
   hipLaunchKernelGGL(nt_mlp_bwd_pc_kernel, dim3(nr_cus), dim3(PC_BLOCK), lds, (hipStream_t)stream,
                      *plan, reinterpret_cast<const _Float16*>(weights_h),
-                     reinterpret_cast<unsigned*>(features), seg_start, grad_rows, grad_weights,
+                     reinterpret_cast<unsigned*>(features), seg_start,
+                     reinterpret_cast<_Float16*>(grad_rows), grad_weights,
                      dfeat_abs_sum);
   VSA_RETURN_LAUNCH_STATUS();
 }

@@ -329,13 +329,19 @@ __global__ __launch_bounds__(SH_BLOCK, 3) void nt_shade_fwd_kernel(
 // occupancy of this atomic-bound kernel cost 27 % (measured), i.e. it is latency-sensitive.
 constexpr int SHB_BLOCK = 128;
 
+// no-return packed f16 add at the memory side (global_atomic_pk_add_f16: one dword per lane)
+__device__ __forceinline__ void atomic_pk_add_f16(_Float16* addr, float a, float b) {
+  const half2_t v = {(_Float16)a, (_Float16)b};
+  asm volatile("global_atomic_pk_add_f16 %0, %1, off" ::"v"(addr), "v"(__builtin_bit_cast(unsigned, v)) : "memory");
+}
+
 template <bool RECOMPUTE>
 __global__ __launch_bounds__(SHB_BLOCK, RECOMPUTE ? 2 : 4) void nt_shade_bwd_kernel(
     vsa_nt_plan plan, const int* __restrict__ hit_slot, const float* __restrict__ tex_uv,
     const float* __restrict__ rays_d, const float4* __restrict__ tris,
     const int* __restrict__ slot_of, const int* __restrict__ seg_start,
     const unsigned* __restrict__ texels, int N, const float* __restrict__ g_surfs_rgb,
-    const float* __restrict__ g_surfs_alpha, float grad_scale, float* __restrict__ grad_rows,
+    const float* __restrict__ g_surfs_alpha, float grad_scale, _Float16* __restrict__ grad_rows,
     const float4* __restrict__ act_in) {
   __shared__ float s_lut[RECOMPUTE ? VSA_NT_MAX_DEG * 256 : 1];
   __shared__ float s_graw[SHB_BLOCK][4];
@@ -392,15 +398,24 @@ __global__ __launch_bounds__(SHB_BLOCK, RECOMPUTE ? 2 : 4) void nt_shade_bwd_ker
     }
   }
   // per-wave cooperative scatter (no workgroup barrier needed: each wave reads
-  // only what its own lanes wrote)
+  // only what its own lanes wrote).  A lane owns a PAIR of adjacent row elements (one packed
+  // f16 atomic per corner: the float-atomic path is byte-bound at the memory side, so f16
+  // pairs halve its time): 36 pairs cover the 64 coefficients of a hit
+  //   degree d: ceil(3 nn / 2) rgb pairs + ceil(nn / 2) alpha pairs, nn = 2d + 1  (3, 7, 11, 15)
+  // an odd tail pairs with a padding element of the row and adds zero to it.
   const int lane = t & 63, wbase = t & ~63;
   const unsigned long long hits = __ballot(c.hit);
-  const int ch = lane < 48 ? lane >> 4 : 3;
-  const int m = lane < 48 ? lane & 15 : lane - 48;
-  const int d = m >= 9 ? 3 : (m >= 4 ? 2 : (m >= 1 ? 1 : 0));
-  const int nn = 2 * d + 1;
-  const int fidx = ch < 3 ? ch * nn + (m - d * d) : 4 * nt_alpha_quad(d) + (m - d * d);
-  const bool active = ch < 3 ? d < plan.rgb_degrees : (has_alpha && d < plan.alpha_degrees);
+  const int d = lane < 3 ? 0 : (lane < 10 ? 1 : (lane < 21 ? 2 : 3));
+  const int jb = lane - (d == 0 ? 0 : (d == 1 ? 3 : (d == 2 ? 10 : 21)));
+  const int nn = 2 * d + 1, n_rgb_pairs = (3 * nn + 1) >> 1;
+  const bool is_alpha = jb >= n_rgb_pairs;
+  const int e0 = is_alpha ? 2 * (jb - n_rgb_pairs) : 2 * jb;          // element index within the part
+  const int part = is_alpha ? nn : 3 * nn;
+  const int fidx = (is_alpha ? 4 * nt_alpha_quad(d) : 0) + e0;        // even: a 4-byte aligned f16 pair
+  const bool band_on = lane < 36 && (is_alpha ? (has_alpha && d < plan.alpha_degrees) : d < plan.rgb_degrees);
+  const bool on1 = band_on && e0 + 1 < part;
+  const int ch0 = is_alpha ? 3 : e0 / nn, ch1 = is_alpha ? 3 : (e0 + 1) / nn;
+  const int m0 = d * d + (is_alpha ? e0 : e0 % nn), m1 = on1 ? d * d + (is_alpha ? e0 + 1 : (e0 + 1) % nn) : 0;
   const float span = plan.sh_span[d];
   // Consecutive hits of a wave are neighbouring pixels: at the coarse degrees
   // (256^2, 512^2 textures) they fall on the SAME or on overlapping 2x2 footprints.
@@ -410,45 +425,52 @@ __global__ __launch_bounds__(SHB_BLOCK, RECOMPUTE ? 2 : 4) void nt_shade_bwd_ker
   // footprint no longer covers are flushed with an atomic (lanes of one degree take
   // the same decisions).
   int cur[4] = {-1, -1, -1, -1};
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
   unsigned long long rem = hits;
   while (rem) {
     const int hl = __ffsll((long long)rem) - 1;
     rem &= rem - 1;
     const int ht = wbase + hl;
-    if (active) {
-      const float g = s_graw[ht][ch] * s_basis[ht][m];
+    if (band_on) {
+      const float g0 = s_graw[ht][ch0] * s_basis[ht][m0];
+      const float g1 = on1 ? s_graw[ht][ch1] * s_basis[ht][m1] : 0.f;
       const float fx = s_f[ht][2 * d], fy = s_f[ht][2 * d + 1];
       // the lerp weights exactly as load_ctx forms them, then x span, then x g
       const float w[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
       int sl[4];
-      float v[4];
+      float v0[4], v1[4];
       const int r0 = s_row[ht][2 * d], r2 = s_row[ht][2 * d + 1], qd = nt_row_quads(d);
       sl[0] = r0, sl[1] = r0 + qd, sl[2] = r2, sl[3] = r2 + qd;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = (w[k] * span) * g;
+      for (int k = 0; k < 4; ++k) {
+        const float ws = w[k] * span;
+        v0[k] = ws * g0;
+        v1[k] = ws * g1;
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         bool kept = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const bool same = cur[j] == sl[k];
-          v[k] += same ? acc[j] : 0.f;
+          v0[k] += same ? acc0[j] : 0.f;
+          v1[k] += same ? acc1[j] : 0.f;
           kept |= same;
         }
-        if (!kept && cur[j] >= 0) atomicAdd(&grad_rows[(long long)cur[j] * 4 + fidx], acc[j]);
+        if (!kept && cur[j] >= 0) atomic_pk_add_f16(grad_rows + (long long)cur[j] * 4 + fidx, acc0[j], acc1[j]);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         cur[k] = sl[k];
-        acc[k] = v[k];
+        acc0[k] = v0[k];
+        acc1[k] = v1[k];
       }
     }
   }
-  if (active) {
+  if (band_on) {
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (cur[k] >= 0) atomicAdd(&grad_rows[(long long)cur[k] * 4 + fidx], acc[k]);
+      if (cur[k] >= 0) atomic_pk_add_f16(grad_rows + (long long)cur[k] * 4 + fidx, acc0[k], acc1[k]);
   }
 }
 
@@ -477,7 +499,7 @@ extern "C" int vsa_nt_shade_bwd(const vsa_nt_plan* plan, const int32_t* hit_slot
                                 const float* tex_uv, const float* rays_d, const float* tris,
                                 const int32_t* slot_of, const int32_t* seg_start,
                                 const uint8_t* texels, int nr_rays, const float* g_surfs_rgb,
-                                const float* g_surfs_alpha, float grad_scale, float* grad_rows,
+                                const float* g_surfs_alpha, float grad_scale, uint16_t* grad_rows,
                                 const float* act_in, void* stream) {
   if (!plan || nr_rays < 0) return VSA_ERR_ARG;
   if (nr_rays == 0) return VSA_OK;
@@ -489,11 +511,12 @@ extern "C" int vsa_nt_shade_bwd(const vsa_nt_plan* plan, const int32_t* hit_slot
     hipLaunchKernelGGL(nt_shade_bwd_kernel<false>, grid, dim3(SHB_BLOCK), 0, (hipStream_t)stream, *plan,
                        hit_slot, tex_uv, rays_d, reinterpret_cast<const float4*>(tris), slot_of,
                        seg_start, reinterpret_cast<const unsigned*>(texels), nr_rays, g_surfs_rgb,
-                       g_surfs_alpha, grad_scale, grad_rows, reinterpret_cast<const float4*>(act_in));
+                       g_surfs_alpha, grad_scale, reinterpret_cast<_Float16*>(grad_rows),
+                       reinterpret_cast<const float4*>(act_in));
   else
     hipLaunchKernelGGL(nt_shade_bwd_kernel<true>, grid, dim3(SHB_BLOCK), 0, (hipStream_t)stream, *plan,
                        hit_slot, tex_uv, rays_d, reinterpret_cast<const float4*>(tris), slot_of,
                        seg_start, reinterpret_cast<const unsigned*>(texels), nr_rays, g_surfs_rgb,
-                       g_surfs_alpha, grad_scale, grad_rows, nullptr);
+                       g_surfs_alpha, grad_scale, reinterpret_cast<_Float16*>(grad_rows), nullptr);
   VSA_RETURN_LAUNCH_STATUS();
 }

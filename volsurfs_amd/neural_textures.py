@@ -154,7 +154,7 @@ class NeuralTextureBank(torch.nn.Module):
         self.weights_h = torch.empty(self.n_tex, WEIGHTS_PER_TEX, dtype=torch.float16, device=dev)
         # per-degree row widths (include/volsurfs_hip.h: VSA_NT_ROW_QUADS), 4 elements per quad
         self.texels = torch.zeros(self.row_quads_total * 4, dtype=u8, device=dev)
-        self.grad_rows = torch.zeros(self.row_quads_total * 4, device=dev) if training else None
+        self.grad_rows = torch.zeros(self.row_quads_total * 4, dtype=torch.float16, device=dev) if training else None
         self.refresh_half_params()
 
     @torch.no_grad()

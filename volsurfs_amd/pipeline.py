@@ -137,7 +137,7 @@ class KShellPipeline:
                         slot_models += P_sd
         self.mlp_flops_fwd = fl          # unpadded FLOPs of one forward over the unique texels
         ntex = sum(1 for x in range(bank.n_tex) if bank.tex_channels(x))
-        rows_u8, rows_f32 = row_quads * 4, row_quads * 16
+        rows_u8, rows_f16 = row_quads * 4, row_quads * 8      # texel rows u8, gradient rows f16
         feats = slot_models * 64                      # 16 levels x f16x2 per (slot, model)
         gathers = M * (16 * 4 + 4 * sum(ROW_QUADS) * 4 + 8) + N * 12   # slot ids + 16 texel rows + uv, dirs
         nodes_b = self.tracer.nodes.numel() * 4 + self.tracer.tris.numel() * 4
@@ -147,8 +147,8 @@ class KShellPipeline:
             "nt_encode_fwd": P * 8 + feats + ntex * bank.n_entries * 4,
             "nt_mlp_fwd": feats + rows_u8 + ntex * 8192 * 2,
             "nt_shade_fwd": gathers + N * K * 16,
-            "nt_shade_bwd": gathers + N * K * 16 + rows_f32,
-            "nt_mlp_bwd": 2 * feats + 2 * rows_f32 + ntex * 8192 * (2 + 4),
+            "nt_shade_bwd": gathers + N * K * 16 + rows_f16,
+            "nt_mlp_bwd": 2 * feats + 2 * rows_f16 + ntex * 8192 * (2 + 4),
             "nt_encode_bwd": feats + P * 8 + ntex * bank.n_entries * 8,
         }
         return self.last_hits, self.last_slots
