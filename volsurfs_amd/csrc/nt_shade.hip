@@ -330,9 +330,10 @@ __global__ __launch_bounds__(SH_BLOCK, 3) void nt_shade_fwd_kernel(
 constexpr int SHB_BLOCK = 128;
 
 // no-return packed f16 add at the memory side (global_atomic_pk_add_f16: one dword per lane)
-__device__ __forceinline__ void atomic_pk_add_f16(_Float16* addr, float a, float b) {
+// (uniform base + 32-bit byte offset: the buffer is far below 4 GiB)
+__device__ __forceinline__ void atomic_pk_add_f16(const _Float16* base, unsigned byte_off, float a, float b) {
   const half2_t v = {(_Float16)a, (_Float16)b};
-  asm volatile("global_atomic_pk_add_f16 %0, %1, off" ::"v"(addr), "v"(__builtin_bit_cast(unsigned, v)) : "memory");
+  asm volatile("global_atomic_pk_add_f16 %0, %1, %2" ::"v"(byte_off), "v"(__builtin_bit_cast(unsigned, v)), "s"(base) : "memory");
 }
 
 template <bool RECOMPUTE>
@@ -398,79 +399,108 @@ __global__ __launch_bounds__(SHB_BLOCK, RECOMPUTE ? 2 : 4) void nt_shade_bwd_ker
     }
   }
   // per-wave cooperative scatter (no workgroup barrier needed: each wave reads
-  // only what its own lanes wrote).  A lane owns a PAIR of adjacent row elements (one packed
-  // f16 atomic per corner: the float-atomic path is byte-bound at the memory side, so f16
-  // pairs halve its time): 36 pairs cover the 64 coefficients of a hit
-  //   degree d: ceil(3 nn / 2) rgb pairs + ceil(nn / 2) alpha pairs, nn = 2d + 1  (3, 7, 11, 15)
-  // an odd tail pairs with a padding element of the row and adds zero to it.
+  // only what its own lanes wrote).  The memory-side atomic path is bound by its 64-byte
+  // REQUESTS (PMC: 18 G requests/s whatever their fill), so the unit of accumulation is the
+  // 64-byte LINE of gradient rows, not the row: a lane owns one PAIR of adjacent f16 elements
+  // at a fixed position of a line (one global_atomic_pk_add_f16 per flush) —
+  //   degree 0: 16-B rows, 4 slots per line x 3 pairs   (lanes  0..11)
+  //   degree 1: 32-B rows, 2 slots per line x 7 pairs   (lanes 12..25)
+  //   degree 2: 64-B rows, 11 pairs                      (lanes 26..36)
+  //   degree 3: 64-B rows, 15 pairs                      (lanes 37..51)
+  // (pairs of a row: ceil(3 nn / 2) rgb + ceil(nn / 2) alpha, nn = 2d + 1; an odd tail pairs
+  // with a padding element and adds zero to it.)
   const int lane = t & 63, wbase = t & ~63;
   const unsigned long long hits = __ballot(c.hit);
-  const int d = lane < 3 ? 0 : (lane < 10 ? 1 : (lane < 21 ? 2 : 3));
-  const int jb = lane - (d == 0 ? 0 : (d == 1 ? 3 : (d == 2 ? 10 : 21)));
-  const int nn = 2 * d + 1, n_rgb_pairs = (3 * nn + 1) >> 1;
+  const int d = lane < 12 ? 0 : (lane < 26 ? 1 : (lane < 37 ? 2 : 3));
+  const int lb = lane - (d == 0 ? 0 : (d == 1 ? 12 : (d == 2 ? 26 : 37)));
+  const int nn = 2 * d + 1, n_rgb_pairs = (3 * nn + 1) >> 1, row_pairs = n_rgb_pairs + ((nn + 1) >> 1);
+  const int q = lb / row_pairs, jb = lb - q * row_pairs;              // slot within the line, pair within the row
   const bool is_alpha = jb >= n_rgb_pairs;
   const int e0 = is_alpha ? 2 * (jb - n_rgb_pairs) : 2 * jb;          // element index within the part
   const int part = is_alpha ? nn : 3 * nn;
-  const int fidx = (is_alpha ? 4 * nt_alpha_quad(d) : 0) + e0;        // even: a 4-byte aligned f16 pair
-  const bool band_on = lane < 36 && (is_alpha ? (has_alpha && d < plan.alpha_degrees) : d < plan.rgb_degrees);
+  const int qd = nt_row_quads(d), qsh = d == 0 ? 1 : (d == 1 ? 2 : 3);
+  // position of the pair in its line, in halfs (even: a 4-byte aligned f16 pair)
+  const int lofs = 4 * (q * qd + (is_alpha ? nt_alpha_quad(d) : 0)) + e0;
+  const bool band_on = lane < 52 && (is_alpha ? (has_alpha && d < plan.alpha_degrees) : d < plan.rgb_degrees);
   const bool on1 = band_on && e0 + 1 < part;
   const int ch0 = is_alpha ? 3 : e0 / nn, ch1 = is_alpha ? 3 : (e0 + 1) / nn;
   const int m0 = d * d + (is_alpha ? e0 : e0 % nn), m1 = on1 ? d * d + (is_alpha ? e0 + 1 : (e0 + 1) % nn) : 0;
   const float span = plan.sh_span[d];
-  // Consecutive hits of a wave are neighbouring pixels: at the coarse degrees
-  // (256^2, 512^2 textures) they fall on the SAME or on overlapping 2x2 footprints.
-  // Each lane keeps the previous hit's four corner rows open with a running sum; a
-  // corner of the new hit that matches any open row (its own position or, after a
-  // one-texel step, a neighbouring one) inherits that sum, and only the rows the new
-  // footprint no longer covers are flushed with an atomic (lanes of one degree take
-  // the same decisions).
+  // Consecutive hits of a wave are neighbouring pixels: their 2x2 footprints fall on the same
+  // or on neighbouring lines.  Each lane keeps up to four lines open with a running sum (the
+  // lines the previous footprint touched: {x0, x1} x {y0, y1}, fewer when corners share a
+  // line); a line of the new footprint that matches ANY open line inherits its sum, and only
+  // lines the new footprint no longer touches are flushed — all lanes of a degree take the
+  // same decisions, so a flush is ONE request for the whole line.
+  // (the pair's two running sums travel as one float2: v_pk_mul / v_pk_fma_f32, and the
+  // "inherit if same line" select is an fma with a 1.0 / 0.0 factor — the loop is VALU-bound)
+  typedef float float2_t __attribute__((ext_vector_type(2)));
   int cur[4] = {-1, -1, -1, -1};
-  float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
+  float2_t acc[4] = {float2_t(0.f), float2_t(0.f), float2_t(0.f), float2_t(0.f)};
+  const unsigned lofs_b = 2u * (unsigned)lofs;
   unsigned long long rem = hits;
   while (rem) {
     const int hl = __ffsll((long long)rem) - 1;
     rem &= rem - 1;
     const int ht = wbase + hl;
     if (band_on) {
-      const float g0 = s_graw[ht][ch0] * s_basis[ht][m0];
-      const float g1 = on1 ? s_graw[ht][ch1] * s_basis[ht][m1] : 0.f;
+      float2_t gg;
+      gg.x = s_graw[ht][ch0] * s_basis[ht][m0];
+      gg.y = on1 ? s_graw[ht][ch1] * s_basis[ht][m1] : 0.f;
       const float fx = s_f[ht][2 * d], fy = s_f[ht][2 * d + 1];
       // the lerp weights exactly as load_ctx forms them, then x span, then x g
       const float w[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
       int sl[4];
-      float v0[4], v1[4];
-      const int r0 = s_row[ht][2 * d], r2 = s_row[ht][2 * d + 1], qd = nt_row_quads(d);
-      sl[0] = r0, sl[1] = r0 + qd, sl[2] = r2, sl[3] = r2 + qd;
+      float wl[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float ws = w[k] * span;
-        v0[k] = ws * g0;
-        v1[k] = ws * g1;
+      for (int y = 0; y < 2; ++y) {
+        const int ra = s_row[ht][2 * d + y], rb = ra + qd;           // the x0 and x1 corner rows (quads)
+        const int la = ra >> 3, lbn = rb >> 3;                        // their lines (8 quads of 8 B)
+        const bool ma = q == ((ra & 7) >> qsh), mb = q == ((rb & 7) >> qsh), one = la == lbn;
+        sl[2 * y] = la;
+        wl[2 * y] = ma ? w[2 * y] : ((one && mb) ? w[2 * y + 1] : 0.f);
+        sl[2 * y + 1] = one ? -1 : lbn;
+        wl[2 * y + 1] = (!one && mb) ? w[2 * y + 1] : 0.f;
       }
+      // the y1 corners may sit on a line of the y0 corners (sparsely marked regions): rare,
+      // so the fold is behind a wave-uniform test
+      const bool dup = sl[2] == sl[0] || sl[2] == sl[1] || ((sl[3] == sl[0] || sl[3] == sl[1]) && sl[3] >= 0);
+      if (__builtin_expect(__ballot(dup) != 0ull, 0)) {
+#pragma unroll
+        for (int k = 2; k < 4; ++k)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            if (sl[k] == sl[i] && sl[k] >= 0) {
+              wl[i] += wl[k];
+              wl[k] = 0.f;
+              sl[k] = -1;
+            }
+      }
+      float2_t v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = float2_t(wl[k] * span) * gg;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         bool kept = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const bool same = cur[j] == sl[k];
-          v0[k] += same ? acc0[j] : 0.f;
-          v1[k] += same ? acc1[j] : 0.f;
+          v[k] = __builtin_elementwise_fma(acc[j], float2_t(same ? 1.0f : 0.0f), v[k]);
           kept |= same;
         }
-        if (!kept && cur[j] >= 0) atomic_pk_add_f16(grad_rows + (long long)cur[j] * 4 + fidx, acc0[j], acc1[j]);
+        if (!kept && cur[j] >= 0) atomic_pk_add_f16(grad_rows, (unsigned)cur[j] * 64u + lofs_b, acc[j].x, acc[j].y);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         cur[k] = sl[k];
-        acc0[k] = v0[k];
-        acc1[k] = v1[k];
+        acc[k] = v[k];
       }
     }
   }
   if (band_on) {
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (cur[k] >= 0) atomic_pk_add_f16(grad_rows + (long long)cur[k] * 4 + fidx, acc0[k], acc1[k]);
+      if (cur[k] >= 0) atomic_pk_add_f16(grad_rows, (unsigned)cur[k] * 64u + lofs_b, acc[k].x, acc[k].y);
   }
 }
 
@@ -506,6 +536,7 @@ extern "C" int vsa_nt_shade_bwd(const vsa_nt_plan* plan, const int32_t* hit_slot
   if (!hit_slot || !tex_uv || !rays_d || !tris || !slot_of || !seg_start || !texels || !g_surfs_rgb ||
       !g_surfs_alpha || !grad_rows)
     return VSA_ERR_ARG;
+  if (plan->row_base[VSA_MAX_SHELLS * VSA_NT_MAX_DEG] * 8 >= (1ll << 32)) return VSA_ERR_UNSUPPORTED;   // 32-bit atomic offsets
   dim3 grid(vsa_div_up(nr_rays, SHB_BLOCK), plan->nr_shells);
   if (act_in)
     hipLaunchKernelGGL(nt_shade_bwd_kernel<false>, grid, dim3(SHB_BLOCK), 0, (hipStream_t)stream, *plan,
