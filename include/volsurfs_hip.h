@@ -444,6 +444,18 @@ int vsa_reel_next_rays_batch(const float* c2w_all, const float* intrinsics_inv_a
                              float* rays_o, float* rays_d, float* gt_rgb, float* gt_mask,
                              float* points_2d, void* stream);
 
+/* Re-orders a row-major per-pixel array [height*width, channels] (channels 1..4, f32) into
+ * 8x8-pixel-tile-major order (inverse = 0), or back (inverse = 1).  height and width must be
+ * multiples of 8.  Used on the rays of a full frame before the traversal (a wave then covers
+ * a square patch of pixels instead of a 64x1 strip) and on the rendered colours after it. */
+int vsa_tile_order(const float* src, float* dst, int height, int width, int channels, int inverse,
+                   void* stream);
+/* The same forward re-ordering for the three per-ray inputs of a frame ([H*W,3] each; gt_rgb
+ * and gt_rgb_tiled may be NULL) in one launch. */
+int vsa_tile_order_rays(const float* rays_o, const float* rays_d, const float* gt_rgb,
+                        float* rays_o_tiled, float* rays_d_tiled, float* gt_rgb_tiled, int height,
+                        int width, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,8 @@ def test_argument_errors_are_reported_not_ignored():
     assert L.vsa_camera_rays(null, null, 4, 4, 1, 0, u64, u64, null, null, null, null) == ERR_ARG
     assert L.vsa_camera_rays(null, null, 0, 4, 1, 0, u64, u64, null, null, null, null) == 0      # no pixels
     assert L.vsa_camera_rays(null, null, 4, 4, 0, 0, u64, u64, null, null, null, null) == ERR_ARG  # R < 1
+    assert L.vsa_tile_order(null, null, 12, 16, 3, 0, null) == ERR_ARG                              # 12 % 8
+    assert L.vsa_tile_order(null, null, 16, 16, 3, 0, null) == ERR_ARG                              # null arrays
     assert L.vsa_reel_next_rays_batch(null, null, null, null, 0, 4, 4, 8, 1, 0, u64, u64, null, null, null,
                                       null, null, null, null) == ERR_ARG                             # no cameras
     h = ctypes.c_void_p()

@@ -28,8 +28,8 @@ def test_pipeline_matches_oracle(K, subdiv, res):
     hits, slots = pipe.stats()
     assert hits == int(ref["hit"].sum()) and hits > res * res // 4
     # per-shell appearance before compositing
-    e_rgb = np.abs(pipe.surfs_rgb.cpu().numpy() - ref["surfs_rgb"])
-    e_a = np.abs(pipe.surfs_alpha.cpu().numpy() - ref["surfs_alpha"])
+    e_rgb = np.abs(pipe.to_ray_order(pipe.surfs_rgb).cpu().numpy() - ref["surfs_rgb"])
+    e_a = np.abs(pipe.to_ray_order(pipe.surfs_alpha).cpu().numpy() - ref["surfs_alpha"])
     # identical except where an 8-bit texel flipped by one step (fp32 summation
     # order inside the MLP: MFMA vs torch-CPU) — see tests/test_nt_shade.py
     assert (e_rgb > 1e-5).mean() < 0.05 and e_rgb.max() < 0.05
@@ -116,7 +116,7 @@ def test_full_size_frame_properties():
     assert hits > 800000 and 16 * hits >= slots > hits        # 4 corners x 4 bands per hit
     seg = pipe.bank.seg_start.cpu()
     assert (seg[1:] >= seg[:-1]).all() and int(seg[-1]) == slots
-    hit_slot = pipe._hit_slot
+    hit_slot = pipe.to_ray_order(pipe._hit_slot, dim=1)
     miss_all = (hit_slot < 0).all(0)
     assert miss_all.any() and torch.equal(a[miss_all], torch.ones_like(a[miss_all]))
     assert a.min() >= 0 and a.max() <= 1.0005

@@ -43,13 +43,27 @@ class KShellPipeline:
     dtype_desc = "f16 (hash features, MLP on MFMA, composite: as the reference), f32 accumulate and I/O"
 
     def __init__(self, meshes, rays_o, rays_d, gt_rgb, bg_color=(1.0, 1.0, 1.0), seed=42,
-                 init="tcnn"):
+                 init="tcnn", image_hw=None):
+        """image_hw = (H, W): the rays are the row-major pixels of one full frame; every step
+        then first re-orders them (and the ground truth) into 8x8-pixel tiles, so that a wave
+        of any per-ray kernel covers a square patch, and returns the colours in the caller's
+        order (vsa_tile_order; both passes are inside the step)."""
         from .neural_textures import NeuralTextureBank
         self.meshes = meshes
         self.K = len(meshes)
         self.tracer = RayTracer(meshes)
         self.rays_o, self.rays_d, self.gt = rays_o, rays_d, gt_rgb
         self.nr_rays = rays_o.shape[0]
+        import os
+        self.image_hw = None
+        if image_hw is not None and image_hw[0] % 8 == 0 and image_hw[1] % 8 == 0 and \
+                image_hw[0] * image_hw[1] == self.nr_rays and os.environ.get("VSA_TILE_ORDER", "1") != "0":
+            self.image_hw = (int(image_hw[0]), int(image_hw[1]))
+            self._o_t, self._d_t, self._gt_t = (torch.empty_like(x) for x in (rays_o, rays_d, gt_rgb))
+            self._rgb_out = torch.empty_like(gt_rgb)
+            H, W = self.image_hw
+            self._tile_idx = torch.arange(H * W, device=rays_o.device).reshape(H // 8, 8, W // 8, 8) \
+                .permute(0, 2, 1, 3).reshape(-1)          # element i of a tile-major array = pixel _tile_idx[i]
         dev = rays_o.device
         self.bg = torch.tensor([bg_color], device=dev, dtype=torch.float32)
         self.timer = StageTimer()
@@ -73,6 +87,15 @@ class KShellPipeline:
         # per-hit output sigmoids kept from shade_fwd for shade_bwd of the same frame
         self._act = torch.empty(K, N, 4, device=dev)
 
+    def to_ray_order(self, x, dim=0):
+        """Tests / inspection: a per-ray internal buffer (surfs_rgb, surfs_alpha, _hit_slot: in
+        tile order when image_hw is set) re-indexed in the caller's ray order."""
+        if self.image_hw is None:
+            return x
+        out = torch.empty_like(x)
+        out.index_copy_(dim, self._tile_idx, x)
+        return out
+
     @classmethod
     def synthetic(cls, K=5, subdiv=6, res=800, device="cuda", seed=42, **kw):
         meshes = nested_shells(K=K, subdiv=subdiv, device=device)
@@ -80,7 +103,7 @@ class KShellPipeline:
                             device=device)
         g = torch.Generator(device=device).manual_seed(seed)
         gt = torch.rand(o.shape[0], 3, device=device, generator=g)
-        p = cls(meshes, o, d, gt, seed=seed, **kw)
+        p = cls(meshes, o, d, gt, seed=seed, image_hw=(res, res), **kw)
         p.res = res
         p.subdiv = subdiv
         return p
@@ -191,8 +214,17 @@ class KShellPipeline:
                 bank.tables.grad.zero_()
                 bank.weights.grad.zero_()
         T.run("zero_grad", zero_grad, record, bytes=(bank.tables.numel() + bank.weights.numel()) * 4)
+        rays_o, rays_d, gt = self.rays_o, self.rays_d, self.gt
+        if self.image_hw is not None:
+            H, W = self.image_hw
+
+            T.run("ray_tile_order",
+                  lambda: _lib.call("vsa_tile_order_rays", self.rays_o, self.rays_d, self.gt, self._o_t,
+                                    self._d_t, self._gt_t, H, W, _lib.stream_ptr()),
+                  record, bytes=N * 72)
+            rays_o, rays_d, gt = self._o_t, self._d_t, self._gt_t
         hit_t, hit_slot, hit_uv = T.run(
-            "trace", lambda: self.tracer.trace_all(self.rays_o, self.rays_d), record,
+            "trace", lambda: self.tracer.trace_all(rays_o, rays_d), record,
             bytes=acct.get("trace", 0))
         self._hit_slot = hit_slot
         tex_uv = T.run("nt_mark_compact",
@@ -203,7 +235,7 @@ class KShellPipeline:
         T.run("nt_mlp_fwd", bank.mlp, record, bytes=acct.get("nt_mlp_fwd", 0), flops=mlp_flops,
               bound="mfma")
         rgb_k, alpha_k, _, _ = T.run(
-            "nt_shade_fwd", lambda: bank.shade(hit_slot, tex_uv, self.rays_d, self.tracer.tris,
+            "nt_shade_fwd", lambda: bank.shade(hit_slot, tex_uv, rays_d, self.tracer.tris,
                                                act_out=self._act),
             record, bytes=acct.get("nt_shade_fwd", 0))
         self.surfs_rgb, self.surfs_alpha = rgb_k, alpha_k
@@ -214,11 +246,11 @@ class KShellPipeline:
         # backward kernel (vsa_composite_dense_bwd_l1)
         from .composite import composite_bwd_l1_raw
         g_c, g_a = T.run("composite_bwd",
-                         lambda: composite_bwd_l1_raw(rgb_k, alpha_k, self.bg, rgb, self.gt,
+                         lambda: composite_bwd_l1_raw(rgb_k, alpha_k, self.bg, rgb, gt,
                                                       1.0 / (3.0 * N)), record,
                          bytes=N * (24 + 32 * K))
         tris = self.tracer.tris
-        T.run("nt_shade_bwd", lambda: bank.backward_shade(hit_slot, tex_uv, self.rays_d, tris, g_c, g_a,
+        T.run("nt_shade_bwd", lambda: bank.backward_shade(hit_slot, tex_uv, rays_d, tris, g_c, g_a,
                                                            self.grad_scale, self._act), record,
               bytes=acct.get("nt_shade_bwd", 0), bound="atomic")
         T.run("nt_mlp_bwd", lambda: bank.backward_mlp(self.grad_scale), record,
@@ -235,4 +267,9 @@ class KShellPipeline:
                     bank.backward_encode(self.grad_scale, shells=(s, s + 1))
                     grad_ready(bank.tables.grad[s * 8:(s + 1) * 8])
             T.run("nt_encode_bwd", by_shell, record, bytes=enc_bytes)
+        if self.image_hw is not None:      # colours back in the caller's (row-major) order
+            T.run("rgb_row_order", lambda: _lib.call("vsa_tile_order", rgb, self._rgb_out, self.image_hw[0],
+                                                     self.image_hw[1], 3, 1, _lib.stream_ptr()),
+                  record, bytes=N * 24)
+            return self._rgb_out
         return rgb
