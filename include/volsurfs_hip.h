@@ -456,6 +456,68 @@ int vsa_tile_order_rays(const float* rays_o, const float* rays_d, const float* g
                         float* rays_o_tiled, float* rays_d_tiled, float* gt_rgb_tiled, int height,
                         int width, void* stream);
 
+/* ---- OccupancyGrid: include/volsurfs/OccupancyGrid.cuh:9-68 -----------------
+ * A cubic grid of nr_voxels_per_dim^3 voxels (a power of two <= 1024) in Morton order, centred on
+ * the origin, with side lengths extent_{x,y,z}: grid_values f32 [n^3], grid_occupancy / grid_roi
+ * u8 (torch.bool) [n^3].  Kernels: kernels/volsurfs/OccupancyGridGPU.cuh, occ_grid_helpers.h.
+ * Every ray marcher is capped at 65536 steps (the reference's loops are unbounded). */
+
+/* get_grid_lower_left_voxels_vertices (centre_of_voxel = 0) / get_grid_samples,
+ * get_random_grid_samples(_in_roi) (centre_of_voxel = 1, optional jitter inside the voxel):
+ * positions [nr_points,3] of the voxels point_indices (NULL = 0..nr_points-1).
+ * OccupancyGridGPU.cuh:31-119. */
+int vsa_occ_grid_points(const int32_t* point_indices, int nr_points, int nr_voxels_per_dim,
+                        float extent_x, float extent_y, float extent_z, int centre_of_voxel, int jitter,
+                        uint64_t rng_state, uint64_t rng_inc, float* out_points, void* stream);
+/* update_grid_values: grid[idx] = max(values, grid[idx] * decay).  OccupancyGridGPU.cuh:122-151. */
+int vsa_occ_update_values(const int32_t* point_indices, const float* values, int nr_points, float decay,
+                          float* grid_values, void* stream);
+/* update_grid_occupancy_with_density_values (:153-225): occupied = value > thresh (any of the 27
+ * neighbours when check_neighbours). */
+int vsa_occ_update_occupancy_density(const int32_t* point_indices, int nr_points, int nr_voxels_per_dim,
+                                     float extent_x, float extent_y, float extent_z,
+                                     float occupancy_thresh, int check_neighbours,
+                                     const float* grid_values, uint8_t* grid_occupancy, void* stream);
+/* update_grid_occupancy_with_sdf_values (:229-315): NeuS logistic density of the smallest |sdf|
+ * reachable in the voxel > thresh; logistic_beta [nr_points]. */
+int vsa_occ_update_occupancy_sdf(const int32_t* point_indices, const float* logistic_beta, int nr_points,
+                                 int nr_voxels_per_dim, float extent_x, float extent_y, float extent_z,
+                                 float occupancy_thresh, const float* grid_values,
+                                 uint8_t* grid_occupancy, void* stream);
+/* check_occupancy (:376-413): per point (roi && occupied) and the voxel's value (false / 0 outside). */
+int vsa_occ_check(const float* points, int nr_points, int nr_voxels_per_dim, float extent_x,
+                  float extent_y, float extent_z, const float* grid_values,
+                  const uint8_t* grid_occupancy, const uint8_t* grid_roi, uint8_t* out_occupancy,
+                  float* out_values, void* stream);
+/* get_rays_t_near_t_far (:318-374). */
+int vsa_occ_rays_t_near_t_far(const float* rays_o, const float* rays_d, const float* ray_t_entry,
+                              const float* ray_t_exit, int nr_rays, int nr_voxels_per_dim,
+                              float extent_x, float extent_y, float extent_z,
+                              const uint8_t* grid_occupancy, const uint8_t* grid_roi, float* out_t_near,
+                              float* out_t_far, void* stream);
+/* get_first_rays_sample_start_of_grid_occupied_regions (:505-581): pack of one sample per ray. */
+int vsa_occ_first_sample(const float* rays_o, const float* rays_d, const float* ray_t_entry,
+                         const float* ray_t_exit, int nr_rays, int nr_voxels_per_dim, float extent_x,
+                         float extent_y, float extent_z, const uint8_t* grid_occupancy,
+                         const uint8_t* grid_roi, float* samples_3d, float* samples_dirs,
+                         float* samples_z, float* samples_dt, int32_t* ray_start_end_idx, void* stream);
+/* advance_ray_sample_to_next_occupied_voxel (:415-503); new_samples_3d may alias samples_3d. */
+int vsa_occ_advance_samples(const float* samples_dirs, const float* samples_3d, int nr_points,
+                            int nr_voxels_per_dim, float extent_x, float extent_y, float extent_z,
+                            const uint8_t* grid_occupancy, const uint8_t* grid_roi,
+                            float* new_samples_3d, uint8_t* is_within_bounds, void* stream);
+/* RaySampler::compute_samples_fg_in_grid_occupied_regions (src/RaySampler.cu:243-334, kernel
+ * RaySamplerGPU.cuh:275-457): equidistant samples in occupied-space arc length; outputs as
+ * vsa_sample_fg. */
+int vsa_sample_fg_occupied(const float* rays_o, const float* rays_d, const float* ray_t_entry,
+                           const float* ray_t_exit, float min_dist_between_samples,
+                           int min_nr_samples_per_ray, int max_nr_samples_per_ray, int jitter_samples,
+                           uint64_t rng_state, uint64_t rng_inc, int nr_voxels_per_dim, float extent_x,
+                           float extent_y, float extent_z, const uint8_t* grid_occupancy,
+                           const uint8_t* grid_roi, float* ray_max_dt, int32_t* samples_idx,
+                           float* samples_3d, float* samples_dirs, float* samples_z,
+                           int32_t* ray_start_end_idx, int nr_rays, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

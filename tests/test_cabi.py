@@ -52,6 +52,13 @@ def test_argument_errors_are_reported_not_ignored():
     assert L.vsa_camera_rays(null, null, 4, 4, 1, 0, u64, u64, null, null, null, null) == ERR_ARG
     assert L.vsa_camera_rays(null, null, 0, 4, 1, 0, u64, u64, null, null, null, null) == 0      # no pixels
     assert L.vsa_camera_rays(null, null, 4, 4, 0, 0, u64, u64, null, null, null, null) == ERR_ARG  # R < 1
+    f1 = ctypes.c_float(1.0)
+    assert L.vsa_occ_grid_points(null, 8, 24, f1, f1, f1, 1, 0, u64, u64, null, null) == ERR_ARG    # 24 is not a power of two
+    assert L.vsa_occ_grid_points(null, 0, 16, f1, f1, f1, 1, 0, u64, u64, null, null) == 0
+    assert L.vsa_occ_update_values(null, null, 4, ctypes.c_float(1.5), null, null) == ERR_ARG       # decay > 1
+    assert L.vsa_occ_check(null, 4, 16, f1, f1, f1, null, null, null, null, null, null) == ERR_ARG
+    assert L.vsa_sample_fg_occupied(null, null, null, null, f1, 1, 8, 0, u64, u64, 16, f1, f1, f1, null, null,
+                                    null, null, null, null, null, null, 4, null) == ERR_ARG
     assert L.vsa_tile_order(null, null, 12, 16, 3, 0, null) == ERR_ARG                              # 12 % 8
     assert L.vsa_tile_order(null, null, 16, 16, 3, 0, null) == ERR_ARG                              # null arrays
     assert L.vsa_reel_next_rays_batch(null, null, null, null, 0, 4, 4, 8, 1, 0, u64, u64, null, null, null,

@@ -1,9 +1,9 @@
 """Mirror of the reference's pybind11 module `volsurfs` (src/PyBridge.cxx:19-139)
 for the classes the K-shell path reaches: RaySamplesPacked, VolumeRendering,
 RaySampler — same class / method names, argument order and return shapes, on the
-HIP kernels of libvolsurfs_hip.so.  Methods of the reference surface that only
-the sibling methods (nerf / surf / offsets_surfs) use raise NotImplementedError
-(SURVEY §8f row 4); OccupancyGrid is not executed by VolSurfs.render_rays (A12).
+HIP kernels of libvolsurfs_hip.so — plus OccupancyGrid and the samplers that only
+the sibling methods (nerf / surf / offsets_surfs) use (not executed
+by VolSurfs.render_rays, A12).
 
 Differences a caller can observe: contract violations raise (the reference CHECKs
 abort the process), kernels are asynchronous on the current stream.
@@ -434,12 +434,34 @@ class RaySampler:
         return c
 
     @staticmethod
-    def _todo(name):
-        raise NotImplementedError(f"RaySampler.{name}: used only by nerf/surf/offsets_surfs "
-                                  "(SURVEY §8f row 4)")
+    def compute_samples_fg_in_grid_occupied_regions(rays_o, rays_d, ray_t_entry, ray_t_exit,
+                                                    min_dist_between_samples, min_nr_samples_per_ray,
+                                                    max_nr_samples_per_ray, jitter_samples,
+                                                    nr_voxels_per_dim, grid_extent, grid_occupancy,
+                                                    grid_roi, values_dim):
+        """src/RaySampler.cu:243-334: foreground samples only where the occupancy grid is occupied
+        (equidistant in occupied-space arc length), compacted."""
+        import ctypes
+        for t, n in ((rays_o, "rays_o"), (rays_d, "rays_d"), (ray_t_entry, "ray_t_entry"), (ray_t_exit, "ray_t_exit")):
+            if t.dim() != 2:
+                raise _lib.VolsurfsHipError(f"{n} should be 2-D, it has sizes {tuple(t.shape)}")
+        N = rays_o.shape[0]
+        p = RaySamplesPacked(N, N * int(max_nr_samples_per_ray), 0, int(values_dim))
+        p.ray_o, p.ray_d = rays_o.clone().contiguous(), rays_d.clone().contiguous()
+        p.ray_enter, p.ray_exit = ray_t_entry.clone().contiguous(), ray_t_exit.clone().contiguous()
+        p.is_compacted = False
+        ex = [float(v) for v in grid_extent]
+        rng = RaySampler.m_rng
+        _lib.call("vsa_sample_fg_occupied", p.ray_o, p.ray_d, p.ray_enter, p.ray_exit,
+                  float(min_dist_between_samples), int(min_nr_samples_per_ray),
+                  int(max_nr_samples_per_ray), bool(jitter_samples), ctypes.c_uint64(rng.state),
+                  ctypes.c_uint64(rng.inc), int(nr_voxels_per_dim), ex[0], ex[1], ex[2],
+                  _as_flags(grid_occupancy), _as_flags(grid_roi), p.ray_max_dt, p.samples_idx,
+                  p.samples_3d, p.samples_dirs, p.samples_z, p.ray_start_end_idx, N, _lib.stream_ptr())
+        if jitter_samples:
+            rng.advance()
+        return p.compact_to_valid_samples()
 
-    compute_samples_fg_in_grid_occupied_regions = staticmethod(
-        lambda *a: RaySampler._todo("compute_samples_fg_in_grid_occupied_regions"))
     @staticmethod
     def init_with_one_sample_per_ray(samples_3d, samples_dir):
         """src/RaySampler.cu:30-68: a pack with exactly one sample per ray (z = dt = 0)."""
@@ -536,3 +558,225 @@ class SumOverRaysFunc(torch.autograd.Function):
                                                    ctx.ray_samples_packed, sample_values)
         ctx.ray_samples_packed = None
         return None, g
+
+
+def _as_flags(t):
+    """torch.bool grid -> the same storage viewed as uint8 (what the kernels index)."""
+    if t.dtype not in (torch.bool, torch.uint8) or not t.is_contiguous():
+        raise _lib.VolsurfsHipError("occupancy / roi grids must be contiguous bool tensors")
+    return t.view(torch.uint8)
+
+
+class OccupancyGrid:
+    """include/volsurfs/OccupancyGrid.cuh:9-68, src/OccupancyGrid.cu: nr_voxels_per_dim^3 voxels
+    in Morton order, centred on the origin; values (density or sdf), occupancy flags and a
+    region-of-interest mask, all resident on the device."""
+    m_rng = _Pcg32State()
+
+    def __init__(self, nr_voxels_per_dim, grid_extent):
+        self.m_nr_voxels_per_dim = int(nr_voxels_per_dim)
+        self.m_grid_extent = [float(v) for v in grid_extent]
+        if len(self.m_grid_extent) != 3:
+            raise _lib.VolsurfsHipError("grid_extent must have 3 components")
+        self.m_grid_values = OccupancyGrid.make_grid_values(nr_voxels_per_dim)
+        self.m_grid_occupancy = OccupancyGrid.make_grid_occupancy(nr_voxels_per_dim)
+        self.m_grid_roi = OccupancyGrid.make_grid_occupancy(nr_voxels_per_dim)
+
+    # ---- construction / accessors (src/OccupancyGrid.cu:18-165)
+    @staticmethod
+    def _check_n(n):
+        n = int(n)
+        if n < 2 or n > 1024 or n & (n - 1):
+            raise _lib.VolsurfsHipError("nr_voxels_per_dim must be a power of two (Morton codes), 2..1024")
+        return n
+
+    @staticmethod
+    def make_grid_values(nr_voxels_per_dim):
+        n = OccupancyGrid._check_n(nr_voxels_per_dim)
+        return torch.ones(n ** 3, dtype=torch.float32, device=_dev())
+
+    @staticmethod
+    def make_grid_occupancy(nr_voxels_per_dim):
+        n = OccupancyGrid._check_n(nr_voxels_per_dim)
+        return torch.ones(n ** 3, dtype=torch.bool, device=_dev())
+
+    def get_grid_values(self):
+        return self.m_grid_values
+
+    def get_grid_occupancy(self):
+        return self.m_grid_occupancy
+
+    def get_grid_roi(self):
+        return self.m_grid_roi
+
+    def get_grid_occupancy_in_roi(self):
+        return self.m_grid_occupancy.masked_select(self.m_grid_roi)
+
+    def set_grid_values(self, grid_values):
+        self.m_grid_values = grid_values
+
+    def set_grid_occupancy(self, grid_occupancy):
+        self.m_grid_occupancy = grid_occupancy
+
+    def set_grid_occupancy_full(self):
+        self.m_grid_occupancy.fill_(True)
+
+    def set_grid_occupancy_empty(self):
+        self.m_grid_occupancy.fill_(False)
+
+    def get_nr_voxels(self):
+        return self.m_nr_voxels_per_dim ** 3
+
+    def get_nr_voxels_per_dim(self):
+        return self.m_nr_voxels_per_dim
+
+    def get_grid_extent(self):
+        return list(self.m_grid_extent)
+
+    def get_nr_voxels_in_roi(self):
+        return int(self.m_grid_roi.sum().item())
+
+    def get_nr_occupied_voxels(self):
+        return int(self.m_grid_occupancy.sum().item())
+
+    def get_nr_occupied_voxels_in_roi(self):
+        return int(self.get_grid_occupancy_in_roi().sum().item())
+
+    def get_grid_max_value(self):
+        return float(self.m_grid_values.max().item())
+
+    def get_grid_min_value(self):
+        return float(self.m_grid_values.min().item())
+
+    def get_grid_max_value_in_roi(self):
+        return float(self.m_grid_values.masked_select(self.m_grid_roi).max().item())
+
+    def get_grid_min_value_in_roi(self):
+        return float(self.m_grid_values.masked_select(self.m_grid_roi).min().item())
+
+    def init_sphere_roi(self, radius, padding):
+        """:112-129: a voxel is in the region of interest when all its 8 vertices lie inside the
+        sphere of `radius - padding`."""
+        ll, _ = self.get_grid_lower_left_voxels_vertices()
+        dist = self.get_grid_all_voxels_vertices(ll).reshape(-1, 3).norm(2, 1, True)
+        self.m_grid_roi = (dist < (radius - padding)).reshape(-1, 8).all(-1)
+
+    def get_grid_all_voxels_vertices(self, ll_vertices):
+        """:167-186: [nr_voxels, 8, 3]."""
+        n = self.m_nr_voxels_per_dim
+        voxel = torch.tensor(self.m_grid_extent, dtype=torch.float32, device=ll_vertices.device) / n
+        offs = torch.tensor([[0, 0, 0], [0, 0, 1], [0, 1, 0], [0, 1, 1], [1, 0, 0], [1, 0, 1], [1, 1, 0],
+                             [1, 1, 1]], dtype=torch.float32, device=ll_vertices.device) * voxel
+        return ll_vertices.view(-1, 1, 3) + offs.view(1, -1, 3)
+
+    # ---- voxel positions (:188-310)
+    def _points(self, indices, count, centre, jitter):
+        import ctypes
+        out = torch.empty(count, 3, dtype=torch.float32, device=_dev())
+        rng = OccupancyGrid.m_rng
+        e = self.m_grid_extent
+        _lib.call("vsa_occ_grid_points", indices, int(count), self.m_nr_voxels_per_dim, e[0], e[1], e[2],
+                  int(centre), bool(jitter), ctypes.c_uint64(rng.state), ctypes.c_uint64(rng.inc), out,
+                  _lib.stream_ptr())
+        if jitter:
+            rng.advance()
+        return out
+
+    def get_grid_lower_left_voxels_vertices(self):
+        n = self.get_nr_voxels()
+        idx = torch.arange(n, dtype=torch.int32, device=_dev())
+        return self._points(idx, n, 0, False), idx
+
+    def get_grid_samples(self, jitter_samples):
+        n = self.get_nr_voxels()
+        idx = torch.arange(n, dtype=torch.int32, device=_dev())
+        return self._points(idx, n, 1, jitter_samples), idx
+
+    def get_random_grid_samples(self, nr_voxels_to_select, jitter_samples):
+        idx = torch.randint(0, self.get_nr_voxels(), (int(nr_voxels_to_select),), dtype=torch.int32,
+                            device=_dev())
+        return self._points(idx, int(nr_voxels_to_select), 1, jitter_samples), idx
+
+    def get_random_grid_samples_in_roi(self, nr_voxels_to_select, jitter_samples):
+        roi_idx = torch.nonzero(self.m_grid_roi).to(torch.int32)
+        pick = torch.randint(0, roi_idx.shape[0], (int(nr_voxels_to_select),), dtype=torch.int32,
+                             device=_dev())
+        idx = roi_idx.index_select(0, pick).squeeze(1).contiguous()
+        return self._points(idx, int(nr_voxels_to_select), 1, jitter_samples), idx
+
+    # ---- updates (:402-474)
+    def update_grid_values(self, point_indices, values, decay):
+        if values.dim() != 2 or point_indices.dim() != 1:
+            raise _lib.VolsurfsHipError("values should be [nr_points,1] and point_indices [nr_points]")
+        if decay > 1.0:
+            raise _lib.VolsurfsHipError(f"decay should be <= 1.0 but it is {decay}")
+        _lib.call("vsa_occ_update_values", point_indices.contiguous(), values.contiguous(),
+                  point_indices.shape[0], float(decay), self.m_grid_values, _lib.stream_ptr())
+
+    def update_grid_occupancy_with_density_values(self, point_indices, occupancy_tresh, check_neighbours):
+        if point_indices.dim() != 1:
+            raise _lib.VolsurfsHipError("point_indices should have dim 1")
+        e = self.m_grid_extent
+        _lib.call("vsa_occ_update_occupancy_density", point_indices.contiguous(), point_indices.shape[0],
+                  self.m_nr_voxels_per_dim, e[0], e[1], e[2], float(occupancy_tresh),
+                  bool(check_neighbours), self.m_grid_values, _as_flags(self.m_grid_occupancy),
+                  _lib.stream_ptr())
+
+    def update_grid_occupancy_with_sdf_values(self, point_indices, logistic_beta, occupancy_thresh,
+                                              check_neighbours):
+        if point_indices.dim() != 1:
+            raise _lib.VolsurfsHipError("point_indices should have dim 1")
+        e = self.m_grid_extent
+        _lib.call("vsa_occ_update_occupancy_sdf", point_indices.contiguous(), logistic_beta.contiguous(),
+                  point_indices.shape[0], self.m_nr_voxels_per_dim, e[0], e[1], e[2],
+                  float(occupancy_thresh), self.m_grid_values, _as_flags(self.m_grid_occupancy),
+                  _lib.stream_ptr())
+
+    # ---- queries along points / rays (:312-400, 476-607)
+    def check_occupancy(self, points):
+        if points.dtype != torch.float32 or points.dim() != 2:
+            raise _lib.VolsurfsHipError("positions should be float [nr_points,3]")
+        P = points.shape[0]
+        occ = torch.ones(P, 1, dtype=torch.bool, device=points.device)
+        val = torch.ones(P, 1, dtype=torch.float32, device=points.device)
+        e = self.m_grid_extent
+        _lib.call("vsa_occ_check", points.contiguous(), P, self.m_nr_voxels_per_dim, e[0], e[1], e[2],
+                  self.m_grid_values, _as_flags(self.m_grid_occupancy), _as_flags(self.m_grid_roi),
+                  occ.view(torch.uint8), val, _lib.stream_ptr())
+        return occ, val
+
+    def get_rays_t_near_t_far(self, rays_o, rays_d, ray_t_entry, ray_t_exit):
+        for t, n in ((rays_o, "rays_o"), (rays_d, "rays_d"), (ray_t_entry, "ray_t_entry"), (ray_t_exit, "ray_t_exit")):
+            if t.dim() != 2:
+                raise _lib.VolsurfsHipError(f"{n} should be 2-D, it has sizes {tuple(t.shape)}")
+        N = rays_o.shape[0]
+        near = torch.empty(N, 1, dtype=torch.float32, device=rays_o.device)
+        far = torch.empty(N, 1, dtype=torch.float32, device=rays_o.device)
+        e = self.m_grid_extent
+        _lib.call("vsa_occ_rays_t_near_t_far", rays_o.contiguous(), rays_d.contiguous(),
+                  ray_t_entry.contiguous(), ray_t_exit.contiguous(), N, self.m_nr_voxels_per_dim, e[0],
+                  e[1], e[2], _as_flags(self.m_grid_occupancy), _as_flags(self.m_grid_roi), near, far,
+                  _lib.stream_ptr())
+        return near, far
+
+    def get_first_rays_sample_start_of_grid_occupied_regions(self, rays_o, rays_d, ray_t_entry, ray_t_exit):
+        N = rays_o.shape[0]
+        p = RaySamplesPacked(N, N, 0, 1)
+        e = self.m_grid_extent
+        _lib.call("vsa_occ_first_sample", rays_o.contiguous(), rays_d.contiguous(),
+                  ray_t_entry.contiguous(), ray_t_exit.contiguous(), N, self.m_nr_voxels_per_dim, e[0],
+                  e[1], e[2], _as_flags(self.m_grid_occupancy), _as_flags(self.m_grid_roi), p.samples_3d,
+                  p.samples_dirs, p.samples_z, p.samples_dt, p.ray_start_end_idx, _lib.stream_ptr())
+        return p
+
+    def advance_ray_sample_to_next_occupied_voxel(self, samples_dirs, samples_3d):
+        """The reference updates samples_3d IN PLACE and returns it (:580-607)."""
+        P = samples_3d.shape[0]
+        if not samples_3d.is_contiguous():
+            raise _lib.VolsurfsHipError("samples_3d must be contiguous (it is updated in place)")
+        within = torch.ones(P, 1, dtype=torch.bool, device=samples_3d.device)
+        e = self.m_grid_extent
+        _lib.call("vsa_occ_advance_samples", samples_dirs.contiguous(), samples_3d, P,
+                  self.m_nr_voxels_per_dim, e[0], e[1], e[2], _as_flags(self.m_grid_occupancy),
+                  _as_flags(self.m_grid_roi), samples_3d, within.view(torch.uint8), _lib.stream_ptr())
+        return samples_3d, within
