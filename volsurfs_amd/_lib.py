@@ -83,10 +83,28 @@ def stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+kernel_events = None   # bench.py: {} -> every call is bracketed by events on the current stream
+
+
+def kernel_ms():
+    """Mean duration per C-ABI entry point over the calls recorded in `kernel_events`."""
+    import torch
+    torch.cuda.synchronize()
+    return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in (kernel_events or {}).items()}
+
+
 def call(name, *args):
     """Call a C-ABI entry point; raise on a non-zero status."""
     fn = getattr(lib(), name)
-    rc = fn(*[_conv(a) for a in args])
+    if kernel_events is not None:
+        import torch
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = fn(*[_conv(x) for x in args])
+        b.record()
+        kernel_events.setdefault(name, []).append((a, b))
+    else:
+        rc = fn(*[_conv(a) for a in args])
     if rc != 0:
         raise VolsurfsHipError(f"{name} failed with status {rc}")
     return rc
