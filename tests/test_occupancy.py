@@ -196,3 +196,45 @@ def test_hip_samples_fg_in_grid_occupied_regions_vs_oracle(jitter):
     # every sample sits in an occupied voxel of the region of interest
     inside, _ = grid.check_occupancy(pack.samples_3d)
     assert inside.all()
+
+
+@pytest.mark.gpu
+def test_hip_occupancy_edge_cases():
+    """Empty inputs, an empty grid, a full grid, rays that start outside the grid."""
+    from volsurfs_amd.volsurfs import OccupancyGrid, RaySampler
+    n, ext = 8, [1.0, 1.0, 1.0]
+    grid = OccupancyGrid(n, ext)
+    z3 = torch.zeros(0, 3, device="cuda")
+    z1 = torch.zeros(0, 1, device="cuda")
+    o, v = grid.check_occupancy(z3)
+    assert o.shape == (0, 1) and v.shape == (0, 1)
+    near, far = grid.get_rays_t_near_t_far(z3, z3, z1, z1)
+    assert near.shape == (0, 1)
+    grid.update_grid_values(torch.zeros(0, dtype=torch.int32, device="cuda"), z1, 0.9)
+    # a fresh grid is fully occupied with value 1 (src/OccupancyGrid.cu:131-147)
+    assert grid.get_nr_occupied_voxels() == n ** 3 == grid.get_nr_voxels_in_roi()
+    assert grid.get_grid_min_value() == grid.get_grid_max_value() == 1.0
+    ro = torch.tensor([[-0.45, 0.0, 0.0], [-3.0, 0.0, 0.0]], device="cuda")
+    rd = torch.tensor([[1.0, 0.0, 0.0], [1.0, 0.0, 0.0]], device="cuda")
+    t0 = torch.zeros(2, 1, device="cuda")
+    t1 = torch.tensor([[0.9], [0.5]], device="cuda")
+    near, far = grid.get_rays_t_near_t_far(ro, rd, t0, t1)
+    assert near[0].item() == 0.0 and abs(far[0].item() - 0.9) < 1e-6     # occupied all the way
+    # (the second ray never reaches the grid: negative coordinates saturate to voxel 0, which is
+    # occupied here — the reference's quirk, reproduced)
+    pack = RaySampler.compute_samples_fg_in_grid_occupied_regions(
+        ro[:1], rd[:1], t0[:1], t1[:1], 0.1, 1, 16, False, n, ext, grid.get_grid_occupancy(), grid.get_grid_roi(), 0)
+    k = pack.get_total_nr_samples()
+    assert 8 <= k <= 9
+    assert torch.allclose(pack.samples_z[1:] - pack.samples_z[:-1], pack.ray_max_dt[0].expand(k - 1, 1), atol=2e-5)
+    grid.set_grid_occupancy_empty()
+    assert grid.get_nr_occupied_voxels() == 0
+    near, far = grid.get_rays_t_near_t_far(ro, rd, t0, t1)
+    assert torch.equal(near, t0) and torch.equal(far, t0)               # nothing occupied: both stay at t_entry
+    pack = RaySampler.compute_samples_fg_in_grid_occupied_regions(
+        ro, rd, t0, t1, 0.1, 1, 16, False, n, ext, grid.get_grid_occupancy(), grid.get_grid_roi(), 0)
+    assert pack.is_empty() and pack.get_total_nr_samples() == 0
+    first = grid.get_first_rays_sample_start_of_grid_occupied_regions(ro, rd, t0, t1)
+    assert (first.ray_start_end_idx == 0).all()
+    grid.set_grid_occupancy_full()
+    assert grid.get_nr_occupied_voxels_in_roi() == n ** 3
