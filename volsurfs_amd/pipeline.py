@@ -98,12 +98,14 @@ class KShellPipeline:
 
     @classmethod
     def synthetic(cls, K=5, subdiv=6, res=800, device="cuda", seed=42, **kw):
+        """res: an int (square frame) or (H, W)."""
         meshes = nested_shells(K=K, subdiv=subdiv, device=device)
-        o, d = pinhole_rays(res, res, focal=1111.1 * res / 800.0, cam_pos=(0.0, 0.0, -1.5),
+        H, W = (res, res) if isinstance(res, int) else res
+        o, d = pinhole_rays(H, W, focal=1111.1 * min(H, W) / 800.0, cam_pos=(0.0, 0.0, -1.5),
                             device=device)
         g = torch.Generator(device=device).manual_seed(seed)
         gt = torch.rand(o.shape[0], 3, device=device, generator=g)
-        p = cls(meshes, o, d, gt, seed=seed, image_hw=(res, res), **kw)
+        p = cls(meshes, o, d, gt, seed=seed, image_hw=(H, W), **kw)
         p.res = res
         p.subdiv = subdiv
         return p
@@ -128,7 +130,8 @@ class KShellPipeline:
 
     def config_desc(self, world):
         return {
-            "workload": f"synthetic kitten-like: {self.res}x{self.res} rays, K={self.K} nested "
+            "workload": f"synthetic kitten-like: {self.res if isinstance(self.res, int) else self.res[1]}x"
+                        f"{self.res if isinstance(self.res, int) else self.res[0]} rays, K={self.K} nested "
                         f"icospheres subdiv {self.subdiv} ({self.tracer.mesh_nr_tris[0]} tris each), "
                         "SH-degree-3 neural textures (rgb + alpha per shell, res 2048/1024/512/256, "
                         "16-level 2-D hash grid + 32-64-64-C MLP, 8-bit quantised, lerp), alpha decay, "
