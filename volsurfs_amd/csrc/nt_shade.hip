@@ -414,7 +414,12 @@ __global__ __launch_bounds__(SHB_BLOCK, RECOMPUTE ? 2 : 4) void nt_shade_bwd_ker
   const int d = lane < 12 ? 0 : (lane < 26 ? 1 : (lane < 37 ? 2 : 3));
   const int lb = lane - (d == 0 ? 0 : (d == 1 ? 12 : (d == 2 ? 26 : 37)));
   const int nn = 2 * d + 1, n_rgb_pairs = (3 * nn + 1) >> 1, row_pairs = n_rgb_pairs + ((nn + 1) >> 1);
-  const int q = lb / row_pairs, jb = lb - q * row_pairs;              // slot within the line, pair within the row
+  // (small unsigned divisions by multiply-high: the generic sequence is ~25 instructions each)
+  const unsigned magic3 = 0x55555556u, magic5 = 0x33333334u, magic7 = 0x24924925u;   // 2^32 / n + 1
+  const unsigned magic_nn = d == 1 ? magic3 : (d == 2 ? magic5 : magic7);
+  auto div_nn = [&](int x) { return d == 0 ? x : (int)__umulhi((unsigned)x, magic_nn); };
+  const int q = d == 0 ? (int)__umulhi((unsigned)lb, magic3) : (d == 1 ? (int)__umulhi((unsigned)lb, magic7) : 0);
+  const int jb = lb - q * row_pairs;                                  // q: slot within the line, jb: pair within the row
   const bool is_alpha = jb >= n_rgb_pairs;
   const int e0 = is_alpha ? 2 * (jb - n_rgb_pairs) : 2 * jb;          // element index within the part
   const int part = is_alpha ? nn : 3 * nn;
@@ -423,8 +428,9 @@ __global__ __launch_bounds__(SHB_BLOCK, RECOMPUTE ? 2 : 4) void nt_shade_bwd_ker
   const int lofs = 4 * (q * qd + (is_alpha ? nt_alpha_quad(d) : 0)) + e0;
   const bool band_on = lane < 52 && (is_alpha ? (has_alpha && d < plan.alpha_degrees) : d < plan.rgb_degrees);
   const bool on1 = band_on && e0 + 1 < part;
-  const int ch0 = is_alpha ? 3 : e0 / nn, ch1 = is_alpha ? 3 : (e0 + 1) / nn;
-  const int m0 = d * d + (is_alpha ? e0 : e0 % nn), m1 = on1 ? d * d + (is_alpha ? e0 + 1 : (e0 + 1) % nn) : 0;
+  const int c0 = div_nn(e0), c1 = div_nn(e0 + 1);
+  const int ch0 = is_alpha ? 3 : c0, ch1 = is_alpha ? 3 : c1;
+  const int m0 = d * d + (is_alpha ? e0 : e0 - c0 * nn), m1 = on1 ? d * d + (is_alpha ? e0 + 1 : e0 + 1 - c1 * nn) : 0;
   const float span = plan.sh_span[d];
   // Consecutive hits of a wave are neighbouring pixels: their 2x2 footprints fall on the same
   // or on neighbouring lines.  Each lane keeps up to four lines open with a running sum (the
