@@ -38,8 +38,14 @@ class _ShadeStage(torch.autograd.Function):
         gt_prev, gw_prev = bank.tables.grad, bank.weights.grad
         bank.tables.grad = torch.zeros_like(bank.tables)
         bank.weights.grad = torch.zeros_like(bank.weights)
+        # scale of the fp16 gradient chain (tcnn's loss scale): by default the batch's ray count
+        # (a mean-reduced loss then gives O(0.1) values whatever the batch size), kept within
+        # [2^10, 2^16] so that per-ray gradients of magnitude 1 (sum-reduced losses) cannot overflow
+        scale = method.grad_scale
+        if scale is None:
+            scale = float(2 ** min(max(int(hit_slot.shape[1]).bit_length() - 1, 10), 16))
         bank.backward(hit_slot, tex_uv, rays_d, method.raytracer.tris, g_rgb.contiguous(),
-                      g_alpha.contiguous(), method.grad_scale, act)
+                      g_alpha.contiguous(), scale, act)
         g_t, g_w = bank.tables.grad, bank.weights.grad
         bank.tables.grad, bank.weights.grad = gt_prev, gw_prev    # autograd accumulates itself
         return g_t, g_w, None, None, None, None
@@ -120,7 +126,7 @@ class VolSurfs(torch.nn.Module):
         self.bg_model, self.bounding_primitive, self.nr_samples_bg = bg_model, bounding_primitive, nr_samples_bg
         if self.bg_color is None and (bg_model is None or bounding_primitive is None):
             raise _lib.VolsurfsHipError("bg_color=None needs bg_model and bounding_primitive")
-        self.grad_scale = 16384.0
+        self.grad_scale = None      # None = chosen per backward call from the batch size (see _ShadeStage)
         self.is_training = True
         self.lr = lr
         self.optimizer = None
