@@ -207,3 +207,35 @@ def test_baked_textures_render_identically_and_match_the_oracle():
         _, q_ref = ONT.quantise(tcnn_like.mlp_forward(w1, w2, w3, feats, C))
         dq = (img.cpu().reshape(-1, C).int() - q_ref.int()).abs()
         assert dq.max() <= 1 and (dq > 0).float().mean() < 2e-3, (s, typ, dg, dq.max())
+
+
+@pytest.mark.gpu
+def test_gradients_do_not_depend_on_the_f16_gradient_scale():
+    """The gradient chain runs in f16 behind a power-of-two scale (tcnn's loss scale; chosen per
+    call from the incoming gradients when `grad_scale` is None).  A mean-reduced and a
+    sum-reduced loss, whose per-ray gradients differ by the ray count, must give the same
+    gradients (up to that factor), and so must explicit scales around the automatic one."""
+    from volsurfs_amd.camera import pinhole_rays
+    m = _method()
+    o, d = pinhole_rays(64, 64, focal=110.0)
+    gt = torch.rand(o.shape[0], 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+
+    def grads(scale, reduce):
+        m.grad_scale = scale
+        for p in (m.bank.tables, m.bank.weights):
+            p.grad = None
+        rgb = m.render_rays(o, d)["renders"]["ray_traced"]["rgb"].float()
+        loss = (rgb - gt).abs().mean() if reduce == "mean" else (rgb - gt).abs().sum()
+        loss.backward()
+        return m.bank.tables.grad.clone(), m.bank.weights.grad.clone()
+
+    ref_t, ref_w = grads(None, "mean")
+    assert ref_t.abs().max() > 0 and torch.isfinite(ref_t).all() and torch.isfinite(ref_w).all()
+    n = gt.numel()
+    for scale, reduce, factor in ((2.0 ** 12, "mean", 1.0), (2.0 ** 16, "mean", 1.0), (None, "sum", float(n))):
+        g_t, g_w = grads(scale, reduce)
+        assert torch.isfinite(g_t).all() and torch.isfinite(g_w).all()
+        for a, b in ((g_t / factor, ref_t), (g_w / factor, ref_w)):
+            cos = torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0)
+            assert cos > 0.999, (scale, reduce, cos)
+            assert (a - b).abs().max() <= 2e-2 * b.abs().max()
