@@ -163,3 +163,32 @@ def test_hip_tile_order_round_trip_and_pipeline_equivalence():
     assert torch.equal(a.to_ray_order(a.surfs_alpha), b.surfs_alpha)
     ga, gb = a.bank.tables.grad, b.bank.tables.grad
     assert (ga - gb).abs().max() <= 2e-3 * gb.abs().max()       # same sums, other atomic order
+
+
+@pytest.mark.gpu
+def test_train_loop_with_callbacks():
+    """trainer.train: the reference loop's hook order and iteration bookkeeping."""
+    from volsurfs_amd import camera as C
+    from volsurfs_amd.mesh import nested_shells
+    from volsurfs_amd.methods import VolSurfs
+    from volsurfs_amd.trainer import train
+    torch.manual_seed(0)
+    H = W = 32
+    cams = [C.Camera.look_at((0.0, 0.2, -1.5), focal=45.0, height=H, width=W)]
+    m = VolSurfs(nested_shells(K=2, subdiv=2), max_rays=4096, textures_res=(64, 32, 16, 8), lr=1e-2,
+                 nr_warmup_iters=0)
+    reel = C.TensorReel(cams, torch.full((1, H, W, 3), 0.3, device="cuda"))
+    log = []
+
+    class Recorder:
+        def training_started(self, **kw): log.append("start")
+        def iter_started(self, phase, **kw): log.append(("it", phase.iter_nr, phase.is_first_iter))
+        def iter_ended(self, phase, losses, **kw): log.append(("end", phase.iter_nr, losses["loss"]))
+        def training_ended(self, **kw): log.append("stop")
+
+    done = train(reel, m, start_iter_nr=5, iter_finish_nr=13, callbacks=[Recorder()], nr_training_rays=512)
+    assert done == 13 and log[0] == "start" and log[-1] == "stop"
+    its = [e for e in log if isinstance(e, tuple) and e[0] == "it"]
+    assert [e[1] for e in its] == list(range(5, 13)) and its[0][2] and not its[1][2]
+    ends = [e for e in log if isinstance(e, tuple) and e[0] == "end"]
+    assert len(ends) == 8 and ends[-1][2] < ends[0][2]

@@ -1,7 +1,8 @@
 """One training iteration of the K-shell method in the reference's order
 (/root/reference/volsurfs_py/trainer.py:118-308): zero_grad -> ray batch -> forward ->
-backward -> optimiser step -> dynamic ray count -> lr scheduler.  Data loading, callbacks,
-checkpoints and evaluation (the rest of trainer.py) are outside SURVEY §8.
+backward -> optimiser step -> dynamic ray count -> lr scheduler, and the loop around it with
+the reference's callback hooks (`train`).  Logging, checkpoints and evaluation (the rest of
+trainer.py) are outside SURVEY §8 and live in the callbacks.
 """
 import torch
 
@@ -63,3 +64,48 @@ def train_step_from_reel(method, reel, nr_rays, jitter_pixels=True, nr_rays_per_
         gt_rgb = gt_rgb.repeat_interleave(nr_rays_per_pixel, 0)
         gt_mask = gt_mask.repeat_interleave(nr_rays_per_pixel, 0)
     return train_step(method, rays_o, rays_d, gt_rgb, gt_mask, iter_nr, nr_rays=nr_rays, **kw)
+
+
+class TrainingState:
+    """utils/training.py's state carried through the callbacks (trainer.py:84-86)."""
+
+    def __init__(self):
+        self.iter_nr = 0
+        self.is_first_iter = True
+        self.loss_rgb = 0.0
+
+
+def train(train_data_tensor_reel, method, start_iter_nr=0, iter_finish_nr=0, callbacks=None,
+          nr_training_rays=None, jitter_training_rays=True, nr_training_rays_per_pixel=1,
+          is_training_masked=False, target_nr_of_training_samples=None, world=1):
+    """The loop of trainer.py:57-440 around `train_step_from_reel`, with the reference's callback
+    hooks (callbacks/callback.py:25-47: training_started / iter_started / iter_ended /
+    training_ended, each called with phase=TrainingState).  Logging, checkpoints, test-loss
+    estimates and evaluation renders of the reference loop are outside SURVEY §8 and belong to
+    the callbacks.  Returns the number of completed iterations."""
+    def hook(name, **kw):
+        for cb in (callbacks or []):
+            fn = getattr(cb, name, None)
+            if fn is not None:
+                fn(**kw)
+
+    phase = TrainingState()
+    phase.iter_nr = start_iter_nr
+    nr_rays = nr_training_rays if nr_training_rays is not None else 512
+    if getattr(method, "optimizer", None) is None:
+        method.init_optim()
+    hook("training_started")
+    for _ in range(start_iter_nr, iter_finish_nr):
+        hook("iter_started", phase=phase)
+        losses, nr_rays = train_step_from_reel(
+            method, train_data_tensor_reel, nr_rays, jitter_pixels=jitter_training_rays,
+            nr_rays_per_pixel=nr_training_rays_per_pixel, iter_nr=phase.iter_nr,
+            is_training_masked=is_training_masked, is_first_iter=phase.is_first_iter,
+            target_nr_of_training_samples=target_nr_of_training_samples, world=world)
+        phase.loss_rgb = losses["loss"]
+        method.is_training = False                                            # set_eval_mode (:324)
+        hook("iter_ended", phase=phase, losses=losses, nr_rays=nr_rays)
+        phase.iter_nr += 1
+        phase.is_first_iter = False
+    hook("training_ended")
+    return phase.iter_nr
