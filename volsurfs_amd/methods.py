@@ -132,6 +132,8 @@ class VolSurfs(torch.nn.Module):
         if self.bg_color is None and (bg_model is None or bounding_primitive is None):
             raise _lib.VolsurfsHipError("bg_color=None needs bg_model and bounding_primitive")
         self.grad_scale = None      # None = chosen per backward call from the incoming gradients (see _ShadeStage)
+        self.save_checkpoints_path = self.load_checkpoints_path = None
+        self.baked = None
         self.is_training = True
         self.lr = lr
         self.optimizer = None
@@ -285,6 +287,65 @@ class VolSurfs(torch.nn.Module):
         else:
             loss_rgb = (gt_rgb - pred).abs().mean()
         return {"loss": loss_rgb, "rgb": loss_rgb}, {}, res["samples_3d"]
+
+    # ---- checkpoints (base_method.py:118-264): <path>/<iter:07d>/models/{key}.pt per model
+    # (rgb_i / alpha_i / bg), the optimiser state under its lower-cased class name
+    def _model_states(self):
+        out = {}
+        if self.bank is not None:
+            b = self.bank
+            for i in range(self.nr_meshes):
+                for typ, name in ((0, "rgb"), (1, "alpha")):
+                    a = b.tex_index(i, typ, 0)
+                    out[f"{name}_{i}"] = (b.tables[a:a + 4], b.weights[a:a + 4])
+        return out
+
+    def save(self, iter_nr):
+        import os
+        if getattr(self, "save_checkpoints_path", None) is None:
+            return None
+        path = os.path.join(self.save_checkpoints_path, format(iter_nr, "07d"), "models")
+        os.makedirs(path, exist_ok=True)
+        for key, (t, w) in self._model_states().items():
+            torch.save({"tables": t.detach().cpu(), "weights": w.detach().cpu()}, os.path.join(path, f"{key}.pt"))
+        for key, model in self.models.items():
+            torch.save(model.state_dict(), os.path.join(path, f"{key}.pt"))
+        if isinstance(self.bg_model, torch.nn.Module):
+            torch.save(self.bg_model.state_dict(), os.path.join(path, "bg.pt"))
+        if getattr(self, "optimizer", None) is not None:
+            torch.save(self.optimizer.state_dict(),
+                       os.path.join(path, f"{self.optimizer.__class__.__name__.lower()}.pt"))
+        return path
+
+    def load(self, iter_nr):
+        """Missing files are skipped, as in the reference (a model absent from the checkpoint
+        keeps its initialisation)."""
+        import os
+        if getattr(self, "load_checkpoints_path", None) is None:
+            return None
+        path = os.path.join(self.load_checkpoints_path, format(iter_nr, "07d"), "models")
+        with torch.no_grad():
+            for key, (t, w) in self._model_states().items():
+                f = os.path.join(path, f"{key}.pt")
+                if os.path.exists(f):
+                    st = torch.load(f, map_location=t.device)
+                    t.copy_(st["tables"])
+                    w.copy_(st["weights"])
+        if self.bank is not None:
+            self.bank.refresh_half_params()
+            self.baked = None                                   # baked textures are stale now
+        for key, model in self.models.items():
+            f = os.path.join(path, f"{key}.pt")
+            if os.path.exists(f):
+                model.load_state_dict(torch.load(f, map_location="cuda"))
+        f = os.path.join(path, "bg.pt")
+        if isinstance(self.bg_model, torch.nn.Module) and os.path.exists(f):
+            self.bg_model.load_state_dict(torch.load(f, map_location="cuda"))
+        if getattr(self, "optimizer", None) is not None:
+            f = os.path.join(path, f"{self.optimizer.__class__.__name__.lower()}.pt")
+            if os.path.exists(f):
+                self.optimizer.load_state_dict(torch.load(f, map_location="cuda"))
+        return path
 
     @torch.no_grad()
     def render_camera(self, camera, nr_rays_per_pixel=1, jitter_pixels=False, chunk=16384):

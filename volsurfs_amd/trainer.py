@@ -109,3 +109,23 @@ def train(train_data_tensor_reel, method, start_iter_nr=0, iter_finish_nr=0, cal
         phase.is_first_iter = False
     hook("training_ended")
     return phase.iter_nr
+
+
+def get_last_checkpoint_in_path(path):
+    """utils/training.py: the lexicographically last <iter:07d> directory, or None."""
+    import os
+    if path is None or not os.path.isdir(path):
+        return None
+    names = sorted(n for n in os.listdir(path) if n.isdigit() and os.path.isdir(os.path.join(path, n)))
+    return names[-1] if names else None
+
+
+def save_checkpoints(method, iter_nr, remove_previous=True):
+    """utils/training.py:59-78: optionally drop the newest previous checkpoint, then method.save."""
+    import os
+    import shutil
+    if remove_previous:
+        last = get_last_checkpoint_in_path(method.save_checkpoints_path)
+        if last is not None:
+            shutil.rmtree(os.path.join(method.save_checkpoints_path, last))
+    return method.save(iter_nr)
