@@ -280,3 +280,20 @@ def test_checkpoint_save_load_resumes_bit_exactly(tmp_path):
     step(b, 3)
     assert (a.bank.tables - b.bank.tables).abs().max() <= 1e-3 * a.bank.tables.abs().max()
     assert b.optimizer.state_dict()["state"][0]["step"] == a.optimizer.state_dict()["state"][0]["step"]
+
+
+@pytest.mark.gpu
+def test_profiler_sections_of_the_reference():
+    """the method reports the reference's hot-path sections to a Profiler."""
+    from volsurfs_amd.camera import pinhole_rays
+    from volsurfs_amd.trainer import Profiler
+    m = _method()
+    m.profiler = Profiler()
+    o, d = pinhole_rays(64, 64, focal=110.0)
+    for _ in range(3):
+        m.render_rays(o, d)
+    t = m.profiler.get_avg_times()
+    assert set(t) == {"meshes_raytracing", "ray_color_inference", "render_fg"}
+    assert all(0 < v < 1.0 for v in t.values())
+    m.profiler.reset()
+    assert m.profiler.get_avg_times() == {}

@@ -133,6 +133,7 @@ class VolSurfs(torch.nn.Module):
             raise _lib.VolsurfsHipError("bg_color=None needs bg_model and bounding_primitive")
         self.grad_scale = None      # None = chosen per backward call from the incoming gradients (see _ShadeStage)
         self.save_checkpoints_path = self.load_checkpoints_path = None
+        self.profiler = None        # a trainer.Profiler (or any object with start(name) / end(name))
         self.baked = None
         self.is_training = True
         self.lr = lr
@@ -201,21 +202,37 @@ class VolSurfs(torch.nn.Module):
         if N > self.max_rays:
             raise _lib.VolsurfsHipError(f"{N} rays > max_rays={self.max_rays}; use render()")
         rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
+        prof = getattr(self, "profiler", None)      # section names of the reference
+        if prof is not None:
+            prof.start("meshes_raytracing")
         hit_t, hit_slot, hit_uv = self.raytracer.trace_all(rays_o, rays_d)     # :476-485, one launch
+        if prof is not None:
+            prof.end("meshes_raytracing")
+            prof.start("ray_color_inference")
         if self.using_neural_textures:
             rgb_k, alpha_k, normals, tex_uv = _ShadeStage.apply(self.bank.tables, self.bank.weights,
                                                                 self, hit_slot, hit_uv, rays_d)
         else:
             rgb_k, alpha_k, normals = self._shade_legacy(rays_o, rays_d, hit_t, hit_slot, iter_nr)
             tex_uv = None
+        if prof is not None:
+            prof.end("ray_color_inference")
         if self.bg_color is not None:
             rgb_bg = self.bg_color
         else:
             from .background import intersect_bounding_primitive, render_contracted_bg
             raycast = intersect_bounding_primitive(self.bounding_primitive, rays_o, rays_d)   # :434
+            if prof is not None:
+                prof.start("render_contracted_bg")
             rgb_bg = render_contracted_bg(self.bg_model, raycast, self.nr_samples_bg,
                                           jitter_samples=self.is_training, iter_nr=iter_nr)["pred_rgb"]
+            if prof is not None:
+                prof.end("render_contracted_bg")
+        if prof is not None:
+            prof.start("render_fg")
         out = composite_dense(rgb_k, alpha_k, rgb_bg)                          # :601-640, 704-708
+        if prof is not None:
+            prof.end("render_fg")
         renders = {
             "rgb": out["rgb"], "rgb_fg": out["rgb_fg"], "rgb_bg": out["rgb_bg"],
             "surfs_alpha": out["surfs_alpha"], "surfs_rgb": out["surfs_rgb"],

@@ -129,3 +129,45 @@ def save_checkpoints(method, iter_nr, remove_previous=True):
         if last is not None:
             shutil.rmtree(os.path.join(method.save_checkpoints_path, last))
     return method.save(iter_nr)
+
+
+class Profiler:
+    """mvdatasets.utils.profiler.Profiler-shaped section timer (trainer.py:555, 703; threaded
+    into the method as `profiler`): start(name) / end(name) bracket a section, `get_avg_time`
+    and `print_avg_times` report.  Sections are timed with events on the current stream and
+    resolved at report time, so the timed code keeps running asynchronously (the reference's
+    wall-clock timer relies on CUDA_LAUNCH_BLOCKING=1, trainer.py:53)."""
+
+    def __init__(self, verbose=False):
+        self.verbose = verbose
+        self._open, self._pairs = {}, {}
+
+    def start(self, name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self._open[name] = e
+
+    def end(self, name):
+        if name not in self._open:
+            return
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self._pairs.setdefault(name, []).append((self._open.pop(name), e))
+
+    def get_avg_time(self, name):
+        """seconds"""
+        pairs = self._pairs.get(name)
+        if not pairs:
+            return None
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in pairs) / len(pairs) * 1e-3
+
+    def get_avg_times(self):
+        return {k: self.get_avg_time(k) for k in self._pairs}
+
+    def print_avg_times(self):
+        for k, v in self.get_avg_times().items():
+            print(f"{k}: {v * 1e3:.3f} ms (n={len(self._pairs[k])})")
+
+    def reset(self):
+        self._open, self._pairs = {}, {}
