@@ -132,4 +132,23 @@ __device__ __forceinline__ void nt_for_each_piece(const vsa_nt_plan& plan,
   }
 }
 
+// Diagnostic build only (make EXTRA=-DNT_SPAN; tools/wg_span.py): wall-clock begin / end of
+// every workgroup of the persistent kernels, to see how evenly the cost axis splits the work.
+#ifdef NT_SPAN
+static __device__ unsigned long long g_span[4][2048][3];
+#define NT_SPAN_MARK(id, which)                                                          \
+  if (threadIdx.x == 0 && blockIdx.x < 2048) {                                           \
+    unsigned long long t__;                                                              \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");     \
+    g_span[id][blockIdx.x][which] = t__;                                                 \
+    if (which == 0) {                                                                    \
+      unsigned hw__, xcc__;                                                              \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw__));                 \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc__));               \
+      g_span[id][blockIdx.x][2] = ((unsigned long long)xcc__ << 32) | hw__;             \
+    }                                                                                    \
+  }
+#else
+#define NT_SPAN_MARK(id, which)
+#endif
 

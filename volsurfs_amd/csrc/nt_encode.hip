@@ -140,6 +140,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
   half2_t* s_tab = reinterpret_cast<half2_t*>(s_raw);
   const long long n_entries = plan.level_offset[plan.n_levels];
   const int nl = plan.n_levels;
+  NT_SPAN_MARK(HASHED ? 1 : 0, 0);
   nt_for_each_piece<ENC_UNIT>(plan, seg_start, n_levels, HASHED ? 32 : 8,
                               [&](int pl, int tex, int first, int last, int, int) {
     const int level = level0 + pl;
@@ -222,6 +223,8 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
     else
       run(std::false_type{});
   });
+  __syncthreads();
+  NT_SPAN_MARK(HASHED ? 1 : 0, 1);
 }
 
 // Backward: grad_table[tex][level entries][feature] += w * dF[slot]; one
@@ -393,6 +396,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
     float* __restrict__ grad_tables, int tex_begin, int tex_end) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   int* s_g = reinterpret_cast<int*>(s_raw);
+  NT_SPAN_MARK(HASHED ? 3 : 2, 0);
   nt_for_each_piece<ENC_UNIT>(plan, seg_start, n_planes, 64,
                               [&](int pl, int tex, int first, int last, int seg_begin, int seg_end) {
     int level = level0, r = pl;
@@ -416,6 +420,8 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
       enc_bwd_piece<HASHED, 1, false>(plan, s_g, level, r, tex, first, last, single, dfeatures,
                                       dfeat_abs_sum, dscale_inv, slot_xy, grad_tables);
   }, tex_begin, tex_end);
+  __syncthreads();
+  NT_SPAN_MARK(HASHED ? 3 : 2, 1);
 }
 
 }  // namespace
@@ -457,6 +463,14 @@ static int set_lds_attr(K kernel) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
   return VSA_OK;
 }
+
+#ifdef NT_SPAN
+extern "C" int vsa_span_read_encode(void* dst) {
+  VSA_HIP_TRY(hipDeviceSynchronize());
+  VSA_HIP_TRY(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_span), sizeof(g_span)));
+  return 0;
+}
+#endif
 
 extern "C" int vsa_nt_encode_fwd(const vsa_nt_plan* plan, const void* tables_h,
                                  const float* slot_xy, const int32_t* seg_start, void* features,

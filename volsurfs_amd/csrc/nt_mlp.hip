@@ -146,6 +146,7 @@ __device__ __forceinline__ float sigmoidf_(float x) {
 
 // Persistent: gridDim.x workgroups split the frame's 32-slot tiles evenly
 // (nt_for_each_piece: cost axis with the weight staging of a run priced at 8 tiles).
+constexpr int MLP_FWD_RUN_COST = 16;   // tiles: fitted 7.6 us per run / 0.48 us per tile (tools/fit_cost.py)
 constexpr int MLP_FWD_DEPTH = 1;        // feature tiles in flight per wave (3 measured slower: PMC shows the
                                         // SIMDs 39 % VALU + 28 % MFMA busy, not waiting on HBM)
 constexpr int MLP_FWD_WGS_PER_CU = 3;   // 148 VGPRs -> 3 waves per SIMD, one per workgroup
@@ -157,7 +158,8 @@ __global__ __launch_bounds__(MLP_BLOCK, MLP_FWD_WGS_PER_CU) void nt_mlp_fwd_kern
   __shared__ half8_t s_frag[16 * 64];
   const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
   const int wave = threadIdx.x >> 6;
-  nt_for_each_piece<32>(plan, seg_start, 1, 8,
+  NT_SPAN_MARK(0, 0);
+  nt_for_each_piece<32>(plan, seg_start, 1, MLP_FWD_RUN_COST,
                         [&](int, int tex, int first, int last, int, int) {
     const TexInfo ti = tex_info(plan, seg_start, tex);
     __syncthreads();   // the previous run's fragments have been read
@@ -217,6 +219,8 @@ __global__ __launch_bounds__(MLP_BLOCK, MLP_FWD_WGS_PER_CU) void nt_mlp_fwd_kern
     }
     }
   });
+  __syncthreads();
+  NT_SPAN_MARK(0, 1);
 }
 
 // ------------------------------------------------------------------ backward
@@ -698,7 +702,7 @@ __device__ __forceinline__ void pc_run(
 // worst-case capacity (70 % of them empty at the bench frame, each still needing the whole
 // CU's LDS to launch and exit; in-kernel timeline: 196 of 256 CUs busy on average, 26 %
 // of a workgroup's cycles in staging + reduction): 1.35 -> 0.88 ms.
-constexpr int PC_RUN_COST = 44;
+constexpr int PC_RUN_COST = 74;   // fitted: 38.6 us per run / 0.52 us per tile (tools/fit_cost.py)
 
 __global__ __launch_bounds__(PC_BLOCK, 2) void nt_mlp_bwd_pc_kernel(
     vsa_nt_plan plan, const _Float16* __restrict__ weights,
@@ -706,6 +710,7 @@ __global__ __launch_bounds__(PC_BLOCK, 2) void nt_mlp_bwd_pc_kernel(
     _Float16* __restrict__ grad_rows, float* __restrict__ grad_weights,
     float* __restrict__ dfeat_abs_sum) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  NT_SPAN_MARK(1, 0);
   nt_for_each_piece<32>(plan, seg_start, 1, PC_RUN_COST,
                         [&](int, int tex, int first, int last, int seg_begin, int seg_end) {
     Work wk;
@@ -716,9 +721,18 @@ __global__ __launch_bounds__(PC_BLOCK, 2) void nt_mlp_bwd_pc_kernel(
     pc_run(plan, wk, s_raw, weights, features, seg_start, grad_rows, grad_weights, dfeat_abs_sum);
     __syncthreads();   // the next run re-stages the fragments
   });
+  NT_SPAN_MARK(1, 1);
 }
 
 }  // namespace
+
+#ifdef NT_SPAN
+extern "C" int vsa_span_read_mlp(void* dst) {
+  VSA_HIP_TRY(hipDeviceSynchronize());
+  VSA_HIP_TRY(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_span), sizeof(g_span)));
+  return 0;
+}
+#endif
 
 #ifdef NT_STAMP
 extern "C" int vsa_debug_read(void* dst) {
