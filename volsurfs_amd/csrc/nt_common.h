@@ -85,48 +85,74 @@ struct Work {
 };
 
 // Persistent work split (one workgroup per CU for the LDS-hungry kernels).  The launch's
-// work = n_planes x (every active texture's slots), laid out on one cost axis in units of
-// UNIT slots: plane-major, and within a plane each non-empty texture contributes `ovh`
-// units of spacing (the per-piece setup: staging / zeroing / flushing LDS) followed by
-// ceil(len / UNIT) units.  Workgroup w owns the units whose coordinate lies in
-// [w*C/G, (w+1)*C/G) and calls body(plane, tex, first_slot, last_slot, seg_begin, seg_end)
-// once per (plane, texture) it overlaps.  All of it is wave-uniform scalar code.
+// work = n_planes x (every active texture's slots), laid out on one cost axis: plane-major,
+// and within a plane each non-empty texture contributes `ovh` units of spacing (the per-piece
+// setup: staging / zeroing / flushing LDS, fitted from per-workgroup timings, tools/fit_cost.py)
+// followed by ceil(len / UNIT) units of UNIT slots, each weighted by wt(plane, degree) / 16 (a
+// unit's relative cost where the kernel takes different code paths per level).  The axis is kept
+// in 1/16 units so that weighted lengths stay exact.  Workgroup w owns the stretch
+// [w*C/G, (w+1)*C/G) and calls body(plane, tex, first_slot, last_slot, seg_begin, seg_end) once
+// per (plane, texture) it overlaps; a unit belongs to the workgroup whose stretch contains its
+// start.  All of it is wave-uniform scalar code.
 // Replaces grids sized for the worst-case slot capacity, where ~2/3 of the workgroups
 // found nothing to do yet each needed a whole CU's LDS to launch and exit.
-template <int UNIT, typename Body>
+struct NtUnitWeight16 {
+  __device__ int operator()(int, int) const { return 16; }
+};
+
+template <int UNIT, typename Body, typename Weight = NtUnitWeight16>
 __device__ __forceinline__ void nt_for_each_piece(const vsa_nt_plan& plan,
                                                   const int* __restrict__ seg_start, int n_planes,
                                                   int ovh, Body&& body, int tex_begin = 0,
-                                                  int tex_end = 1 << 30) {
+                                                  int tex_end = 1 << 30, Weight wt = Weight()) {
   const int n_all = plan.nr_shells * 2 * VSA_NT_MAX_DEG;
   const int n_tex = tex_end < n_all ? tex_end : n_all;   // textures [tex_begin, n_tex) only
-  long long T = 0;
+  long long units_deg[VSA_NT_MAX_DEG] = {0, 0, 0, 0};
+  long long pieces = 0;
   for (int tex = tex_begin; tex < n_tex; ++tex) {
     if (!tex_active(plan, tex)) continue;
-    const int sd = (tex / (2 * VSA_NT_MAX_DEG)) * VSA_NT_MAX_DEG + tex % VSA_NT_MAX_DEG;
+    const int deg = tex % VSA_NT_MAX_DEG;
+    const int sd = (tex / (2 * VSA_NT_MAX_DEG)) * VSA_NT_MAX_DEG + deg;
     const int len = seg_start[sd + 1] - seg_start[sd];
-    if (len > 0) T += ovh + (len + UNIT - 1) / UNIT;
+    if (len > 0) {
+      units_deg[deg] += (len + UNIT - 1) / UNIT;
+      pieces += 1;
+    }
   }
-  if (T == 0) return;
-  const long long total = T * n_planes;
+  if (pieces == 0) return;
+  auto plane_cost = [&](int pl) {
+    long long c = pieces * ovh * 16;
+#pragma unroll
+    for (int d = 0; d < VSA_NT_MAX_DEG; ++d) c += units_deg[d] * wt(pl, d);
+    return c;
+  };
+  long long total = 0;
+  for (int pl = 0; pl < n_planes; ++pl) total += plane_cost(pl);
   const long long lo = total * blockIdx.x / gridDim.x, hi = total * (blockIdx.x + 1) / gridDim.x;
   if (hi <= lo) return;
-  const int pl0 = (int)(lo / T), pl1 = (int)((hi - 1) / T);
-  for (int pl = pl0; pl <= pl1; ++pl) {
-    long long c0 = (long long)pl * T;
+  long long c0 = 0;
+  for (int pl = 0; pl < n_planes && c0 < hi; ++pl) {
+    const long long pc = plane_cost(pl);
+    if (c0 + pc <= lo) {
+      c0 += pc;
+      continue;
+    }
     for (int tex = tex_begin; tex < n_tex; ++tex) {
       if (!tex_active(plan, tex)) continue;
-      const int sd = (tex / (2 * VSA_NT_MAX_DEG)) * VSA_NT_MAX_DEG + tex % VSA_NT_MAX_DEG;
+      const int deg = tex % VSA_NT_MAX_DEG;
+      const int sd = (tex / (2 * VSA_NT_MAX_DEG)) * VSA_NT_MAX_DEG + deg;
       const int begin = seg_start[sd], end = seg_start[sd + 1];
       if (end <= begin) continue;
-      const int units = (end - begin + UNIT - 1) / UNIT;
-      const long long t0 = c0 + ovh;
-      c0 = t0 + units;
+      const int units = (end - begin + UNIT - 1) / UNIT, w = wt(pl, deg);
+      const long long t0 = c0 + (long long)ovh * 16;
+      c0 = t0 + (long long)units * w;
       if (t0 >= hi) break;
-      const long long a = lo > t0 ? lo - t0 : 0, b = hi - t0 < units ? hi - t0 : units;
+      const long long a = lo > t0 ? lo - t0 : 0, b = hi - t0 < (long long)units * w ? hi - t0 : (long long)units * w;
       if (b <= a) continue;
-      const int first = begin + (int)a * UNIT;
-      const long long lastl = (long long)begin + b * UNIT;
+      const int ua = (int)((a + w - 1) / w), ub = (int)((b + w - 1) / w);   // units whose start lies in [a, b)
+      if (ub <= ua) continue;
+      const int first = begin + ua * UNIT;
+      const long long lastl = (long long)begin + (long long)ub * UNIT;
       body(pl, tex, first, lastl < end ? (int)lastl : end, begin, end);
     }
   }

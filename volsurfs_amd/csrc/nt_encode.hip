@@ -141,7 +141,14 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
   const long long n_entries = plan.level_offset[plan.n_levels];
   const int nl = plan.n_levels;
   NT_SPAN_MARK(HASHED ? 1 : 0, 0);
-  nt_for_each_piece<ENC_UNIT>(plan, seg_start, n_levels, HASHED ? 32 : 8,
+  // per-piece overheads and unit weights: fitted from per-workgroup timings (tools/fit_cost.py):
+  // a piece costs 87 (hashed: a 128 KiB table to stage) / 27 (dense) units of 256 slots, and a
+  // unit of a level finer than the texture (no reuse of the previous slot's cell) 0.92 of one
+  // that goes through the reuse bookkeeping
+  auto unit_weight = [&](int pl, int deg) {
+    return !HASHED || plan.level_scale[level0 + pl] < (float)plan.tex_res[deg] ? 16 : 15;
+  };
+  nt_for_each_piece<ENC_UNIT>(plan, seg_start, n_levels, HASHED ? 87 : 27,
                               [&](int pl, int tex, int first, int last, int, int) {
     const int level = level0 + pl;
     const LevelGeom g = level_geom(plan, level);
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
       run(std::true_type{});
     else
       run(std::false_type{});
-  });
+  }, 0, 1 << 30, unit_weight);
   __syncthreads();
   NT_SPAN_MARK(HASHED ? 1 : 0, 1);
 }
@@ -397,7 +404,12 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   int* s_g = reinterpret_cast<int*>(s_raw);
   NT_SPAN_MARK(HASHED ? 3 : 2, 0);
-  nt_for_each_piece<ENC_UNIT>(plan, seg_start, n_planes, 64,
+  // fitted (tools/fit_cost.py): 145 (hashed) / 64 (dense) units per piece (zeroing + flushing the
+  // LDS plane), and a unit on the no-merge path (level finer than the texture) costs 0.875
+  auto unit_weight = [&](int pl, int deg) {
+    return !HASHED || plan.level_scale[level0 + (pl >> 1)] < (float)plan.tex_res[deg] ? 16 : 14;
+  };
+  nt_for_each_piece<ENC_UNIT>(plan, seg_start, n_planes, HASHED ? 145 : 64,
                               [&](int pl, int tex, int first, int last, int seg_begin, int seg_end) {
     int level = level0, r = pl;
     bool both = enc_both_features(plan, level, HASHED);
@@ -419,7 +431,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
     else
       enc_bwd_piece<HASHED, 1, false>(plan, s_g, level, r, tex, first, last, single, dfeatures,
                                       dfeat_abs_sum, dscale_inv, slot_xy, grad_tables);
-  }, tex_begin, tex_end);
+  }, tex_begin, tex_end, unit_weight);
   __syncthreads();
   NT_SPAN_MARK(HASHED ? 3 : 2, 1);
 }
