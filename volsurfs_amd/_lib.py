@@ -98,6 +98,10 @@ def call(name, *args):
     fn = getattr(lib(), name)
     if kernel_events is not None:
         import torch
+        # keep the queue busy while the host prepares the launch: with an idle queue the start
+        # event's timestamp is taken before the kernel has even been submitted, and the host's
+        # launch latency would be counted as kernel time
+        torch.cuda._sleep(400000)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         rc = fn(*[_conv(x) for x in args])
