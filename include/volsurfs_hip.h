@@ -77,6 +77,15 @@ int vsa_composite_dense_bwd_l1(const float* surfs_rgb, const float* surfs_alpha,
                                float* g_surfs_alpha, int nr_rays, int nr_shells, int carry_f16,
                                void* stream);
 
+/* Forward, L1 loss and backward of a training step in ONE pass over the shells' colours: writes the
+ * composited out_rgb [N,3] (bit-identical to vsa_composite_dense_fwd) and the gradients of
+ * loss_scale * sum |out_rgb - gt_rgb| w.r.t. surfs_rgb / surfs_alpha (as vsa_composite_dense_bwd_l1). */
+int vsa_composite_dense_fwd_bwd_l1(const float* surfs_rgb, const float* surfs_alpha,
+                                   const float* rgb_bg, int bg_is_broadcast, const float* gt_rgb,
+                                   float loss_scale, float* out_rgb, float* g_surfs_rgb,
+                                   float* g_surfs_alpha, int nr_rays, int nr_shells, int carry_f16,
+                                   void* stream);
+
 /* ------------------------------------------------------------------------
  * A2  BVH build (host) + K-shell closest-hit traversal (device).
  * Replaces raytracelib.RayTracer(tensor_meshes) / .trace(rays_o, rays_d, mesh_id)

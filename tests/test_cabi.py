@@ -37,6 +37,7 @@ def test_argument_errors_are_reported_not_ignored():
     assert "#define VSA_ERR_ARG (-1)" in hdr and "#define VSA_ERR_UNSUPPORTED (-2)" in hdr
     assert L.vsa_composite_dense_fwd(null, null, null, 0, null, null, null, null, null, null, 10, 5, 0, null) == ERR_ARG
     assert L.vsa_composite_dense_bwd_l1(null, null, null, 0, null, null, ctypes.c_float(1.0), null, null, 10, 5, 0, null) == ERR_ARG
+    assert L.vsa_composite_dense_fwd_bwd_l1(null, null, null, 0, null, ctypes.c_float(1.0), null, null, null, 10, 5, 0, null) == ERR_ARG
     assert L.vsa_trace(null, null, null, 1, 10, null, null, 10, ctypes.c_float(0), null, null, null, null) == ERR_ARG
     roots = (ctypes.c_int32 * 1)(0)
     assert L.vsa_trace(null, null, roots, 1, 99, null, null, 10, ctypes.c_float(0), null, null, null, null) == ERR_UNSUPPORTED   # tree deeper than the stack

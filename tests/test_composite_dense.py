@@ -195,3 +195,22 @@ def test_fused_l1_backward_equals_explicit_gradient():
     got_c, got_a = composite_bwd_l1_raw(c, a, bg, pred, gt, 1.0 / (3.0 * N))
     assert torch.equal(got_c, ref_c) and torch.equal(got_a, ref_a)
     assert got_c[:7].abs().sum() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [1, 5, 7])
+def test_fused_forward_l1_backward_equals_the_two_kernels(K):
+    """vsa_composite_dense_fwd_bwd_l1 == vsa_composite_dense_fwd followed by
+    vsa_composite_dense_bwd_l1, bit for bit (ragged last tile included)."""
+    from volsurfs_amd.composite import composite_fwd_raw, composite_bwd_l1_raw, composite_fwd_bwd_l1_raw
+    g = torch.Generator(device="cuda").manual_seed(K)
+    N = 1000 + 37
+    c = torch.rand(N, K, 3, device="cuda", generator=g)
+    a = torch.rand(N, K, device="cuda", generator=g)
+    a[torch.rand(N, K, device="cuda", generator=g) < 0.3] = 0.0
+    gt = torch.rand(N, 3, device="cuda", generator=g)
+    for bg in (torch.ones(1, 3, device="cuda"), torch.rand(N, 3, device="cuda", generator=g)):
+        rgb = composite_fwd_raw(c, a, bg)
+        gc, ga = composite_bwd_l1_raw(c, a, bg, rgb, gt, 1.0 / (3 * N))
+        rgb2, gc2, ga2 = composite_fwd_bwd_l1_raw(c, a, bg, gt, 1.0 / (3 * N))
+        assert torch.equal(rgb, rgb2) and torch.equal(gc, gc2) and torch.equal(ga, ga2)

@@ -100,3 +100,16 @@ def composite_bwd_l1_raw(surfs_rgb, surfs_alpha, rgb_bg, pred_rgb, gt_rgb, loss_
     _lib.call("vsa_composite_dense_bwd_l1", surfs_rgb, surfs_alpha, rgb_bg, bcast, pred_rgb, gt_rgb,
               float(loss_scale), g_c, g_a, N, K, int(carry_f16), _lib.stream_ptr())
     return g_c, g_a
+
+
+def composite_fwd_bwd_l1_raw(surfs_rgb, surfs_alpha, rgb_bg, gt_rgb, loss_scale, carry_f16=False):
+    """One launch: the composited colour [N,3] and the gradients of the mean-L1 loss w.r.t. the
+    per-shell colours / alphas (composite_fwd_raw + composite_bwd_l1_raw)."""
+    N, K, _ = surfs_rgb.shape
+    rgb = torch.empty(N, 3, device=surfs_rgb.device)
+    g_c = torch.empty_like(surfs_rgb)
+    g_a = torch.empty_like(surfs_alpha)
+    bcast = rgb_bg.shape[0] == 1 and N != 1
+    _lib.call("vsa_composite_dense_fwd_bwd_l1", surfs_rgb, surfs_alpha, rgb_bg, bcast, gt_rgb,
+              float(loss_scale), rgb, g_c, g_a, N, K, int(carry_f16), _lib.stream_ptr())
+    return rgb, g_c, g_a

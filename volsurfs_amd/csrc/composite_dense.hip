@@ -165,7 +165,8 @@ __global__ __launch_bounds__(TILE) void composite_dense_bwd_kernel(
     const float* __restrict__ surfs_rgb, const float* __restrict__ surfs_alpha,
     const float* __restrict__ rgb_bg, int bg_bcast, const float* __restrict__ g_rgb,
     float* __restrict__ g_surfs_rgb, float* __restrict__ g_surfs_alpha,
-    float* __restrict__ g_rgb_bg, int N, const float* __restrict__ l1_gt, float l1_scale) {
+    float* __restrict__ g_rgb_bg, int N, const float* __restrict__ l1_gt, float l1_scale,
+    float* __restrict__ pred_out) {
   using L = Lds<K>;
   __shared__ float s_c[TILE * L::SC];
   __shared__ float s_a[TILE * L::SA];
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(TILE) void composite_dense_bwd_kernel(
   const int rows = min(TILE, (int)(N - ray0));
   slab_load<3 * K, L::SC>(surfs_rgb + ray0 * 3 * K, s_c, rows);
   slab_load<K, L::SA>(surfs_alpha + ray0 * K, s_a, rows);
-  slab_load<3, 3>(g_rgb + ray0 * 3, s_g, rows);
+  if (!pred_out) slab_load<3, 3>(g_rgb + ray0 * 3, s_g, rows);
   if (!bg_bcast) slab_load<3, 3>(rgb_bg + ray0 * 3, s_b, rows);
   if (l1_gt) slab_load<3, 3>(l1_gt + ray0 * 3, s_t, rows);
   __syncthreads();
@@ -189,12 +190,17 @@ __global__ __launch_bounds__(TILE) void composite_dense_bwd_kernel(
     float g[3], bg[3];
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-      g[ch] = s_g[r * 3 + ch];
-      if (l1_gt) {   // g_rgb holds the prediction: d mean|gt - pred| / d pred = sign(pred - gt) * scale
+      bg[ch] = vsa_round_f16(bg_bcast ? rgb_bg[ch] : s_b[r * 3 + ch]);
+      if (pred_out) {   // fused forward: the composited colour, exactly as composite_dense_fwd_kernel forms it
+        g[ch] = vsa_round_f16(f.fg[ch] + vsa_round_f16(f.bgT * bg[ch]));
+        s_g[r * 3 + ch] = g[ch];
+      } else {
+        g[ch] = s_g[r * 3 + ch];
+      }
+      if (l1_gt) {   // g holds the prediction: d mean|gt - pred| / d pred = sign(pred - gt) * scale
         const float d = g[ch] - s_t[r * 3 + ch];
         g[ch] = d > 0.f ? l1_scale : (d < 0.f ? -l1_scale : 0.f);
       }
-      bg[ch] = vsa_round_f16(bg_bcast ? rgb_bg[ch] : s_b[r * 3 + ch]);
     }
     // S_{K-1} = g.bg ; walk inner -> outer side (k = 0 is the innermost shell,
     // i.e. the LAST one in composite order), oracle/composite.py.
@@ -216,6 +222,7 @@ __global__ __launch_bounds__(TILE) void composite_dense_bwd_kernel(
   slab_store<3 * K, L::SC>(g_surfs_rgb + ray0 * 3 * K, s_c, rows);
   slab_store<K, L::SA>(g_surfs_alpha + ray0 * K, s_a, rows);
   if (g_rgb_bg) slab_store<3, 3>(g_rgb_bg + ray0 * 3, s_b, rows);
+  if (pred_out) slab_store<3, 3>(pred_out + ray0 * 3, s_g, rows);
 }
 
 }  // namespace
@@ -264,10 +271,10 @@ static int composite_bwd_launch(const float* surfs_rgb, const float* surfs_alpha
                                 const float* rgb_bg, int bg_is_broadcast, const float* g_rgb,
                                 float* g_surfs_rgb, float* g_surfs_alpha, float* g_rgb_bg,
                                 int nr_rays, int nr_shells, int carry_f16, const float* l1_gt,
-                                float l1_scale, void* stream) {
+                                float l1_scale, void* stream, float* pred_out = nullptr) {
   if (nr_rays < 0) return VSA_ERR_ARG;
   if (nr_rays == 0) return VSA_OK;
-  if (!surfs_rgb || !surfs_alpha || !rgb_bg || !g_rgb || !g_surfs_rgb || !g_surfs_alpha)
+  if (!surfs_rgb || !surfs_alpha || !rgb_bg || (!g_rgb && !pred_out) || !g_surfs_rgb || !g_surfs_alpha)
     return VSA_ERR_ARG;
   dim3 grid(vsa_div_up(nr_rays, TILE)), block(TILE);
   hipStream_t st = (hipStream_t)stream;
@@ -275,11 +282,11 @@ static int composite_bwd_launch(const float* surfs_rgb, const float* surfs_alpha
     if (carry_f16)
       hipLaunchKernelGGL((composite_dense_bwd_kernel<KK, true>), grid, block, 0, st, surfs_rgb,
                          surfs_alpha, rgb_bg, bg_is_broadcast, g_rgb, g_surfs_rgb, g_surfs_alpha,
-                         g_rgb_bg, nr_rays, l1_gt, l1_scale);
+                         g_rgb_bg, nr_rays, l1_gt, l1_scale, pred_out);
     else
       hipLaunchKernelGGL((composite_dense_bwd_kernel<KK, false>), grid, block, 0, st, surfs_rgb,
                          surfs_alpha, rgb_bg, bg_is_broadcast, g_rgb, g_surfs_rgb, g_surfs_alpha,
-                         g_rgb_bg, nr_rays, l1_gt, l1_scale);
+                         g_rgb_bg, nr_rays, l1_gt, l1_scale, pred_out);
   });
   VSA_RETURN_LAUNCH_STATUS();
 }
@@ -304,4 +311,15 @@ extern "C" int vsa_composite_dense_bwd_l1(const float* surfs_rgb, const float* s
   return composite_bwd_launch(surfs_rgb, surfs_alpha, rgb_bg, bg_is_broadcast, pred_rgb,
                               g_surfs_rgb, g_surfs_alpha, nullptr, nr_rays, nr_shells, carry_f16,
                               gt_rgb, loss_scale, stream);
+}
+
+extern "C" int vsa_composite_dense_fwd_bwd_l1(const float* surfs_rgb, const float* surfs_alpha,
+                                              const float* rgb_bg, int bg_is_broadcast,
+                                              const float* gt_rgb, float loss_scale, float* out_rgb,
+                                              float* g_surfs_rgb, float* g_surfs_alpha, int nr_rays,
+                                              int nr_shells, int carry_f16, void* stream) {
+  if (!gt_rgb || (nr_rays > 0 && !out_rgb)) return VSA_ERR_ARG;
+  return composite_bwd_launch(surfs_rgb, surfs_alpha, rgb_bg, bg_is_broadcast, nullptr, g_surfs_rgb,
+                              g_surfs_alpha, nullptr, nr_rays, nr_shells, carry_f16, gt_rgb,
+                              loss_scale, stream, out_rgb);
 }

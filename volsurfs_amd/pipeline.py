@@ -242,16 +242,12 @@ class KShellPipeline:
                                                act_out=self._act),
             record, bytes=acct.get("nt_shade_fwd", 0))
         self.surfs_rgb, self.surfs_alpha = rgb_k, alpha_k
-        rgb = T.run("composite_fwd", lambda: composite_fwd_raw(rgb_k, alpha_k, self.bg), record,
-                    bytes=N * (16 * K + 12))
-
-        # d mean|gt - pred| / d pred (utils/losses.py:14-19) is formed inside the composite
-        # backward kernel (vsa_composite_dense_bwd_l1)
-        from .composite import composite_bwd_l1_raw
-        g_c, g_a = T.run("composite_bwd",
-                         lambda: composite_bwd_l1_raw(rgb_k, alpha_k, self.bg, rgb, gt,
-                                                      1.0 / (3.0 * N)), record,
-                         bytes=N * (24 + 32 * K))
+        # forward composite, d mean|gt - pred| / d pred (utils/losses.py:14-19) and the composite
+        # backward in one pass over the shells' colours (vsa_composite_dense_fwd_bwd_l1)
+        from .composite import composite_fwd_bwd_l1_raw
+        rgb, g_c, g_a = T.run("composite_fwd_bwd",
+                              lambda: composite_fwd_bwd_l1_raw(rgb_k, alpha_k, self.bg, gt, 1.0 / (3.0 * N)),
+                              record, bytes=N * (12 + 12 + 32 * K))
         tris = self.tracer.tris
         T.run("nt_shade_bwd", lambda: bank.backward_shade(hit_slot, tex_uv, rays_d, tris, g_c, g_a,
                                                            self.grad_scale, self._act), record,
