@@ -245,14 +245,16 @@ int vsa_nt_mlp_fwd(const vsa_nt_plan* plan, const void* weights_h, const void* f
  * grad_rows (f16, already multiplied by grad_scale) through sigmoid (round = STE)
  * and the three layers on MFMA.  Overwrites `features` IN PLACE with the feature
  * gradients (f16x2, still scaled) and accumulates grad_weights (f32
- * [n_tex][VSA_NT_WEIGHTS_PER_TEX], scaled) with one flush per workgroup.
+ * [n_tex][VSA_NT_WEIGHTS_PER_TEX]) += weight_grad_scale x (the scaled weight gradients), one
+ * flush per workgroup; weight_grad_scale = 1 / grad_scale adds the true gradients straight to
+ * weights.grad.
  * grad_rows is CONSUMED: every row read is reset to zero, so the buffer (zero
  * at allocation) is zero again outside a [vsa_nt_shade_bwd, vsa_nt_mlp_bwd] pair.
  * dfeat_abs_sum (f32 [n_tex][32], zeroed by the caller) += sum over slots of |dF| per
  * feature row: the overflow bound of vsa_nt_encode_bwd's fixed-point accumulation. */
 int vsa_nt_mlp_bwd(const vsa_nt_plan* plan, const void* weights_h, void* features,
                    const int32_t* seg_start, uint16_t* grad_rows, float* grad_weights,
-                   float* dfeat_abs_sum, void* stream);
+                   float* dfeat_abs_sum, float weight_grad_scale, void* stream);
 
 /* Step 5: per-hit shading from the texel rows (expand LUT -> lerp -> fp16 SH
  * coefficients -> SH eval -> sigmoid -> alpha decay), scattered dense:

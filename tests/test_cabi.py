@@ -44,7 +44,7 @@ def test_argument_errors_are_reported_not_ignored():
     assert L.vsa_trace(null, null, roots, 1, 10, null, null, 0, ctypes.c_float(0), null, null, null, null) == 0                 # empty batch is fine
     assert L.vsa_trace(null, null, roots, 17, 10, null, null, 10, ctypes.c_float(0), null, null, null, null) == ERR_ARG        # > VSA_MAX_SHELLS
     assert L.vsa_nt_encode_fwd(null, null, null, null, null, null) == ERR_ARG
-    assert L.vsa_nt_mlp_bwd(null, null, null, null, null, null, null, null) == ERR_ARG
+    assert L.vsa_nt_mlp_bwd(null, null, null, null, null, null, null, ctypes.c_float(1.0), null) == ERR_ARG
     assert L.vsa_nt_shade_fwd(null, null, null, null, null, null, null, null, 10, null, null, null, null, null, null) == ERR_ARG
     assert L.vsa_grid_encode_fwd(null, null, null, 10, null, null) == ERR_ARG
     assert L.vsa_sh_encode(null, 10, 7, null, null) == ERR_ARG                                   # degree > 4

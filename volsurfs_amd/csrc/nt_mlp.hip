@@ -351,7 +351,7 @@ __device__ __forceinline__ void pc_run(
     const vsa_nt_plan& plan, const Work wk, unsigned char* s_raw,
     const _Float16* __restrict__ weights, unsigned* __restrict__ features,
     const int* __restrict__ seg_start, _Float16* __restrict__ grad_rows,
-    float* __restrict__ grad_weights, float* __restrict__ dfeat_abs_sum) {
+    float* __restrict__ grad_weights, float* __restrict__ dfeat_abs_sum, float gw_scale) {
   half8_t* s_frag = reinterpret_cast<half8_t*>(s_raw) - 16 * 64;   // indexed by fragment id 16..35 (20 KiB)
   _Float16* s_img_all = reinterpret_cast<_Float16*>(s_raw + PC_FRAGS * 64 * 16);
 #ifdef NT_STAMP
@@ -677,7 +677,7 @@ __device__ __forceinline__ void pc_run(
     const int w3_end = W3_OFF + ti.channels * 64;
     for (int i = threadIdx.x; i < w3_end; i += PC_BLOCK) {
       const float v = s_acc[i];
-      if (v != 0.0f) atomicAdd(&gw[i], v);
+      if (v != 0.0f) atomicAdd(&gw[i], v * gw_scale);
     }
   }
 #ifdef NT_STAMP
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(PC_BLOCK, 2) void nt_mlp_bwd_pc_kernel(
     vsa_nt_plan plan, const _Float16* __restrict__ weights,
     unsigned* __restrict__ features, const int* __restrict__ seg_start,
     _Float16* __restrict__ grad_rows, float* __restrict__ grad_weights,
-    float* __restrict__ dfeat_abs_sum) {
+    float* __restrict__ dfeat_abs_sum, float gw_scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   NT_SPAN_MARK(1, 0);
   nt_for_each_piece<32>(plan, seg_start, 1, PC_RUN_COST,
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(PC_BLOCK, 2) void nt_mlp_bwd_pc_kernel(
     wk.seg_len = seg_end - seg_begin;
     wk.first = first;
     wk.last = last;
-    pc_run(plan, wk, s_raw, weights, features, seg_start, grad_rows, grad_weights, dfeat_abs_sum);
+    pc_run(plan, wk, s_raw, weights, features, seg_start, grad_rows, grad_weights, dfeat_abs_sum, gw_scale);
     __syncthreads();   // the next run re-stages the fragments
   });
   NT_SPAN_MARK(1, 1);
@@ -757,7 +757,7 @@ extern "C" int vsa_nt_mlp_fwd(const vsa_nt_plan* plan, const void* weights_h, co
 
 extern "C" int vsa_nt_mlp_bwd(const vsa_nt_plan* plan, const void* weights_h, void* features,
                               const int32_t* seg_start, uint16_t* grad_rows, float* grad_weights,
-                              float* dfeat_abs_sum, void* stream) {
+                              float* dfeat_abs_sum, float weight_grad_scale, void* stream) {
   if (!plan || !weights_h || !features || !seg_start || !grad_rows || !grad_weights ||
       !dfeat_abs_sum)
     return VSA_ERR_ARG;
@@ -774,6 +774,6 @@ extern "C" int vsa_nt_mlp_bwd(const vsa_nt_plan* plan, const void* weights_h, vo
                      *plan, reinterpret_cast<const _Float16*>(weights_h),
                      reinterpret_cast<unsigned*>(features), seg_start,
                      reinterpret_cast<_Float16*>(grad_rows), grad_weights,
-                     dfeat_abs_sum);
+                     dfeat_abs_sum, weight_grad_scale);
   VSA_RETURN_LAUNCH_STATUS();
 }

@@ -302,8 +302,6 @@ class NeuralTextureBank(torch.nn.Module):
             self.tables.grad = torch.zeros_like(self.tables)
         if self.weights.grad is None:
             self.weights.grad = torch.zeros_like(self.weights)
-        if getattr(self, "_gw_scaled", None) is None:
-            self._gw_scaled = torch.zeros_like(self.weights)
 
     def backward_shade(self, hit_slot, tex_uv, rays_d, tris, g_surfs_rgb, g_surfs_alpha, grad_scale,
                        act=None):
@@ -317,14 +315,13 @@ class NeuralTextureBank(torch.nn.Module):
                   _lib.stream_ptr())
 
     def backward_mlp(self, grad_scale):
-        self._gw_scaled.zero_()
         if getattr(self, "_dfsum", None) is None:
             self._dfsum = torch.zeros(self.n_tex, 32, device=self.weights.device)
         else:
             self._dfsum.zero_()
         _lib.call("vsa_nt_mlp_bwd", ctypes.byref(self.plan), self.weights_h, self.features,
-                  self.seg_start, self.grad_rows, self._gw_scaled, self._dfsum, _lib.stream_ptr())
-        self.weights.grad.add_(self._gw_scaled, alpha=1.0 / float(grad_scale))
+                  self.seg_start, self.grad_rows, self.weights.grad, self._dfsum,
+                  1.0 / float(grad_scale), _lib.stream_ptr())
 
     def backward_encode(self, grad_scale, shells=None):
         """shells=(begin, end) restricts the launch to those shells' textures (their table
