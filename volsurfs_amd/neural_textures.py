@@ -303,6 +303,28 @@ class NeuralTextureBank(torch.nn.Module):
         if self.weights.grad is None:
             self.weights.grad = torch.zeros_like(self.weights)
 
+    def zero_grads(self):
+        """tables.grad, weights.grad and the per-texture sum |dF| of the MLP backward live in ONE
+        allocation so that a training step clears them with one fill (three small launches
+        otherwise).  Returns False if the gradient tensors are not (any more) those views —
+        e.g. an optimiser's zero_grad(set_to_none=True) dropped them — and clears what exists."""
+        flat = getattr(self, "_grad_flat", None)
+        nt, nw = self.tables.numel(), self.weights.numel()
+        if flat is None:
+            flat = torch.zeros(nt + nw + self.n_tex * 32, device=self.tables.device)
+            self._grad_flat = flat
+            self._flat_t, self._flat_w = flat[:nt].view_as(self.tables), flat[nt:nt + nw].view_as(self.weights)
+            self._dfsum = flat[nt + nw:].view(self.n_tex, 32)
+        if self.tables.grad is None and self.weights.grad is None:
+            self.tables.grad, self.weights.grad = self._flat_t, self._flat_w
+        if self.tables.grad is self._flat_t and self.weights.grad is self._flat_w:
+            flat.zero_()
+            self._dfsum_clean = True
+            return True
+        self.tables.grad.zero_()
+        self.weights.grad.zero_()
+        return False
+
     def backward_shade(self, hit_slot, tex_uv, rays_d, tris, g_surfs_rgb, g_surfs_alpha, grad_scale,
                        act=None):
         self._ensure_grads()
@@ -317,8 +339,9 @@ class NeuralTextureBank(torch.nn.Module):
     def backward_mlp(self, grad_scale):
         if getattr(self, "_dfsum", None) is None:
             self._dfsum = torch.zeros(self.n_tex, 32, device=self.weights.device)
-        else:
+        elif not getattr(self, "_dfsum_clean", False):
             self._dfsum.zero_()
+        self._dfsum_clean = False            # (zero_grads() has just cleared it together with the gradients)
         _lib.call("vsa_nt_mlp_bwd", ctypes.byref(self.plan), self.weights_h, self.features,
                   self.seg_start, self.grad_rows, self.weights.grad, self._dfsum,
                   1.0 / float(grad_scale), _lib.stream_ptr())

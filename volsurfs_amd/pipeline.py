@@ -212,11 +212,7 @@ class KShellPipeline:
         T, bank = self.timer, self.bank
         acct = getattr(self, "acct", None) or {}     # algorithmic bytes per stage (stats())
 
-        def zero_grad():
-            if bank.tables.grad is not None:
-                bank.tables.grad.zero_()
-                bank.weights.grad.zero_()
-        T.run("zero_grad", zero_grad, record, bytes=(bank.tables.numel() + bank.weights.numel()) * 4)
+        T.run("zero_grad", bank.zero_grads, record, bytes=(bank.tables.numel() + bank.weights.numel()) * 4)
         rays_o, rays_d, gt = self.rays_o, self.rays_d, self.gt
         if self.image_hw is not None:
             H, W = self.image_hw
