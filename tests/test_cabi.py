@@ -69,3 +69,31 @@ def test_argument_errors_are_reported_not_ignored():
     # the Python layer turns any non-zero status into an exception
     with pytest.raises(_lib.VolsurfsHipError):
         _lib.call("vsa_sh_encode", None, 10, 7, None, None)
+
+
+def test_import_volsurfs_resolves_to_the_mirror():
+    """src/PyBridge.cxx:19 names the extension `volsurfs`; utils/background.py:3,5 and
+    params/cmd_params.py:2,8-9 import it under that name and locate the repo root from it."""
+    import importlib
+    import inspect
+    volsurfs = importlib.import_module("volsurfs")
+    from volsurfs import OccupancyGrid, RaySampler, RaySamplesPacked, VolumeRendering
+    from volsurfs_amd import volsurfs as mirror
+    assert VolumeRendering is mirror.VolumeRendering and RaySampler is mirror.RaySampler
+    assert OccupancyGrid is mirror.OccupancyGrid and RaySamplesPacked is mirror.RaySamplesPacked
+    root = os.path.dirname(os.path.abspath(volsurfs.__file__))
+    assert os.path.isdir(os.path.join(root, "volsurfs_amd"))          # module sits at the repo root
+    # every method the pybind module exports exists with the same name (PyBridge.cxx:33-138)
+    for cls, names in ((VolumeRendering, ["cumprod_one_minus_alpha_to_transmittance", "integrate_with_weights_1d",
+                                          "integrate_with_weights_3d", "sdf2alpha", "sum_over_rays",
+                                          "median_depth_over_rays", "cumsum_over_rays", "compute_cdf",
+                                          "importance_sample", "combine_ray_samples_packets",
+                                          "cumprod_one_minus_alpha_to_transmittance_backward",
+                                          "integrate_with_weights_1d_backward",
+                                          "integrate_with_weights_3d_backward", "sum_over_rays_backward"]),
+                       (RaySampler, ["compute_samples_fg", "compute_samples_fg_in_grid_occupied_regions",
+                                     "compute_samples_bg", "init_with_one_sample_per_ray", "contract_samples",
+                                     "uncontract_samples"])):
+        for n in names:
+            assert callable(inspect.getattr_static(cls, n).__func__), n
+    assert VolumeRendering.bug_compat is True      # default = what the reference computes

@@ -50,7 +50,7 @@ def _worker(rank, world, port, n_rays, q):
     allreduce_gradients([w], world)
     frame = gather_frame(pred.detach(), n_rays, rank, world, chunk=1000)
     if rank == 0:
-        q.put((w.grad.clone(), frame))
+        q.put((w.grad.numpy().copy(), frame.numpy().copy()))   # by value: a tensor travels as an fd the parent may read too late
     dist.barrier()
     dist.destroy_process_group()
 
@@ -63,7 +63,7 @@ def test_two_ranks_equal_one_rank():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_rays, q)) for r in range(2)]
     for p in procs:
         p.start()
-    grad, frame = q.get(timeout=120)
+    grad, frame = (torch.from_numpy(x) for x in q.get(timeout=120))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -91,7 +91,7 @@ def _overlap_worker(rank, world, port, q):
     ov.wait()
     assert ov.works == []
     if rank == 0:
-        q.put((g.clone(), w.clone()))
+        q.put((g.numpy().copy(), w.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -103,9 +103,87 @@ def test_gradient_overlap_slices_two_ranks():
     procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    g, w = q.get(timeout=120)
+    g, w = (torch.from_numpy(x) for x in q.get(timeout=120))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     torch.testing.assert_close(g, torch.arange(40 * 6, dtype=torch.float32).view(40, 6) * 3)
     torch.testing.assert_close(w, torch.full((5,), 3.0))
+
+
+class _LinearMethod(torch.nn.Module):
+    """CPU stand-in with the call shape trainer.train_step expects of VolSurfs (the HIP
+    renderer cannot run without a GPU; the -m gpu twin of this test drives the real pipeline,
+    tests/test_training_loop.py::test_two_rank_train_step_on_hip)."""
+
+    def __init__(self, max_rays):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.linspace(-1, 1, 12).view(4, 3))
+        self.max_rays, self.lr_scheduler, self.is_training = max_rays, None, True
+        self.optimizer = torch.optim.SGD([self.w], lr=0.5)
+        self.forward_sizes = []
+
+    def optim_step(self):
+        self.optimizer.step()
+
+    def forward(self, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first_iter=False,
+                is_training_masked=False):
+        self.forward_sizes.append(rays_o.shape[0])
+        pred = torch.cat([rays_o, rays_d[:, :1]], 1) @ self.w
+        d = (gt_rgb - pred).abs()
+        loss = (d * gt_mask).mean() if (is_training_masked and gt_mask is not None) else d.mean()
+        return {"loss": loss, "rgb": loss}, {}, rays_o[: rays_o.shape[0] // 2]
+
+
+def _train_step_worker(rank, world, port, n_rays, q):
+    from volsurfs_amd.trainer import train_step
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    o = torch.rand(n_rays, 3, generator=torch.Generator().manual_seed(1))
+    d = torch.rand(n_rays, 3, generator=torch.Generator().manual_seed(3))
+    gt = torch.rand(n_rays, 3, generator=torch.Generator().manual_seed(2))
+    idx = shard_indices(n_rays, rank, world, chunk=1000)       # uneven: 4000 vs 3300 rays
+    m = _LinearMethod(max_rays=1 << 20)
+    losses, _ = train_step(m, o[idx], d[idx], gt[idx], world=world)
+    if rank == 0:
+        q.put(m.w.detach().numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_step_two_ranks_equals_one_rank_and_chunks_over_max_rays():
+    """train_step(world>1) must produce the gradient of the GLOBAL mean loss, also
+    for uneven shards; and a batch above max_rays must be chunked, not refused."""
+    from volsurfs_amd.trainer import train_step
+    n_rays = 7300
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_step_worker, args=(r, 2, port, n_rays, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    w2 = torch.from_numpy(q.get(timeout=120))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    o = torch.rand(n_rays, 3, generator=torch.Generator().manual_seed(1))
+    d = torch.rand(n_rays, 3, generator=torch.Generator().manual_seed(3))
+    gt = torch.rand(n_rays, 3, generator=torch.Generator().manual_seed(2))
+    one = _LinearMethod(max_rays=1 << 20)
+    l1, _ = train_step(one, o, d, gt)
+    torch.testing.assert_close(w2, one.w.detach(), rtol=1e-5, atol=1e-7)
+    # the same batch through a method that holds only 2048 rays: 4 chunks, same step, same loss,
+    # and the dynamic ray count sees the samples of every chunk
+    small = _LinearMethod(max_rays=2048)
+    l2, nr = train_step(small, o, d, gt, nr_rays=n_rays, target_nr_of_training_samples=49152)
+    assert small.forward_sizes == [2048, 2048, 2048, 1156]
+    torch.testing.assert_close(small.w.detach(), one.w.detach(), rtol=1e-5, atol=1e-7)
+    assert abs(l2["loss"] - l1["loss"]) < 1e-6
+    assert nr == int(n_rays * (49152.0 / (1024 * 3 + 578)))
+    # masked training reaches the method (ADVICE r1, low)
+    m3 = _LinearMethod(max_rays=1 << 20)
+    mask = (torch.arange(n_rays) % 2 == 0).float()[:, None]
+    l3, _ = train_step(m3, o, d, gt, mask, is_training_masked=True)
+    ref = ((gt - torch.cat([o, d[:, :1]], 1) @ torch.linspace(-1, 1, 12).view(4, 3)).abs() * mask).mean()
+    assert abs(l3["loss"] - ref.item()) < 1e-6

@@ -395,6 +395,16 @@ GENS = {"composite": gen_composite, "nt": gen_nt, "glue": gen_glue, "legacy": ge
         "misc": gen_misc}
 
 if __name__ == "__main__":
+    # One generator per process: each one imports the reference with its own set of stand-ins
+    # for the absent third-party modules (bare placeholders vs the oracle's tcnn / uv helpers),
+    # and Python caches the first import.  `python tools/make_golden.py` regenerates every
+    # fixture; `python tools/make_golden.py nt glue` only those.
+    import subprocess
     which = sys.argv[1:] or list(GENS)
-    for w in which:
-        GENS[w]()
+    if len(which) == 1 and which[0].startswith("--only="):
+        GENS[which[0][7:]]()
+    else:
+        for w in which:
+            if w not in GENS:
+                raise SystemExit(f"unknown generator {w!r}; have {sorted(GENS)}")
+            subprocess.run([sys.executable, os.path.abspath(__file__), f"--only={w}"], check=True)

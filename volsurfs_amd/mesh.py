@@ -140,16 +140,177 @@ def save_obj(path, mesh):
                                                   tri[2] + 1, 3 * i + 3))
 
 
+_PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2",
+              "ushort": "u2", "uint16": "u2", "int": "i4", "int32": "i4", "uint": "u4",
+              "uint32": "u4", "float": "f4", "float32": "f4", "double": "f8", "float64": "f8"}
+
+
+def load_ply(path, device="cuda"):
+    """Stanford PLY -> TensorMesh (the reference accepts `.ply` next to `.obj`,
+    utils/mesh_loaders.py:22-31; marching-cubes shells before the xatlas pass are PLY).
+    ascii, binary_little_endian and binary_big_endian; vertex x/y/z (+ optional per-vertex
+    s/t or u/v or texture_u/texture_v); face `vertex_indices` lists (polygons are
+    fan-triangulated) + optional per-face `texcoord` list of 2*n floats (MeshLab wedge uvs).
+    Other elements / properties are skipped."""
+    with open(path, "rb") as f:
+        if f.readline().strip() != b"ply":
+            raise ValueError(f"{path}: not a PLY file")
+        fmt, elements = None, []
+        while True:
+            line = f.readline()
+            if not line:
+                raise ValueError(f"{path}: truncated PLY header")
+            tok = line.decode("ascii", "replace").split()
+            if not tok or tok[0] in ("comment", "obj_info"):
+                continue
+            if tok[0] == "format":
+                fmt = tok[1]
+            elif tok[0] == "element":
+                elements.append((tok[1], int(tok[2]), []))
+            elif tok[0] == "property":
+                if tok[1] == "list":
+                    elements[-1][2].append((tok[4], ("list", _PLY_TYPES[tok[2]], _PLY_TYPES[tok[3]])))
+                else:
+                    elements[-1][2].append((tok[2], _PLY_TYPES[tok[1]]))
+            elif tok[0] == "end_header":
+                break
+        if fmt not in ("ascii", "binary_little_endian", "binary_big_endian"):
+            raise ValueError(f"{path}: unsupported PLY format {fmt}")
+        end = ">" if fmt == "binary_big_endian" else "<"
+        data = {}
+        if fmt == "ascii":
+            toks = iter(f.read().split())
+        for name, count, props in elements:
+            has_list = any(isinstance(t, tuple) for _, t in props)
+            if not has_list:
+                if fmt == "ascii":
+                    arr = np.array([[float(next(toks)) for _ in props] for _ in range(count)],
+                                   np.float64).reshape(count, len(props))
+                    data[name] = {pn: arr[:, i] for i, (pn, _) in enumerate(props)}
+                else:
+                    dt = np.dtype([(pn, end + t) for pn, t in props])
+                    arr = np.frombuffer(f.read(dt.itemsize * count), dt, count)
+                    data[name] = {pn: arr[pn] for pn, _ in props}
+                continue
+            rows = {pn: [] for pn, _ in props}
+            if fmt != "ascii" and count:
+                # fast path: all-triangle faces have fixed-size records (3 indices, 6 wedge uvs)
+                guess = {"vertex_indices": 3, "vertex_index": 3, "texcoord": 6}
+                fields = []
+                for pn, t in props:
+                    if isinstance(t, tuple):
+                        fields += [(pn + "#n", end + t[1]), (pn, end + t[2], (guess.get(pn, 3),))]
+                    else:
+                        fields.append((pn, end + t))
+                dt = np.dtype(fields)
+                pos = f.tell()
+                buf = f.read(dt.itemsize * count)
+                ok = len(buf) == dt.itemsize * count
+                if ok:
+                    arr = np.frombuffer(buf, dt, count)
+                    ok = all((arr[pn + "#n"] == guess.get(pn, 3)).all() for pn, t in props
+                             if isinstance(t, tuple))
+                if ok:
+                    data[name] = {pn: arr[pn] for pn, _ in props}
+                    continue
+                f.seek(pos)
+            for _ in range(count):
+                for pn, t in props:
+                    if isinstance(t, tuple):
+                        if fmt == "ascii":
+                            n = int(next(toks))
+                            vals = [float(next(toks)) for _ in range(n)]
+                        else:
+                            n = int(np.frombuffer(f.read(np.dtype(t[1]).itemsize), end + t[1])[0])
+                            vals = np.frombuffer(f.read(np.dtype(t[2]).itemsize * n), end + t[2]).tolist()
+                        rows[pn].append(vals)
+                    elif fmt == "ascii":
+                        rows[pn].append(float(next(toks)))
+                    else:
+                        rows[pn].append(np.frombuffer(f.read(np.dtype(t).itemsize), end + t)[0])
+            data[name] = rows
+    if "vertex" not in data or "face" not in data:
+        raise ValueError(f"{path}: no geometry")
+    vd = data["vertex"]
+    verts = np.stack([np.asarray(vd[k], np.float64) for k in ("x", "y", "z")], 1).astype(np.float32)
+    fkey = next((k for k in ("vertex_indices", "vertex_index") if k in data["face"]), None)
+    if fkey is None:
+        raise ValueError(f"{path}: faces carry no vertex_indices")
+    vuv = None
+    for a, b in (("s", "t"), ("u", "v"), ("texture_u", "texture_v")):
+        if a in vd and b in vd:
+            vuv = np.stack([np.asarray(vd[a], np.float32), np.asarray(vd[b], np.float32)], 1)
+    wedge = data["face"].get("texcoord")
+    faces, fuvs = [], []
+    for i, poly in enumerate(data["face"][fkey]):
+        poly = [int(x) for x in poly]
+        for k in range(1, len(poly) - 1):
+            tri = [poly[0], poly[k], poly[k + 1]]
+            faces.append(tri)
+            if wedge is not None and len(wedge[i]) >= 2 * len(poly):
+                w = np.asarray(wedge[i], np.float32).reshape(-1, 2)
+                fuvs.append([w[0], w[k], w[k + 1]])
+            elif vuv is not None:
+                fuvs.append(vuv[tri])
+    if not len(verts) or not faces:
+        raise ValueError(f"{path}: no geometry")
+    has_uvs = len(fuvs) == len(faces)
+    fuv = np.asarray(fuvs, np.float32).reshape(-1, 3, 2) if has_uvs else np.zeros((len(faces), 3, 2), np.float32)
+    mesh = TensorMesh(verts, np.asarray(faces, np.int32), fuv, device=device)
+    mesh.has_uvs = has_uvs
+    return mesh
+
+
+def save_ply(path, mesh, binary=True):
+    """TensorMesh -> PLY with MeshLab-style per-face `texcoord` wedge uvs (round-trips
+    through load_ply)."""
+    v = mesh.vertices.detach().cpu().numpy().astype("<f4")
+    f = mesh.faces.detach().cpu().numpy().astype("<i4")
+    fuv = mesh.get_faces_uvs()
+    fuv = None if fuv is None else fuv.detach().cpu().numpy().astype("<f4").reshape(-1, 6)
+    hdr = ["ply", "format %s 1.0" % ("binary_little_endian" if binary else "ascii"),
+           "comment volsurfs_amd", f"element vertex {len(v)}", "property float x", "property float y",
+           "property float z", f"element face {len(f)}", "property list uchar int vertex_indices"]
+    if fuv is not None:
+        hdr.append("property list uchar float texcoord")
+    hdr.append("end_header")
+    with open(path, "wb") as out:
+        out.write(("\n".join(hdr) + "\n").encode("ascii"))
+        if binary:
+            out.write(v.tobytes())
+            for i in range(len(f)):
+                out.write(b"\x03" + f[i].tobytes())
+                if fuv is not None:
+                    out.write(b"\x06" + fuv[i].tobytes())
+        else:
+            for p_ in v.tolist():
+                out.write(("%.9g %.9g %.9g\n" % tuple(p_)).encode())
+            for i in range(len(f)):
+                line = "3 %d %d %d" % tuple(f[i].tolist())
+                if fuv is not None:
+                    line += " 6 " + " ".join("%.9g" % x for x in fuv[i].tolist())
+                out.write((line + "\n").encode())
+
+
+def load_mesh(path, device="cuda"):
+    """.obj or .ply by extension (utils/mesh_loaders.py:26)."""
+    if path.endswith(".ply"):
+        return load_ply(path, device=device)
+    if path.endswith(".obj"):
+        return load_obj(path, device=device)
+    raise ValueError(f"{path}: unsupported mesh format (expected .obj or .ply)")
+
+
 def load_meshes_indexed_from_path(meshes_indices, meshes_path, require_uvs=False, return_paths=False,
                                   device="cuda"):
-    """utils/mesh_loaders.py:35-110: the .obj files of a directory sorted by the isolevel in
+    """utils/mesh_loaders.py:35-110: the .obj / .ply files of a directory sorted by the isolevel in
     their name (inner -> outer), optionally a subset by index.  Errors raise (the reference
     prints and exit(1)s)."""
     import os
     if not os.path.exists(meshes_path):
         raise FileNotFoundError(f"mesh path {meshes_path} does not exist")
-    names = [n for n in os.listdir(meshes_path) if n.endswith(".obj")]
-    names.sort(key=lambda x: float(x[:-4]))
+    names = [n for n in os.listdir(meshes_path) if n.endswith(".obj") or n.endswith(".ply")]
+    names.sort(key=lambda x: float(x[:-4]))                       # mesh_loaders.py:22-31
     if not names:
         raise FileNotFoundError(f"no meshes found in {meshes_path}")
     if meshes_indices is not None:
@@ -161,7 +322,7 @@ def load_meshes_indexed_from_path(meshes_indices, meshes_path, require_uvs=False
                 raise IndexError(f"mesh index {i} out of range")
         names = [names[i] for i in idx]
     paths = [os.path.join(meshes_path, n) for n in names]
-    meshes = [load_obj(p, device=device) for p in paths]
+    meshes = [load_mesh(p, device=device) for p in paths]
     if require_uvs:
         for n, m in zip(names, meshes):
             if not m.has_uvs:

@@ -24,10 +24,14 @@ class _ShadeStage(torch.autograd.Function):
         tex_uv = bank.mark_and_compact(hit_slot, hit_uv, method.face_uvs)
         bank.encode()
         bank.mlp()
+        # (torch.is_grad_enabled() is always False inside Function.forward: decide from the inputs)
         act = torch.empty(hit_slot.shape[0], hit_slot.shape[1], 4, device=hit_slot.device) \
-            if torch.is_grad_enabled() else None
+            if (tables.requires_grad or weights.requires_grad) else None
         rgb, alpha, normals, _ = bank.shade(hit_slot, tex_uv, rays_d, method.raytracer.tris,
                                             want_normals=True, act_out=act)
+        # backward reads the bank's per-frame state (slot_of, seg_start, texels, features): stamp it
+        bank.frame_generation = getattr(bank, "frame_generation", 0) + 1
+        ctx.generation = bank.frame_generation
         ctx.method, ctx.saved = method, (hit_slot, tex_uv, rays_d, act)
         ctx.mark_non_differentiable(normals, tex_uv)
         return rgb, alpha, normals, tex_uv
@@ -37,6 +41,10 @@ class _ShadeStage(torch.autograd.Function):
         method = ctx.method
         bank = method.bank
         hit_slot, tex_uv, rays_d, act = ctx.saved
+        if bank.frame_generation != ctx.generation:
+            raise _lib.VolsurfsHipError(
+                "backward of a render_rays call whose per-frame texel state was overwritten by a "
+                "later render_rays: call backward before rendering again")
         gt_prev, gw_prev = bank.tables.grad, bank.weights.grad
         bank.tables.grad = torch.zeros_like(bank.tables)
         bank.weights.grad = torch.zeros_like(bank.weights)
@@ -346,6 +354,11 @@ class VolSurfs(torch.nn.Module):
                 f = os.path.join(path, f"{key}.pt")
                 if os.path.exists(f):
                     st = torch.load(f, map_location=t.device)
+                    from .checkpoint import is_reference_state_dict, load_reference_state_dict
+                    if is_reference_state_dict(st):      # a checkpoint written by the reference itself
+                        name, i = key.rsplit("_", 1)
+                        load_reference_state_dict(self.bank, int(i), 0 if name == "rgb" else 1, st)
+                        continue
                     t.copy_(st["tables"])
                     w.copy_(st["weights"])
         if self.bank is not None:
@@ -371,7 +384,8 @@ class VolSurfs(torch.nn.Module):
         from .camera import get_camera_rays
         rays_o, rays_d, _ = get_camera_rays(camera, nr_rays_per_pixel, jitter_pixels)
         full = self.render(rays_o, rays_d, nr_rays_per_pixel, chunk)
-        return {k: v.reshape(camera.height, camera.width, *v.shape[1:]) for k, v in full.items()}
+        return {k: None if v is None else v.reshape(camera.height, camera.width, *v.shape[1:])
+                for k, v in full.items()}
 
     @torch.no_grad()
     def render(self, rays_o, rays_d, nr_rays_per_pixel=1, chunk=16384):
@@ -381,7 +395,9 @@ class VolSurfs(torch.nn.Module):
         for a in range(0, rays_o.shape[0], chunk):
             r = self.render_rays(rays_o[a:a + chunk], rays_d[a:a + chunk], return_samples=False)
             outs.append(r["renders"]["ray_traced"])
-        full = {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
+        # keys a configuration does not produce are None (surfs_uvs on the legacy branch)
+        full = {k: None if outs[0][k] is None else torch.cat([o[k] for o in outs], 0) for k in outs[0]}
         if nr_rays_per_pixel > 1:
-            full = {k: v.reshape(-1, nr_rays_per_pixel, *v.shape[1:]).mean(1) for k, v in full.items()}
+            full = {k: None if v is None else v.reshape(-1, nr_rays_per_pixel, *v.shape[1:]).mean(1)
+                    for k, v in full.items()}
         return full

@@ -27,22 +27,52 @@ def dynamic_nr_rays(nr_rays, nr_samples, target_nr_samples):
 
 
 def train_step(method, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first_iter=False,
-               nr_rays=None, target_nr_of_training_samples=None, world=1):
+               nr_rays=None, target_nr_of_training_samples=None, world=1, is_training_masked=False,
+               group=None):
     """Returns (losses dict with a float "loss", next nr_rays).  `method` is a
-    volsurfs_amd.methods.VolSurfs with init_optim() called.  world > 1: the caller feeds this
-    rank's shard; gradients are summed over ranks before the step."""
+    volsurfs_amd.methods.VolSurfs with init_optim() called.
+
+    A batch larger than `method.max_rays` (the dynamic ray count of trainer.py:288-304 grows
+    without bound) is run as chunks of at most max_rays rays whose losses are weighted by their
+    share of the batch, gradients accumulating: the step equals the one-shot step.
+
+    world > 1: the caller feeds this rank's shard.  The reference's loss is a MEAN over the
+    batch (utils/losses.py:14-19), so each rank's loss is weighted by local_rays / global_rays
+    (one all-reduce of the ray counts) before backward and the gradients are summed over the
+    ranks: the result is the gradient of the global mean for even and uneven shards alike
+    (SURVEY §8e)."""
     method.is_training = True
     method.optimizer.zero_grad()                                            # trainer.py:118
-    losses, _, samples_3d = method(rays_o, rays_d, gt_rgb, gt_mask, iter_nr,
-                                   is_first_iter=is_first_iter)             # :229
-    losses["loss"].backward()                                               # :264
+    n_local = rays_o.shape[0]
+    share = 1.0
+    if world > 1:
+        import torch.distributed as dist
+        cnt = torch.tensor([float(n_local)], device=rays_o.device, dtype=torch.float64)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+        share = n_local / cnt.item()
+    cap = int(getattr(method, "max_rays", n_local) or n_local)
+    bounds = list(range(0, n_local, cap)) if n_local > cap else [0]
+    losses, nr_samples = {}, 0
+    for ci, a in enumerate(bounds):
+        b = min(n_local, a + cap) if len(bounds) > 1 else n_local
+        sl = slice(a, b)
+        l, _, samples_3d = method(rays_o[sl], rays_d[sl], gt_rgb[sl],
+                                  None if gt_mask is None else gt_mask[sl], iter_nr,
+                                  is_first_iter=is_first_iter and ci == 0,
+                                  is_training_masked=is_training_masked)   # :229
+        w = (b - a) / max(n_local, 1)
+        (l["loss"] * (w * share)).backward()                                # :264
+        for k, v in l.items():
+            losses[k] = losses.get(k, 0.0) + (v.detach() if isinstance(v, torch.Tensor) else v) * w
+        if samples_3d is not None:
+            nr_samples += samples_3d.shape[0]
     if world > 1:
         from .parallel import allreduce_gradients
-        allreduce_gradients([p for g in method.optimizer.param_groups for p in g["params"]], world)
+        allreduce_gradients([p for g in method.optimizer.param_groups for p in g["params"]], world, group)
     method.optim_step()                                                     # :278
     losses = {k: (v.item() if isinstance(v, torch.Tensor) else v) for k, v in losses.items()}
-    if nr_rays is not None and target_nr_of_training_samples and samples_3d is not None:
-        nr_rays = dynamic_nr_rays(nr_rays, samples_3d.shape[0], target_nr_of_training_samples)
+    if nr_rays is not None and target_nr_of_training_samples and nr_samples:
+        nr_rays = dynamic_nr_rays(nr_rays, nr_samples, target_nr_of_training_samples)
     if method.lr_scheduler is not None:                                     # :306-308
         method.lr_scheduler.step()
     return losses, nr_rays
@@ -63,7 +93,8 @@ def train_step_from_reel(method, reel, nr_rays, jitter_pixels=True, nr_rays_per_
     if nr_rays_per_pixel > 1:
         gt_rgb = gt_rgb.repeat_interleave(nr_rays_per_pixel, 0)
         gt_mask = gt_mask.repeat_interleave(nr_rays_per_pixel, 0)
-    return train_step(method, rays_o, rays_d, gt_rgb, gt_mask, iter_nr, nr_rays=nr_rays, **kw)
+    return train_step(method, rays_o, rays_d, gt_rgb, gt_mask, iter_nr, nr_rays=nr_rays,
+                      is_training_masked=is_training_masked, **kw)
 
 
 class TrainingState:

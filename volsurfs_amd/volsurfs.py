@@ -161,7 +161,12 @@ def _check_pack(p, *tensors):
 
 class VolumeRendering:
     """include/volsurfs/VolumeRendering.cuh:69-97: static methods, same order of arguments."""
-    bug_compat = False   # reproduce VolumeRenderingGPU.cuh:1021 / :407 (SURVEY §7.3 item 9)
+    # True (default) = compute what the reference computes, including its two slips:
+    # integrate_with_weights_3d_backward reads the y lane of grad_result for the z lane
+    # (kernels/volsurfs/VolumeRenderingGPU.cuh:1021) and median_depth_over_rays falls back to the
+    # reference's value when no sample crosses the threshold (:407).  Opt out with
+    # `VolumeRendering.bug_compat = False` for the mathematically intended result.
+    bug_compat = True
 
     @staticmethod
     def cumprod_one_minus_alpha_to_transmittance(pack, one_minus_alpha):
@@ -236,11 +241,6 @@ class VolumeRendering:
                   weights.contiguous(), float(threshold), out, pack.get_nr_rays(),
                   bool(VolumeRendering.bug_compat), _lib.stream_ptr())
         return out
-
-    @staticmethod
-    def _todo(name):
-        raise NotImplementedError(f"VolumeRendering.{name}: used only by nerf/surf/offsets_surfs "
-                                  "(SURVEY §8f row 4), not on the VolSurfs path")
 
     @staticmethod
     def sdf2alpha(pack, samples_sdf, logistic_beta):
