@@ -297,3 +297,77 @@ def test_profiler_sections_of_the_reference():
     assert all(0 < v < 1.0 for v in t.values())
     m.profiler.reset()
     assert m.profiler.get_avg_times() == {}
+
+
+@pytest.mark.gpu
+def test_dtu_config_full_size_learned_background():
+    """BASELINE configs[3] at full size: 1600x1200 rays, K=5 shells, `bg_color=None` ->
+    NerfHash background with 32 contracted samples per ray through the packed ops
+    (volsurfs.py:686-702, utils/background.py:31-141).  Size-independent properties of the
+    full frame, then one training step (fwd + bwd + Adam) on a 65 536-ray batch."""
+    from volsurfs_amd.background import BoundingBox
+    from volsurfs_amd.camera import pinhole_rays
+    from volsurfs_amd.mesh import nested_shells
+    from volsurfs_amd.methods import VolSurfs
+    from volsurfs_amd.models import NerfHash
+    from volsurfs_amd.trainer import train_step
+    torch.manual_seed(0)
+    H, W, K = 1200, 1600, 5
+    bg = NerfHash(3, "gridhash", "spherical_harmonics")
+    m = VolSurfs(nested_shells(K=K, subdiv=6), max_rays=65536, bg_color=None, bg_model=bg,
+                 bounding_primitive=BoundingBox(1.0), nr_samples_bg=32)
+    o, d = pinhole_rays(H, W, focal=1111.1 * H / 800.0, cam_pos=(0.0, 0.0, -1.5))
+    assert o.shape[0] == 1920000
+    m.is_training = False                              # no sample jitter: renders are repeatable
+    full = m.render(o, d, chunk=65536)
+    rgb, rgb_bg, bgT = full["rgb"], full["rgb_bg"], full["bg_transmittance"]
+    assert rgb.shape == (H * W, 3) and torch.isfinite(rgb).all() and rgb.min() >= 0 and rgb.max() <= 1.001
+    miss = full["surfs_alpha"].sum((1, 2)) == 0
+    assert miss.any() and (~miss).sum() > H * W // 8
+    assert torch.equal(rgb[miss], rgb_bg[miss])        # a ray that misses every shell shows the field
+    assert (bgT[miss] == 1).all()
+    # rgb = rgb_fg + bg_T * rgb_bg in fp16 (volsurfs.py:704-708), everywhere
+    recon = (full["rgb_fg"].half() + bgT.half() * rgb_bg.half()).float()
+    assert (rgb - recon).abs().max() <= 1e-3
+    # partition of unity of the blending weights
+    tot = full["surfs_blending_weights"].sum(1) + bgT
+    assert (tot - 1).abs().max() < 4e-3
+    # the background is a function of the ray only: a second render of a slice is identical
+    again = m.render(o[:131072], d[:131072], chunk=65536)
+    assert torch.equal(again["rgb"], rgb[:131072])
+    # one training step on a 65 536-ray batch spread over the frame
+    m.init_optim()
+    idx = torch.linspace(0, H * W - 1, 65536, device="cuda").long()
+    gt = torch.rand(65536, 3, device="cuda")
+    w0 = bg.mlp_rgb.layers[0].weight.detach().clone()
+    t0 = m.bank.tables.detach().clone()
+    losses, _ = train_step(m, o[idx].contiguous(), d[idx].contiguous(), gt, iter_nr=0, is_first_iter=True)
+    assert np.isfinite(losses["loss"])
+    losses2, _ = train_step(m, o[idx].contiguous(), d[idx].contiguous(), gt, iter_nr=1)
+    assert not torch.equal(bg.mlp_rgb.layers[0].weight, w0) and not torch.equal(m.bank.tables, t0)
+    assert bg.pos_encoder.encoder.params.grad.abs().sum() > 0
+
+
+@pytest.mark.gpu
+def test_train_step_chunks_a_batch_larger_than_max_rays():
+    """the dynamic ray count grows past max_rays (trainer.py:288-304); the step then
+    runs as chunks whose gradients accumulate and equals the one-shot step of a larger bank."""
+    from volsurfs_amd.camera import pinhole_rays
+    from volsurfs_amd.trainer import train_step
+    o, d = pinhole_rays(64, 64, focal=110.0)
+    gt = torch.rand(4096, 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)) * 0.3
+    big, small = _method(max_rays=4096), _method(max_rays=1024)
+    for m in (big, small):
+        m.init_optim()
+        m.grad_scale = 4096.0
+    l1, n1 = train_step(big, o, d, gt, iter_nr=0, is_first_iter=True, nr_rays=4096,
+                        target_nr_of_training_samples=3000)
+    l2, n2 = train_step(small, o, d, gt, iter_nr=0, is_first_iter=True, nr_rays=4096,
+                        target_nr_of_training_samples=3000)
+    assert abs(l1["loss"] - l2["loss"]) < 1e-6 and n1 == n2 and n1 != 4096
+    # the gradients the optimiser saw (they stay in .grad until the next zero_grad): the same sums,
+    # accumulated chunk by chunk (fp16 gradient chain with a per-chunk rounding pattern)
+    for a, b in ((big.bank.weights.grad, small.bank.weights.grad), (big.bank.tables.grad, small.bank.tables.grad)):
+        s_ = a.abs().max().item()
+        assert s_ > 0 and (a - b).abs().max().item() <= 2e-2 * s_
+        assert torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0) > 0.9995

@@ -96,3 +96,56 @@ def test_mlp_fwd_asymmetric_weights_exact():
             ref = tcnn_like.mlp_forward(w1, w2, w3, f, C)
             base = 0 if typ == 0 else 24
             assert torch.equal(pre[a:b, base:base + C].cpu(), ref), (typ, d)
+
+
+def test_quant_table_header_is_the_generated_one():
+    """volsurfs_amd/csrc/nt_quant_table.h == tools/gen_quant_table.py's output on this machine
+    (the reference's sigmoid -> x255 -> round evaluated by torch-CPU for every fp16)."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_quant_table.py"), "--check"])
+    assert r.returncode == 0
+
+
+@pytest.mark.gpu
+def test_quantise_exhaustive():
+    """The kernel's 8-bit texel for EVERY finite fp16 network output equals the reference's
+    round(sigmoid(float(x)) * 255) (neural_texture.py:155-169, torch-CPU): the network is set
+    to the identity (x -> relu(x) - relu(-x)) and the 63 488 finite fp16 patterns are fed as
+    features."""
+    bank, face_uvs, hit_slot, hit_uv = _bank(K=1, N=30000, seed=11)
+    bank.mark_and_compact(hit_slot, hit_uv, face_uvs)
+    seg = bank.seg_start.cpu().numpy()
+    a, b = int(seg[0]), int(seg[1])
+    bits = np.arange(65536, dtype=np.uint16)
+    vals = bits.view(np.float16)
+    pat = torch.from_numpy(vals[np.isfinite(vals)].copy())
+    n = pat.numel()
+    assert n == 63488 and b - a >= n
+    with torch.no_grad():
+        bank.weights.zero_()
+        for typ, C in ((0, 3), (1, 1)):
+            w = bank.weights[bank.tex_index(0, typ, 0)]
+            w1, w2, w3 = unpack_weights(w)
+            w1[0, 0], w1[1, 0] = 1.0, -1.0
+            w2[0, 0] = w2[1, 1] = 1.0
+            w3[:C, 0], w3[:C, 1] = 1.0, -1.0
+    bank.refresh_half_params()
+    bank.encode()
+    f = bank.features_level_major()                       # [type, level, slot, 2] (a copy)
+    f.zero_()
+    f[:, 0, a:a + n, 0] = pat.cuda()
+    bank.features.copy_(f.reshape(2, 16, -1, 256, 2).permute(0, 2, 1, 3, 4))
+    texels, pre = bank.mlp(want_pre=True)
+    torch.cuda.synchronize()
+    x = pat.float()
+    q_ref = torch.round(torch.sigmoid(x) * 255.0).to(torch.uint8)
+    for base, C in ((0, 3), (24, 1)):
+        for c in range(C):
+            got_pre = pre[a:a + n, base + c].cpu()
+            assert torch.equal(got_pre.float(), x), "identity network must reproduce its input"
+            q = texels[a:a + n, base + c].cpu()
+            bad = (q != q_ref).nonzero()[:, 0]
+            assert bad.numel() == 0, [(float(x[i]), int(q[i]), int(q_ref[i])) for i in bad[:10]]

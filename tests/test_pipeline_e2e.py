@@ -92,11 +92,12 @@ def test_step_with_gradient_callbacks_matches_plain_step():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("K_,res,n_rays", [(5, 800, 640000),             # BASELINE configs[1] (the bench workload)
-                                           (7, (1080, 1920), 2073600),   # configs[4]: K=7 shells at 1080p
-                                           (5, (1200, 1600), 1920000)])  # configs[3]: 1600x1200 frame
-def test_full_size_frame_properties(K_, res, n_rays):
-    """BASELINE configurations at their full sizes (subdiv-6 shells, full-resolution textures):
+@pytest.mark.parametrize("K_,res,n_rays,subdiv", [
+    (5, 800, 640000, 6),             # BASELINE configs[1] (the bench workload)
+    (7, (1080, 1920), 2073600, 8),   # configs[4]: K=7 HIGH-POLY shells (subdiv 8: 1 310 720 triangles each) at 1080p
+    (5, (1200, 1600), 1920000, 6)])  # configs[3]'s frame with a constant background (learned background: test_methods.py)
+def test_full_size_frame_properties(K_, res, n_rays, subdiv):
+    """BASELINE configurations at their full sizes (SURVEY §8d geometry, full-resolution textures):
     size-independent properties of the whole step.
       * forward is bit-deterministic; HIP-graph replay equals the eager step
       * every ray that misses all shells shows the background, hit rays do not exceed [0, 1]
@@ -108,9 +109,9 @@ def test_full_size_frame_properties(K_, res, n_rays):
         grad_scale: same gradients after unscaling)"""
     from volsurfs_amd.composite import composite_dense
     from volsurfs_amd.pipeline import KShellPipeline
-    pipe = KShellPipeline.synthetic(K=K_, res=res)
+    pipe = KShellPipeline.synthetic(K=K_, res=res, subdiv=subdiv)
     N, K = pipe.nr_rays, pipe.K
-    assert N == n_rays and K == K_
+    assert N == n_rays and K == K_ and pipe.tracer.mesh_nr_tris[0] == 20 * 4 ** subdiv
     a = pipe.step().clone()
     gw1, gt1 = pipe.bank.weights.grad.clone(), pipe.bank.tables.grad.clone()
     b = pipe.step().clone()

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include "nt_common.h"
+#include "nt_quant_table.h"
 
 namespace {
 
@@ -156,8 +157,10 @@ __global__ __launch_bounds__(MLP_BLOCK, MLP_FWD_WGS_PER_CU) void nt_mlp_fwd_kern
     const unsigned* __restrict__ features, const int* __restrict__ seg_start,
     unsigned* __restrict__ texels, _Float16* __restrict__ pre_out) {
   __shared__ half8_t s_frag[16 * 64];
+  __shared__ unsigned s_qt[257];      // thresholds of the 8-bit quantisation (nt_quant_table.h)
   const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
   const int wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 257; i += MLP_BLOCK) s_qt[i] = NT_QUANT_THR[i];
   NT_SPAN_MARK(0, 0);
   nt_for_each_piece<32>(plan, seg_start, 1, MLP_FWD_RUN_COST,
                         [&](int, int tex, int first, int last, int, int) {
@@ -208,8 +211,13 @@ __global__ __launch_bounds__(MLP_BLOCK, MLP_FWD_WGS_PER_CU) void nt_mlp_fwd_kern
           const _Float16 o_h = (_Float16)acc3[4 * g + i];
           if (pre_out && row0 + i < ti.channels)
             pre_out[(long long)slot * 32 + pre_base + row0 + i] = o_h;
-          float q = rintf(sigmoidf_((float)o_h) * 255.0f);
-          unsigned qb = row0 + i < ti.channels ? (unsigned)q : 0u;
+          // fast estimate (within one step of the reference's round(sigmoid(x) * 255)), then the
+          // exact step function: compare x with the two neighbouring thresholds of the table
+          unsigned q = (unsigned)rintf(sigmoidf_((float)o_h) * 255.0f);
+          const unsigned ob = __builtin_bit_cast(unsigned short, o_h);
+          const unsigned key = (ob & 0x8000u) ? (~ob & 0xffffu) : (ob | 0x8000u);
+          q = q - (key < s_qt[q] ? 1u : 0u) + (key >= s_qt[q + 1] ? 1u : 0u);
+          unsigned qb = row0 + i < ti.channels ? q : 0u;
           packed |= qb << (8 * i);
         }
         // (measured: staging the tile's quads through LDS and storing them in memory order,
