@@ -324,6 +324,32 @@ int vsa_grid_encode_bwd(const vsa_grid_plan* plan, const float* x, const float* 
 /* out [nr_dirs][(degree+1)^2]: SH basis of each direction, degree 0..4. */
 int vsa_sh_encode(const float* dirs, int nr_dirs, int degree, float* out, void* stream);
 
+/* A5  Permutohedral-lattice hash encoding: `PermutoHashEncoder`
+ * (volsurfs_py/encodings/permutohash.py:28-37, 68-96) = permutohedral_encoding.PermutoEncoding
+ * (un-vendored fork, .gitmodules:7-9; published algorithm restated, parity unpinned).
+ * lattice_values [n_levels][capacity][2] f32; x [N][pos_dim] f32 (the wrapper maps the bounding
+ * box to [0,1] first); window [n_levels] f32 (Coarse2Fine) or NULL (= ones);
+ * out[b*out_stride + 2*l + f] (out_stride >= 2*n_levels, even: the caller may own a wider row
+ * that also holds the concatenated points).  scale_factor[l][i] = 1 / (sigma_l * sqrt((i+1)(i+2))),
+ * sigma_l = the level's scale (np.geomspace(coarsest, finest, n_levels), permutohash.py:27). */
+typedef struct vsa_permuto_plan {
+  int32_t pos_dim;     /* 2..4 */
+  int32_t n_levels;    /* <= VSA_GRID_MAX_LEVELS */
+  int32_t n_features;  /* 2 */
+  int32_t capacity;    /* entries per level (2^18) */
+  float scale_factor[VSA_GRID_MAX_LEVELS][4];
+  float random_shift[VSA_GRID_MAX_LEVELS][4];
+} vsa_permuto_plan;
+
+int vsa_permuto_encode_fwd(const vsa_permuto_plan* plan, const float* lattice_values,
+                           const float* x, const float* window, int nr_points, float* out,
+                           int out_stride, void* stream);
+/* grad_values (fp32, same shape as lattice_values) += transpose of the interpolation applied to
+ * g_out[b*g_stride + 2*l + f].  Positions carry no gradient on this path (hit points). */
+int vsa_permuto_encode_bwd(const vsa_permuto_plan* plan, const float* x, const float* window,
+                           const float* g_out, int g_stride, int nr_points, float* grad_values,
+                           void* stream);
+
 /* ------------------------------------------------------------------------
  * A8 / A9 / A11  Packed (ragged) per-ray sample ops of the background path:
  * what render_contracted_bg (volsurfs_py/utils/background.py:31-141) calls in the

@@ -371,3 +371,71 @@ def test_train_step_chunks_a_batch_larger_than_max_rays():
         s_ = a.abs().max().item()
         assert s_ > 0 and (a - b).abs().max().item() <= 2e-2 * s_
         assert torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0) > 0.9995
+
+
+@pytest.mark.gpu
+def test_permutohash_legacy_branch_matches_oracle_and_trains():
+    """BASELINE configs[2]'s appearance: `using_neural_textures=False`,
+    `rgb_pos_encoder_type="permutohash"` (24 levels x 2, capacity 2^18) + SH-3 view encoding ->
+    MLP [128,128,64] -> sigmoid (models/rgb.py:104-149), per shell, rgb + alpha models."""
+    from oracle import composite as OC
+    from oracle import legacy_models as OL
+    from oracle import permuto as OP
+    from oracle.neural_texture import sh_basis_values
+    from volsurfs_amd.camera import pinhole_rays
+    from volsurfs_amd.mesh import nested_shells
+    from volsurfs_amd.methods import VolSurfs
+    K = 2
+    m = VolSurfs(nested_shells(K=K, subdiv=3), max_rays=4096, using_neural_textures=False,
+                 rgb_pos_encoder_type="permutohash", rgb_mlp_layers_dims=(128, 128, 64), bb_sides=1.0)
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for mod in m.models.values():
+            p = mod.pos_encoder.encoder.lattice_values
+            assert tuple(p.shape) == (24, 1 << 18, 2) and mod.pos_encoder.output_dim == 50
+            assert mod.mlp.layers[0].in_features == 50 + 16
+            p.copy_((torch.rand(p.shape, generator=g) * 2 - 1).cuda())
+    o, d = pinhole_rays(40, 40, focal=70.0)
+    rt = m.render_rays(o, d, iter_nr=None)["renders"]["ray_traced"]
+    hit_t, hit_slot, _ = m.raytracer.trace_all(o, d)
+    N = o.shape[0]
+    s_rgb, s_a = torch.zeros(N, K, 3), torch.zeros(N, K)
+    for i in range(K):
+        hits = (hit_slot[i] >= 0).cpu()
+        tri = m.raytracer.tris[hit_slot[i][hit_slot[i] >= 0].long()].cpu()
+        nrm = torch.nn.functional.normalize(torch.cross(tri[:, 4:7], tri[:, 8:11], dim=1), dim=1)
+        dd = d.cpu()[hits]
+        pts = o.cpu()[hits] + hit_t[i].cpu()[hits][:, None] * dd
+        outs = []
+        for key in (f"rgb_{i}", f"alpha_{i}"):
+            mod = m.models[key]
+            layers = [(l.weight.detach().cpu(), l.bias.detach().cpu()) for l in mod.mlp.layers
+                      if isinstance(l, torch.nn.Linear)]
+            enc, _ = OP.permuto_hash_encoder(mod.pos_encoder.encoder.lattice_values.detach().cpu().numpy(),
+                                             pts.numpy(), mod.pos_encoder.encoder.random_shift_per_level.cpu().numpy(),
+                                             bb_sides=1.0)
+            x = torch.cat([torch.from_numpy(enc), sh_basis_values(dd, 3)], 1)
+            outs.append(torch.sigmoid(OL.mlp_forward(layers, x)))
+        dot = torch.sum(-dd * nrm, dim=1).clamp(0.0, 1.0)
+        s_rgb[hits, i] = outs[0]
+        s_a[hits, i] = outs[1][:, 0] * (torch.sigmoid(10.0 * dot) * 2.0 - 1.0)
+    ref = OC.composite_dense_fwd(s_rgb.numpy(), s_a.numpy(), np.ones((1, 3), np.float32))["rgb"]
+    err = np.abs(rt["rgb"].detach().cpu().numpy() - ref)
+    assert err.max() < 2e-3 and np.median(err) < 1e-4, (err.max(), np.median(err))   # fp16 composite
+    # full-frame evaluation of the legacy configuration (ADVICE r1: render() crashed on None keys)
+    full = m.render(o, d, chunk=1024)
+    assert full["surfs_uvs"] is None and torch.allclose(full["rgb"], rt["rgb"].detach(), atol=1e-6)
+    ss = m.render(torch.cat([o, o]).reshape(2, -1, 3).transpose(0, 1).reshape(-1, 3).contiguous(),
+                  torch.cat([d, d]).reshape(2, -1, 3).transpose(0, 1).reshape(-1, 3).contiguous(),
+                  nr_rays_per_pixel=2, chunk=2048)
+    assert ss["surfs_uvs"] is None and torch.allclose(ss["rgb"], full["rgb"], atol=1e-6)
+    opt = m.init_optim()
+    gt = torch.rand(N, 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)) * 0.2
+    losses = []
+    for it in range(8):
+        opt.zero_grad()
+        l, _, _ = m(o, d, gt, None, it)
+        l["loss"].backward()
+        m.optim_step()
+        losses.append(l["loss"].item())
+    assert losses[-1] < losses[0], losses

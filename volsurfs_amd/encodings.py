@@ -6,8 +6,10 @@ same class names, constructor arguments, call signatures and `output_dim`.
   ("Grid"/"Hash", fp32); here the grid is `vsa_grid_encode_fwd/bwd` (csrc/grid_encode.hip).
 * SHEncoder (encodings/sphericalharmonics.py:36-229): `__call__` = `vsa_sh_encode`.
 * FrequencyEncoder / IdentityEncoder: elementwise torch ops, as in the reference.
-* PermutoHashEncoder: needs the un-vendored `permutohedral_encoding` fork; not
-  built — `get_encoder("permutohash")` raises NotImplementedError naming this.
+* PermutoHashEncoder (encodings/permutohash.py:10-99): the reference wraps the un-vendored
+  `permutohedral_encoding` fork (parity unpinned); `PermutoEncoding` here is the
+  published permutohedral-lattice encoding on `vsa_permuto_encode_fwd/bwd`
+  (csrc/permuto_encode.hip), restated in oracle/permuto.py.
 """
 import ctypes
 import math
@@ -206,6 +208,160 @@ class GridHashEncoder(Encoder):
         pass
 
 
+class PermutoPlan(ctypes.Structure):
+    """Mirror of `vsa_permuto_plan` (include/volsurfs_hip.h)."""
+    _fields_ = [
+        ("pos_dim", ctypes.c_int32), ("n_levels", ctypes.c_int32),
+        ("n_features", ctypes.c_int32), ("capacity", ctypes.c_int32),
+        ("scale_factor", (ctypes.c_float * 4) * GRID_MAX_LEVELS),
+        ("random_shift", (ctypes.c_float * 4) * GRID_MAX_LEVELS),
+    ]
+
+
+class _PermutoEncode(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, values, x, window, enc, extra):
+        """values [L, capacity, 2]; x [B, D] in [0,1]; window [L] or None.  Returns
+        [B, 2L + extra]: the encoding in the first 2L columns of a row that the caller fills up
+        (concatenated points) — written in place by the kernel, no torch.cat copy."""
+        plan = enc.plan
+        x = _lib.check_f32(x.contiguous(), x.shape[0], plan.pos_dim)
+        width = 2 * plan.n_levels + extra
+        stride = width + (width & 1)                  # float2 stores: even row stride
+        buf = torch.empty(x.shape[0], stride, device=x.device)
+        _lib.call("vsa_permuto_encode_fwd", ctypes.byref(plan), values, x, window, x.shape[0], buf,
+                  stride, _lib.stream_ptr())
+        if extra:                       # concatenated points (no gradient path: hit points)
+            buf[:, 2 * plan.n_levels:width] = x * enc.concat_points_scaling
+        ctx.save_for_backward(x, window)
+        ctx.plan, ctx.shape = plan, values.shape
+        return buf[:, :width]
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x, window = ctx.saved_tensors
+        g_values = torch.zeros(ctx.shape, device=x.device)
+        g_out = g_out.contiguous()
+        _lib.call("vsa_permuto_encode_bwd", ctypes.byref(ctx.plan), x, window, g_out,
+                  g_out.shape[1], x.shape[0], g_values, _lib.stream_ptr())
+        return g_values, None, None, None, None      # positions carry no gradient on this path
+
+
+class PermutoEncoding(torch.nn.Module):
+    """`permutohedral_encoding.PermutoEncoding(pos_dim, capacity, nr_levels, nr_feat_per_level,
+    scale_list, appply_random_shift_per_level=, concat_points=, concat_points_scaling=)` shaped
+    (permutohash.py:28-37): callable `(points, window)`, `.output_dims()`, `.reset()`.
+    Parameters: `lattice_values` [nr_levels, capacity, nr_feat] ~ N(0, 1e-5^2); buffer
+    `random_shift_per_level` [nr_levels, pos_dim] ~ 10 N(0,1) (zeros when the shift is off)."""
+
+    def __init__(self, pos_dim, capacity, nr_levels, nr_feat_per_level, scale_list,
+                 appply_random_shift_per_level=True, concat_points=False,
+                 concat_points_scaling=1.0, init_scale=1e-5, seed=0, device="cuda"):
+        super().__init__()
+        if nr_feat_per_level != 2 or not 2 <= pos_dim <= 4 or nr_levels > GRID_MAX_LEVELS:
+            raise _lib.VolsurfsHipError("PermutoEncoding: 2 features per level, pos_dim 2..4, "
+                                        f"<= {GRID_MAX_LEVELS} levels")
+        if len(scale_list) != nr_levels:
+            raise _lib.VolsurfsHipError("scale_list must have one entry per level")
+        self.pos_dim, self.capacity, self.nr_levels = pos_dim, int(capacity), nr_levels
+        self.nr_feat_per_level = nr_feat_per_level
+        self.scale_list = np.asarray(scale_list, np.float64)
+        self.concat_points, self.concat_points_scaling = concat_points, concat_points_scaling
+        self.init_scale, self._seed = init_scale, seed
+        g = torch.Generator().manual_seed(seed)
+        self.lattice_values = torch.nn.Parameter(
+            (torch.randn(nr_levels, self.capacity, nr_feat_per_level, generator=g) * init_scale).to(device))
+        shift = torch.randn(nr_levels, pos_dim, generator=g) * 10.0 if appply_random_shift_per_level \
+            else torch.zeros(nr_levels, pos_dim)
+        self.register_buffer("random_shift_per_level", shift.to(device))
+        self._plan, self._plan_key = None, None
+
+    @property
+    def plan(self):
+        """The kernel's view of the geometry; rebuilt if the shift buffer was replaced
+        (load_state_dict)."""
+        key = self.random_shift_per_level._version, self.random_shift_per_level.data_ptr()
+        if self._plan is None or key != self._plan_key:
+            p = PermutoPlan()
+            p.pos_dim, p.n_levels, p.n_features, p.capacity = self.pos_dim, self.nr_levels, 2, self.capacity
+            shift = self.random_shift_per_level.detach().cpu().numpy()
+            for l in range(self.nr_levels):
+                for i in range(self.pos_dim):
+                    p.scale_factor[l][i] = float(np.float32(
+                        1.0 / math.sqrt((i + 1) * (i + 2)) / self.scale_list[l]))
+                    p.random_shift[l][i] = float(shift[l, i])
+            self._plan, self._plan_key = p, key
+        return self._plan
+
+    def output_dims(self):
+        return self.nr_levels * self.nr_feat_per_level + (self.pos_dim if self.concat_points else 0)
+
+    def forward(self, positions, anneal_window=None):
+        extra = self.pos_dim if self.concat_points else 0
+        if anneal_window is not None:
+            anneal_window = anneal_window.to(positions.device, torch.float32).contiguous().view(-1)
+        return _PermutoEncode.apply(self.lattice_values, positions.float(), anneal_window, self, extra)
+
+    @torch.no_grad()
+    def reset(self):
+        g = torch.Generator().manual_seed(self._seed + 1)
+        self.lattice_values.copy_((torch.randn(self.lattice_values.shape, generator=g) * self.init_scale))
+
+
+class PermutoHashEncoder(Encoder):
+    """encodings/permutohash.py:10-99: 24 levels x 2 features, capacity 2^18, sigma from 1.0 to
+    1e-4 (np.geomspace), random shift per level, coarse-to-fine window, bounding-box
+    normalisation, concatenated points with the LAST channel dropped (`remove_last_element`)."""
+
+    def __init__(self, input_dim=3, nr_levels=24, log2_hashmap_size=18, nr_feat_per_level=2,
+                 coarsest_scale=1.0, finest_scale=0.0001, nr_iters_for_c2f=0,
+                 appply_random_shift_per_level=True, concat_points=True, concat_points_scaling=1.0,
+                 remove_last_element=True, bb_sides=2.0, device="cuda"):
+        capacity = pow(2, log2_hashmap_size)
+        scale_list = np.geomspace(coarsest_scale, finest_scale, num=nr_levels)
+        encoder = PermutoEncoding(input_dim, capacity, nr_levels, nr_feat_per_level, scale_list,
+                                  appply_random_shift_per_level=appply_random_shift_per_level,
+                                  concat_points=concat_points,
+                                  concat_points_scaling=concat_points_scaling, device=device)
+        super().__init__(input_dim, encoder.output_dims() - (1 if remove_last_element else 0))
+        self.remove_last_element = remove_last_element
+        self.encoder = encoder
+        self.capacity, self.nr_levels, self.nr_feat_per_level = capacity, nr_levels, nr_feat_per_level
+        self.scale_list = scale_list
+        self.appply_random_shift_per_level = appply_random_shift_per_level
+        self.concat_points, self.concat_points_scaling = concat_points, concat_points_scaling
+        self.bb_sides = bb_sides
+        if self.bb_sides is not None:
+            if isinstance(self.bb_sides, float):
+                self.bb_sides = np.array([self.bb_sides] * input_dim)
+            if isinstance(self.bb_sides, np.ndarray):
+                self.bb_sides = torch.tensor(self.bb_sides, dtype=torch.float32)
+            self.bb_sides = self.bb_sides.to(device)
+        self.c2f = Coarse2Fine(nr_levels)
+        self.nr_iters_for_c2f = nr_iters_for_c2f
+
+    def forward(self, points, iter_nr=None, **kwargs):
+        if iter_nr is None or iter_nr < 0:
+            t = 1.0
+        else:
+            t = map_range_val(iter_nr, 0.0, self.nr_iters_for_c2f, 0.3, 1.0)
+        window = self.c2f(t)
+        if self.bb_sides is not None:
+            out_of_bounds = torch.logical_or((points <= -self.bb_sides / 2).any(dim=1),
+                                             (points >= self.bb_sides / 2).any(dim=1))
+            points = points * (1 / (self.bb_sides / 2))
+            points = (points + 1) / 2
+        else:
+            out_of_bounds = None
+        enc = self.encoder(points, window.view(-1))
+        if self.remove_last_element:
+            enc = enc[:, :-1]
+        return enc, out_of_bounds
+
+    def reset(self):
+        self.encoder.reset()
+
+
 def get_encoder(encoding, **kwargs):
     """utils/encoder.py:8-48."""
     if encoding == "none":
@@ -219,8 +375,8 @@ def get_encoder(encoding, **kwargs):
                                nr_iters_for_c2f=kwargs["nr_iters_for_c2f"],
                                bb_sides=kwargs.get("bb_sides"))
     if encoding == "permutohash":
-        raise NotImplementedError(
-            "PermutoHashEncoder wraps the un-vendored permutohedral_encoding fork "
-            "(SURVEY G5, §8c: parity unpinnable); use pos_encoder_type='gridhash'")
+        return PermutoHashEncoder(input_dim=kwargs["input_dim"], nr_levels=kwargs["nr_levels"],
+                                  nr_iters_for_c2f=kwargs["nr_iters_for_c2f"],
+                                  bb_sides=kwargs.get("bb_sides"))
     raise NotImplementedError(
         "Unknown encoding mode, choose from [None, frequency, spherical_harmonics, permutohash, gridhash]")
