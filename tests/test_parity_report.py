@@ -255,27 +255,38 @@ def test_order_matched_rgb_and_f32_gradients(K, subdiv, res):
            "rgb_abs_err": _pcts(e), "rgb_frac_over_1e-4": over,
            "rgb_cause_of_any_excess": "an fp32 difference <= 2e-6 in a per-shell colour flips its fp16 "
                                       "cast in the composite (1 ulp = 4.9e-4 in [0.5,1))"}
-    # north_star: 1e-4 on RGB.  Holds on all but the fp16-flip pixels; those move by <= 2 fp16 ulps
-    assert over < 0.02 and e.max() <= 1.5e-3
+    # north_star: 1e-4 on RGB, EVERY pixel (measured on MI355X: bit-identical, max error 0.0 — the
+    # <= 2.4e-7 differences of the per-shell colours never straddle an fp16 rounding boundary in
+    # these frames; profiles/r02/parity_report.json)
+    assert over == 0.0 and e.max() <= 1e-4
 
     # ---- C: gradients, fp32 oracle at the kernel's texels vs the kernel's fp16 chain
     loss = (surfs_rgb * g_c).sum() + (surfs_alpha * g_a).sum()
     loss.backward()
     rel_w, rel_t, worst = [], [], 0.0
+    lvl_worst = np.zeros(geom.n_levels)
     for x, (table, w1, w2, w3) in leaves.items():
         ref_w = torch.cat([w1.grad.flatten(), w2.grad.flatten(), w3.grad.flatten()])
         rw = ((gw[x] - ref_w).abs() / ref_w.abs().max()).numpy()
         rt = ((gt[x] - table.grad).abs() / table.grad.abs().max()).flatten().numpy()
         rel_w.append(rw)
         rel_t.append(rt)
+        rt2 = rt.reshape(-1, 2).max(1)
+        for l in range(geom.n_levels):
+            lvl_worst[l] = max(lvl_worst[l], rt2[geom.offset[l]:geom.offset[l + 1]].max())
         worst = max(worst, float(rw.max()), float(rt.max()))
         cw = torch.nn.functional.cosine_similarity(gw[x], ref_w, dim=0)
         ct = torch.nn.functional.cosine_similarity(gt[x].flatten(), table.grad.flatten(), dim=0)
         assert cw > 0.9999 and ct > 0.9999, (x, float(cw), float(ct))
     rep["grad_weights_err_rel_to_tensor_max"] = _pcts(np.concatenate(rel_w))
     rep["grad_tables_err_rel_to_tensor_max"] = _pcts(np.concatenate(rel_t))
+    rep["grad_tables_worst_err_per_level"] = [float(x) for x in lvl_worst]
     _emit(f"order_matched_K{K}_res{res}", rep)
-    # north_star: 1e-3 on grads (relative to each tensor's largest gradient), every element
-    assert rep["grad_weights_err_rel_to_tensor_max"]["p99"] <= 1e-3
-    assert rep["grad_tables_err_rel_to_tensor_max"]["p99"] <= 1e-3
-    assert worst <= 5e-3
+    # north_star: 1e-3 on grads, relative to each tensor's largest gradient: every element of every
+    # MLP weight gradient; every hash-table entry but a handful of outliers (measured: p99 1.7e-5,
+    # max 4.8e-3 — the 16-bit fixed-point / f16 steps of the table accumulation on entries where
+    # many texels collide), bounded here
+    assert rep["grad_weights_err_rel_to_tensor_max"]["max"] <= 1e-3
+    assert rep["grad_tables_err_rel_to_tensor_max"]["p99"] <= 1e-4
+    assert float((np.concatenate(rel_t) > 1e-3).mean()) < 1e-5
+    assert worst <= 1e-2
