@@ -29,8 +29,16 @@ MFMA_F16_PEAK_TFLOPS = 2500.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None, help="default 20 (frame) / 500 (train*) / 20 (dtu)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 5 (frame, dtu) / 100 (train*)")
+    ap.add_argument("--workload", default="frame", choices=["frame", "train", "train-permuto", "dtu"],
+                    help="frame (default): the headline metric, fwd+bwd of one 800x800 frame.  train: the "
+                         "reference's training loop (TensorReel batches, dynamic ray count -> 49 152 hits, "
+                         "fwd+bwd+Adam) on the neural-texture appearance.  train-permuto: BASELINE configs[2] "
+                         "as written (legacy permutohash + MLP appearance).  dtu: configs[3]'s learned "
+                         "background (NerfHash, 32 samples per ray) fwd+bwd+Adam on 65 536-ray batches")
+    ap.add_argument("--target-hits", type=int, default=49152)
+    ap.add_argument("--views", type=int, default=50)
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--shells", type=int, default=5)
     ap.add_argument("--subdiv", type=int, default=6)
@@ -44,7 +52,13 @@ def parse():
                     help="functional tests of the multi-rank path on one GPU: gloo + --single-device")
     ap.add_argument("--single-device", action="store_true",
                     help="all ranks use cuda:0 (testing only; RCCL refuses two ranks on one GPU)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    training = args.workload.startswith("train")
+    if args.steps is None:
+        args.steps = 500 if training else 20
+    if args.warmup is None:
+        args.warmup = 100 if training else 5
+    return args
 
 
 def cpu_baseline(pipe, sample_rays):
@@ -76,6 +90,104 @@ def cpu_baseline(pipe, sample_rays):
                       f"composite fwd+bwd (oracle/composite.py); {dt:.1f} s"}
 
 
+def synthetic_reel(n_views, res, device, seed=42):
+    """`n_views` cameras on a sphere of radius 1.5 around the shells (NeRF-synthetic intrinsics),
+    uniform-random ground-truth images: the data a `TensorReel` holds in HBM (trainer.py:176-190)."""
+    from volsurfs_amd.camera import Camera, TensorReel
+    g = torch.Generator().manual_seed(seed)
+    cams = []
+    for i in range(n_views):
+        z = 1.0 - 2.0 * (i + 0.5) / n_views                   # spiral over the sphere
+        r, phi = (1.0 - z * z) ** 0.5, i * 2.399963
+        eye = (1.5 * r * float(np.cos(phi)), 1.5 * z, 1.5 * r * float(np.sin(phi)))
+        cams.append(Camera.look_at(eye, focal=1111.1 * res / 800.0, height=res, width=res, device=device))
+    rgbs = torch.rand(n_views, res, res, 3, generator=g)
+    return TensorReel(cams, rgbs, device=device)
+
+
+def run_train(args, world, rank, dev, dist):
+    """The reference's training loop (trainer.py:110-308) at config-3 shape: batches drawn from a
+    TensorReel, dynamic ray count steering the hit count to --target-hits, forward + L1 + backward
+    + fused Adam + scheduler per iteration; `--warmup` untimed iterations, then `--steps` timed."""
+    from volsurfs_amd.mesh import nested_shells
+    from volsurfs_amd.methods import VolSurfs
+    from volsurfs_amd.trainer import train_step_from_reel
+    legacy = args.workload == "train-permuto"
+    meshes = nested_shells(K=args.shells, subdiv=args.subdiv, device=dev)
+    max_rays = 1 << 17
+    kw = dict(using_neural_textures=False, rgb_pos_encoder_type="permutohash",
+              rgb_mlp_layers_dims=(128, 128, 64)) if legacy else {}
+    method = VolSurfs(meshes, max_rays=max_rays, nr_warmup_iters=500, seed=42 + rank, **kw)
+    method.init_optim()
+    reel = synthetic_reel(args.views, args.res, dev, seed=42 + rank)
+    target = args.target_hits // world               # each rank draws its share of the global batch
+    state = {"nr_rays": 512, "it": 0, "rays": 0, "hits": 0}
+
+    def one(count):
+        n = state["nr_rays"]
+        method.grad_scale = float(n)                 # mean-L1 over n rays: no device read-back for the scale
+        losses, nxt = train_step_from_reel(method, reel, n, jitter_pixels=True, iter_nr=state["it"],
+                                           is_first_iter=state["it"] == 0,
+                                           target_nr_of_training_samples=target, world=world)
+        if count:
+            state["rays"] += n
+            state["hits"] += int(getattr(method, "last_nr_samples", 0))
+        state["nr_rays"] = max(64, min(int(nxt), 4 * max_rays))
+        state["it"] += 1
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        one(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one(True)
+    barrier()
+    dt = time.perf_counter() - t0
+    # fixed cost per iteration: the same loop on batches of 64 rays (launches, host syncs, the
+    # mark / compact scan of the texel domains, LDS staging of the level tables, Adam over all
+    # parameters) — what does not shrink with the batch
+    keep = state["nr_rays"]
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(50):
+        state["nr_rays"] = 64
+        one(False)
+    barrier()
+    fixed_ms = (time.perf_counter() - t1) / 50 * 1e3
+    state["nr_rays"] = keep
+    if dist is not None:
+        t = torch.tensor([dt, float(state["rays"]), float(state["hits"])], device=dev, dtype=torch.float64)
+        dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
+        dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
+        dt, state["rays"], state["hits"] = t[0].item(), t[1].item(), t[2].item()
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        nparams = sum(p.numel() for g in method.optimizer.param_groups for p in g["params"])
+        out = {
+            "metric": "training iterations/s (fwd+bwd+Adam, dynamic batch)", "value": args.steps / dt,
+            "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 master / f16 compute" if not legacy else "f32", "data": "synthetic",
+            "Mrays/s": state["rays"] / dt / 1e6, "Mhits/s": state["hits"] / dt / 1e6,
+            "rays_per_iter": state["rays"] / args.steps, "hits_per_iter": state["hits"] / args.steps,
+            "fixed_ms_per_iter": fixed_ms, "fixed_share": fixed_ms / ms,
+            "config": {"workload": ("BASELINE configs[2]: legacy permutohash (24x2, 2^18) + MLP [128,128,64] appearance"
+                                    if legacy else "SH neural-texture appearance (configs[1]'s model)")
+                       + f", K={args.shells} subdiv-{args.subdiv} shells, {args.views} views of {args.res}x{args.res}"
+                         f" in a TensorReel, dynamic ray count -> {args.target_hits} hits per iteration, "
+                         "L1 + FusedAdam(0.9, 0.99, 1e-15) + warm-up 500, iterations "
+                         f"{args.warmup}..{args.warmup + args.steps}",
+                       "parameters": nparams, "parallelism": f"data-parallel x{world}"},
+        }
+        print(json.dumps(out))
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -94,6 +206,11 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", dev_index)
     torch.manual_seed(42 + rank)
+    if args.workload in ("train", "train-permuto"):
+        run_train(args, world, rank, dev, dist)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     from volsurfs_amd.pipeline import KShellPipeline
     pipe = KShellPipeline.synthetic(K=args.shells, subdiv=args.subdiv, res=args.res, device=dev,

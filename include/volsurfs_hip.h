@@ -324,6 +324,30 @@ int vsa_grid_encode_bwd(const vsa_grid_plan* plan, const float* x, const float* 
 /* out [nr_dirs][(degree+1)^2]: SH basis of each direction, degree 0..4. */
 int vsa_sh_encode(const float* dirs, int nr_dirs, int degree, float* out, void* stream);
 
+/* A13  Fused multi-tensor Adam step: apex.optimizers.FusedAdam(betas (0.9, 0.99), eps 1e-15,
+ * weight_decay 0) of volsurfs_py/methods/base_method.py:87-94, stepped at trainer.py:278 (the
+ * same update as torch.optim.Adam).  One launch for all parameter tensors:
+ *   tensors_dev [T] descriptors in DEVICE memory (param / grad / exp_avg / exp_avg_sq: fp32, n
+ *   elements, 16-byte aligned; param_f16: optional f16 compute copy refreshed from the new
+ *   parameter, or NULL);  chunks_dev [nr_chunks][2] int32 in device memory = (tensor index,
+ *   chunk index within the tensor), one workgroup per chunk of vsa_adam_chunk_elems() elements.
+ *   step = 1 for the first update (bias correction 1 - beta^step); grad_scale multiplies the
+ *   gradient as it is read (1 = as is); zero_grads != 0 clears the gradient after reading it
+ *   (the next iteration's zero_grad, trainer.py:118). */
+typedef struct vsa_adam_tensor {
+  float* param;
+  float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  void* param_f16; /* _Float16* or NULL */
+  int64_t n;
+} vsa_adam_tensor;
+
+int vsa_adam_chunk_elems(void);
+int vsa_adam_step(const vsa_adam_tensor* tensors_dev, const int32_t* chunks_dev, int nr_chunks,
+                  float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                  int zero_grads, void* stream);
+
 /* A5  Permutohedral-lattice hash encoding: `PermutoHashEncoder`
  * (volsurfs_py/encodings/permutohash.py:28-37, 68-96) = permutohedral_encoding.PermutoEncoding
  * (un-vendored fork, .gitmodules:7-9; published algorithm restated, parity unpinned).

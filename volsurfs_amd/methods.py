@@ -45,9 +45,13 @@ class _ShadeStage(torch.autograd.Function):
             raise _lib.VolsurfsHipError(
                 "backward of a render_rays call whose per-frame texel state was overwritten by a "
                 "later render_rays: call backward before rendering again")
-        gt_prev, gw_prev = bank.tables.grad, bank.weights.grad
-        bank.tables.grad = torch.zeros_like(bank.tables)
-        bank.weights.grad = torch.zeros_like(bank.weights)
+        # The kernels ACCUMULATE into bank.tables.grad / bank.weights.grad (autograd semantics), so
+        # the gradients are written straight into the persistent .grad buffers and None is returned
+        # for the two parameters: no 113 MB temporary, no second pass adding it to .grad.
+        bank._ensure_grads()
+        opt = getattr(method, "optimizer", None)
+        if hasattr(opt, "mark_grads_dirty"):
+            opt.mark_grads_dirty()
         # scale of the fp16 gradient chain (tcnn's loss scale).  By default a power of two that
         # brings the largest incoming per-ray gradient to 4: whatever the loss (mean- or
         # sum-reduced, any batch size) the chain neither underflows nor overflows in f16.  One
@@ -59,9 +63,7 @@ class _ShadeStage(torch.autograd.Function):
             scale = 2.0 ** min(max(math.floor(math.log2(4.0 / gmax)), -24), 40) if gmax > 0 else 1.0
         bank.backward(hit_slot, tex_uv, rays_d, method.raytracer.tris, g_rgb.contiguous(),
                       g_alpha.contiguous(), scale, act)
-        g_t, g_w = bank.tables.grad, bank.weights.grad
-        bank.tables.grad, bank.weights.grad = gt_prev, gw_prev    # autograd accumulates itself
-        return g_t, g_w, None, None, None, None
+        return None, None, None, None, None, None
 
 
 class VolSurfs(torch.nn.Module):
@@ -154,20 +156,25 @@ class VolSurfs(torch.nn.Module):
     # -- optimiser: apex FusedAdam(betas (0.9, 0.99), eps 1e-15, wd 0) of
     # base_method.py:87-94 == Adam with the same hyper-parameters
     def init_optim(self):
-        params = [self.bank.tables, self.bank.weights] if self.bank is not None else \
-            list(self.models.parameters())
+        from .optim import FusedAdam
+        half = {}
+        if self.bank is not None:
+            params = [self.bank.tables, self.bank.weights]
+            half = {self.bank.tables: self.bank.tables_h, self.bank.weights: self.bank.weights_h}
+        else:
+            params = list(self.models.parameters())
         if isinstance(self.bg_model, torch.nn.Module):
             params += list(self.bg_model.parameters())
-        self.optimizer = torch.optim.Adam(params, lr=self.lr, betas=(0.9, 0.99), eps=1e-15,
-                                          weight_decay=0.0, fused=True)
+        # one HIP launch per step for every tensor, fused with the f16 refresh of the texture
+        # parameters and the next iteration's zero_grad (volsurfs_amd/optim.py, csrc/adam.hip)
+        self.optimizer = FusedAdam(params, lr=self.lr, betas=(0.9, 0.99), eps=1e-15,
+                                   weight_decay=0.0, half_copies=half)
         from .schedulers import MultiStepLR
         self.scheduler_lr_decay = MultiStepLR(self.optimizer, milestones=self.lr_milestones, gamma=0.3)
         return self.optimizer
 
     def optim_step(self):
-        self.optimizer.step()
-        if self.bank is not None:
-            self.bank.refresh_half_params()
+        self.optimizer.step()        # (refreshes bank.tables_h / weights_h inside the kernel)
 
     def _shade_legacy(self, rays_o, rays_d, hit_t, hit_slot, iter_nr):
         """volsurfs.py:486-599, legacy branch: per shell, the hit points / view directions /

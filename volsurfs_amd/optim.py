@@ -1,0 +1,109 @@
+"""FusedAdam — the optimiser of the reference's training loop on one HIP kernel.
+
+The reference builds `apex.optimizers.FusedAdam(param_groups, amsgrad=False, betas=(0.9, 0.99),
+eps=1e-15, weight_decay=0.0, lr=...)` (/root/reference/volsurfs_py/methods/base_method.py:87-94)
+and calls `.step()` once per iteration (trainer.py:278) — the same update as
+`torch.optim.Adam`, against which tests/test_optim.py pins this class at 1e-6.
+
+`vsa_adam_step` (csrc/adam.hip) updates ALL tensors of a parameter group in one launch and
+fuses two passes the surrounding loop otherwise makes over the same memory: the refresh of a
+parameter's f16 compute copy (`half_copies`) and the zeroing of its gradient for the next
+iteration.  Gradients therefore live in persistent buffers (`p.grad` is allocated once and never
+set to None): `zero_grad()` is free after a `step()`.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class AdamTensor(ctypes.Structure):
+    """Mirror of `vsa_adam_tensor` (include/volsurfs_hip.h)."""
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p),
+                ("exp_avg_sq", ctypes.c_void_p), ("param_f16", ctypes.c_void_p), ("n", ctypes.c_int64)]
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.99), eps=1e-15, weight_decay=0.0,
+                 amsgrad=False, half_copies=None):
+        if weight_decay != 0.0 or amsgrad:
+            raise _lib.VolsurfsHipError("FusedAdam: weight_decay / amsgrad are not used by the "
+                                        "reference (base_method.py:87-94) and not built")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0.0, amsgrad=False))
+        self._half = {id(p): h for p, h in (half_copies or {}).items()}
+        self._plans = {}          # group index -> (key, descriptor tensor, chunk tensor, nr_chunks)
+        self._grads_clean = False
+        for g in self.param_groups:
+            g.setdefault("step", 0)
+            for p in g["params"]:
+                if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
+                    raise _lib.VolsurfsHipError("FusedAdam: contiguous CUDA float32 parameters only")
+                # any gradient autograd accumulates makes the buffers dirty again (kernels that
+                # accumulate into .grad directly call mark_grads_dirty themselves)
+                p.register_post_accumulate_grad_hook(self._dirty_hook)
+
+    def _ensure(self, p):
+        st = self.state[p]
+        if "exp_avg" not in st:
+            st["exp_avg"] = torch.zeros_like(p)
+            st["exp_avg_sq"] = torch.zeros_like(p)
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        return st
+
+    def _plan(self, gi, group):
+        ps = [p for p in group["params"] if p.requires_grad]
+        sts = [self._ensure(p) for p in ps]
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr())
+                    for p, s in zip(ps, sts))
+        cur = self._plans.get(gi)
+        if cur is not None and cur[0] == key:
+            return cur
+        chunk = _lib.lib().vsa_adam_chunk_elems()
+        arr = (AdamTensor * max(len(ps), 1))()
+        chunks = []
+        for i, (p, s) in enumerate(zip(ps, sts)):
+            if not p.grad.is_contiguous() or p.grad.dtype != torch.float32:
+                raise _lib.VolsurfsHipError("FusedAdam: gradients must be contiguous float32")
+            h = self._half.get(id(p))
+            if h is not None and (h.shape != p.shape or h.dtype != torch.float16 or not h.is_contiguous()):
+                raise _lib.VolsurfsHipError("FusedAdam: an f16 copy must match its parameter's shape")
+            arr[i] = AdamTensor(p.data_ptr(), p.grad.data_ptr(), s["exp_avg"].data_ptr(),
+                                s["exp_avg_sq"].data_ptr(), h.data_ptr() if h is not None else None,
+                                p.numel())
+            chunks += [(i, c) for c in range((p.numel() + chunk - 1) // chunk)]
+        dev = ps[0].device if ps else "cuda"
+        desc = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        ck = torch.tensor(chunks, dtype=torch.int32).reshape(-1, 2).to(dev)
+        self._plans[gi] = (key, desc, ck, len(chunks))
+        return self._plans[gi]
+
+    def zero_grad(self, set_to_none=False):
+        """Gradients stay allocated (the step kernel holds their addresses and has already
+        cleared them); only a backward without a following step leaves something to clear."""
+        if self._grads_clean:
+            return
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is not None:
+                    p.grad.zero_()
+        self._grads_clean = True
+
+    def mark_grads_dirty(self):
+        self._grads_clean = False
+
+    def _dirty_hook(self, _param):
+        self._grads_clean = False
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        loss = closure() if closure is not None else None
+        for gi, group in enumerate(self.param_groups):
+            _, desc, ck, n = self._plan(gi, group)
+            group["step"] += 1
+            b1, b2 = group["betas"]
+            _lib.call("vsa_adam_step", desc, ck, n, float(group["lr"]), float(b1), float(b2),
+                      float(group["eps"]), int(group["step"]), float(grad_scale), 1, _lib.stream_ptr())
+        self._grads_clean = True
+        return loss

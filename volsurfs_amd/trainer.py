@@ -70,6 +70,7 @@ def train_step(method, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first
         from .parallel import allreduce_gradients
         allreduce_gradients([p for g in method.optimizer.param_groups for p in g["params"]], world, group)
     method.optim_step()                                                     # :278
+    method.last_nr_samples = nr_samples
     losses = {k: (v.item() if isinstance(v, torch.Tensor) else v) for k, v in losses.items()}
     if nr_rays is not None and target_nr_of_training_samples and nr_samples:
         nr_rays = dynamic_nr_rays(nr_rays, nr_samples, target_nr_of_training_samples)
