@@ -54,8 +54,9 @@ def test_fused_adam_matches_torch_adam():
             np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=1e-6, atol=1e-6)
     for p, q in zip(a, b):
         sa, sb = opt.state[p], ref.state[q]
-        np.testing.assert_allclose(sa["exp_avg"].cpu().numpy(), sb["exp_avg"].cpu().numpy(), rtol=1e-5, atol=1e-12)
-        np.testing.assert_allclose(sa["exp_avg_sq"].cpu().numpy(), sb["exp_avg_sq"].cpu().numpy(), rtol=1e-5, atol=1e-20)
+        for k in ("exp_avg", "exp_avg_sq"):      # 1e-6 of each moment tensor's scale
+            x, y = sa[k].cpu().numpy(), sb[k].cpu().numpy()
+            np.testing.assert_allclose(x, y, rtol=1e-5, atol=1e-6 * float(np.abs(y).max()))
     assert torch.equal(halves[a[0]], a[0].detach().half()) and torch.equal(halves[a[2]], a[2].detach().half())
     # the optimiser state survives a state_dict round trip (checkpoints, base_method.py:118-264)
     sd = opt.state_dict()
