@@ -72,3 +72,43 @@ def test_train_step_order_and_schedule():
     assert lrs[0] == 2e-3
     np.testing.assert_allclose(lrs[1:], [lr_at(i, 2e-3, 5, [8]) for i in range(1, 14)], rtol=1e-12)
     assert losses[-1] < losses[1]
+
+
+@pytest.mark.gpu
+def test_fused_step_equals_the_autograd_step():
+    """train_step's fused path (one launch sequence, no autograd graph, asynchronous hit count)
+    computes what forward + loss.backward() computes: same loss, same hit count, same gradients
+    up to the backward's unordered f16 atomics."""
+    from volsurfs_amd.camera import pinhole_rays
+    from volsurfs_amd.mesh import nested_shells
+    from volsurfs_amd.methods import VolSurfs
+    from volsurfs_amd.trainer import train_step
+    o, d = pinhole_rays(48, 48, focal=80.0)
+    gt = torch.rand(48 * 48, 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)) * 0.3
+    res = {}
+    for fused in (True, False):
+        m = VolSurfs(nested_shells(K=2, subdiv=3), max_rays=4096, textures_res=(256, 128, 64, 32),
+                     nr_warmup_iters=0, lr=2e-3)
+        g = torch.Generator().manual_seed(0)
+        with torch.no_grad():
+            m.bank.tables.copy_((torch.rand(m.bank.tables.shape, generator=g) * 2 - 1).cuda())
+        m.bank.refresh_half_params()
+        m.init_optim()
+        m.grad_scale = float(48 * 48)
+        assert m.supports_fused_step()
+        seen = {}
+
+        def snap(m=m, inner=m.optim_step):
+            seen["g"] = (m.bank.weights.grad.clone(), m.bank.tables.grad.clone())
+            inner()
+        m.optim_step = snap
+        l, nr = train_step(m, o, d, gt, None, iter_nr=0, is_first_iter=True, nr_rays=2304,
+                           target_nr_of_training_samples=1000, fused=fused)
+        res[fused] = (l["loss"], nr, seen["g"], m.last_nr_samples)
+    assert abs(res[True][0] - res[False][0]) < 1e-6 and res[True][1] == res[False][1]
+    assert res[True][3] == res[False][3] > 500
+    for a, b in zip(res[True][2], res[False][2]):
+        s_ = a.abs().max().item()
+        assert s_ > 0 and (a - b).abs().max().item() <= 2e-3 * s_
+    # a masked loss or a learned background falls back to the autograd path
+    assert not m.supports_fused_step(torch.ones(1), True)

@@ -301,10 +301,17 @@ class VolSurfs(torch.nn.Module):
             outs.append(out)
         return {k: torch.cat([o_[k] for o_ in outs], 0) for k in outs[0]}
 
-    def forward(self, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first_iter=False,
-                is_training_masked=False):
-        """volsurfs.py:763-816: L1 rgb loss (utils/losses.py:14-19)."""
-        if is_first_iter and self.scheduler_lr_decay is not None:              # :774-783
+    # -- fused training path: the same forward + mean-L1 + backward as `forward(...)` followed by
+    # `loss.backward()`, as ONE sequence of C-ABI launches on the current stream (no autograd
+    # graph, no temporaries for the gradients, no host synchronisation): trace -> mark/compact ->
+    # encode -> MLP -> shade -> composite+L1+its backward (one launch) -> shade_bwd -> MLP bwd ->
+    # encode bwd, accumulating into the persistent bank.tables.grad / bank.weights.grad.
+    def supports_fused_step(self, gt_mask=None, is_training_masked=False):
+        return (self.bank is not None and self.bg_color is not None and self.baked is None
+                and not (is_training_masked and gt_mask is not None))
+
+    def _warmup_scheduler(self, is_first_iter):
+        if is_first_iter and self.scheduler_lr_decay is not None:              # volsurfs.py:774-783
             from .schedulers import GradualWarmupScheduler
             if self.nr_warmup_iters > 0:
                 self.lr_scheduler = GradualWarmupScheduler(self.optimizer, multiplier=1,
@@ -312,6 +319,43 @@ class VolSurfs(torch.nn.Module):
                                                            after_scheduler=self.scheduler_lr_decay)
             else:
                 self.lr_scheduler = self.scheduler_lr_decay
+
+    def fused_forward_backward(self, rays_o, rays_d, gt_rgb, loss_weight=1.0, is_first_iter=False):
+        """Gradients of `loss_weight * mean|gt_rgb - rgb|` (utils/losses.py:14-19) w.r.t. every
+        texture parameter, accumulated into .grad.  Returns (loss [] device tensor — the
+        unweighted mean, nr_hits [] int64 device tensor, rgb [N,3])."""
+        from .composite import composite_fwd_bwd_l1_raw
+        self._warmup_scheduler(is_first_iter)
+        N = rays_o.shape[0]
+        if N > self.max_rays:
+            raise _lib.VolsurfsHipError(f"{N} rays > max_rays={self.max_rays}")
+        bank = self.bank
+        bank._ensure_grads()
+        opt = getattr(self, "optimizer", None)
+        if hasattr(opt, "mark_grads_dirty"):
+            opt.mark_grads_dirty()
+        bank.frame_generation = getattr(bank, "frame_generation", 0) + 1
+        rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
+        hit_t, hit_slot, hit_uv = self.raytracer.trace_all(rays_o, rays_d)
+        nr_hits = (hit_slot >= 0).sum()
+        tex_uv = bank.mark_and_compact(hit_slot, hit_uv, self.face_uvs)
+        bank.encode()
+        bank.mlp()
+        act = torch.empty(self.nr_meshes, N, 4, device=rays_o.device)
+        tris = self.raytracer.tris
+        rgb_k, alpha_k, _, _ = bank.shade(hit_slot, tex_uv, rays_d, tris, act_out=act)
+        loss_scale = float(loss_weight) / (3.0 * N)
+        rgb, g_c, g_a = composite_fwd_bwd_l1_raw(rgb_k, alpha_k, self.bg_color, gt_rgb.contiguous(),
+                                                 loss_scale)
+        scale = self.grad_scale if self.grad_scale is not None else 1.0 / (3.0 * loss_scale)
+        bank.backward(hit_slot, tex_uv, rays_d, tris, g_c, g_a, scale, act)
+        loss = (gt_rgb - rgb).abs().mean()
+        return loss, nr_hits, rgb
+
+    def forward(self, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first_iter=False,
+                is_training_masked=False):
+        """volsurfs.py:763-816: L1 rgb loss (utils/losses.py:14-19)."""
+        self._warmup_scheduler(is_first_iter)                                   # :774-783
         res = self.render_rays(rays_o=rays_o, rays_d=rays_d, iter_nr=iter_nr)
         pred = res["renders"]["ray_traced"]["rgb"]
         if is_training_masked and gt_mask is not None:

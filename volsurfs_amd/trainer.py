@@ -26,9 +26,26 @@ def dynamic_nr_rays(nr_rays, nr_samples, target_nr_samples):
     return int(nr_rays * (float(target_nr_samples) / nr_samples))
 
 
+class _HostCount:
+    """A device counter copied to pinned host memory without stalling the stream: the copy is
+    queued right where the value is produced and only waited for when it is read."""
+
+    def __init__(self):
+        self.buf = torch.zeros(1, dtype=torch.int64).pin_memory()
+        self.event = torch.cuda.Event()
+
+    def post(self, t):
+        self.buf.copy_(t.reshape(1), non_blocking=True)
+        self.event.record()
+
+    def get(self):
+        self.event.synchronize()
+        return int(self.buf[0])
+
+
 def train_step(method, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first_iter=False,
                nr_rays=None, target_nr_of_training_samples=None, world=1, is_training_masked=False,
-               group=None):
+               group=None, sync_losses=True, fused=True):
     """Returns (losses dict with a float "loss", next nr_rays).  `method` is a
     volsurfs_amd.methods.VolSurfs with init_optim() called.
 
@@ -40,7 +57,14 @@ def train_step(method, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first
     batch (utils/losses.py:14-19), so each rank's loss is weighted by local_rays / global_rays
     (one all-reduce of the ray counts) before backward and the gradients are summed over the
     ranks: the result is the gradient of the global mean for even and uneven shards alike
-    (SURVEY §8e)."""
+    (SURVEY §8e).
+
+    fused=True uses `method.fused_forward_backward` when the method offers it for this
+    configuration (neural textures, constant background, unmasked L1): the same arithmetic as
+    forward + backward, as one launch sequence without an autograd graph.  The only host read of
+    an iteration is then the hit count the dynamic ray count needs (trainer.py:293-304), copied
+    asynchronously right after the traversal, so the host queues the next iteration while this
+    one still runs.  sync_losses=False leaves the losses as device tensors (no .item())."""
     method.is_training = True
     method.optimizer.zero_grad()                                            # trainer.py:118
     n_local = rays_o.shape[0]
@@ -52,26 +76,41 @@ def train_step(method, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first
         share = n_local / cnt.item()
     cap = int(getattr(method, "max_rays", n_local) or n_local)
     bounds = list(range(0, n_local, cap)) if n_local > cap else [0]
-    losses, nr_samples = {}, 0
+    use_fused = fused and hasattr(method, "supports_fused_step") and \
+        method.supports_fused_step(gt_mask, is_training_masked)
+    losses, nr_samples, counts = {}, 0, []
     for ci, a in enumerate(bounds):
         b = min(n_local, a + cap) if len(bounds) > 1 else n_local
         sl = slice(a, b)
-        l, _, samples_3d = method(rays_o[sl], rays_d[sl], gt_rgb[sl],
-                                  None if gt_mask is None else gt_mask[sl], iter_nr,
-                                  is_first_iter=is_first_iter and ci == 0,
-                                  is_training_masked=is_training_masked)   # :229
         w = (b - a) / max(n_local, 1)
-        (l["loss"] * (w * share)).backward()                                # :264
+        if use_fused:
+            loss, nr_hits, _ = method.fused_forward_backward(rays_o[sl], rays_d[sl], gt_rgb[sl],
+                                                            loss_weight=w * share,
+                                                            is_first_iter=is_first_iter and ci == 0)
+            pool = method.__dict__.setdefault("_host_counts", [])
+            while len(pool) <= ci:
+                pool.append(_HostCount())
+            pool[ci].post(nr_hits)
+            counts.append(pool[ci])
+            l = {"loss": loss, "rgb": loss}
+        else:
+            l, _, samples_3d = method(rays_o[sl], rays_d[sl], gt_rgb[sl],
+                                      None if gt_mask is None else gt_mask[sl], iter_nr,
+                                      is_first_iter=is_first_iter and ci == 0,
+                                      is_training_masked=is_training_masked)   # :229
+            (l["loss"] * (w * share)).backward()                            # :264
+            if samples_3d is not None:
+                nr_samples += samples_3d.shape[0]
         for k, v in l.items():
             losses[k] = losses.get(k, 0.0) + (v.detach() if isinstance(v, torch.Tensor) else v) * w
-        if samples_3d is not None:
-            nr_samples += samples_3d.shape[0]
     if world > 1:
         from .parallel import allreduce_gradients
         allreduce_gradients([p for g in method.optimizer.param_groups for p in g["params"]], world, group)
     method.optim_step()                                                     # :278
+    nr_samples += sum(c.get() for c in counts)
     method.last_nr_samples = nr_samples
-    losses = {k: (v.item() if isinstance(v, torch.Tensor) else v) for k, v in losses.items()}
+    if sync_losses:
+        losses = {k: (v.item() if isinstance(v, torch.Tensor) else v) for k, v in losses.items()}
     if nr_rays is not None and target_nr_of_training_samples and nr_samples:
         nr_rays = dynamic_nr_rays(nr_rays, nr_samples, target_nr_of_training_samples)
     if method.lr_scheduler is not None:                                     # :306-308
