@@ -37,6 +37,9 @@ def parse():
                          "fwd+bwd+Adam) on the neural-texture appearance.  train-permuto: BASELINE configs[2] "
                          "as written (legacy permutohash + MLP appearance).  dtu: configs[3]'s learned "
                          "background (NerfHash, 32 samples per ray) fwd+bwd+Adam on 65 536-ray batches")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1, frame workload: weak = one full frame per rank (default); strong = ONE frame "
+                         "dealt to the ranks in 8-row bands, round-robin (parallel.shard_bands)")
     ap.add_argument("--target-hits", type=int, default=49152)
     ap.add_argument("--views", type=int, default=50)
     ap.add_argument("--res", type=int, default=800)
@@ -59,6 +62,19 @@ def parse():
     if args.warmup is None:
         args.warmup = 100 if training else 5
     return args
+
+
+def kernel_source_hash():
+    """sha256 over the HIP / C++ sources and headers the library is built from."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "volsurfs_amd", "csrc")
+    for n in sorted(os.listdir(d)):
+        if n.endswith((".hip", ".h", ".cpp")):
+            h.update(n.encode())
+            h.update(open(os.path.join(d, n), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "volsurfs_hip.h"), "rb").read())
+    return h.hexdigest()
 
 
 def cpu_baseline(pipe, sample_rays):
@@ -214,8 +230,13 @@ def main():
         return
 
     from volsurfs_amd.pipeline import KShellPipeline
+    strong = args.scaling == "strong" and world > 1
+    rows = None
+    if strong:       # every rank sees the same frame (same seed) and renders its own bands of it
+        from volsurfs_amd.parallel import shard_bands
+        rows = shard_bands(args.res, rank, world)
     pipe = KShellPipeline.synthetic(K=args.shells, subdiv=args.subdiv, res=args.res, device=dev,
-                                    seed=42 + rank)
+                                    seed=42 if strong else 42 + rank, rows=rows)
     N = pipe.nr_rays
 
     def barrier():
@@ -283,17 +304,23 @@ def main():
         dt = t.item()
 
     if rank == 0:
-        total_rays = N * world * args.steps
+        total_rays = (pipe.loss_rays if strong else N * world) * args.steps
         value = total_rays / dt / 1e6
         # dominant KERNEL: the two encode stages are two launches each (dense / hashed levels)
         launches = {"nt_encode_fwd": 2, "nt_encode_bwd": 2}
         dom = max(((k, v) for k, v in stages.items() if k != "grad_allreduce"),
                   key=lambda kv: kv[1]["ms"] / launches.get(kv[0], 1))
         name, st = dom
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-measured HBM bytes per launch
+        # PMC-measured HBM bytes per launch (tools/traffic.sh -> profiles/traffic.json), valid only
+        # for the kernel sources they were collected at: a stale file is reported as null
+        traffic, traffic_note = None, None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
-            traffic = json.load(open(tf)).get(name)
+            tj = json.load(open(tf))
+            if tj.get("_kernel_source_sha256") == kernel_source_hash():
+                traffic = tj.get(name)
+            else:
+                traffic_note = "profiles/traffic.json was collected at other kernel sources (stale): re-run tools/traffic.sh"
         # the kernel's own duration: events directly around its launch (a stage also holds the
         # small torch kernels next to it); one launch per stage except the encode stages
         k_ms = kernel_ms.get("vsa_" + name, st["ms"]) if name not in launches else st["ms"]
@@ -311,14 +338,20 @@ def main():
             "metric": "Mrays/s (fwd+bwd) at 800x800, K=5 shells",
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": pipe.dtype_desc, "data": "synthetic",
             "config": dict(pipe.config_desc(world), launch="hip-graph replay" if use_graph else "eager"),
             "roofline": roof,
+            # hit fraction per (ray, shell) and the rate per hit: 71 % of the (ray, shell) pairs of this
+            # frame are misses that cost almost nothing, so Mrays/s alone overstates the shading rate
+            "h": (pipe.last_hits or 0) / float(N * pipe.K),
+            "Mhits/s": (pipe.last_hits or 0) * world * args.steps / dt / 1e6 if not strong else None,
             "stages_ms": {k: round(v["ms"], 4) for k, v in stages.items()},
             "stage_roofline": {k: pipe.stage_roofline(v, HBM_PEAK_GBS, MFMA_F16_PEAK_TFLOPS)
                                for k, v in stages.items()},
         }
+        if traffic_note:
+            out["roofline"]["traffic_note"] = traffic_note
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pipe, args.cpu_sample_rays)
         print(json.dumps(out))

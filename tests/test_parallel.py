@@ -187,3 +187,58 @@ def test_train_step_two_ranks_equals_one_rank_and_chunks_over_max_rays():
     l3, _ = train_step(m3, o, d, gt, mask, is_training_masked=True)
     ref = ((gt - torch.cat([o, d[:, :1]], 1) @ torch.linspace(-1, 1, 12).view(4, 3)).abs() * mask).mean()
     assert abs(l3["loss"] - ref.item()) < 1e-6
+
+
+def _hip_rank(rank, world, port, res, q):
+    """One rank of the strong-scaling schedule on the REAL HIP pipeline (both ranks share
+    cuda:0; gloo carries the collectives, as bench.py --dist-backend gloo --single-device)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from volsurfs_amd.parallel import shard_bands
+    from volsurfs_amd.pipeline import KShellPipeline
+    torch.cuda.set_device(0)
+    pipe = KShellPipeline.synthetic(K=2, subdiv=3, res=res, init="spread", seed=3,
+                                    rows=shard_bands(res, rank, world))
+    ov = GradientOverlap(world)
+    rgb = pipe.step(grad_ready=ov.reduce_async)      # weights.grad, then one tables.grad slice per shell
+    ov.wait()
+    torch.cuda.synchronize()
+    frame = gather_rows = None
+    outs = [torch.empty_like(rgb) for _ in range(world)] if rank == 0 else None
+    dist.gather(rgb, outs, dst=0)
+    if rank == 0:
+        q.put((pipe.bank.weights.grad.cpu().numpy(), pipe.bank.tables.grad.cpu().numpy(),
+               [o.cpu().numpy() for o in outs]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_strong_scaling_on_the_hip_pipeline_equals_one_rank():
+    """the N > 1 schedule through the real kernels, not a stand-in:
+    one frame dealt in 8-row bands to two ranks, each renders + back-propagates its share of the
+    FRAME's mean-L1, gradients all-reduced slice by slice during backward; the sums equal the
+    one-rank gradients of the whole frame and the gathered bands equal its image."""
+    from volsurfs_amd.parallel import shard_bands
+    from volsurfs_amd.pipeline import KShellPipeline
+    res = 64
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hip_rank, args=(r, 2, port, res, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    gw, gt, bands = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    one = KShellPipeline.synthetic(K=2, subdiv=3, res=res, init="spread", seed=3)
+    rgb = one.step().cpu().numpy().reshape(res, res, 3)
+    for r in range(2):
+        rows = shard_bands(res, r, 2).numpy()
+        assert (bands[r].reshape(len(rows), res, 3) == rgb[rows]).all()          # forward: bit-identical
+    for got, ref in ((gw, one.bank.weights.grad.cpu().numpy()), (gt, one.bank.tables.grad.cpu().numpy())):
+        s = abs(ref).max()
+        assert s > 0 and abs(got - ref).max() <= 2e-2 * s                          # f16 chain, two partial sums
+        assert (got * ref).sum() / ((got ** 2).sum() ** 0.5 * (ref ** 2).sum() ** 0.5) > 0.9995

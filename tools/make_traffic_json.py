@@ -19,6 +19,9 @@ for st, subs in stages.items():
             if s in k:
                 b += (2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024
     out[st] = int(b)
+sys.path.insert(0, root)
+import bench  # noqa: E402  (kernel_source_hash: bench.py refuses the file once the kernels change)
+out["_kernel_source_sha256"] = bench.kernel_source_hash()
 json.dump(out, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 shutil.copy(os.path.join(root, "gpurun_out", "traffic_raw.json"),

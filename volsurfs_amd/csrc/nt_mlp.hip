@@ -211,12 +211,13 @@ __global__ __launch_bounds__(MLP_BLOCK, MLP_FWD_WGS_PER_CU) void nt_mlp_fwd_kern
           const _Float16 o_h = (_Float16)acc3[4 * g + i];
           if (pre_out && row0 + i < ti.channels)
             pre_out[(long long)slot * 32 + pre_base + row0 + i] = o_h;
-          // fast estimate (within one step of the reference's round(sigmoid(x) * 255)), then the
-          // exact step function: compare x with the two neighbouring thresholds of the table
-          unsigned q = (unsigned)rintf(sigmoidf_((float)o_h) * 255.0f);
+          // the reference's round(sigmoid(x) * 255) as the exact step function of x: a fast
+          // estimate biased low by 0.01 of a step (the hardware exp2 / rcp are good to ~1e-4 of
+          // one) is the exact value or one below it; one threshold of the table decides which
+          unsigned q = (unsigned)(sigmoidf_((float)o_h) * 255.0f + 0.49f);
           const unsigned ob = __builtin_bit_cast(unsigned short, o_h);
           const unsigned key = (ob & 0x8000u) ? (~ob & 0xffffu) : (ob | 0x8000u);
-          q = q - (key < s_qt[q] ? 1u : 0u) + (key >= s_qt[q + 1] ? 1u : 0u);
+          q += key >= s_qt[q + 1] ? 1u : 0u;
           unsigned qb = row0 + i < ti.channels ? q : 0u;
           packed |= qb << (8 * i);
         }

@@ -24,6 +24,18 @@ def shard_indices(nr_rays, rank, world, chunk=16384, device="cpu"):
     return torch.cat(parts) if parts else torch.zeros(0, dtype=torch.long, device=device)
 
 
+def shard_bands(height, rank, world, band=8):
+    """Rows of an image owned by `rank` when the frame is dealt round-robin in horizontal bands
+    of `band` rows (8 = the pixel-tile edge of KShellPipeline's ray order, so a rank's rows form
+    an image of its own whose 8x8 tiles are tiles of the full frame).  Strong scaling of ONE
+    frame: rays that miss every shell are almost free, so contiguous blocks would leave the
+    ranks holding the frame's border idle."""
+    if height % band:
+        raise ValueError(f"image height {height} is not a multiple of the band height {band}")
+    rows = [r for b in range(rank, height // band, world) for r in range(b * band, (b + 1) * band)]
+    return torch.tensor(rows, dtype=torch.long)
+
+
 def allreduce_gradients(params, world, group=None):
     """Sum the gradients over ranks (each rank back-propagated its shard of a loss
     normalised by the GLOBAL ray count, so the sum is the gradient of the global

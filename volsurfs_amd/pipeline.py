@@ -83,6 +83,9 @@ class KShellPipeline:
             self.bank.refresh_half_params()
         self.shading = "neural_textures"
         self.grad_scale = float(N)
+        # rays the mean of the L1 loss runs over: this pipeline's own, or — when it renders one
+        # rank's share of a frame (bench.py --scaling strong) — the whole frame's
+        self.loss_rays = N
         self.surfs_rgb = self.surfs_alpha = None
         # per-hit output sigmoids kept from shade_fwd for shade_bwd of the same frame
         self._act = torch.empty(K, N, 4, device=dev)
@@ -97,15 +100,24 @@ class KShellPipeline:
         return out
 
     @classmethod
-    def synthetic(cls, K=5, subdiv=6, res=800, device="cuda", seed=42, **kw):
-        """res: an int (square frame) or (H, W)."""
+    def synthetic(cls, K=5, subdiv=6, res=800, device="cuda", seed=42, rows=None, **kw):
+        """res: an int (square frame) or (H, W).  rows: optional LongTensor of image rows (whole
+        8-row bands, parallel.shard_bands): the pipeline then renders only those rows of the
+        frame — one rank's share under strong scaling — with the loss still the frame's mean."""
         meshes = nested_shells(K=K, subdiv=subdiv, device=device)
         H, W = (res, res) if isinstance(res, int) else res
         o, d = pinhole_rays(H, W, focal=1111.1 * min(H, W) / 800.0, cam_pos=(0.0, 0.0, -1.5),
                             device=device)
         g = torch.Generator(device=device).manual_seed(seed)
         gt = torch.rand(o.shape[0], 3, device=device, generator=g)
-        p = cls(meshes, o, d, gt, seed=seed, image_hw=(H, W), **kw)
+        n_frame, h_local = H * W, H
+        if rows is not None:
+            rows = rows.to(device)
+            o, d, gt = (x.view(H, W, 3)[rows].reshape(-1, 3).contiguous() for x in (o, d, gt))
+            h_local = int(rows.numel())
+        p = cls(meshes, o, d, gt, seed=seed, image_hw=(h_local, W), **kw)
+        p.loss_rays = n_frame
+        p.grad_scale = float(n_frame)      # the f16 gradient chain is conditioned for 1 / (3 n_frame) per ray
         p.res = res
         p.subdiv = subdiv
         return p
@@ -136,7 +148,8 @@ class KShellPipeline:
                         "SH-degree-3 neural textures (rgb + alpha per shell, res 2048/1024/512/256, "
                         "16-level 2-D hash grid + 32-64-64-C MLP, 8-bit quantised, lerp), alpha decay, "
                         "white bg, L1 loss, gradients to all hash tables and MLP weights",
-            "rays_per_gpu": self.nr_rays, "global_rays": self.nr_rays * world,
+            "rays_per_gpu": self.nr_rays,
+            "global_rays": self.loss_rays if self.loss_rays != self.nr_rays else self.nr_rays * world,
             "parallelism": f"tile-parallel x{world}",
             "hits_per_frame": getattr(self, "last_hits", None),
             "unique_texels_per_frame": getattr(self, "last_slots", None),
@@ -242,7 +255,8 @@ class KShellPipeline:
         # backward in one pass over the shells' colours (vsa_composite_dense_fwd_bwd_l1)
         from .composite import composite_fwd_bwd_l1_raw
         rgb, g_c, g_a = T.run("composite_fwd_bwd",
-                              lambda: composite_fwd_bwd_l1_raw(rgb_k, alpha_k, self.bg, gt, 1.0 / (3.0 * N)),
+                              lambda: composite_fwd_bwd_l1_raw(rgb_k, alpha_k, self.bg, gt,
+                                                               1.0 / (3.0 * self.loss_rays)),
                               record, bytes=N * (12 + 12 + 32 * K))
         tris = self.tracer.tris
         T.run("nt_shade_bwd", lambda: bank.backward_shade(hit_slot, tex_uv, rays_d, tris, g_c, g_a,
