@@ -482,6 +482,16 @@ int vsa_combine_packs(const int32_t* start_end_1, const int32_t* idx_1, const fl
                       int32_t* out_idx, float* out_3d, float* out_dirs, float* out_z,
                       float* out_values, int32_t* out_start_end, int nr_rays, void* stream);
 
+/* A1  Ray / bounding-primitive intersection: `intersect_bounding_primitive`
+ * (volsurfs_py/utils/raycasting.py:4-36) -> mvdatasets BoundingBox / BoundingSphere .intersect
+ * (absent: parity unpinned; the primitive is chosen at utils/volsurfs_utils.py:234-272).
+ * kind 0 = origin-centred cube of HALF side `size`, kind 1 = origin-centred sphere of radius
+ * `size`.  is_hit [N] u8, t_near / t_far [N] (0 on a miss, t_near clamped to >= 0),
+ * points_near / points_far [N,3] (optional).  VolSurfs consumes t_far (volsurfs.py:688-693). */
+int vsa_intersect_primitive(const float* rays_o, const float* rays_d, int nr_rays, int kind,
+                            float size, uint8_t* is_hit, float* t_near, float* t_far,
+                            float* points_near, float* points_far, void* stream);
+
 /* ---- ray generation (mvdatasets is an empty submodule: parity unpinned) ----
  * Pinhole rays of one camera, replacing mvdatasets.utils.raycasting.get_camera_rays as called at
  * methods/base_method.py:389-394 and renderers/base_renderer.py:59.  c2w [3,4] and

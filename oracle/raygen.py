@@ -62,3 +62,40 @@ def reel_batch(c2w_all, kinv_all, rgbs, masks, B, R=1, jitter=False, rng=None):
             o[b * R + s], d[b * R + s] = pinhole_ray(c2w_all[c], kinv_all[c], x, y)
             p[b * R + s] = (x, y)
     return cam, o, d, gt, gm, p
+
+
+def intersect_primitive(rays_o, rays_d, kind, size):
+    """Restatement of vsa_intersect_primitive (utils/raycasting.py:4-36 ->
+    mvdatasets BoundingBox / BoundingSphere .intersect, absent: PARITY UNPINNED — this library's
+    definition of the slab / quadratic test, fp32, in the kernel's operation order).
+    kind 0: origin-centred cube of half side `size`; kind 1: sphere of radius `size`.
+    Returns (is_hit, t_near, t_far, p_near, p_far)."""
+    o, d = np.asarray(rays_o, f32), np.asarray(rays_d, f32)
+    size = f32(size)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        if kind == 0:
+            inv = (f32(1.0) / d).astype(f32)
+            a = ((-size - o) * inv).astype(f32)
+            b = ((size - o) * inv).astype(f32)
+            tn = np.full(o.shape[0], -np.inf, f32)
+            tf = np.full(o.shape[0], np.inf, f32)
+            for i in range(3):                       # fmaxf / fminf drop NaNs (0 * inf of a parallel ray)
+                tn = np.fmax(tn, np.fmin(a[:, i], b[:, i]))
+                tf = np.fmin(tf, np.fmax(a[:, i], b[:, i]))
+            hit = (tn <= tf) & (tf > 0)
+        else:
+            def dot(u, v):
+                return ((u[:, 0] * v[:, 0] + u[:, 1] * v[:, 1]).astype(f32) + u[:, 2] * v[:, 2]).astype(f32)
+            a = dot(d, d)
+            b = (f32(2.0) * dot(o, d)).astype(f32)
+            c = (dot(o, o) - size * size).astype(f32)
+            disc = ((b * b).astype(f32) - ((f32(4.0) * a).astype(f32) * c).astype(f32)).astype(f32)
+            sq = np.sqrt(np.fmax(disc, f32(0))).astype(f32)
+            tn = ((-b - sq).astype(f32) / (f32(2.0) * a).astype(f32)).astype(f32)
+            tf = ((-b + sq).astype(f32) / (f32(2.0) * a).astype(f32)).astype(f32)
+            hit = (disc >= 0) & (tf > 0)
+        tn = np.where(hit, np.fmax(tn, f32(0)), f32(0)).astype(f32)
+        tf = np.where(hit, tf, f32(0)).astype(f32)
+        pn = (o + (tn[:, None] * d).astype(f32)).astype(f32)
+        pf = (o + (tf[:, None] * d).astype(f32)).astype(f32)
+    return hit, tn, tf, pn, pf

@@ -192,3 +192,45 @@ def test_train_loop_with_callbacks():
     assert [e[1] for e in its] == list(range(5, 13)) and its[0][2] and not its[1][2]
     ends = [e for e in log if isinstance(e, tuple) and e[0] == "end"]
     assert len(ends) == 8 and ends[-1][2] < ends[0][2]
+
+
+def test_oracle_primitive_intersection_known_answers():
+    """A1 (utils/raycasting.py:4-36): hand-checkable cases of the restated slab / sphere tests."""
+    from oracle.raygen import intersect_primitive
+    o = np.array([[0, 0, -2], [0, 0, 0], [0, 0, -2], [0, 2, -2], [0, 0, 2]], np.float32)
+    d = np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0], [0, 0, 1], [0, 0, 1]], np.float32)
+    hit, tn, tf, pn, pf = intersect_primitive(o, d, 0, 0.5)
+    assert hit.tolist() == [True, True, False, False, False]       # through, from inside, parallel, beside, behind
+    assert tn[:2].tolist() == [1.5, 0.0] and tf[:2].tolist() == [2.5, 0.5]
+    assert pf[0].tolist() == [0.0, 0.0, 0.5] and tn[2] == tf[2] == 0.0 and pn[2].tolist() == [0.0, 0.0, -2.0]
+    hit, tn, tf, pn, pf = intersect_primitive(o, d, 1, 0.5)
+    assert hit.tolist() == [True, True, False, False, False]
+    assert tn[:2].tolist() == [1.5, 0.0] and tf[:2].tolist() == [2.5, 0.5]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [0, 1])
+def test_hip_primitive_intersection_bit_exact_vs_oracle(kind):
+    """vsa_intersect_primitive through BoundingBox / BoundingSphere and
+    intersect_bounding_primitive (same dict keys as utils/raycasting.py:4-36)."""
+    from oracle.raygen import intersect_primitive
+    from volsurfs_amd.background import BoundingBox, BoundingSphere, intersect_bounding_primitive
+    g = np.random.default_rng(kind)
+    n = 20000
+    o = (g.standard_normal((n, 3)) * 0.6).astype(np.float32)
+    d = g.standard_normal((n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:50, 0] = 0.0                                   # axis-parallel rays: infinite reciprocals
+    d[50:100, 1:] = 0.0
+    o[100:150] = 0.0
+    prim = BoundingBox(0.9) if kind == 0 else BoundingSphere(0.45)
+    rc = intersect_bounding_primitive(prim, torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda())
+    assert set(rc) == {"rays_o", "rays_d", "nr_rays", "points_near", "points_far", "t_near", "t_far", "is_hit"}
+    assert rc["t_near"].shape == (n, 1) and rc["t_far"].shape == (n, 1) and rc["nr_rays"] == n
+    hit, tn, tf, pn, pf = intersect_primitive(o, d, kind, 0.45)
+    assert 0.2 < hit.mean() < 0.95
+    assert np.array_equal(rc["is_hit"].cpu().numpy(), hit)
+    for got, ref in ((rc["t_near"][:, 0], tn), (rc["t_far"][:, 0], tf), (rc["points_near"], pn), (rc["points_far"], pf)):
+        assert np.array_equal(got.cpu().numpy(), ref, equal_nan=True)
+    empty = intersect_bounding_primitive(prim, torch.zeros(0, 3).cuda(), torch.zeros(0, 3).cuda())
+    assert empty["t_far"].shape == (0, 1)

@@ -5,14 +5,28 @@ The radiance model itself (`NerfHash`) is any callable
 `model_bg(points [S,3], dirs [S,3], iter_nr) -> (rgb [S,3], density [S,1])`."""
 import torch
 
+from . import _lib
 from .volsurfs import (CumprodOneMinusAlphaToTransmittanceFunc, IntegrateWithWeights3DFunc,
                        RaySampler, VolumeRendering)
+
+
+def _intersect(kind, size, rays_o, rays_d):
+    N = rays_o.shape[0]
+    rays_o = _lib.check_f32(rays_o.contiguous(), N, 3)
+    rays_d = _lib.check_f32(rays_d.contiguous(), N, 3)
+    dev = rays_o.device
+    hit = torch.empty(N, dtype=torch.uint8, device=dev)
+    t_near, t_far = torch.empty(N, device=dev), torch.empty(N, device=dev)
+    p_near, p_far = torch.empty(N, 3, device=dev), torch.empty(N, 3, device=dev)
+    _lib.call("vsa_intersect_primitive", rays_o, rays_d, N, kind, float(size), hit, t_near, t_far,
+              p_near, p_far, _lib.stream_ptr())
+    return hit.bool(), t_near, t_far, p_near, p_far
 
 
 class BoundingBox:
     """Axis-aligned cube of side `side` centred at the origin (the reference builds
     it with side 2*scene_radius, utils/volsurfs_utils.py:234-272; the class itself
-    lives in the absent mvdatasets)."""
+    lives in the absent mvdatasets).  `intersect` = vsa_intersect_primitive (kind 0)."""
 
     def __init__(self, side=1.0):
         self.half = 0.5 * float(side)
@@ -22,15 +36,7 @@ class BoundingBox:
 
     @torch.no_grad()
     def intersect(self, rays_o, rays_d):
-        inv = 1.0 / rays_d
-        t0, t1 = (-self.half - rays_o) * inv, (self.half - rays_o) * inv
-        t_near = torch.minimum(t0, t1).amax(dim=1)
-        t_far = torch.maximum(t0, t1).amin(dim=1)
-        is_hit = (t_near <= t_far) & (t_far > 0)
-        t_near = torch.where(is_hit, t_near.clamp(min=0.0), torch.zeros_like(t_near))
-        t_far = torch.where(is_hit, t_far, torch.zeros_like(t_far))
-        return (is_hit, t_near, t_far, rays_o + t_near[:, None] * rays_d,
-                rays_o + t_far[:, None] * rays_d)
+        return _intersect(0, self.half, rays_o, rays_d)
 
 
 class BoundingSphere:
@@ -42,18 +48,7 @@ class BoundingSphere:
 
     @torch.no_grad()
     def intersect(self, rays_o, rays_d):
-        a = (rays_d * rays_d).sum(1)
-        b = 2.0 * (rays_o * rays_d).sum(1)
-        c = (rays_o * rays_o).sum(1) - self.radius ** 2
-        disc = b * b - 4 * a * c
-        is_hit = disc >= 0
-        sq = torch.sqrt(disc.clamp(min=0.0))
-        t_near, t_far = (-b - sq) / (2 * a), (-b + sq) / (2 * a)
-        is_hit = is_hit & (t_far > 0)
-        t_near = torch.where(is_hit, t_near.clamp(min=0.0), torch.zeros_like(t_near))
-        t_far = torch.where(is_hit, t_far, torch.zeros_like(t_far))
-        return (is_hit, t_near, t_far, rays_o + t_near[:, None] * rays_d,
-                rays_o + t_far[:, None] * rays_d)
+        return _intersect(1, self.radius, rays_o, rays_d)
 
 
 @torch.no_grad()

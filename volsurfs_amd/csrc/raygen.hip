@@ -201,3 +201,67 @@ extern "C" int vsa_reel_next_rays_batch(const float* c2w_all, const float* intri
                      rays_d, gt_rgb, gt_mask, points_2d);
   VSA_RETURN_LAUNCH_STATUS();
 }
+
+// ---- A1: bounding-primitive intersection (utils/raycasting.py:4-36 -> mvdatasets BoundingBox /
+// BoundingSphere .intersect, absent: this library's definition, restated in oracle/raygen.py).
+// kind 0: axis-aligned cube of half side `size` centred at the origin (slab test);
+// kind 1: sphere of radius `size` centred at the origin.  Misses report t = 0 and the points at
+// the ray origin.  Fixed evaluation order (no contraction) so that the oracle matches bit for bit.
+namespace {
+__global__ void intersect_primitive_kernel(const float* __restrict__ rays_o,
+                                           const float* __restrict__ rays_d, int N, int kind,
+                                           float size, unsigned char* __restrict__ is_hit,
+                                           float* __restrict__ t_near, float* __restrict__ t_far,
+                                           float* __restrict__ p_near, float* __restrict__ p_far) {
+  const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float o[3] = {rays_o[3 * n], rays_o[3 * n + 1], rays_o[3 * n + 2]};
+  const float d[3] = {rays_d[3 * n], rays_d[3 * n + 1], rays_d[3 * n + 2]};
+  float tn, tf;
+  bool hit;
+  if (kind == 0) {
+    tn = -INFINITY;
+    tf = INFINITY;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float inv = 1.0f / d[i];
+      const float a = (-size - o[i]) * inv, b = (size - o[i]) * inv;
+      tn = fmaxf(tn, fminf(a, b));
+      tf = fminf(tf, fmaxf(a, b));
+    }
+    hit = tn <= tf && tf > 0.0f;
+  } else {
+    const float a = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
+    const float b = 2.0f * ((o[0] * d[0] + o[1] * d[1]) + o[2] * d[2]);
+    const float c = ((o[0] * o[0] + o[1] * o[1]) + o[2] * o[2]) - size * size;
+    const float disc = b * b - (4.0f * a) * c;
+    const float sq = sqrtf(fmaxf(disc, 0.0f));
+    tn = (-b - sq) / (2.0f * a);
+    tf = (-b + sq) / (2.0f * a);
+    hit = disc >= 0.0f && tf > 0.0f;
+  }
+  tn = hit ? fmaxf(tn, 0.0f) : 0.0f;
+  tf = hit ? tf : 0.0f;
+  is_hit[n] = hit ? 1 : 0;
+  t_near[n] = tn;
+  t_far[n] = tf;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    if (p_near) p_near[3 * n + i] = o[i] + tn * d[i];
+    if (p_far) p_far[3 * n + i] = o[i] + tf * d[i];
+  }
+}
+}  // namespace
+
+extern "C" int vsa_intersect_primitive(const float* rays_o, const float* rays_d, int nr_rays,
+                                       int kind, float size, uint8_t* is_hit, float* t_near,
+                                       float* t_far, float* points_near, float* points_far,
+                                       void* stream) {
+  if (nr_rays < 0 || (kind != 0 && kind != 1) || !(size > 0.0f)) return VSA_ERR_ARG;
+  if (nr_rays == 0) return VSA_OK;
+  if (!rays_o || !rays_d || !is_hit || !t_near || !t_far) return VSA_ERR_ARG;
+  hipLaunchKernelGGL(intersect_primitive_kernel, dim3(vsa_div_up(nr_rays, 256)), dim3(256), 0,
+                     (hipStream_t)stream, rays_o, rays_d, nr_rays, kind, size, is_hit, t_near, t_far,
+                     points_near, points_far);
+  VSA_RETURN_LAUNCH_STATUS();
+}
