@@ -324,6 +324,39 @@ int vsa_grid_encode_bwd(const vsa_grid_plan* plan, const float* x, const float* 
 /* out [nr_dirs][(degree+1)^2]: SH basis of each direction, degree 0..4. */
 int vsa_sh_encode(const float* dirs, int nr_dirs, int degree, float* out, void* stream);
 
+/* A5 / A10  Fused fp32 MLP (Linear + bias, exact GELU between layers, last layer linear) on the
+ * fp32-input matrix cores: `MLP` (volsurfs_py/models/mlp.py:8-69) as used by RGB (models/rgb.py:139),
+ * ColorSH (models/color_sh.py) and NerfHash (models/nerfhash.py:44-56).  Layer l maps dims[l] ->
+ * dims[l+1] with w[l] [dims[l+1]][dims[l]] row-major (torch.nn.Linear.weight) and b[l] [dims[l+1]]
+ * or NULL; every width <= 128, hidden widths multiples of 32.  All pointers are device pointers.
+ *   vsa_mlp_workspace: sizes (floats) of packed_ws (weights in MFMA fragment order, rewritten by
+ *     every call), of each of z_ws / dz_ws / a_ws (nr_points x sum of hidden widths) and of
+ *     partial_ws (per-workgroup weight-gradient blocks).
+ *   vsa_mlp_fwd: y [nr_points][y_stride] = MLP(x [nr_points][x_stride]); z_ws receives the hidden
+ *     pre-activations (pass NULL for inference).
+ *   vsa_mlp_bwd: from dy = dL/dy and the z_ws of the matching forward: dx (optional), and
+ *     grads->dw[l] / db[l] (OVERWRITTEN, not accumulated; NULL entries are skipped). */
+#define VSA_MLP_MAX_LAYERS 6
+typedef struct vsa_mlp_plan {
+  int32_t n_layers;
+  int32_t dims[VSA_MLP_MAX_LAYERS + 1];
+  const float* w[VSA_MLP_MAX_LAYERS];
+  const float* b[VSA_MLP_MAX_LAYERS];
+} vsa_mlp_plan;
+typedef struct vsa_mlp_grads {
+  float* dw[VSA_MLP_MAX_LAYERS];
+  float* db[VSA_MLP_MAX_LAYERS];
+} vsa_mlp_grads;
+
+int vsa_mlp_workspace(const vsa_mlp_plan* plan, long long nr_points, long long* packed_floats,
+                      long long* act_floats, long long* partial_floats);
+int vsa_mlp_fwd(const vsa_mlp_plan* plan, const float* x, int x_stride, int nr_points, float* y,
+                int y_stride, float* z_ws, float* packed_ws, void* stream);
+int vsa_mlp_bwd(const vsa_mlp_plan* plan, const float* x, int x_stride, int nr_points,
+                const float* dy, int dy_stride, const float* z_ws, float* dz_ws, float* a_ws,
+                float* packed_ws, float* partial_ws, float* dx, int dx_stride,
+                const vsa_mlp_grads* grads, void* stream);
+
 /* A13  Fused multi-tensor Adam step: apex.optimizers.FusedAdam(betas (0.9, 0.99), eps 1e-15,
  * weight_decay 0) of volsurfs_py/methods/base_method.py:87-94, stepped at trainer.py:278 (the
  * same update as torch.optim.Adam).  One launch for all parameter tensors:

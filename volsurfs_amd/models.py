@@ -4,17 +4,19 @@ forward signatures and module layout (`mlp.layers.<i>.weight/bias` state-dict ke
 /root/reference/volsurfs_py/models/{mlp,rgb,color_sh,nerfhash}.py, so the reference's
 checkpoints load).
 
-The encoders run on the HIP kernels of csrc/grid_encode.hip (volsurfs_amd/encodings.py).
-The MLPs are the reference's own op sequence — fp32 `torch.nn.Linear` (+bias) and exact
-GELU — i.e. plain library GEMMs (rocBLAS/hipBLASLt through torch), which is where the
-prompt's MI355X rules put un-fused fp32 GEMMs; they are not on the headline path
-(neural-texture shading never calls them).
+The encoders run on the HIP kernels of csrc/grid_encode.hip / permuto_encode.hip
+(volsurfs_amd/encodings.py).  The MLPs (fp32 Linear + bias, exact GELU) run as ONE fused
+launch on the fp32-input matrix cores (csrc/mlp_f32.hip: `vsa_mlp_fwd` / `vsa_mlp_bwd`),
+activations never leaving registers between layers; `MLP.fused = False` selects the
+reference's own torch op sequence (library GEMMs), which the tests compare against.
 """
 import copy
+import ctypes
 
 import numpy as np
 import torch
 
+from . import _lib
 from .encodings import SHEncoder, get_encoder
 from .neural_textures import MAX_DEG  # noqa: F401  (re-exported for symmetry)
 
@@ -40,6 +42,96 @@ class _LinearBiasByGemv(torch.autograd.Function):
         return gx, gw, gb
 
 
+MLP_MAX_LAYERS = 6
+
+
+class MlpPlan(ctypes.Structure):
+    """Mirror of `vsa_mlp_plan` (include/volsurfs_hip.h)."""
+    _fields_ = [("n_layers", ctypes.c_int32), ("dims", ctypes.c_int32 * (MLP_MAX_LAYERS + 1)),
+                ("w", ctypes.c_void_p * MLP_MAX_LAYERS), ("b", ctypes.c_void_p * MLP_MAX_LAYERS)]
+
+
+class MlpGrads(ctypes.Structure):
+    """Mirror of `vsa_mlp_grads`."""
+    _fields_ = [("dw", ctypes.c_void_p * MLP_MAX_LAYERS), ("db", ctypes.c_void_p * MLP_MAX_LAYERS)]
+
+
+def _mlp_plan(weights, biases):
+    p = MlpPlan()
+    p.n_layers = len(weights)
+    p.dims[0] = weights[0].shape[1]
+    for l, w in enumerate(weights):
+        p.dims[l + 1] = w.shape[0]
+        p.w[l] = w.data_ptr()
+        p.b[l] = biases[l].data_ptr() if biases[l] is not None else None
+    return p
+
+
+def fused_mlp_supported(dims, x):
+    """csrc/mlp_f32.hip: <= 6 linear layers, widths <= 128, hidden widths multiples of 32."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and 1 <= len(dims) - 1 <= MLP_MAX_LAYERS
+            and all(1 <= d <= 128 for d in dims) and all(d % 32 == 0 for d in dims[1:-1]))
+
+
+class _FusedMLP(torch.autograd.Function):
+    """y = W_L(... GELU(W_1 x + b_1) ...) + b_L in ONE launch on the fp32 matrix cores
+    (vsa_mlp_fwd); backward = vsa_mlp_bwd (data-gradient chain, weight gradients, bias sums).
+    params = (w_0, b_0 or None, w_1, b_1, ...)."""
+
+    @staticmethod
+    def forward(ctx, x, has_bias, *params):
+        nl = len(params) // 2 if has_bias else len(params)
+        ws = [params[2 * l] if has_bias else params[l] for l in range(nl)]
+        bs = [params[2 * l + 1] if has_bias else None for l in range(nl)]
+        ws = [w.contiguous() for w in ws]
+        bs = [b.contiguous() if b is not None else None for b in bs]
+        x = x.contiguous()
+        M = x.shape[0]
+        plan = _mlp_plan(ws, bs)
+        sizes = [ctypes.c_longlong() for _ in range(3)]
+        _lib.call("vsa_mlp_workspace", ctypes.byref(plan), ctypes.c_longlong(M),
+                  *[ctypes.byref(v) for v in sizes])
+        need = x.requires_grad or any(p_.requires_grad for p_ in params if p_ is not None)
+        dev = x.device
+        packed = torch.empty(max(sizes[0].value, 1), device=dev)
+        z = torch.empty(max(sizes[1].value, 1), device=dev) if need else None
+        y = torch.empty(M, ws[-1].shape[0], device=dev)
+        _lib.call("vsa_mlp_fwd", ctypes.byref(plan), x, x.shape[1], M, y, y.shape[1], z, packed,
+                  _lib.stream_ptr())
+        ctx.save_for_backward(x, z, *ws, *[b for b in bs if b is not None])
+        ctx.meta = (nl, has_bias, sizes[1].value, sizes[2].value)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        nl, has_bias, act_n, part_n = ctx.meta
+        x, z = ctx.saved_tensors[:2]
+        ws = list(ctx.saved_tensors[2:2 + nl])
+        bs = list(ctx.saved_tensors[2 + nl:]) if has_bias else [None] * nl
+        M, dev = x.shape[0], x.device
+        plan = _mlp_plan(ws, bs)
+        gy = gy.contiguous()
+        dz, a = torch.empty(max(act_n, 1), device=dev), torch.empty(max(act_n, 1), device=dev)
+        packed = torch.empty(sum(((w.shape[0] + 31) // 32) * ((w.shape[1] + 31) // 32) * 1024 for w in ws),
+                             device=dev)
+        partial = torch.empty(max(part_n, 1), device=dev)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = [torch.empty_like(w) for w in ws]
+        gb = [torch.empty_like(b) if b is not None else None for b in bs]
+        grads = MlpGrads()
+        for l in range(nl):
+            grads.dw[l] = gw[l].data_ptr()
+            grads.db[l] = gb[l].data_ptr() if gb[l] is not None else None
+        _lib.call("vsa_mlp_bwd", ctypes.byref(plan), x, x.shape[1], M, gy, gy.shape[1], z, dz, a,
+                  packed, partial, dx, x.shape[1], ctypes.byref(grads), _lib.stream_ptr())
+        out = []
+        for l in range(nl):
+            out.append(gw[l])
+            if has_bias:
+                out.append(gb[l])
+        return (dx, None, *out)
+
+
 class MLP(torch.nn.Module):
     """models/mlp.py:8-69: Linear + GELU stack, optional linear last layer."""
 
@@ -60,7 +152,18 @@ class MLP(torch.nn.Module):
             in_channels_ = cur
         self.layers = torch.nn.Sequential(*modules)
 
+    fused = True      # class-wide switch: False = the torch op sequence (tests compare the two)
+
     def forward(self, x):
+        linears = [m for m in self.layers if isinstance(m, torch.nn.Linear)]
+        dims = [linears[0].in_features] + [m.out_features for m in linears]
+        if MLP.fused and self.last_layer_linear and fused_mlp_supported(dims, x):
+            params = []
+            for m in linears:
+                params.append(m.weight)
+                if self.bias:
+                    params.append(m.bias)
+            return _FusedMLP.apply(x, bool(self.bias), *params)
         for layer in self.layers:
             if isinstance(layer, torch.nn.Linear) and layer.bias is not None and x.dim() == 2 \
                     and torch.is_grad_enabled():
