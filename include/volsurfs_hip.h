@@ -321,6 +321,11 @@ int vsa_grid_encode_fwd(const vsa_grid_plan* plan, const float* tables, const fl
 /* grad_tables (fp32, same shape as tables) += transpose-interpolation of g_out. */
 int vsa_grid_encode_bwd(const vsa_grid_plan* plan, const float* x, const float* g_out,
                         int nr_points, float* grad_tables, void* stream);
+/* The same gradients for LARGE batches without memory-side atomics: workgroups own (level, 2^14-entry
+ * slice) accumulators in LDS and scan the samples (csrc/grid_encode.hip).  workspace: nr_points *
+ * 2 * n_levels floats (the output gradient re-laid level-major). */
+int vsa_grid_encode_bwd_sliced(const vsa_grid_plan* plan, const float* x, const float* g_out,
+                               int nr_points, float* grad_tables, float* workspace, void* stream);
 /* out [nr_dirs][(degree+1)^2]: SH basis of each direction, degree 0..4. */
 int vsa_sh_encode(const float* dirs, int nr_dirs, int degree, float* out, void* stream);
 

@@ -20,6 +20,7 @@ import torch
 from . import _lib
 
 GRID_MAX_LEVELS = 32
+SLICED_BWD_MIN_POINTS = 1 << 18     # below this the plain atomic scatter is cheaper (fixed scan cost)
 
 
 class GridPlan(ctypes.Structure):
@@ -65,8 +66,15 @@ class _GridEncode(torch.autograd.Function):
     def backward(ctx, g_out):
         (x,) = ctx.saved_tensors
         g_tables = torch.zeros(ctx.shape, device=x.device)
-        _lib.call("vsa_grid_encode_bwd", ctypes.byref(ctx.plan), x, g_out.contiguous(), x.shape[0],
-                  g_tables, _lib.stream_ptr())
+        g_out = g_out.contiguous()
+        if x.shape[0] >= SLICED_BWD_MIN_POINTS:
+            # large batches: LDS-resident table slices instead of memory-side float atomics
+            ws = torch.empty(g_out.numel(), device=x.device)
+            _lib.call("vsa_grid_encode_bwd_sliced", ctypes.byref(ctx.plan), x, g_out, x.shape[0],
+                      g_tables, ws, _lib.stream_ptr())
+        else:
+            _lib.call("vsa_grid_encode_bwd", ctypes.byref(ctx.plan), x, g_out, x.shape[0],
+                      g_tables, _lib.stream_ptr())
         return g_tables, None, None      # positions carry no gradient on this path
 
 
