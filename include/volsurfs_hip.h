@@ -322,8 +322,8 @@ int vsa_grid_encode_fwd(const vsa_grid_plan* plan, const float* tables, const fl
 int vsa_grid_encode_bwd(const vsa_grid_plan* plan, const float* x, const float* g_out,
                         int nr_points, float* grad_tables, void* stream);
 /* The same gradients for LARGE batches without memory-side atomics: workgroups own (level, 2^14-entry
- * slice) accumulators in LDS and scan the samples (csrc/grid_encode.hip).  workspace: nr_points *
- * 2 * n_levels floats (the output gradient re-laid level-major). */
+ * slice) fixed-point accumulators in LDS and scan the samples (csrc/grid_encode.hip).  workspace:
+ * nr_points * 2 * n_levels + 32 floats (the output gradient re-laid level-major + max|g| per level). */
 int vsa_grid_encode_bwd_sliced(const vsa_grid_plan* plan, const float* x, const float* g_out,
                                int nr_points, float* grad_tables, float* workspace, void* stream);
 /* out [nr_dirs][(degree+1)^2]: SH basis of each direction, degree 0..4. */

@@ -46,7 +46,9 @@ __device__ __forceinline__ unsigned grid_index(const GridLevel& g, const unsigne
 #pragma unroll
     for (int d = 0; d < D; ++d) index ^= c[d] * GRID_PRIMES[d];
   }
-  return index % g.size;
+  // hashed levels have power-of-two sizes: a mask instead of a ~35-instruction 32-bit modulo
+  // (uniform per level; the general form remains for the small dense levels)
+  return (g.size & (g.size - 1)) == 0 ? (index & (g.size - 1)) : index % g.size;
 }
 
 template <int D>
@@ -136,62 +138,170 @@ __global__ __launch_bounds__(256) void grid_encode_bwd_kernel(vsa_grid_plan plan
 // The kernel above is bound by the request rate of the memory-side float-atomic path (measured:
 // 403 M requests -> 26 ms for the 2.1 M samples x 24 levels of a background batch, ~16 G
 // requests/s whatever the occupancy).  A 2^18-entry level does not fit the LDS, but a SLICE of it
-// does: a workgroup owns (level, slice of 2^14 entries = 128 KiB of float2 sums in LDS), scans
-// its share of ALL samples, recomputes their corner indices and accumulates only the corners
-// that fall into its slice (ds_add_f32), then flushes the slice once.  The index arithmetic is
-// redone 16x — VALU work the chip has to spare (~3 ms) — against 26 ms of atomics.
-// g_lm: the output gradient re-laid level-major [L][B] float2 (grid_transpose_kernel) so that a
-// workgroup streams its level's gradients contiguously.
-constexpr int GS_SLICE_LOG2 = 14;
+// does: a workgroup owns (level, slice of 2^13 entries), scans its share of ALL samples,
+// recomputes their corner indices and accumulates only the corners that fall into its slice,
+// then flushes the slice once.  The index arithmetic is redone 32x — VALU work the chip has to
+// spare — against 26 ms of atomics.  The LDS accumulators are 64-bit FIXED POINT (ds_add_u64:
+// LDS float atomics are ~20x slower on gfx950, tools/ubench/lds_atomics.hip; first version of this
+// kernel with ds_add_f32: 27.7 ms), scaled by a power of two from max|g| so that
+// 8 B contributions cannot overflow: resolution 2^-38 of the level's largest gradient, i.e. finer
+// than the fp32 sums it replaces for any level within 2^-14 of that, and independent of the summation order (bit-reproducible).
+// g_lm: the output gradient re-laid level-major [L][B] float2 (grid_transpose_kernel, which also
+// reduces max|g|) so that a workgroup streams its level's gradients contiguously.
+constexpr int GS_SLICE_LOG2 = 13;
 constexpr int GS_SLICE = 1 << GS_SLICE_LOG2;
 constexpr int GS_THREADS = 1024;
 
-__global__ void grid_transpose_kernel(const float2* __restrict__ g_out, int B, int L,
-                                      float2* __restrict__ g_lm) {
+__global__ __launch_bounds__(256) void grid_transpose_kernel(const float2* __restrict__ g_out, int B,
+                                                             int L, float2* __restrict__ g_lm,
+                                                             unsigned* __restrict__ max_bits) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long long)B * L) return;
-  const long long b = t / L;
-  const int l = (int)(t - b * L);
-  g_lm[(long long)l * B + b] = g_out[t];
+  float m = 0.f;
+  if (t < (long long)B * L) {
+    const long long b = t / L;
+    const int l = (int)(t - b * L);
+    const float2 g = g_out[t];
+    g_lm[(long long)l * B + b] = g;
+    m = fmaxf(fabsf(g.x), fabsf(g.y));
+    if (!(m < INFINITY)) m = 0.f;
+  }
+  // max |g| over everything: wave reduction, one atomic per wave (non-negative floats order like
+  // their bit patterns)
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  // (one atomic per wave on ONE address serialises at the memory side: 8.9 ms.  Only a wave that
+  // would RAISE the maximum it currently sees issues one — a handful per launch)
+  if ((threadIdx.x & 63) == 0 && m > 0.f &&
+      __float_as_uint(m) > __hip_atomic_load(max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(max_bits, __float_as_uint(m));
+}
+
+// Only ~1 corner in 32 falls into a workgroup's slice, and an LDS atomic INSTRUCTION costs its
+// ~36 cycles whether 2 or 64 of its lanes are active (second version of this kernel: one masked
+// ds_add_u64 pair per corner, 20.9 ms, bound by the 352 M LDS-atomic instructions).  So the
+// in-slice contributions of a wave are first compacted: each corner's in-slice lanes append
+// (entry, w g_x, w g_y) to a per-wave ring buffer in LDS (ballot / mbcnt give the positions),
+// and whenever 64 are queued the wave adds them with ONE fully active atomic pair.
+constexpr int GS_QUEUE = 128;                      // ring entries per wave (a corner adds <= 64)
+
+// round(v) as a two's-complement 64-bit integer for |v| < 2^62, from two native 32-bit
+// conversions (the float -> int64 conversion itself is a ~30-instruction software sequence):
+// v = hi * 2^32 + lo with hi = floor(v / 2^32) exact (a power-of-two scaling), lo in [0, 2^32)
+__device__ __forceinline__ unsigned long long fixed62(float v) {
+  const float r = rintf(v);
+  const float hi = floorf(r * 2.3283064365386963e-10f);
+  const float lo = r - hi * 4294967296.0f;            // exact: r has 24 significant bits
+  return ((unsigned long long)(unsigned)(int)hi << 32) + (unsigned long long)(unsigned)lo;
 }
 
 template <int D>
 __global__ __launch_bounds__(GS_THREADS) void grid_encode_bwd_sliced_kernel(
-    vsa_grid_plan plan, const float* __restrict__ x, const float2* __restrict__ g_lm, int B,
-    float* __restrict__ g_tables) {
-  extern __shared__ float s_acc[];                 // [GS_SLICE][2]
+    vsa_grid_plan plan, const float* __restrict__ x, const float2* __restrict__ g_lm,
+    const unsigned* __restrict__ max_bits, int count_bits, int B, float* __restrict__ g_tables) {
+  extern __shared__ unsigned long long s_acc[];    // [GS_SLICE][2] fixed point, then the queues
   const int slice = blockIdx.x, l = blockIdx.y;
   const GridLevel g = grid_level(plan, l);
   if ((unsigned)slice << GS_SLICE_LOG2 >= g.size) return;
-  for (int i = threadIdx.x; i < 2 * GS_SLICE; i += GS_THREADS) s_acc[i] = 0.f;
+  const float gmax = __uint_as_float(max_bits[0]);
+  if (!(gmax > 0.f)) return;                         // no gradient at all
+  int e;
+  frexpf(gmax, &e);                                  // gmax < 2^e
+  const float scale = ldexpf(1.0f, 62 - count_bits - e);
+  for (int i = threadIdx.x; i < 2 * GS_SLICE; i += GS_THREADS) s_acc[i] = 0ull;
   __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned* s_q = reinterpret_cast<unsigned*>(s_acc + 2 * GS_SLICE) + wave * (GS_QUEUE * 3);
+  int q_head = 0, q_count = 0;                       // wave-uniform
+  auto drain = [&](int n) {
+    __builtin_amdgcn_wave_barrier();
+    if (lane < n) {
+      const int pos = (q_head + lane) & (GS_QUEUE - 1);
+      const unsigned ent = s_q[3 * pos];
+      const float vx = __uint_as_float(s_q[3 * pos + 1]), vy = __uint_as_float(s_q[3 * pos + 2]);
+      atomicAdd(s_acc + 2 * ent, fixed62(vx * scale));
+      atomicAdd(s_acc + 2 * ent + 1, fixed62(vy * scale));
+    }
+    __builtin_amdgcn_wave_barrier();
+    q_head = (q_head + n) & (GS_QUEUE - 1);
+    q_count -= n;
+  };
   const long long per = (B + gridDim.z - 1) / gridDim.z;
   const long long b0 = blockIdx.z * per, b1 = min((long long)B, b0 + per);
   const float2* gl = g_lm + (long long)l * B;
-  for (long long b = b0 + threadIdx.x; b < b1; b += GS_THREADS) {
-    const float2 go = gl[b];
-    if (go.x == 0.f && go.y == 0.f) continue;
-    const GridCell<D> cell = grid_cell<D>(g, x + b * D);
+  // A lane takes GS_PER consecutive samples per trip and the NEXT trip's samples are loaded before
+  // this trip's arithmetic: ~5 KiB per wave in flight.  (PMC of the versions with one sample per
+  // trip: 56 % of the wave cycles waiting — the ~3 us load latency of 256 workgroups streaming
+  // 430 MB exceeds a trip's ~1.2 us of arithmetic, so a single sample of prefetch hid nothing.)
+  constexpr int GS_PER = 8;
+  auto load_samples = [&](long long bfirst, float2 go[GS_PER], float xv[GS_PER][D]) {
 #pragma unroll
-    for (int corner = 0; corner < (1 << D); ++corner) {
-      unsigned c[D];
+    for (int j = 0; j < GS_PER; ++j) {
+      const long long b = bfirst + j;
+      go[j] = make_float2(0.f, 0.f);
 #pragma unroll
-      for (int d = 0; d < D; ++d) c[d] = cell.c[d] + ((corner >> d) & 1);
-      const unsigned idx = grid_index<D>(g, c);
-      if ((idx >> GS_SLICE_LOG2) == (unsigned)slice) {
-        const float w = corner_weight<D>(cell, corner);
-        float* e = s_acc + 2 * (idx & (GS_SLICE - 1));
-        atomicAdd(e, w * go.x);
-        atomicAdd(e + 1, w * go.y);
+      for (int d = 0; d < D; ++d) xv[j][d] = 0.f;
+      if (b < b1) {
+        go[j] = gl[b];
+#pragma unroll
+        for (int d = 0; d < D; ++d) xv[j][d] = x[b * D + d];
+      }
+    }
+  };
+  float2 go_n[GS_PER];
+  float x_n[GS_PER][D];
+  constexpr long long GS_STEP = (long long)GS_THREADS * GS_PER;
+  load_samples(b0 + ((long long)wave * 64 + lane) * GS_PER, go_n, x_n);
+  for (long long base = b0 + (long long)wave * 64 * GS_PER; base < b1; base += GS_STEP) {   // wave-uniform trips
+    float2 go_c[GS_PER];
+    float x_c[GS_PER][D];
+#pragma unroll
+    for (int j = 0; j < GS_PER; ++j) {
+      go_c[j] = go_n[j];
+#pragma unroll
+      for (int d = 0; d < D; ++d) x_c[j][d] = x_n[j][d];
+    }
+    load_samples(base + GS_STEP + (long long)lane * GS_PER, go_n, x_n);
+#pragma unroll 1
+    for (int j = 0; j < GS_PER; ++j) {
+      const float2 go = go_c[j];
+      const bool active = go.x != 0.f || go.y != 0.f;
+      if (!__ballot(active)) continue;
+      const GridCell<D> cell = grid_cell<D>(g, x_c[j]);
+#pragma unroll
+      for (int corner = 0; corner < (1 << D); ++corner) {
+        unsigned idx = 0;
+        bool in = false;
+        if (active) {
+          unsigned c[D];
+#pragma unroll
+          for (int d = 0; d < D; ++d) c[d] = cell.c[d] + ((corner >> d) & 1);
+          idx = grid_index<D>(g, c);
+          in = (idx >> GS_SLICE_LOG2) == (unsigned)slice;
+        }
+        const unsigned long long mask = __ballot(in);
+        if (mask) {
+          if (in) {
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                       __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+            const int pos = (q_head + q_count + rank) & (GS_QUEUE - 1);
+            const float w = corner_weight<D>(cell, corner);
+            s_q[3 * pos] = idx & (GS_SLICE - 1);
+            s_q[3 * pos + 1] = __float_as_uint(w * go.x);
+            s_q[3 * pos + 2] = __float_as_uint(w * go.y);
+          }
+          q_count += __popcll(mask);
+          if (q_count >= 64) drain(64);
+        }
       }
     }
   }
+  if (q_count > 0) drain(q_count);
   __syncthreads();
   float* out = g_tables + 2ll * (g.offset + ((unsigned)slice << GS_SLICE_LOG2));
   const int n = min(GS_SLICE, (int)(g.size - ((unsigned)slice << GS_SLICE_LOG2)));
+  const double inv = 1.0 / (double)scale;
   for (int i = threadIdx.x; i < 2 * n; i += GS_THREADS) {
-    const float v = s_acc[i];
-    if (v != 0.f) atomicAdd(out + i, v);           // += semantics; other sample chunks add theirs
+    const long long v = (long long)s_acc[i];
+    if (v != 0) atomicAdd(out + i, (float)((double)v * inv));   // += semantics; other sample chunks add theirs
   }
 }
 
@@ -300,13 +410,16 @@ extern "C" int vsa_grid_encode_bwd_sliced(const vsa_grid_plan* plan, const float
   if (!x || !g_out || !grad_tables || !workspace) return VSA_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int L = plan->n_levels;
+  // workspace: [L][B] float2, then L words of max|g| bits
+  unsigned* level_max = reinterpret_cast<unsigned*>(workspace + 2ll * nr_points * L);
+  VSA_HIP_TRY(hipMemsetAsync(level_max, 0, sizeof(unsigned) * VSA_GRID_MAX_LEVELS, st));
   hipLaunchKernelGGL(grid_transpose_kernel, dim3(vsa_div_up((long long)nr_points * L, 256)), dim3(256), 0,
                      st, reinterpret_cast<const float2*>(g_out), nr_points, L,
-                     reinterpret_cast<float2*>(workspace));
+                     reinterpret_cast<float2*>(workspace), level_max);
   int max_size = 1;
   for (int l = 0; l < L; ++l) max_size = plan->level_size[l] > max_size ? plan->level_size[l] : max_size;
   const int slices = (max_size + GS_SLICE - 1) >> GS_SLICE_LOG2;
-  const size_t lds = 2ull * GS_SLICE * sizeof(float);
+  const size_t lds = 2ull * GS_SLICE * sizeof(unsigned long long) + (GS_THREADS / 64) * GS_QUEUE * 3 * sizeof(unsigned);
   static bool attr_set = false;
   if (!attr_set) {
     VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(grid_encode_bwd_sliced_kernel<2>),
@@ -319,16 +432,20 @@ extern "C" int vsa_grid_encode_bwd_sliced(const vsa_grid_plan* plan, const float
   int nr_cus = 0;
   rc = vsa_cu_count(&nr_cus);
   if (rc) return rc;
-  int chunks = (3 * nr_cus + slices * L - 1) / (slices * L);
+  int chunks = (6 * nr_cus + slices * L - 1) / (slices * L);
   if (chunks < 1) chunks = 1;
+  // an entry receives at most 2^D corners of every sample of a chunk
+  long long worst = ((long long)(nr_points + chunks - 1) / chunks) << plan->n_dims;
+  int count_bits = 1;
+  while ((1ll << count_bits) < worst) ++count_bits;
   dim3 grid(slices, L, chunks);
   const float2* g_lm = reinterpret_cast<const float2*>(workspace);
   if (plan->n_dims == 2)
     hipLaunchKernelGGL(grid_encode_bwd_sliced_kernel<2>, grid, dim3(GS_THREADS), lds, st, *plan, x, g_lm,
-                       nr_points, grad_tables);
+                       level_max, count_bits, nr_points, grad_tables);
   else
     hipLaunchKernelGGL(grid_encode_bwd_sliced_kernel<3>, grid, dim3(GS_THREADS), lds, st, *plan, x, g_lm,
-                       nr_points, grad_tables);
+                       level_max, count_bits, nr_points, grad_tables);
   VSA_RETURN_LAUNCH_STATUS();
 }
 

@@ -69,7 +69,7 @@ class _GridEncode(torch.autograd.Function):
         g_out = g_out.contiguous()
         if x.shape[0] >= SLICED_BWD_MIN_POINTS:
             # large batches: LDS-resident table slices instead of memory-side float atomics
-            ws = torch.empty(g_out.numel(), device=x.device)
+            ws = torch.empty(g_out.numel() + 32, device=x.device)
             _lib.call("vsa_grid_encode_bwd_sliced", ctypes.byref(ctx.plan), x, g_out, x.shape[0],
                       g_tables, ws, _lib.stream_ptr())
         else:
