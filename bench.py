@@ -58,7 +58,7 @@ def parse():
     args = ap.parse_args()
     training = args.workload.startswith("train")
     if args.steps is None:
-        args.steps = 500 if training else 20
+        args.steps = 500 if training else (3 if args.workload == "dtu" else 20)
     if args.warmup is None:
         args.warmup = 100 if training else 5
     return args
@@ -205,6 +205,71 @@ def run_train(args, world, rank, dev, dist):
         print(json.dumps(out))
 
 
+def run_dtu(args, world, rank, dev, dist):
+    """BASELINE configs[3]'s per-GPU work: one 1600x1200 frame of a K=5 scene WITH the learned
+    contracted background (`bg_color=None`: NerfHash field, 32 inverse-depth samples per ray through
+    the packed ops; volsurfs.py:686-702, utils/background.py:31-141), forward + L1 + backward +
+    fused Adam, in batches of 65 536 rays.  A step = one whole frame (30 batches)."""
+    from volsurfs_amd.background import BoundingSphere
+    from volsurfs_amd.camera import pinhole_rays
+    from volsurfs_amd.mesh import nested_shells
+    from volsurfs_amd.methods import VolSurfs
+    from volsurfs_amd.models import NerfHash
+    from volsurfs_amd.trainer import train_step
+    H, W, batch = 1200, 1600, 65536
+    meshes = nested_shells(K=args.shells, subdiv=args.subdiv, device=dev)
+    bg = NerfHash(3, "gridhash", "spherical_harmonics", device=dev)
+    m = VolSurfs(meshes, max_rays=batch, bg_color=None, bg_model=bg,
+                 bounding_primitive=BoundingSphere(0.5), nr_samples_bg=32, nr_warmup_iters=0)
+    m.init_optim()
+    o, d = pinhole_rays(H, W, focal=1111.1 * H / 800.0, cam_pos=(0.0, 0.0, -1.5), device=dev)
+    g = torch.Generator(device=dev).manual_seed(42 + rank)
+    gt = torch.rand(H * W, 3, device=dev, generator=g)
+    perm = torch.randperm(H * W, device=dev, generator=g)          # training draws random pixels
+    o, d, gt = o[perm].contiguous(), d[perm].contiguous(), gt[perm].contiguous()
+    N = H * W
+    state = {"it": 0}
+
+    def frame():
+        for a in range(0, N, batch):
+            m.grad_scale = float(min(batch, N - a))
+            train_step(m, o[a:a + batch], d[a:a + batch], gt[a:a + batch], iter_nr=state["it"],
+                       is_first_iter=state["it"] == 0, world=world, sync_losses=False)
+            state["it"] += 1
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, min(args.warmup, 2))):
+        frame()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    if rank == 0:
+        nb = (N + batch - 1) // batch
+        print(json.dumps({
+            "metric": "Mrays/s (fwd+bwd+Adam) at 1600x1200, K=5 shells + learned background",
+            "value": N * world * args.steps / dt / 1e6, "unit": "Mrays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": min(args.warmup, 2), "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_batch": dt / args.steps / nb * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 (background field) + f16 neural textures", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[3] per-GPU work: {W}x{H} frame, K={args.shells} subdiv-{args.subdiv} "
+                                   "shells with SH neural textures, NerfHash background (3-D hash grid 24x2 2^18 + "
+                                   "MLPs 51-64-64-64-65 / 80-64-64-3 on the fp32 matrix cores), 32 contracted samples "
+                                   f"per ray through the packed ops, {nb} batches of {batch} random pixels per frame",
+                       "bg_samples_per_frame": N * 32, "parallelism": f"data-parallel x{world}"}}))
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -223,8 +288,8 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", dev_index)
     torch.manual_seed(42 + rank)
-    if args.workload in ("train", "train-permuto"):
-        run_train(args, world, rank, dev, dist)
+    if args.workload in ("train", "train-permuto", "dtu"):
+        (run_dtu if args.workload == "dtu" else run_train)(args, world, rank, dev, dist)
         if dist is not None:
             dist.destroy_process_group()
         return
