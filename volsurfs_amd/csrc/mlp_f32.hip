@@ -324,6 +324,9 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_wgrad_kernel(
   // (one load -> one MFMA per trip left every wave waiting out a full memory latency: 11.6 ms
   // for the 2.1 M samples of a background batch, 20x the MFMA time)
   constexpr int WG_UNROLL = 8;
+  // a wave's pairs are wave, wave + 4, ...: for 1, 2 or 4 input blocks they all share ONE input
+  // block (4 is a multiple of inb), so the B operand is loaded once per point pair, not per pair
+  const bool shared_b = (4 % inb) == 0;
   for (long long p0 = p_begin; p0 < p_end; p0 += 2 * WG_UNROLL) {
     float av[WG_UNROLL][MLP_MAXB], bv[WG_UNROLL][MLP_MAXB];
 #pragma unroll
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_wgrad_kernel(
         if (pm[q] >= 0) {
           const int n = 32 * pm[q] + i, k = 32 * pb[q] + i;
           if (ok && n < out) av[u][q] = dop[pt * d_stride + n];
-          if (ok && k < in) bv[u][q] = aop[pt * a_stride + k];
+          if (ok && k < in && (q == 0 || !shared_b)) bv[u][q] = aop[pt * a_stride + k];
         }
       }
     }
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_wgrad_kernel(
 #pragma unroll
       for (int q = 0; q < MLP_MAXB; ++q) {
         if (pm[q] >= 0) {
-          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][q], bv[u][q], acc[q], 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][q], shared_b ? bv[u][0] : bv[u][q], acc[q], 0, 0, 0);
           bsum[q] += av[u][q];
         }
       }

@@ -288,6 +288,12 @@ __device__ __forceinline__ void prefetch_features(const vsa_nt_plan& plan,
 //                   gradients (operands by ds_read_b64_tr_b16), dF stores, sum|dF|
 // Each role stays below 256 registers (MFMA results in plain VGPRs), hand-off is ONE
 // workgroup barrier per tile over a double-buffered image set.
+#ifndef NT_PC_DW3_LATE
+#define NT_PC_DW3_LATE 0
+#endif
+#ifndef NT_PC_PRIO
+#define NT_PC_PRIO 0          /* issue priority: 0 consumer raised, 1 producer raised, 2 none, 3 producer at 3 */
+#endif
 constexpr int PC_BLOCK = 512;
 constexpr int PC_PAIRS = 4;
 constexpr int S64 = 68, S32 = 40;   // row strides (halfs): 136 B (8-B aligned, bank-spread), 80 B (16-B aligned)
@@ -423,6 +429,11 @@ __device__ __forceinline__ void pc_run(
 #endif
 
   if (producer) {
+#if NT_PC_PRIO == 1
+    __builtin_amdgcn_s_setprio(1);
+#elif NT_PC_PRIO == 3
+    __builtin_amdgcn_s_setprio(3);
+#endif
     auto load_grows = [&](int slot, half4_t gr[4]) {   // raw f16: converting here would wait for the prefetch
       const bool ok = slot < wk.last;
 #pragma unroll
@@ -448,6 +459,21 @@ __device__ __forceinline__ void pc_run(
 #endif
     for (int it = 0; it <= iters; ++it) {
       STAMP(q0);
+#if NT_PC_DW3_LATE
+      // dW3 of the PREVIOUS tile, from the image set this wave wrote before the last barrier (the
+      // consumer reads the same set meanwhile): no wait on this trip's own LDS stores, and the
+      // matrix pipe has independent work while the prefetched features arrive
+      if (it > 0) {
+        const _Float16* prev = pair + ((it - 1) & 1) * SET_HALFS;
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+          const half8_t a3 = read_tr_s<S32>(prev + SET_DOUT, 0, sx, lane);
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+            gW3[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3, read_tr_s<S64>(prev + SET_H2, 32 * m, sx, lane), gW3[m], 0, 0, 0);
+        }
+      }
+#endif
       if (it < iters) {
         const int slot = wk.first + (pr + it * PC_PAIRS) * 32 + p;
         _Float16* set = pair + (it & 1) * SET_HALFS;
@@ -499,6 +525,7 @@ __device__ __forceinline__ void pc_run(
 #pragma unroll
         for (int sx = 0; sx < 2; ++sx)
           *reinterpret_cast<half8_t*>(set + SET_X + p * S32 + 16 * sx + 8 * h) = bx[sx];
+#if !NT_PC_DW3_LATE
         // ---- dW3 += dOut . H2^T  (transposed reads of this wave's own, just-written images)
 #pragma unroll
         for (int sx = 0; sx < 2; ++sx) {
@@ -507,6 +534,7 @@ __device__ __forceinline__ void pc_run(
           for (int m = 0; m < 2; ++m)
             gW3[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3, read_tr_s<S64>(set + SET_H2, 32 * m, sx, lane), gW3[m], 0, 0, 0);
         }
+#endif
       }
       STAMP(q1);
       pc_barrier();
@@ -548,7 +576,9 @@ __device__ __forceinline__ void pc_run(
     float16_t dabs = {0};   // per-lane sum |dF| per feature row (hash-grad fixed-point bound)
     // the consumer is the longer stream AND the later-dispatched wave of its SIMD (the
     // arbitration loser at equal priority): raise it once, statically
+#if NT_PC_PRIO == 0
     __builtin_amdgcn_s_setprio(1);
+#endif
 #ifdef NT_STAMP
     unsigned long long tw_ = 0, tb_ = 0, q0, q1, q2;
 #endif

@@ -184,21 +184,30 @@ class VolSurfs(torch.nn.Module):
         surfs_rgb = torch.zeros(N, K, 3, device=dev)
         surfs_alpha = torch.zeros(N, K, device=dev)
         surfs_normals = torch.zeros(N, K, 3, device=dev)
+        # ONE compaction for all shells (the reference synchronises per shell: `any_hit`, then a
+        # boolean-mask gather per buffer, volsurfs.py:481-507): the hits sorted by shell, and the
+        # per-shell counts read back once
+        shell_of, ray_of = (hit_slot >= 0).nonzero(as_tuple=True)
+        counts = torch.bincount(shell_of, minlength=K).tolist()
+        off = 0
         for i in range(K):
-            hits = hit_slot[i] >= 0
-            if not bool(hits.any()):            # volsurfs.py:481 (the reference's host sync)
+            c = counts[i]
+            if c == 0:
                 continue
-            slots = hit_slot[i][hits].long()
+            rows = ray_of[off:off + c]
+            off += c
+            slots = hit_slot[i][rows].long()
             tri = self.raytracer.tris[slots]                                    # [M,12]: v0+id, e1, e2
             nrm = torch.nn.functional.normalize(torch.cross(tri[:, 4:7], tri[:, 8:11], dim=1), dim=1)
-            d = rays_d[hits]
-            pts = rays_o[hits] + hit_t[i][hits][:, None] * d
+            d = rays_d[rows]
+            pts = rays_o[rows] + hit_t[i][rows][:, None] * d
             m_rgb = self.models[f"rgb_{i}" if self.colors_indep else "rgb"]
             pred = m_rgb(points=pts, samples_dirs=d, normals=nrm, iter_nr=iter_nr)
-            surfs_rgb[hits, i] = pred[:, :3]
+            col = torch.full_like(rows, i)
+            surfs_rgb = surfs_rgb.index_put((rows, col), pred[:, :3])
             key = f"alpha_{i}" if self.alphas_indep else "alpha"
             if key not in self.models or (self.solid_inner and i == 0):
-                a = torch.ones(pts.shape[0], device=dev)
+                a = torch.ones(c, device=dev)
             else:
                 a = self.models[key](points=pts, samples_dirs=d, normals=nrm, iter_nr=iter_nr)[:, 0]
                 if self.with_alpha_decay:
@@ -206,8 +215,8 @@ class VolSurfs(torch.nn.Module):
                         dot = torch.sum(-d * nrm, dim=1).clamp(0.0, 1.0)
                         decay = torch.sigmoid(10.0 * dot) * 2.0 - 1.0
                     a = a * decay
-            surfs_alpha[hits, i] = a
-            surfs_normals[hits, i] = nrm
+            surfs_alpha = surfs_alpha.index_put((rows, col), a)
+            surfs_normals = surfs_normals.index_put((rows, col), nrm)
         return surfs_rgb, surfs_alpha, surfs_normals
 
     def render_rays(self, rays_o, rays_d, iter_nr=None, return_samples=True, **kwargs):
