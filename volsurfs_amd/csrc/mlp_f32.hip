@@ -416,6 +416,16 @@ size_t max_layer_bytes(const vsa_mlp_plan& p) {
   return mx;
 }
 
+// workgroups of the weight-gradient kernel: two per CU for large batches, fewer for small ones
+// (every workgroup writes a full set of partial blocks that mlp_reduce then has to read: 512
+// workgroups on a 10 k-point batch made the reduction the most expensive kernel of the step)
+int wgrad_total_wgs(const vsa_mlp_plan& p, long long nr_points, int nr_cus) {
+  long long n = nr_points / 512;
+  if (n < p.n_layers) n = p.n_layers;
+  if (n > 2ll * nr_cus) n = 2ll * nr_cus;
+  return (int)n;
+}
+
 WgradLayers wgrad_layers(const vsa_mlp_plan& p, int total_wgs) {
   // workgroups per layer in proportion to the layer's MFMA count (>= 1 each)
   WgradLayers wl;
@@ -457,7 +467,8 @@ extern "C" int vsa_mlp_workspace(const vsa_mlp_plan* plan, long long nr_points,
   int nr_cus = 0;
   rc = vsa_cu_count(&nr_cus);
   if (rc) return rc;
-  if (partial_floats) *partial_floats = wgrad_layers(*plan, 2 * nr_cus).part_off[plan->n_layers];
+  if (partial_floats)
+    *partial_floats = wgrad_layers(*plan, wgrad_total_wgs(*plan, nr_points, nr_cus)).part_off[plan->n_layers];
   return VSA_OK;
 }
 
@@ -523,9 +534,9 @@ extern "C" int vsa_mlp_bwd(const vsa_mlp_plan* plan, const float* x, int x_strid
   if (L > 1 || dx)
     hipLaunchKernelGGL(mlp_dgrad_kernel, dim3(grid), dim3(MLP_BLOCK), max_layer_bytes(*plan), st, *plan,
                        packed_ws, dy, dy_stride, nr_points, z_ws, dz_ws, a_ws, dx, dx_stride);
-  const WgradLayers wl = wgrad_layers(*plan, 2 * nr_cus);
+  const WgradLayers wl = wgrad_layers(*plan, wgrad_total_wgs(*plan, nr_points, nr_cus));
   hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(wl.wg_begin[L]), dim3(MLP_BLOCK), 0, st, *plan, wl, x,
                      x_stride, dy, dy_stride, nr_points, dz_ws, a_ws, partial_ws);
-  hipLaunchKernelGGL(mlp_reduce_kernel, dim3(16, L), dim3(256), 0, st, *plan, wl, partial_ws, *grads);
+  hipLaunchKernelGGL(mlp_reduce_kernel, dim3(68, L), dim3(256), 0, st, *plan, wl, partial_ws, *grads);   // 68 x 256 >= one thread per element of a 128 x 128 (+bias) layer
   VSA_RETURN_LAUNCH_STATUS();
 }
