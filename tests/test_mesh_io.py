@@ -82,3 +82,22 @@ def test_ply_round_trip_mixed_directory_and_polygons(tmp_path, binary):
                        "end_header\n0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n")
     m = load_ply(p, device="cpu")
     assert not m.has_uvs and m.faces.tolist() == [[0, 1, 2]]
+
+
+def test_run_meshes_are_copied_at_start_and_reloaded_on_resume(tmp_path):
+    """methods/volsurfs.py:75-117."""
+    from volsurfs_amd.mesh import prepare_run_meshes, save_ply
+    src, ckpt = tmp_path / "meshes_simplified_uvs", tmp_path / "run"
+    src.mkdir()
+    ckpt.mkdir()
+    save_obj(os.path.join(src, "0.01.obj"), _mesh(0.31))
+    save_ply(os.path.join(src, "-0.01.ply"), _mesh(0.29))
+    save_obj(os.path.join(src, "0.0.obj"), _mesh(0.30))
+    first = prepare_run_meshes(str(src), ["0", "2"], str(ckpt), start_iter_nr=0, device="cpu")
+    assert sorted(os.listdir(ckpt / "meshes")) == ["0.ply", "1.obj"]          # inner -> outer, renumbered
+    shutil_free = [m.vertices.norm(dim=1).mean().item() for m in first]
+    assert abs(shutil_free[0] - 0.29) < 0.01 and abs(shutil_free[1] - 0.31) < 0.01
+    resumed = prepare_run_meshes("/nonexistent", None, str(ckpt), start_iter_nr=100, device="cpu")
+    assert len(resumed) == 2
+    for a, b in zip(first, resumed):
+        assert torch.allclose(a.vertices, b.vertices, atol=1e-7) and torch.equal(a.faces, b.faces)

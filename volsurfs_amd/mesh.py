@@ -328,3 +328,22 @@ def load_meshes_indexed_from_path(meshes_indices, meshes_path, require_uvs=False
             if not m.has_uvs:
                 raise ValueError(f"mesh {n} does not have UVs")
     return (meshes, paths) if return_paths else meshes
+
+
+def prepare_run_meshes(meshes_path, meshes_indices, load_checkpoints_path, start_iter_nr=0,
+                       require_uvs=True, device="cuda"):
+    """methods/volsurfs.py:75-117: at the first iteration the shells are loaded from
+    `meshes_path` (optionally a subset by index), and copied to `<checkpoints>/meshes/<nr>.<ext>`
+    so that a run is self-contained; a resumed run (`start_iter_nr > 0`) loads them from there.
+    Returns the TensorMesh list, inner -> outer."""
+    import os
+    import shutil
+    local = os.path.join(load_checkpoints_path, "meshes")
+    if start_iter_nr == 0:
+        meshes, paths = load_meshes_indexed_from_path(meshes_indices, meshes_path, require_uvs=require_uvs,
+                                                      return_paths=True, device=device)
+        os.makedirs(local, exist_ok=True)
+        for nr, path in enumerate(paths):
+            shutil.copy(path, os.path.join(local, f"{nr}.{os.path.basename(path).split('.')[-1]}"))
+        return meshes
+    return load_meshes_indexed_from_path(None, local, require_uvs=require_uvs, device=device)

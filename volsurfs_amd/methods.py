@@ -153,6 +153,19 @@ class VolSurfs(torch.nn.Module):
         self.lr_milestones, self.nr_warmup_iters = list(lr_milestones), nr_warmup_iters
         self.scheduler_lr_decay = self.lr_scheduler = None
 
+    @classmethod
+    def from_meshes_path(cls, meshes_path, load_checkpoints_path, meshes_indices=None, start_iter_nr=0,
+                         device="cuda", **kwargs):
+        """The constructor path of methods/volsurfs.py:62-128: shells from `meshes_path` (.obj / .ply,
+        sorted by isolevel, optionally a subset), copied into `<checkpoints>/meshes/` at the first
+        iteration and loaded from there when a run resumes; then the BVHs are built."""
+        from .mesh import prepare_run_meshes
+        meshes = prepare_run_meshes(meshes_path, meshes_indices, load_checkpoints_path, start_iter_nr,
+                                    require_uvs=kwargs.get("using_neural_textures", True), device=device)
+        m = cls(meshes, **kwargs)
+        m.load_checkpoints_path = m.save_checkpoints_path = load_checkpoints_path
+        return m
+
     # -- optimiser: apex FusedAdam(betas (0.9, 0.99), eps 1e-15, wd 0) of
     # base_method.py:87-94 == Adam with the same hyper-parameters
     def init_optim(self):
