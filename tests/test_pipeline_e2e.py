@@ -36,10 +36,13 @@ def test_pipeline_matches_oracle(K, subdiv, res):
     assert (e_a > 1e-5).mean() < 0.05 and e_a.max() < 0.05
     # composited colour: BASELINE north_star asks 1e-4 on RGB; fp16 composite => the
     # bulk is bit-identical, the flipped-texel pixels move by a few fp16 ulps
+    # (measured, profiles/r02/parity_report.json: 8e-5 .. 7e-4 of the pixels above 1e-4, max 1.5e-3 —
+    # one or two fp16 ulps where an 8-bit texel flipped (rate 1.4e-5); the order-matched check of
+    # tests/test_parity_report.py, which removes the MLP's summation order, is bit-exact)
     e = np.abs(rgb.cpu().numpy() - ref["rgb"])
     assert np.median(e) == 0.0
-    assert (e <= 1e-4).mean() > 0.9
-    assert e.max() < 0.05
+    assert (e <= 1e-4).mean() > 0.99
+    assert e.max() < 1e-2
     # gradients w.r.t. every hash table and MLP (north_star: 1e-3 on grads, here as a
     # relative bound on each tensor plus direction)
     gw, gt = pipe.bank.weights.grad.cpu(), pipe.bank.tables.grad.cpu()
