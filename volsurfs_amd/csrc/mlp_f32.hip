@@ -89,11 +89,20 @@ __device__ __forceinline__ void stage_layer(const float* __restrict__ src, float
 }
 
 // ------------------------------------------------------------------ forward
+// RESIDENT: the packed weights of ALL layers fit the workgroup's LDS (networks up to 64 wide:
+// NerfHash's two MLPs are 72 and 48 KiB): they are staged once per workgroup and the layer loop has
+// no barrier at all — the four waves run their tiles independently.  Otherwise (128-wide RGB /
+// ColorSH: 152 KiB) one layer at a time is staged, two barriers per layer.
+template <bool RESIDENT>
 __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_fwd_kernel(
     vsa_mlp_plan plan, const float* __restrict__ packed, const float* __restrict__ x, int x_stride,
     int M, float* __restrict__ y, int y_stride, float* __restrict__ z_ws) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];
   const PackOffsets off = pack_offsets(plan);
+  if (RESIDENT) {
+    stage_layer(packed, s_w, off.fwd[plan.n_layers]);
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 31, h = lane >> 5;
   const int ntiles = (M + MLP_TILE - 1) / MLP_TILE;
   const int per_round = gridDim.x * 4;
@@ -118,9 +127,12 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_fwd_kernel(
     for (int l = 0; l < plan.n_layers; ++l) {
       const int in = plan.dims[l], out = plan.dims[l + 1];
       const int inb = blocks_of(in), outb = blocks_of(out);
-      __syncthreads();      // the previous layer's fragments have been read by every wave
-      stage_layer(packed + off.fwd[l], s_w, inb * outb * 1024);
-      __syncthreads();
+      if (!RESIDENT) {
+        __syncthreads();      // the previous layer's fragments have been read by every wave
+        stage_layer(packed + off.fwd[l], s_w, inb * outb * 1024);
+        __syncthreads();
+      }
+      const float* s_l = RESIDENT ? s_w + off.fwd[l] : s_w;
       f32x16 acc[MLP_MAXB];
 #pragma unroll
       for (int m = 0; m < MLP_MAXB; ++m) {
@@ -129,7 +141,7 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_fwd_kernel(
 #pragma unroll
           for (int b = 0; b < MLP_MAXB; ++b) {
             if (b < inb) {
-              const float* frag = s_w + ((m * inb + b) * 16) * 64 + lane;
+              const float* frag = s_l + ((m * inb + b) * 16) * 64 + lane;
 #pragma unroll
               for (int s = 0; s < 16; ++s)
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(frag[s * 64], act[b][s], acc[m], 0, 0, 0);
@@ -176,12 +188,17 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_fwd_kernel(
 // ------------------------------------------------------------------ backward 1: data gradients
 // dZ_l and A_l = GELU(z_l) of every hidden layer are written to dz_ws / a_ws ([point][width],
 // same offsets as z_ws); dX [point][dims[0]] optional.
+template <bool RESIDENT>
 __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_dgrad_kernel(
     vsa_mlp_plan plan, const float* __restrict__ packed_t, const float* __restrict__ dy,
     int dy_stride, int M, const float* __restrict__ z_ws, float* __restrict__ dz_ws,
     float* __restrict__ a_ws, float* __restrict__ dx, int dx_stride) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];
   const PackOffsets off = pack_offsets(plan);
+  if (RESIDENT) {
+    stage_layer(packed_t, s_w, off.fwd[plan.n_layers]);
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 31, h = lane >> 5;
   const int ntiles = (M + MLP_TILE - 1) / MLP_TILE;
   const int per_round = gridDim.x * 4;
@@ -209,9 +226,11 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_dgrad_kernel(
     for (int l = L - 1; l >= 0; --l) {
       const int in = plan.dims[l], out = plan.dims[l + 1];
       const int inb = blocks_of(in), outb = blocks_of(out);
-      __syncthreads();
-      stage_layer(packed_t + off.fwd[l], s_w, inb * outb * 1024);
-      __syncthreads();
+      if (!RESIDENT) {
+        __syncthreads();
+        stage_layer(packed_t + off.fwd[l], s_w, inb * outb * 1024);
+        __syncthreads();
+      }
       f32x16 da[MLP_MAXB];
 #pragma unroll
       for (int b = 0; b < MLP_MAXB; ++b) {
@@ -220,7 +239,7 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_dgrad_kernel(
 #pragma unroll
           for (int m = 0; m < MLP_MAXB; ++m) {
             if (m < outb) {
-              const float* frag = s_w + ((b * outb + m) * 16) * 64 + lane;
+              const float* frag = s_w + (RESIDENT ? off.fwd[l] : 0) + ((b * outb + m) * 16) * 64 + lane;
 #pragma unroll
               for (int s = 0; s < 16; ++s)
                 da[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(frag[s * 64], dz[m][s], da[b], 0, 0, 0);
@@ -285,17 +304,27 @@ struct WgradLayers {
   long long part_off[VSA_MLP_MAX_LAYERS + 1];   // offset (floats) of layer l's partial blocks
 };
 
-__global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_wgrad_kernel(
+// Operands go through LDS in 32-point tiles: the workgroup loads the tile's dZ rows and A rows
+// once (coalesced, 16 bytes per lane where the row stride allows) and its four waves read their
+// MFMA fragments from there — lane (i, kk): tile[2 s + kk][32 m + i], 32 consecutive floats per
+// half-wave, the row stride = 32 mod 64 floats so that the two halves use different banks.  The
+// next tile is fetched into registers while the current one is multiplied.  (First version: every
+// wave loaded its own fragments straight from L2, one dword per lane and MFMA: 11.6 ms for the
+// 2.1 M samples of a background batch, 2.9 ms with an 8-deep unroll; the matrix time is ~0.5 ms.)
+constexpr int WG_TP = 32;                               // points per tile
+__host__ __device__ inline int wg_stride(int width_pad) { return width_pad + ((width_pad & 63) ? 0 : 32); }
+
+__global__ __launch_bounds__(MLP_BLOCK, 3) void mlp_wgrad_kernel(
     vsa_mlp_plan plan, WgradLayers wl, const float* __restrict__ x, int x_stride,
     const float* __restrict__ dy, int dy_stride, int M, const float* __restrict__ dz_ws,
     const float* __restrict__ a_ws, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float s_t[];
   int l = 0;
   while (l + 1 < plan.n_layers && (int)blockIdx.x >= wl.wg_begin[l + 1]) ++l;
   const int L = plan.n_layers;
   const int in = plan.dims[l], out = plan.dims[l + 1];
   const int inb = blocks_of(in), outb = blocks_of(out);
   const int nwg = wl.wg_begin[l + 1] - wl.wg_begin[l], wg = blockIdx.x - wl.wg_begin[l];
-  // operand arrays of this layer
   long long zo = 0;
   for (int j = 0; j + 1 < l; ++j) zo += (long long)M * plan.dims[j + 1];     // A_{l-1} block (l >= 1)
   const float* aop = l == 0 ? x : a_ws + zo;
@@ -306,9 +335,13 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_wgrad_kernel(
   const int d_stride = l == L - 1 ? dy_stride : out;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, kk = lane >> 5;
   const int npairs = inb * outb;
-  // this workgroup's points: contiguous range, even length (two points per MFMA)
-  const long long per = ((M + nwg - 1) / nwg + 1) & ~1ll;
-  const long long p_begin = wg * per, p_end = min((long long)M, p_begin + per);
+  const int SA = wg_stride(32 * outb), SB = wg_stride(32 * inb);
+  float* s_a = s_t;                       // [WG_TP][SA]  dZ rows
+  float* s_b = s_t + WG_TP * SA;          // [WG_TP][SB]  A rows
+  // this workgroup's points: a contiguous range of whole tiles
+  const long long ntiles = (M + WG_TP - 1) / WG_TP;
+  const long long t_per = (ntiles + nwg - 1) / nwg;
+  const long long t_begin = wg * t_per, t_end = min(ntiles, t_begin + t_per);
   f32x16 acc[MLP_MAXB];
   float bsum[MLP_MAXB];
   int pm[MLP_MAXB], pb[MLP_MAXB];
@@ -320,36 +353,69 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_wgrad_kernel(
     pm[q] = pair < npairs ? pair / inb : -1;
     pb[q] = pair < npairs ? pair % inb : 0;
   }
-  // WG_UNROLL point pairs per trip: all operand loads of a trip are issued before its first MFMA
-  // (one load -> one MFMA per trip left every wave waiting out a full memory latency: 11.6 ms
-  // for the 2.1 M samples of a background batch, 20x the MFMA time)
-  constexpr int WG_UNROLL = 8;
-  // a wave's pairs are wave, wave + 4, ...: for 1, 2 or 4 input blocks they all share ONE input
-  // block (4 is a multiple of inb), so the B operand is loaded once per point pair, not per pair
-  const bool shared_b = (4 % inb) == 0;
-  for (long long p0 = p_begin; p0 < p_end; p0 += 2 * WG_UNROLL) {
-    float av[WG_UNROLL][MLP_MAXB], bv[WG_UNROLL][MLP_MAXB];
+  // tile loader: element e of the [WG_TP][width_pad] tile, 4 consecutive columns per lane
+  constexpr int LD_MAX = (WG_TP * 32 * MLP_MAXB) / (4 * MLP_BLOCK);      // float4 per thread and operand: 4
+  float4 ra[LD_MAX], rb[LD_MAX];
+  auto fetch = [&](long long tile, const float* src, int stride, int width, int wpad, float4 r[LD_MAX]) {
+    const long long p0 = tile * WG_TP;
+    const int nvec = WG_TP * wpad / 4;
+    const bool vec_ok = ((stride & 3) == 0) && ((reinterpret_cast<size_t>(src) & 15) == 0);
 #pragma unroll
-    for (int u = 0; u < WG_UNROLL; ++u) {
-      const long long pt = p0 + 2 * u + kk;
-      const bool ok = pt < p_end;
-#pragma unroll
-      for (int q = 0; q < MLP_MAXB; ++q) {
-        av[u][q] = bv[u][q] = 0.f;
-        if (pm[q] >= 0) {
-          const int n = 32 * pm[q] + i, k = 32 * pb[q] + i;
-          if (ok && n < out) av[u][q] = dop[pt * d_stride + n];
-          if (ok && k < in && (q == 0 || !shared_b)) bv[u][q] = aop[pt * a_stride + k];
+    for (int k = 0; k < LD_MAX; ++k) {
+      const int v = threadIdx.x + k * MLP_BLOCK;
+      r[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (v < nvec) {
+        const int row = (v * 4) / wpad, c = (v * 4) - row * wpad;
+        const long long pt = p0 + row;
+        if (pt < M) {
+          const float* g = src + pt * stride + c;
+          if (vec_ok && c + 3 < width) {
+            r[k] = *reinterpret_cast<const float4*>(g);
+          } else {
+            if (c < width) r[k].x = g[0];
+            if (c + 1 < width) r[k].y = g[1];
+            if (c + 2 < width) r[k].z = g[2];
+            if (c + 3 < width) r[k].w = g[3];
+          }
         }
       }
     }
+  };
+  auto stash = [&](float* dst, int S, int wpad, const float4 r[LD_MAX]) {
+    const int nvec = WG_TP * wpad / 4;
 #pragma unroll
-    for (int u = 0; u < WG_UNROLL; ++u) {
+    for (int k = 0; k < LD_MAX; ++k) {
+      const int v = threadIdx.x + k * MLP_BLOCK;
+      if (v < nvec) {
+        const int row = (v * 4) / wpad, c = (v * 4) - row * wpad;
+        *reinterpret_cast<float4*>(dst + row * S + c) = r[k];
+      }
+    }
+  };
+  const int apad = 32 * outb, bpad = 32 * inb;
+  if (t_begin < t_end) {
+    fetch(t_begin, dop, d_stride, out, apad, ra);
+    fetch(t_begin, aop, a_stride, in, bpad, rb);
+  }
+  for (long long t = t_begin; t < t_end; ++t) {
+    __syncthreads();                       // the previous tile's fragments have been read
+    stash(s_a, SA, apad, ra);
+    stash(s_b, SB, bpad, rb);
+    __syncthreads();
+    if (t + 1 < t_end) {
+      fetch(t + 1, dop, d_stride, out, apad, ra);
+      fetch(t + 1, aop, a_stride, in, bpad, rb);
+    }
+#pragma unroll
+    for (int st = 0; st < WG_TP / 2; ++st) {
+      const float* ar = s_a + (2 * st + kk) * SA + i;
+      const float* br = s_b + (2 * st + kk) * SB + i;
 #pragma unroll
       for (int q = 0; q < MLP_MAXB; ++q) {
         if (pm[q] >= 0) {
-          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][q], shared_b ? bv[u][0] : bv[u][q], acc[q], 0, 0, 0);
-          bsum[q] += av[u][q];
+          const float av = ar[32 * pm[q]];
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, br[32 * pb[q]], acc[q], 0, 0, 0);
+          bsum[q] += av;
         }
       }
     }
@@ -420,10 +486,28 @@ size_t max_layer_bytes(const vsa_mlp_plan& p) {
 // (every workgroup writes a full set of partial blocks that mlp_reduce then has to read: 512
 // workgroups on a 10 k-point batch made the reduction the most expensive kernel of the step)
 int wgrad_total_wgs(const vsa_mlp_plan& p, long long nr_points, int nr_cus) {
-  long long n = nr_points / 512;
+  long long n = nr_points / 128;
   if (n < p.n_layers) n = p.n_layers;
-  if (n > 2ll * nr_cus) n = 2ll * nr_cus;
+  if (n > 3ll * nr_cus) n = 3ll * nr_cus;     // three co-resident workgroups per CU (168 VGPRs; four spill)
   return (int)n;
+}
+
+constexpr size_t MLP_RESIDENT_BYTES = 78 * 1024;     // two workgroups per CU
+
+int set_lds_attrs() {
+  static bool done = false;
+  if (!done) {
+    VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)MLP_RESIDENT_BYTES));
+    VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)MLP_RESIDENT_BYTES));
+    VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    done = true;
+  }
+  return VSA_OK;
 }
 
 WgradLayers wgrad_layers(const vsa_mlp_plan& p, int total_wgs) {
@@ -486,20 +570,20 @@ extern "C" int vsa_mlp_fwd(const vsa_mlp_plan* plan, const float* x, int x_strid
   int nr_cus = 0;
   rc = vsa_cu_count(&nr_cus);
   if (rc) return rc;
-  const size_t lds = max_layer_bytes(*plan);
-  static bool attr_set = false;
-  if (!attr_set) {
-    VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    attr_set = true;
-  }
+  rc = set_lds_attrs();
+  if (rc) return rc;
+  const size_t all = (size_t)pack_offsets(*plan).fwd[plan->n_layers] * sizeof(float);
+  const bool resident = all <= MLP_RESIDENT_BYTES;
+  const size_t lds = resident ? all : max_layer_bytes(*plan);
   const int ntiles = vsa_div_up(nr_points, MLP_TILE);
   int grid = vsa_div_up(ntiles, 4);
   if (grid > 2 * nr_cus) grid = 2 * nr_cus;
-  hipLaunchKernelGGL(mlp_fwd_kernel, dim3(grid), dim3(MLP_BLOCK), lds, st, *plan, packed_ws, x, x_stride,
-                     nr_points, y, y_stride, z_ws);
+  if (resident)
+    hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(grid), dim3(MLP_BLOCK), lds, st, *plan, packed_ws, x,
+                       x_stride, nr_points, y, y_stride, z_ws);
+  else
+    hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(grid), dim3(MLP_BLOCK), lds, st, *plan, packed_ws, x,
+                       x_stride, nr_points, y, y_stride, z_ws);
   VSA_RETURN_LAUNCH_STATUS();
 }
 
@@ -522,20 +606,27 @@ extern "C" int vsa_mlp_bwd(const vsa_mlp_plan* plan, const float* x, int x_strid
   int nr_cus = 0;
   rc = vsa_cu_count(&nr_cus);
   if (rc) return rc;
-  static bool attr_set = false;
-  if (!attr_set) {
-    VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    attr_set = true;
-  }
+  rc = set_lds_attrs();
+  if (rc) return rc;
+  const size_t all = (size_t)pack_offsets(*plan).fwd[L] * sizeof(float);
+  const bool resident = all <= MLP_RESIDENT_BYTES;
+  const size_t lds = resident ? all : max_layer_bytes(*plan);
   const int ntiles = vsa_div_up(nr_points, MLP_TILE);
   int grid = vsa_div_up(ntiles, 4);
   if (grid > 2 * nr_cus) grid = 2 * nr_cus;
-  if (L > 1 || dx)
-    hipLaunchKernelGGL(mlp_dgrad_kernel, dim3(grid), dim3(MLP_BLOCK), max_layer_bytes(*plan), st, *plan,
-                       packed_ws, dy, dy_stride, nr_points, z_ws, dz_ws, a_ws, dx, dx_stride);
+  if (L > 1 || dx) {
+    if (resident)
+      hipLaunchKernelGGL(mlp_dgrad_kernel<true>, dim3(grid), dim3(MLP_BLOCK), lds, st, *plan, packed_ws, dy,
+                         dy_stride, nr_points, z_ws, dz_ws, a_ws, dx, dx_stride);
+    else
+      hipLaunchKernelGGL(mlp_dgrad_kernel<false>, dim3(grid), dim3(MLP_BLOCK), lds, st, *plan, packed_ws, dy,
+                         dy_stride, nr_points, z_ws, dz_ws, a_ws, dx, dx_stride);
+  }
   const WgradLayers wl = wgrad_layers(*plan, wgrad_total_wgs(*plan, nr_points, nr_cus));
-  hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(wl.wg_begin[L]), dim3(MLP_BLOCK), 0, st, *plan, wl, x,
+  int wmax = 1;
+  for (int l = 0; l <= L; ++l) wmax = blocks_of(plan->dims[l]) > wmax ? blocks_of(plan->dims[l]) : wmax;
+  const size_t wg_lds = (size_t)WG_TP * (wg_stride(32 * wmax) * 2) * sizeof(float);   // 24 KiB (64 wide) .. 40 KiB (128)
+  hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(wl.wg_begin[L]), dim3(MLP_BLOCK), wg_lds, st, *plan, wl, x,
                      x_stride, dy, dy_stride, nr_points, dz_ws, a_ws, partial_ws);
   hipLaunchKernelGGL(mlp_reduce_kernel, dim3(68, L), dim3(256), 0, st, *plan, wl, partial_ws, *grads);   // 68 x 256 >= one thread per element of a 128 x 128 (+bias) layer
   VSA_RETURN_LAUNCH_STATUS();
