@@ -326,6 +326,14 @@ int vsa_grid_encode_bwd(const vsa_grid_plan* plan, const float* x, const float* 
  * nr_points * 2 * n_levels + 32 floats (the output gradient re-laid level-major + max|g| per level). */
 int vsa_grid_encode_bwd_sliced(const vsa_grid_plan* plan, const float* x, const float* g_out,
                                int nr_points, float* grad_tables, float* workspace, void* stream);
+/* The same gradients for VERY large batches: the 2^D x n_levels contributions of every sample are
+ * binned by (level, 2^13-entry slice) once (LDS counting sort, contiguous runs) and each bin is
+ * accumulated densely in LDS fixed point.  workspace: vsa_grid_encode_bwd_binned_workspace floats
+ * (~14 x 2^D x n_levels x nr_points bytes: 4.8 GB for 2.1 M samples). */
+int vsa_grid_encode_bwd_binned_workspace(const vsa_grid_plan* plan, int nr_points,
+                                         long long* workspace_floats);
+int vsa_grid_encode_bwd_binned(const vsa_grid_plan* plan, const float* x, const float* g_out,
+                               int nr_points, float* grad_tables, float* workspace, void* stream);
 /* out [nr_dirs][(degree+1)^2]: SH basis of each direction, degree 0..4. */
 int vsa_sh_encode(const float* dirs, int nr_dirs, int degree, float* out, void* stream);
 

@@ -172,7 +172,7 @@ def test_nerfhash_drives_the_background_path():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_dims,levels,log2,growth", [(3, 24, 18, 2.0), (2, 16, 15, 1.5)])
-def test_grid_encode_backward_sliced_equals_atomic_scatter(n_dims, levels, log2, growth):
+def test_grid_encode_backward_sliced_and_binned_equal_atomic_scatter(n_dims, levels, log2, growth):
     """vsa_grid_encode_bwd_sliced (LDS-resident table slices, large batches) accumulates the
     same table gradients as vsa_grid_encode_bwd (memory-side float atomics), itself pinned to
     the oracle above; exercised through the size switch of encodings._GridEncode."""
@@ -186,15 +186,22 @@ def test_grid_encode_backward_sliced_equals_atomic_scatter(n_dims, levels, log2,
     go = torch.randn(B, 2 * levels, generator=g).cuda()
     go[::7] = 0                                             # rows the kernels skip
     grads = {}
-    keep = E.SLICED_BWD_MIN_POINTS
-    for name, thr in (("sliced", 1), ("atomic", 1 << 30)):
-        E.SLICED_BWD_MIN_POINTS = thr
+    keep = (E.SLICED_BWD_MIN_POINTS, E.BINNED_BWD_MIN_POINTS)
+    for name, thr in (("sliced", (1, 1 << 30)), ("binned", (1, 1)), ("atomic", (1 << 30, 1 << 30))):
+        E.SLICED_BWD_MIN_POINTS, E.BINNED_BWD_MIN_POINTS = thr
         try:
             enc.params.grad = None
             enc(x).backward(go)
         finally:
-            E.SLICED_BWD_MIN_POINTS = keep
+            E.SLICED_BWD_MIN_POINTS, E.BINNED_BWD_MIN_POINTS = keep
         grads[name] = enc.params.grad.clone()
-    a, b = grads["sliced"], grads["atomic"]
-    assert b.abs().max() > 0 and (a != 0).sum() == (b != 0).sum()
-    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-5 * b.abs().max().item())
+    b = grads["atomic"]
+    assert b.abs().max() > 0
+    for name in ("sliced", "binned"):
+        a = grads[name]
+        assert (a != 0).sum() == (b != 0).sum(), name
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-5 * b.abs().max().item())
+    # both LDS paths accumulate in 64-bit fixed point: independent of the summation order, i.e. equal
+    # to each other bit for bit up to the final per-chunk float adds of the sliced path
+    np.testing.assert_allclose(grads["sliced"].cpu().numpy(), grads["binned"].cpu().numpy(), rtol=1e-6,
+                               atol=1e-7 * b.abs().max().item())
