@@ -66,16 +66,19 @@ def parse():
     return args
 
 
+FRAME_PATH_SOURCES = ("common.h", "nt_common.h", "nt_quant_table.h", "nt_texels.hip", "nt_encode.hip",
+                      "nt_mlp.hip", "nt_shade.hip", "trace.hip", "composite_dense.hip", "raygen.hip")
+
+
 def kernel_source_hash():
-    """sha256 over the HIP / C++ sources and headers the library is built from."""
+    """sha256 over the sources of the kernels the frame workload launches (the ones
+    profiles/traffic.json holds PMC traffic for)."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "volsurfs_amd", "csrc")
-    for n in sorted(os.listdir(d)):
-        if n.endswith((".hip", ".h", ".cpp")):
-            h.update(n.encode())
-            h.update(open(os.path.join(d, n), "rb").read())
-    h.update(open(os.path.join(ROOT, "include", "volsurfs_hip.h"), "rb").read())
+    for n in FRAME_PATH_SOURCES:
+        h.update(n.encode())
+        h.update(open(os.path.join(d, n), "rb").read())
     return h.hexdigest()
 
 
