@@ -1,0 +1,55 @@
+"""bench.py's contract (one JSON line on stdout, the keys the driver reads) for every workload,
+at sizes that finish in seconds."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args, timeout=600):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True,
+                       text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_kernel_source_hash_guards_the_traffic_file():
+    sys.path.insert(0, ROOT)
+    import bench
+    h = bench.kernel_source_hash()
+    assert len(h) == 64 and h == bench.kernel_source_hash()
+    tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    assert "_kernel_source_sha256" in tj and "nt_mlp_bwd" in tj
+
+
+@pytest.mark.gpu
+def test_frame_workload_line():
+    d = _run("--res", "128", "--shells", "2", "--subdiv", "3", "--steps", "3", "--warmup", "1",
+             "--cpu-sample-rays", "64")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "h", "Mhits/s"):
+        assert k in d, k
+    assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["peak"] in (8000.0, 2500.0) and 0 < rf["frac"] < 1
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert 0 < d["h"] <= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["train", "train-permuto"])
+def test_training_workload_lines(workload):
+    d = _run("--workload", workload, "--res", "128", "--views", "3", "--shells", "2", "--subdiv", "3",
+             "--steps", "6", "--warmup", "3", "--target-hits", "4096")
+    assert d["unit"] == "it/s" and d["value"] > 0 and d["steps"] == 6
+    assert d["hits_per_iter"] > 0 and d["rays_per_iter"] > 0 and 0 < d["fixed_share"]
+    assert "workload" in d["config"] and d["config"]["parameters"] > 0

@@ -450,3 +450,31 @@ def test_permutohash_legacy_branch_matches_oracle_and_trains():
         m.optim_step()
         losses.append(l["loss"].item())
     assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.gpu
+def test_from_meshes_path_builds_the_method_and_resumes(tmp_path):
+    """methods/volsurfs.py:62-128: shells from a directory of .obj / .ply files (sorted by isolevel),
+    copied into the run's checkpoints at the first iteration, loaded from there on resume."""
+    import os
+    from volsurfs_amd.camera import pinhole_rays
+    from volsurfs_amd.mesh import nested_shells, save_obj, save_ply
+    from volsurfs_amd.methods import VolSurfs
+    src, run = tmp_path / "meshes_simplified_uvs", tmp_path / "checkpoints"
+    src.mkdir()
+    run.mkdir()
+    shells = nested_shells(K=3, subdiv=3)
+    save_obj(os.path.join(src, "-0.01.obj"), shells[0])
+    save_ply(os.path.join(src, "0.0.ply"), shells[1])
+    save_obj(os.path.join(src, "0.01.obj"), shells[2])
+    kw = dict(max_rays=4096, textures_res=(128, 64, 32, 16))
+    a = VolSurfs.from_meshes_path(str(src), str(run), start_iter_nr=0, **kw)
+    assert a.nr_meshes == 3 and sorted(os.listdir(run / "meshes")) == ["0.obj", "1.ply", "2.obj"]
+    b = VolSurfs.from_meshes_path("/nonexistent", str(run), start_iter_nr=10, **kw)
+    ref = VolSurfs(shells, **kw)
+    o, d = pinhole_rays(32, 32, focal=50.0)
+    with torch.no_grad():
+        ra, rb, rr = (m.render_rays(o, d, return_samples=False)["renders"]["ray_traced"]["rgb"] for m in (a, b, ref))
+    assert torch.equal(ra, rb) and torch.equal(ra, rr)          # same seed, same shells -> same image
+    sub = VolSurfs.from_meshes_path(str(src), str(tmp_path / "run2"), meshes_indices=["2", "0"], **kw)
+    assert sub.nr_meshes == 2
