@@ -18,7 +18,10 @@
 
 namespace {
 
-constexpr int TILE = 256;
+#ifndef VSA_COMP_TILE
+#define VSA_COMP_TILE 256
+#endif
+constexpr int TILE = VSA_COMP_TILE;
 
 template <int K>
 struct Lds {
