@@ -64,6 +64,16 @@ def test_argument_errors_are_reported_not_ignored():
     assert L.vsa_tile_order(null, null, 16, 16, 3, 0, null) == ERR_ARG                              # null arrays
     assert L.vsa_reel_next_rays_batch(null, null, null, null, 0, 4, 4, 8, 1, 0, u64, u64, null, null, null,
                                       null, null, null, null) == ERR_ARG                             # no cameras
+    # round-2 entry points
+    assert L.vsa_intersect_primitive(null, null, 10, 0, f1, null, null, null, null, null, null) == ERR_ARG
+    assert L.vsa_intersect_primitive(null, null, 10, 2, f1, null, null, null, null, null, null) == ERR_ARG     # kind
+    assert L.vsa_intersect_primitive(null, null, 0, 1, f1, null, null, null, null, null, null) == 0
+    assert L.vsa_permuto_encode_fwd(null, null, null, null, 10, null, 48, null) == ERR_ARG
+    assert L.vsa_permuto_encode_bwd(null, null, null, null, 48, 10, null, null) == ERR_ARG
+    assert L.vsa_mlp_bwd(null, null, 0, 10, null, 0, null, null, null, null, null, null, 0, null, null) == ERR_ARG
+    assert L.vsa_grid_encode_bwd_sliced(null, null, null, 10, null, null, null) == ERR_ARG
+    assert L.vsa_grid_encode_bwd_binned(null, null, null, 10, null, null, null) == ERR_ARG
+    assert L.vsa_grid_encode_bwd_binned_workspace(null, 10, null) == ERR_ARG
     h = ctypes.c_void_p()
     assert L.vsa_bvh_build(null, null, 0, 0, 4, ctypes.byref(h)) != 0
     # the Python layer turns any non-zero status into an exception

@@ -320,7 +320,10 @@ __global__ __launch_bounds__(GS_THREADS) void grid_encode_bwd_sliced_kernel(
 // Traffic: 2 x 12 B x 8 L B (4.8 GB written + read at 2.1 M samples) instead of 32x the index VALU.
 constexpr int GB_SAMPLES = 1024;                    // samples per scatter trip = threads per workgroup
 constexpr int GB_MAX_SLICES = 32;                   // 2^18 entries / 2^13
-constexpr unsigned long long GB_QUANTUM = 1ull << 18;   // records per accumulate workgroup
+#ifndef VSA_GB_QUANTUM_LOG2
+#define VSA_GB_QUANTUM_LOG2 18
+#endif
+constexpr unsigned long long GB_QUANTUM = 1ull << VSA_GB_QUANTUM_LOG2;   // records per accumulate workgroup
 
 template <int D>
 __device__ __forceinline__ void grid_corner_indices(const GridLevel& g, const GridCell<D>& cell,
