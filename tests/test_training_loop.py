@@ -112,3 +112,36 @@ def test_fused_step_equals_the_autograd_step():
         assert s_ > 0 and (a - b).abs().max().item() <= 2e-3 * s_
     # a masked loss or a learned background falls back to the autograd path
     assert not m.supports_fused_step(torch.ones(1), True)
+
+
+@pytest.mark.gpu
+def test_overlapped_optimiser_step_trains_identically():
+    """train_step(overlap_optimizer=True): Adam on a side stream beside the next iteration's
+    traversal / compaction; the parameters' next reader waits for it.  Same training trajectory as
+    the in-line step (the backward's unordered f16 atomics are the only run-to-run difference)."""
+    from volsurfs_amd.camera import pinhole_rays
+    from volsurfs_amd.mesh import nested_shells
+    from volsurfs_amd.methods import VolSurfs
+    from volsurfs_amd.trainer import train_step
+    o, d = pinhole_rays(48, 48, focal=80.0)
+    gt = torch.rand(48 * 48, 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)) * 0.3
+    runs = {}
+    for overlap in (False, True):
+        m = VolSurfs(nested_shells(K=2, subdiv=3), max_rays=4096, textures_res=(256, 128, 64, 32),
+                     nr_warmup_iters=0, lr=2e-3)
+        m.init_optim()
+        m.grad_scale = float(48 * 48)
+        losses = []
+        for it in range(12):
+            l, _ = train_step(m, o, d, gt, None, iter_nr=it, is_first_iter=(it == 0), sync_losses=False,
+                              overlap_optimizer=overlap)
+            losses.append(l["loss"])
+        m.bank.wait_params()
+        torch.cuda.synchronize()
+        assert torch.equal(m.bank.tables_h, m.bank.tables.detach().half())
+        assert float(m.bank.tables.grad.abs().sum()) == 0.0
+        runs[overlap] = ([float(x) for x in losses], m.bank.weights.detach().clone())
+    la, lb = runs[False][0], runs[True][0]
+    assert la[-1] < la[0] - 1e-3 and lb[-1] < lb[0] - 1e-3
+    assert max(abs(a - b) for a, b in zip(la, lb)) < 2e-4
+    assert (runs[False][1] - runs[True][1]).abs().max() < 12 * 2e-3 * 0.5     # a few Adam steps of noise at most

@@ -186,8 +186,18 @@ class VolSurfs(torch.nn.Module):
         self.scheduler_lr_decay = MultiStepLR(self.optimizer, milestones=self.lr_milestones, gamma=0.3)
         return self.optimizer
 
-    def optim_step(self):
-        self.optimizer.step()        # (refreshes bank.tables_h / weights_h inside the kernel)
+    def optim_step(self, overlap=False):
+        """overlap=True (neural textures only): the Adam launch goes to a side stream and the next
+        reader of the texture parameters on the current stream waits for it (bank.wait_params, in
+        encode / mlp): the next iteration's ray batch, traversal and texel compaction run beside the
+        HBM-bound update.  Code that reads `bank.tables` / `.weights` directly with torch ops must
+        call `bank.wait_params()` first."""
+        if overlap and self.bank is not None and self.bg_model is None:
+            if getattr(self, "_optim_stream", None) is None:
+                self._optim_stream = torch.cuda.Stream()
+            self.bank._params_event = self.optimizer.step(stream=self._optim_stream)
+        else:
+            self.optimizer.step()    # (refreshes bank.tables_h / weights_h inside the kernel)
 
     def _shade_legacy(self, rays_o, rays_d, hit_t, hit_slot, iter_nr):
         """volsurfs.py:486-599, legacy branch: per shell, the hit points / view directions /

@@ -160,6 +160,7 @@ class NeuralTextureBank(torch.nn.Module):
     @torch.no_grad()
     def refresh_half_params(self):
         """fp16 compute copies of the fp32 masters (tcnn keeps the same pair)."""
+        self.wait_params()
         self.tables_h.copy_(self.tables)
         self.weights_h.copy_(self.weights)
 
@@ -238,7 +239,16 @@ class NeuralTextureBank(torch.nn.Module):
                   self.marks, _lib.stream_ptr())
         return tex_uv
 
+    def wait_params(self):
+        """An optimiser step may still be running on a side stream (VolSurfs.optim_step(overlap=True)):
+        the first reader of the parameters on the current stream waits for it here."""
+        ev = getattr(self, "_params_event", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self._params_event = None
+
     def encode(self):
+        self.wait_params()
         _lib.call("vsa_nt_encode_fwd", ctypes.byref(self.plan), self.tables_h, self.slot_xy,
                   self.seg_start, self.features, _lib.stream_ptr())
         return self.features
@@ -249,6 +259,7 @@ class NeuralTextureBank(torch.nn.Module):
         return f.reshape(2, 16, self.slot_capacity, 2)
 
     def mlp(self, want_pre=False):
+        self.wait_params()
         pre = None
         if want_pre:
             pre = torch.zeros(self.slot_capacity, 32, dtype=torch.float16, device=self.texels.device)

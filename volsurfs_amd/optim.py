@@ -97,13 +97,25 @@ class FusedAdam(torch.optim.Optimizer):
         self._grads_clean = False
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0):
+    def step(self, closure=None, grad_scale=1.0, stream=None):
+        """stream: a side `torch.cuda.Stream` to run the update on (ordered after everything
+        queued on the current stream); the returned event marks its completion and whoever reads
+        the parameters next must wait for it.  The update is HBM-bound and the start of the next
+        iteration (ray batch, traversal, texel compaction) neither reads nor writes parameters,
+        so the two overlap."""
         loss = closure() if closure is not None else None
+        if stream is not None:
+            stream.wait_stream(torch.cuda.current_stream())
+        sp = ctypes.c_void_p(stream.cuda_stream) if stream is not None else _lib.stream_ptr()
         for gi, group in enumerate(self.param_groups):
             _, desc, ck, n = self._plan(gi, group)
             group["step"] += 1
             b1, b2 = group["betas"]
             _lib.call("vsa_adam_step", desc, ck, n, float(group["lr"]), float(b1), float(b2),
-                      float(group["eps"]), int(group["step"]), float(grad_scale), 1, _lib.stream_ptr())
+                      float(group["eps"]), int(group["step"]), float(grad_scale), 1, sp)
         self._grads_clean = True
+        if stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            return ev
         return loss

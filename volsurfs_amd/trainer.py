@@ -45,7 +45,7 @@ class _HostCount:
 
 def train_step(method, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first_iter=False,
                nr_rays=None, target_nr_of_training_samples=None, world=1, is_training_masked=False,
-               group=None, sync_losses=True, fused=True):
+               group=None, sync_losses=True, fused=True, overlap_optimizer=False):
     """Returns (losses dict with a float "loss", next nr_rays).  `method` is a
     volsurfs_amd.methods.VolSurfs with init_optim() called.
 
@@ -64,7 +64,9 @@ def train_step(method, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first
     forward + backward, as one launch sequence without an autograd graph.  The only host read of
     an iteration is then the hit count the dynamic ray count needs (trainer.py:293-304), copied
     asynchronously right after the traversal, so the host queues the next iteration while this
-    one still runs.  sync_losses=False leaves the losses as device tensors (no .item())."""
+    one still runs.  sync_losses=False leaves the losses as device tensors (no .item()).
+    overlap_optimizer=True (fused path only) runs the Adam launch on a side stream; the next
+    reader of the texture parameters waits for it (methods.VolSurfs.optim_step)."""
     method.is_training = True
     method.optimizer.zero_grad()                                            # trainer.py:118
     n_local = rays_o.shape[0]
@@ -106,7 +108,10 @@ def train_step(method, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first
     if world > 1:
         from .parallel import allreduce_gradients
         allreduce_gradients([p for g in method.optimizer.param_groups for p in g["params"]], world, group)
-    method.optim_step()                                                     # :278
+    if overlap_optimizer and use_fused:                                      # :278
+        method.optim_step(overlap=True)          # Adam beside the next iteration's traversal
+    else:
+        method.optim_step()
     nr_samples += sum(c.get() for c in counts)
     method.last_nr_samples = nr_samples
     if sync_losses:
