@@ -150,7 +150,7 @@ def run_train(args, world, rank, dev, dist):
         losses, nxt = train_step_from_reel(method, reel, n, jitter_pixels=True, iter_nr=state["it"],
                                            is_first_iter=state["it"] == 0,
                                            target_nr_of_training_samples=target, world=world,
-                                           sync_losses=False, overlap_optimizer=not legacy)
+                                           sync_losses=False)
         if count:
             state["rays"] += n
             state["hits"] += int(getattr(method, "last_nr_samples", 0))
