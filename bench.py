@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1, frame workload: weak = one full frame per rank (default); strong = ONE frame "
                          "dealt to the ranks in 8-row bands, round-robin (parallel.shard_bands)")
+    ap.add_argument("--grad-wire-dtype", default="f32", choices=["f32", "bf16"],
+                    help="N > 1: width of the gradient all-reduce on the wire (bf16 halves the bytes, rounds the sum)")
     ap.add_argument("--target-hits", type=int, default=49152)
     ap.add_argument("--views", type=int, default=50)
     ap.add_argument("--res", type=int, default=800)
@@ -317,7 +319,7 @@ def main():
 
     from volsurfs_amd.parallel import GradientOverlap
     params = [pipe.bank.tables, pipe.bank.weights]
-    overlap = GradientOverlap(world)
+    overlap = GradientOverlap(world, wire_dtype=torch.bfloat16 if args.grad_wire_dtype == "bf16" else None)
 
     def step(record=False):
         if world == 1:

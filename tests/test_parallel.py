@@ -90,6 +90,12 @@ def _overlap_worker(rank, world, port, q):
         ov.reduce_async(g[s * 8:(s + 1) * 8])      # contiguous slice, reduced in place
     ov.wait()
     assert ov.works == []
+    # opt-in bf16 wire format: the sum of bf16-representable values is exact here
+    c = torch.arange(16, dtype=torch.float32) * (rank + 1)
+    ovc = GradientOverlap(world, wire_dtype=torch.bfloat16)
+    ovc.reduce_async(c)
+    ovc.wait()
+    assert c.dtype == torch.float32 and torch.equal(c, torch.arange(16, dtype=torch.float32) * 3)
     if rank == 0:
         q.put((g.numpy().copy(), w.numpy().copy()))
     dist.barrier()

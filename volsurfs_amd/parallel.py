@@ -55,20 +55,33 @@ class GradientOverlap:
     """All-reduce gradient tensors as they become final, overlapped with the rest of
     backward: `reduce_async(t)` enqueues an asynchronous all-reduce(sum) of `t` (ordered
     after the work already queued on the current stream), `wait()` makes the current
-    stream wait for all of them.  One instance per training loop."""
+    stream wait for all of them.  One instance per training loop.
 
-    def __init__(self, world, group=None):
-        self.world, self.group, self.works = world, group, []
+    wire_dtype (opt-in, e.g. torch.bfloat16): the tensor is converted, reduced at that width and
+    converted back in `wait()` — half the bytes on the xGMI ring (the 114 MB of fp32 texture
+    gradients are what bounds strong scaling) at the price of a bf16-rounded SUM
+    (~2^-9 relative per hop); the default (None) reduces the fp32 tensors in place, exactly."""
+
+    def __init__(self, world, group=None, wire_dtype=None):
+        self.world, self.group, self.works, self.wire_dtype = world, group, [], wire_dtype
 
     def reduce_async(self, t):
         if self.world == 1:
             return
         import torch.distributed as dist
-        self.works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.wire_dtype is None:
+            self.works.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True),
+                               None, None))
+        else:
+            buf = t.to(self.wire_dtype)
+            self.works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True),
+                               t, buf))
 
     def wait(self):
-        for w in self.works:
+        for w, t, buf in self.works:
             w.wait()
+            if buf is not None:
+                t.copy_(buf)
         self.works = []
 
 
