@@ -478,3 +478,63 @@ def test_from_meshes_path_builds_the_method_and_resumes(tmp_path):
     assert torch.equal(ra, rb) and torch.equal(ra, rr)          # same seed, same shells -> same image
     sub = VolSurfs.from_meshes_path(str(src), str(tmp_path / "run2"), meshes_indices=["2", "0"], **kw)
     assert sub.nr_meshes == 2
+
+
+@pytest.mark.gpu
+def test_baseline_config0_plumbing_case_matches_cpu_restatement():
+    """BASELINE configs[0] / SURVEY §8d C1: one 64x64 pinhole view (focal 70 px, camera at (0,0,-1.5)),
+    K=1 icosphere (subdiv 4, r = 0.3), legacy `RGB` appearance with the frequency position encoder
+    (39 dims) + SH-3 view encoding and a [32, 32] MLP, white background — the reference's own
+    CPU-runnable case.  The HIP path (trace, fused fp32 MLP, fp16 composite) against the same
+    models evaluated with plain torch on the CPU from the same hits, forward and gradients."""
+    from oracle import composite as OC
+    from oracle import legacy_models as OL
+    from oracle.neural_texture import sh_basis_values
+    from volsurfs_amd.camera import pinhole_rays
+    from volsurfs_amd.mesh import TensorMesh, icosphere, octahedral_uv
+    from volsurfs_amd.methods import VolSurfs
+    v, f = icosphere(4, 0.3)
+    fuv = octahedral_uv(v.astype(np.float64) / 0.3)[f].astype(np.float32)
+    m = VolSurfs([TensorMesh(v, f, fuv)], max_rays=4096, using_neural_textures=False,
+                 rgb_pos_encoder_type="frequency", rgb_mlp_layers_dims=(32, 32), bb_sides=1.0)
+    assert m.models["rgb_0"].mlp.layers[0].in_features == 39 + 16
+    o, d = pinhole_rays(64, 64, focal=70.0, cam_pos=(0.0, 0.0, -1.5))
+    gt = torch.rand(4096, 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    losses, _, _ = m(o, d, gt, None, 0)
+    losses["loss"].backward()
+    rgb = m.render_rays(o, d, return_samples=False)["renders"]["ray_traced"]["rgb"].detach().cpu().numpy()
+    # CPU restatement from the same hits
+    hit_t, hit_slot, _ = m.raytracer.trace_all(o, d)
+    hits = (hit_slot[0] >= 0).cpu()
+    assert 800 < int(hits.sum()) < 2000
+    tri = m.raytracer.tris[hit_slot[0][hit_slot[0] >= 0].long()].cpu()
+    nrm = torch.nn.functional.normalize(torch.cross(tri[:, 4:7], tri[:, 8:11], dim=1), dim=1)
+    dd = d.cpu()[hits]
+    pts = o.cpu()[hits] + hit_t[0].cpu()[hits][:, None] * dd
+    outs, leaves = [], []
+    for key in ("rgb_0", "alpha_0"):
+        mod = m.models[key]
+        layers = [(l.weight.detach().cpu().clone().requires_grad_(True), l.bias.detach().cpu().clone().requires_grad_(True))
+                  for l in mod.mlp.layers if isinstance(l, torch.nn.Linear)]
+        leaves.append(layers)
+        parts = [pts] + [fn(pts * 2.0 ** l) for l in range(6) for fn in (torch.sin, torch.cos)]
+        x = torch.cat(parts + [sh_basis_values(dd, 3)], 1)
+        outs.append(torch.sigmoid(OL.mlp_forward(layers, x)))
+    dot = torch.sum(-dd * nrm, dim=1).clamp(0.0, 1.0)
+    s_rgb = torch.zeros(4096, 1, 3).index_put((hits.nonzero()[:, 0], torch.tensor(0)), outs[0])
+    a = outs[1][:, 0] * (torch.sigmoid(10.0 * dot) * 2.0 - 1.0)
+    s_a = torch.zeros(4096, 1).index_put((hits.nonzero()[:, 0], torch.tensor(0)), a)
+    bg = np.ones((1, 3), np.float32)
+    ref = OC.composite_dense_fwd(s_rgb.detach().numpy(), s_a.detach().numpy(), bg)["rgb"]
+    e = np.abs(rgb - ref)
+    assert e.max() < 1e-3 and (e <= 1e-4).mean() > 0.99          # fp16 composite of fp32 models
+    g = np.sign(ref - gt.cpu().numpy()).astype(np.float32) / (4096 * 3)
+    gc, ga, _ = OC.composite_dense_bwd(s_rgb.detach().numpy(), s_a.detach().numpy(), bg, g)
+    ((s_rgb * torch.from_numpy(gc)).sum() + (s_a * torch.from_numpy(ga)).sum()).backward()
+    for key, layers in zip(("rgb_0", "alpha_0"), leaves):
+        lin = [l for l in m.models[key].mlp.layers if isinstance(l, torch.nn.Linear)]
+        for l, (w, b) in zip(lin, layers):
+            for got, want in ((l.weight.grad.cpu(), w.grad), (l.bias.grad.cpu(), b.grad)):
+                assert want.abs().max() > 0
+                assert (got - want).abs().max() <= 2e-2 * want.abs().max()        # fp16 composite backward
+                assert torch.nn.functional.cosine_similarity(got.flatten(), want.flatten(), dim=0) > 0.999
