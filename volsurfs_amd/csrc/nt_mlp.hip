@@ -288,6 +288,9 @@ __device__ __forceinline__ void prefetch_features(const vsa_nt_plan& plan,
 //                   gradients (operands by ds_read_b64_tr_b16), dF stores, sum|dF|
 // Each role stays below 256 registers (MFMA results in plain VGPRs), hand-off is ONE
 // workgroup barrier per tile over a double-buffered image set.
+#ifndef NT_PC_CLEAR_IN_CONSUMER
+#define NT_PC_CLEAR_IN_CONSUMER 0     /* measured: slower in the consumer (0.88 vs 0.857 ms), DESIGN 9.1 */
+#endif
 #ifndef NT_PC_DW3_LATE
 #define NT_PC_DW3_LATE 0
 #endif
@@ -496,8 +499,12 @@ __device__ __forceinline__ void pc_run(
           if (8 * g < ti.channels) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+#ifdef NT_DIAG_NOSIG      /* diagnostic only: prices the sigmoid' of dOut in the producer's stream */
+              d3h[g >> 1][4 * (g & 1) + i] = (_Float16)(gv[i] * 0.25f);
+#else
               const float sg = sigmoidf_((float)(_Float16)acc3[4 * g + i]);
               d3h[g >> 1][4 * (g & 1) + i] = (_Float16)(gv[i] * sg * (1.0f - sg));
+#endif
             }
           } else {
 #pragma unroll
@@ -508,6 +515,7 @@ __device__ __forceinline__ void pc_run(
         // store instruction covers whole stretches of a few lines (one 8-byte store per lane at
         // its own row stride touched 32 lines per instruction and cost 180 us a frame).  The
         // rows' loads have returned (d3h above); a wave's memory operations complete in order.
+#if !defined(NT_DIAG_NOCLEAR) && !NT_PC_CLEAR_IN_CONSUMER
         if (ti.channels > 0) {
           const int s0 = slot - p, nq = min(32, wk.last - s0) * ti.own_quads;
           half4_t* rows = reinterpret_cast<half4_t*>(grad_rows) + ti.row_first +
@@ -517,6 +525,7 @@ __device__ __forceinline__ void pc_run(
             rows[sl * ti.row_quads + (i - sl * ti.own_quads)] = half4_t{0, 0, 0, 0};
           }
         }
+#endif
         store_frags_s<S32>(set + SET_DOUT, 0, d3h[0], d3h[1], p, h);
         store_frags_s<S64>(set + SET_H2, 0, b3[0], b3[1], p, h);
         store_frags_s<S64>(set + SET_H2, 32, b3[2], b3[3], p, h);
@@ -589,6 +598,21 @@ __device__ __forceinline__ void pc_run(
         const int slot = wk.first + (pr + t * PC_PAIRS) * 32 + p;
         const bool valid = slot < wk.last;
         const _Float16* set = pair + (t & 1) * SET_HALFS;
+#if NT_PC_CLEAR_IN_CONSUMER && !defined(NT_DIAG_NOCLEAR)
+        // consume-and-clear of tile t's gradient rows, by the CONSUMER: the producer read them two
+        // trips ago (prefetch) and used them last trip; in-kernel stamps show the producer as the
+        // longer stream (5 050 vs 3 880 cycles per tile, the consumer waiting 1 500 at the barrier),
+        // and pricing the clear in the producer (diagnostic build without it) gave 4 % of the kernel
+        if (ti.channels > 0) {
+          const int s0 = slot - p, nq = min(32, wk.last - s0) * ti.own_quads;
+          half4_t* rows = reinterpret_cast<half4_t*>(grad_rows) + ti.row_first +
+                          (long long)(s0 - ti.begin) * ti.row_quads;
+          for (int i = lane; i < nq; i += 64) {
+            const int sl = ti.own_quads == 1 ? i : (int)__umulhi((unsigned)i, ti.own_magic);
+            rows[sl * ti.row_quads + (i - sl * ti.own_quads)] = half4_t{0, 0, 0, 0};
+          }
+        }
+#endif
         // ---- dH2 = W3^T dOut (B operand: this point's dOut row, natural channel order)
         half8_t dh2[4];
         {
