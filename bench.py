@@ -31,12 +31,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="default 200 (frame) / 500 (train*) / 3 frames (dtu)")
     ap.add_argument("--warmup", type=int, default=None, help="default 10 (frame, dtu) / 100 (train*)")
-    ap.add_argument("--workload", default="frame", choices=["frame", "train", "train-permuto", "dtu"],
+    ap.add_argument("--workload", default="frame", choices=["frame", "train", "train-permuto", "dtu", "render"],
                     help="frame (default): the headline metric, fwd+bwd of one 800x800 frame.  train: the "
                          "reference's training loop (TensorReel batches, dynamic ray count -> 49 152 hits, "
                          "fwd+bwd+Adam) on the neural-texture appearance.  train-permuto: BASELINE configs[2] "
                          "as written (legacy permutohash + MLP appearance).  dtu: configs[3]'s learned "
-                         "background (NerfHash, 32 samples per ray) fwd+bwd+Adam on 65 536-ray batches")
+                         "background (NerfHash, 32 samples per ray) fwd+bwd+Adam on 65 536-ray batches.  render: forward-only "
+                         "full-frame evaluation (BaseMethod.render), live neural textures and baked 8-bit textures")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1, frame workload: weak = one full frame per rank (default); strong = ONE frame "
                          "dealt to the ranks in 8-row bands, round-robin (parallel.shard_bands)")
@@ -62,7 +63,7 @@ def parse():
     if args.steps is None:
         # frame: 200 steps = 0.64 s of back-to-back graph replays (the round-1 default of 20 was a 63 ms
         # timed region, too short for any external GPU-busy sampler to corroborate)
-        args.steps = 500 if training else (3 if args.workload == "dtu" else 200)
+        args.steps = 500 if training else (3 if args.workload == "dtu" else (50 if args.workload == "render" else 200))
     if args.warmup is None:
         args.warmup = 100 if training else 10
     return args
@@ -277,6 +278,44 @@ def run_dtu(args, world, rank, dev, dist):
                        "bg_samples_per_frame": N * 32, "parallelism": f"data-parallel x{world}"}}))
 
 
+def run_render(args, world, rank, dev, dist):
+    """Forward-only evaluation of one frame per step (base_method.py:366-541): the live model
+    (trace -> unique texels -> encode -> MLP -> shade -> composite) and the deploy format
+    (`bake()` once, then trace -> bilinear fetch of the 8-bit SH textures -> composite)."""
+    from volsurfs_amd.camera import pinhole_rays
+    from volsurfs_amd.mesh import nested_shells
+    from volsurfs_amd.methods import VolSurfs
+    res = args.res
+    meshes = nested_shells(K=args.shells, subdiv=args.subdiv, device=dev)
+    m = VolSurfs(meshes, max_rays=res * res)
+    m.is_training = False
+    o, d = pinhole_rays(res, res, focal=1111.1 * res / 800.0, cam_pos=(0.0, 0.0, -1.5), device=dev)
+
+    def timed(fn):
+        for _ in range(max(1, args.warmup)):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / args.steps
+    t_live = timed(lambda: m.render(o, d, chunk=res * res))
+    m.bake()
+    t_baked = timed(lambda: m.render_baked(o, d))
+    if rank == 0:
+        n = res * res
+        print(json.dumps({
+            "metric": f"Mrays/s (forward only) at {res}x{res}, K={args.shells} shells", "value": n / t_live / 1e6,
+            "unit": "Mrays/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": t_live * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16 neural textures / fp16 composite", "data": "synthetic",
+            "baked": {"Mrays/s": n / t_baked / 1e6, "ms_per_frame": t_baked * 1e3,
+                      "note": "8-bit baked SH textures (the deploy format): trace + shade + composite"},
+            "config": {"workload": f"BaseMethod.render of one {res}x{res} frame, K={args.shells} subdiv-{args.subdiv} "
+                                   "shells, SH neural textures, white background, one chunk"}}))
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -295,8 +334,8 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", dev_index)
     torch.manual_seed(42 + rank)
-    if args.workload in ("train", "train-permuto", "dtu"):
-        (run_dtu if args.workload == "dtu" else run_train)(args, world, rank, dev, dist)
+    if args.workload in ("train", "train-permuto", "dtu", "render"):
+        {"dtu": run_dtu, "render": run_render}.get(args.workload, run_train)(args, world, rank, dev, dist)
         if dist is not None:
             dist.destroy_process_group()
         return

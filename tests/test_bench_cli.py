@@ -53,3 +53,9 @@ def test_training_workload_lines(workload):
     assert d["unit"] == "it/s" and d["value"] > 0 and d["steps"] == 6
     assert d["hits_per_iter"] > 0 and d["rays_per_iter"] > 0 and 0 < d["fixed_share"]
     assert "workload" in d["config"] and d["config"]["parameters"] > 0
+
+
+@pytest.mark.gpu
+def test_render_workload_line():
+    d = _run("--workload", "render", "--res", "128", "--shells", "2", "--subdiv", "3", "--steps", "3", "--warmup", "1")
+    assert d["unit"] == "Mrays/s" and d["value"] > 0 and d["baked"]["Mrays/s"] > 0
