@@ -461,7 +461,7 @@ class VolSurfs(torch.nn.Module):
         return path
 
     @torch.no_grad()
-    def render_camera(self, camera, nr_rays_per_pixel=1, jitter_pixels=False, chunk=16384):
+    def render_camera(self, camera, nr_rays_per_pixel=1, jitter_pixels=False, chunk=None):
         """base_method.py:366-541 from the camera down: device ray generation (`ray_gen`,
         :386-402) then the chunked render, reshaped to [H, W, C] images."""
         from .camera import get_camera_rays
@@ -471,9 +471,13 @@ class VolSurfs(torch.nn.Module):
                 for k, v in full.items()}
 
     @torch.no_grad()
-    def render(self, rays_o, rays_d, nr_rays_per_pixel=1, chunk=16384):
-        """base_method.py:366-541: chunked full-frame render (test_rays_batch_size =
-        16384), supersample mean over nr_rays_per_pixel; buffers stay on the device."""
+    def render(self, rays_o, rays_d, nr_rays_per_pixel=1, chunk=None):
+        """base_method.py:366-541: chunked full-frame render, supersample mean over
+        nr_rays_per_pixel; buffers stay on the device.  chunk: rays per render_rays call — the
+        reference's test_rays_batch_size is 16 384; the default here is what this method's buffers
+        hold (`max_rays`), so a method built for whole frames renders them in one launch sequence
+        (chunking never changes a pixel: test_render_chunks_equal_one_shot)."""
+        chunk = int(chunk) if chunk else self.max_rays
         outs = []
         for a in range(0, rays_o.shape[0], chunk):
             r = self.render_rays(rays_o[a:a + chunk], rays_d[a:a + chunk], return_samples=False)
