@@ -54,8 +54,9 @@ def grid_plan(n_dims, n_levels, log2_hashmap_size, base_resolution, per_level_sc
 
 class _GridEncode(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, tables, x, plan):
+    def forward(ctx, tables, x, plan, owner=None):
         x = _lib.check_f32(x.contiguous(), x.shape[0], plan.n_dims)
+        ctx.owner = owner        # the nn.Parameter behind `tables` (direct gradient accumulation)
         out = torch.empty(x.shape[0], plan.n_levels * 2, device=x.device)
         _lib.call("vsa_grid_encode_fwd", ctypes.byref(plan), tables, x, x.shape[0], out,
                   _lib.stream_ptr())
@@ -66,7 +67,9 @@ class _GridEncode(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out):
         (x,) = ctx.saved_tensors
-        g_tables = torch.zeros(ctx.shape, device=x.device)
+        from .optim import accumulate_into_grad
+        direct = accumulate_into_grad(ctx.owner) if ctx.owner is not None else None
+        g_tables = direct if direct is not None else torch.zeros(ctx.shape, device=x.device)
         g_out = g_out.contiguous()
         if x.shape[0] >= BINNED_BWD_MIN_POINTS:
             # very large batches: bin the contributions by table slice once, accumulate densely
@@ -84,7 +87,7 @@ class _GridEncode(torch.autograd.Function):
         else:
             _lib.call("vsa_grid_encode_bwd", ctypes.byref(ctx.plan), x, g_out, x.shape[0],
                       g_tables, _lib.stream_ptr())
-        return g_tables, None, None      # positions carry no gradient on this path
+        return (None if direct is not None else g_tables), None, None, None   # positions carry no gradient on this path
 
 
 class HashGrid(torch.nn.Module):
@@ -103,7 +106,7 @@ class HashGrid(torch.nn.Module):
         self.n_output_dims = 2 * config["n_levels"]
 
     def forward(self, x):
-        return _GridEncode.apply(self.params, x.float(), self.plan)
+        return _GridEncode.apply(self.params, x.float(), self.plan, self.params)
 
 
 class Encoder(torch.nn.Module):
@@ -254,17 +257,19 @@ class _PermutoEncode(torch.autograd.Function):
         if extra:                       # concatenated points (no gradient path: hit points)
             buf[:, 2 * plan.n_levels:width] = x * enc.concat_points_scaling
         ctx.save_for_backward(x, window)
-        ctx.plan, ctx.shape = plan, values.shape
+        ctx.plan, ctx.shape, ctx.owner = plan, values.shape, enc.lattice_values
         return buf[:, :width]
 
     @staticmethod
     def backward(ctx, g_out):
         x, window = ctx.saved_tensors
-        g_values = torch.zeros(ctx.shape, device=x.device)
+        from .optim import accumulate_into_grad
+        direct = accumulate_into_grad(ctx.owner)
+        g_values = direct if direct is not None else torch.zeros(ctx.shape, device=x.device)
         g_out = g_out.contiguous()
         _lib.call("vsa_permuto_encode_bwd", ctypes.byref(ctx.plan), x, window, g_out,
                   g_out.shape[1], x.shape[0], g_values, _lib.stream_ptr())
-        return g_values, None, None, None, None      # positions carry no gradient on this path
+        return (None if direct is not None else g_values), None, None, None, None   # positions: no gradient here
 
 
 class PermutoEncoding(torch.nn.Module):

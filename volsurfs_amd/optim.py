@@ -12,6 +12,7 @@ iteration.  Gradients therefore live in persistent buffers (`p.grad` is allocate
 set to None): `zero_grad()` is free after a `step()`.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -42,6 +43,7 @@ class FusedAdam(torch.optim.Optimizer):
                 # any gradient autograd accumulates makes the buffers dirty again (kernels that
                 # accumulate into .grad directly call mark_grads_dirty themselves)
                 p.register_post_accumulate_grad_hook(self._dirty_hook)
+                p._vsa_optimizer = weakref.ref(self)     # kernels that add into .grad themselves (accumulate_into_grad)
 
     def _ensure(self, p):
         st = self.state[p]
@@ -119,3 +121,19 @@ class FusedAdam(torch.optim.Optimizer):
             ev.record(stream)
             return ev
         return loss
+
+
+def accumulate_into_grad(param):
+    """For autograd Functions whose backward kernel ACCUMULATES (+=) into a table-sized gradient:
+    if `param` already owns a contiguous fp32 `.grad` (the persistent buffers FusedAdam keeps),
+    return it — the kernel then adds straight into it and the Function returns None for that input,
+    saving a zero-filled temporary and autograd's separate accumulation pass over it.  Returns None
+    when there is no such buffer (the Function allocates and returns a gradient as usual)."""
+    g = param.grad
+    if g is None or not g.is_contiguous() or g.dtype != torch.float32 or g.shape != param.shape:
+        return None
+    opt = getattr(param, "_vsa_optimizer", None)
+    opt = opt() if opt is not None else None
+    if opt is not None:
+        opt.mark_grads_dirty()
+    return g
