@@ -212,7 +212,8 @@ class GridHashEncoder(Encoder):
             t = map_range_val(iter_nr, 0.0, self.nr_iters_for_c2f, 0.3, 1.0)
         window = self.c2f(t)
         all_open = bool((window == 1.0).all())        # t = 1 (evaluation, c2f off): the window is a no-op
-        window = window.to(points.device).repeat_interleave(self.config["n_features_per_level"])
+        if not all_open:                              # (no host-to-device copy otherwise)
+            window = window.to(points.device).repeat_interleave(self.config["n_features_per_level"])
         if self.bb_sides is not None:
             out_of_bounds = torch.logical_or((points <= -self.bb_sides / 2).any(dim=1),
                                              (points >= self.bb_sides / 2).any(dim=1))
@@ -371,6 +372,9 @@ class PermutoHashEncoder(Encoder):
         else:
             t = map_range_val(iter_nr, 0.0, self.nr_iters_for_c2f, 0.3, 1.0)
         window = self.c2f(t)
+        # t = 1 (evaluation, c2f off): all ones — the kernel takes NULL for that, which also spares
+        # a host-to-device copy (an implicit synchronisation) per model and forward
+        window = None if bool((window == 1.0).all()) else window.view(-1)
         if self.bb_sides is not None:
             out_of_bounds = torch.logical_or((points <= -self.bb_sides / 2).any(dim=1),
                                              (points >= self.bb_sides / 2).any(dim=1))
@@ -378,7 +382,7 @@ class PermutoHashEncoder(Encoder):
             points = (points + 1) / 2
         else:
             out_of_bounds = None
-        enc = self.encoder(points, window.view(-1))
+        enc = self.encoder(points, window)
         if self.remove_last_element:
             enc = enc[:, :-1]
         return enc, out_of_bounds
