@@ -347,7 +347,7 @@ def main():
         from volsurfs_amd.parallel import shard_bands
         rows = shard_bands(args.res, rank, world)
     pipe = KShellPipeline.synthetic(K=args.shells, subdiv=args.subdiv, res=args.res, device=dev,
-                                    seed=42 if strong else 42 + rank, rows=rows)
+                                    seed=42, gt_seed=42 if strong else 42 + rank, rows=rows)
     N = pipe.nr_rays
 
     def barrier():

@@ -100,7 +100,7 @@ class KShellPipeline:
         return out
 
     @classmethod
-    def synthetic(cls, K=5, subdiv=6, res=800, device="cuda", seed=42, rows=None, **kw):
+    def synthetic(cls, K=5, subdiv=6, res=800, device="cuda", seed=42, rows=None, gt_seed=None, **kw):
         """res: an int (square frame) or (H, W).  rows: optional LongTensor of image rows (whole
         8-row bands, parallel.shard_bands): the pipeline then renders only those rows of the
         frame — one rank's share under strong scaling — with the loss still the frame's mean."""
@@ -108,7 +108,8 @@ class KShellPipeline:
         H, W = (res, res) if isinstance(res, int) else res
         o, d = pinhole_rays(H, W, focal=1111.1 * min(H, W) / 800.0, cam_pos=(0.0, 0.0, -1.5),
                             device=device)
-        g = torch.Generator(device=device).manual_seed(seed)
+        # (gt_seed: data-parallel ranks share the parameters — `seed` — and differ in their data)
+        g = torch.Generator(device=device).manual_seed(seed if gt_seed is None else gt_seed)
         gt = torch.rand(o.shape[0], 3, device=device, generator=g)
         n_frame, h_local = H * W, H
         if rows is not None:
