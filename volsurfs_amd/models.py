@@ -164,6 +164,13 @@ class MLP(torch.nn.Module):
                 if self.bias:
                     params.append(m.bias)
             return _FusedMLP.apply(x, bool(self.bias), *params)
+        if MLP.fused and x.is_cuda and not getattr(self, "_warned_unfused", False):
+            # not silent: a CUDA MLP outside what csrc/mlp_f32.hip covers (wider than 128, hidden
+            # widths not multiples of 32, GELU after the last layer, non-fp32) runs as library GEMMs
+            import warnings
+            warnings.warn(f"volsurfs_amd.models.MLP {dims}: outside the fused HIP kernel's shapes; "
+                          "running the torch op sequence (rocBLAS GEMMs)", RuntimeWarning, stacklevel=2)
+            self._warned_unfused = True
         for layer in self.layers:
             if isinstance(layer, torch.nn.Linear) and layer.bias is not None and x.dim() == 2 \
                     and torch.is_grad_enabled():
