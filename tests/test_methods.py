@@ -538,3 +538,53 @@ def test_baseline_config0_plumbing_case_matches_cpu_restatement():
                 assert want.abs().max() > 0
                 assert (got - want).abs().max() <= 2e-2 * want.abs().max()        # fp16 composite backward
                 assert torch.nn.functional.cosine_similarity(got.flatten(), want.flatten(), dim=0) > 0.999
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [dict(), dict(is_inner_mesh_solid=True, rgb_normal_dep=True),
+                                 dict(are_volsurfs_colors_indep=False, are_volsurfs_alphas_indep=False,
+                                      rgb_pos_encoder_type="gridhash")])
+def test_legacy_grouped_shading_equals_the_per_shell_loop(cfg):
+    """methods._shade_legacy_grouped (all shells' hits prepared at once, one grouped MLP op per
+    model type) against the per-shell loop it replaces: identical forward, equal gradients."""
+    from volsurfs_amd.camera import pinhole_rays
+    from volsurfs_amd.mesh import nested_shells
+    from volsurfs_amd.methods import VolSurfs
+    kw = dict(max_rays=4096, using_neural_textures=False, rgb_pos_encoder_type="permutohash",
+              rgb_mlp_layers_dims=(64, 32), bb_sides=1.0)
+    kw.update(cfg)
+    m = VolSurfs(nested_shells(K=3, subdiv=3), **kw)
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for mod in m.models.values():
+            enc = mod.pos_encoder.encoder
+            p = enc.lattice_values if hasattr(enc, "lattice_values") else enc.params
+            p.copy_((torch.rand(p.shape, generator=g) * 2 - 1).cuda())
+    o, d = pinhole_rays(40, 40, focal=70.0)
+    gt = torch.rand(1600, 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    res = {}
+    for grouped in (True, False):
+        VolSurfs.legacy_grouped = grouped
+        try:
+            assert m._legacy_groupable(o)
+            for p in m.parameters():
+                p.grad = None
+            losses, _, _ = m(o, d, gt, None, None)
+            losses["loss"].backward()
+            rt = m.render_rays(o, d, return_samples=False)["renders"]["ray_traced"]
+        finally:
+            VolSurfs.legacy_grouped = True
+        res[grouped] = ({k: v.detach().clone() for k, v in rt.items() if v is not None},
+                        [None if p.grad is None else p.grad.clone() for p in m.parameters()],
+                        losses["loss"].item())
+    for k in res[True][0]:
+        assert torch.equal(res[True][0][k], res[False][0][k]), k
+    assert res[True][2] == res[False][2]
+    n_with_grad = 0
+    for a, b in zip(res[True][1], res[False][1]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            n_with_grad += 1
+            s_ = b.abs().max().item()
+            assert (a - b).abs().max().item() <= 1e-5 * s_ + 1e-12
+    assert n_with_grad >= 6

@@ -199,9 +199,99 @@ class VolSurfs(torch.nn.Module):
         else:
             self.optimizer.step()    # (refreshes bank.tables_h / weights_h inside the kernel)
 
+    legacy_grouped = True     # class-wide switch: False = the per-shell loop (tests compare the two)
+
+    def _legacy_groupable(self, x_probe):
+        """The grouped path covers the configuration BASELINE configs[2] trains: every model an `RGB`
+        with a position encoder, no geometry features, and per type (rgb / alpha) one MLP architecture
+        and one set of input flags."""
+        from .models import RGB, mlps_groupable
+        for typ in ("rgb", "alpha"):
+            mods = [m for k, m in self.models.items() if k.split("_")[0] == typ]
+            if not mods:
+                continue
+            if not all(isinstance(m, RGB) and m.pos_dep and not m.geom_feat_dep for m in mods):
+                return False
+            f0 = (mods[0].view_dep, mods[0].normal_dep, mods[0].sh_deg, mods[0].dir_encoder_type)
+            if any((m.view_dep, m.normal_dep, m.sh_deg, m.dir_encoder_type) != f0 for m in mods):
+                return False
+            if not mlps_groupable([m.mlp for m in mods], x_probe):
+                return False
+        return True
+
+    def _shade_legacy_grouped(self, rays_o, rays_d, hit_t, hit_slot, iter_nr):
+        """The same arithmetic as the per-shell loop with the hits of ALL shells prepared at once and
+        each model type evaluated as one grouped op (models._FusedMLPGrouped): ~80 torch ops per
+        call instead of ~350 — the legacy training loop is bound by the host's op dispatch."""
+        from .models import fused_mlp_grouped
+        N, K = rays_o.shape[0], self.nr_meshes
+        dev = rays_o.device
+        surfs_rgb = torch.zeros(N, K, 3, device=dev)
+        surfs_alpha = torch.zeros(N, K, device=dev)
+        surfs_normals = torch.zeros(N, K, 3, device=dev)
+        shell_of, ray_of = (hit_slot >= 0).nonzero(as_tuple=True)      # sorted by shell, then ray
+        counts = torch.bincount(shell_of, minlength=K).tolist()
+        M = int(sum(counts))
+        if M == 0:
+            return surfs_rgb, surfs_alpha, surfs_normals
+        begin = [0]
+        for c in counts:
+            begin.append(begin[-1] + c)
+        slots = hit_slot[shell_of, ray_of].long()
+        tri = self.raytracer.tris[slots]
+        nrm = torch.nn.functional.normalize(torch.cross(tri[:, 4:7], tri[:, 8:11], dim=1), dim=1)
+        d = rays_d[ray_of]
+        pts = rays_o[ray_of] + hit_t[shell_of, ray_of][:, None] * d
+
+        def evaluate(typ, indep, first_shell):
+            """sigmoid(MLP(cat(pos enc, dir enc, normals))) for the hits of shells >= first_shell."""
+            a0 = begin[first_shell]
+            if a0 == M:
+                return None
+            if indep:
+                mods = [self.models[f"{typ}_{i}"] for i in range(first_shell, K)]
+                sizes = counts[first_shell:]
+            else:
+                mods, sizes = [self.models[typ]], [M - a0]
+            m0 = mods[0]
+            encs, a = [], a0
+            for mod, n in zip(mods, sizes):
+                if n:
+                    f = mod.pos_encoder(pts[a:a + n], iter_nr=iter_nr)
+                    encs.append(f[0] if isinstance(f, tuple) else f)
+                a += n
+            parts = [torch.cat(encs, 0) if len(encs) > 1 else encs[0]]
+            if m0.view_dep:
+                with torch.no_grad():
+                    parts.append(m0.dir_encoder(d[a0:], iter_nr=iter_nr))
+            if m0.normal_dep:
+                parts.append(nrm[a0:])
+            y = fused_mlp_grouped([mod.mlp for mod in mods], torch.cat(parts, 1), sizes)
+            return torch.sigmoid(y)
+        pred = evaluate("rgb", self.colors_indep, 0)
+        surfs_rgb = surfs_rgb.index_put((ray_of, shell_of), pred[:, :3])
+        first = 1 if self.solid_inner else 0
+        alpha = torch.ones(M, device=dev)
+        has_alpha = any(k.split("_")[0] == "alpha" for k in self.models)
+        if has_alpha:
+            pa = evaluate("alpha", self.alphas_indep, first)
+            if pa is not None:
+                av = pa[:, 0]
+                if self.with_alpha_decay:
+                    with torch.no_grad():
+                        dot = torch.sum(-d[begin[first]:] * nrm[begin[first]:], dim=1).clamp(0.0, 1.0)
+                        decay = torch.sigmoid(10.0 * dot) * 2.0 - 1.0
+                    av = av * decay
+                alpha = torch.cat([alpha[:begin[first]], av]) if begin[first] else av
+        surfs_alpha = surfs_alpha.index_put((ray_of, shell_of), alpha)
+        surfs_normals = surfs_normals.index_put((ray_of, shell_of), nrm)
+        return surfs_rgb, surfs_alpha, surfs_normals
+
     def _shade_legacy(self, rays_o, rays_d, hit_t, hit_slot, iter_nr):
         """volsurfs.py:486-599, legacy branch: per shell, the hit points / view directions /
         face normals go through that shell's RGB (or ColorSH) models; alpha decay; dense scatter."""
+        if VolSurfs.legacy_grouped and self._legacy_groupable(rays_o):
+            return self._shade_legacy_grouped(rays_o, rays_d, hit_t, hit_slot, iter_nr)
         N, K = rays_o.shape[0], self.nr_meshes
         dev = rays_o.device
         surfs_rgb = torch.zeros(N, K, 3, device=dev)

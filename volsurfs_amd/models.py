@@ -132,6 +132,111 @@ class _FusedMLP(torch.autograd.Function):
         return (dx, None, *out)
 
 
+class _FusedMLPGrouped(torch.autograd.Function):
+    """G MLPs of ONE architecture (the per-shell models of the legacy appearance branch) applied to
+    G consecutive row segments of x in one autograd node: the C entry points are called per group on
+    slices, so the kernels are the single-model ones, but torch sees one op instead of G x (apply +
+    allocations + saved tensors) — the training loop of BASELINE configs[2] is bound by the host's
+    op dispatch, not by the GPU.  params = group-major (w_0, b_0, w_1, b_1, ...) per group."""
+
+    @staticmethod
+    def forward(ctx, x, sizes, has_bias, nl, *params):
+        x = x.contiguous()
+        per = nl * (2 if has_bias else 1)
+        G = len(sizes)
+        groups = []
+        for g in range(G):
+            ps = params[g * per:(g + 1) * per]
+            ws = [(ps[2 * l] if has_bias else ps[l]).contiguous() for l in range(nl)]
+            bs = [ps[2 * l + 1].contiguous() if has_bias else None for l in range(nl)]
+            groups.append((ws, bs))
+        need = x.requires_grad or any(p_.requires_grad for p_ in params)
+        dev = x.device
+        out_dim = groups[0][0][-1].shape[0]
+        hidden = sum(w.shape[0] for w in groups[0][0][:-1])
+        packed_n = sum(((w.shape[0] + 31) // 32) * ((w.shape[1] + 31) // 32) * 1024 for w in groups[0][0])
+        M = x.shape[0]
+        y = torch.empty(M, out_dim, device=dev)
+        z = torch.empty(max(M * hidden, 1), device=dev) if need else None
+        packed = torch.empty(max(packed_n, 1), device=dev)
+        a = 0
+        for g, n in enumerate(sizes):
+            if n:
+                plan = _mlp_plan(*groups[g])
+                _lib.call("vsa_mlp_fwd", ctypes.byref(plan), x[a:a + n], x.shape[1], n, y[a:a + n], out_dim,
+                          z[a * hidden:] if z is not None else None, packed, _lib.stream_ptr())
+            a += n
+        ctx.save_for_backward(x, z, *[t for ws, bs in groups for t in ws + [b for b in bs if b is not None]])
+        ctx.meta = (tuple(sizes), has_bias, nl, hidden, packed_n)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        sizes, has_bias, nl, hidden, packed_n = ctx.meta
+        x, z = ctx.saved_tensors[:2]
+        flat = list(ctx.saved_tensors[2:])
+        per = nl * (2 if has_bias else 1)
+        dev = x.device
+        gy = gy.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        nmax = max(sizes) if sizes else 0
+        dz = torch.empty(max(nmax * hidden, 1), device=dev)
+        av = torch.empty(max(nmax * hidden, 1), device=dev)
+        packed = torch.empty(max(packed_n, 1), device=dev)
+        partial = None
+        grads_out = []
+        a = 0
+        for g, n in enumerate(sizes):
+            ps = flat[g * per:(g + 1) * per]
+            ws, bs = ps[:nl], (ps[nl:] if has_bias else [None] * nl)
+            gw = [torch.zeros_like(w) if n == 0 else torch.empty_like(w) for w in ws]
+            gb = [None if b is None else (torch.zeros_like(b) if n == 0 else torch.empty_like(b)) for b in bs]
+            if n:
+                plan = _mlp_plan(ws, bs)
+                if partial is None:
+                    sz = ctypes.c_longlong()
+                    _lib.call("vsa_mlp_workspace", ctypes.byref(plan), ctypes.c_longlong(nmax), None, None,
+                              ctypes.byref(sz))
+                    partial = torch.empty(max(sz.value, 1), device=dev)
+                grads = MlpGrads()
+                for l in range(nl):
+                    grads.dw[l] = gw[l].data_ptr()
+                    grads.db[l] = gb[l].data_ptr() if gb[l] is not None else None
+                _lib.call("vsa_mlp_bwd", ctypes.byref(plan), x[a:a + n], x.shape[1], n, gy[a:a + n], gy.shape[1],
+                          z[a * hidden:], dz, av, packed, partial, dx[a:a + n] if dx is not None else None,
+                          x.shape[1], ctypes.byref(grads), _lib.stream_ptr())
+            for l in range(nl):
+                grads_out.append(gw[l])
+                if has_bias:
+                    grads_out.append(gb[l])
+            a += n
+        return (dx, None, None, None, *grads_out)
+
+
+def fused_mlp_grouped(mlps, x, sizes):
+    """mlps: G `MLP` modules of one architecture; x [sum(sizes), in]; segment g goes through
+    mlps[g].  Returns [sum(sizes), out]."""
+    first = [m for m in mlps[0].layers if isinstance(m, torch.nn.Linear)]
+    nl, has_bias = len(first), bool(mlps[0].bias)
+    params = []
+    for mlp in mlps:
+        lin = [m for m in mlp.layers if isinstance(m, torch.nn.Linear)]
+        for m in lin:
+            params.append(m.weight)
+            if has_bias:
+                params.append(m.bias)
+    return _FusedMLPGrouped.apply(x, tuple(int(n) for n in sizes), has_bias, nl, *params)
+
+
+def mlps_groupable(mlps, x):
+    """All MLPs share one architecture the fused kernel covers."""
+    def sig(m):
+        lin = [l for l in m.layers if isinstance(l, torch.nn.Linear)]
+        return ([lin[0].in_features] + [l.out_features for l in lin], bool(m.bias), m.last_layer_linear)
+    s0 = sig(mlps[0])
+    return (MLP.fused and s0[2] and all(sig(m) == s0 for m in mlps) and fused_mlp_supported(s0[0], x))
+
+
 class MLP(torch.nn.Module):
     """models/mlp.py:8-69: Linear + GELU stack, optional linear last layer."""
 
