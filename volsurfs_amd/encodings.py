@@ -110,6 +110,10 @@ class HashGrid(torch.nn.Module):
 
 
 class Encoder(torch.nn.Module):
+    # hash encoders return (features, points_out_of_bounds) like the reference's; the models that own
+    # them (RGB / ColorSH / NerfHash, here as there) use only the features and switch the mask off
+    compute_out_of_bounds = True
+
     def __init__(self, input_dim, output_dim):
         super().__init__()
         self.input_dim, self.output_dim = input_dim, output_dim
@@ -162,11 +166,15 @@ class Coarse2Fine:
 
     def __init__(self, nr_levels):
         self.nr_levels = nr_levels
+        self._memo = (None, None)
 
     def __call__(self, t):
-        alpha = float(t) * self.nr_levels
-        i = torch.arange(self.nr_levels, dtype=torch.float32)
-        return 0.5 * (1.0 - torch.cos(math.pi * torch.clamp(alpha - i, 0.0, 1.0)))
+        t = float(t)
+        if self._memo[0] != t:           # (t is constant for whole phases of training: 1.0 once c2f is over)
+            alpha = t * self.nr_levels
+            i = torch.arange(self.nr_levels, dtype=torch.float32)
+            self._memo = (t, 0.5 * (1.0 - torch.cos(math.pi * torch.clamp(alpha - i, 0.0, 1.0))))
+        return self._memo[1]
 
 
 def map_range_val(input_val, input_start, input_end, output_start, output_end):
@@ -214,13 +222,13 @@ class GridHashEncoder(Encoder):
         all_open = bool((window == 1.0).all())        # t = 1 (evaluation, c2f off): the window is a no-op
         if not all_open:                              # (no host-to-device copy otherwise)
             window = window.to(points.device).repeat_interleave(self.config["n_features_per_level"])
+        out_of_bounds = None
         if self.bb_sides is not None:
-            out_of_bounds = torch.logical_or((points <= -self.bb_sides / 2).any(dim=1),
-                                             (points >= self.bb_sides / 2).any(dim=1))
+            if self.compute_out_of_bounds:
+                out_of_bounds = torch.logical_or((points <= -self.bb_sides / 2).any(dim=1),
+                                                 (points >= self.bb_sides / 2).any(dim=1))
             points = points * (1 / (self.bb_sides / 2))
             points = (points + 1) / 2
-        else:
-            out_of_bounds = None
         enc = self.encoder(points)
         if not all_open:                              # (x * 1 is exact: skipping it changes no bit, and
             enc = enc * window                        #  saves two passes over [samples, 48] per step)
@@ -375,13 +383,13 @@ class PermutoHashEncoder(Encoder):
         # t = 1 (evaluation, c2f off): all ones — the kernel takes NULL for that, which also spares
         # a host-to-device copy (an implicit synchronisation) per model and forward
         window = None if bool((window == 1.0).all()) else window.view(-1)
+        out_of_bounds = None
         if self.bb_sides is not None:
-            out_of_bounds = torch.logical_or((points <= -self.bb_sides / 2).any(dim=1),
-                                             (points >= self.bb_sides / 2).any(dim=1))
+            if self.compute_out_of_bounds:
+                out_of_bounds = torch.logical_or((points <= -self.bb_sides / 2).any(dim=1),
+                                                 (points >= self.bb_sides / 2).any(dim=1))
             points = points * (1 / (self.bb_sides / 2))
             points = (points + 1) / 2
-        else:
-            out_of_bounds = None
         enc = self.encoder(points, window)
         if self.remove_last_element:
             enc = enc[:, :-1]

@@ -324,6 +324,7 @@ class RGB(torch.nn.Module):
             self.pos_encoder = get_encoder(pos_encoder_type, input_dim=in_channels, nr_levels=24,
                                            nr_iters_for_c2f=nr_iters_for_c2f, multires=6,
                                            bb_sides=self.bb_sides)
+            self.pos_encoder.compute_out_of_bounds = False       # (models/rgb.py:112-116 drops it too)
             mlp_in += self.pos_encoder.output_dim
         if view_dep:
             self.dir_encoder = get_encoder(dir_encoder_type, input_dim=3, degree=sh_deg)
@@ -381,6 +382,7 @@ class ColorSH(torch.nn.Module):
         # the reference passes `points_scaling=` here, which get_encoder ignores: bb_sides=None
         self.pos_encoder = get_encoder(pos_encoder_type, input_dim=in_channels, nr_levels=24,
                                        nr_iters_for_c2f=nr_iters_for_c2f, multires=6)
+        self.pos_encoder.compute_out_of_bounds = False
         mlp_in = self.pos_encoder.output_dim + (3 if normal_dep else 0) + \
             (in_geom_feat_size if geom_feat_dep else 0)
         self.mlp = MLP(mlp_in, self.mlp_layers_dims + [self.out_channels], last_layer_linear=True).to(device)
@@ -415,6 +417,7 @@ class NerfHash(torch.nn.Module):
         self.pos_encoder_type, self.dir_encoder_type = pos_encoder_type, dir_encoder_type
         self.pos_encoder = get_encoder(pos_encoder_type, input_dim=in_channels, nr_levels=24,
                                        nr_iters_for_c2f=nr_iters_for_c2f, multires=6, bb_sides=2.0)
+        self.pos_encoder.compute_out_of_bounds = False
         self.pos_encoder_output_dims = self.pos_encoder.output_dim
         self.dir_encoder = get_encoder(dir_encoder_type, input_dim=3, degree=3)
         self.dir_encoder_output_dims = self.dir_encoder.output_dim
