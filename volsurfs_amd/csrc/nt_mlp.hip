@@ -52,12 +52,31 @@ __device__ void stage_weights_fwd(const _Float16* __restrict__ W, half8_t* s_fra
   }
 }
 
+// INT_RELU: the maximum taken on the f16 BIT patterns as signed 16-bit integers (v_pk_max_i16).
+// Same values as the floating-point maximum for every finite input, but a zero always comes out
+// as +0 (bits 0), never -0: the backward pass tests "activation > 0" as "bits != 0" without
+// stripping the sign first.
+template <bool INT_RELU = false>
 __device__ __forceinline__ half8_t relu_pack(const float16_t& acc, int s) {
   half8_t b;
 #pragma unroll
   for (int j = 0; j < 8; ++j) b[j] = (_Float16)acc[8 * s + j];
   // ReLU after the fp16 rounding (same values as before it): 4 v_pk_max_f16
-  return __builtin_elementwise_max(b, half8_t{0, 0, 0, 0, 0, 0, 0, 0});
+  if constexpr (INT_RELU) {
+    // (inline asm on the packed words: the vector form on short8 makes the compiler convert the
+    // accumulators one by one and pack them with v_perm_b32 instead of v_cvt_pk_f16_f32)
+    typedef unsigned uint4v_ __attribute__((ext_vector_type(4)));
+    uint4v_ bi = __builtin_bit_cast(uint4v_, b);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned w = bi[i];
+      asm("v_pk_max_i16 %0, %0, 0" : "+v"(w));
+      bi[i] = w;
+    }
+    return __builtin_bit_cast(half8_t, bi);
+  } else {
+    return __builtin_elementwise_max(b, half8_t{0, 0, 0, 0, 0, 0, 0, 0});
+  }
 }
 
 struct TexInfo {
@@ -97,6 +116,7 @@ __device__ __forceinline__ TexInfo tex_info(const vsa_nt_plan& p, const int* seg
 // wf: the 16 forward weight fragments of this lane, register resident (loaded once
 // per workgroup task; re-reading them from LDS per MFMA exposes an LDS round trip
 // in front of every matrix instruction at one wave per SIMD).
+template <bool INT_RELU = false>
 __device__ __forceinline__ void mlp_tile_fwd(const half8_t wf[16], const half8_t bx[2],
                                              half8_t b2[4], half8_t b3[4], float16_t& acc3) {
 #pragma unroll
@@ -105,8 +125,8 @@ __device__ __forceinline__ void mlp_tile_fwd(const half8_t wf[16], const half8_t
 #pragma unroll
     for (int s = 0; s < 2; ++s)
       a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[m * 2 + s], bx[s], a, 0, 0, 0);
-    b2[2 * m] = relu_pack(a, 0);
-    b2[2 * m + 1] = relu_pack(a, 1);
+    b2[2 * m] = relu_pack<INT_RELU>(a, 0);
+    b2[2 * m + 1] = relu_pack<INT_RELU>(a, 1);
   }
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
@@ -114,8 +134,8 @@ __device__ __forceinline__ void mlp_tile_fwd(const half8_t wf[16], const half8_t
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[4 + m * 4 + q], b2[q], a, 0, 0, 0);
-    b3[2 * m] = relu_pack(a, 0);
-    b3[2 * m + 1] = relu_pack(a, 1);
+    b3[2 * m] = relu_pack<INT_RELU>(a, 0);
+    b3[2 * m + 1] = relu_pack<INT_RELU>(a, 1);
   }
   float16_t a = {0};
 #pragma unroll
@@ -141,6 +161,18 @@ __device__ __forceinline__ void load_features(const unsigned* __restrict__ F,
 
 // sigmoid with the hardware exp2 / rcp (1 ulp each): the result is quantised to 8
 // bits (forward) or multiplies a gradient (backward), so exact division buys nothing
+// fp32 product of one half of a packed f16 pair and an fp32 value: conversion and multiply in
+// one instruction (v_fma_mix_f32 with a zero addend; the same product as convert-then-multiply)
+template <int HI>
+__device__ __forceinline__ float mul_mix(unsigned h2, float f) {
+  float r;
+  if constexpr (HI)
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(f));
+  else
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(f));
+  return r;
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
@@ -241,15 +273,16 @@ __global__ __launch_bounds__(MLP_BLOCK, MLP_FWD_WGS_PER_CU) void nt_mlp_fwd_kern
 typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
 
 // accumulator -> two f16 fragments, zeroed where the forward activation was <= 0.
-// Packed integer form, 5 VALU ops per f16 pair (the element-wise select compiled to ~12):
-// the activations are ReLU outputs (>= 0, possibly -0), so "> 0" is "magnitude bits != 0";
-// min(bits, 1) * 0xffff is the per-half AND mask.
+// Packed integer form, 3 VALU ops per f16 pair (the element-wise select compiled to ~12):
+// the activations are the backward recompute's ReLU outputs (relu_pack<true>: a zero is
+// always bits 0), so "> 0" is "bits != 0"; the gradient's f16 bits times min(bits, 1) as
+// 16-bit integers are the gradient or 0.
 __device__ __forceinline__ unsigned relu_mask_pair(float a0, float a1, unsigned act_bits) {
   const half2_t hp = {(_Float16)a0, (_Float16)a1};
-  unsigned nz = act_bits & 0x7fff7fffu;
+  unsigned r = __builtin_bit_cast(unsigned, hp);
   // (inline asm: the compiler scalarises the vector form into per-half compares and selects)
-  asm("v_pk_min_u16 %0, %0, %1\n\tv_pk_mul_lo_u16 %0, %0, %2" : "+v"(nz) : "v"(0x00010001u), "v"(0xffffffffu));
-  return __builtin_bit_cast(unsigned, hp) & nz;
+  asm("v_pk_min_u16 %1, %1, %2\n\tv_pk_mul_lo_u16 %0, %0, %1" : "+v"(r), "+v"(act_bits) : "v"(0x00010001u));
+  return r;
 }
 
 __device__ __forceinline__ void mask_pack(const float16_t& acc, const half8_t& act0,
@@ -288,11 +321,8 @@ __device__ __forceinline__ void prefetch_features(const vsa_nt_plan& plan,
 //                   gradients (operands by ds_read_b64_tr_b16), dF stores, sum|dF|
 // Each role stays below 256 registers (MFMA results in plain VGPRs), hand-off is ONE
 // workgroup barrier per tile over a double-buffered image set.
-#ifndef NT_PC_CLEAR_IN_CONSUMER
-#define NT_PC_CLEAR_IN_CONSUMER 0     /* measured: slower in the consumer (0.88 vs 0.857 ms), DESIGN 9.1 */
-#endif
-#ifndef NT_PC_DW3_LATE
-#define NT_PC_DW3_LATE 0
+#ifndef NT_PC_UNROLL2
+#define NT_PC_UNROLL2 0       /* producer loop unrolled by two (no register-set copies): spills inside the loop */
 #endif
 #ifndef NT_PC_PRIO
 #define NT_PC_PRIO 0          /* issue priority: 0 consumer raised, 1 producer raised, 2 none, 3 producer at 3 */
@@ -365,6 +395,8 @@ __device__ __forceinline__ void pc_barrier() {
 // One run = a contiguous slot range [wk.first, wk.last) of ONE texture: stage the weight
 // fragments, stream the tiles through the producer/consumer pairs, reduce and flush the
 // weight gradients.
+constexpr int PC_PART_FLOATS = VSA_NT_WEIGHTS_PER_TEX;   // one wave pair's weight-gradient partials (32 KiB)
+
 __device__ __forceinline__ void pc_run(
     const vsa_nt_plan& plan, const Work wk, unsigned char* s_raw,
     const _Float16* __restrict__ weights, unsigned* __restrict__ features,
@@ -380,8 +412,17 @@ __device__ __forceinline__ void pc_run(
   const int tex = wk.tex;
   const TexInfo ti = tex_info(plan, seg_start, tex);
   {
-    const _Float16* W = weights + (long long)tex * VSA_NT_WEIGHTS_PER_TEX;
+    // the texture's 8192 weights come in with ONE 16-byte load per thread pair of rounds, then the
+    // 36 fragments are gathered from that LDS copy (gathering them from memory with 2-byte loads
+    // was 36 dependent-latency rounds per thread at the head of every run)
     half8_t* s_tmp = reinterpret_cast<half8_t*>(s_img_all);   // forward fragments, until the images start
+    _Float16* W = s_img_all + 16 * 64 * 8;                    // raw copy, behind the forward fragments
+    {
+      const half8_t* Wg = reinterpret_cast<const half8_t*>(weights + (long long)tex * VSA_NT_WEIGHTS_PER_TEX);
+      for (int i = threadIdx.x; i < VSA_NT_WEIGHTS_PER_TEX / 8; i += PC_BLOCK)
+        reinterpret_cast<half8_t*>(W)[i] = Wg[i];
+    }
+    __syncthreads();
     for (int idx = threadIdx.x; idx < 36 * 64; idx += PC_BLOCK) {
       const int frag = idx >> 6, ln = idx & 63, r = ln & 31, hh = ln >> 5;
       half8_t v;
@@ -425,6 +466,7 @@ __device__ __forceinline__ void pc_run(
   const int pr = wave & (PC_PAIRS - 1);
   _Float16* pair = s_img_all + pr * PAIR_HALFS;
   _Float16* priv = pair + 2 * SET_HALFS;
+  float* s_part = reinterpret_cast<float*>(s_img_all) + pr * PC_PART_FLOATS;   // after the tile loop
   const int ntiles = (wk.last - wk.first + 31) >> 5;
   const int iters = (ntiles + PC_PAIRS - 1) / PC_PAIRS;     // same for every wave: barriers match
 #ifdef NT_STAMP
@@ -437,74 +479,80 @@ __device__ __forceinline__ void pc_run(
 #elif NT_PC_PRIO == 3
     __builtin_amdgcn_s_setprio(3);
 #endif
-    auto load_grows = [&](int slot, half4_t gr[4]) {   // raw f16: converting here would wait for the prefetch
-      const bool ok = slot < wk.last;
+    // gradient rows of one slot (raw f16: converting here would wait for the prefetch).  No
+    // branches around the quads this lane has no use for — slots past the end, rows beyond the
+    // texture's channels: those lanes read a valid neighbouring quad (the last slot's / the
+    // group's first) and dOut is zeroed by a select once it is formed (row_ok / the slot test)
+    const half4_t* const grow_base = reinterpret_cast<const half4_t*>(grad_rows) + ti.row_first;
+    bool row_ok[4];
+    int quad_of[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      row_ok[g] = 8 * g + 4 * h < ti.channels;
+      quad_of[g] = 2 * g + (row_ok[g] ? h : 0);
+    }
+    auto load_grows = [&](int slot, half4_t (&gr)[4]) {
+      const half4_t* rp = grow_base + (long long)(min(slot, wk.last - 1) - ti.begin) * ti.row_quads;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int row0 = 8 * g + 4 * h;
         gr[g] = half4_t{0, 0, 0, 0};
-        if (ok && row0 < ti.channels) {
-          gr[g] = reinterpret_cast<const half4_t*>(grad_rows)[ti.row_first +
-                      (long long)(slot - ti.begin) * ti.row_quads + (row0 >> 2)];
-        }
+        if (8 * g < ti.channels) gr[g] = rp[quad_of[g]];     // uniform condition
       }
     };
-    float16_t gW3[2] = {float16_t{0}, float16_t{0}};   // the producer has slack: it also owns dW3
-    half8_t bx[2], bx_next[2];
-    half4_t gr[4], gr_next[4];
+    float16_t gW3[2] = {float16_t{0}, float16_t{0}};   // the producer also owns dW3
+    // two register sets for {features, gradient rows}: the trip that computes on one prefetches
+    // into the other (the loop is unrolled by two so that the sets never have to be copied)
+    half8_t bxA[2], bxB[2];
+    half4_t grA[4], grB[4];
     {
       const int s0 = wk.first + pr * 32 + p;
-      prefetch_features(plan, features, ti.type, s0, wk.last, h, bx_next);
-      load_grows(s0, gr_next);
+      prefetch_features(plan, features, ti.type, s0, wk.last, h, bxA);
+      load_grows(s0, grA);
     }
 #ifdef NT_STAMP
     unsigned long long tw_ = 0, tb_ = 0, q0, q1, q2;
 #endif
-    for (int it = 0; it <= iters; ++it) {
+    auto trip = [&](const int it, half8_t (&bx)[2], half4_t (&gr)[4], half8_t (&bx_next)[2],
+                    half4_t (&gr_next)[4]) {
       STAMP(q0);
-#if NT_PC_DW3_LATE
-      // dW3 of the PREVIOUS tile, from the image set this wave wrote before the last barrier (the
-      // consumer reads the same set meanwhile): no wait on this trip's own LDS stores, and the
-      // matrix pipe has independent work while the prefetched features arrive
-      if (it > 0) {
-        const _Float16* prev = pair + ((it - 1) & 1) * SET_HALFS;
-#pragma unroll
-        for (int sx = 0; sx < 2; ++sx) {
-          const half8_t a3 = read_tr_s<S32>(prev + SET_DOUT, 0, sx, lane);
-#pragma unroll
-          for (int m = 0; m < 2; ++m)
-            gW3[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3, read_tr_s<S64>(prev + SET_H2, 32 * m, sx, lane), gW3[m], 0, 0, 0);
-        }
-      }
-#endif
       if (it < iters) {
         const int slot = wk.first + (pr + it * PC_PAIRS) * 32 + p;
         _Float16* set = pair + (it & 1) * SET_HALFS;
-        bx[0] = bx_next[0];
-        bx[1] = bx_next[1];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) gr[g] = gr_next[g];
         if (it + 1 < iters) {
           prefetch_features(plan, features, ti.type, slot + PC_PAIRS * 32, wk.last, h, bx_next);
           load_grows(slot + PC_PAIRS * 32, gr_next);
         }
         half8_t b2[4], b3[4], d3h[2];
         float16_t acc3;
-        mlp_tile_fwd(wf, bx, b2, b3, acc3);
+        mlp_tile_fwd<true>(wf, bx, b2, b3, acc3);
         // dL/d(pre-sigmoid output): G * sig * (1 - sig) (round = STE); G is zero for
-        // padding rows and slots past the end
+        // padding rows and slots past the end.  The f16 operands enter through fused
+        // multiply-adds with a zero addend (v_fma_mix_f32: conversion and product in one
+        // instruction, the same fp32 product as convert-then-multiply)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const float gv[4] = {(float)gr[g][0], (float)gr[g][1], (float)gr[g][2], (float)gr[g][3]};
           if (8 * g < ti.channels) {
+            typedef unsigned uint2v_ __attribute__((ext_vector_type(2)));
+            const uint2v_ gb = __builtin_bit_cast(uint2v_, gr[g]);
+            const bool keep = row_ok[g] && slot < wk.last;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i2 = 0; i2 < 2; ++i2) {
+              half2_t d;
 #ifdef NT_DIAG_NOSIG      /* diagnostic only: prices the sigmoid' of dOut in the producer's stream */
-              d3h[g >> 1][4 * (g & 1) + i] = (_Float16)(gv[i] * 0.25f);
+              d.x = (_Float16)(mul_mix<0>(gb[i2], 0.25f));
+              d.y = (_Float16)(mul_mix<1>(gb[i2], 0.25f));
 #else
-              const float sg = sigmoidf_((float)(_Float16)acc3[4 * g + i]);
-              d3h[g >> 1][4 * (g & 1) + i] = (_Float16)(gv[i] * sg * (1.0f - sg));
+              const half2_t o_h = {(_Float16)acc3[4 * g + 2 * i2], (_Float16)acc3[4 * g + 2 * i2 + 1]};
+              const unsigned ob = __builtin_bit_cast(unsigned, o_h);
+              const float sg0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(mul_mix<0>(ob, -1.4426950408889634f)));
+              const float sg1 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(mul_mix<1>(ob, -1.4426950408889634f)));
+              d.x = (_Float16)(mul_mix<0>(gb[i2], sg0) * (1.0f - sg0));
+              d.y = (_Float16)(mul_mix<1>(gb[i2], sg1) * (1.0f - sg1));
 #endif
+              const unsigned db = keep ? __builtin_bit_cast(unsigned, d) : 0u;
+              const half2_t dz = __builtin_bit_cast(half2_t, db);
+              d3h[g >> 1][4 * (g & 1) + 2 * i2] = dz.x;
+              d3h[g >> 1][4 * (g & 1) + 2 * i2 + 1] = dz.y;
             }
           } else {
 #pragma unroll
@@ -515,7 +563,7 @@ __device__ __forceinline__ void pc_run(
         // store instruction covers whole stretches of a few lines (one 8-byte store per lane at
         // its own row stride touched 32 lines per instruction and cost 180 us a frame).  The
         // rows' loads have returned (d3h above); a wave's memory operations complete in order.
-#if !defined(NT_DIAG_NOCLEAR) && !NT_PC_CLEAR_IN_CONSUMER
+#if !defined(NT_DIAG_NOCLEAR)
         if (ti.channels > 0) {
           const int s0 = slot - p, nq = min(32, wk.last - s0) * ti.own_quads;
           half4_t* rows = reinterpret_cast<half4_t*>(grad_rows) + ti.row_first +
@@ -534,7 +582,6 @@ __device__ __forceinline__ void pc_run(
 #pragma unroll
         for (int sx = 0; sx < 2; ++sx)
           *reinterpret_cast<half8_t*>(set + SET_X + p * S32 + 16 * sx + 8 * h) = bx[sx];
-#if !NT_PC_DW3_LATE
         // ---- dW3 += dOut . H2^T  (transposed reads of this wave's own, just-written images)
 #pragma unroll
         for (int sx = 0; sx < 2; ++sx) {
@@ -543,7 +590,6 @@ __device__ __forceinline__ void pc_run(
           for (int m = 0; m < 2; ++m)
             gW3[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3, read_tr_s<S64>(set + SET_H2, 32 * m, sx, lane), gW3[m], 0, 0, 0);
         }
-#endif
       }
       STAMP(q1);
       pc_barrier();
@@ -551,28 +597,32 @@ __device__ __forceinline__ void pc_run(
 #ifdef NT_STAMP
       tw_ += q1 - q0; tb_ += q2 - q1;
 #endif
+    };
+#if NT_PC_UNROLL2
+    for (int it = 0; it <= iters; it += 2) {
+      trip(it, bxA, grA, bxB, grB);
+      if (it + 1 <= iters) trip(it + 1, bxB, grB, bxA, grA);
     }
+#else
+    for (int it = 0; it <= iters; ++it) {
+      trip(it, bxA, grA, bxB, grB);
+      bxA[0] = bxB[0];
+      bxA[1] = bxB[1];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) grA[g] = grB[g];
+    }
+#endif
 #ifdef NT_STAMP
     if (blockIdx.x == 0x7fffffff && lane == 0) printf("P wave %d: work %llu barrier-wait %llu cycles/tile\n", wave, tw_ / iters, tb_ / iters);
-#endif
-#ifdef NT_STAMP
     STAMP(ph2);
 #endif
-    // weight-gradient reduction: the consumers go first (they initialise the buffer),
-    // then the producers add their dW3
+    // weight-gradient partials of this pair into its own 32 KiB of the (now free) image area
     __syncthreads();
-    for (int w = 0; w < PC_PAIRS; ++w) __syncthreads();
-    float* s_acc = reinterpret_cast<float*>(s_img_all);
-    for (int w = 0; w < PC_PAIRS; ++w) {
-      if (pr == w) {
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
 #pragma unroll
-          for (int m = 0; m < 2; ++m) s_acc[W3_OFF + row * 64 + 32 * m + p] += gW3[m][reg];
-        }
-      }
-      __syncthreads();
+      for (int m = 0; m < 2; ++m) s_part[W3_OFF + row * 64 + 32 * m + p] = gW3[m][reg];
     }
   } else {
     float16_t gW2[2][2], gW1[2];
@@ -583,8 +633,8 @@ __device__ __forceinline__ void pc_run(
       gW2[i][1] = float16_t{0};
     }
     float16_t dabs = {0};   // per-lane sum |dF| per feature row (hash-grad fixed-point bound)
-    // the consumer is the longer stream AND the later-dispatched wave of its SIMD (the
-    // arbitration loser at equal priority): raise it once, statically
+    // the consumer is the later-dispatched wave of its SIMD (the arbitration loser at equal
+    // priority): raise it once, statically (measured against the other assignments)
 #if NT_PC_PRIO == 0
     __builtin_amdgcn_s_setprio(1);
 #endif
@@ -598,21 +648,6 @@ __device__ __forceinline__ void pc_run(
         const int slot = wk.first + (pr + t * PC_PAIRS) * 32 + p;
         const bool valid = slot < wk.last;
         const _Float16* set = pair + (t & 1) * SET_HALFS;
-#if NT_PC_CLEAR_IN_CONSUMER && !defined(NT_DIAG_NOCLEAR)
-        // consume-and-clear of tile t's gradient rows, by the CONSUMER: the producer read them two
-        // trips ago (prefetch) and used them last trip; in-kernel stamps show the producer as the
-        // longer stream (5 050 vs 3 880 cycles per tile, the consumer waiting 1 500 at the barrier),
-        // and pricing the clear in the producer (diagnostic build without it) gave 4 % of the kernel
-        if (ti.channels > 0) {
-          const int s0 = slot - p, nq = min(32, wk.last - s0) * ti.own_quads;
-          half4_t* rows = reinterpret_cast<half4_t*>(grad_rows) + ti.row_first +
-                          (long long)(s0 - ti.begin) * ti.row_quads;
-          for (int i = lane; i < nq; i += 64) {
-            const int sl = ti.own_quads == 1 ? i : (int)__umulhi((unsigned)i, ti.own_magic);
-            rows[sl * ti.row_quads + (i - sl * ti.own_quads)] = half4_t{0, 0, 0, 0};
-          }
-        }
-#endif
         // ---- dH2 = W3^T dOut (B operand: this point's dOut row, natural channel order)
         half8_t dh2[4];
         {
@@ -694,8 +729,6 @@ __device__ __forceinline__ void pc_run(
     }
 #ifdef NT_STAMP
     if (blockIdx.x == 0x7fffffff && lane == 0) printf("C wave %d: work %llu barrier-wait %llu cycles/tile\n", wave, tw_ / iters, tb_ / iters);
-#endif
-#ifdef NT_STAMP
     STAMP(ph2);
 #endif
     // sum |dF| per feature row: reduce over the 32 lanes of each half, one atomic per row
@@ -707,39 +740,31 @@ __device__ __forceinline__ void pc_run(
       const int f = (reg & 3) + 8 * (reg >> 2) + 4 * h;
       if (p == 0 && v != 0.0f) atomicAdd(&dfeat_abs_sum[tex * 32 + f], v);
     }
-    // workgroup reduction of the weight gradients (consumer waves take turns: LDS
-    // float atomics are slow on gfx950), then one global atomic per weight
     __syncthreads();
-    float* s_acc = reinterpret_cast<float*>(s_img_all);   // 8192 floats, aliases the images
-    for (int w = 0; w < PC_PAIRS; ++w) {
-      if (pr == w) {
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
 #pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            const int i3 = W3_OFF + row * 64 + 32 * m + p;
-            const int i1 = W1_OFF + (32 * m + row) * 32 + p;
-            if (w == 0) s_acc[i3] = 0.0f;                      // the producers add dW3 afterwards
-            s_acc[i1] = (w ? s_acc[i1] : 0.0f) + gW1[m][reg];
+      for (int m = 0; m < 2; ++m) {
+        s_part[W1_OFF + (32 * m + row) * 32 + p] = gW1[m][reg];
 #pragma unroll
-            for (int mj = 0; mj < 2; ++mj) {
-              const int i2 = W2_OFF + (32 * m + row) * 64 + 32 * mj + p;
-              s_acc[i2] = (w ? s_acc[i2] : 0.0f) + gW2[m][mj][reg];
-            }
-          }
-        }
+        for (int mj = 0; mj < 2; ++mj) s_part[W2_OFF + (32 * m + row) * 64 + 32 * mj + p] = gW2[m][mj][reg];
       }
-      __syncthreads();
     }
-    for (int w = 0; w < PC_PAIRS; ++w) __syncthreads();   // the producers' dW3 rounds
   }
+  // workgroup reduction of the weight gradients: the four pairs' partials, summed in pair order
+  // (all eight waves wrote theirs at once; the earlier scheme — pairs taking turns on one buffer,
+  // eight barrier rounds of read-modify-write — was most of a run's 38 us of fixed cost), then one
+  // global atomic per non-zero weight
+  __syncthreads();
   {
-    const float* s_acc = reinterpret_cast<const float*>(s_img_all);
+    const float* s_all = reinterpret_cast<const float*>(s_img_all);
     float* gw = grad_weights + (long long)tex * VSA_NT_WEIGHTS_PER_TEX;
     const int w3_end = W3_OFF + ti.channels * 64;
     for (int i = threadIdx.x; i < w3_end; i += PC_BLOCK) {
-      const float v = s_acc[i];
+      float v = s_all[i];
+#pragma unroll
+      for (int w = 1; w < PC_PAIRS; ++w) v += s_all[w * PC_PART_FLOATS + i];
       if (v != 0.0f) atomicAdd(&gw[i], v * gw_scale);
     }
   }
@@ -830,7 +855,9 @@ extern "C" int vsa_nt_mlp_bwd(const vsa_nt_plan* plan, const void* weights_h, vo
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
     attr_set = true;
   }
-  const size_t lds = (size_t)PC_FRAGS * 64 * 16 + (size_t)PC_PAIRS * PAIR_HALFS * 2;   // >= frags + 32 KiB reduction buffer
+  // fragments + the larger of {image sets, the four pairs' weight-gradient partials (4 x 32 KiB)}
+  constexpr size_t img_bytes = (size_t)PC_PAIRS * PAIR_HALFS * 2, part_bytes = (size_t)PC_PAIRS * PC_PART_FLOATS * 4;
+  const size_t lds = (size_t)PC_FRAGS * 64 * 16 + (img_bytes > part_bytes ? img_bytes : part_bytes);
   int nr_cus = 0;
   { const int rc = vsa_cu_count(&nr_cus); if (rc) return rc; }
   hipLaunchKernelGGL(nt_mlp_bwd_pc_kernel, dim3(nr_cus), dim3(PC_BLOCK), lds, (hipStream_t)stream,
