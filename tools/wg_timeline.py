@@ -8,10 +8,14 @@ p = KShellPipeline.synthetic()
 for _ in range(3):
     p.step()
 torch.cuda.synchronize()
-buf = np.zeros(16384 * 8, dtype=np.uint64)
+buf = np.zeros(16384 * 20, dtype=np.uint64)
 L = _lib.lib()
 rc = L.vsa_debug_read(buf.ctypes.data_as(ctypes.c_void_p))
-r = buf.reshape(-1, 8)
+stage = buf[16384 * 12:].reshape(-1, 8)
+role = buf[16384 * 8:16384 * 12].reshape(-1, 4)
+r = buf[:16384 * 8].reshape(-1, 8)
+role = role[r[:, 7] == 1]
+stage = stage[r[:, 7] == 1]
 r = r[r[:, 7] == 1]
 t0 = int(r[:, 0].min()); t1 = int(r[:, 1].max())
 print("active WGs", len(r), "kernel span us", (t1 - t0) / 100.0)
@@ -19,6 +23,10 @@ dur = (r[:, 1] - r[:, 0]).astype(np.float64) / 100
 print("WG dur us mean %.1f min %.1f max %.1f" % (dur.mean(), dur.min(), dur.max()))
 print("iters hist", sorted(collections.Counter(r[:, 3].tolist()).items()))
 print("cycles stage/loop/epi mean", r[:, 4].mean(), r[:, 5].mean(), r[:, 6].mean(), " loop/iter", (r[:, 5] / np.maximum(r[:, 3], 1)).mean())
+it_ = np.maximum(r[:, 3], 1).astype(np.float64)
+big = r[:, 3] > 100
+print("per tile (runs > 100 trips): producer work %.0f wait %.0f | consumer work %.0f wait %.0f cycles" % tuple((role[big, k] / it_[big]).mean() for k in range(4)))
+print("consumer stages per tile (dH2+mask | dH1 chain | dW2 (+dW3) | dX chain | dW1; the rest = epilogue):", " ".join("%.0f" % (stage[big, k] / it_[big]).mean() for k in range(5)))
 cu = collections.defaultdict(list)
 for row in r:
     hw = int(row[2]) & 0xffffffff; xcc = int(row[2]) >> 32

@@ -15,6 +15,8 @@
 // loads from the level-major feature planes.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "nt_common.h"
 #include "nt_quant_table.h"
 
@@ -173,6 +175,15 @@ __device__ __forceinline__ float mul_mix(unsigned h2, float f) {
   return r;
 }
 
+// {f16(lo(h2) * f0), f16(hi(h2) * f1)}: the fp32 products of the two halves of a packed f16 pair,
+// each rounded once to f16, packed (v_fma_mixlo_f16 / v_fma_mixhi_f16)
+__device__ __forceinline__ unsigned mul_mix_pk(unsigned h2, float f0, float f1) {
+  unsigned r;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(f0));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(h2), "v"(f1));
+  return r;
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
@@ -313,19 +324,30 @@ __device__ __forceinline__ void prefetch_features(const vsa_nt_plan& plan,
 // the ISSUE rate of that one wave (in-kernel stamps: 7.6k cycles per tile, of which
 // 170 wait on memory).  Here the two waves that share a SIMD (w and w+4) split a
 // tile stream so that both issue streams are busy:
-//   PRODUCER  (t)   gradient rows + features (prefetched), forward recompute,
-//                   dOut = G * sigmoid' -> writes the point-major f16 images
-//                   {dOut, H2, H1, X} of tile t into LDS buffer t&1
+//   PRODUCER  (t)   gradient rows + features (prefetched one tile ahead), forward
+//                   recompute, dOut = G * sigmoid' -> writes the point-major f16 images
+//                   {dOut, H2, H1, X} of tile t into LDS buffer t&1 (each as soon as its
+//                   fragments exist); dW3 of tile t-1 from buffer (t-1)&1 at the head of the trip
 //   CONSUMER  (t-1) reads buffer (t-1)&1: dgrad chain dH2, dH1, dX (B operands by
-//                   16-B row reads, ReLU masks from the H images), the three weight
-//                   gradients (operands by ds_read_b64_tr_b16), dF stores, sum|dF|
-// Each role stays below 256 registers (MFMA results in plain VGPRs), hand-off is ONE
-// workgroup barrier per tile over a double-buffered image set.
-#ifndef NT_PC_UNROLL2
-#define NT_PC_UNROLL2 0       /* producer loop unrolled by two (no register-set copies): spills inside the loop */
+//                   16-B row reads, ReLU masks from the H images), dW2 and dW1 (operands by
+//                   ds_read_b64_tr_b16), dF stores, sum|dF|
+// Each role stays below 256 registers with nothing spilled inside the loops (MFMA results in
+// plain VGPRs), hand-off is ONE workgroup barrier per tile over a double-buffered image set.
+// The tile loops are compiled once per output width (producer: 1..4 groups of 8 channels,
+// consumer: 1 or 2 k-steps of dH2); each instance owns its accumulators and its epilogue.
+// Round-2 stamps (NT_STAMP, tools/wg_timeline.py; cycles per tile, producer | consumer work):
+// 5050 | 3880 before, 2740 | 3460 now — see DESIGN.md 9.1 for what moved and what it cost.
+#ifndef NT_PC_DW3_CONSUMER
+#define NT_PC_DW3_CONSUMER 0    /* dW3: 0 producer, 1 consumer (from the finished images), 2 split by 32-column block */
+#endif
+#ifndef NT_PC_BATCH
+#define NT_PC_BATCH 1           /* consumer: operands fetched in batches a stage ahead of their MFMAs */
+#endif
+#ifndef NT_PC_DW3_LATE
+#define NT_PC_DW3_LATE 1        /* the producer's dW3 blocks one trip late, from the set written before the last barrier */
 #endif
 #ifndef NT_PC_PRIO
-#define NT_PC_PRIO 0          /* issue priority: 0 consumer raised, 1 producer raised, 2 none, 3 producer at 3 */
+#define NT_PC_PRIO 2          /* issue priority: 0 consumer raised, 1 producer raised, 2 none, 3 producer at 3 */
 #endif
 constexpr int PC_BLOCK = 512;
 constexpr int PC_PAIRS = 4;
@@ -335,6 +357,7 @@ constexpr int SET_HALFS = SET_H1 + 32 * S64;          // one {dOut, X, H2, H1} s
 constexpr int PRIV_HALFS = 32 * S64;                  // consumer-private dH2 / dH1 image
 constexpr int PAIR_HALFS = 2 * SET_HALFS + PRIV_HALFS;
 constexpr int PC_FRAGS = 20;   // persistent in LDS: ids 16..31 transposed (perm k), 32..35 W3^T natural k
+constexpr int PC_FRAG_ID0 = 16;
                                // (ids 0..15, the forward set, are staged through the image area into registers)
 
 template <int STRIDE>
@@ -374,6 +397,8 @@ __device__ __forceinline__ half8_t read_tr_s(const _Float16* img, int col_base, 
 
 #ifdef NT_STAMP
 __device__ unsigned long long g_dbg[16384 * 8];   // per-workgroup timeline of the last pc launch
+__device__ unsigned long long g_dbg_stage[16384 * 8];   // consumer wave 4 / producer wave 0: cycles per stage (NT_PC_BATCH build)
+__device__ unsigned long long g_dbg_role[16384 * 4];   // {producer work, wait, consumer work, wait} cycles of wave 0 / 4
 #endif
 #ifdef NT_STAMP   // diagnostic build only (tools: make EXTRA=-DNT_STAMP): per-role cycles per tile
 #define STAMP(var)                                                               \
@@ -395,14 +420,16 @@ __device__ __forceinline__ void pc_barrier() {
 // One run = a contiguous slot range [wk.first, wk.last) of ONE texture: stage the weight
 // fragments, stream the tiles through the producer/consumer pairs, reduce and flush the
 // weight gradients.
+constexpr int PC_DABS_STRIDE = 66;     // floats per (pair, register) row of the sum|dF| partials: 64 lanes + 2 (bank spread)
 constexpr int PC_PART_FLOATS = VSA_NT_WEIGHTS_PER_TEX;   // one wave pair's weight-gradient partials (32 KiB)
+static_assert(PC_PAIRS * 16 * PC_DABS_STRIDE * 4 <= PC_FRAGS * 64 * 16, "sum|dF| partials live in the fragment area");
 
 __device__ __forceinline__ void pc_run(
     const vsa_nt_plan& plan, const Work wk, unsigned char* s_raw,
     const _Float16* __restrict__ weights, unsigned* __restrict__ features,
     const int* __restrict__ seg_start, _Float16* __restrict__ grad_rows,
     float* __restrict__ grad_weights, float* __restrict__ dfeat_abs_sum, float gw_scale) {
-  half8_t* s_frag = reinterpret_cast<half8_t*>(s_raw) - 16 * 64;   // indexed by fragment id 16..35 (20 KiB)
+  half8_t* s_frag = reinterpret_cast<half8_t*>(s_raw) - PC_FRAG_ID0 * 64;   // indexed by fragment id (16|20)..35
   _Float16* s_img_all = reinterpret_cast<_Float16*>(s_raw + PC_FRAGS * 64 * 16);
 #ifdef NT_STAMP
   unsigned long long ph0, ph1, ph2, ph3, rt0, rt1;
@@ -479,152 +506,211 @@ __device__ __forceinline__ void pc_run(
 #elif NT_PC_PRIO == 3
     __builtin_amdgcn_s_setprio(3);
 #endif
-    // gradient rows of one slot (raw f16: converting here would wait for the prefetch).  No
-    // branches around the quads this lane has no use for — slots past the end, rows beyond the
-    // texture's channels: those lanes read a valid neighbouring quad (the last slot's / the
-    // group's first) and dOut is zeroed by a select once it is formed (row_ok / the slot test)
-    const half4_t* const grow_base = reinterpret_cast<const half4_t*>(grad_rows) + ti.row_first;
-    bool row_ok[4];
-    int quad_of[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      row_ok[g] = 8 * g + 4 * h < ti.channels;
-      quad_of[g] = 2 * g + (row_ok[g] ? h : 0);
-    }
-    auto load_grows = [&](int slot, half4_t (&gr)[4]) {
-      const half4_t* rp = grow_base + (long long)(min(slot, wk.last - 1) - ti.begin) * ti.row_quads;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        gr[g] = half4_t{0, 0, 0, 0};
-        if (8 * g < ti.channels) gr[g] = rp[quad_of[g]];     // uniform condition
-      }
-    };
-    float16_t gW3[2] = {float16_t{0}, float16_t{0}};   // the producer also owns dW3
-    // two register sets for {features, gradient rows}: the trip that computes on one prefetches
-    // into the other (the loop is unrolled by two so that the sets never have to be copied)
-    half8_t bxA[2], bxB[2];
-    half4_t grA[4], grB[4];
-    {
-      const int s0 = wk.first + pr * 32 + p;
-      prefetch_features(plan, features, ti.type, s0, wk.last, h, bxA);
-      load_grows(s0, grA);
-    }
 #ifdef NT_STAMP
     unsigned long long tw_ = 0, tb_ = 0, q0, q1, q2;
 #endif
-    auto trip = [&](const int it, half8_t (&bx)[2], half4_t (&gr)[4], half8_t (&bx_next)[2],
-                    half4_t (&gr_next)[4]) {
-      STAMP(q0);
-      if (it < iters) {
-        const int slot = wk.first + (pr + it * PC_PAIRS) * 32 + p;
-        _Float16* set = pair + (it & 1) * SET_HALFS;
-        if (it + 1 < iters) {
+    // The tile loop, compiled once per number NG of 8-channel groups the texture's output has
+    // (alpha textures and degree 0: 1, degrees 1-2: 2, degree 3: 3): nothing inside tests
+    // ti.channels, and channels 16..31 of dOut are neither formed nor stored when NG <= 2 (the
+    // consumer then skips their k-step; the transposed reads for dW3 see stale columns there,
+    // which only reach accumulator rows >= channels, never flushed).
+    auto run_producer = [&](auto ng_tag) {
+      constexpr int NG = decltype(ng_tag)::value;
+      // (accumulators and epilogue live inside the instance: values merging across the instances
+      // made the register allocator copy whole accumulator sets around inside the loops)
+      constexpr int PM0 = 0, PM1 = NT_PC_DW3_CONSUMER == 0 ? 2 : NT_PC_DW3_CONSUMER == 2 ? 1 : 0;   // producer's dW3 blocks
+      float16_t gW3[2] = {float16_t{0}, float16_t{0}};
+      // gradient rows of one slot (raw f16: converting here would wait for the prefetch).  No
+      // branches around the quads this lane has no use for — slots past the end, rows beyond the
+      // texture's channels: those lanes read a valid quad (the last slot's / quad 0) and dOut
+      // is zeroed by a select once it is formed (row_ok / the slot test)
+      const half4_t* const grow_base = reinterpret_cast<const half4_t*>(grad_rows) + ti.row_first;
+      bool row_ok[NG];
+      int quad_of[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        row_ok[g] = 8 * g + 4 * h < ti.channels;
+        quad_of[g] = row_ok[g] ? 2 * g + h : 0;
+      }
+      auto load_grows = [&](int slot, half4_t (&gr)[4]) {
+        const half4_t* rp = grow_base + (long long)(min(slot, wk.last - 1) - ti.begin) * ti.row_quads;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) gr[g] = rp[quad_of[g]];
+      };
+      // {features, gradient rows} of the next tile are in flight while a tile is processed.  The
+      // copy out of the landing registers comes FIRST in a trip, before the next loads are
+      // issued: the wait it needs is then for loads a whole trip old, and nothing after the new
+      // loads has to wait on the vector-memory counter (with the copy at the end of the trip the
+      // compiler put an s_waitcnt vmcnt(0) right behind the prefetch, for the path that enters the
+      // loop from its preheader — the full memory latency exposed in every trip)
+      half8_t bx[2], bx_next[2];
+      half4_t gr[4], gr_next[4];
+      {
+        const int s0 = wk.first + pr * 32 + p;
+        prefetch_features(plan, features, ti.type, s0, wk.last, h, bx_next);
+        load_grows(s0, gr_next);
+      }
+      auto dw3_from = [&](const _Float16* img) {
+        if constexpr (PM1 > PM0) {
+#pragma unroll
+          for (int sx = 0; sx < 2; ++sx) {
+            const half8_t a3 = read_tr_s<S32>(img + SET_DOUT, 0, sx, lane);
+#pragma unroll
+            for (int m = PM0; m < PM1; ++m)
+              gW3[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3, read_tr_s<S64>(img + SET_H2, 32 * m, sx, lane), gW3[m], 0, 0, 0);
+          }
+        }
+      };
+      auto trip = [&](const int it) {
+        STAMP(q0);
+        {
+#if NT_PC_DW3_LATE
+          // dW3 of the PREVIOUS tile, from the set written before the last barrier (the consumer
+          // reads the same set meanwhile): no wait on this trip's own LDS stores
+          if (it > 0) dw3_from(pair + ((it - 1) & 1) * SET_HALFS);
+#endif
+          const int slot = wk.first + (pr + it * PC_PAIRS) * 32 + p;
+          _Float16* set = pair + (it & 1) * SET_HALFS;
+          bx[0] = bx_next[0];
+          bx[1] = bx_next[1];
+#pragma unroll
+          for (int g = 0; g < NG; ++g) gr[g] = gr_next[g];
+          // consume-and-clear.  Lanes run over (slot, own quad) pairs in memory order, so a
+          // store instruction covers whole stretches of a few lines (one 8-byte store per lane at
+          // its own row stride touched 32 lines per instruction and cost 180 us a frame).  The
+          // rows' loads have returned (the copy above waited for them).  Program order per trip is
+          // {copy, clear stores, next loads}: the only wait on the vector-memory counter is the
+          // copy's, for loads that are a whole trip old, and it is exact (nothing newer in flight).
+#if !defined(NT_DIAG_NOCLEAR)
+          if (ti.channels > 0) {
+            const int s0 = slot - p, nq = min(32, wk.last - s0) * ti.own_quads;
+            half4_t* rows = reinterpret_cast<half4_t*>(grad_rows) + ti.row_first +
+                            (long long)(s0 - ti.begin) * ti.row_quads;
+            for (int i = lane; i < nq; i += 64) {
+              const int sl = ti.own_quads == 1 ? i : (int)__umulhi((unsigned)i, ti.own_magic);
+              rows[sl * ti.row_quads + (i - sl * ti.own_quads)] = half4_t{0, 0, 0, 0};
+            }
+          }
+#endif
+          // the next tile's operands: unconditional (past the end the loads clamp to the last slot)
           prefetch_features(plan, features, ti.type, slot + PC_PAIRS * 32, wk.last, h, bx_next);
           load_grows(slot + PC_PAIRS * 32, gr_next);
-        }
-        half8_t b2[4], b3[4], d3h[2];
-        float16_t acc3;
-        mlp_tile_fwd<true>(wf, bx, b2, b3, acc3);
-        // dL/d(pre-sigmoid output): G * sig * (1 - sig) (round = STE); G is zero for
-        // padding rows and slots past the end.  The f16 operands enter through fused
-        // multiply-adds with a zero addend (v_fma_mix_f32: conversion and product in one
-        // instruction, the same fp32 product as convert-then-multiply)
+          // forward recompute (mlp_tile_fwd's chain); every image is stored as soon as its
+          // fragments exist, so that they stop occupying registers and the LDS writes overlap
+          // the next layer's matrix instructions
+          float16_t acc3;
+          {
+            half8_t b2[4], b3[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          if (8 * g < ti.channels) {
+            for (int m = 0; m < 2; ++m) {
+              float16_t a = {0};
+#pragma unroll
+              for (int s_ = 0; s_ < 2; ++s_)
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[m * 2 + s_], bx[s_], a, 0, 0, 0);
+              b2[2 * m] = relu_pack<true>(a, 0);
+              b2[2 * m + 1] = relu_pack<true>(a, 1);
+              store_frags_s<S64>(set + SET_H1, 32 * m, b2[2 * m], b2[2 * m + 1], p, h);
+            }
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx)
+              *reinterpret_cast<half8_t*>(set + SET_X + p * S32 + 16 * sx + 8 * h) = bx[sx];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+              float16_t a = {0};
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[4 + m * 4 + q], b2[q], a, 0, 0, 0);
+              b3[2 * m] = relu_pack<true>(a, 0);
+              b3[2 * m + 1] = relu_pack<true>(a, 1);
+              store_frags_s<S64>(set + SET_H2, 32 * m, b3[2 * m], b3[2 * m + 1], p, h);
+            }
+            float16_t a = {0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[12 + q], b3[q], a, 0, 0, 0);
+            acc3 = a;
+          }
+          // dL/d(pre-sigmoid output): G * sig' with sig' = sig - sig^2 (round = STE); zero for
+          // padding rows and slots past the end.  The f16 operands enter through mixed-precision
+          // fused multiply-adds (conversion and fp32 product in one instruction), the last of
+          // which rounds straight to the f16 half it is stored in.
+          unsigned dq[2 * NG];     // dOut of this lane's point: channel pairs (8g + 4h + {0,1}, {2,3})
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
             typedef unsigned uint2v_ __attribute__((ext_vector_type(2)));
             const uint2v_ gb = __builtin_bit_cast(uint2v_, gr[g]);
             const bool keep = row_ok[g] && slot < wk.last;
 #pragma unroll
             for (int i2 = 0; i2 < 2; ++i2) {
-              half2_t d;
 #ifdef NT_DIAG_NOSIG      /* diagnostic only: prices the sigmoid' of dOut in the producer's stream */
-              d.x = (_Float16)(mul_mix<0>(gb[i2], 0.25f));
-              d.y = (_Float16)(mul_mix<1>(gb[i2], 0.25f));
+              const unsigned db = mul_mix_pk(gb[i2], 0.25f, 0.25f);
 #else
               const half2_t o_h = {(_Float16)acc3[4 * g + 2 * i2], (_Float16)acc3[4 * g + 2 * i2 + 1]};
               const unsigned ob = __builtin_bit_cast(unsigned, o_h);
               const float sg0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(mul_mix<0>(ob, -1.4426950408889634f)));
               const float sg1 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(mul_mix<1>(ob, -1.4426950408889634f)));
-              d.x = (_Float16)(mul_mix<0>(gb[i2], sg0) * (1.0f - sg0));
-              d.y = (_Float16)(mul_mix<1>(gb[i2], sg1) * (1.0f - sg1));
+              const unsigned db = mul_mix_pk(gb[i2], __builtin_fmaf(-sg0, sg0, sg0), __builtin_fmaf(-sg1, sg1, sg1));
 #endif
-              const unsigned db = keep ? __builtin_bit_cast(unsigned, d) : 0u;
-              const half2_t dz = __builtin_bit_cast(half2_t, db);
-              d3h[g >> 1][4 * (g & 1) + 2 * i2] = dz.x;
-              d3h[g >> 1][4 * (g & 1) + 2 * i2 + 1] = dz.y;
+              dq[2 * g + i2] = keep ? db : 0u;
             }
-          } else {
+          }
+          {
+            typedef unsigned uint2v_ __attribute__((ext_vector_type(2)));
+            _Float16* row = set + SET_DOUT + p * S32 + 4 * h;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) d3h[g >> 1][4 * (g & 1) + i] = (_Float16)0;
+            for (int g = 0; g < (NG > 2 ? 4 : 2); ++g)
+              *reinterpret_cast<uint2v_*>(row + 8 * g) = g < NG ? uint2v_{dq[2 * (g < NG ? g : 0)], dq[2 * (g < NG ? g : 0) + 1]} : uint2v_{0u, 0u};
           }
-        }
-        // consume-and-clear.  Lanes run over (slot, own quad) pairs in memory order, so a
-        // store instruction covers whole stretches of a few lines (one 8-byte store per lane at
-        // its own row stride touched 32 lines per instruction and cost 180 us a frame).  The
-        // rows' loads have returned (d3h above); a wave's memory operations complete in order.
-#if !defined(NT_DIAG_NOCLEAR)
-        if (ti.channels > 0) {
-          const int s0 = slot - p, nq = min(32, wk.last - s0) * ti.own_quads;
-          half4_t* rows = reinterpret_cast<half4_t*>(grad_rows) + ti.row_first +
-                          (long long)(s0 - ti.begin) * ti.row_quads;
-          for (int i = lane; i < nq; i += 64) {
-            const int sl = ti.own_quads == 1 ? i : (int)__umulhi((unsigned)i, ti.own_magic);
-            rows[sl * ti.row_quads + (i - sl * ti.own_quads)] = half4_t{0, 0, 0, 0};
-          }
-        }
+#if !NT_PC_DW3_LATE
+          // ---- dW3 += dOut . H2^T  (transposed reads of this wave's own, just-written images)
+          dw3_from(set);
 #endif
-        store_frags_s<S32>(set + SET_DOUT, 0, d3h[0], d3h[1], p, h);
-        store_frags_s<S64>(set + SET_H2, 0, b3[0], b3[1], p, h);
-        store_frags_s<S64>(set + SET_H2, 32, b3[2], b3[3], p, h);
-        store_frags_s<S64>(set + SET_H1, 0, b2[0], b2[1], p, h);
-        store_frags_s<S64>(set + SET_H1, 32, b2[2], b2[3], p, h);
+        }
+        STAMP(q1);
+        pc_barrier();
+        STAMP(q2);
+#ifdef NT_STAMP
+        tw_ += q1 - q0; tb_ += q2 - q1;
+#endif
+      };
+      for (int it = 0; it < iters; ++it) trip(it);
+#if NT_PC_DW3_LATE
+      if (iters > 0) dw3_from(pair + ((iters - 1) & 1) * SET_HALFS);
+#endif
+      pc_barrier();     // the consumer's last tile
+#ifdef NT_STAMP
+      STAMP(ph2);
+      if (wave == 0 && lane == 0 && blockIdx.x < 16384) { g_dbg_role[4 * blockIdx.x + 0] = tw_; g_dbg_role[4 * blockIdx.x + 1] = tb_; }
+#endif
+      // weight-gradient partials of this pair into its own 32 KiB of the (now free) image area
+      __syncthreads();
+      if constexpr (PM1 > PM0) {
+        // one lane-dependent base, the (register, tile) part of the index as an immediate offset
+        float* const b3_ = s_part + W3_OFF + 4 * h * 64 + p;
 #pragma unroll
-        for (int sx = 0; sx < 2; ++sx)
-          *reinterpret_cast<half8_t*>(set + SET_X + p * S32 + 16 * sx + 8 * h) = bx[sx];
-        // ---- dW3 += dOut . H2^T  (transposed reads of this wave's own, just-written images)
+        for (int reg = 0; reg < 16; ++reg) {
+          const int r0 = (reg & 3) + 8 * (reg >> 2);
 #pragma unroll
-        for (int sx = 0; sx < 2; ++sx) {
-          const half8_t a3 = read_tr_s<S32>(set + SET_DOUT, 0, sx, lane);
-#pragma unroll
-          for (int m = 0; m < 2; ++m)
-            gW3[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3, read_tr_s<S64>(set + SET_H2, 32 * m, sx, lane), gW3[m], 0, 0, 0);
+          for (int m = PM0; m < PM1; ++m) b3_[r0 * 64 + 32 * m] = gW3[m][reg];
         }
       }
-      STAMP(q1);
-      pc_barrier();
-      STAMP(q2);
-#ifdef NT_STAMP
-      tw_ += q1 - q0; tb_ += q2 - q1;
-#endif
     };
-#if NT_PC_UNROLL2
-    for (int it = 0; it <= iters; it += 2) {
-      trip(it, bxA, grA, bxB, grB);
-      if (it + 1 <= iters) trip(it + 1, bxB, grB, bxA, grA);
-    }
-#else
-    for (int it = 0; it <= iters; ++it) {
-      trip(it, bxA, grA, bxB, grB);
-      bxA[0] = bxB[0];
-      bxA[1] = bxB[1];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) grA[g] = grB[g];
-    }
+    if (ti.channels <= 8) run_producer(std::integral_constant<int, 1>{});
+    else if (ti.channels <= 16) run_producer(std::integral_constant<int, 2>{});
+    else if (ti.channels <= 24) run_producer(std::integral_constant<int, 3>{});
+    else run_producer(std::integral_constant<int, 4>{});
+  } else {
+    // the consumer is the later-dispatched wave of its SIMD (the arbitration loser at equal
+    // priority): raise it once, statically (measured against the other assignments, DESIGN 9.1)
+#if NT_PC_PRIO == 0
+    __builtin_amdgcn_s_setprio(1);
 #endif
 #ifdef NT_STAMP
-    if (blockIdx.x == 0x7fffffff && lane == 0) printf("P wave %d: work %llu barrier-wait %llu cycles/tile\n", wave, tw_ / iters, tb_ / iters);
-    STAMP(ph2);
+    unsigned long long tw_ = 0, tb_ = 0, q0, q1, q2;
+    unsigned long long st_[5] = {0, 0, 0, 0, 0};
 #endif
-    // weight-gradient partials of this pair into its own 32 KiB of the (now free) image area
-    __syncthreads();
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-#pragma unroll
-      for (int m = 0; m < 2; ++m) s_part[W3_OFF + row * 64 + 32 * m + p] = gW3[m][reg];
-    }
-  } else {
+    auto run_consumer = [&](auto ks_tag) {
+    constexpr int KS3 = decltype(ks_tag)::value;   // k-steps of dH2 = W3^T dOut
     float16_t gW2[2][2], gW1[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -633,14 +719,8 @@ __device__ __forceinline__ void pc_run(
       gW2[i][1] = float16_t{0};
     }
     float16_t dabs = {0};   // per-lane sum |dF| per feature row (hash-grad fixed-point bound)
-    // the consumer is the later-dispatched wave of its SIMD (the arbitration loser at equal
-    // priority): raise it once, statically (measured against the other assignments, DESIGN 9.1)
-#if NT_PC_PRIO == 0
-    __builtin_amdgcn_s_setprio(1);
-#endif
-#ifdef NT_STAMP
-    unsigned long long tw_ = 0, tb_ = 0, q0, q1, q2;
-#endif
+    constexpr int CM0 = NT_PC_DW3_CONSUMER == 2 ? 1 : 0, CM1 = NT_PC_DW3_CONSUMER ? 2 : 0;   // consumer's dW3 blocks
+    float16_t gW3[2] = {float16_t{0}, float16_t{0}};
     for (int it = 0; it <= iters; ++it) {
       STAMP(q0);
       if (it > 0) {
@@ -648,19 +728,161 @@ __device__ __forceinline__ void pc_run(
         const int slot = wk.first + (pr + t * PC_PAIRS) * 32 + p;
         const bool valid = slot < wk.last;
         const _Float16* set = pair + (t & 1) * SET_HALFS;
+#if NT_PC_BATCH
+        // Operands are fetched a stage ahead of the matrix instructions that use them, in batches,
+        // and the data-gradient chain runs while the private image's store -> transposed-read
+        // round trips are in flight (issued in the order written: each MFMA of the plain version
+        // waited for an LDS read issued right in front of it, ~28 exposed LDS latencies per tile).
+#define NT_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifdef NT_STAMP
+        unsigned long long c0_, c1_, c2_, c3_, c4_, c5_;
+        STAMP(c0_);
+#define CSTAMP(v) STAMP(v)
+#else
+#define CSTAMP(v)
+#endif
+        half8_t dh2[4], dh1[4];
+        float16_t dx;
+        {
+          // ---- stage 1: dH2 = W3^T dOut, masked by H2 > 0
+          const half8_t d0 = *reinterpret_cast<const half8_t*>(set + SET_DOUT + p * S32 + 8 * h);
+          half8_t d1 = {0, 0, 0, 0, 0, 0, 0, 0};     // channels 16..31: only degree-3 colour textures have them
+          if constexpr (KS3 == 2) d1 = *reinterpret_cast<const half8_t*>(set + SET_DOUT + p * S32 + 16 + 8 * h);
+          half8_t f3[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (KS3 == 2 || !(i & 1)) f3[i] = s_frag[(32 + i) * 64 + lane];
+          half8_t hr[4];
+          load_frags_s<S64>(set + SET_H2, 0, hr[0], hr[1], p, h);
+          load_frags_s<S64>(set + SET_H2, 32, hr[2], hr[3], p, h);
+          NT_FENCE();
+          float16_t a0 = {0}, a1 = {0};
+          a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f3[0], d0, a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f3[2], d0, a1, 0, 0, 0);
+          if constexpr (KS3 == 2) {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f3[1], d1, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f3[3], d1, a1, 0, 0, 0);
+          }
+          mask_pack(a0, hr[0], hr[1], dh2[0], dh2[1]);
+          mask_pack(a1, hr[2], hr[3], dh2[2], dh2[3]);
+        }
+        store_frags_s<S64>(priv, 0, dh2[0], dh2[1], p, h);
+        store_frags_s<S64>(priv, 32, dh2[2], dh2[3], p, h);
+        NT_FENCE();
+        CSTAMP(c1_);
+        {
+          // ---- stage 2: dH1 = W2^T dH2 (from registers) while the dH2 image lands
+          half8_t f2[8], hr[4];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) f2[i] = s_frag[(20 + i) * 64 + lane];
+          load_frags_s<S64>(set + SET_H1, 0, hr[0], hr[1], p, h);
+          load_frags_s<S64>(set + SET_H1, 32, hr[2], hr[3], p, h);
+          NT_FENCE();
+          float16_t a0 = {0}, a1 = {0};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f2[q], dh2[q], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f2[4 + q], dh2[q], a1, 0, 0, 0);
+          }
+          NT_FENCE();
+          CSTAMP(c2_);
+          // ---- stage 3: operands of dW2 += dH2 . H1^T (transposed reads), then the masks of dH1
+          half8_t a2[2][2], b1[2][2];
+#pragma unroll
+          for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+              a2[sx][m] = read_tr_s<S64>(priv, 32 * m, sx, lane);
+              b1[sx][m] = read_tr_s<S64>(set + SET_H1, 32 * m, sx, lane);
+            }
+          mask_pack(a0, hr[0], hr[1], dh1[0], dh1[1]);
+          mask_pack(a1, hr[2], hr[3], dh1[2], dh1[3]);
+          NT_FENCE();
+#pragma unroll
+          for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+              for (int mj = 0; mj < 2; ++mj)
+                gW2[m][mj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[sx][m], b1[sx][mj], gW2[m][mj], 0, 0, 0);
+        }
+        if constexpr (CM1 > CM0) {
+          // ---- dW3 += dOut . H2^T: operands from the finished images, independent of the chain
+          half8_t a3[2], b3t[2][2];
+#pragma unroll
+          for (int sx = 0; sx < 2; ++sx) {
+            a3[sx] = read_tr_s<S32>(set + SET_DOUT, 0, sx, lane);
+#pragma unroll
+            for (int m = CM0; m < CM1; ++m) b3t[sx][m] = read_tr_s<S64>(set + SET_H2, 32 * m, sx, lane);
+          }
+#pragma unroll
+          for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+            for (int m = CM0; m < CM1; ++m)
+              gW3[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3[sx], b3t[sx][m], gW3[m], 0, 0, 0);
+        }
+        NT_FENCE();
+        CSTAMP(c3_);
+        // ---- stage 4: dH1 image (dW2's reads of the private image are done), dX = W1^T dH1 meanwhile
+        store_frags_s<S64>(priv, 0, dh1[0], dh1[1], p, h);
+        store_frags_s<S64>(priv, 32, dh1[2], dh1[3], p, h);
+        {
+          half8_t f1[4], bxx[2];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) f1[q] = s_frag[(28 + q) * 64 + lane];
+#pragma unroll
+          for (int sx = 0; sx < 2; ++sx) bxx[sx] = read_tr_s<S32>(set + SET_X, 0, sx, lane);
+          NT_FENCE();
+          dx = float16_t{0};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dx = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1[q], dh1[q], dx, 0, 0, 0);
+          NT_FENCE();
+          CSTAMP(c4_);
+          // ---- stage 5: dW1 += dH1 . X^T
+          half8_t a1t[2][2];
+#pragma unroll
+          for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) a1t[sx][m] = read_tr_s<S64>(priv, 32 * m, sx, lane);
+          NT_FENCE();
+#pragma unroll
+          for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+              gW1[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1t[sx][m], bxx[sx], gW1[m], 0, 0, 0);
+        }
+        CSTAMP(c5_);
+#ifdef NT_STAMP
+        st_[0] += c1_ - c0_; st_[1] += c2_ - c1_; st_[2] += c3_ - c2_; st_[3] += c4_ - c3_; st_[4] += c5_ - c4_;
+#endif
+#undef CSTAMP
+#undef NT_FENCE
+#else
         // ---- dH2 = W3^T dOut (B operand: this point's dOut row, natural channel order)
         half8_t dh2[4];
         {
           const half8_t d0 = *reinterpret_cast<const half8_t*>(set + SET_DOUT + p * S32 + 8 * h);
-          const half8_t d1 = *reinterpret_cast<const half8_t*>(set + SET_DOUT + p * S32 + 16 + 8 * h);
+          half8_t d1 = {0, 0, 0, 0, 0, 0, 0, 0};     // channels 16..31: only degree-3 colour textures have them
+          if constexpr (KS3 == 2) d1 = *reinterpret_cast<const half8_t*>(set + SET_DOUT + p * S32 + 16 + 8 * h);
 #pragma unroll
           for (int m = 0; m < 2; ++m) {
             float16_t a = {0};
             a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_frag[(32 + m * 2 + 0) * 64 + lane], d0, a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_frag[(32 + m * 2 + 1) * 64 + lane], d1, a, 0, 0, 0);
+            if constexpr (KS3 == 2)
+              a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_frag[(32 + m * 2 + 1) * 64 + lane], d1, a, 0, 0, 0);
             half8_t h0, h1;
             load_frags_s<S64>(set + SET_H2, 32 * m, h0, h1, p, h);
             mask_pack(a, h0, h1, dh2[2 * m], dh2[2 * m + 1]);
+          }
+        }
+        // ---- dW3 += dOut . H2^T: operands from the finished images, independent of the chain
+        if constexpr (CM1 > CM0) {
+#pragma unroll
+          for (int sx = 0; sx < 2; ++sx) {
+            const half8_t a3 = read_tr_s<S32>(set + SET_DOUT, 0, sx, lane);
+#pragma unroll
+            for (int m = CM0; m < CM1; ++m)
+              gW3[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3, read_tr_s<S64>(set + SET_H2, 32 * m, sx, lane), gW3[m], 0, 0, 0);
           }
         }
         // ---- dW2 += dH2 . H1^T
@@ -704,6 +926,7 @@ __device__ __forceinline__ void pc_run(
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           dx = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_frag[(28 + q) * 64 + lane], dh1[q], dx, 0, 0, 0);
+#endif
         if (valid) {
 #pragma unroll
           for (int reg = 0; reg < 16; ++reg) dabs[reg] += fabsf(dx[reg]);
@@ -728,29 +951,43 @@ __device__ __forceinline__ void pc_run(
 #endif
     }
 #ifdef NT_STAMP
-    if (blockIdx.x == 0x7fffffff && lane == 0) printf("C wave %d: work %llu barrier-wait %llu cycles/tile\n", wave, tw_ / iters, tb_ / iters);
     STAMP(ph2);
-#endif
-    // sum |dF| per feature row: reduce over the 32 lanes of each half, one atomic per row
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      float v = dabs[reg];
-#pragma unroll
-      for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 32);
-      const int f = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-      if (p == 0 && v != 0.0f) atomicAdd(&dfeat_abs_sum[tex * 32 + f], v);
+    if (wave == PC_PAIRS && lane == 0 && blockIdx.x < 16384) {
+      g_dbg_role[4 * blockIdx.x + 2] = tw_; g_dbg_role[4 * blockIdx.x + 3] = tb_;
+      for (int i = 0; i < 5; ++i) g_dbg_stage[8 * blockIdx.x + i] = st_[i];
     }
+#endif
     __syncthreads();
+    {
+      // sum |dF| per feature row: the lanes' partial sums go to the (now free) fragment area and
+      // are added up after the barrier below (80 dependent ds_bpermute steps per wave before)
+      float* const d_ = reinterpret_cast<float*>(s_raw) + pr * (16 * PC_DABS_STRIDE) + 32 * h + p;
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      for (int reg = 0; reg < 16; ++reg) d_[reg * PC_DABS_STRIDE] = dabs[reg];
+      float* const b1_ = s_part + W1_OFF + 4 * h * 32 + p;
+      float* const b2_ = s_part + W2_OFF + 4 * h * 64 + p;
+      if constexpr (CM1 > CM0) {
+        float* const b3_ = s_part + W3_OFF + 4 * h * 64 + p;
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        s_part[W1_OFF + (32 * m + row) * 32 + p] = gW1[m][reg];
+        for (int reg = 0; reg < 16; ++reg) {
 #pragma unroll
-        for (int mj = 0; mj < 2; ++mj) s_part[W2_OFF + (32 * m + row) * 64 + 32 * mj + p] = gW2[m][mj][reg];
+          for (int m = CM0; m < CM1; ++m) b3_[((reg & 3) + 8 * (reg >> 2)) * 64 + 32 * m] = gW3[m][reg];
+        }
+      }
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int r0 = (reg & 3) + 8 * (reg >> 2);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          b1_[(32 * m + r0) * 32] = gW1[m][reg];
+#pragma unroll
+          for (int mj = 0; mj < 2; ++mj) b2_[(32 * m + r0) * 64 + 32 * mj] = gW2[m][mj][reg];
+        }
       }
     }
+    };
+    if (ti.channels <= 16) run_consumer(std::integral_constant<int, 1>{});
+    else run_consumer(std::integral_constant<int, 2>{});
   }
   // workgroup reduction of the weight gradients: the four pairs' partials, summed in pair order
   // (all eight waves wrote theirs at once; the earlier scheme — pairs taking turns on one buffer,
@@ -766,6 +1003,15 @@ __device__ __forceinline__ void pc_run(
 #pragma unroll
       for (int w = 1; w < PC_PAIRS; ++w) v += s_all[w * PC_PART_FLOATS + i];
       if (v != 0.0f) atomicAdd(&gw[i], v * gw_scale);
+    }
+    if (threadIdx.x < 32 * PC_PAIRS) {
+      const int f = threadIdx.x & 31, w = threadIdx.x >> 5;
+      const float* d_ = reinterpret_cast<const float*>(s_raw) +
+                        (w * 16 + (f & 3) + 4 * (f >> 3)) * PC_DABS_STRIDE + 32 * ((f >> 2) & 1);
+      float v = 0.0f;
+#pragma unroll 8
+      for (int i = 0; i < 32; ++i) v += d_[i];
+      if (v != 0.0f) atomicAdd(&dfeat_abs_sum[tex * 32 + f], v);
     }
   }
 #ifdef NT_STAMP
@@ -825,6 +1071,10 @@ extern "C" int vsa_span_read_mlp(void* dst) {
 #ifdef NT_STAMP
 extern "C" int vsa_debug_read(void* dst) {
   VSA_HIP_TRY(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * 16384 * 8));
+  VSA_HIP_TRY(hipMemcpyFromSymbol(static_cast<unsigned long long*>(dst) + 16384 * 8, HIP_SYMBOL(g_dbg_role),
+                                  sizeof(unsigned long long) * 16384 * 4));
+  VSA_HIP_TRY(hipMemcpyFromSymbol(static_cast<unsigned long long*>(dst) + 16384 * 12, HIP_SYMBOL(g_dbg_stage),
+                                  sizeof(unsigned long long) * 16384 * 8));
   VSA_HIP_TRY(hipMemset(nullptr, 0, 0));
   return 0;
 }
