@@ -32,28 +32,6 @@ constexpr int W1_OFF = 0, W2_OFF = 2048, W3_OFF = 6144;
 //   12..15 A3[q]      W3 rows r,     cols 16q + 8(j>>2) + 4h + (j&3)
 __device__ __forceinline__ int perm_k(int q, int h, int j) { return 16 * q + 8 * (j >> 2) + 4 * h + (j & 3); }
 
-__device__ void stage_weights_fwd(const _Float16* __restrict__ W, half8_t* s_frag) {
-  for (int idx = threadIdx.x; idx < 16 * 64; idx += MLP_BLOCK) {
-    const int frag = idx >> 6, lane = idx & 63, r = lane & 31, h = lane >> 5;
-    half8_t v;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      _Float16 x;
-      if (frag < 4) {
-        const int m = frag >> 1, s = frag & 1;
-        x = W[W1_OFF + (32 * m + r) * 32 + 16 * s + 8 * h + j];
-      } else if (frag < 12) {
-        const int f = frag - 4, m = f >> 2, q = f & 3;
-        x = W[W2_OFF + (32 * m + r) * 64 + perm_k(q, h, j)];
-      } else {
-        x = W[W3_OFF + r * 64 + perm_k(frag - 12, h, j)];
-      }
-      v[j] = x;
-    }
-    s_frag[idx] = v;
-  }
-}
-
 // INT_RELU: the maximum taken on the f16 BIT patterns as signed 16-bit integers (v_pk_max_i16).
 // Same values as the floating-point maximum for every finite input, but a zero always comes out
 // as +0 (bits 0), never -0: the backward pass tests "activation > 0" as "bits != 0" without
@@ -188,90 +166,115 @@ __device__ __forceinline__ float sigmoidf_(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 
+// The 16 forward weight fragments of this lane straight from memory: every fragment is one
+// 16-byte run (W1, natural k) or two 8-byte runs (W2 / W3, permuted k) of a weight row, so a
+// lane needs 4 + 24 wide loads per run and nothing goes through LDS (the 2-byte gather into a
+// shared image that this replaces cost 4 dependent rounds of 8 loads plus two barriers per run).
+__device__ __forceinline__ void load_fwd_frags(const _Float16* __restrict__ W, int lane, half8_t wf[16]) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    wf[i] = *reinterpret_cast<const half8_t*>(W + W1_OFF + (32 * (i >> 1) + r) * 32 + 16 * (i & 1) + 8 * h);
+#pragma unroll
+  for (int i = 4; i < 16; ++i) {
+    const _Float16* row = i < 12 ? W + W2_OFF + (32 * ((i - 4) >> 2) + r) * 64 : W + W3_OFF + r * 64;
+    const int q = i < 12 ? (i - 4) & 3 : i - 12;
+    const half4_t lo = *reinterpret_cast<const half4_t*>(row + 16 * q + 4 * h);
+    const half4_t hi = *reinterpret_cast<const half4_t*>(row + 16 * q + 8 + 4 * h);
+    wf[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+
 // Persistent: gridDim.x workgroups split the frame's 32-slot tiles evenly
 // (nt_for_each_piece: cost axis with the weight staging of a run priced at 8 tiles).
 constexpr int MLP_FWD_RUN_COST = 16;   // tiles: fitted 7.6 us per run / 0.48 us per tile (tools/fit_cost.py)
-constexpr int MLP_FWD_DEPTH = 1;        // feature tiles in flight per wave (3 measured slower: PMC shows the
-                                        // SIMDs 39 % VALU + 28 % MFMA busy, not waiting on HBM)
 constexpr int MLP_FWD_WGS_PER_CU = 3;   // 148 VGPRs -> 3 waves per SIMD, one per workgroup
 
+// PRE: also write the pre-sigmoid outputs (tests only; the production launch has no such stores).
+template <bool PRE>
 __global__ __launch_bounds__(MLP_BLOCK, MLP_FWD_WGS_PER_CU) void nt_mlp_fwd_kernel(
     vsa_nt_plan plan, const _Float16* __restrict__ weights,
     const unsigned* __restrict__ features, const int* __restrict__ seg_start,
     unsigned* __restrict__ texels, _Float16* __restrict__ pre_out) {
-  __shared__ half8_t s_frag[16 * 64];
   __shared__ unsigned s_qt[257];      // thresholds of the 8-bit quantisation (nt_quant_table.h)
   const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
   const int wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < 257; i += MLP_BLOCK) s_qt[i] = NT_QUANT_THR[i];
+  __syncthreads();
   NT_SPAN_MARK(0, 0);
   nt_for_each_piece<32>(plan, seg_start, 1, MLP_FWD_RUN_COST,
                         [&](int, int tex, int first, int last, int, int) {
     const TexInfo ti = tex_info(plan, seg_start, tex);
-    __syncthreads();   // the previous run's fragments have been read
-    stage_weights_fwd(weights + (long long)tex * VSA_NT_WEIGHTS_PER_TEX, s_frag);
-    __syncthreads();
     half8_t wf[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) wf[i] = s_frag[i * 64 + lane];
+    load_fwd_frags(weights + (long long)tex * VSA_NT_WEIGHTS_PER_TEX, lane, wf);
     const int pre_base = ti.type == 0 ? 0 : 24;    // pre_out keeps the fixed 32-wide test layout
     const int ntiles = (last - first + 31) >> 5;
-    // MLP_FWD_DEPTH tiles of features are in flight per wave (a static ring)
-    half8_t q[MLP_FWD_DEPTH][2];
-#pragma unroll
-    for (int j = 0; j < MLP_FWD_DEPTH; ++j) {
-      const int t = wave + j * MLP_WAVES;
-      if (t < ntiles) {
-        const int s0 = first + t * 32 + p;
-        load_features(features, plan, ti.type, s0 < last ? s0 : last - 1, h, q[j]);
+    // the tile loop, compiled once per number NG of 8-channel groups of the output (as the
+    // backward's producer): no test of ti.channels inside
+    auto run = [&](auto ng_tag) {
+      constexpr int NG = decltype(ng_tag)::value;
+      half8_t q[2];     // one tile of features in flight per wave
+      if (wave < ntiles) {
+        const int s0 = first + wave * 32 + p;
+        load_features(features, plan, ti.type, s0 < last ? s0 : last - 1, h, q);
       }
-    }
-    for (int tile0 = wave; tile0 < ntiles; tile0 += MLP_WAVES * MLP_FWD_DEPTH) {
-#pragma unroll
-    for (int j = 0; j < MLP_FWD_DEPTH; ++j) {
-      const int tile = tile0 + j * MLP_WAVES;
-      if (tile >= ntiles) break;
-      const int slot = first + tile * 32 + p;
-      const bool valid = slot < last;
-      half8_t bx[2];
-      bx[0] = q[j][0];
-      bx[1] = q[j][1];
-      if (tile + MLP_WAVES * MLP_FWD_DEPTH < ntiles) {   // refill this stage
-        const int sn = slot + MLP_WAVES * MLP_FWD_DEPTH * 32;
-        load_features(features, plan, ti.type, sn < last ? sn : last - 1, h, q[j]);
-      }
-      half8_t b2[4], b3[4];
-      float16_t acc3;
-      mlp_tile_fwd(wf, bx, b2, b3, acc3);
-      if (!valid) continue;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int row0 = 8 * g + 4 * h;
-        if (row0 >= ti.channels) continue;
-        unsigned packed = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const _Float16 o_h = (_Float16)acc3[4 * g + i];
-          if (pre_out && row0 + i < ti.channels)
-            pre_out[(long long)slot * 32 + pre_base + row0 + i] = o_h;
-          // the reference's round(sigmoid(x) * 255) as the exact step function of x: a fast
-          // estimate biased low by 0.01 of a step (the hardware exp2 / rcp are good to ~1e-4 of
-          // one) is the exact value or one below it; one threshold of the table decides which
-          unsigned q = (unsigned)(sigmoidf_((float)o_h) * 255.0f + 0.49f);
-          const unsigned ob = __builtin_bit_cast(unsigned short, o_h);
-          const unsigned key = (ob & 0x8000u) ? (~ob & 0xffffu) : (ob | 0x8000u);
-          q += key >= s_qt[q + 1] ? 1u : 0u;
-          unsigned qb = row0 + i < ti.channels ? q : 0u;
-          packed |= qb << (8 * i);
+      for (int tile = wave; tile < ntiles; tile += MLP_WAVES) {
+        const int slot = first + tile * 32 + p;
+        const bool valid = slot < last;
+        half8_t bx[2];
+        bx[0] = q[0];
+        bx[1] = q[1];
+        {   // the next tile's features (past the end: the last slot's again)
+          const int sn = slot + MLP_WAVES * 32;
+          load_features(features, plan, ti.type, sn < last ? sn : last - 1, h, q);
         }
-        // (measured: staging the tile's quads through LDS and storing them in memory order,
-        // as the backward's clear does, is SLOWER here: 0.28 -> 0.32 ms)
-        texels[ti.row_first + (long long)(slot - ti.begin) * ti.row_quads + (row0 >> 2)] = packed;
+        half8_t b2[4], b3[4];
+        float16_t acc3;
+        mlp_tile_fwd(wf, bx, b2, b3, acc3);
+        unsigned* const trow = texels + ti.row_first + (long long)(slot - ti.begin) * ti.row_quads + h;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const int row0 = 8 * g + 4 * h;
+          unsigned qv[4];
+#pragma unroll
+          for (int i2 = 0; i2 < 2; ++i2) {
+            const half2_t o_h = {(_Float16)acc3[4 * g + 2 * i2], (_Float16)acc3[4 * g + 2 * i2 + 1]};
+            const unsigned ob = __builtin_bit_cast(unsigned, o_h);
+            if constexpr (PRE) {
+              if (valid && row0 + 2 * i2 < ti.channels) pre_out[(long long)slot * 32 + pre_base + row0 + 2 * i2] = o_h.x;
+              if (valid && row0 + 2 * i2 + 1 < ti.channels) pre_out[(long long)slot * 32 + pre_base + row0 + 2 * i2 + 1] = o_h.y;
+            }
+            // the reference's round(sigmoid(x) * 255) as the exact step function of x: a fast
+            // estimate biased low by 0.01 of a step (the hardware exp2 / rcp are good to ~1e-4 of
+            // one) is the exact value or one below it; one threshold of the table decides which.
+            // The monotone 16-bit keys of both halves at once: negative -> ~bits, else bits | 0x8000.
+            unsigned m2 = ob, key2;
+            asm("v_pk_ashrrev_i16 %0, %1, %0" : "+v"(m2) : "v"(0x000f000fu));
+            key2 = ob ^ (m2 | 0x80008000u);
+            const float s0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(mul_mix<0>(ob, -1.4426950408889634f)));
+            const float s1 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(mul_mix<1>(ob, -1.4426950408889634f)));
+            unsigned q0 = (unsigned)__builtin_fmaf(s0, 255.0f, 0.49f);
+            unsigned q1 = (unsigned)__builtin_fmaf(s1, 255.0f, 0.49f);
+            q0 += (key2 & 0xffffu) >= s_qt[q0 + 1] ? 1u : 0u;
+            q1 += (key2 >> 16) >= s_qt[q1 + 1] ? 1u : 0u;
+            if (g == NG - 1) {     // only the last group can hold rows beyond the texture's channels
+              q0 = row0 + 2 * i2 < ti.channels ? q0 : 0u;
+              q1 = row0 + 2 * i2 + 1 < ti.channels ? q1 : 0u;
+            }
+            qv[2 * i2] = q0;
+            qv[2 * i2 + 1] = q1;
+          }
+          // (measured: staging the tile's quads through LDS and storing them in memory order,
+          // as the backward's clear does, is SLOWER here: 0.28 -> 0.32 ms)
+          if (valid && row0 < ti.channels) trow[2 * g] = qv[0] | (qv[1] << 8) | (qv[2] << 16) | (qv[3] << 24);
+        }
       }
-    }
-    }
+    };
+    if (ti.channels <= 8) run(std::integral_constant<int, 1>{});
+    else if (ti.channels <= 16) run(std::integral_constant<int, 2>{});
+    else if (ti.channels <= 24) run(std::integral_constant<int, 3>{});
+    else run(std::integral_constant<int, 4>{});
   });
-  __syncthreads();
   NT_SPAN_MARK(0, 1);
 }
 
@@ -438,32 +441,31 @@ __device__ __forceinline__ void pc_run(
 #endif
   const int tex = wk.tex;
   const TexInfo ti = tex_info(plan, seg_start, tex);
+  const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
+  const int wave = threadIdx.x >> 6;
+  const bool producer = wave < PC_PAIRS;
+  // forward fragments: straight from memory into the producers' registers (load_fwd_frags)
+  half8_t wf[16];
+  if (producer) load_fwd_frags(weights + (long long)tex * VSA_NT_WEIGHTS_PER_TEX, lane, wf);
   {
-    // the texture's 8192 weights come in with ONE 16-byte load per thread pair of rounds, then the
-    // 36 fragments are gathered from that LDS copy (gathering them from memory with 2-byte loads
-    // was 36 dependent-latency rounds per thread at the head of every run)
-    half8_t* s_tmp = reinterpret_cast<half8_t*>(s_img_all);   // forward fragments, until the images start
-    _Float16* W = s_img_all + 16 * 64 * 8;                    // raw copy, behind the forward fragments
+    // the transposed fragments 16..35 are gathers with a stride: the texture's 8192 weights come
+    // in with 16-byte loads into the (still free) image area and the fragments are gathered from
+    // that LDS copy (gathering them from memory with 2-byte loads was 36 dependent-latency
+    // rounds per thread at the head of every run)
+    _Float16* W = s_img_all;
     {
       const half8_t* Wg = reinterpret_cast<const half8_t*>(weights + (long long)tex * VSA_NT_WEIGHTS_PER_TEX);
       for (int i = threadIdx.x; i < VSA_NT_WEIGHTS_PER_TEX / 8; i += PC_BLOCK)
         reinterpret_cast<half8_t*>(W)[i] = Wg[i];
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < 36 * 64; idx += PC_BLOCK) {
+    for (int idx = 16 * 64 + threadIdx.x; idx < 36 * 64; idx += PC_BLOCK) {
       const int frag = idx >> 6, ln = idx & 63, r = ln & 31, hh = ln >> 5;
       half8_t v;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         _Float16 x;
-        if (frag < 4) {                      // forward W1
-          x = W[W1_OFF + (32 * (frag >> 1) + r) * 32 + 16 * (frag & 1) + 8 * hh + j];
-        } else if (frag < 12) {              // forward W2 (perm k)
-          const int f_ = frag - 4;
-          x = W[W2_OFF + (32 * (f_ >> 2) + r) * 64 + perm_k(f_ & 3, hh, j)];
-        } else if (frag < 16) {              // forward W3 (perm k)
-          x = W[W3_OFF + r * 64 + perm_k(frag - 12, hh, j)];
-        } else if (frag < 20) {              // W3^T, perm k (unused by v4, kept for id parity)
+        if (frag < 20) {                     // W3^T, perm k (unused by v4, kept for id parity)
           const int f_ = frag - 16;
           x = W[W3_OFF + perm_k(f_ & 1, hh, j) * 64 + 32 * (f_ >> 1) + r];
         } else if (frag < 28) {              // W2^T, perm k
@@ -477,17 +479,8 @@ __device__ __forceinline__ void pc_run(
         }
         v[j] = x;
       }
-      if (frag < 16) s_tmp[idx] = v; else s_frag[idx] = v;
+      s_frag[idx] = v;
     }
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
-  const int wave = threadIdx.x >> 6;
-  const bool producer = wave < PC_PAIRS;
-  half8_t wf[16];
-  if (producer) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) wf[i] = reinterpret_cast<const half8_t*>(s_img_all)[i * 64 + lane];
   }
   __syncthreads();   // the image area may be overwritten from here on
   const int pr = wave & (PC_PAIRS - 1);
@@ -1086,10 +1079,16 @@ extern "C" int vsa_nt_mlp_fwd(const vsa_nt_plan* plan, const void* weights_h, co
   if (!plan || !weights_h || !features || !seg_start || !texels) return VSA_ERR_ARG;
   int nr_cus = 0;
   { const int rc = vsa_cu_count(&nr_cus); if (rc) return rc; }
-  hipLaunchKernelGGL(nt_mlp_fwd_kernel, dim3(nr_cus * MLP_FWD_WGS_PER_CU), dim3(MLP_BLOCK), 0,
-                     (hipStream_t)stream, *plan, reinterpret_cast<const _Float16*>(weights_h),
-                     reinterpret_cast<const unsigned*>(features), seg_start,
-                     reinterpret_cast<unsigned*>(texels), reinterpret_cast<_Float16*>(pre_out));
+  if (pre_out)
+    hipLaunchKernelGGL(nt_mlp_fwd_kernel<true>, dim3(nr_cus * MLP_FWD_WGS_PER_CU), dim3(MLP_BLOCK), 0,
+                       (hipStream_t)stream, *plan, reinterpret_cast<const _Float16*>(weights_h),
+                       reinterpret_cast<const unsigned*>(features), seg_start,
+                       reinterpret_cast<unsigned*>(texels), reinterpret_cast<_Float16*>(pre_out));
+  else
+    hipLaunchKernelGGL(nt_mlp_fwd_kernel<false>, dim3(nr_cus * MLP_FWD_WGS_PER_CU), dim3(MLP_BLOCK), 0,
+                       (hipStream_t)stream, *plan, reinterpret_cast<const _Float16*>(weights_h),
+                       reinterpret_cast<const unsigned*>(features), seg_start,
+                       reinterpret_cast<unsigned*>(texels), nullptr);
   VSA_RETURN_LAUNCH_STATUS();
 }
 
