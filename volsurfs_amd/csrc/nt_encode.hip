@@ -131,6 +131,9 @@ __device__ __forceinline__ CellCorners cell_corners(const LevelGeom& g, float x,
   return c;
 }
 
+#ifndef NT_ENC_PREFETCH_FWD
+#define NT_ENC_PREFETCH_FWD 0     /* stretches of texel centres in flight per lane (0: loaded at their use) */
+#endif
 template <bool HASHED>
 __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
     vsa_nt_plan plan, int level0, int n_levels, const half2_t* __restrict__ tables,
@@ -170,11 +173,35 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
     const int a_first = first & ~(ENC_UNROLL_FWD - 1);
     auto run = [&](auto reuse_tag) {
       constexpr bool REUSE = decltype(reuse_tag)::value;
+#if NT_ENC_PREFETCH_FWD
+      // NT_ENC_PREFETCH_FWD stretches of texel centres are in flight per lane, requested AFTER the
+      // stores of the stretch that is being finished: the wait at the head of a trip then never
+      // includes those stores (past the end: the last stretch again, unused)
+      constexpr int PD = NT_ENC_PREFETCH_FWD;
+      const int s_max = (last - 1) & ~(ENC_UNROLL_FWD - 1);
+      float4 xyn[PD][ENC_UNROLL_FWD / 2];
+      auto request = [&](int s, float4 (&dst)[ENC_UNROLL_FWD / 2]) {
+        const float4* xp = reinterpret_cast<const float4*>(slot_xy + (s < s_max ? s : s_max));
+#pragma unroll
+        for (int i = 0; i < ENC_UNROLL_FWD / 2; ++i) dst[i] = xp[i];
+      };
+#pragma unroll
+      for (int d = 0; d < PD; ++d) request(a_first + threadIdx.x * ENC_UNROLL_FWD + d * ENC_BLOCK * ENC_UNROLL_FWD, xyn[d]);
+#endif
       for (int s0 = a_first + threadIdx.x * ENC_UNROLL_FWD; s0 < last; s0 += ENC_BLOCK * ENC_UNROLL_FWD) {
         float4 xyv[ENC_UNROLL_FWD / 2];
+#if NT_ENC_PREFETCH_FWD
+#pragma unroll
+        for (int i = 0; i < ENC_UNROLL_FWD / 2; ++i) xyv[i] = xyn[0][i];
+#pragma unroll
+        for (int d = 0; d + 1 < PD; ++d)
+#pragma unroll
+          for (int i = 0; i < ENC_UNROLL_FWD / 2; ++i) xyn[d][i] = xyn[d + 1][i];
+#else
         const float4* xp = reinterpret_cast<const float4*>(slot_xy + s0);
 #pragma unroll
         for (int i = 0; i < ENC_UNROLL_FWD / 2; ++i) xyv[i] = xp[i];
+#endif
         CellRefS cr[ENC_UNROLL_FWD];
         bool fresh[ENC_UNROLL_FWD];
 #pragma unroll
@@ -223,6 +250,9 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
           for (int u = 0; u < ENC_UNROLL_FWD; ++u)
             if (s0 + u >= first && s0 + u < last) op[u] = outw[u];
         }
+#if NT_ENC_PREFETCH_FWD
+        request(s0 + PD * ENC_BLOCK * ENC_UNROLL_FWD, xyn[PD - 1]);
+#endif
       }
     };
     if (g.scale < (float)plan.tex_res[tex % VSA_NT_MAX_DEG])
@@ -252,6 +282,9 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
 // of `level`.  NF = 1: feature `feat` only (the plane fills the LDS); NF = 2: both
 // features in one pass over the slots (two planes; levels of <= 16384 entries), which
 // shares the loads, the cell arithmetic and the indices between the features.
+#ifndef NT_ENC_PREFETCH
+#define NT_ENC_PREFETCH 1
+#endif
 template <bool HASHED, int NF, bool MERGE>
 __device__ __forceinline__ void enc_bwd_piece(
     const vsa_nt_plan& plan, int* s_g, int level, int feat, int tex, int first, int last,
@@ -297,15 +330,51 @@ __device__ __forceinline__ void enc_bwd_piece(
   // their four corner contributions are summed in registers and added once.  The sums
   // are integers, so the result is independent of this grouping.
   const int a_first = first & ~(ENC_UNROLL - 1);
+#if NT_ENC_PREFETCH
+  // NT_ENC_PREFETCH stretches of texel centres and gradients are in flight per lane (past the
+  // end: the last stretch's again, unused); the loop has no other vector-memory operation, so
+  // the wait at the head of a trip is for exactly the oldest request
+  constexpr int PD = NT_ENC_PREFETCH;
+  const int s_max = (last - 1) & ~(ENC_UNROLL - 1);
+  float4 xyn[PD][ENC_UNROLL / 2];
+  uint4 dn[PD][ENC_UNROLL / 4];
+  auto request = [&](int s, float4 (&xd)[ENC_UNROLL / 2], uint4 (&dd)[ENC_UNROLL / 4]) {
+    const int sc = s < s_max ? s : s_max;
+    const float4* xp = reinterpret_cast<const float4*>(slot_xy + sc);
+    const uint4* dp = reinterpret_cast<const uint4*>(dFw + nt_feat_in_plane(nl, sc));
+#pragma unroll
+    for (int i = 0; i < ENC_UNROLL / 2; ++i) xd[i] = xp[i];
+#pragma unroll
+    for (int i = 0; i < ENC_UNROLL / 4; ++i) dd[i] = dp[i];
+  };
+#pragma unroll
+  for (int d = 0; d < PD; ++d)
+    request(a_first + threadIdx.x * ENC_UNROLL + d * ENC_BLOCK * ENC_UNROLL, xyn[d], dn[d]);
+#endif
   for (int s0 = a_first + threadIdx.x * ENC_UNROLL; s0 < last; s0 += ENC_BLOCK * ENC_UNROLL) {
     float4 xyv[ENC_UNROLL / 2];
     uint4 dv[ENC_UNROLL / 4];
+#if NT_ENC_PREFETCH
+#pragma unroll
+    for (int i = 0; i < ENC_UNROLL / 2; ++i) xyv[i] = xyn[0][i];
+#pragma unroll
+    for (int i = 0; i < ENC_UNROLL / 4; ++i) dv[i] = dn[0][i];
+#pragma unroll
+    for (int d = 0; d + 1 < PD; ++d) {
+#pragma unroll
+      for (int i = 0; i < ENC_UNROLL / 2; ++i) xyn[d][i] = xyn[d + 1][i];
+#pragma unroll
+      for (int i = 0; i < ENC_UNROLL / 4; ++i) dn[d][i] = dn[d + 1][i];
+    }
+    request(s0 + PD * ENC_BLOCK * ENC_UNROLL, xyn[PD - 1], dn[PD - 1]);
+#else
     const float4* xp = reinterpret_cast<const float4*>(slot_xy + s0);
     const uint4* dp = reinterpret_cast<const uint4*>(dFw + nt_feat_in_plane(nl, s0));
 #pragma unroll
     for (int i = 0; i < ENC_UNROLL / 2; ++i) xyv[i] = xp[i];
 #pragma unroll
     for (int i = 0; i < ENC_UNROLL / 4; ++i) dv[i] = dp[i];
+#endif
     const unsigned dws[ENC_UNROLL] = {dv[0].x, dv[0].y, dv[0].z, dv[0].w,
                                       dv[1].x, dv[1].y, dv[1].z, dv[1].w};
     unsigned cur_idx[4] = {0, 0, 0, 0};

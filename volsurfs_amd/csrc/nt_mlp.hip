@@ -187,7 +187,10 @@ __device__ __forceinline__ void load_fwd_frags(const _Float16* __restrict__ W, i
 
 // Persistent: gridDim.x workgroups split the frame's 32-slot tiles evenly
 // (nt_for_each_piece: cost axis with the weight staging of a run priced at 8 tiles).
-constexpr int MLP_FWD_RUN_COST = 16;   // tiles: fitted 7.6 us per run / 0.48 us per tile (tools/fit_cost.py)
+#ifndef NT_FWD_RUN_COST
+#define NT_FWD_RUN_COST 16
+#endif
+constexpr int MLP_FWD_RUN_COST = NT_FWD_RUN_COST;   // tiles: fitted 7.6 us per run / 0.48 us per tile (tools/fit_cost.py)
 constexpr int MLP_FWD_WGS_PER_CU = 3;   // 148 VGPRs -> 3 waves per SIMD, one per workgroup
 
 // PRE: also write the pre-sigmoid outputs (tests only; the production launch has no such stores).
@@ -1029,7 +1032,10 @@ __device__ __forceinline__ void pc_run(
 // worst-case capacity (70 % of them empty at the bench frame, each still needing the whole
 // CU's LDS to launch and exit; in-kernel timeline: 196 of 256 CUs busy on average, 26 %
 // of a workgroup's cycles in staging + reduction): 1.35 -> 0.88 ms.
-constexpr int PC_RUN_COST = 74;   // fitted: 38.6 us per run / 0.52 us per tile (tools/fit_cost.py)
+#ifndef NT_PC_RUN_COST
+#define NT_PC_RUN_COST 74
+#endif
+constexpr int PC_RUN_COST = NT_PC_RUN_COST;   // fitted: 38.6 us per run / 0.52 us per tile (tools/fit_cost.py)
 
 __global__ __launch_bounds__(PC_BLOCK, 2) void nt_mlp_bwd_pc_kernel(
     vsa_nt_plan plan, const _Float16* __restrict__ weights,
