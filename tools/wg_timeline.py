@@ -14,9 +14,9 @@ rc = L.vsa_debug_read(buf.ctypes.data_as(ctypes.c_void_p))
 stage = buf[16384 * 12:].reshape(-1, 8)
 role = buf[16384 * 8:16384 * 12].reshape(-1, 4)
 r = buf[:16384 * 8].reshape(-1, 8)
-role = role[r[:, 7] == 1]
-stage = stage[r[:, 7] == 1]
-r = r[r[:, 7] == 1]
+role = role[r[:, 7] > 0]
+stage = stage[r[:, 7] > 0]
+r = r[r[:, 7] > 0]
 t0 = int(r[:, 0].min()); t1 = int(r[:, 1].max())
 print("active WGs", len(r), "kernel span us", (t1 - t0) / 100.0)
 dur = (r[:, 1] - r[:, 0]).astype(np.float64) / 100
@@ -27,6 +27,13 @@ it_ = np.maximum(r[:, 3], 1).astype(np.float64)
 big = r[:, 3] > 100
 print("per tile (runs > 100 trips): producer work %.0f wait %.0f | consumer work %.0f wait %.0f cycles" % tuple((role[big, k] / it_[big]).mean() for k in range(4)))
 print("consumer stages per tile (dH2+mask | dH1 chain | dW2 (+dW3) | dX chain | dW1; the rest = epilogue):", " ".join("%.0f" % (stage[big, k] / it_[big]).mean() for k in range(5)))
+# loop cycles per trip by (type, degree) of the LAST run of each workgroup (runs of > 100 trips)
+by = collections.defaultdict(list)
+for row in r:
+    if row[3] > 100:
+        tex = int(row[7]) - 1
+        by[((tex // 4) & 1, tex % 4)].append(float(row[5]) / float(row[3]))
+print("loop cycles per trip by (type, degree):", {k: round(float(np.mean(v))) for k, v in sorted(by.items())})
 cu = collections.defaultdict(list)
 for row in r:
     hw = int(row[2]) & 0xffffffff; xcc = int(row[2]) >> 32

@@ -88,8 +88,9 @@ struct Work {
 // work = n_planes x (every active texture's slots), laid out on one cost axis: plane-major,
 // and within a plane each non-empty texture contributes `ovh` units of spacing (the per-piece
 // setup: staging / zeroing / flushing LDS, fitted from per-workgroup timings, tools/fit_cost.py)
-// followed by ceil(len / UNIT) units of UNIT slots, each weighted by wt(plane, degree) / 16 (a
-// unit's relative cost where the kernel takes different code paths per level).  The axis is kept
+// followed by ceil(len / UNIT) units of UNIT slots, each weighted by wt(plane, degree, type) / 16
+// (a unit's relative cost where the kernel takes different code paths per level, or per output
+// width: type 0 = colour, 1 = alpha texture).  The axis is kept
 // in 1/16 units so that weighted lengths stay exact.  Workgroup w owns the stretch
 // [w*C/G, (w+1)*C/G) and calls body(plane, tex, first_slot, last_slot, seg_begin, seg_end) once
 // per (plane, texture) it overlaps; a unit belongs to the workgroup whose stretch contains its
@@ -97,7 +98,7 @@ struct Work {
 // Replaces grids sized for the worst-case slot capacity, where ~2/3 of the workgroups
 // found nothing to do yet each needed a whole CU's LDS to launch and exit.
 struct NtUnitWeight16 {
-  __device__ int operator()(int, int) const { return 16; }
+  __device__ int operator()(int, int, int) const { return 16; }
 };
 
 template <int UNIT, typename Body, typename Weight = NtUnitWeight16>
@@ -107,7 +108,7 @@ __device__ __forceinline__ void nt_for_each_piece(const vsa_nt_plan& plan,
                                                   int tex_end = 1 << 30, Weight wt = Weight()) {
   const int n_all = plan.nr_shells * 2 * VSA_NT_MAX_DEG;
   const int n_tex = tex_end < n_all ? tex_end : n_all;   // textures [tex_begin, n_tex) only
-  long long units_deg[VSA_NT_MAX_DEG] = {0, 0, 0, 0};
+  long long units_td[2][VSA_NT_MAX_DEG] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   long long pieces = 0;
   for (int tex = tex_begin; tex < n_tex; ++tex) {
     if (!tex_active(plan, tex)) continue;
@@ -115,7 +116,7 @@ __device__ __forceinline__ void nt_for_each_piece(const vsa_nt_plan& plan,
     const int sd = (tex / (2 * VSA_NT_MAX_DEG)) * VSA_NT_MAX_DEG + deg;
     const int len = seg_start[sd + 1] - seg_start[sd];
     if (len > 0) {
-      units_deg[deg] += (len + UNIT - 1) / UNIT;
+      units_td[(tex / VSA_NT_MAX_DEG) & 1][deg] += (len + UNIT - 1) / UNIT;
       pieces += 1;
     }
   }
@@ -123,7 +124,7 @@ __device__ __forceinline__ void nt_for_each_piece(const vsa_nt_plan& plan,
   auto plane_cost = [&](int pl) {
     long long c = pieces * ovh * 16;
 #pragma unroll
-    for (int d = 0; d < VSA_NT_MAX_DEG; ++d) c += units_deg[d] * wt(pl, d);
+    for (int d = 0; d < VSA_NT_MAX_DEG; ++d) c += units_td[0][d] * wt(pl, d, 0) + units_td[1][d] * wt(pl, d, 1);
     return c;
   };
   long long total = 0;
@@ -143,7 +144,7 @@ __device__ __forceinline__ void nt_for_each_piece(const vsa_nt_plan& plan,
       const int sd = (tex / (2 * VSA_NT_MAX_DEG)) * VSA_NT_MAX_DEG + deg;
       const int begin = seg_start[sd], end = seg_start[sd + 1];
       if (end <= begin) continue;
-      const int units = (end - begin + UNIT - 1) / UNIT, w = wt(pl, deg);
+      const int units = (end - begin + UNIT - 1) / UNIT, w = wt(pl, deg, (tex / VSA_NT_MAX_DEG) & 1);
       const long long t0 = c0 + (long long)ovh * 16;
       c0 = t0 + (long long)units * w;
       if (t0 >= hi) break;

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
   // a piece costs 87 (hashed: a 128 KiB table to stage) / 27 (dense) units of 256 slots, and a
   // unit of a level finer than the texture (no reuse of the previous slot's cell) 0.92 of one
   // that goes through the reuse bookkeeping
-  auto unit_weight = [&](int pl, int deg) {
+  auto unit_weight = [&](int pl, int deg, int) {
     return !HASHED || plan.level_scale[level0 + pl] < (float)plan.tex_res[deg] ? 16 : 15;
   };
   nt_for_each_piece<ENC_UNIT>(plan, seg_start, n_levels, HASHED ? 87 : 27,
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
   NT_SPAN_MARK(HASHED ? 3 : 2, 0);
   // fitted (tools/fit_cost.py): 145 (hashed) / 64 (dense) units per piece (zeroing + flushing the
   // LDS plane), and a unit on the no-merge path (level finer than the texture) costs 0.875
-  auto unit_weight = [&](int pl, int deg) {
+  auto unit_weight = [&](int pl, int deg, int) {
     return !HASHED || plan.level_scale[level0 + (pl >> 1)] < (float)plan.tex_res[deg] ? 16 : 14;
   };
   nt_for_each_piece<ENC_UNIT>(plan, seg_start, n_planes, HASHED ? 145 : 64,

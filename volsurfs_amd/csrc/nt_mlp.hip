@@ -187,6 +187,9 @@ __device__ __forceinline__ void load_fwd_frags(const _Float16* __restrict__ W, i
 
 // Persistent: gridDim.x workgroups split the frame's 32-slot tiles evenly
 // (nt_for_each_piece: cost axis with the weight staging of a run priced at 8 tiles).
+#ifndef NT_FWD_W_PER_GROUP
+#define NT_FWD_W_PER_GROUP 2     /* 1/16 tile units per further 8-channel output group */
+#endif
 #ifndef NT_FWD_RUN_COST
 #define NT_FWD_RUN_COST 16
 #endif
@@ -205,6 +208,12 @@ __global__ __launch_bounds__(MLP_BLOCK, MLP_FWD_WGS_PER_CU) void nt_mlp_fwd_kern
   for (int i = threadIdx.x; i < 257; i += MLP_BLOCK) s_qt[i] = NT_QUANT_THR[i];
   __syncthreads();
   NT_SPAN_MARK(0, 0);
+  // a tile's cost grows with the number of 8-channel groups the quantiser has to form and store
+  // (tools/wg_span.py: 0.85-0.88 span efficiency with equal weights)
+  auto unit_weight = [&](int, int deg, int type) {
+    const int channels = type == 0 ? 3 * (2 * deg + 1) : 2 * deg + 1;
+    return 16 + NT_FWD_W_PER_GROUP * ((channels + 7) / 8 - 1);
+  };
   nt_for_each_piece<32>(plan, seg_start, 1, MLP_FWD_RUN_COST,
                         [&](int, int tex, int first, int last, int, int) {
     const TexInfo ti = tex_info(plan, seg_start, tex);
@@ -277,7 +286,7 @@ __global__ __launch_bounds__(MLP_BLOCK, MLP_FWD_WGS_PER_CU) void nt_mlp_fwd_kern
     else if (ti.channels <= 16) run(std::integral_constant<int, 2>{});
     else if (ti.channels <= 24) run(std::integral_constant<int, 3>{});
     else run(std::integral_constant<int, 4>{});
-  });
+  }, 0, 1 << 30, unit_weight);
   NT_SPAN_MARK(0, 1);
 }
 
@@ -546,14 +555,14 @@ __device__ __forceinline__ void pc_run(
         prefetch_features(plan, features, ti.type, s0, wk.last, h, bx_next);
         load_grows(s0, gr_next);
       }
-      auto dw3_from = [&](const _Float16* img) {
+      auto dw3_from = [&](const _Float16* img_dout, const _Float16* img_h2) {
         if constexpr (PM1 > PM0) {
 #pragma unroll
           for (int sx = 0; sx < 2; ++sx) {
-            const half8_t a3 = read_tr_s<S32>(img + SET_DOUT, 0, sx, lane);
+            const half8_t a3 = read_tr_s<S32>(img_dout, 0, sx, lane);
 #pragma unroll
             for (int m = PM0; m < PM1; ++m)
-              gW3[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3, read_tr_s<S64>(img + SET_H2, 32 * m, sx, lane), gW3[m], 0, 0, 0);
+              gW3[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3, read_tr_s<S64>(img_h2, 32 * m, sx, lane), gW3[m], 0, 0, 0);
           }
         }
       };
@@ -563,14 +572,31 @@ __device__ __forceinline__ void pc_run(
 #if NT_PC_DW3_LATE
           // dW3 of the PREVIOUS tile, from the set written before the last barrier (the consumer
           // reads the same set meanwhile): no wait on this trip's own LDS stores
-          if (it > 0) dw3_from(pair + ((it - 1) & 1) * SET_HALFS);
+          if (it > 0) dw3_from(pair + ((it - 1) & 1) * SET_HALFS + SET_DOUT, pair + ((it - 1) & 1) * SET_HALFS + SET_H2);
 #endif
           const int slot = wk.first + (pr + it * PC_PAIRS) * 32 + p;
           _Float16* set = pair + (it & 1) * SET_HALFS;
+          _Float16* const img_dout_w = set + SET_DOUT;
+          _Float16* const img_h2_w = set + SET_H2;
           bx[0] = bx_next[0];
           bx[1] = bx_next[1];
 #pragma unroll
           for (int g = 0; g < NG; ++g) gr[g] = gr_next[g];
+          // pin the wait for the landed operands HERE, ahead of the clear stores and the next
+          // requests (the compiler otherwise sinks these register copies below the clear loop,
+          // where the wait for them also drains the stores just issued): an empty asm that reads
+          // every landed register and orders memory operations around it
+          {
+            typedef unsigned uint4v_ __attribute__((ext_vector_type(4)));
+            typedef unsigned uint2v_ __attribute__((ext_vector_type(2)));
+            const uint4v_ u0 = __builtin_bit_cast(uint4v_, bx[0]), u1 = __builtin_bit_cast(uint4v_, bx[1]);
+            asm volatile("" ::"v"(u0), "v"(u1) : "memory");
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+              const uint2v_ ug = __builtin_bit_cast(uint2v_, gr[g]);
+              asm volatile("" ::"v"(ug) : "memory");
+            }
+          }
           // consume-and-clear.  Lanes run over (slot, own quad) pairs in memory order, so a
           // store instruction covers whole stretches of a few lines (one 8-byte store per lane at
           // its own row stride touched 32 lines per instruction and cost 180 us a frame).  The
@@ -595,8 +621,9 @@ __device__ __forceinline__ void pc_run(
           // fragments exist, so that they stop occupying registers and the LDS writes overlap
           // the next layer's matrix instructions
           float16_t acc3;
+          half8_t b3[4];
           {
-            half8_t b2[4], b3[4];
+            half8_t b2[4];
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
               float16_t a = {0};
@@ -618,7 +645,7 @@ __device__ __forceinline__ void pc_run(
                 a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[4 + m * 4 + q], b2[q], a, 0, 0, 0);
               b3[2 * m] = relu_pack<true>(a, 0);
               b3[2 * m + 1] = relu_pack<true>(a, 1);
-              store_frags_s<S64>(set + SET_H2, 32 * m, b3[2 * m], b3[2 * m + 1], p, h);
+              store_frags_s<S64>(img_h2_w, 32 * m, b3[2 * m], b3[2 * m + 1], p, h);
             }
             float16_t a = {0};
 #pragma unroll
@@ -652,14 +679,14 @@ __device__ __forceinline__ void pc_run(
           }
           {
             typedef unsigned uint2v_ __attribute__((ext_vector_type(2)));
-            _Float16* row = set + SET_DOUT + p * S32 + 4 * h;
+            _Float16* row = img_dout_w + p * S32 + 4 * h;
 #pragma unroll
             for (int g = 0; g < (NG > 2 ? 4 : 2); ++g)
               *reinterpret_cast<uint2v_*>(row + 8 * g) = g < NG ? uint2v_{dq[2 * (g < NG ? g : 0)], dq[2 * (g < NG ? g : 0) + 1]} : uint2v_{0u, 0u};
           }
 #if !NT_PC_DW3_LATE
           // ---- dW3 += dOut . H2^T  (transposed reads of this wave's own, just-written images)
-          dw3_from(set);
+          dw3_from(img_dout_w, img_h2_w);
 #endif
         }
         STAMP(q1);
@@ -671,7 +698,7 @@ __device__ __forceinline__ void pc_run(
       };
       for (int it = 0; it < iters; ++it) trip(it);
 #if NT_PC_DW3_LATE
-      if (iters > 0) dw3_from(pair + ((iters - 1) & 1) * SET_HALFS);
+      if (iters > 0) dw3_from(pair + ((iters - 1) & 1) * SET_HALFS + SET_DOUT, pair + ((iters - 1) & 1) * SET_HALFS + SET_H2);
 #endif
       pc_barrier();     // the consumer's last tile
 #ifdef NT_STAMP
@@ -1019,7 +1046,7 @@ __device__ __forceinline__ void pc_run(
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     unsigned long long* d = g_dbg + 8 * blockIdx.x;
     d[0] = rt0; d[1] = rt1; d[2] = ((unsigned long long)xcc << 32) | hwid; d[3] = iters;
-    d[4] = ph1 - ph0; d[5] = ph2 - ph1; d[6] = ph3 - ph2; d[7] = 1;
+    d[4] = ph1 - ph0; d[5] = ph2 - ph1; d[6] = ph3 - ph2; d[7] = 1 + tex;
   }
 #endif
 }
