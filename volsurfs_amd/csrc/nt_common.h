@@ -108,7 +108,11 @@ __device__ __forceinline__ void nt_for_each_piece(const vsa_nt_plan& plan,
                                                   int tex_end = 1 << 30, Weight wt = Weight()) {
   const int n_all = plan.nr_shells * 2 * VSA_NT_MAX_DEG;
   const int n_tex = tex_end < n_all ? tex_end : n_all;   // textures [tex_begin, n_tex) only
-  long long units_td[2][VSA_NT_MAX_DEG] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  // units per (type, degree) class.  Only ever indexed with compile-time constants (the update
+  // below is a fully unrolled compare-and-add): a dynamically indexed private array lands in
+  // scratch memory, and the ~40 dependent scratch round trips of this prologue cost every
+  // persistent kernel 15-20 us per launch
+  long long units_td[2 * VSA_NT_MAX_DEG] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long pieces = 0;
   for (int tex = tex_begin; tex < n_tex; ++tex) {
     if (!tex_active(plan, tex)) continue;
@@ -116,7 +120,10 @@ __device__ __forceinline__ void nt_for_each_piece(const vsa_nt_plan& plan,
     const int sd = (tex / (2 * VSA_NT_MAX_DEG)) * VSA_NT_MAX_DEG + deg;
     const int len = seg_start[sd + 1] - seg_start[sd];
     if (len > 0) {
-      units_td[(tex / VSA_NT_MAX_DEG) & 1][deg] += (len + UNIT - 1) / UNIT;
+      const int cls = ((tex / VSA_NT_MAX_DEG) & 1) * VSA_NT_MAX_DEG + deg;
+      const long long n_units = (len + UNIT - 1) / UNIT;
+#pragma unroll
+      for (int c = 0; c < 2 * VSA_NT_MAX_DEG; ++c) units_td[c] += c == cls ? n_units : 0;
       pieces += 1;
     }
   }
@@ -124,7 +131,7 @@ __device__ __forceinline__ void nt_for_each_piece(const vsa_nt_plan& plan,
   auto plane_cost = [&](int pl) {
     long long c = pieces * ovh * 16;
 #pragma unroll
-    for (int d = 0; d < VSA_NT_MAX_DEG; ++d) c += units_td[0][d] * wt(pl, d, 0) + units_td[1][d] * wt(pl, d, 1);
+    for (int d = 0; d < VSA_NT_MAX_DEG; ++d) c += units_td[d] * wt(pl, d, 0) + units_td[VSA_NT_MAX_DEG + d] * wt(pl, d, 1);
     return c;
   };
   long long total = 0;
