@@ -51,6 +51,40 @@ __host__ __device__ inline PackOffsets pack_offsets(const vsa_mlp_plan& p) {
   return o;
 }
 
+// Per-layer constants of the plan in LDS.  The kernels walk the layers with a run-time index; on
+// the by-value kernel argument that made the compiler copy the whole plan (and the offsets
+// derived from it) to scratch memory and fetch dims / offsets / bias pointers from there inside
+// the layer loops.  Here the copy is made once with compile-time indices (straight from the
+// kernel-argument registers), and the loops read LDS.
+struct LayerMeta {
+  int dims[VSA_MLP_MAX_LAYERS + 1];
+  int fwd[VSA_MLP_MAX_LAYERS + 1];       // PackOffsets::fwd
+  const float* b[VSA_MLP_MAX_LAYERS];
+};
+
+__device__ __forceinline__ void load_layer_meta(const vsa_mlp_plan& plan, LayerMeta& m) {
+  if (threadIdx.x == 0) {
+    int acc = 0;
+#pragma unroll
+    for (int l = 0; l < VSA_MLP_MAX_LAYERS; ++l) {
+      m.dims[l] = plan.dims[l];
+      m.b[l] = plan.b[l];
+      m.fwd[l] = acc;
+      if (l < plan.n_layers) acc += blocks_of(plan.dims[l]) * blocks_of(plan.dims[l + 1]) * 16 * 64;
+    }
+    m.dims[VSA_MLP_MAX_LAYERS] = plan.dims[VSA_MLP_MAX_LAYERS];
+    m.fwd[VSA_MLP_MAX_LAYERS] = acc;
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ int meta_dim(const LayerMeta& m, int l) { return __builtin_amdgcn_readfirstlane(m.dims[l]); }
+__device__ __forceinline__ int meta_fwd(const LayerMeta& m, int l) { return __builtin_amdgcn_readfirstlane(m.fwd[l]); }
+__device__ __forceinline__ const float* meta_bias(const LayerMeta& m, int l) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(m.b[l]);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+}
+
 // packed_fwd[l][((m * inb + b) * 16 + s) * 64 + lane] = W_l[32 m + (lane & 31)][32 b + rho(s, lane >> 5)]
 // packed_bwd[l][((b * outb + m) * 16 + s) * 64 + lane] = W_l[32 m + rho(s, lane >> 5)][32 b + (lane & 31)]
 __global__ void mlp_pack_kernel(vsa_mlp_plan plan, float* __restrict__ packed_fwd,
@@ -98,9 +132,11 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_fwd_kernel(
     vsa_mlp_plan plan, const float* __restrict__ packed, const float* __restrict__ x, int x_stride,
     int M, float* __restrict__ y, int y_stride, float* __restrict__ z_ws) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];
-  const PackOffsets off = pack_offsets(plan);
+  __shared__ LayerMeta s_meta;
+  load_layer_meta(plan, s_meta);
+  const int L = plan.n_layers;
   if (RESIDENT) {
-    stage_layer(packed, s_w, off.fwd[plan.n_layers]);
+    stage_layer(packed, s_w, meta_fwd(s_meta, L));
     __syncthreads();
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 31, h = lane >> 5;
@@ -124,15 +160,15 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_fwd_kernel(
         }
     }
     long long z_off = 0;
-    for (int l = 0; l < plan.n_layers; ++l) {
-      const int in = plan.dims[l], out = plan.dims[l + 1];
+    for (int l = 0; l < L; ++l) {
+      const int in = meta_dim(s_meta, l), out = meta_dim(s_meta, l + 1);
       const int inb = blocks_of(in), outb = blocks_of(out);
       if (!RESIDENT) {
         __syncthreads();      // the previous layer's fragments have been read by every wave
-        stage_layer(packed + off.fwd[l], s_w, inb * outb * 1024);
+        stage_layer(packed + meta_fwd(s_meta, l), s_w, inb * outb * 1024);
         __syncthreads();
       }
-      const float* s_l = RESIDENT ? s_w + off.fwd[l] : s_w;
+      const float* s_l = RESIDENT ? s_w + meta_fwd(s_meta, l) : s_w;
       f32x16 acc[MLP_MAXB];
 #pragma unroll
       for (int m = 0; m < MLP_MAXB; ++m) {
@@ -149,8 +185,8 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_fwd_kernel(
           }
         }
       }
-      const bool last = l + 1 == plan.n_layers;
-      const float* bias = plan.b[l];
+      const bool last = l + 1 == L;
+      const float* bias = meta_bias(s_meta, l);
 #pragma unroll
       for (int m = 0; m < MLP_MAXB; ++m) {
         if (m < outb) {
@@ -194,25 +230,26 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_dgrad_kernel(
     int dy_stride, int M, const float* __restrict__ z_ws, float* __restrict__ dz_ws,
     float* __restrict__ a_ws, float* __restrict__ dx, int dx_stride) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];
-  const PackOffsets off = pack_offsets(plan);
+  __shared__ LayerMeta s_meta;
+  load_layer_meta(plan, s_meta);
+  const int L = plan.n_layers;
   if (RESIDENT) {
-    stage_layer(packed_t, s_w, off.fwd[plan.n_layers]);
+    stage_layer(packed_t, s_w, meta_fwd(s_meta, L));
     __syncthreads();
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 31, h = lane >> 5;
   const int ntiles = (M + MLP_TILE - 1) / MLP_TILE;
   const int per_round = gridDim.x * 4;
   const int rounds = (ntiles + per_round - 1) / per_round;
-  const int L = plan.n_layers;
   long long z_end = 0;                      // offset just past the last hidden layer's block
-  for (int l = 0; l + 1 < L; ++l) z_end += (long long)M * plan.dims[l + 1];
+  for (int l = 0; l + 1 < L; ++l) z_end += (long long)M * meta_dim(s_meta, l + 1);
   for (int rd = 0; rd < rounds; ++rd) {
     const int tile = rd * per_round + blockIdx.x * 4 + wave;
     const long long pt = (long long)tile * MLP_TILE + p;
     const bool valid = tile < ntiles && pt < M;
     float dz[MLP_MAXB][16];                 // dZ of the layer being processed (rows of its OUTPUT)
     {
-      const int out = plan.dims[L];
+      const int out = meta_dim(s_meta, L);
       const float* row = dy + (valid ? pt : 0) * (long long)dy_stride;
 #pragma unroll
       for (int m = 0; m < MLP_MAXB; ++m)
@@ -224,11 +261,12 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_dgrad_kernel(
     }
     long long z_off = z_end;
     for (int l = L - 1; l >= 0; --l) {
-      const int in = plan.dims[l], out = plan.dims[l + 1];
+      const int in = meta_dim(s_meta, l), out = meta_dim(s_meta, l + 1);
       const int inb = blocks_of(in), outb = blocks_of(out);
+      const int w_off = meta_fwd(s_meta, l);
       if (!RESIDENT) {
         __syncthreads();
-        stage_layer(packed_t + off.fwd[l], s_w, inb * outb * 1024);
+        stage_layer(packed_t + w_off, s_w, inb * outb * 1024);
         __syncthreads();
       }
       f32x16 da[MLP_MAXB];
@@ -239,7 +277,7 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_dgrad_kernel(
 #pragma unroll
           for (int m = 0; m < MLP_MAXB; ++m) {
             if (m < outb) {
-              const float* frag = s_w + (RESIDENT ? off.fwd[l] : 0) + ((b * outb + m) * 16) * 64 + lane;
+              const float* frag = s_w + (RESIDENT ? w_off : 0) + ((b * outb + m) * 16) * 64 + lane;
 #pragma unroll
               for (int s = 0; s < 16; ++s)
                 da[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(frag[s * 64], dz[m][s], da[b], 0, 0, 0);
@@ -314,7 +352,10 @@ struct WgradLayers {
 constexpr int WG_TP = 32;                               // points per tile
 __host__ __device__ inline int wg_stride(int width_pad) { return width_pad + ((width_pad & 63) ? 0 : 32); }
 
-__global__ __launch_bounds__(MLP_BLOCK, 3) void mlp_wgrad_kernel(
+#ifndef MLP_WGRAD_WGS
+#define MLP_WGRAD_WGS 3
+#endif
+__global__ __launch_bounds__(MLP_BLOCK, MLP_WGRAD_WGS) void mlp_wgrad_kernel(
     vsa_mlp_plan plan, WgradLayers wl, const float* __restrict__ x, int x_stride,
     const float* __restrict__ dy, int dy_stride, int M, const float* __restrict__ dz_ws,
     const float* __restrict__ a_ws, float* __restrict__ partial) {
