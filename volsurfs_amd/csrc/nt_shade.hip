@@ -336,6 +336,9 @@ __device__ __forceinline__ void atomic_pk_add_f16(const _Float16* base, unsigned
   asm volatile("global_atomic_pk_add_f16 %0, %1, %2" ::"v"(byte_off), "v"(__builtin_bit_cast(unsigned, v)), "s"(base) : "memory");
 }
 
+#ifndef NT_SHB_PREFETCH
+#define NT_SHB_PREFETCH 1
+#endif
 template <bool RECOMPUTE>
 __global__ __launch_bounds__(SHB_BLOCK, RECOMPUTE ? 2 : 4) void nt_shade_bwd_kernel(
     vsa_nt_plan plan, const int* __restrict__ hit_slot, const float* __restrict__ tex_uv,
@@ -445,22 +448,49 @@ __global__ __launch_bounds__(SHB_BLOCK, RECOMPUTE ? 2 : 4) void nt_shade_bwd_ker
   float2_t acc[4] = {float2_t(0.f), float2_t(0.f), float2_t(0.f), float2_t(0.f)};
   const unsigned lofs_b = 2u * (unsigned)lofs;
   unsigned long long rem = hits;
+#if NT_SHB_PREFETCH
+  // the eight LDS values a lane needs of a hit are read one hit ahead of their use
+  struct HitIn { float g0, g1, b0, b1, fx, fy; int r0, r1; };
+  auto fetch = [&](int ht) {
+    HitIn r;
+    r.g0 = s_graw[ht][ch0], r.g1 = s_graw[ht][ch1], r.b0 = s_basis[ht][m0], r.b1 = s_basis[ht][m1];
+    r.fx = s_f[ht][2 * d], r.fy = s_f[ht][2 * d + 1];
+    r.r0 = s_row[ht][2 * d], r.r1 = s_row[ht][2 * d + 1];
+    return r;
+  };
+  HitIn nx = fetch(wbase + (rem ? __ffsll((long long)rem) - 1 : 0));
+#endif
   while (rem) {
     const int hl = __ffsll((long long)rem) - 1;
     rem &= rem - 1;
     const int ht = wbase + hl;
+#if NT_SHB_PREFETCH
+    const HitIn cu = nx;
+    nx = fetch(wbase + (rem ? __ffsll((long long)rem) - 1 : hl));
+    (void)ht;
+#endif
     if (band_on) {
       float2_t gg;
+#if NT_SHB_PREFETCH
+      gg.x = cu.g0 * cu.b0;
+      gg.y = on1 ? cu.g1 * cu.b1 : 0.f;
+      const float fx = cu.fx, fy = cu.fy;
+#else
       gg.x = s_graw[ht][ch0] * s_basis[ht][m0];
       gg.y = on1 ? s_graw[ht][ch1] * s_basis[ht][m1] : 0.f;
       const float fx = s_f[ht][2 * d], fy = s_f[ht][2 * d + 1];
+#endif
       // the lerp weights exactly as load_ctx forms them, then x span, then x g
       const float w[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
       int sl[4];
       float wl[4];
 #pragma unroll
       for (int y = 0; y < 2; ++y) {
+#if NT_SHB_PREFETCH
+        const int ra = y ? cu.r1 : cu.r0, rb = ra + qd;              // the x0 and x1 corner rows (quads)
+#else
         const int ra = s_row[ht][2 * d + y], rb = ra + qd;           // the x0 and x1 corner rows (quads)
+#endif
         const int la = ra >> 3, lbn = rb >> 3;                        // their lines (8 quads of 8 B)
         const bool ma = q == ((ra & 7) >> qsh), mb = q == ((rb & 7) >> qsh), one = la == lbn;
         sl[2 * y] = la;
