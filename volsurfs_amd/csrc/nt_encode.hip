@@ -97,6 +97,20 @@ __device__ __forceinline__ CellRefS cell_ref_s(const LevelGeom& g, float x, floa
   return c;
 }
 
+#ifndef NT_ENC_MIX
+#define NT_ENC_MIX 1
+#endif
+// fp32 product of one half of a packed f16 pair and an fp32 value (see nt_mlp.hip mul_mix)
+template <int HI>
+__device__ __forceinline__ float enc_mul_mix(unsigned h2, float f) {
+  float r;
+  if constexpr (HI)
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(f));
+  else
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(f));
+  return r;
+}
+
 // the 4 table entries of a cell.  HASHED: tiny-cuda-nn's coherent prime hash, table
 // size 2^k.  Dense: x + y*res, wrapped only at the far edge / on the apron of tiny
 // textures.
@@ -231,8 +245,17 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
           float f0 = 0.f, f1 = 0.f;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
+#if NT_ENC_MIX
+            // w * (float)entry in ONE instruction per feature (v_fma_mix_f32 with a zero addend:
+            // the f16 -> f32 conversion is exact, so the product is the same single rounding as
+            // convert-then-multiply; saves the 8 conversions of a (slot, level))
+            const unsigned eb = __builtin_bit_cast(unsigned, v[u][k]);
+            f0 = f0 + enc_mul_mix<0>(eb, cr[u].w[k]);
+            f1 = f1 + enc_mul_mix<1>(eb, cr[u].w[k]);
+#else
             f0 = f0 + cr[u].w[k] * (float)v[u][k].x;
             f1 = f1 + cr[u].w[k] * (float)v[u][k].y;
+#endif
           }
           half2_t r;
           r.x = (_Float16)f0;
@@ -391,8 +414,15 @@ __device__ __forceinline__ void enc_bwd_piece(
       bool nz = false;
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
+#if NT_ENC_MIX
+        // conversion and scaling in one instruction (enc_mul_mix); NF = 2: the two halves of the
+        // word, NF = 1: the word shifted so that feature `feat` is the low half
+        gv[f] = NF == 2 ? (f ? enc_mul_mix<1>(dws[u], S[f]) : enc_mul_mix<0>(dws[u], S[f]))
+                        : enc_mul_mix<0>(dws[u] >> (16 * feat), S[f]);
+#else
         const unsigned short hb = (unsigned short)(dws[u] >> (16 * (feat + f)));
         gv[f] = (float)__builtin_bit_cast(_Float16, hb) * S[f];
+#endif
         nz |= gv[f] != 0.f;
       }
       if (slot >= first && slot < last && nz) {
