@@ -57,18 +57,50 @@ struct CellRef {
   f32x2 w01, w23;   // corner weights (x0y0, x1y0), (x0y1, x1y1)
 };
 
+#ifndef NT_ENC_FRACT
+#define NT_ENC_FRACT 1
+#endif
+// floor and fraction of a positive coordinate in two instructions instead of three:
+// v_cvt_flr_i32_f32 = (int)floor(p), v_fract_f32 = p - floor(p) (the subtraction is exact in
+// fp32, so this is the same value as the oracle's p - floorf(p))
+__device__ __forceinline__ int enc_floor_i(float p) {
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(p));
+  return r;
+}
+__device__ __forceinline__ float enc_fract(float p) {
+  float r;
+  asm("v_fract_f32 %0, %1" : "=v"(r) : "v"(p));
+  return r;
+}
+// round to the nearest integer, halves upward, in one instruction (v_cvt_rpi_i32_f32 = (int)floor(x + 0.5));
+// the backward's fixed-point contributions differ from round-half-to-even only on exact ties
+__device__ __forceinline__ int enc_round_i(float x) {
+  int r;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
 // Backward form, written on 2-vectors so that the x and y halves (and the weight pairs) go
 // through v_pk_mul_f32 / v_pk_add_f32: the kernel is VALU-bound (PMC: ~70 % VALU-busy).
 // Every operation is still one IEEE fp32 op with -ffp-contract=off: same bits.
 __device__ __forceinline__ CellRef cell_ref(const LevelGeom& g, float x, float y) {
   const f32x2 xy = {x, y};
   const f32x2 p = xy * g.scale + 0.5f;
+#if NT_ENC_FRACT
+  const f32x2 f = {enc_fract(p.x), enc_fract(p.y)};
+  const f32x2 q = 1.0f - f;
+  CellRef c;
+  c.cx = (unsigned)enc_floor_i(p.x);
+  c.cy = (unsigned)enc_floor_i(p.y);
+#else
   const f32x2 fl = {floorf(p.x), floorf(p.y)};
   const f32x2 f = p - fl;
   const f32x2 q = 1.0f - f;
   CellRef c;
   c.cx = (unsigned)(int)fl.x;
   c.cy = (unsigned)(int)fl.y;
+#endif
   const f32x2 ax = {q.x, f.x};
   c.w01 = ax * q.y;
   c.w23 = ax * f.y;
@@ -84,12 +116,20 @@ struct CellRefS {
 
 __device__ __forceinline__ CellRefS cell_ref_s(const LevelGeom& g, float x, float y) {
   const float px = x * g.scale + 0.5f, py = y * g.scale + 0.5f;
+#if NT_ENC_FRACT
+  const float fx = enc_fract(px), fy = enc_fract(py);
+  const float gx = 1.0f - fx, gy = 1.0f - fy;
+  CellRefS c;
+  c.cx = (unsigned)enc_floor_i(px);
+  c.cy = (unsigned)enc_floor_i(py);
+#else
   const float flx = floorf(px), fly = floorf(py);
   const float fx = px - flx, fy = py - fly;
   const float gx = 1.0f - fx, gy = 1.0f - fy;
   CellRefS c;
   c.cx = (unsigned)(int)flx;
   c.cy = (unsigned)(int)fly;
+#endif
   c.w[0] = gx * gy;
   c.w[1] = fx * gy;
   c.w[2] = gx * fy;
@@ -431,8 +471,13 @@ __device__ __forceinline__ void enc_bwd_piece(
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
           const f32x2 p01 = cr.w01 * gv[f], p23 = cr.w23 * gv[f];
+#if NT_ENC_FRACT
+          v[f][0] = enc_round_i(p01.x), v[f][1] = enc_round_i(p01.y);
+          v[f][2] = enc_round_i(p23.x), v[f][3] = enc_round_i(p23.y);
+#else
           v[f][0] = __float2int_rn(p01.x), v[f][1] = __float2int_rn(p01.y);
           v[f][2] = __float2int_rn(p23.x), v[f][3] = __float2int_rn(p23.y);
+#endif
         }
         if (!MERGE) {   // cells are finer than texels: every slot has its own cell
           unsigned idx[4];
