@@ -5,7 +5,8 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from volsurfs_amd import _lib
 from volsurfs_amd.pipeline import KShellPipeline
-p = KShellPipeline.synthetic()
+import os
+p = KShellPipeline.synthetic(res=int(os.environ.get("SPAN_RES", "800")))
 for _ in range(3):
     p.step()
 torch.cuda.synchronize()

@@ -345,6 +345,12 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
 // of `level`.  NF = 1: feature `feat` only (the plane fills the LDS); NF = 2: both
 // features in one pass over the slots (two planes; levels of <= 16384 entries), which
 // shares the loads, the cell arithmetic and the indices between the features.
+#ifndef NT_ENC_DIAG
+#define NT_ENC_DIAG 0
+#endif
+#ifndef NT_ENC_FLUSH_BATCH
+#define NT_ENC_FLUSH_BATCH 8     /* table entries per thread whose read-modify-write is in flight together (0: one at a time) */
+#endif
 #ifndef NT_ENC_PREFETCH
 #define NT_ENC_PREFETCH 1
 #endif
@@ -374,13 +380,18 @@ __device__ __forceinline__ void enc_bwd_piece(
     }
   }
   if (!any) return;   // nothing to add (uniform across the workgroup)
+#if NT_ENC_DIAG & 8
+  return;
+#endif
   int copies = 1;
   if (!HASHED) {
     while (copies < 32 && (long long)g.size * copies * 2 * NF <= LDS_ENTRIES) copies *= 2;
   }
   const int plane = (int)g.size * copies;   // LDS entries per feature
   __syncthreads();   // the previous piece's flush has read the planes
+#if !(NT_ENC_DIAG & 2)
   for (int i = threadIdx.x; i < plane * NF; i += ENC_BLOCK) s_g[i] = 0;
+#endif
   int* my_g = s_g + (threadIdx.x & (copies - 1)) * g.size;   // consecutive lanes -> different copies
   const int type = (tex / VSA_NT_MAX_DEG) & 1;
   const unsigned* dFw = reinterpret_cast<const unsigned*>(dfeatures + nt_feat_plane_base(plan, type, level));
@@ -514,8 +525,77 @@ __device__ __forceinline__ void enc_bwd_piece(
         for (int k = 0; k < 4; ++k) atomicAdd(&my_g[f * plane + cur_idx[k]], acc[f][k]);
     }
   }
+#if NT_ENC_PREFETCH
+  // retire the last (unused) request here: left pending, its landing registers made the
+  // compiler put an s_waitcnt vmcnt(0) in front of every register it reuses in the flush
+  // below — i.e. in front of every flush atomic, which then waited for the previous one
+#pragma unroll
+  for (int d = 0; d < PD; ++d) {
+#pragma unroll
+    for (int i = 0; i < ENC_UNROLL / 2; ++i)
+      asm volatile("" ::"v"(xyn[d][i].x), "v"(xyn[d][i].y), "v"(xyn[d][i].z), "v"(xyn[d][i].w));
+#pragma unroll
+    for (int i = 0; i < ENC_UNROLL / 4; ++i)
+      asm volatile("" ::"v"(dn[d][i].x), "v"(dn[d][i].y), "v"(dn[d][i].z), "v"(dn[d][i].w));
+  }
+#endif
   __syncthreads();
+#if NT_ENC_DIAG & 1
+  return;
+#endif
   float* gt = grad_tables + ((long long)tex * n_entries + plan.level_offset[level]) * 2 + feat;
+#if NT_ENC_FLUSH_BATCH
+  // FB entries per thread and trip: their table values are all requested before the first one is
+  // waited for.  (One entry at a time — LDS read, test, global load, add, store, with a branch in
+  // between — is a serial global round trip per entry: 32 of them per thread and 128 KiB plane,
+  // i.e. most of the 17-40 us a piece costs before it has touched a slot.)
+  constexpr int FB = NT_ENC_FLUSH_BATCH;
+  auto plane_sums = [&](int i0, int (&vi)[FB][NF]) {
+#pragma unroll
+    for (int b = 0; b < FB; ++b) {
+      const int i = i0 + b * ENC_BLOCK;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        int acc = 0;
+        if (i < (int)g.size)
+          for (int cpy = 0; cpy < copies; ++cpy) acc += s_g[f * plane + cpy * g.size + i];
+        vi[b][f] = acc;
+      }
+    }
+  };
+  // two SEPARATE loops: with both modes in one loop body the compiler's wait-count bookkeeping
+  // carried the other mode's pending loads around the back edge and put an s_waitcnt vmcnt(0)
+  // in front of every atomic — each one then waited for the previous one's acknowledgement
+  if (single) {        // sole writer of this (texture, level, feature) plane: plain read-modify-write
+    for (int i0 = threadIdx.x; i0 < (int)g.size; i0 += ENC_BLOCK * FB) {
+      int vi[FB][NF];
+      float old[FB][NF];
+      plane_sums(i0, vi);
+#pragma unroll
+      for (int b = 0; b < FB; ++b)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          old[b][f] = 0.f;
+          if (vi[b][f] != 0) old[b][f] = gt[2 * (long long)(i0 + b * ENC_BLOCK) + f];
+        }
+#pragma unroll
+      for (int b = 0; b < FB; ++b)
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+          if (vi[b][f] != 0) gt[2 * (long long)(i0 + b * ENC_BLOCK) + f] = old[b][f] + (float)vi[b][f] * S_inv[f];
+    }
+  } else {
+    for (int i0 = threadIdx.x; i0 < (int)g.size; i0 += ENC_BLOCK * FB) {
+      int vi[FB][NF];
+      plane_sums(i0, vi);
+#pragma unroll
+      for (int b = 0; b < FB; ++b)
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+          if (vi[b][f] != 0) atomicAdd(&gt[2 * (long long)(i0 + b * ENC_BLOCK) + f], (float)vi[b][f] * S_inv[f]);
+    }
+  }
+#else
   for (int i = threadIdx.x; i < (int)g.size; i += ENC_BLOCK) {
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
@@ -530,6 +610,7 @@ __device__ __forceinline__ void enc_bwd_piece(
       }
     }
   }
+#endif
 }
 
 // Planes of a launch over levels [level0, level0 + n_levels): a dense level whose two
