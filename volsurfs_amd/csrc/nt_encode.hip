@@ -212,9 +212,25 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
     const half2_t* tab = tables + (long long)tex * n_entries + plan.level_offset[level];
     __syncthreads();   // the previous piece is done with the table
     {  // stage the level (size is a multiple of 8 entries = 32 B)
-      const uint4* src = reinterpret_cast<const uint4*>(tab);
-      uint4* dst = reinterpret_cast<uint4*>(s_tab);
-      for (int i = threadIdx.x; i < (int)(g.size / 4); i += ENC_BLOCK) dst[i] = src[i];
+      // all of a thread's loads in flight together (a 2^15-entry level is 8 x 16 B per thread; one
+      // load, wait, store per trip made staging eight memory latencies long).  Native vectors and
+      // an unconditional (clamped) fill: HIP's uint4 struct, or a predicated fill, sends r[] to scratch.
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4* src = reinterpret_cast<const u32x4*>(tab);
+      u32x4* dst = reinterpret_cast<u32x4*>(s_tab);
+      constexpr int SB = 8;
+      const int nvec = (int)(g.size / 4);
+      for (int i0 = threadIdx.x; i0 < nvec; i0 += ENC_BLOCK * SB) {
+        u32x4 r[SB];
+#pragma unroll
+        for (int k = 0; k < SB; ++k) {
+          const int i = i0 + k * ENC_BLOCK;
+          r[k] = src[i < nvec ? i : nvec - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < SB; ++k)
+          if (i0 + k * ENC_BLOCK < nvec) dst[i0 + k * ENC_BLOCK] = r[k];
+      }
     }
     __syncthreads();
     const int type = (tex / VSA_NT_MAX_DEG) & 1;
