@@ -102,7 +102,7 @@ struct NtUnitWeight16 {
 };
 
 template <int UNIT, typename Body, typename Weight = NtUnitWeight16>
-__device__ __forceinline__ void nt_for_each_piece(const vsa_nt_plan& plan,
+__device__ __forceinline__ void nt_for_each_piece_scalar(const vsa_nt_plan& plan,
                                                   const int* __restrict__ seg_start, int n_planes,
                                                   int ovh, Body&& body, int tex_begin = 0,
                                                   int tex_end = 1 << 30, Weight wt = Weight()) {
@@ -163,6 +163,104 @@ __device__ __forceinline__ void nt_for_each_piece(const vsa_nt_plan& plan,
       const long long lastl = (long long)begin + (long long)ub * UNIT;
       body(pl, tex, first, lastl < end ? (int)lastl : end, begin, end);
     }
+  }
+}
+
+// Inclusive prefix sum over the 64 lanes of a wave (DPP: four shifts within the rows of 16, then
+// the row broadcasts 15 and 31); lane 63 holds the total.
+__device__ __forceinline__ int nt_wave_incl_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
+  return v;
+}
+
+// The split with ONE TEXTURE PER LANE (up to 64 textures = 8 shells; more fall back to the scalar
+// walk below).  The scalar version looks the segment table and the plan up ~100 times per
+// workgroup with dependent scalar loads: 24 us per workgroup at the head of every persistent
+// launch (stamps: 19 k cycles for the class counts, 9 k for the plane costs, 23 k for the scan —
+// `-DNT_SPAN`, g_split), whatever the size of the frame.  Here every lane loads its texture's
+// segment once (two vector loads per pass), the plane costs are wave sums, a texture's position in
+// a plane is a wave prefix sum, and the few textures that overlap the workgroup's stretch are
+// picked off a ballot.  Same axis, same integer arithmetic, same pieces.
+template <int UNIT, typename Body, typename Weight = NtUnitWeight16>
+__device__ __forceinline__ void nt_for_each_piece(const vsa_nt_plan& plan,
+                                                  const int* __restrict__ seg_start, int n_planes,
+                                                  int ovh, Body&& body, int tex_begin = 0,
+                                                  int tex_end = 1 << 30, Weight wt = Weight()) {
+  const int n_all = plan.nr_shells * 2 * VSA_NT_MAX_DEG;
+  if (n_all > 64) {
+    nt_for_each_piece_scalar<UNIT>(plan, seg_start, n_planes, ovh, body, tex_begin, tex_end, wt);
+    return;
+  }
+  const int n_tex = tex_end < n_all ? tex_end : n_all;   // textures [tex_begin, n_tex) only
+  const int lane = threadIdx.x & 63;
+  // this lane's texture (lanes beyond the textures, inactive or empty textures: units = 0)
+  const int tex = lane;
+  const int deg = tex % VSA_NT_MAX_DEG, type = (tex / VSA_NT_MAX_DEG) & 1, shell = tex / (2 * VSA_NT_MAX_DEG);
+  const int rgb_deg = plan.rgb_degrees, alpha_deg = plan.alpha_degrees;
+  const bool solid0 = plan.inner_solid != 0;
+  bool act = tex >= tex_begin && tex < n_tex &&
+             (type == 0 ? deg < rgb_deg : (!(solid0 && shell == 0) && deg < alpha_deg));
+  const int sd = shell * VSA_NT_MAX_DEG + deg;
+  int begin = 0, end = 0;
+  if (act) {
+    begin = seg_start[sd];
+    end = seg_start[sd + 1];
+  }
+  act = act && end > begin;
+  const int units = act ? (end - begin + UNIT - 1) / UNIT : 0;
+  const unsigned long long act_mask = __ballot(act);
+  const long long pieces = __popcll(act_mask);
+  if (pieces == 0) return;
+  // a texture's cost in plane pl (1/16 units; < 2^31: at most 64 textures x (a few million slots / UNIT) x 16)
+  auto lane_cost = [&](int pl) { return act ? ovh * 16 + units * wt(pl, deg, type) : 0; };
+  auto plane_cost = [&](int pl) -> long long {
+    return (long long)(unsigned)__builtin_amdgcn_readlane(nt_wave_incl_scan(lane_cost(pl)), 63);
+  };
+  long long total = 0;
+  for (int pl = 0; pl < n_planes; ++pl) total += plane_cost(pl);
+  const long long lo = total * blockIdx.x / gridDim.x, hi = total * (blockIdx.x + 1) / gridDim.x;
+  if (hi <= lo) return;
+  long long c0 = 0;
+  for (int pl = 0; pl < n_planes && c0 < hi; ++pl) {
+    const int cl = lane_cost(pl);
+    const int incl = nt_wave_incl_scan(cl);
+    const long long pc = (long long)(unsigned)__builtin_amdgcn_readlane(incl, 63);
+    if (c0 + pc <= lo) {
+      c0 += pc;
+      continue;
+    }
+    // lane's texture occupies [t0, t0 + ovh*16 + units*w) of the axis; its units start at t0 + ovh*16
+    const long long t0l = c0 + (long long)(incl - cl) + (long long)ovh * 16;
+    const int w = wt(pl, deg, type);
+    const long long span = (long long)units * w;
+    // the same tests as the scalar walk: t0 < hi, and [max(lo - t0, 0), min(hi - t0, span)) non-empty in whole units
+    bool hit = act && t0l < hi;
+    int ua = 0, ub = 0;
+    if (hit) {
+      const long long a = lo > t0l ? lo - t0l : 0, b = hi - t0l < span ? hi - t0l : span;
+      hit = b > a;
+      if (hit) {
+        ua = (int)(((unsigned)a + (unsigned)w - 1u) / (unsigned)w);      // units whose start lies in [a, b); a, b <= span < 2^31
+        ub = (int)(((unsigned)b + (unsigned)w - 1u) / (unsigned)w);
+        hit = ub > ua;
+      }
+    }
+    unsigned long long todo = __ballot(hit);
+    while (todo) {
+      const int j = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const int jb = __builtin_amdgcn_readlane(begin, j), je = __builtin_amdgcn_readlane(end, j);
+      const int ja = __builtin_amdgcn_readlane(ua, j), jub = __builtin_amdgcn_readlane(ub, j);
+      const int first = jb + ja * UNIT;
+      const long long lastl = (long long)jb + (long long)jub * UNIT;
+      body(pl, j, first, lastl < je ? (int)lastl : je, jb, je);
+    }
+    c0 += pc;
   }
 }
 
