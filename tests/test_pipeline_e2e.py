@@ -15,7 +15,9 @@ def _oracle(pipe):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("K,subdiv,res", [(1, 2, 40), (3, 3, 56), (1, 3, 64)])   # last: the shape of BASELINE configs[0] (one 64x64 view, K=1)
+# (9 shells = 72 textures: more than the 64 the one-texture-per-lane work split handles, i.e. the
+# scalar walk of nt_for_each_piece_scalar)
+@pytest.mark.parametrize("K,subdiv,res", [(1, 2, 40), (3, 3, 56), (1, 3, 64), (9, 2, 40)])   # third: the shape of BASELINE configs[0] (one 64x64 view, K=1)
 def test_pipeline_matches_oracle(K, subdiv, res):
     from volsurfs_amd.pipeline import KShellPipeline
     pipe = KShellPipeline.synthetic(K=K, subdiv=subdiv, res=res, init="spread", seed=5)
@@ -50,7 +52,11 @@ def test_pipeline_matches_oracle(K, subdiv, res):
     for x, (g_t, g_w) in ref["grads"].items():
         cw = torch.nn.functional.cosine_similarity(gw[x], g_w, dim=0)
         ct = torch.nn.functional.cosine_similarity(gt[x].flatten(), g_t.flatten(), dim=0)
-        assert cw > 0.995 and ct > 0.995, (x, cw, ct)
+        # (K = 9: the innermost shells sit behind eight others; their gradients are a few f16 ulps of
+        # the gradient rows, so the direction is noisier — 0.987 for the innermost table, the same
+        # with the scalar and the per-lane work split)
+        cos_min = 0.995 if K <= 3 else 0.98
+        assert cw > cos_min and ct > cos_min, (x, cw, ct)
         assert (gw[x] - g_w).abs().max() <= 5e-2 * g_w.abs().max()
 
 
