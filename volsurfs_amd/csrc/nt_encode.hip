@@ -205,7 +205,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
   auto unit_weight = [&](int pl, int deg, int) {
     return !HASHED || plan.level_scale[level0 + pl] < (float)plan.tex_res[deg] ? 16 : 15;
   };
-  nt_for_each_piece<ENC_UNIT>(plan, seg_start, n_levels, HASHED ? 87 : 27,
+  nt_for_each_piece<ENC_UNIT>(plan, seg_start, n_levels, HASHED ? NT_ENC_OVH_FH : NT_ENC_OVH_FD,
                               [&](int pl, int tex, int first, int last, int, int) {
     const int level = level0 + pl;
     const LevelGeom g = level_geom(plan, level);
@@ -363,6 +363,20 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
 // shares the loads, the cell arithmetic and the indices between the features.
 #ifndef NT_ENC_DIAG
 #define NT_ENC_DIAG 0
+#endif
+// per-piece overheads of the cost axis (units of 256 slots): forward hashed / dense, backward hashed / dense
+// (re-swept after the per-lane work split: 60/20/120/45 and 110/35/180/80 are within 2 % of these either way)
+#ifndef NT_ENC_OVH_FH
+#define NT_ENC_OVH_FH 87
+#endif
+#ifndef NT_ENC_OVH_FD
+#define NT_ENC_OVH_FD 27
+#endif
+#ifndef NT_ENC_OVH_BH
+#define NT_ENC_OVH_BH 145
+#endif
+#ifndef NT_ENC_OVH_BD
+#define NT_ENC_OVH_BD 64
 #endif
 #ifndef NT_ENC_FLUSH_BATCH
 #define NT_ENC_FLUSH_BATCH 8     /* table entries per thread whose read-modify-write is in flight together (0: one at a time) */
@@ -650,7 +664,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
   auto unit_weight = [&](int pl, int deg, int) {
     return !HASHED || plan.level_scale[level0 + (pl >> 1)] < (float)plan.tex_res[deg] ? 16 : 14;
   };
-  nt_for_each_piece<ENC_UNIT>(plan, seg_start, n_planes, HASHED ? 145 : 64,
+  nt_for_each_piece<ENC_UNIT>(plan, seg_start, n_planes, HASHED ? NT_ENC_OVH_BH : NT_ENC_OVH_BD,
                               [&](int pl, int tex, int first, int last, int seg_begin, int seg_end) {
     int level = level0, r = pl;
     bool both = enc_both_features(plan, level, HASHED);
