@@ -19,6 +19,20 @@
 
 namespace {
 
+// per-piece overheads of the cost axis (units of 256 slots): forward hashed / dense, backward hashed / dense
+// (re-swept after the per-lane work split: 60/20/120/45 and 110/35/180/80 are within 2 % of these either way)
+#ifndef NT_ENC_OVH_FH
+#define NT_ENC_OVH_FH 87
+#endif
+#ifndef NT_ENC_OVH_FD
+#define NT_ENC_OVH_FD 27
+#endif
+#ifndef NT_ENC_OVH_BH
+#define NT_ENC_OVH_BH 145
+#endif
+#ifndef NT_ENC_OVH_BD
+#define NT_ENC_OVH_BD 64
+#endif
 constexpr int ENC_BLOCK = 1024;     // 16 waves: a 128 KiB level pins one workgroup per CU
 constexpr int ENC_UNROLL = 8;       // slots in flight per lane (backward)
 #ifndef ENC_UNROLL_FWD_N
@@ -363,20 +377,6 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
 // shares the loads, the cell arithmetic and the indices between the features.
 #ifndef NT_ENC_DIAG
 #define NT_ENC_DIAG 0
-#endif
-// per-piece overheads of the cost axis (units of 256 slots): forward hashed / dense, backward hashed / dense
-// (re-swept after the per-lane work split: 60/20/120/45 and 110/35/180/80 are within 2 % of these either way)
-#ifndef NT_ENC_OVH_FH
-#define NT_ENC_OVH_FH 87
-#endif
-#ifndef NT_ENC_OVH_FD
-#define NT_ENC_OVH_FD 27
-#endif
-#ifndef NT_ENC_OVH_BH
-#define NT_ENC_OVH_BH 145
-#endif
-#ifndef NT_ENC_OVH_BD
-#define NT_ENC_OVH_BD 64
 #endif
 #ifndef NT_ENC_FLUSH_BATCH
 #define NT_ENC_FLUSH_BATCH 8     /* table entries per thread whose read-modify-write is in flight together (0: one at a time) */
