@@ -348,7 +348,9 @@ int vsa_sh_encode(const float* dirs, int nr_dirs, int degree, float* out, void* 
  *   vsa_mlp_fwd: y [nr_points][y_stride] = MLP(x [nr_points][x_stride]); z_ws receives the hidden
  *     pre-activations (pass NULL for inference).
  *   vsa_mlp_bwd: from dy = dL/dy and the z_ws of the matching forward: dx (optional), and
- *     grads->dw[l] / db[l] (OVERWRITTEN, not accumulated; NULL entries are skipped). */
+ *     grads->dw[l] / db[l] (NULL entries are skipped): overwritten, or added to what the buffers
+ *     hold when grads->accumulate != 0 (a caller that owns persistent .grad buffers lets the
+ *     kernel add into them instead of running one accumulation kernel per parameter). */
 #define VSA_MLP_MAX_LAYERS 6
 typedef struct vsa_mlp_plan {
   int32_t n_layers;
@@ -359,6 +361,7 @@ typedef struct vsa_mlp_plan {
 typedef struct vsa_mlp_grads {
   float* dw[VSA_MLP_MAX_LAYERS];
   float* db[VSA_MLP_MAX_LAYERS];
+  int32_t accumulate; /* 0: dw / db are overwritten, else added to */
 } vsa_mlp_grads;
 
 int vsa_mlp_workspace(const vsa_mlp_plan* plan, long long nr_points, long long* packed_floats,

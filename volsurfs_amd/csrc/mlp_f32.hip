@@ -493,10 +493,13 @@ __global__ void mlp_reduce_kernel(vsa_mlp_plan plan, WgradLayers wl, const float
     for (int g = 0; g < nwg; ++g) s += partial[wl.part_off[l] + (long long)g * per + idx];
     if (idx < out_pad * in_pad) {
       const int row = idx / in_pad, col = idx - row * in_pad;
-      if (row < out && col < in && grads.dw[l]) grads.dw[l][(long long)row * in + col] = s;
+      if (row < out && col < in && grads.dw[l]) {
+        float* d = grads.dw[l] + (long long)row * in + col;
+        *d = grads.accumulate ? *d + s : s;
+      }
     } else {
       const int n = idx - out_pad * in_pad;
-      if (n < out && grads.db[l]) grads.db[l][n] = s;
+      if (n < out && grads.db[l]) grads.db[l][n] = grads.accumulate ? grads.db[l][n] + s : s;
     }
   }
 }

@@ -219,7 +219,7 @@ class VolSurfs(torch.nn.Module):
                 return False
         return True
 
-    def _shade_legacy_grouped(self, rays_o, rays_d, hit_t, hit_slot, iter_nr):
+    def _shade_legacy_grouped(self, rays_o, rays_d, hit_t, hit_slot, iter_nr, ahead=None):
         """The same arithmetic as the per-shell loop with the hits of ALL shells prepared at once and
         each model type evaluated as one grouped op (models._FusedMLPGrouped): ~80 torch ops per
         call instead of ~350 — the legacy training loop is bound by the host's op dispatch."""
@@ -229,9 +229,14 @@ class VolSurfs(torch.nn.Module):
         surfs_rgb = torch.zeros(N, K, 3, device=dev)
         surfs_alpha = torch.zeros(N, K, device=dev)
         surfs_normals = torch.zeros(N, K, 3, device=dev)
-        shell_of, ray_of = (hit_slot >= 0).nonzero(as_tuple=True)      # sorted by shell, then ray
-        counts = torch.bincount(shell_of, minlength=K).tolist()
-        M = int(sum(counts))
+        if ahead is not None:          # compacted when the traversal was queued (trace_ahead)
+            counts = ahead.counts()
+            M = int(sum(counts))
+            shell_of, ray_of = ahead.idx[:M, 0], ahead.idx[:M, 1]
+        else:
+            shell_of, ray_of = (hit_slot >= 0).nonzero(as_tuple=True)      # sorted by shell, then ray
+            counts = torch.bincount(shell_of, minlength=K).tolist()
+            M = int(sum(counts))
         if M == 0:
             return surfs_rgb, surfs_alpha, surfs_normals
         begin = [0]
@@ -287,11 +292,11 @@ class VolSurfs(torch.nn.Module):
         surfs_normals = surfs_normals.index_put((ray_of, shell_of), nrm)
         return surfs_rgb, surfs_alpha, surfs_normals
 
-    def _shade_legacy(self, rays_o, rays_d, hit_t, hit_slot, iter_nr):
+    def _shade_legacy(self, rays_o, rays_d, hit_t, hit_slot, iter_nr, ahead=None):
         """volsurfs.py:486-599, legacy branch: per shell, the hit points / view directions /
         face normals go through that shell's RGB (or ColorSH) models; alpha decay; dense scatter."""
         if VolSurfs.legacy_grouped and self._legacy_groupable(rays_o):
-            return self._shade_legacy_grouped(rays_o, rays_d, hit_t, hit_slot, iter_nr)
+            return self._shade_legacy_grouped(rays_o, rays_d, hit_t, hit_slot, iter_nr, ahead)
         N, K = rays_o.shape[0], self.nr_meshes
         dev = rays_o.device
         surfs_rgb = torch.zeros(N, K, 3, device=dev)
@@ -332,7 +337,46 @@ class VolSurfs(torch.nn.Module):
             surfs_normals = surfs_normals.index_put((rows, col), nrm)
         return surfs_rgb, surfs_alpha, surfs_normals
 
-    def render_rays(self, rays_o, rays_d, iter_nr=None, return_samples=True, **kwargs):
+    look_ahead = True      # trainer.train_step_from_reel queues the next batch's traversal a step ahead (legacy models)
+
+    class _TraceAhead:
+        """The traversal and hit compaction of a batch, queued ahead of time (trace_ahead)."""
+
+        def __init__(self, rays_o, rays_d, hit, idx, counts_dev):
+            self.rays_o, self.rays_d = rays_o, rays_d
+            self.hit_t, self.hit_slot, self.hit_uv = hit
+            self.idx = idx                                  # [K*N, 2] (shell, ray), sorted, zero padded
+            self._host = torch.zeros(counts_dev.shape[0], dtype=torch.int64).pin_memory()
+            self._host.copy_(counts_dev, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record()
+            self._counts = None
+
+        def counts(self):
+            """Hits per shell as Python ints: waits for the traversal only, not for whatever was
+            queued behind it."""
+            if self._counts is None:
+                self._event.synchronize()
+                self._counts = self._host.tolist()
+            return self._counts
+
+    def trace_ahead(self, rays_o, rays_d):
+        """Queue the traversal of a batch and the compaction of its hits NOW and read the hit
+        counts later (`render_rays(..., ahead=ctx)`).  The legacy shading needs the counts on the
+        host (one model per shell); read right after the traversal they stall the host until
+        everything queued before — the previous iteration's backward pass and optimiser step — has
+        run.  The training loop therefore queues the NEXT batch's traversal between this batch's
+        forward and backward passes: by the time the host has queued the backward pass, the counts
+        of the next batch are already there, and host and device work overlap (the traversal reads
+        no parameter, so the order does not matter).  No sync in here: `nonzero_static` over the
+        whole [K, N] mask, padded."""
+        rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
+        hit = self.raytracer.trace_all(rays_o, rays_d)
+        mask = hit[1] >= 0
+        idx = torch.nonzero_static(mask, size=mask.numel(), fill_value=0)
+        return VolSurfs._TraceAhead(rays_o, rays_d, hit, idx, mask.sum(1))
+
+    def render_rays(self, rays_o, rays_d, iter_nr=None, return_samples=True, ahead=None, **kwargs):
         """volsurfs.py:423-761: returns {"renders": {"ray_traced": {...}}, "samples_3d",
         "samples_grad"} with the reference's keys, shapes and dtypes."""
         N, K = rays_o.shape[0], self.nr_meshes
@@ -342,7 +386,12 @@ class VolSurfs(torch.nn.Module):
         prof = getattr(self, "profiler", None)      # section names of the reference
         if prof is not None:
             prof.start("meshes_raytracing")
-        hit_t, hit_slot, hit_uv = self.raytracer.trace_all(rays_o, rays_d)     # :476-485, one launch
+        if ahead is not None and (ahead.rays_o.data_ptr() != rays_o.data_ptr() or ahead.rays_o.shape != rays_o.shape):
+            ahead = None                                                       # not this batch's: trace now
+        if ahead is not None:
+            hit_t, hit_slot, hit_uv = ahead.hit_t, ahead.hit_slot, ahead.hit_uv
+        else:
+            hit_t, hit_slot, hit_uv = self.raytracer.trace_all(rays_o, rays_d)     # :476-485, one launch
         if prof is not None:
             prof.end("meshes_raytracing")
             prof.start("ray_color_inference")
@@ -350,7 +399,7 @@ class VolSurfs(torch.nn.Module):
             rgb_k, alpha_k, normals, tex_uv = _ShadeStage.apply(self.bank.tables, self.bank.weights,
                                                                 self, hit_slot, hit_uv, rays_d)
         else:
-            rgb_k, alpha_k, normals = self._shade_legacy(rays_o, rays_d, hit_t, hit_slot, iter_nr)
+            rgb_k, alpha_k, normals = self._shade_legacy(rays_o, rays_d, hit_t, hit_slot, iter_nr, ahead)
             tex_uv = None
         if prof is not None:
             prof.end("ray_color_inference")
@@ -378,6 +427,8 @@ class VolSurfs(torch.nn.Module):
             "surfs_uvs": None if tex_uv is None else tex_uv.permute(1, 0, 2).contiguous(),  # [N,K,2], :509-516
         }
         res = {"renders": {"ray_traced": renders}, "samples_3d": None, "samples_grad": None}
+        if ahead is not None and not self.using_neural_textures:
+            self.last_nr_hits = int(sum(ahead.counts()))     # the trainer's sample count without the compaction
         if return_samples:       # :713-716 (boolean compaction = a host sync, as in the reference)
             hits = (hit_slot >= 0).t()
             pts = rays_o[:, None, :] + hit_t.t()[..., None] * rays_d[:, None, :]
@@ -475,10 +526,12 @@ class VolSurfs(torch.nn.Module):
         return loss, nr_hits, rgb
 
     def forward(self, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first_iter=False,
-                is_training_masked=False):
-        """volsurfs.py:763-816: L1 rgb loss (utils/losses.py:14-19)."""
+                is_training_masked=False, ahead=None):
+        """volsurfs.py:763-816: L1 rgb loss (utils/losses.py:14-19).  `ahead`: this batch's
+        trace_ahead context (then samples_3d is not gathered: `last_nr_hits` has the count)."""
         self._warmup_scheduler(is_first_iter)                                   # :774-783
-        res = self.render_rays(rays_o=rays_o, rays_d=rays_d, iter_nr=iter_nr)
+        res = self.render_rays(rays_o=rays_o, rays_d=rays_d, iter_nr=iter_nr, ahead=ahead,
+                               return_samples=ahead is None or self.using_neural_textures)
         pred = res["renders"]["ray_traced"]["rgb"]
         if is_training_masked and gt_mask is not None:
             loss_rgb = ((gt_rgb - pred).abs() * gt_mask).mean()

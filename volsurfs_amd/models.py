@@ -53,7 +53,8 @@ class MlpPlan(ctypes.Structure):
 
 class MlpGrads(ctypes.Structure):
     """Mirror of `vsa_mlp_grads`."""
-    _fields_ = [("dw", ctypes.c_void_p * MLP_MAX_LAYERS), ("db", ctypes.c_void_p * MLP_MAX_LAYERS)]
+    _fields_ = [("dw", ctypes.c_void_p * MLP_MAX_LAYERS), ("db", ctypes.c_void_p * MLP_MAX_LAYERS),
+                ("accumulate", ctypes.c_int32)]
 
 
 def _mlp_plan(weights, biases):
@@ -132,6 +133,16 @@ class _FusedMLP(torch.autograd.Function):
         return (dx, None, *out)
 
 
+def _direct_grads(params):
+    """The parameters' own .grad buffers if EVERY one of them has a usable one (optim.accumulate_into_grad),
+    else None (then the Function returns freshly allocated gradients as usual)."""
+    from .optim import accumulate_into_grad
+    if not params or not all(isinstance(p_, torch.nn.Parameter) and p_.requires_grad for p_ in params):
+        return None
+    got = [accumulate_into_grad(p_) for p_ in params]
+    return got if all(g is not None for g in got) else None
+
+
 class _FusedMLPGrouped(torch.autograd.Function):
     """G MLPs of ONE architecture (the per-shell models of the legacy appearance branch) applied to
     G consecutive row segments of x in one autograd node: the C entry points are called per group on
@@ -168,6 +179,7 @@ class _FusedMLPGrouped(torch.autograd.Function):
             a += n
         ctx.save_for_backward(x, z, *[t for ws, bs in groups for t in ws + [b for b in bs if b is not None]])
         ctx.meta = (tuple(sizes), has_bias, nl, hidden, packed_n)
+        ctx.param_objs = params        # the Parameter objects themselves: backward may add into their .grad
         return y
 
     @staticmethod
@@ -189,8 +201,25 @@ class _FusedMLPGrouped(torch.autograd.Function):
         for g, n in enumerate(sizes):
             ps = flat[g * per:(g + 1) * per]
             ws, bs = ps[:nl], (ps[nl:] if has_bias else [None] * nl)
-            gw = [torch.zeros_like(w) if n == 0 else torch.empty_like(w) for w in ws]
-            gb = [None if b is None else (torch.zeros_like(b) if n == 0 else torch.empty_like(b)) for b in bs]
+            # parameters that own a persistent .grad (FusedAdam): the reduce kernel adds straight into
+            # it and autograd gets None — one accumulation kernel per parameter less (80 per step)
+            objs = ctx.param_objs[g * per:(g + 1) * per]
+            pw = [objs[2 * l] if has_bias else objs[l] for l in range(nl)]
+            pb = [objs[2 * l + 1] if has_bias else None for l in range(nl)]
+            direct = _direct_grads(pw + [b for b in pb if b is not None])
+            if direct is not None:
+                if n == 0:
+                    for l in range(nl):
+                        grads_out.append(None)
+                        if has_bias:
+                            grads_out.append(None)
+                    a += n
+                    continue
+                gw = [p_.grad for p_ in pw]
+                gb = [None if b is None else b.grad for b in pb]
+            else:
+                gw = [torch.zeros_like(w) if n == 0 else torch.empty_like(w) for w in ws]
+                gb = [None if b is None else (torch.zeros_like(b) if n == 0 else torch.empty_like(b)) for b in bs]
             if n:
                 plan = _mlp_plan(ws, bs)
                 if partial is None:
@@ -199,6 +228,7 @@ class _FusedMLPGrouped(torch.autograd.Function):
                               ctypes.byref(sz))
                     partial = torch.empty(max(sz.value, 1), device=dev)
                 grads = MlpGrads()
+                grads.accumulate = 1 if direct is not None else 0
                 for l in range(nl):
                     grads.dw[l] = gw[l].data_ptr()
                     grads.db[l] = gb[l].data_ptr() if gb[l] is not None else None
@@ -206,9 +236,9 @@ class _FusedMLPGrouped(torch.autograd.Function):
                           z[a * hidden:], dz, av, packed, partial, dx[a:a + n] if dx is not None else None,
                           x.shape[1], ctypes.byref(grads), _lib.stream_ptr())
             for l in range(nl):
-                grads_out.append(gw[l])
+                grads_out.append(None if direct is not None else gw[l])
                 if has_bias:
-                    grads_out.append(gb[l])
+                    grads_out.append(None if direct is not None else gb[l])
             a += n
         return (dx, None, None, None, *grads_out)
 

@@ -45,7 +45,8 @@ class _HostCount:
 
 def train_step(method, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first_iter=False,
                nr_rays=None, target_nr_of_training_samples=None, world=1, is_training_masked=False,
-               group=None, sync_losses=True, fused=True, overlap_optimizer=False):
+               group=None, sync_losses=True, fused=True, overlap_optimizer=False, ahead=None,
+               prefetch=None):
     """Returns (losses dict with a float "loss", next nr_rays).  `method` is a
     volsurfs_amd.methods.VolSurfs with init_optim() called.
 
@@ -66,7 +67,13 @@ def train_step(method, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first
     asynchronously right after the traversal, so the host queues the next iteration while this
     one still runs.  sync_losses=False leaves the losses as device tensors (no .item()).
     overlap_optimizer=True (fused path only) runs the Adam launch on a side stream; the next
-    reader of the texture parameters waits for it (methods.VolSurfs.optim_step)."""
+    reader of the texture parameters waits for it (methods.VolSurfs.optim_step).
+
+    ahead / prefetch (the autograd path of the legacy models, one chunk): `ahead` is this batch's
+    `method.trace_ahead` context; `prefetch(next_nr_rays)` is called between the forward and the
+    backward pass so that the caller can queue the NEXT batch's traversal there
+    (train_step_from_reel does): the host then never waits for the backward pass and the
+    optimiser step before it can size the next forward pass."""
     method.is_training = True
     method.optimizer.zero_grad()                                            # trainer.py:118
     n_local = rays_o.shape[0]
@@ -96,13 +103,22 @@ def train_step(method, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first
             counts.append(pool[ci])
             l = {"loss": loss, "rgb": loss}
         else:
+            single = len(bounds) == 1
+            extra = {"ahead": ahead} if (ahead is not None and single) else {}
             l, _, samples_3d = method(rays_o[sl], rays_d[sl], gt_rgb[sl],
                                       None if gt_mask is None else gt_mask[sl], iter_nr,
                                       is_first_iter=is_first_iter and ci == 0,
-                                      is_training_masked=is_training_masked)   # :229
-            (l["loss"] * (w * share)).backward()                            # :264
+                                      is_training_masked=is_training_masked, **extra)   # :229
             if samples_3d is not None:
                 nr_samples += samples_3d.shape[0]
+            elif extra:
+                nr_samples += int(getattr(method, "last_nr_hits", 0))
+            if prefetch is not None and single:      # the next batch's traversal goes in HERE
+                nxt = nr_rays
+                if nr_rays is not None and target_nr_of_training_samples and nr_samples:
+                    nxt = dynamic_nr_rays(nr_rays, nr_samples, target_nr_of_training_samples)
+                prefetch(nxt)
+            (l["loss"] * (w * share)).backward()                            # :264
         for k, v in l.items():
             losses[k] = losses.get(k, 0.0) + (v.detach() if isinstance(v, torch.Tensor) else v) * w
     if world > 1:
@@ -128,7 +144,28 @@ def train_step_from_reel(method, reel, nr_rays, jitter_pixels=True, nr_rays_per_
     """trainer.py:176-235: draw the batch on the device (TensorReel.get_next_rays_batch), apply
     the mask to the ground truth as :203-207 does, and step.  With nr_rays_per_pixel > 1 each
     ray is compared with its pixel's value."""
-    _, rays_o, rays_d, vals, _ = reel.get_next_rays_batch(nr_rays, jitter_pixels, nr_rays_per_pixel)
+    # look-ahead (methods.VolSurfs.trace_ahead): the batch may have been drawn, and its traversal
+    # queued, during the previous step; and this step queues the next one's
+    can_ahead = hasattr(method, "trace_ahead") and not getattr(method, "using_neural_textures", True) \
+        and getattr(method, "look_ahead", True)
+    key = (id(reel), int(nr_rays), bool(jitter_pixels), int(nr_rays_per_pixel))
+    la = method.__dict__.pop("_lookahead", None) if can_ahead else None
+    if la is not None and la["key"] == key:
+        rays_o, rays_d, vals, ahead = la["rays_o"], la["rays_d"], la["vals"], la["ahead"]
+    else:
+        _, rays_o, rays_d, vals, _ = reel.get_next_rays_batch(nr_rays, jitter_pixels, nr_rays_per_pixel)
+        ahead = method.trace_ahead(rays_o, rays_d) if can_ahead and rays_o.shape[0] <= method.max_rays else None
+
+    def prefetch(next_nr_rays):
+        n = max(64, int(next_nr_rays))
+        _, ro, rd, v, _ = reel.get_next_rays_batch(n, jitter_pixels, nr_rays_per_pixel)
+        if ro.shape[0] > method.max_rays:
+            return
+        method._lookahead = {"key": (id(reel), n, bool(jitter_pixels), int(nr_rays_per_pixel)), "rays_o": ro,
+                             "rays_d": rd, "vals": v, "ahead": method.trace_ahead(ro, rd)}
+    if can_ahead and ahead is not None:
+        kw = dict(kw, ahead=ahead, prefetch=prefetch)
+        rays_o, rays_d = ahead.rays_o, ahead.rays_d     # the contiguous tensors the context was traced with
     gt_rgb = vals["rgb"]
     gt_mask = vals["mask"] if "mask" in vals else torch.ones_like(gt_rgb[:, :1])
     if is_training_masked:
