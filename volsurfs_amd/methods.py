@@ -526,12 +526,14 @@ class VolSurfs(torch.nn.Module):
         return loss, nr_hits, rgb
 
     def forward(self, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first_iter=False,
-                is_training_masked=False, ahead=None):
+                is_training_masked=False, ahead=None, return_samples=True):
         """volsurfs.py:763-816: L1 rgb loss (utils/losses.py:14-19).  `ahead`: this batch's
-        trace_ahead context (then samples_3d is not gathered: `last_nr_hits` has the count)."""
+        trace_ahead context (then samples_3d is not gathered: `last_nr_hits` has the count);
+        return_samples=False skips the boolean compaction of the hit points (two host syncs) when
+        the caller has no use for them."""
         self._warmup_scheduler(is_first_iter)                                   # :774-783
         res = self.render_rays(rays_o=rays_o, rays_d=rays_d, iter_nr=iter_nr, ahead=ahead,
-                               return_samples=ahead is None or self.using_neural_textures)
+                               return_samples=return_samples and (ahead is None or self.using_neural_textures))
         pred = res["renders"]["ray_traced"]["rgb"]
         if is_training_masked and gt_mask is not None:
             loss_rgb = ((gt_rgb - pred).abs() * gt_mask).mean()

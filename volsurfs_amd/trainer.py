@@ -105,13 +105,15 @@ def train_step(method, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first
         else:
             single = len(bounds) == 1
             extra = {"ahead": ahead} if (ahead is not None and single) else {}
+            if not target_nr_of_training_samples and hasattr(method, "trace_ahead"):
+                extra["return_samples"] = False      # the hit points are only counted, and only for the dynamic ray count
             l, _, samples_3d = method(rays_o[sl], rays_d[sl], gt_rgb[sl],
                                       None if gt_mask is None else gt_mask[sl], iter_nr,
                                       is_first_iter=is_first_iter and ci == 0,
                                       is_training_masked=is_training_masked, **extra)   # :229
             if samples_3d is not None:
                 nr_samples += samples_3d.shape[0]
-            elif extra:
+            elif "ahead" in extra:
                 nr_samples += int(getattr(method, "last_nr_hits", 0))
             if prefetch is not None and single:      # the next batch's traversal goes in HERE
                 nxt = nr_rays
