@@ -14,7 +14,9 @@ def test_mlp_plan_layout_and_argument_checks():
     from volsurfs_amd.models import MlpGrads, MlpPlan, fused_mlp_supported
     hdr = open(_lib.HEADER_PATH).read()
     assert "#define VSA_MLP_MAX_LAYERS 6" in hdr
-    assert ctypes.sizeof(MlpPlan) == 4 + 7 * 4 + 6 * 8 + 6 * 8 and ctypes.sizeof(MlpGrads) == 96
+    # vsa_mlp_grads: 6 + 6 pointers, then the int32 `accumulate` flag (padded to 8)
+    assert ctypes.sizeof(MlpPlan) == 4 + 7 * 4 + 6 * 8 + 6 * 8 and ctypes.sizeof(MlpGrads) == 96 + 8
+    assert MlpGrads.accumulate.offset == 96 and "int32_t accumulate;" in hdr
     body = re.search(r"typedef struct vsa_mlp_plan \{(.*?)\} vsa_mlp_plan;", hdr, re.S).group(1)
     assert re.findall(r"(\w+)(?:\[[^\]]*\])?;", body) == [f[0] for f in MlpPlan._fields_]
     L = _lib.lib()
