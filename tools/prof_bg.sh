@@ -4,6 +4,6 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun
 python3 - <<PY
 import csv,glob
 import os; f=max(glob.glob("$root/gpurun_out/bg/*/*kernel_stats.csv"), key=os.path.getmtime)
-for r in list(csv.DictReader(open(f)))[:14]:
+for r in list(csv.DictReader(open(f)))[:40]:
     print(f"{r['Name'][:70]:70s} n={r['Calls']:>4s} avg_us={float(r['AverageNs'])/1e3:9.1f} {r['Percentage']}%")
 PY

@@ -20,6 +20,12 @@ __global__ __launch_bounds__(1024) void k(float* out, int iters, unsigned mask) 
       if (MODE == 2) atomicAdd(reinterpret_cast<int*>(&s[a]), 3);              // ds_add_u32
       if (MODE == 3) acc += s[a];                                              // ds_read_b32
       if (MODE == 4) atomicAdd(reinterpret_cast<unsigned long long*>(&s[a & ~1u]), 3ull);  // ds_add_u64
+      if (MODE == 5) {   // 64-bit add as two 32-bit limbs: returned low limb -> carry into the high one
+        unsigned* lo = reinterpret_cast<unsigned*>(&s[a & 16383u]);
+        const unsigned v = x | 1u;
+        const unsigned old = atomicAdd(lo, v);                                 // ds_add_rtn_u32
+        atomicAdd(lo + 16384, (x >> 31) + (old + v < old ? 1u : 0u));          // ds_add_u32
+      }
     }
   }
   __syncthreads();
@@ -46,6 +52,7 @@ int main() {
     run<2>("ds_add_u32", d_out, 64, m);
     run<3>("ds_read_b32", d_out, 64, m);
     run<4>("ds_add_u64", d_out, 64, m);
+    run<5>("2x32 carry", d_out, 64, m);
   }
   return 0;
 }

@@ -31,6 +31,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int MLP_MAXB = 4;               // layer widths up to 128 (4 blocks of 32)
 constexpr int MLP_BLOCK = 256;            // 4 waves = 4 tiles of 32 points
 constexpr int MLP_TILE = 32;
+#ifndef MLP_XPF
+#define MLP_XPF 1
+#endif
+#ifndef MLP_ZPF
+#define MLP_ZPF 1
+#endif
 
 __device__ __forceinline__ int rho(int s, int h) { return 8 * (s >> 2) + 4 * h + (s & 3); }
 __host__ __device__ __forceinline__ int blocks_of(int w) { return (w + 31) / 32; }
@@ -127,7 +133,7 @@ __device__ __forceinline__ void stage_layer(const float* __restrict__ src, float
 // NerfHash's two MLPs are 72 and 48 KiB): they are staged once per workgroup and the layer loop has
 // no barrier at all — the four waves run their tiles independently.  Otherwise (128-wide RGB /
 // ColorSH: 152 KiB) one layer at a time is staged, two barriers per layer.
-template <bool RESIDENT>
+template <bool RESIDENT, int NB>
 __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_fwd_kernel(
     vsa_mlp_plan plan, const float* __restrict__ packed, const float* __restrict__ x, int x_stride,
     int M, float* __restrict__ y, int y_stride, float* __restrict__ z_ws) {
@@ -143,21 +149,38 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_fwd_kernel(
   const int ntiles = (M + MLP_TILE - 1) / MLP_TILE;
   const int per_round = gridDim.x * 4;
   const int rounds = (ntiles + per_round - 1) / per_round;
+  // the input rows of round rd + 1 are requested before round rd's layers (up to 96 wide; at 128
+  // the second set of 64 registers does not fit)
+  constexpr bool XPF = MLP_XPF && NB <= 3;
+  float xn[XPF ? NB : 1][16];
+  auto load_x = [&](int rd, float dst[][16]) {
+    const int tile = rd * per_round + blockIdx.x * 4 + wave;
+    const long long pt = (long long)tile * MLP_TILE + p;
+    const bool valid = tile < ntiles && pt < M;
+    const int in = plan.dims[0];
+    const float* row = x + (valid ? pt : 0) * (long long)x_stride;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = 32 * b + rho(r, h);
+        dst[b][r] = (valid && k < in) ? row[k] : 0.f;
+      }
+  };
+  if (XPF && rounds > 0) load_x(0, xn);
   for (int rd = 0; rd < rounds; ++rd) {
     const int tile = rd * per_round + blockIdx.x * 4 + wave;
     const long long pt = (long long)tile * MLP_TILE + p;
     const bool valid = tile < ntiles && pt < M;
-    float act[MLP_MAXB][16];
-    {
-      const int in = plan.dims[0];
-      const float* row = x + (valid ? pt : 0) * (long long)x_stride;
+    float act[NB][16];
+    if (XPF) {
 #pragma unroll
-      for (int b = 0; b < MLP_MAXB; ++b)
+      for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int k = 32 * b + rho(r, h);
-          act[b][r] = (valid && k < in) ? row[k] : 0.f;
-        }
+        for (int r = 0; r < 16; ++r) act[b][r] = xn[XPF ? b : 0][r];
+      if (rd + 1 < rounds) load_x(rd + 1, xn);
+    } else {
+      load_x(rd, act);
     }
     long long z_off = 0;
     for (int l = 0; l < L; ++l) {
@@ -169,13 +192,13 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_fwd_kernel(
         __syncthreads();
       }
       const float* s_l = RESIDENT ? s_w + meta_fwd(s_meta, l) : s_w;
-      f32x16 acc[MLP_MAXB];
+      f32x16 acc[NB];
 #pragma unroll
-      for (int m = 0; m < MLP_MAXB; ++m) {
+      for (int m = 0; m < NB; ++m) {
         acc[m] = f32x16{0};
         if (m < outb) {
 #pragma unroll
-          for (int b = 0; b < MLP_MAXB; ++b) {
+          for (int b = 0; b < NB; ++b) {
             if (b < inb) {
               const float* frag = s_l + ((m * inb + b) * 16) * 64 + lane;
 #pragma unroll
@@ -188,7 +211,7 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_fwd_kernel(
       const bool last = l + 1 == L;
       const float* bias = meta_bias(s_meta, l);
 #pragma unroll
-      for (int m = 0; m < MLP_MAXB; ++m) {
+      for (int m = 0; m < NB; ++m) {
         if (m < outb) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
@@ -224,7 +247,7 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_fwd_kernel(
 // ------------------------------------------------------------------ backward 1: data gradients
 // dZ_l and A_l = GELU(z_l) of every hidden layer are written to dz_ws / a_ws ([point][width],
 // same offsets as z_ws); dX [point][dims[0]] optional.
-template <bool RESIDENT>
+template <bool RESIDENT, int NB>
 __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_dgrad_kernel(
     vsa_mlp_plan plan, const float* __restrict__ packed_t, const float* __restrict__ dy,
     int dy_stride, int M, const float* __restrict__ z_ws, float* __restrict__ dz_ws,
@@ -247,12 +270,12 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_dgrad_kernel(
     const int tile = rd * per_round + blockIdx.x * 4 + wave;
     const long long pt = (long long)tile * MLP_TILE + p;
     const bool valid = tile < ntiles && pt < M;
-    float dz[MLP_MAXB][16];                 // dZ of the layer being processed (rows of its OUTPUT)
+    float dz[NB][16];                 // dZ of the layer being processed (rows of its OUTPUT)
     {
       const int out = meta_dim(s_meta, L);
       const float* row = dy + (valid ? pt : 0) * (long long)dy_stride;
 #pragma unroll
-      for (int m = 0; m < MLP_MAXB; ++m)
+      for (int m = 0; m < NB; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int n = 32 * m + rho(r, h);
@@ -269,13 +292,29 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_dgrad_kernel(
         stage_layer(packed_t + w_off, s_w, inb * outb * 1024);
         __syncthreads();
       }
-      f32x16 da[MLP_MAXB];
+      // the saved pre-activations this layer's epilogue needs are requested BEFORE its MFMAs: the
+      // loads do not depend on them, and with 8 waves per CU nothing else hides their latency
+      // (not at 128 wide: dz, da and a third 64-register block do not fit the 256 registers)
+      constexpr bool ZPF = MLP_ZPF && NB <= 3;
+      float4 zq[ZPF ? NB : 1][4];
+      if (l > 0) z_off -= (long long)M * in;
+      if (ZPF && l > 0) {
 #pragma unroll
-      for (int b = 0; b < MLP_MAXB; ++b) {
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            zq[ZPF ? b : 0][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b < inb && valid)
+              zq[ZPF ? b : 0][g] = *reinterpret_cast<const float4*>(z_ws + z_off + pt * in + 32 * b + 8 * g + 4 * h);
+          }
+      }
+      f32x16 da[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
         da[b] = f32x16{0};
         if (b < inb && (l > 0 || dx)) {
 #pragma unroll
-          for (int m = 0; m < MLP_MAXB; ++m) {
+          for (int m = 0; m < NB; ++m) {
             if (m < outb) {
               const float* frag = s_w + (RESIDENT ? w_off : 0) + ((b * outb + m) * 16) * 64 + lane;
 #pragma unroll
@@ -288,7 +327,7 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_dgrad_kernel(
       if (l == 0) {
         if (dx && valid) {
 #pragma unroll
-          for (int b = 0; b < MLP_MAXB; ++b)
+          for (int b = 0; b < NB; ++b)
             if (b < inb)
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
@@ -298,16 +337,18 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_dgrad_kernel(
         }
       } else {
         // layer l-1's output (width `in`, a multiple of 32): dZ = dA * GELU'(z), A = GELU(z)
-        z_off -= (long long)M * in;
 #pragma unroll
-        for (int b = 0; b < MLP_MAXB; ++b) {
+        for (int b = 0; b < NB; ++b) {
           if (b < inb) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const int k0 = 32 * b + 8 * g + 4 * h;
               const long long o = z_off + pt * in + k0;
-              float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-              if (valid) z4 = *reinterpret_cast<const float4*>(z_ws + o);
+              float4 z4 = zq[ZPF ? b : 0][g];
+              if (!ZPF) {
+                z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (valid) z4 = *reinterpret_cast<const float4*>(z_ws + o);
+              }
               const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
               float a4[4], d4[4];
 #pragma unroll
@@ -350,12 +391,14 @@ struct WgradLayers {
 // wave loaded its own fragments straight from L2, one dword per lane and MFMA: 11.6 ms for the
 // 2.1 M samples of a background batch, 2.9 ms with an 8-deep unroll; the matrix time is ~0.5 ms.)
 constexpr int WG_TP = 32;                               // points per tile
-__host__ __device__ inline int wg_stride(int width_pad) { return width_pad + ((width_pad & 63) ? 0 : 32); }
+__host__ __device__ constexpr int wg_stride(int width_pad) { return width_pad + ((width_pad & 63) ? 0 : 32); }
 
-#ifndef MLP_WGRAD_WGS
-#define MLP_WGRAD_WGS 3
-#endif
-__global__ __launch_bounds__(MLP_BLOCK, MLP_WGRAD_WGS) void mlp_wgrad_kernel(
+// NB = widest layer of the network in 32-blocks (tile loader registers), Q = block pairs per
+// wave (accumulators), PF = tiles requested ahead.  The loop is bound by the latency of the tile
+// loads, not by the 16 MFMAs per pair between them: what counts is the number of bytes a CU keeps
+// in flight, i.e. co-resident workgroups x PF.
+template <int NB, int Q, int PF, int WGS>
+__global__ __launch_bounds__(MLP_BLOCK, WGS) void mlp_wgrad_kernel(
     vsa_mlp_plan plan, WgradLayers wl, const float* __restrict__ x, int x_stride,
     const float* __restrict__ dy, int dy_stride, int M, const float* __restrict__ dz_ws,
     const float* __restrict__ a_ws, float* __restrict__ partial) {
@@ -376,87 +419,90 @@ __global__ __launch_bounds__(MLP_BLOCK, MLP_WGRAD_WGS) void mlp_wgrad_kernel(
   const int d_stride = l == L - 1 ? dy_stride : out;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, kk = lane >> 5;
   const int npairs = inb * outb;
-  const int SA = wg_stride(32 * outb), SB = wg_stride(32 * inb);
-  float* s_a = s_t;                       // [WG_TP][SA]  dZ rows
-  float* s_b = s_t + WG_TP * SA;          // [WG_TP][SB]  A rows
+  // LDS tiles are laid out for the widest layer of the network (compile-time row stride: every
+  // fragment read is one base register + an immediate offset, and the loader needs no division)
+  constexpr int W = 32 * NB, S = wg_stride(W);
+  float* s_a = s_t;                       // [WG_TP][S]  dZ rows
+  float* s_b = s_t + WG_TP * S;           // [WG_TP][S]  A rows
   // this workgroup's points: a contiguous range of whole tiles
   const long long ntiles = (M + WG_TP - 1) / WG_TP;
   const long long t_per = (ntiles + nwg - 1) / nwg;
   const long long t_begin = wg * t_per, t_end = min(ntiles, t_begin + t_per);
-  f32x16 acc[MLP_MAXB];
-  float bsum[MLP_MAXB];
-  int pm[MLP_MAXB], pb[MLP_MAXB];
+  f32x16 acc[Q];
+  float bsum[Q];
+  int pm[Q], pb[Q];
 #pragma unroll
-  for (int q = 0; q < MLP_MAXB; ++q) {
+  for (int q = 0; q < Q; ++q) {
     acc[q] = f32x16{0};
     bsum[q] = 0.f;
     const int pair = wave + 4 * q;
     pm[q] = pair < npairs ? pair / inb : -1;
     pb[q] = pair < npairs ? pair % inb : 0;
   }
-  // tile loader: element e of the [WG_TP][width_pad] tile, 4 consecutive columns per lane
-  constexpr int LD_MAX = (WG_TP * 32 * MLP_MAXB) / (4 * MLP_BLOCK);      // float4 per thread and operand: 4
-  float4 ra[LD_MAX], rb[LD_MAX];
-  auto fetch = [&](long long tile, const float* src, int stride, int width, int wpad, float4 r[LD_MAX]) {
+  // tile loader: 4 consecutive columns of the [WG_TP][W] tile per lane and request
+  constexpr int LD_MAX = (WG_TP * W) / (4 * MLP_BLOCK);      // float4 per thread and operand
+  float4 ra[PF][LD_MAX], rb[PF][LD_MAX];
+  auto fetch = [&](long long tile, const float* src, int stride, int width, float4 r[LD_MAX]) {
     const long long p0 = tile * WG_TP;
-    const int nvec = WG_TP * wpad / 4;
     const bool vec_ok = ((stride & 3) == 0) && ((reinterpret_cast<size_t>(src) & 15) == 0);
 #pragma unroll
     for (int k = 0; k < LD_MAX; ++k) {
       const int v = threadIdx.x + k * MLP_BLOCK;
+      const int row = (v * 4) / W, c = (v * 4) % W;
+      const long long pt = p0 + row;
       r[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (v < nvec) {
-        const int row = (v * 4) / wpad, c = (v * 4) - row * wpad;
-        const long long pt = p0 + row;
-        if (pt < M) {
-          const float* g = src + pt * stride + c;
-          if (vec_ok && c + 3 < width) {
-            r[k] = *reinterpret_cast<const float4*>(g);
-          } else {
-            if (c < width) r[k].x = g[0];
-            if (c + 1 < width) r[k].y = g[1];
-            if (c + 2 < width) r[k].z = g[2];
-            if (c + 3 < width) r[k].w = g[3];
-          }
+      if (pt < M && c < width) {
+        const float* g = src + pt * stride + c;
+        if (vec_ok && c + 3 < width) {
+          r[k] = *reinterpret_cast<const float4*>(g);
+        } else {
+          r[k].x = g[0];
+          if (c + 1 < width) r[k].y = g[1];
+          if (c + 2 < width) r[k].z = g[2];
+          if (c + 3 < width) r[k].w = g[3];
         }
       }
     }
   };
-  auto stash = [&](float* dst, int S, int wpad, const float4 r[LD_MAX]) {
-    const int nvec = WG_TP * wpad / 4;
+  auto stash = [&](float* dst, const float4 r[LD_MAX]) {
 #pragma unroll
     for (int k = 0; k < LD_MAX; ++k) {
       const int v = threadIdx.x + k * MLP_BLOCK;
-      if (v < nvec) {
-        const int row = (v * 4) / wpad, c = (v * 4) - row * wpad;
-        *reinterpret_cast<float4*>(dst + row * S + c) = r[k];
-      }
+      const int row = (v * 4) / W, c = (v * 4) % W;
+      *reinterpret_cast<float4*>(dst + row * S + c) = r[k];
     }
   };
-  const int apad = 32 * outb, bpad = 32 * inb;
-  if (t_begin < t_end) {
-    fetch(t_begin, dop, d_stride, out, apad, ra);
-    fetch(t_begin, aop, a_stride, in, bpad, rb);
-  }
-  for (long long t = t_begin; t < t_end; ++t) {
-    __syncthreads();                       // the previous tile's fragments have been read
-    stash(s_a, SA, apad, ra);
-    stash(s_b, SB, bpad, rb);
-    __syncthreads();
-    if (t + 1 < t_end) {
-      fetch(t + 1, dop, d_stride, out, apad, ra);
-      fetch(t + 1, aop, a_stride, in, bpad, rb);
+#pragma unroll
+  for (int f = 0; f < PF; ++f)
+    if (t_begin + f < t_end) {
+      fetch(t_begin + f, dop, d_stride, out, ra[f]);
+      fetch(t_begin + f, aop, a_stride, in, rb[f]);
     }
+  for (long long t0 = t_begin; t0 < t_end; t0 += PF) {
 #pragma unroll
-    for (int st = 0; st < WG_TP / 2; ++st) {
-      const float* ar = s_a + (2 * st + kk) * SA + i;
-      const float* br = s_b + (2 * st + kk) * SB + i;
+    for (int f = 0; f < PF; ++f) {
+      const long long t = t0 + f;
+      if (t < t_end) {                       // uniform over the workgroup
+        __syncthreads();                     // the previous tile's fragments have been read
+        stash(s_a, ra[f]);
+        stash(s_b, rb[f]);
+        __syncthreads();
+        if (t + PF < t_end) {
+          fetch(t + PF, dop, d_stride, out, ra[f]);
+          fetch(t + PF, aop, a_stride, in, rb[f]);
+        }
 #pragma unroll
-      for (int q = 0; q < MLP_MAXB; ++q) {
-        if (pm[q] >= 0) {
-          const float av = ar[32 * pm[q]];
-          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, br[32 * pb[q]], acc[q], 0, 0, 0);
-          bsum[q] += av;
+        for (int st = 0; st < WG_TP / 2; ++st) {
+          const float* ar = s_a + (2 * st + kk) * S + i;
+          const float* br = s_b + (2 * st + kk) * S + i;
+#pragma unroll
+          for (int q = 0; q < Q; ++q) {
+            if (pm[q] >= 0) {
+              const float av = ar[32 * pm[q]];
+              acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, br[32 * pb[q]], acc[q], 0, 0, 0);
+              bsum[q] += av;
+            }
+          }
         }
       }
     }
@@ -465,7 +511,7 @@ __global__ __launch_bounds__(MLP_BLOCK, MLP_WGRAD_WGS) void mlp_wgrad_kernel(
   const int in_pad = 32 * inb, out_pad = 32 * outb;
   float* part = partial + wl.part_off[l] + (long long)wg * (out_pad * in_pad + out_pad);
 #pragma unroll
-  for (int q = 0; q < MLP_MAXB; ++q) {
+  for (int q = 0; q < Q; ++q) {
     if (pm[q] >= 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -526,41 +572,105 @@ size_t max_layer_bytes(const vsa_mlp_plan& p) {
   return mx;
 }
 
-// workgroups of the weight-gradient kernel: two per CU for large batches, fewer for small ones
-// (every workgroup writes a full set of partial blocks that mlp_reduce then has to read: 512
-// workgroups on a 10 k-point batch made the reduction the most expensive kernel of the step)
+// Instance of the weight-gradient kernel for a network: NB from its widest layer, Q from the layer
+// with the most 32 x 32 block pairs.  Networks up to 96 wide (NerfHash) take the small instances:
+// 32 / 48 accumulator and loader registers instead of 64 / 64 leave room for a second tile in
+// flight and a fourth co-resident workgroup.
+#ifndef MLP_WG_SMALL_WGS
+#define MLP_WG_SMALL_WGS 4
+#endif
+#ifndef MLP_WG_SMALL_PF
+#define MLP_WG_SMALL_PF 1
+#endif
+#ifndef MLP_WG_COST
+#define MLP_WG_COST 1
+#endif
+struct WgradShape {
+  int nb, q, wgs;
+};
+WgradShape wgrad_shape(const vsa_mlp_plan& p) {
+  int wmax = 1, pmax = 1;
+  for (int l = 0; l <= p.n_layers; ++l) wmax = blocks_of(p.dims[l]) > wmax ? blocks_of(p.dims[l]) : wmax;
+  for (int l = 0; l < p.n_layers; ++l) {
+    const int pr = blocks_of(p.dims[l]) * blocks_of(p.dims[l + 1]);
+    pmax = pr > pmax ? pr : pmax;
+  }
+  if (wmax <= 2) return {2, 1, MLP_WG_SMALL_WGS};
+  if (wmax == 3 && pmax <= 8) return {3, 2, MLP_WG_SMALL_WGS};
+  return {4, 4, 3};
+}
+
+// workgroups of the weight-gradient kernel: as many as are co-resident for large batches, fewer
+// for small ones (every workgroup writes a full set of partial blocks that mlp_reduce then has to
+// read: 512 workgroups on a 10 k-point batch made the reduction the most expensive kernel of the
+// step)
 int wgrad_total_wgs(const vsa_mlp_plan& p, long long nr_points, int nr_cus) {
   long long n = nr_points / 128;
   if (n < p.n_layers) n = p.n_layers;
-  if (n > 3ll * nr_cus) n = 3ll * nr_cus;     // three co-resident workgroups per CU (168 VGPRs; four spill)
+  const long long cap = (long long)wgrad_shape(p).wgs * nr_cus;
+  if (n > cap) n = cap;
   return (int)n;
 }
 
 constexpr size_t MLP_RESIDENT_BYTES = 78 * 1024;     // two workgroups per CU
 
+int max_blocks(const vsa_mlp_plan& p) {
+  int wmax = 2;
+  for (int l = 0; l <= p.n_layers; ++l) wmax = blocks_of(p.dims[l]) > wmax ? blocks_of(p.dims[l]) : wmax;
+  return wmax;
+}
+
+template <bool RESIDENT, int NB>
+int set_lds_attr_of() {
+  const int bytes = RESIDENT ? (int)MLP_RESIDENT_BYTES : 64 * 1024;
+  VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<RESIDENT, NB>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_kernel<RESIDENT, NB>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  return VSA_OK;
+}
+
 int set_lds_attrs() {
   static bool done = false;
   if (!done) {
-    VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)MLP_RESIDENT_BYTES));
-    VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)MLP_RESIDENT_BYTES));
-    VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    int rc = set_lds_attr_of<true, 2>();
+    if (!rc) rc = set_lds_attr_of<true, 3>();
+    if (!rc) rc = set_lds_attr_of<true, 4>();
+    if (!rc) rc = set_lds_attr_of<false, 2>();
+    if (!rc) rc = set_lds_attr_of<false, 3>();
+    if (!rc) rc = set_lds_attr_of<false, 4>();
+    if (rc) return rc;
     done = true;
   }
   return VSA_OK;
 }
+
+// kernel instance by (weights resident in LDS, widest layer in 32-blocks)
+#define VSA_MLP_DISPATCH(KERNEL, RES, NB, ...)                                            \
+  do {                                                                                    \
+    if (RES) {                                                                            \
+      if ((NB) == 2) hipLaunchKernelGGL((KERNEL<true, 2>), __VA_ARGS__);                  \
+      else if ((NB) == 3) hipLaunchKernelGGL((KERNEL<true, 3>), __VA_ARGS__);             \
+      else hipLaunchKernelGGL((KERNEL<true, 4>), __VA_ARGS__);                            \
+    } else {                                                                              \
+      if ((NB) == 2) hipLaunchKernelGGL((KERNEL<false, 2>), __VA_ARGS__);                 \
+      else if ((NB) == 3) hipLaunchKernelGGL((KERNEL<false, 3>), __VA_ARGS__);            \
+      else hipLaunchKernelGGL((KERNEL<false, 4>), __VA_ARGS__);                           \
+    }                                                                                     \
+  } while (0)
 
 WgradLayers wgrad_layers(const vsa_mlp_plan& p, int total_wgs) {
   // workgroups per layer in proportion to the layer's MFMA count (>= 1 each)
   WgradLayers wl;
   int cost[VSA_MLP_MAX_LAYERS], sum = 0;
   for (int l = 0; l < p.n_layers; ++l) {
+#if MLP_WG_COST == 0
     // a wave issues ceil(pairs / 4) MFMAs per point pair
     cost[l] = (blocks_of(p.dims[l]) * blocks_of(p.dims[l + 1]) + 3) / 4;
+#else
+    // the loop waits for its tile loads, not for its MFMAs: bytes per point
+    cost[l] = blocks_of(p.dims[l]) + blocks_of(p.dims[l + 1]);
+#endif
     sum += cost[l];
   }
   int begin = 0;
@@ -622,12 +732,8 @@ extern "C" int vsa_mlp_fwd(const vsa_mlp_plan* plan, const float* x, int x_strid
   const int ntiles = vsa_div_up(nr_points, MLP_TILE);
   int grid = vsa_div_up(ntiles, 4);
   if (grid > 2 * nr_cus) grid = 2 * nr_cus;
-  if (resident)
-    hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(grid), dim3(MLP_BLOCK), lds, st, *plan, packed_ws, x,
-                       x_stride, nr_points, y, y_stride, z_ws);
-  else
-    hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(grid), dim3(MLP_BLOCK), lds, st, *plan, packed_ws, x,
-                       x_stride, nr_points, y, y_stride, z_ws);
+  VSA_MLP_DISPATCH(mlp_fwd_kernel, resident, max_blocks(*plan), dim3(grid), dim3(MLP_BLOCK), lds, st, *plan,
+                   packed_ws, x, x_stride, nr_points, y, y_stride, z_ws);
   VSA_RETURN_LAUNCH_STATUS();
 }
 
@@ -659,19 +765,19 @@ extern "C" int vsa_mlp_bwd(const vsa_mlp_plan* plan, const float* x, int x_strid
   int grid = vsa_div_up(ntiles, 4);
   if (grid > 2 * nr_cus) grid = 2 * nr_cus;
   if (L > 1 || dx) {
-    if (resident)
-      hipLaunchKernelGGL(mlp_dgrad_kernel<true>, dim3(grid), dim3(MLP_BLOCK), lds, st, *plan, packed_ws, dy,
-                         dy_stride, nr_points, z_ws, dz_ws, a_ws, dx, dx_stride);
-    else
-      hipLaunchKernelGGL(mlp_dgrad_kernel<false>, dim3(grid), dim3(MLP_BLOCK), lds, st, *plan, packed_ws, dy,
-                         dy_stride, nr_points, z_ws, dz_ws, a_ws, dx, dx_stride);
+    VSA_MLP_DISPATCH(mlp_dgrad_kernel, resident, max_blocks(*plan), dim3(grid), dim3(MLP_BLOCK), lds, st,
+                     *plan, packed_ws, dy, dy_stride, nr_points, z_ws, dz_ws, a_ws, dx, dx_stride);
   }
   const WgradLayers wl = wgrad_layers(*plan, wgrad_total_wgs(*plan, nr_points, nr_cus));
-  int wmax = 1;
-  for (int l = 0; l <= L; ++l) wmax = blocks_of(plan->dims[l]) > wmax ? blocks_of(plan->dims[l]) : wmax;
-  const size_t wg_lds = (size_t)WG_TP * (wg_stride(32 * wmax) * 2) * sizeof(float);   // 24 KiB (64 wide) .. 40 KiB (128)
-  hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(wl.wg_begin[L]), dim3(MLP_BLOCK), wg_lds, st, *plan, wl, x,
-                     x_stride, dy, dy_stride, nr_points, dz_ws, a_ws, partial_ws);
+  const WgradShape ws = wgrad_shape(*plan);
+  const size_t wg_lds = (size_t)WG_TP * (wg_stride(32 * ws.nb) * 2) * sizeof(float);   // 24 KiB (64 / 96 wide) .. 40 KiB (128)
+#define VSA_WGRAD_LAUNCH(NB_, Q_, PF_, WGS_)                                                              \
+  hipLaunchKernelGGL((mlp_wgrad_kernel<NB_, Q_, PF_, WGS_>), dim3(wl.wg_begin[L]), dim3(MLP_BLOCK), wg_lds, st, \
+                     *plan, wl, x, x_stride, dy, dy_stride, nr_points, dz_ws, a_ws, partial_ws)
+  if (ws.nb == 2) VSA_WGRAD_LAUNCH(2, 1, MLP_WG_SMALL_PF, MLP_WG_SMALL_WGS);
+  else if (ws.nb == 3) VSA_WGRAD_LAUNCH(3, 2, MLP_WG_SMALL_PF, MLP_WG_SMALL_WGS);
+  else VSA_WGRAD_LAUNCH(4, 4, 1, 3);
+#undef VSA_WGRAD_LAUNCH
   hipLaunchKernelGGL(mlp_reduce_kernel, dim3(68, L), dim3(256), 0, st, *plan, wl, partial_ws, *grads);   // 68 x 256 >= one thread per element of a 128 x 128 (+bias) layer
   VSA_RETURN_LAUNCH_STATUS();
 }
