@@ -334,8 +334,34 @@ int vsa_grid_encode_bwd_binned_workspace(const vsa_grid_plan* plan, int nr_point
                                          long long* workspace_floats);
 int vsa_grid_encode_bwd_binned(const vsa_grid_plan* plan, const float* x, const float* g_out,
                                int nr_points, float* grad_tables, float* workspace, void* stream);
+/* The same four with a row stride (floats) on out / g_out, for callers that keep the features
+ * inside a wider row: GridHashEncoder's `torch.cat([enc, points], 1)` (gridhash.py:88-90) becomes
+ * out_stride = 2 * n_levels + n_dims with append_x = 1 (the kernel writes x behind the features),
+ * and the gradient of that matrix is read in place (g_stride; the x columns are ignored: positions
+ * carry no gradient on this path). */
+int vsa_grid_encode_fwd_ld(const vsa_grid_plan* plan, const float* tables, const float* x,
+                           int nr_points, float* out, int out_stride, int append_x, void* stream);
+int vsa_grid_encode_bwd_ld(const vsa_grid_plan* plan, const float* x, const float* g_out,
+                           int g_stride, int nr_points, float* grad_tables, void* stream);
+int vsa_grid_encode_bwd_sliced_ld(const vsa_grid_plan* plan, const float* x, const float* g_out,
+                                  int g_stride, int nr_points, float* grad_tables, float* workspace,
+                                  void* stream);
+int vsa_grid_encode_bwd_binned_ld(const vsa_grid_plan* plan, const float* x, const float* g_out,
+                                  int g_stride, int nr_points, float* grad_tables, float* workspace,
+                                  void* stream);
 /* out [nr_dirs][(degree+1)^2]: SH basis of each direction, degree 0..4. */
 int vsa_sh_encode(const float* dirs, int nr_dirs, int degree, float* out, void* stream);
+
+/* A10  The elementwise glue between NerfHash's two MLPs (volsurfs_py/models/nerfhash.py:72-91), one
+ * pass each way instead of eleven torch launches over [samples, 64..80] floats:
+ *   fwd: density [n] = softplus(y1[:, 0]);  x2 [n][nr_feat + nr_dir] = cat(gelu(y1[:, 1:1+nr_feat]), dirs_enc)
+ *   bwd: dy1 [n][1 + nr_feat] from dx2 (gradient of x2; its dirs columns are ignored) and d_density
+ *        (either may be NULL = zero).
+ * y1 [n][1 + nr_feat] is the first MLP's output, dirs_enc [n][nr_dir] the encoded directions. */
+int vsa_field_head_fwd(const float* y1, const float* dirs_enc, long long nr_points, int nr_feat,
+                       int nr_dir, float* x2, float* density, void* stream);
+int vsa_field_head_bwd(const float* y1, const float* dx2, const float* d_density, long long nr_points,
+                       int nr_feat, int nr_dir, float* dy1, void* stream);
 
 /* A5 / A10  Fused fp32 MLP (Linear + bias, exact GELU between layers, last layer linear) on the
  * fp32-input matrix cores: `MLP` (volsurfs_py/models/mlp.py:8-69) as used by RGB (models/rgb.py:139),

@@ -171,6 +171,45 @@ def test_nerfhash_drives_the_background_path():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [1000, 300_000])
+def test_nerfhash_fused_glue_equals_the_torch_op_sequence(n):
+    """nerfhash.py:72-91 as the reference writes it (slice, gelu, cat, softplus; GridHashEncoder's
+    torch.cat of the points) against the fused kernels (csrc/field_head.hip, vsa_grid_encode_*_ld):
+    outputs and every parameter gradient.  300 k samples take the sliced table-gradient path."""
+    from volsurfs_amd.encodings import GridHashEncoder
+    from volsurfs_amd.models import NerfHash
+    torch.manual_seed(3)
+    nh = NerfHash(3, "gridhash", "spherical_harmonics")
+    with torch.no_grad():      # tables at a scale where the features matter
+        nh.pos_encoder.encoder.params.mul_(3e3)
+    g = torch.Generator().manual_seed(1)
+    pts = (torch.rand(n, 3, generator=g) * 1.6 - 0.8).cuda()
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).cuda()
+    w_rgb = torch.rand(n, 3, generator=g).cuda()
+    w_den = torch.rand(n, 1, generator=g).cuda()
+
+    def run(fused):
+        NerfHash.fused_head = GridHashEncoder.fused_concat = fused
+        try:
+            nh.zero_grad(set_to_none=True)
+            rgb, dens = nh(pts, dirs, iter_nr=None)
+            ((rgb * w_rgb).sum() + (dens * w_den).sum()).backward()
+            return rgb.detach(), dens.detach(), [p_.grad.clone() for p_ in nh.parameters()]
+        finally:
+            NerfHash.fused_head = GridHashEncoder.fused_concat = True
+
+    rgb_a, den_a, g_a = run(True)
+    rgb_b, den_b, g_b = run(False)
+    # the same arithmetic term for term; torch's own GELU / softplus kernels may contract differently
+    np.testing.assert_allclose(rgb_a.cpu().numpy(), rgb_b.cpu().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(den_a.cpu().numpy(), den_b.cpu().numpy(), rtol=2e-6, atol=1e-7)
+    for (name, _), ga, gb in zip(nh.named_parameters(), g_a, g_b):
+        scale = gb.abs().max().item()
+        assert scale > 0, name
+        np.testing.assert_allclose(ga.cpu().numpy(), gb.cpu().numpy(), rtol=2e-4, atol=2e-6 * scale, err_msg=name)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n_dims,levels,log2,growth", [(3, 24, 18, 2.0), (2, 16, 15, 1.5)])
 def test_grid_encode_backward_sliced_and_binned_equal_atomic_scatter(n_dims, levels, log2, growth):
     """vsa_grid_encode_bwd_sliced (LDS-resident table slices, large batches) accumulates the

@@ -86,7 +86,8 @@ template <int D>
 __global__ __launch_bounds__(256) void grid_encode_fwd_kernel(vsa_grid_plan plan,
                                                               const float2* __restrict__ tables,
                                                               const float* __restrict__ x, int B,
-                                                              float2* __restrict__ out) {
+                                                              float* __restrict__ out, int out_stride,
+                                                              int append_x) {
   const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
   const int l = blockIdx.y;
   if (b >= B) return;
@@ -103,7 +104,20 @@ __global__ __launch_bounds__(256) void grid_encode_fwd_kernel(vsa_grid_plan plan
     f0 = f0 + w * v.x;
     f1 = f1 + w * v.y;
   }
-  out[b * plan.n_levels + l] = make_float2(f0, f1);
+  // out row = [2 L features | the D inputs when append_x] (GridHashEncoder's concat_points written
+  // here instead of by a torch.cat over the whole feature matrix); rows of odd stride are not
+  // 8-byte aligned
+  float* o = out + b * out_stride + 2 * l;
+  if ((out_stride & 1) == 0) {
+    *reinterpret_cast<float2*>(o) = make_float2(f0, f1);
+  } else {
+    o[0] = f0;
+    o[1] = f1;
+  }
+  if (append_x && l == 0) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) out[b * out_stride + 2 * plan.n_levels + d] = x[b * D + d];
+  }
 }
 
 // Two lanes per (sample, level), one per feature: the two float atomics of an entry sit in
@@ -114,13 +128,14 @@ template <int D>
 __global__ __launch_bounds__(256) void grid_encode_bwd_kernel(vsa_grid_plan plan,
                                                               const float* __restrict__ x,
                                                               const float* __restrict__ g_out,
-                                                              int B, float* __restrict__ g_tables) {
+                                                              int g_stride, int B,
+                                                              float* __restrict__ g_tables) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long b = t >> 1;
   const int f = (int)(t & 1);
   const int l = blockIdx.y;
   if (b >= B) return;
-  const float go = g_out[(b * plan.n_levels + l) * 2 + f];
+  const float go = g_out[b * g_stride + 2 * l + f];
   if (go == 0.f) return;
   const GridLevel g = grid_level(plan, l);
   const GridCell<D> cell = grid_cell<D>(g, x + b * D);
@@ -152,15 +167,17 @@ constexpr int GS_SLICE_LOG2 = 13;
 constexpr int GS_SLICE = 1 << GS_SLICE_LOG2;
 constexpr int GS_THREADS = 1024;
 
-__global__ __launch_bounds__(256) void grid_transpose_kernel(const float2* __restrict__ g_out, int B,
-                                                             int L, float2* __restrict__ g_lm,
+__global__ __launch_bounds__(256) void grid_transpose_kernel(const float* __restrict__ g_out,
+                                                             int g_stride, int B, int L,
+                                                             float2* __restrict__ g_lm,
                                                              unsigned* __restrict__ max_bits) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   float m = 0.f;
   if (t < (long long)B * L) {
     const long long b = t / L;
     const int l = (int)(t - b * L);
-    const float2 g = g_out[t];
+    const float* gp = g_out + b * g_stride + 2 * l;
+    const float2 g = make_float2(gp[0], gp[1]);
     g_lm[(long long)l * B + b] = g;
     m = fmaxf(fabsf(g.x), fabsf(g.y));
     if (!(m < INFINITY)) m = 0.f;
@@ -596,48 +613,59 @@ int plan_ok(const vsa_grid_plan* p) {
 
 }  // namespace
 
-extern "C" int vsa_grid_encode_fwd(const vsa_grid_plan* plan, const float* tables, const float* x,
-                                   int nr_points, float* out, void* stream) {
+extern "C" int vsa_grid_encode_fwd_ld(const vsa_grid_plan* plan, const float* tables, const float* x,
+                                      int nr_points, float* out, int out_stride, int append_x,
+                                      void* stream) {
   int rc = plan_ok(plan);
   if (rc) return rc;
-  if (nr_points < 0) return VSA_ERR_ARG;
+  if (nr_points < 0 || out_stride < 2 * plan->n_levels + (append_x ? plan->n_dims : 0)) return VSA_ERR_ARG;
   if (nr_points == 0) return VSA_OK;
   if (!tables || !x || !out) return VSA_ERR_ARG;
   dim3 grid(vsa_div_up(nr_points, 256), plan->n_levels);
   if (plan->n_dims == 2)
     hipLaunchKernelGGL(grid_encode_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, *plan,
-                       reinterpret_cast<const float2*>(tables), x, nr_points,
-                       reinterpret_cast<float2*>(out));
+                       reinterpret_cast<const float2*>(tables), x, nr_points, out, out_stride, append_x);
   else
     hipLaunchKernelGGL(grid_encode_fwd_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, *plan,
-                       reinterpret_cast<const float2*>(tables), x, nr_points,
-                       reinterpret_cast<float2*>(out));
+                       reinterpret_cast<const float2*>(tables), x, nr_points, out, out_stride, append_x);
   VSA_RETURN_LAUNCH_STATUS();
 }
 
-extern "C" int vsa_grid_encode_bwd(const vsa_grid_plan* plan, const float* x, const float* g_out,
-                                   int nr_points, float* grad_tables, void* stream) {
+extern "C" int vsa_grid_encode_fwd(const vsa_grid_plan* plan, const float* tables, const float* x,
+                                   int nr_points, float* out, void* stream) {
+  if (!plan) return VSA_ERR_ARG;
+  return vsa_grid_encode_fwd_ld(plan, tables, x, nr_points, out, 2 * plan->n_levels, 0, stream);
+}
+
+extern "C" int vsa_grid_encode_bwd_ld(const vsa_grid_plan* plan, const float* x, const float* g_out,
+                                      int g_stride, int nr_points, float* grad_tables, void* stream) {
   int rc = plan_ok(plan);
   if (rc) return rc;
-  if (nr_points < 0) return VSA_ERR_ARG;
+  if (nr_points < 0 || g_stride < 2 * plan->n_levels) return VSA_ERR_ARG;
   if (nr_points == 0) return VSA_OK;
   if (!x || !g_out || !grad_tables) return VSA_ERR_ARG;
   dim3 grid(vsa_div_up(2ll * nr_points, 256), plan->n_levels);
   if (plan->n_dims == 2)
     hipLaunchKernelGGL(grid_encode_bwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, *plan, x,
-                       g_out, nr_points, grad_tables);
+                       g_out, g_stride, nr_points, grad_tables);
   else
     hipLaunchKernelGGL(grid_encode_bwd_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, *plan, x,
-                       g_out, nr_points, grad_tables);
+                       g_out, g_stride, nr_points, grad_tables);
   VSA_RETURN_LAUNCH_STATUS();
 }
 
-extern "C" int vsa_grid_encode_bwd_sliced(const vsa_grid_plan* plan, const float* x,
-                                          const float* g_out, int nr_points, float* grad_tables,
-                                          float* workspace, void* stream) {
+extern "C" int vsa_grid_encode_bwd(const vsa_grid_plan* plan, const float* x, const float* g_out,
+                                   int nr_points, float* grad_tables, void* stream) {
+  if (!plan) return VSA_ERR_ARG;
+  return vsa_grid_encode_bwd_ld(plan, x, g_out, 2 * plan->n_levels, nr_points, grad_tables, stream);
+}
+
+extern "C" int vsa_grid_encode_bwd_sliced_ld(const vsa_grid_plan* plan, const float* x,
+                                             const float* g_out, int g_stride, int nr_points,
+                                             float* grad_tables, float* workspace, void* stream) {
   int rc = plan_ok(plan);
   if (rc) return rc;
-  if (nr_points < 0) return VSA_ERR_ARG;
+  if (nr_points < 0 || g_stride < 2 * plan->n_levels) return VSA_ERR_ARG;
   if (nr_points == 0) return VSA_OK;
   if (!x || !g_out || !grad_tables || !workspace) return VSA_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -646,8 +674,7 @@ extern "C" int vsa_grid_encode_bwd_sliced(const vsa_grid_plan* plan, const float
   unsigned* level_max = reinterpret_cast<unsigned*>(workspace + 2ll * nr_points * L);
   VSA_HIP_TRY(hipMemsetAsync(level_max, 0, sizeof(unsigned) * VSA_GRID_MAX_LEVELS, st));
   hipLaunchKernelGGL(grid_transpose_kernel, dim3(vsa_div_up((long long)nr_points * L, 256)), dim3(256), 0,
-                     st, reinterpret_cast<const float2*>(g_out), nr_points, L,
-                     reinterpret_cast<float2*>(workspace), level_max);
+                     st, g_out, g_stride, nr_points, L, reinterpret_cast<float2*>(workspace), level_max);
   int max_size = 1;
   for (int l = 0; l < L; ++l) max_size = plan->level_size[l] > max_size ? plan->level_size[l] : max_size;
   const int slices = (max_size + GS_SLICE - 1) >> GS_SLICE_LOG2;
@@ -681,6 +708,14 @@ extern "C" int vsa_grid_encode_bwd_sliced(const vsa_grid_plan* plan, const float
   VSA_RETURN_LAUNCH_STATUS();
 }
 
+extern "C" int vsa_grid_encode_bwd_sliced(const vsa_grid_plan* plan, const float* x,
+                                          const float* g_out, int nr_points, float* grad_tables,
+                                          float* workspace, void* stream) {
+  if (!plan) return VSA_ERR_ARG;
+  return vsa_grid_encode_bwd_sliced_ld(plan, x, g_out, 2 * plan->n_levels, nr_points, grad_tables, workspace,
+                                       stream);
+}
+
 extern "C" int vsa_grid_encode_bwd_binned_workspace(const vsa_grid_plan* plan, int nr_points,
                                                     long long* workspace_floats) {
   int rc = plan_ok(plan);
@@ -693,12 +728,12 @@ extern "C" int vsa_grid_encode_bwd_binned_workspace(const vsa_grid_plan* plan, i
   return VSA_OK;
 }
 
-extern "C" int vsa_grid_encode_bwd_binned(const vsa_grid_plan* plan, const float* x,
-                                          const float* g_out, int nr_points, float* grad_tables,
-                                          float* workspace, void* stream) {
+extern "C" int vsa_grid_encode_bwd_binned_ld(const vsa_grid_plan* plan, const float* x,
+                                             const float* g_out, int g_stride, int nr_points,
+                                             float* grad_tables, float* workspace, void* stream) {
   int rc = plan_ok(plan);
   if (rc) return rc;
-  if (nr_points < 0) return VSA_ERR_ARG;
+  if (nr_points < 0 || g_stride < 2 * plan->n_levels) return VSA_ERR_ARG;
   if (nr_points == 0) return VSA_OK;
   if (!x || !g_out || !grad_tables || !workspace) return VSA_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -719,7 +754,7 @@ extern "C" int vsa_grid_encode_bwd_binned(const vsa_grid_plan* plan, const float
   unsigned long long* cursors = offsets + nbins + 1;
   VSA_HIP_TRY(hipMemsetAsync(max_bits, 0, 64 * sizeof(unsigned) + (nbins + 1) * sizeof(unsigned long long), st));
   hipLaunchKernelGGL(grid_transpose_kernel, dim3(vsa_div_up(B * L, 256)), dim3(256), 0, st,
-                     reinterpret_cast<const float2*>(g_out), nr_points, (int)L, g_lm, max_bits);
+                     g_out, g_stride, nr_points, (int)L, g_lm, max_bits);
   int nr_cus = 0;
   rc = vsa_cu_count(&nr_cus);
   if (rc) return rc;
@@ -760,6 +795,14 @@ extern "C" int vsa_grid_encode_bwd_binned(const vsa_grid_plan* plan, const float
   hipLaunchKernelGGL(grid_bin_accumulate_kernel, dim3(GB_MAX_SLICES, (unsigned)L, zmax), dim3(GS_THREADS), lds_acc, st,
                      *plan, offsets, rec_idx, rec_x, rec_y, max_bits, count_bits, grad_tables);
   VSA_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int vsa_grid_encode_bwd_binned(const vsa_grid_plan* plan, const float* x,
+                                          const float* g_out, int nr_points, float* grad_tables,
+                                          float* workspace, void* stream) {
+  if (!plan) return VSA_ERR_ARG;
+  return vsa_grid_encode_bwd_binned_ld(plan, x, g_out, 2 * plan->n_levels, nr_points, grad_tables, workspace,
+                                       stream);
 }
 
 extern "C" int vsa_sh_encode(const float* dirs, int nr_dirs, int degree, float* out, void* stream) {

@@ -53,15 +53,20 @@ def grid_plan(n_dims, n_levels, log2_hashmap_size, base_resolution, per_level_sc
 
 
 class _GridEncode(torch.autograd.Function):
+    """append=True: the output rows are [2 L features | x] (GridHashEncoder's concat_points,
+    gridhash.py:88-90) written by the encode kernel itself, and the backward reads the gradient of
+    that wider matrix in place (`vsa_grid_encode_*_ld`): no torch.cat forward, no slice copy back."""
+
     @staticmethod
-    def forward(ctx, tables, x, plan, owner=None):
+    def forward(ctx, tables, x, plan, owner=None, append=False):
         x = _lib.check_f32(x.contiguous(), x.shape[0], plan.n_dims)
         ctx.owner = owner        # the nn.Parameter behind `tables` (direct gradient accumulation)
-        out = torch.empty(x.shape[0], plan.n_levels * 2, device=x.device)
-        _lib.call("vsa_grid_encode_fwd", ctypes.byref(plan), tables, x, x.shape[0], out,
-                  _lib.stream_ptr())
+        width = plan.n_levels * 2 + (plan.n_dims if append else 0)
+        out = torch.empty(x.shape[0], width, device=x.device)
+        _lib.call("vsa_grid_encode_fwd_ld", ctypes.byref(plan), tables, x, x.shape[0], out, width,
+                  1 if append else 0, _lib.stream_ptr())
         ctx.save_for_backward(x)
-        ctx.plan, ctx.shape = plan, tables.shape
+        ctx.plan, ctx.shape, ctx.width = plan, tables.shape, width
         return out
 
     @staticmethod
@@ -77,17 +82,18 @@ class _GridEncode(torch.autograd.Function):
             _lib.call("vsa_grid_encode_bwd_binned_workspace", ctypes.byref(ctx.plan), x.shape[0],
                       ctypes.byref(n))
             ws = torch.empty(n.value, device=x.device)
-            _lib.call("vsa_grid_encode_bwd_binned", ctypes.byref(ctx.plan), x, g_out, x.shape[0],
-                      g_tables, ws, _lib.stream_ptr())
+            _lib.call("vsa_grid_encode_bwd_binned_ld", ctypes.byref(ctx.plan), x, g_out, ctx.width,
+                      x.shape[0], g_tables, ws, _lib.stream_ptr())
         elif x.shape[0] >= SLICED_BWD_MIN_POINTS:
             # large batches: LDS-resident table slices instead of memory-side float atomics
-            ws = torch.empty(g_out.numel() + 32, device=x.device)
-            _lib.call("vsa_grid_encode_bwd_sliced", ctypes.byref(ctx.plan), x, g_out, x.shape[0],
-                      g_tables, ws, _lib.stream_ptr())
+            ws = torch.empty(x.shape[0] * ctx.plan.n_levels * 2 + 32, device=x.device)
+            _lib.call("vsa_grid_encode_bwd_sliced_ld", ctypes.byref(ctx.plan), x, g_out, ctx.width,
+                      x.shape[0], g_tables, ws, _lib.stream_ptr())
         else:
-            _lib.call("vsa_grid_encode_bwd", ctypes.byref(ctx.plan), x, g_out, x.shape[0],
+            _lib.call("vsa_grid_encode_bwd_ld", ctypes.byref(ctx.plan), x, g_out, ctx.width, x.shape[0],
                       g_tables, _lib.stream_ptr())
-        return (None if direct is not None else g_tables), None, None, None   # positions carry no gradient on this path
+        # positions carry no gradient on this path
+        return (None if direct is not None else g_tables), None, None, None, None
 
 
 class HashGrid(torch.nn.Module):
@@ -105,8 +111,8 @@ class HashGrid(torch.nn.Module):
             ((torch.rand(n_entries, 2, generator=g) * 2 - 1) * 1e-4).to(device))
         self.n_output_dims = 2 * config["n_levels"]
 
-    def forward(self, x):
-        return _GridEncode.apply(self.params, x.float(), self.plan, self.params)
+    def forward(self, x, append_points=False):
+        return _GridEncode.apply(self.params, x.float(), self.plan, self.params, append_points)
 
 
 class Encoder(torch.nn.Module):
@@ -229,12 +235,19 @@ class GridHashEncoder(Encoder):
                                                  (points >= self.bb_sides / 2).any(dim=1))
             points = points * (1 / (self.bb_sides / 2))
             points = (points + 1) / 2
+        if all_open and self.concat_points and GridHashEncoder.fused_concat and points.is_cuda \
+                and not points.requires_grad:
+            # the encode kernel writes the points behind the features (and its backward reads the
+            # wider gradient in place): no cat, no slice copy
+            return self.encoder(points, append_points=True), out_of_bounds
         enc = self.encoder(points)
         if not all_open:                              # (x * 1 is exact: skipping it changes no bit, and
             enc = enc * window                        #  saves two passes over [samples, 48] per step)
         if self.concat_points:
             enc = torch.cat([enc, points], dim=1)
         return enc, out_of_bounds
+
+    fused_concat = True       # class-wide switch: False = torch.cat (tests compare the two)
 
     def reset(self):
         pass

@@ -436,6 +436,35 @@ class ColorSH(torch.nn.Module):
         return self.sigmoid(sh_eval(sh, samples_dirs, self.sh_deg))
 
 
+class _FieldHead(torch.autograd.Function):
+    """nerfhash.py:72-91 between the two MLPs, one kernel each way (csrc/field_head.hip):
+    (y1 [n, 1+F], dirs_enc [n, E]) -> (x2 = cat(gelu(y1[:, 1:]), dirs_enc), softplus(y1[:, :1]))."""
+
+    @staticmethod
+    def forward(ctx, y1, dirs_enc):
+        y1 = _lib.check_f32(y1.contiguous())
+        dirs_enc = _lib.check_f32(dirs_enc.contiguous(), y1.shape[0], dirs_enc.shape[1])
+        n, F, E = y1.shape[0], y1.shape[1] - 1, dirs_enc.shape[1]
+        x2 = torch.empty(n, F + E, device=y1.device)
+        density = torch.empty(n, 1, device=y1.device)
+        _lib.call("vsa_field_head_fwd", y1, dirs_enc, ctypes.c_longlong(n), F, E, x2, density,
+                  _lib.stream_ptr())
+        ctx.save_for_backward(y1)
+        ctx.dims = (F, E)
+        return x2, density
+
+    @staticmethod
+    def backward(ctx, g_x2, g_density):
+        (y1,) = ctx.saved_tensors
+        F, E = ctx.dims
+        g_x2 = g_x2.contiguous() if g_x2 is not None else None
+        g_density = g_density.contiguous() if g_density is not None else None
+        dy1 = torch.empty_like(y1)
+        _lib.call("vsa_field_head_bwd", y1, g_x2, g_density, ctypes.c_longlong(y1.shape[0]), F, E, dy1,
+                  _lib.stream_ptr())
+        return dy1, None
+
+
 class NerfHash(torch.nn.Module):
     """models/nerfhash.py:11-91: the background radiance field render_contracted_bg evaluates
     at 32 contracted samples per ray (utils/background.py:72-80)."""
@@ -469,10 +498,16 @@ class NerfHash(torch.nn.Module):
         with torch.no_grad():
             dirs_enc = self.dir_encoder(samples_dirs)
         feat_and_density = self.mlp_feat_and_density(point_features)
+        if NerfHash.fused_head and feat_and_density.is_cuda and feat_and_density.dtype == torch.float32 \
+                and dirs_enc.dtype == torch.float32 and not dirs_enc.requires_grad:
+            x_rgb, density = _FieldHead.apply(feat_and_density, dirs_enc)
+            return self.sigmoid(self.mlp_rgb(x_rgb)), density
         density = feat_and_density[:, 0:1]
         feat_rgb = feat_and_density[:, 1:self.nr_feat_for_rgb + 1]
         rgb = self.mlp_rgb(torch.cat([self.gelu(feat_rgb), dirs_enc], 1))
         return self.sigmoid(rgb), self.softplus(density)
+
+    fused_head = True      # class-wide switch: False = the torch op sequence (tests compare the two)
 
     def get_only_density(self, ray_samples, iter_nr=None):
         points = ray_samples.view(-1, ray_samples.shape[-1])
