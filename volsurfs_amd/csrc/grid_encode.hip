@@ -167,20 +167,31 @@ constexpr int GS_SLICE_LOG2 = 13;
 constexpr int GS_SLICE = 1 << GS_SLICE_LOG2;
 constexpr int GS_THREADS = 1024;
 
+// A workgroup re-lays GT_ROWS samples x L levels through LDS: rows are read as they lie (contiguous
+// per sample), and every level's GT_ROWS gradients leave as one contiguous 512-byte run (written
+// straight from the row-major order each lane's 8 bytes went to its own 16 MB-strided address).
+constexpr int GT_ROWS = 64;
 __global__ __launch_bounds__(256) void grid_transpose_kernel(const float* __restrict__ g_out,
                                                              int g_stride, int B, int L,
                                                              float2* __restrict__ g_lm,
                                                              unsigned* __restrict__ max_bits) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float2 s_tile[VSA_GRID_MAX_LEVELS][GT_ROWS + 1];
+  const long long b0 = (long long)blockIdx.x * GT_ROWS;
+  const int rows = (int)min((long long)GT_ROWS, (long long)B - b0);
   float m = 0.f;
-  if (t < (long long)B * L) {
-    const long long b = t / L;
-    const int l = (int)(t - b * L);
-    const float* gp = g_out + b * g_stride + 2 * l;
+  for (int idx = threadIdx.x; idx < rows * L; idx += 256) {
+    const int r = idx / L, l = idx - r * L;
+    const float* gp = g_out + (b0 + r) * g_stride + 2 * l;
     const float2 g = make_float2(gp[0], gp[1]);
-    g_lm[(long long)l * B + b] = g;
-    m = fmaxf(fabsf(g.x), fabsf(g.y));
-    if (!(m < INFINITY)) m = 0.f;
+    s_tile[l][r] = g;
+    float mm = fmaxf(fabsf(g.x), fabsf(g.y));
+    if (!(mm < INFINITY)) mm = 0.f;
+    m = fmaxf(m, mm);
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < L * GT_ROWS; idx += 256) {
+    const int l = idx / GT_ROWS, r = idx - l * GT_ROWS;
+    if (r < rows) g_lm[(long long)l * B + b0 + r] = s_tile[l][r];
   }
   // max |g| over everything: wave reduction, one atomic per wave (non-negative floats order like
   // their bit patterns)
@@ -673,7 +684,7 @@ extern "C" int vsa_grid_encode_bwd_sliced_ld(const vsa_grid_plan* plan, const fl
   // workspace: [L][B] float2, then L words of max|g| bits
   unsigned* level_max = reinterpret_cast<unsigned*>(workspace + 2ll * nr_points * L);
   VSA_HIP_TRY(hipMemsetAsync(level_max, 0, sizeof(unsigned) * VSA_GRID_MAX_LEVELS, st));
-  hipLaunchKernelGGL(grid_transpose_kernel, dim3(vsa_div_up((long long)nr_points * L, 256)), dim3(256), 0,
+  hipLaunchKernelGGL(grid_transpose_kernel, dim3(vsa_div_up(nr_points, GT_ROWS)), dim3(256), 0,
                      st, g_out, g_stride, nr_points, L, reinterpret_cast<float2*>(workspace), level_max);
   int max_size = 1;
   for (int l = 0; l < L; ++l) max_size = plan->level_size[l] > max_size ? plan->level_size[l] : max_size;
@@ -753,7 +764,7 @@ extern "C" int vsa_grid_encode_bwd_binned_ld(const vsa_grid_plan* plan, const fl
   unsigned long long* offsets = counts + nbins + 1;
   unsigned long long* cursors = offsets + nbins + 1;
   VSA_HIP_TRY(hipMemsetAsync(max_bits, 0, 64 * sizeof(unsigned) + (nbins + 1) * sizeof(unsigned long long), st));
-  hipLaunchKernelGGL(grid_transpose_kernel, dim3(vsa_div_up(B * L, 256)), dim3(256), 0, st,
+  hipLaunchKernelGGL(grid_transpose_kernel, dim3(vsa_div_up(B, GT_ROWS)), dim3(256), 0, st,
                      g_out, g_stride, nr_points, (int)L, g_lm, max_bits);
   int nr_cus = 0;
   rc = vsa_cu_count(&nr_cus);

@@ -199,9 +199,9 @@ __global__ void update_dt_kernel(const int* __restrict__ start_end,
 }
 
 // RaySamplerGPU.cuh:39-139.  Without jitter every sample is independent: lanes =
-// samples.  With jitter t_i = lerp(t_{i-1}, t_i, u) chains through the ray, and the
-// reference's per-thread rng.advance(ray) + next_float() sequence is reproduced by
-// lane 0 serially (training-time only).
+// samples.  With jitter t_i = lerp(t_{i-1}, t_i, u) chains through the ray; the draws of the
+// reference's per-thread rng.advance(ray) + next_float() sequence are reproduced lane-parallel
+// (skip-ahead), only the lerps run in order (see below).
 __global__ void sample_bg_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                  const float* __restrict__ t_start_in, float t_far, int ns,
                                  int jitter, unsigned long long rng_state,
@@ -250,30 +250,53 @@ __global__ void sample_bg_kernel(const float* __restrict__ rays_o, const float* 
 #pragma unroll
     for (int off = SUB / 2; off > 0; off >>= 1) max_dt = fmaxf(max_dt, __shfl_xor(max_dt, off, SUB));
     if (l == 0) ray_max_dt[ray] = max_dt;
-  } else if (l == 0) {
-    Pcg32 rng{rng_state, rng_inc};
-    float s = 1.0f, t_prec = t_start, max_dt = 0.f;
-    for (int i = 0; i < ns; ++i) {
+  } else {
+    // Jitter: t_i = lerp(t_{i-1}, t_i, u_i) chains through the ray, but the draws do not: the
+    // reference's per-sample rng.advance(ray) + next_float() leaves the generator (i - 1)(ray + 1) +
+    // ray steps from its seed before the draw of sample i, so every lane jumps there on its own
+    // (O(log) LCG skip-ahead), forms its un-jittered t_i (a double division) in parallel, and only
+    // the 32 lerps of the chain run in order, through shuffles.  (One lane doing all of it
+    // serially: 0.55 ms for the 65 k rays of a background batch.)
+    float t_prec = t_start, max_dt = 0.f;
+    for (int c = 0; c < ns; c += SUB) {
+      const int i = c + l;
+      float s = 1.0f;
+      for (int k = 0; k < i && k < ns; ++k) s -= delta_s;
       float t = (float)(1.0 / (double)(s + eps) - 1.0);
       t += t_start;
       t = fminf(fmaxf(t, t_start), t_far);
-      if (i != 0 && i != ns - 1) {
-        rng.advance((unsigned long long)ray);
-        const float u = rng.next_float();
-        t = t_prec + u * (t - t_prec);   // helper_math lerp: a + t*(b-a)
+      const bool jit = i != 0 && i < ns - 1;
+      float u = 0.f;
+      if (jit) {
+        Pcg32 rng{rng_state, rng_inc};
+        rng.advance((unsigned long long)(i - 1) * ((unsigned long long)ray + 1ull) + (unsigned long long)ray);
+        u = rng.next_float();
       }
-      sz[base + i] = t;
-      s3d[3 * (base + i)] = ox + t * dx;
-      s3d[3 * (base + i) + 1] = oy + t * dy;
-      s3d[3 * (base + i) + 2] = oz + t * dz;
-      sdirs[3 * (base + i)] = dx;
-      sdirs[3 * (base + i) + 1] = dy;
-      sdirs[3 * (base + i) + 2] = dz;
-      s -= delta_s;
-      max_dt = fmaxf(max_dt, t - t_prec);
-      t_prec = t;
+      float my_t = t, my_dt = 0.f;
+      for (int k = 0; k < SUB && c + k < ns; ++k) {
+        const float tk = __shfl(t, k, SUB), uk = __shfl(u, k, SUB);
+        const int jk = __shfl((int)jit, k, SUB);
+        const float tt = jk ? t_prec + uk * (tk - t_prec) : tk;   // helper_math lerp: a + t*(b-a)
+        if (l == k) {
+          my_t = tt;
+          my_dt = tt - t_prec;
+        }
+        t_prec = tt;
+      }
+      if (i < ns) {
+        sz[base + i] = my_t;
+        s3d[3 * (base + i)] = ox + my_t * dx;
+        s3d[3 * (base + i) + 1] = oy + my_t * dy;
+        s3d[3 * (base + i) + 2] = oz + my_t * dz;
+        sdirs[3 * (base + i)] = dx;
+        sdirs[3 * (base + i) + 1] = dy;
+        sdirs[3 * (base + i) + 2] = dz;
+        max_dt = fmaxf(max_dt, my_dt);
+      }
     }
-    ray_max_dt[ray] = max_dt;
+#pragma unroll
+    for (int off = SUB / 2; off > 0; off >>= 1) max_dt = fmaxf(max_dt, __shfl_xor(max_dt, off, SUB));
+    if (l == 0) ray_max_dt[ray] = max_dt;
   }
   if (l == 0) {
     start_end[2 * ray] = (int)base;
