@@ -90,6 +90,33 @@ def test_hip_permuto_encoding_matches_oracle_values_and_gradients(D):
 
 
 @pytest.mark.gpu
+def test_hip_permuto_backward_coarse_levels_through_lds_and_fine_levels_direct():
+    """24 levels 1 .. 1e-3 at capacity 2^14, 20 k points: the first ten levels take the LDS-table
+    kernel (several chunks per level; at this capacity the finer of them overflow the 4096 slots and
+    fall back to memory atomics), the rest the plain kernel — all against the oracle."""
+    from volsurfs_amd.encodings import PermutoEncoding
+    g = np.random.default_rng(7)
+    L, C, N = 24, 1 << 14, 20000
+    scales = np.geomspace(1.0, 1e-3, L)
+    vals = g.standard_normal((L, C, 2)).astype(np.float32)
+    shift = (g.standard_normal((L, 3)) * 10).astype(np.float32)
+    x = (g.random((N, 3), dtype=np.float32) - 0.5) * 0.8
+    enc = PermutoEncoding(3, C, L, 2, scales)
+    with torch.no_grad():
+        enc.lattice_values.copy_(torch.from_numpy(vals))
+        enc.random_shift_per_level.copy_(torch.from_numpy(shift))
+    out = enc(torch.from_numpy(x).cuda(), None)
+    go = g.standard_normal(out.shape).astype(np.float32)
+    go[::7] = 0.0                                     # rows without gradient are skipped
+    out.backward(torch.from_numpy(go).cuda())
+    gref = P.encode_backward(go, x, scales, shift, C, None)
+    got = enc.lattice_values.grad.cpu().numpy()
+    np.testing.assert_allclose(got, gref, rtol=2e-4, atol=2e-4 * np.abs(gref).max())
+    for l in (0, 5, 9, 10, 23):
+        assert np.abs(got[l]).max() > 0
+
+
+@pytest.mark.gpu
 def test_hip_permuto_hash_encoder_reference_configuration():
     """The configuration the reference instantiates (permutohash.py:12-37 via get_encoder):
     24 levels, capacity 2^18, sigma 1 .. 1e-4, random shift, points concatenated, last channel

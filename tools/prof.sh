@@ -9,6 +9,6 @@ echo "rocprof rc=$?"
 python3 - <<PY
 import csv,glob
 f=glob.glob("$root/gpurun_out/$tag/*/*kernel_stats.csv")[0]
-for r in list(csv.DictReader(open(f)))[:16]:
+for r in list(csv.DictReader(open(f)))[:28]:
     print(f"{r['Name'][:64]:64s} n={r['Calls']:>4s} avg_us={float(r['AverageNs'])/1e3:9.1f} {r['Percentage']}%")
 PY

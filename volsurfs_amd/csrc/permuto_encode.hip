@@ -19,6 +19,13 @@
 // 48 MiB: L2 / MALL resident), fp32 throughout, operations in the oracle's order.
 #include "common.h"
 
+#ifndef PERMUTO_LDS_LEVELS
+#define PERMUTO_LDS_LEVELS 10
+#endif
+#ifndef PERMUTO_LDS_MIN_POINTS
+#define PERMUTO_LDS_MIN_POINTS 512
+#endif
+
 namespace {
 
 template <int D>
@@ -132,12 +139,12 @@ __global__ __launch_bounds__(256) void permuto_bwd_kernel(vsa_permuto_plan plan,
                                                           const float* __restrict__ x,
                                                           const float* __restrict__ window,
                                                           const float* __restrict__ g_out,
-                                                          int g_stride, int B,
+                                                          int g_stride, int B, int l0,
                                                           float* __restrict__ g_values) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long b = t >> 1;
   const int f = (int)(t & 1);
-  const int l = blockIdx.y;
+  const int l = l0 + blockIdx.y;
   if (b >= B) return;
   const float wl = window ? window[l] : 1.0f;
   const float go = g_out[b * g_stride + 2 * l + f];
@@ -148,6 +155,115 @@ __global__ __launch_bounds__(256) void permuto_bwd_kernel(vsa_permuto_plan plan,
   for (int k = 0; k <= D; ++k) {
     const float w = s.bary[k] * wl;
     atomicAdd(tab + 2ll * permuto_index<D>(s, k, (unsigned)plan.capacity) + f, go * w);
+  }
+}
+
+// ---- the coarse levels: accumulate in LDS first.
+// The kernel above spends most of its time on the COARSE levels (measured on the 10 k points one
+// per-shell model sees in the training loop of BASELINE configs[2]: levels 0-7 take 134 of its
+// 172 us, levels 12-23 together 19 us): thousands of points share the few hundred lattice
+// vertices a coarse level has on the surface, and device-scope float atomics on one address are
+// serialised at the memory side.  Here a workgroup owns (level, chunk of PL_CHUNK points): it adds
+// the chunk's contributions into an open-addressing table in LDS (keys claimed with ds_cmpst,
+// values 64-bit FIXED POINT as in grid_encode.hip: ds_add_u64 is ~16x faster than ds_add_f32 on
+// gfx950, and integer sums make the result independent of the order inside the chunk), and then
+// flushes each distinct vertex ONCE.  The power-of-two scale comes from the chunk's own max|g|
+// (first pass over the chunk's gradient column).  A contribution that finds neither its key nor a
+// free slot within PL_PROBES probes (more distinct vertices than slots) goes straight to memory
+// like before.
+constexpr int PL_THREADS = 512;
+constexpr int PL_SLOTS = 4096;            // keys 16 KiB + 2 x 32 KiB of accumulators
+constexpr int PL_PROBES = 16;
+constexpr int PL_CHUNK = 4096;            // points per workgroup
+constexpr unsigned PL_EMPTY = 0xffffffffu;
+
+__device__ __forceinline__ unsigned long long pl_fixed62(float v) {      // as grid_encode.hip's fixed62
+  const float r = rintf(v);
+  const float hi = floorf(r * 2.3283064365386963e-10f);
+  const float lo = r - hi * 4294967296.0f;
+  return ((unsigned long long)(unsigned)(int)hi << 32) + (unsigned long long)(unsigned)lo;
+}
+
+template <int D>
+__global__ __launch_bounds__(PL_THREADS) void permuto_bwd_lds_kernel(vsa_permuto_plan plan,
+                                                                     const float* __restrict__ x,
+                                                                     const float* __restrict__ window,
+                                                                     const float* __restrict__ g_out,
+                                                                     int g_stride, int B,
+                                                                     float* __restrict__ g_values) {
+  __shared__ unsigned s_key[PL_SLOTS];
+  __shared__ unsigned long long s_val[2 * PL_SLOTS];
+  __shared__ float s_max[PL_THREADS / 64];
+  const int l = blockIdx.y;
+  const long long p0 = (long long)blockIdx.x * PL_CHUNK;
+  const int np = (int)min((long long)PL_CHUNK, (long long)B - p0);
+  const float wl = window ? window[l] : 1.0f;
+  if (wl == 0.f) return;
+  for (int i = threadIdx.x; i < PL_SLOTS; i += PL_THREADS) {
+    s_key[i] = PL_EMPTY;
+    s_val[2 * i] = 0ull;
+    s_val[2 * i + 1] = 0ull;
+  }
+  // max |g| of this chunk's column pair
+  float m = 0.f;
+  for (int t = threadIdx.x; t < 2 * np; t += PL_THREADS) {
+    float a = fabsf(g_out[(p0 + (t >> 1)) * g_stride + 2 * l + (t & 1)]);
+    if (!(a < INFINITY)) a = 0.f;
+    m = fmaxf(m, a);
+  }
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = 0.f;
+#pragma unroll
+  for (int w = 0; w < PL_THREADS / 64; ++w) m = fmaxf(m, s_max[w]);
+  if (m == 0.f) return;                       // uniform: nothing to add
+  // |contribution| <= m |wl| (barycentric weights are in [0, 1]); a slot receives at most
+  // (D + 1) * np of them: 62 - count_bits - exponent bits of headroom
+  int e;
+  frexpf(m * fabsf(wl), &e);
+  int count_bits = 1;
+  while ((1 << count_bits) < (D + 1) * PL_CHUNK) ++count_bits;
+  const float scale = ldexpf(1.0f, 62 - count_bits - e);
+  float* tab = g_values + 2ll * l * plan.capacity;
+  for (int t = threadIdx.x; t < 2 * np; t += PL_THREADS) {
+    const long long b = p0 + (t >> 1);
+    const int f = t & 1;
+    const float go = g_out[b * g_stride + 2 * l + f];
+    if (go == 0.f || !(fabsf(go) < INFINITY)) {
+      if (go != 0.f) {                        // inf / nan: as the plain kernel would propagate it
+        const Simplex<D> s = permuto_simplex<D>(plan, l, x + b * D);
+#pragma unroll
+        for (int k = 0; k <= D; ++k)
+          atomicAdd(tab + 2ll * permuto_index<D>(s, k, (unsigned)plan.capacity) + f, go * (s.bary[k] * wl));
+      }
+      continue;
+    }
+    const Simplex<D> s = permuto_simplex<D>(plan, l, x + b * D);
+#pragma unroll
+    for (int k = 0; k <= D; ++k) {
+      const float w = s.bary[k] * wl;
+      const unsigned idx = permuto_index<D>(s, k, (unsigned)plan.capacity);
+      unsigned slot = (idx * 2654435761u) >> 20;          // 12 bits
+      int found = -1;
+      for (int pr = 0; pr < PL_PROBES; ++pr) {
+        const unsigned prev = atomicCAS(&s_key[slot], PL_EMPTY, idx);
+        if (prev == PL_EMPTY || prev == idx) {
+          found = (int)slot;
+          break;
+        }
+        slot = (slot + 1) & (PL_SLOTS - 1);
+      }
+      if (found >= 0) atomicAdd(&s_val[2 * found + f], pl_fixed62((go * w) * scale));
+      else atomicAdd(tab + 2ll * idx + f, go * w);
+    }
+  }
+  __syncthreads();
+  const double inv = 1.0 / (double)scale;
+  for (int i = threadIdx.x; i < 2 * PL_SLOTS; i += PL_THREADS) {
+    const unsigned key = s_key[i >> 1];
+    const long long v = (long long)s_val[i];
+    if (key != PL_EMPTY && v != 0) atomicAdd(tab + 2ll * key + (i & 1), (float)((double)v * inv));
   }
 }
 
@@ -189,10 +305,21 @@ extern "C" int vsa_permuto_encode_bwd(const vsa_permuto_plan* plan, const float*
   if (nr_points < 0 || g_stride < 2 * plan->n_levels) return VSA_ERR_ARG;
   if (nr_points == 0) return VSA_OK;
   if (!x || !g_out || !grad_values) return VSA_ERR_ARG;
-  dim3 grid(vsa_div_up(2ll * nr_points, 256), plan->n_levels);
-#define VSA_PERMUTO_BWD(D)                                                                       \
-  hipLaunchKernelGGL(permuto_bwd_kernel<D>, grid, dim3(256), 0, (hipStream_t)stream, *plan, x,   \
-                     window, g_out, g_stride, nr_points, grad_values)
+  // the first PERMUTO_LDS_LEVELS levels (the coarse ones: levels are ordered coarse to fine) go
+  // through the LDS tables, the rest straight to memory
+  int n_lds = PERMUTO_LDS_LEVELS < plan->n_levels ? PERMUTO_LDS_LEVELS : plan->n_levels;
+  if (nr_points < PERMUTO_LDS_MIN_POINTS) n_lds = 0;
+#define VSA_PERMUTO_BWD(D)                                                                          \
+  do {                                                                                              \
+    if (n_lds > 0)                                                                                  \
+      hipLaunchKernelGGL(permuto_bwd_lds_kernel<D>, dim3(vsa_div_up(nr_points, PL_CHUNK), n_lds),   \
+                         dim3(PL_THREADS), 0, (hipStream_t)stream, *plan, x, window, g_out, g_stride, \
+                         nr_points, grad_values);                                                   \
+    if (n_lds < plan->n_levels)                                                                     \
+      hipLaunchKernelGGL(permuto_bwd_kernel<D>, dim3(vsa_div_up(2ll * nr_points, 256), plan->n_levels - n_lds), \
+                         dim3(256), 0, (hipStream_t)stream, *plan, x, window, g_out, g_stride,       \
+                         nr_points, n_lds, grad_values);                                            \
+  } while (0)
   if (plan->pos_dim == 2) VSA_PERMUTO_BWD(2);
   else if (plan->pos_dim == 3) VSA_PERMUTO_BWD(3);
   else VSA_PERMUTO_BWD(4);
