@@ -49,6 +49,13 @@ __global__ __launch_bounds__(ADAM_BLOCK) void adam_kernel(const vsa_adam_tensor*
         v[k] = in ? t.exp_avg_sq[i + k] : 0.f;
       }
     }
+    // An entry that has never received a gradient (g = m = v = 0: most of a hash table's coarse
+    // levels, and every slot no sample has hashed to yet) stays exactly as it is — m' = v' = 0 and
+    // p' = p - step * (0 / eps) = p — so none of its five stores is issued: 16 B instead of 34 B
+    // of traffic for it.
+    bool idle = true;
+#pragma unroll
+    for (int k = 0; k < ADAM_VEC; ++k) idle = idle && g[k] == 0.f && m[k] == 0.f && v[k] == 0.f;
 #pragma unroll
     for (int k = 0; k < ADAM_VEC; ++k) {
       const float gk = g[k] * grad_scale;
@@ -57,7 +64,9 @@ __global__ __launch_bounds__(ADAM_BLOCK) void adam_kernel(const vsa_adam_tensor*
       const float denom = sqrtf(v[k]) * inv_bc2_sqrt + eps;
       p[k] = p[k] - step_size * (m[k] / denom);
     }
-    if (full) {
+    if (idle) {
+      // nothing to write
+    } else if (full) {
       *reinterpret_cast<float4*>(t.param + i) = *reinterpret_cast<const float4*>(p);
       *reinterpret_cast<float4*>(t.exp_avg + i) = *reinterpret_cast<const float4*>(m);
       *reinterpret_cast<float4*>(t.exp_avg_sq + i) = *reinterpret_cast<const float4*>(v);
