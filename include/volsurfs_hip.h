@@ -399,6 +399,22 @@ int vsa_mlp_bwd(const vsa_mlp_plan* plan, const float* x, int x_stride, int nr_p
                 float* packed_ws, float* partial_ws, float* dx, int dx_stride,
                 const vsa_mlp_grads* grads, void* stream);
 
+/* The same two for up to 8 networks of ONE architecture in one set of launches: the K per-shell
+ * models of the legacy appearance branch (volsurfs_py/methods/volsurfs.py:402-470), each applied to
+ * its own shell's hits.  Group g owns rows [sum nr_points[0..g), +nr_points[g]) of x / y / dy / dx
+ * and the matching rows x (sum of hidden widths) floats of z_ws / dz_ws / a_ws; packed_ws holds
+ * nr_groups x packed_floats, partial_ws nr_groups x the partial_floats vsa_mlp_workspace reports
+ * for the largest group; grads [nr_groups] (one `accumulate` setting for all).  plans / nr_points /
+ * grads are HOST arrays.  vsa_mlp_fwd / vsa_mlp_bwd are the one-group case. */
+int vsa_mlp_fwd_grouped(const vsa_mlp_plan* plans, int nr_groups, const int* nr_points,
+                        const float* x, int x_stride, float* y, int y_stride, float* z_ws,
+                        float* packed_ws, void* stream);
+int vsa_mlp_bwd_grouped(const vsa_mlp_plan* plans, int nr_groups, const int* nr_points,
+                        const float* x, int x_stride, const float* dy, int dy_stride,
+                        const float* z_ws, float* dz_ws, float* a_ws, float* packed_ws,
+                        float* partial_ws, float* dx, int dx_stride, const vsa_mlp_grads* grads,
+                        void* stream);
+
 /* A13  Fused multi-tensor Adam step: apex.optimizers.FusedAdam(betas (0.9, 0.99), eps 1e-15,
  * weight_decay 0) of volsurfs_py/methods/base_method.py:87-94, stepped at trainer.py:278 (the
  * same update as torch.optim.Adam).  One launch for all parameter tensors:

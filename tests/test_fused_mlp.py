@@ -100,3 +100,51 @@ def test_fused_mlp_inference_and_frozen_inputs():
         MLP.fused = True
     assert (y1 - y2).abs().max() < 1e-5
     assert m(torch.zeros(0, 80, device="cuda")).shape == (0, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sizes", [[9000, 0, 12001, 700, 10000], [300] * 9 + [0, 41]])
+def test_grouped_launch_equals_the_networks_one_by_one(sizes):
+    """vsa_mlp_fwd_grouped / vsa_mlp_bwd_grouped (group = blockIdx.y, up to 8 per launch; 11 groups
+    = two launches) against one vsa_mlp_fwd / vsa_mlp_bwd per network: outputs bit for bit (the
+    tiles and their arithmetic are the same), gradients to 1e-5 of their scale (the weight-gradient
+    workgroups share the co-resident budget between the groups, so the partial sums are grouped
+    differently)."""
+    from volsurfs_amd.models import MLP, fused_mlp_grouped
+    torch.manual_seed(11)
+    mlps = [MLP(66, [128, 128, 64, 3], last_layer_linear=True).cuda() for _ in sizes]
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x = torch.randn(sum(sizes), 66, device="cuda", generator=g)
+    gy = torch.randn(sum(sizes), 3, device="cuda", generator=g)
+
+    xa = x.clone().requires_grad_(True)
+    ya = fused_mlp_grouped(mlps, xa, sizes)
+    ya.backward(gy)
+    ga = [p_.grad.clone() if p_.grad is not None else None for m in mlps for p_ in m.parameters()]
+    for m in mlps:
+        m.zero_grad(set_to_none=True)
+
+    xb = x.clone().requires_grad_(True)
+    outs, a = [], 0
+    for m, n in zip(mlps, sizes):
+        outs.append(m(xb[a:a + n]))
+        a += n
+    yb = torch.cat(outs, 0)
+    yb.backward(gy)
+    gb = [p_.grad if p_.grad is not None else None for m in mlps for p_ in m.parameters()]
+
+    assert torch.equal(ya, yb)
+    np.testing.assert_allclose(xa.grad.cpu().numpy(), xb.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    for (m, n) in zip(mlps, sizes):
+        pass
+    k = 0
+    for m, n in zip(mlps, sizes):
+        for p_ in m.parameters():
+            a_, b_ = ga[k], gb[k]
+            k += 1
+            if n == 0:
+                assert a_ is None or float(a_.abs().max()) == 0.0
+                assert b_ is None or float(b_.abs().max()) == 0.0
+                continue
+            scale = float(b_.abs().max())
+            np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)

@@ -68,13 +68,54 @@ struct LayerMeta {
   const float* b[VSA_MLP_MAX_LAYERS];
 };
 
-__device__ __forceinline__ void load_layer_meta(const vsa_mlp_plan& plan, LayerMeta& m) {
+// Every launch covers up to MLP_MAX_GROUPS networks of ONE architecture (the K per-shell models of
+// the legacy appearance branch, volsurfs.py:402-470: each applied to its own shell's hits — ~80
+// workgroups per network on a 256-CU part when launched one by one, and five launches where one
+// does): `plan` carries the shared layer widths, this descriptor what differs per group — weight /
+// bias pointers, the number of rows and where they start.  Group = blockIdx.y (pack / reduce: z).
+// A single network is the one-group case.  Rows of group g start at row0[g] in x / y / dy / dx and
+// at row0[g] * (sum of hidden widths) floats in the z / dz / a workspaces; packed weights and
+// weight-gradient partials are per group (stride given at launch).
+constexpr int MLP_MAX_GROUPS = 8;
+struct MlpGroups {
+  int M[MLP_MAX_GROUPS];
+  long long row0[MLP_MAX_GROUPS];
+  const float* w[MLP_MAX_GROUPS][VSA_MLP_MAX_LAYERS];
+  const float* b[MLP_MAX_GROUPS][VSA_MLP_MAX_LAYERS];
+};
+struct MlpGroupGrads {
+  float* dw[MLP_MAX_GROUPS][VSA_MLP_MAX_LAYERS];
+  float* db[MLP_MAX_GROUPS][VSA_MLP_MAX_LAYERS];
+  int accumulate;
+};
+// element g of a kernel-argument array WITHOUT indexing it at run time (that would move the whole
+// argument to scratch memory, as the layer loops did with the plan): a chain of selects over
+// compile-time indices; g is uniform, so they are scalar
+template <class T, int N>
+__device__ __forceinline__ T pick(const T (&a)[N], int g) {
+  T r = a[0];
+#pragma unroll
+  for (int i = 1; i < N; ++i)
+    if (g == i) r = a[i];
+  return r;
+}
+template <class T, int N, int K>
+__device__ __forceinline__ T pick2(const T (&a)[N][K], int g, int k /* compile-time at the call sites that matter */) {
+  T r = a[0][k];
+#pragma unroll
+  for (int i = 1; i < N; ++i)
+    if (g == i) r = a[i][k];
+  return r;
+}
+
+__device__ __forceinline__ void load_layer_meta(const vsa_mlp_plan& plan, const MlpGroups& gp, int g,
+                                                LayerMeta& m) {
   if (threadIdx.x == 0) {
     int acc = 0;
 #pragma unroll
     for (int l = 0; l < VSA_MLP_MAX_LAYERS; ++l) {
       m.dims[l] = plan.dims[l];
-      m.b[l] = plan.b[l];
+      m.b[l] = pick2(gp.b, g, l);
       m.fwd[l] = acc;
       if (l < plan.n_layers) acc += blocks_of(plan.dims[l]) * blocks_of(plan.dims[l + 1]) * 16 * 64;
     }
@@ -93,14 +134,19 @@ __device__ __forceinline__ const float* meta_bias(const LayerMeta& m, int l) {
 
 // packed_fwd[l][((m * inb + b) * 16 + s) * 64 + lane] = W_l[32 m + (lane & 31)][32 b + rho(s, lane >> 5)]
 // packed_bwd[l][((b * outb + m) * 16 + s) * 64 + lane] = W_l[32 m + rho(s, lane >> 5)][32 b + (lane & 31)]
-__global__ void mlp_pack_kernel(vsa_mlp_plan plan, float* __restrict__ packed_fwd,
-                                float* __restrict__ packed_bwd) {
+__global__ void mlp_pack_kernel(vsa_mlp_plan plan, MlpGroups gp, long long packed_stride,
+                                float* __restrict__ packed_fwd, float* __restrict__ packed_bwd) {
   const PackOffsets off = pack_offsets(plan);
-  const int l = blockIdx.y;
+  const int l = blockIdx.y, g = blockIdx.z;
   const int in = plan.dims[l], out = plan.dims[l + 1];
   const int inb = blocks_of(in), outb = blocks_of(out);
   const int n = inb * outb * 16 * 64;
-  const float* W = plan.w[l];
+  const float* W = nullptr;
+#pragma unroll
+  for (int k = 0; k < VSA_MLP_MAX_LAYERS; ++k)
+    if (l == k) W = pick2(gp.w, g, k);
+  if (packed_fwd) packed_fwd += g * packed_stride;
+  if (packed_bwd) packed_bwd += g * packed_stride;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
     const int lane = idx & 63, s = (idx >> 6) & 15, blk = idx >> 10;
     const int i = lane & 31, h = lane >> 5;
@@ -135,12 +181,22 @@ __device__ __forceinline__ void stage_layer(const float* __restrict__ src, float
 // ColorSH: 152 KiB) one layer at a time is staged, two barriers per layer.
 template <bool RESIDENT, int NB>
 __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_fwd_kernel(
-    vsa_mlp_plan plan, const float* __restrict__ packed, const float* __restrict__ x, int x_stride,
-    int M, float* __restrict__ y, int y_stride, float* __restrict__ z_ws) {
+    vsa_mlp_plan plan, MlpGroups gp, long long packed_stride, long long hidden,
+    const float* __restrict__ packed, const float* __restrict__ x, int x_stride,
+    float* __restrict__ y, int y_stride, float* __restrict__ z_ws) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];
   __shared__ LayerMeta s_meta;
-  load_layer_meta(plan, s_meta);
+  const int grp = blockIdx.y;
+  load_layer_meta(plan, gp, grp, s_meta);
   const int L = plan.n_layers;
+  const int M = pick(gp.M, grp);
+  {
+    const long long r0 = pick(gp.row0, grp);
+    packed += grp * packed_stride;
+    x += r0 * x_stride;
+    y += r0 * y_stride;
+    if (z_ws) z_ws += r0 * hidden;
+  }
   if (RESIDENT) {
     stage_layer(packed, s_w, meta_fwd(s_meta, L));
     __syncthreads();
@@ -249,13 +305,25 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_fwd_kernel(
 // same offsets as z_ws); dX [point][dims[0]] optional.
 template <bool RESIDENT, int NB>
 __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_dgrad_kernel(
-    vsa_mlp_plan plan, const float* __restrict__ packed_t, const float* __restrict__ dy,
-    int dy_stride, int M, const float* __restrict__ z_ws, float* __restrict__ dz_ws,
+    vsa_mlp_plan plan, MlpGroups gp, long long packed_stride, long long hidden,
+    const float* __restrict__ packed_t, const float* __restrict__ dy,
+    int dy_stride, const float* __restrict__ z_ws, float* __restrict__ dz_ws,
     float* __restrict__ a_ws, float* __restrict__ dx, int dx_stride) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];
   __shared__ LayerMeta s_meta;
-  load_layer_meta(plan, s_meta);
+  const int grp = blockIdx.y;
+  load_layer_meta(plan, gp, grp, s_meta);
   const int L = plan.n_layers;
+  const int M = pick(gp.M, grp);
+  {
+    const long long r0 = pick(gp.row0, grp);
+    packed_t += grp * packed_stride;
+    dy += r0 * dy_stride;
+    z_ws += r0 * hidden;
+    dz_ws += r0 * hidden;
+    a_ws += r0 * hidden;
+    if (dx) dx += r0 * dx_stride;
+  }
   if (RESIDENT) {
     stage_layer(packed_t, s_w, meta_fwd(s_meta, L));
     __syncthreads();
@@ -399,10 +467,21 @@ __host__ __device__ constexpr int wg_stride(int width_pad) { return width_pad + 
 // in flight, i.e. co-resident workgroups x PF.
 template <int NB, int Q, int PF, int WGS>
 __global__ __launch_bounds__(MLP_BLOCK, WGS) void mlp_wgrad_kernel(
-    vsa_mlp_plan plan, WgradLayers wl, const float* __restrict__ x, int x_stride,
-    const float* __restrict__ dy, int dy_stride, int M, const float* __restrict__ dz_ws,
+    vsa_mlp_plan plan, WgradLayers wl, MlpGroups gp, long long hidden, long long partial_stride,
+    const float* __restrict__ x, int x_stride,
+    const float* __restrict__ dy, int dy_stride, const float* __restrict__ dz_ws,
     const float* __restrict__ a_ws, float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) float s_t[];
+  const int grp = blockIdx.y;
+  const int M = pick(gp.M, grp);
+  {
+    const long long r0 = pick(gp.row0, grp);
+    x += r0 * x_stride;
+    dy += r0 * dy_stride;
+    dz_ws += r0 * hidden;
+    a_ws += r0 * hidden;
+    partial += grp * partial_stride;
+  }
   int l = 0;
   while (l + 1 < plan.n_layers && (int)blockIdx.x >= wl.wg_begin[l + 1]) ++l;
   const int L = plan.n_layers;
@@ -527,25 +606,34 @@ __global__ __launch_bounds__(MLP_BLOCK, WGS) void mlp_wgrad_kernel(
 }
 
 // dW_l / db_l = sum over the layer's workgroups of their partial blocks
-__global__ void mlp_reduce_kernel(vsa_mlp_plan plan, WgradLayers wl, const float* __restrict__ partial,
-                                  vsa_mlp_grads grads) {
-  const int l = blockIdx.y;
+__global__ void mlp_reduce_kernel(vsa_mlp_plan plan, WgradLayers wl, long long partial_stride,
+                                  const float* __restrict__ partial, MlpGroupGrads grads) {
+  const int l = blockIdx.y, g = blockIdx.z;
+  partial += g * partial_stride;
   const int in = plan.dims[l], out = plan.dims[l + 1];
   const int in_pad = 32 * blocks_of(in), out_pad = 32 * blocks_of(out);
   const int nwg = wl.wg_begin[l + 1] - wl.wg_begin[l];
   const int per = out_pad * in_pad + out_pad;
+  float* dw = nullptr;
+  float* db = nullptr;
+#pragma unroll
+  for (int k = 0; k < VSA_MLP_MAX_LAYERS; ++k)
+    if (l == k) {
+      dw = pick2(grads.dw, g, k);
+      db = pick2(grads.db, g, k);
+    }
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < per; idx += gridDim.x * blockDim.x) {
     float s = 0.f;
-    for (int g = 0; g < nwg; ++g) s += partial[wl.part_off[l] + (long long)g * per + idx];
+    for (int k = 0; k < nwg; ++k) s += partial[wl.part_off[l] + (long long)k * per + idx];
     if (idx < out_pad * in_pad) {
       const int row = idx / in_pad, col = idx - row * in_pad;
-      if (row < out && col < in && grads.dw[l]) {
-        float* d = grads.dw[l] + (long long)row * in + col;
+      if (row < out && col < in && dw) {
+        float* d = dw + (long long)row * in + col;
         *d = grads.accumulate ? *d + s : s;
       }
     } else {
       const int n = idx - out_pad * in_pad;
-      if (n < out && grads.db[l]) grads.db[l][n] = grads.accumulate ? grads.db[l][n] + s : s;
+      if (n < out && db) db[n] = grads.accumulate ? db[n] + s : s;
     }
   }
 }
@@ -604,11 +692,11 @@ WgradShape wgrad_shape(const vsa_mlp_plan& p) {
 // for small ones (every workgroup writes a full set of partial blocks that mlp_reduce then has to
 // read: 512 workgroups on a 10 k-point batch made the reduction the most expensive kernel of the
 // step)
-int wgrad_total_wgs(const vsa_mlp_plan& p, long long nr_points, int nr_cus) {
+int wgrad_total_wgs(const vsa_mlp_plan& p, long long nr_points, int nr_cus, int nr_groups = 1) {
   long long n = nr_points / 128;
-  if (n < p.n_layers) n = p.n_layers;
-  const long long cap = (long long)wgrad_shape(p).wgs * nr_cus;
+  long long cap = (long long)wgrad_shape(p).wgs * nr_cus / nr_groups;
   if (n > cap) n = cap;
+  if (n < p.n_layers) n = p.n_layers;
   return (int)n;
 }
 
@@ -710,30 +798,151 @@ extern "C" int vsa_mlp_workspace(const vsa_mlp_plan* plan, long long nr_points,
   return VSA_OK;
 }
 
-extern "C" int vsa_mlp_fwd(const vsa_mlp_plan* plan, const float* x, int x_stride, int nr_points,
-                           float* y, int y_stride, float* z_ws, float* packed_ws, void* stream) {
-  int rc = plan_ok(plan);
+namespace {
+
+// shared-architecture check + the group descriptor of a launch
+int make_groups(const vsa_mlp_plan* plans, int nr_groups, const int* nr_points, MlpGroups* gp,
+                long long* total_rows, int* max_rows) {
+  if (!plans || !nr_points || nr_groups < 1 || nr_groups > MLP_MAX_GROUPS) return VSA_ERR_ARG;
+  int rc = plan_ok(&plans[0]);
   if (rc) return rc;
-  if (nr_points < 0 || x_stride < plan->dims[0] || y_stride < plan->dims[plan->n_layers])
-    return VSA_ERR_ARG;
-  if (nr_points == 0) return VSA_OK;
+  long long row = 0;
+  int mx = 0;
+  for (int g = 0; g < MLP_MAX_GROUPS; ++g) {
+    const int src = g < nr_groups ? g : 0;
+    if (g < nr_groups) {
+      rc = plan_ok(&plans[g]);
+      if (rc) return rc;
+      if (plans[g].n_layers != plans[0].n_layers) return VSA_ERR_ARG;
+      for (int l = 0; l <= plans[0].n_layers; ++l)
+        if (plans[g].dims[l] != plans[0].dims[l]) return VSA_ERR_ARG;
+      if (nr_points[g] < 0) return VSA_ERR_ARG;
+    }
+    gp->M[g] = g < nr_groups ? nr_points[g] : 0;
+    gp->row0[g] = row;
+    for (int l = 0; l < VSA_MLP_MAX_LAYERS; ++l) {
+      gp->w[g][l] = l < plans[src].n_layers ? plans[src].w[l] : nullptr;
+      gp->b[g][l] = l < plans[src].n_layers ? plans[src].b[l] : nullptr;
+    }
+    if (g < nr_groups) {
+      row += nr_points[g];
+      mx = nr_points[g] > mx ? nr_points[g] : mx;
+    }
+  }
+  *total_rows = row;
+  *max_rows = mx;
+  return VSA_OK;
+}
+
+long long hidden_width(const vsa_mlp_plan& p) {
+  long long h = 0;
+  for (int l = 1; l < p.n_layers; ++l) h += p.dims[l];
+  return h;
+}
+
+}  // namespace
+
+extern "C" int vsa_mlp_fwd_grouped(const vsa_mlp_plan* plans, int nr_groups, const int* nr_points,
+                                   const float* x, int x_stride, float* y, int y_stride, float* z_ws,
+                                   float* packed_ws, void* stream) {
+  MlpGroups gp;
+  long long rows = 0;
+  int mx = 0;
+  int rc = make_groups(plans, nr_groups, nr_points, &gp, &rows, &mx);
+  if (rc) return rc;
+  const vsa_mlp_plan* plan = &plans[0];
+  if (x_stride < plan->dims[0] || y_stride < plan->dims[plan->n_layers]) return VSA_ERR_ARG;
+  if (rows == 0) return VSA_OK;
   if (!x || !y || !packed_ws) return VSA_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(mlp_pack_kernel, dim3(16, plan->n_layers), dim3(256), 0, st, *plan, packed_ws,
-                     (float*)nullptr);
+  const long long packed_stride = pack_offsets(*plan).fwd[plan->n_layers];
+  hipLaunchKernelGGL(mlp_pack_kernel, dim3(16, plan->n_layers, nr_groups), dim3(256), 0, st, *plan, gp,
+                     packed_stride, packed_ws, (float*)nullptr);
   int nr_cus = 0;
   rc = vsa_cu_count(&nr_cus);
   if (rc) return rc;
   rc = set_lds_attrs();
   if (rc) return rc;
-  const size_t all = (size_t)pack_offsets(*plan).fwd[plan->n_layers] * sizeof(float);
+  const size_t all = (size_t)packed_stride * sizeof(float);
   const bool resident = all <= MLP_RESIDENT_BYTES;
   const size_t lds = resident ? all : max_layer_bytes(*plan);
-  const int ntiles = vsa_div_up(nr_points, MLP_TILE);
+  const int ntiles = vsa_div_up(mx, MLP_TILE);
   int grid = vsa_div_up(ntiles, 4);
-  if (grid > 2 * nr_cus) grid = 2 * nr_cus;
-  VSA_MLP_DISPATCH(mlp_fwd_kernel, resident, max_blocks(*plan), dim3(grid), dim3(MLP_BLOCK), lds, st, *plan,
-                   packed_ws, x, x_stride, nr_points, y, y_stride, z_ws);
+  const int cap = vsa_div_up(2 * nr_cus, nr_groups);          // two workgroups per CU over all groups
+  if (grid > cap) grid = cap;
+  VSA_MLP_DISPATCH(mlp_fwd_kernel, resident, max_blocks(*plan), dim3(grid, nr_groups), dim3(MLP_BLOCK), lds, st,
+                   *plan, gp, packed_stride, hidden_width(*plan), packed_ws, x, x_stride, y, y_stride, z_ws);
+  VSA_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int vsa_mlp_fwd(const vsa_mlp_plan* plan, const float* x, int x_stride, int nr_points,
+                           float* y, int y_stride, float* z_ws, float* packed_ws, void* stream) {
+  return vsa_mlp_fwd_grouped(plan, 1, &nr_points, x, x_stride, y, y_stride, z_ws, packed_ws, stream);
+}
+
+extern "C" int vsa_mlp_bwd_grouped(const vsa_mlp_plan* plans, int nr_groups, const int* nr_points,
+                                   const float* x, int x_stride, const float* dy, int dy_stride,
+                                   const float* z_ws, float* dz_ws, float* a_ws, float* packed_ws,
+                                   float* partial_ws, float* dx, int dx_stride,
+                                   const vsa_mlp_grads* grads, void* stream) {
+  MlpGroups gp;
+  long long rows = 0;
+  int mx = 0;
+  int rc = make_groups(plans, nr_groups, nr_points, &gp, &rows, &mx);
+  if (rc) return rc;
+  const vsa_mlp_plan* plan = &plans[0];
+  const int L = plan->n_layers;
+  if (x_stride < plan->dims[0] || dy_stride < plan->dims[L] || (dx && dx_stride < plan->dims[0]))
+    return VSA_ERR_ARG;
+  if (!grads) return VSA_ERR_ARG;
+  if (rows == 0) return VSA_OK;
+  if (!x || !dy || !packed_ws || !partial_ws || (L > 1 && (!z_ws || !dz_ws || !a_ws)))
+    return VSA_ERR_ARG;
+  MlpGroupGrads gg;
+  gg.accumulate = grads[0].accumulate;
+  for (int g = 0; g < MLP_MAX_GROUPS; ++g)
+    for (int l = 0; l < VSA_MLP_MAX_LAYERS; ++l) {
+      gg.dw[g][l] = g < nr_groups ? grads[g].dw[l] : nullptr;
+      gg.db[g][l] = g < nr_groups ? grads[g].db[l] : nullptr;
+    }
+  for (int g = 1; g < nr_groups; ++g)
+    if ((grads[g].accumulate != 0) != (gg.accumulate != 0)) return VSA_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const long long packed_stride = pack_offsets(*plan).fwd[L];
+  const long long hidden = hidden_width(*plan);
+  hipLaunchKernelGGL(mlp_pack_kernel, dim3(16, L, nr_groups), dim3(256), 0, st, *plan, gp, packed_stride,
+                     (float*)nullptr, packed_ws);
+  int nr_cus = 0;
+  rc = vsa_cu_count(&nr_cus);
+  if (rc) return rc;
+  rc = set_lds_attrs();
+  if (rc) return rc;
+  const size_t all = (size_t)packed_stride * sizeof(float);
+  const bool resident = all <= MLP_RESIDENT_BYTES;
+  const size_t lds = resident ? all : max_layer_bytes(*plan);
+  const int ntiles = vsa_div_up(mx, MLP_TILE);
+  int grid = vsa_div_up(ntiles, 4);
+  const int cap = vsa_div_up(2 * nr_cus, nr_groups);
+  if (grid > cap) grid = cap;
+  if (L > 1 || dx)
+    VSA_MLP_DISPATCH(mlp_dgrad_kernel, resident, max_blocks(*plan), dim3(grid, nr_groups), dim3(MLP_BLOCK), lds, st,
+                     *plan, gp, packed_stride, hidden, packed_ws, dy, dy_stride, z_ws, dz_ws, a_ws, dx, dx_stride);
+  // the weight-gradient workgroups of ONE group (every group gets the same split; the co-resident
+  // budget is shared between the groups)
+  const WgradLayers wl = wgrad_layers(*plan, wgrad_total_wgs(*plan, mx, nr_cus, nr_groups));
+  const long long partial_stride = wl.part_off[L];
+  const WgradShape ws = wgrad_shape(*plan);
+  const size_t wg_lds = (size_t)WG_TP * (wg_stride(32 * ws.nb) * 2) * sizeof(float);   // 24 KiB (64 / 96 wide) .. 40 KiB (128)
+#define VSA_WGRAD_LAUNCH(NB_, Q_, PF_, WGS_)                                                              \
+  hipLaunchKernelGGL((mlp_wgrad_kernel<NB_, Q_, PF_, WGS_>), dim3(wl.wg_begin[L], nr_groups), dim3(MLP_BLOCK), \
+                     wg_lds, st, *plan, wl, gp, hidden, partial_stride, x, x_stride, dy, dy_stride, dz_ws, a_ws, \
+                     partial_ws)
+  if (ws.nb == 2) VSA_WGRAD_LAUNCH(2, 1, MLP_WG_SMALL_PF, MLP_WG_SMALL_WGS);
+  else if (ws.nb == 3) VSA_WGRAD_LAUNCH(3, 2, MLP_WG_SMALL_PF, MLP_WG_SMALL_WGS);
+  else VSA_WGRAD_LAUNCH(4, 4, 1, 3);
+#undef VSA_WGRAD_LAUNCH
+  hipLaunchKernelGGL(mlp_reduce_kernel, dim3(68, L, nr_groups), dim3(256), 0, st, *plan, wl, partial_stride,
+                     partial_ws, gg);   // 68 x 256 >= one thread per element of a 128 x 128 (+bias) layer
   VSA_RETURN_LAUNCH_STATUS();
 }
 
@@ -741,43 +950,6 @@ extern "C" int vsa_mlp_bwd(const vsa_mlp_plan* plan, const float* x, int x_strid
                            const float* dy, int dy_stride, const float* z_ws, float* dz_ws,
                            float* a_ws, float* packed_ws, float* partial_ws, float* dx,
                            int dx_stride, const vsa_mlp_grads* grads, void* stream) {
-  int rc = plan_ok(plan);
-  if (rc) return rc;
-  const int L = plan->n_layers;
-  if (nr_points < 0 || x_stride < plan->dims[0] || dy_stride < plan->dims[L] ||
-      (dx && dx_stride < plan->dims[0]))
-    return VSA_ERR_ARG;
-  if (!grads) return VSA_ERR_ARG;
-  if (nr_points == 0) return VSA_OK;
-  if (!x || !dy || !packed_ws || !partial_ws || (L > 1 && (!z_ws || !dz_ws || !a_ws)))
-    return VSA_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(mlp_pack_kernel, dim3(16, L), dim3(256), 0, st, *plan, (float*)nullptr, packed_ws);
-  int nr_cus = 0;
-  rc = vsa_cu_count(&nr_cus);
-  if (rc) return rc;
-  rc = set_lds_attrs();
-  if (rc) return rc;
-  const size_t all = (size_t)pack_offsets(*plan).fwd[L] * sizeof(float);
-  const bool resident = all <= MLP_RESIDENT_BYTES;
-  const size_t lds = resident ? all : max_layer_bytes(*plan);
-  const int ntiles = vsa_div_up(nr_points, MLP_TILE);
-  int grid = vsa_div_up(ntiles, 4);
-  if (grid > 2 * nr_cus) grid = 2 * nr_cus;
-  if (L > 1 || dx) {
-    VSA_MLP_DISPATCH(mlp_dgrad_kernel, resident, max_blocks(*plan), dim3(grid), dim3(MLP_BLOCK), lds, st,
-                     *plan, packed_ws, dy, dy_stride, nr_points, z_ws, dz_ws, a_ws, dx, dx_stride);
-  }
-  const WgradLayers wl = wgrad_layers(*plan, wgrad_total_wgs(*plan, nr_points, nr_cus));
-  const WgradShape ws = wgrad_shape(*plan);
-  const size_t wg_lds = (size_t)WG_TP * (wg_stride(32 * ws.nb) * 2) * sizeof(float);   // 24 KiB (64 / 96 wide) .. 40 KiB (128)
-#define VSA_WGRAD_LAUNCH(NB_, Q_, PF_, WGS_)                                                              \
-  hipLaunchKernelGGL((mlp_wgrad_kernel<NB_, Q_, PF_, WGS_>), dim3(wl.wg_begin[L]), dim3(MLP_BLOCK), wg_lds, st, \
-                     *plan, wl, x, x_stride, dy, dy_stride, nr_points, dz_ws, a_ws, partial_ws)
-  if (ws.nb == 2) VSA_WGRAD_LAUNCH(2, 1, MLP_WG_SMALL_PF, MLP_WG_SMALL_WGS);
-  else if (ws.nb == 3) VSA_WGRAD_LAUNCH(3, 2, MLP_WG_SMALL_PF, MLP_WG_SMALL_WGS);
-  else VSA_WGRAD_LAUNCH(4, 4, 1, 3);
-#undef VSA_WGRAD_LAUNCH
-  hipLaunchKernelGGL(mlp_reduce_kernel, dim3(68, L), dim3(256), 0, st, *plan, wl, partial_ws, *grads);   // 68 x 256 >= one thread per element of a 128 x 128 (+bias) layer
-  VSA_RETURN_LAUNCH_STATUS();
+  return vsa_mlp_bwd_grouped(plan, 1, &nr_points, x, x_stride, dy, dy_stride, z_ws, dz_ws, a_ws, packed_ws,
+                             partial_ws, dx, dx_stride, grads, stream);
 }

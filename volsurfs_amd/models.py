@@ -117,8 +117,10 @@ class _FusedMLP(torch.autograd.Function):
                              device=dev)
         partial = torch.empty(max(part_n, 1), device=dev)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        gw = [torch.empty_like(w) for w in ws]
-        gb = [torch.empty_like(b) if b is not None else None for b in bs]
+        # (an empty batch: the entry point returns without a launch — the gradients are zero)
+        alloc = torch.zeros_like if M == 0 else torch.empty_like
+        gw = [alloc(w) for w in ws]
+        gb = [alloc(b) if b is not None else None for b in bs]
         grads = MlpGrads()
         for l in range(nl):
             grads.dw[l] = gw[l].data_ptr()
@@ -143,12 +145,26 @@ def _direct_grads(params):
     return got if all(g is not None for g in got) else None
 
 
+MLP_MAX_GROUPS = 8
+
+
 class _FusedMLPGrouped(torch.autograd.Function):
     """G MLPs of ONE architecture (the per-shell models of the legacy appearance branch) applied to
-    G consecutive row segments of x in one autograd node: the C entry points are called per group on
-    slices, so the kernels are the single-model ones, but torch sees one op instead of G x (apply +
-    allocations + saved tensors) — the training loop of BASELINE configs[2] is bound by the host's
-    op dispatch, not by the GPU.  params = group-major (w_0, b_0, w_1, b_1, ...) per group."""
+    G consecutive row segments of x: one autograd node and ONE set of launches for up to 8 groups
+    (`vsa_mlp_fwd_grouped` / `vsa_mlp_bwd_grouped`: group = blockIdx.y) — launched one by one the
+    networks fill a third of the chip each (~80 workgroups for the 10 k hits of a shell) and cost five
+    times the host calls; the training loop of BASELINE configs[2] is bound by both.
+    params = group-major (w_0, b_0, w_1, b_1, ...) per group."""
+
+    @staticmethod
+    def _batches(sizes):
+        """[(first group, nr groups, first row, rows)] in runs of at most MLP_MAX_GROUPS groups."""
+        out, a = [], 0
+        for g0 in range(0, len(sizes), MLP_MAX_GROUPS):
+            n = sum(sizes[g0:g0 + MLP_MAX_GROUPS])
+            out.append((g0, min(MLP_MAX_GROUPS, len(sizes) - g0), a, n))
+            a += n
+        return out
 
     @staticmethod
     def forward(ctx, x, sizes, has_bias, nl, *params):
@@ -169,14 +185,14 @@ class _FusedMLPGrouped(torch.autograd.Function):
         M = x.shape[0]
         y = torch.empty(M, out_dim, device=dev)
         z = torch.empty(max(M * hidden, 1), device=dev) if need else None
-        packed = torch.empty(max(packed_n, 1), device=dev)
-        a = 0
-        for g, n in enumerate(sizes):
-            if n:
-                plan = _mlp_plan(*groups[g])
-                _lib.call("vsa_mlp_fwd", ctypes.byref(plan), x[a:a + n], x.shape[1], n, y[a:a + n], out_dim,
-                          z[a * hidden:] if z is not None else None, packed, _lib.stream_ptr())
-            a += n
+        packed = torch.empty(max(packed_n, 1) * min(G, MLP_MAX_GROUPS), device=dev)
+        for g0, ng, a, n in _FusedMLPGrouped._batches(sizes):
+            if n == 0:
+                continue
+            plans = (MlpPlan * ng)(*[_mlp_plan(*groups[g0 + i]) for i in range(ng)])
+            cnt = (ctypes.c_int * ng)(*sizes[g0:g0 + ng])
+            _lib.call("vsa_mlp_fwd_grouped", plans, ng, cnt, x[a:a + n], x.shape[1], y[a:a + n], out_dim,
+                      z[a * hidden:] if z is not None else None, packed, _lib.stream_ptr())
         ctx.save_for_backward(x, z, *[t for ws, bs in groups for t in ws + [b for b in bs if b is not None]])
         ctx.meta = (tuple(sizes), has_bias, nl, hidden, packed_n)
         ctx.param_objs = params        # the Parameter objects themselves: backward may add into their .grad
@@ -188,58 +204,60 @@ class _FusedMLPGrouped(torch.autograd.Function):
         x, z = ctx.saved_tensors[:2]
         flat = list(ctx.saved_tensors[2:])
         per = nl * (2 if has_bias else 1)
+        G = len(sizes)
         dev = x.device
         gy = gy.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         nmax = max(sizes) if sizes else 0
-        dz = torch.empty(max(nmax * hidden, 1), device=dev)
-        av = torch.empty(max(nmax * hidden, 1), device=dev)
-        packed = torch.empty(max(packed_n, 1), device=dev)
-        partial = None
-        grads_out = []
-        a = 0
-        for g, n in enumerate(sizes):
+        dz = torch.empty(max(x.shape[0] * hidden, 1), device=dev)
+        av = torch.empty(max(x.shape[0] * hidden, 1), device=dev)
+        packed = torch.empty(max(packed_n, 1) * min(G, MLP_MAX_GROUPS), device=dev)
+        # parameters that own a persistent .grad (FusedAdam): the reduce kernel adds straight into it
+        # and autograd gets None — one accumulation kernel per parameter less (80 per step).  One
+        # setting for the whole launch: every parameter of every group has to qualify.
+        direct = _direct_grads(list(ctx.param_objs))
+        per_group = []
+        for g in range(G):
             ps = flat[g * per:(g + 1) * per]
             ws, bs = ps[:nl], (ps[nl:] if has_bias else [None] * nl)
-            # parameters that own a persistent .grad (FusedAdam): the reduce kernel adds straight into
-            # it and autograd gets None — one accumulation kernel per parameter less (80 per step)
-            objs = ctx.param_objs[g * per:(g + 1) * per]
-            pw = [objs[2 * l] if has_bias else objs[l] for l in range(nl)]
-            pb = [objs[2 * l + 1] if has_bias else None for l in range(nl)]
-            direct = _direct_grads(pw + [b for b in pb if b is not None])
             if direct is not None:
-                if n == 0:
-                    for l in range(nl):
-                        grads_out.append(None)
-                        if has_bias:
-                            grads_out.append(None)
-                    a += n
-                    continue
-                gw = [p_.grad for p_ in pw]
-                gb = [None if b is None else b.grad for b in pb]
+                objs = ctx.param_objs[g * per:(g + 1) * per]
+                gw = [(objs[2 * l] if has_bias else objs[l]).grad for l in range(nl)]
+                gb = [objs[2 * l + 1].grad if has_bias else None for l in range(nl)]
             else:
-                gw = [torch.zeros_like(w) if n == 0 else torch.empty_like(w) for w in ws]
-                gb = [None if b is None else (torch.zeros_like(b) if n == 0 else torch.empty_like(b)) for b in bs]
-            if n:
-                plan = _mlp_plan(ws, bs)
-                if partial is None:
-                    sz = ctypes.c_longlong()
-                    _lib.call("vsa_mlp_workspace", ctypes.byref(plan), ctypes.c_longlong(nmax), None, None,
-                              ctypes.byref(sz))
-                    partial = torch.empty(max(sz.value, 1), device=dev)
-                grads = MlpGrads()
-                grads.accumulate = 1 if direct is not None else 0
+                gw = [torch.empty_like(w) for w in ws]
+                gb = [None if b is None else torch.empty_like(b) for b in bs]
+            per_group.append((ws, bs, gw, gb))
+        partial = None
+        for g0, ng, a, n in _FusedMLPGrouped._batches(sizes):
+            if n == 0:
+                if direct is None:
+                    for ws, bs, gw, gb in per_group[g0:g0 + ng]:
+                        for t in gw + [b for b in gb if b is not None]:
+                            t.zero_()
+                continue
+            plans = (MlpPlan * ng)(*[_mlp_plan(ws, bs) for ws, bs, _, _ in per_group[g0:g0 + ng]])
+            cnt = (ctypes.c_int * ng)(*sizes[g0:g0 + ng])
+            if partial is None:
+                sz = ctypes.c_longlong()
+                _lib.call("vsa_mlp_workspace", ctypes.byref(plans[0]), ctypes.c_longlong(nmax), None, None,
+                          ctypes.byref(sz))
+                partial = torch.empty(max(sz.value, 1) * min(G, MLP_MAX_GROUPS), device=dev)
+            grads = (MlpGrads * ng)()
+            for i, (_, _, gw, gb) in enumerate(per_group[g0:g0 + ng]):
+                grads[i].accumulate = 1 if direct is not None else 0
                 for l in range(nl):
-                    grads.dw[l] = gw[l].data_ptr()
-                    grads.db[l] = gb[l].data_ptr() if gb[l] is not None else None
-                _lib.call("vsa_mlp_bwd", ctypes.byref(plan), x[a:a + n], x.shape[1], n, gy[a:a + n], gy.shape[1],
-                          z[a * hidden:], dz, av, packed, partial, dx[a:a + n] if dx is not None else None,
-                          x.shape[1], ctypes.byref(grads), _lib.stream_ptr())
+                    grads[i].dw[l] = gw[l].data_ptr()
+                    grads[i].db[l] = gb[l].data_ptr() if gb[l] is not None else None
+            _lib.call("vsa_mlp_bwd_grouped", plans, ng, cnt, x[a:a + n], x.shape[1], gy[a:a + n], gy.shape[1],
+                      z[a * hidden:], dz[a * hidden:], av[a * hidden:], packed, partial,
+                      dx[a:a + n] if dx is not None else None, x.shape[1], grads, _lib.stream_ptr())
+        grads_out = []
+        for _, _, gw, gb in per_group:
             for l in range(nl):
                 grads_out.append(None if direct is not None else gw[l])
                 if has_bias:
                     grads_out.append(None if direct is not None else gb[l])
-            a += n
         return (dx, None, None, None, *grads_out)
 
 
