@@ -115,6 +115,18 @@ class HashGrid(torch.nn.Module):
         return _GridEncode.apply(self.params, x.float(), self.plan, self.params, append_points)
 
 
+def _inv_half_sides(enc):
+    """1 / (bb_sides / 2) of an encoder, formed once (two launches per call otherwise — the training
+    loop of the per-shell models is bound by the host's op dispatch); same tensor ops, same values."""
+    bb = enc.bb_sides
+    key = (bb.data_ptr(), bb._version)
+    memo = getattr(enc, "_inv_half_memo", None)
+    if memo is None or memo[0] != key:
+        memo = (key, 1 / (bb / 2))
+        enc._inv_half_memo = memo
+    return memo[1]
+
+
 class Encoder(torch.nn.Module):
     # hash encoders return (features, points_out_of_bounds) like the reference's; the models that own
     # them (RGB / ColorSH / NerfHash, here as there) use only the features and switch the mask off
@@ -179,8 +191,12 @@ class Coarse2Fine:
         if self._memo[0] != t:           # (t is constant for whole phases of training: 1.0 once c2f is over)
             alpha = t * self.nr_levels
             i = torch.arange(self.nr_levels, dtype=torch.float32)
-            self._memo = (t, 0.5 * (1.0 - torch.cos(math.pi * torch.clamp(alpha - i, 0.0, 1.0))))
+            w = 0.5 * (1.0 - torch.cos(math.pi * torch.clamp(alpha - i, 0.0, 1.0)))
+            self._memo = (t, w)
+            self.all_open = bool((w == 1.0).all())
         return self._memo[1]
+
+    all_open = False                     # the last window returned is all ones (a no-op)
 
 
 def map_range_val(input_val, input_start, input_end, output_start, output_end):
@@ -225,7 +241,7 @@ class GridHashEncoder(Encoder):
         else:
             t = map_range_val(iter_nr, 0.0, self.nr_iters_for_c2f, 0.3, 1.0)
         window = self.c2f(t)
-        all_open = bool((window == 1.0).all())        # t = 1 (evaluation, c2f off): the window is a no-op
+        all_open = self.c2f.all_open                  # t = 1 (evaluation, c2f off): the window is a no-op
         if not all_open:                              # (no host-to-device copy otherwise)
             window = window.to(points.device).repeat_interleave(self.config["n_features_per_level"])
         out_of_bounds = None
@@ -233,7 +249,7 @@ class GridHashEncoder(Encoder):
             if self.compute_out_of_bounds:
                 out_of_bounds = torch.logical_or((points <= -self.bb_sides / 2).any(dim=1),
                                                  (points >= self.bb_sides / 2).any(dim=1))
-            points = points * (1 / (self.bb_sides / 2))
+            points = points * _inv_half_sides(self)
             points = (points + 1) / 2
         if all_open and self.concat_points and GridHashEncoder.fused_concat and points.is_cuda \
                 and not points.requires_grad:
@@ -292,6 +308,91 @@ class _PermutoEncode(torch.autograd.Function):
         _lib.call("vsa_permuto_encode_bwd", ctypes.byref(ctx.plan), x, window, g_out,
                   g_out.shape[1], x.shape[0], g_values, _lib.stream_ptr())
         return (None if direct is not None else g_values), None, None, None, None   # positions: no gradient here
+
+
+class _PermutoEncodeGrouped(torch.autograd.Function):
+    """G encodings of one geometry (the per-shell models' position encoders) on G consecutive row
+    segments of x as ONE autograd node writing one output matrix: the C entry points are the
+    single-encoding ones, called per group on row slices, but torch sees one op instead of G x
+    (apply, output allocation, point columns, slice and cat bookkeeping forward and backward)."""
+
+    @staticmethod
+    def forward(ctx, x, sizes, window, extra, encs, *values):
+        plan0 = encs[0].plan
+        x = _lib.check_f32(x.contiguous(), x.shape[0], plan0.pos_dim)
+        width = 2 * plan0.n_levels + extra
+        stride = width + (width & 1)                  # float2 stores: even row stride
+        buf = torch.empty(x.shape[0], stride, device=x.device)
+        a = 0
+        for enc, v, n in zip(encs, values, sizes):
+            if n:
+                _lib.call("vsa_permuto_encode_fwd", ctypes.byref(enc.plan), v, x[a:a + n], window, n, buf[a:a + n],
+                          stride, _lib.stream_ptr())
+            a += n
+        if extra:                       # concatenated points (no gradient path: hit points)
+            buf[:, 2 * plan0.n_levels:width] = x * encs[0].concat_points_scaling
+        ctx.save_for_backward(x, window)
+        ctx.encs, ctx.sizes = encs, sizes
+        return buf[:, :width]
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x, window = ctx.saved_tensors
+        from .optim import accumulate_into_grad
+        g_out = g_out.contiguous()
+        grads, a = [], 0
+        for enc, n in zip(ctx.encs, ctx.sizes):
+            direct = accumulate_into_grad(enc.lattice_values)
+            g_values = direct if direct is not None else torch.zeros_like(enc.lattice_values)
+            if n:
+                _lib.call("vsa_permuto_encode_bwd", ctypes.byref(enc.plan), x[a:a + n], window, g_out[a:a + n],
+                          g_out.shape[1], n, g_values, _lib.stream_ptr())
+            grads.append(None if direct is not None else g_values)
+            a += n
+        return (None, None, None, None, None, *grads)      # positions: no gradient here
+
+
+def permuto_hash_encoders_groupable(encs, points):
+    """PermutoHashEncoders of one configuration (what `get_encoder("permutohash", ...)` gives every
+    per-shell model) on CUDA points without a gradient path."""
+    e0 = encs[0]
+    if not all(isinstance(e, PermutoHashEncoder) for e in encs) or not points.is_cuda or points.requires_grad:
+        return False
+
+    def sig(e):
+        got = getattr(e, "_group_sig", None)
+        if got is None:               # formed once per encoder (the bounding box is a device read)
+            bb = None if e.bb_sides is None else tuple(e.bb_sides.tolist())
+            got = e._group_sig = (e.nr_levels, e.capacity, tuple(np.asarray(e.scale_list).tolist()),
+                                  e.concat_points, e.concat_points_scaling, e.remove_last_element,
+                                  e.nr_iters_for_c2f, e.encoder.pos_dim, bb)
+        return got
+    s0 = sig(e0)
+    return all(sig(e) == s0 for e in encs[1:])
+
+
+def permuto_hash_encode_grouped(encs, points, sizes, iter_nr=None):
+    """[sum(sizes), output_dim]: rows of segment g through encs[g] — PermutoHashEncoder.forward's
+    arithmetic (window, bounding-box normalisation, concatenated points, last channel dropped) done
+    once for all segments, the lattice lookups per segment.  out_of_bounds is not computed (the
+    per-shell models do not use it)."""
+    e0 = encs[0]
+    if iter_nr is None or iter_nr < 0:
+        t = 1.0
+    else:
+        t = map_range_val(iter_nr, 0.0, e0.nr_iters_for_c2f, 0.3, 1.0)
+    window = e0.c2f(t)
+    window = None if e0.c2f.all_open else window.view(-1).to(points.device, torch.float32).contiguous()
+    if e0.bb_sides is not None:
+        points = points * _inv_half_sides(e0)
+        points = (points + 1) / 2
+    extra = e0.encoder.pos_dim if e0.concat_points else 0
+    inner = tuple(e.encoder for e in encs)
+    enc = _PermutoEncodeGrouped.apply(points.float(), tuple(int(n) for n in sizes), window, extra, inner,
+                                      *[e.lattice_values for e in inner])
+    if e0.remove_last_element:
+        enc = enc[:, :-1]
+    return enc
 
 
 class PermutoEncoding(torch.nn.Module):
@@ -395,13 +496,13 @@ class PermutoHashEncoder(Encoder):
         window = self.c2f(t)
         # t = 1 (evaluation, c2f off): all ones — the kernel takes NULL for that, which also spares
         # a host-to-device copy (an implicit synchronisation) per model and forward
-        window = None if bool((window == 1.0).all()) else window.view(-1)
+        window = None if self.c2f.all_open else window.view(-1)
         out_of_bounds = None
         if self.bb_sides is not None:
             if self.compute_out_of_bounds:
                 out_of_bounds = torch.logical_or((points <= -self.bb_sides / 2).any(dim=1),
                                                  (points >= self.bb_sides / 2).any(dim=1))
-            points = points * (1 / (self.bb_sides / 2))
+            points = points * _inv_half_sides(self)
             points = (points + 1) / 2
         enc = self.encoder(points, window)
         if self.remove_last_element:

@@ -223,6 +223,7 @@ class VolSurfs(torch.nn.Module):
         """The same arithmetic as the per-shell loop with the hits of ALL shells prepared at once and
         each model type evaluated as one grouped op (models._FusedMLPGrouped): ~80 torch ops per
         call instead of ~350 — the legacy training loop is bound by the host's op dispatch."""
+        from .encodings import permuto_hash_encode_grouped, permuto_hash_encoders_groupable
         from .models import fused_mlp_grouped
         N, K = rays_o.shape[0], self.nr_meshes
         dev = rays_o.device
@@ -259,13 +260,18 @@ class VolSurfs(torch.nn.Module):
             else:
                 mods, sizes = [self.models[typ]], [M - a0]
             m0 = mods[0]
-            encs, a = [], a0
-            for mod, n in zip(mods, sizes):
-                if n:
-                    f = mod.pos_encoder(pts[a:a + n], iter_nr=iter_nr)
-                    encs.append(f[0] if isinstance(f, tuple) else f)
-                a += n
-            parts = [torch.cat(encs, 0) if len(encs) > 1 else encs[0]]
+            pos_encs = [mod.pos_encoder for mod in mods]
+            if VolSurfs.legacy_grouped_encode and len(mods) > 1 and permuto_hash_encoders_groupable(pos_encs, pts):
+                # one autograd node for all shells' position encodings (encodings._PermutoEncodeGrouped)
+                parts = [permuto_hash_encode_grouped(pos_encs, pts[a0:], sizes, iter_nr=iter_nr)]
+            else:
+                encs, a = [], a0
+                for mod, n in zip(mods, sizes):
+                    if n:
+                        f = mod.pos_encoder(pts[a:a + n], iter_nr=iter_nr)
+                        encs.append(f[0] if isinstance(f, tuple) else f)
+                    a += n
+                parts = [torch.cat(encs, 0) if len(encs) > 1 else encs[0]]
             if m0.view_dep:
                 with torch.no_grad():
                     parts.append(m0.dir_encoder(d[a0:], iter_nr=iter_nr))
@@ -337,6 +343,7 @@ class VolSurfs(torch.nn.Module):
             surfs_normals = surfs_normals.index_put((rows, col), nrm)
         return surfs_rgb, surfs_alpha, surfs_normals
 
+    legacy_grouped_encode = __import__("os").environ.get("VSA_GROUPED_ENCODE", "1") != "0"   # A/B switch
     look_ahead = True      # trainer.train_step_from_reel queues the next batch's traversal a step ahead (legacy models)
 
     class _TraceAhead:
