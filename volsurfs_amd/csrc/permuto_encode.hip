@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256) void permuto_bwd_kernel(vsa_permuto_plan plan,
 // per-shell model sees in the training loop of BASELINE configs[2]: levels 0-7 take 134 of its
 // 172 us, levels 12-23 together 19 us): thousands of points share the few hundred lattice
 // vertices a coarse level has on the surface, and device-scope float atomics on one address are
-// serialised at the memory side.  Here a workgroup owns (level, chunk of PL_CHUNK points): it adds
+// serialised at the memory side.  Here a workgroup owns (level, chunk of PL_CHUNK points: 1 024 —
+// with 4 096 the ten levels of a 10 k-point batch were 30 workgroups, the slowest 51 us): it adds
 // the chunk's contributions into an open-addressing table in LDS (keys claimed with ds_cmpst,
 // values 64-bit FIXED POINT as in grid_encode.hip: ds_add_u64 is ~16x faster than ds_add_f32 on
 // gfx950, and integer sums make the result independent of the order inside the chunk), and then
@@ -174,7 +175,10 @@ __global__ __launch_bounds__(256) void permuto_bwd_kernel(vsa_permuto_plan plan,
 constexpr int PL_THREADS = 512;
 constexpr int PL_SLOTS = 4096;            // keys 16 KiB + 2 x 32 KiB of accumulators
 constexpr int PL_PROBES = 16;
-constexpr int PL_CHUNK = 4096;            // points per workgroup
+#ifndef PL_CHUNK_POINTS
+#define PL_CHUNK_POINTS 1024
+#endif
+constexpr int PL_CHUNK = PL_CHUNK_POINTS;  // points per workgroup
 constexpr unsigned PL_EMPTY = 0xffffffffu;
 
 __device__ __forceinline__ unsigned long long pl_fixed62(float v) {      // as grid_encode.hip's fixed62
