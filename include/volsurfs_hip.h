@@ -465,6 +465,20 @@ int vsa_permuto_encode_bwd(const vsa_permuto_plan* plan, const float* x, const f
                            const float* g_out, int g_stride, int nr_points, float* grad_values,
                            void* stream);
 
+/* Up to 8 encodings of one geometry (the position encoders of the K per-shell models,
+ * volsurfs_py/methods/volsurfs.py:402-470) in one launch each way: group g owns the rows after the
+ * first g groups' in x / out / g_out.  plan_host: group 0's plan (levels, dimension, capacity are
+ * shared); plans_dev: the nr_groups plans in DEVICE memory (the per-level shifts may differ);
+ * lattice_values / grad_values: HOST arrays of nr_groups device pointers; nr_points: host [nr_groups]. */
+int vsa_permuto_encode_fwd_grouped(const vsa_permuto_plan* plan_host, const vsa_permuto_plan* plans_dev,
+                                   const float* const* lattice_values, int nr_groups,
+                                   const int* nr_points, const float* x, const float* window,
+                                   float* out, int out_stride, void* stream);
+int vsa_permuto_encode_bwd_grouped(const vsa_permuto_plan* plan_host, const vsa_permuto_plan* plans_dev,
+                                   int nr_groups, const int* nr_points, const float* x,
+                                   const float* window, const float* g_out, int g_stride,
+                                   float* const* grad_values, void* stream);
+
 /* ------------------------------------------------------------------------
  * A8 / A9 / A11  Packed (ragged) per-ray sample ops of the background path:
  * what render_contracted_bg (volsurfs_py/utils/background.py:31-141) calls in the

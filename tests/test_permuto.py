@@ -147,3 +147,46 @@ def test_hip_permuto_hash_encoder_reference_configuration():
     e2 = get_encoder("permutohash", input_dim=3, nr_levels=24, nr_iters_for_c2f=1000, bb_sides=2.0)
     e2.load_state_dict(e.state_dict())
     assert torch.equal(e2(pts.cuda())[0], e(pts.cuda())[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sizes", [[3000, 0, 4100, 700, 2500], [200] * 9 + [0, 33]])
+def test_hip_permuto_grouped_launch_equals_the_encoders_one_by_one(sizes):
+    """encodings.permuto_hash_encode_grouped (vsa_permuto_encode_fwd_grouped / _bwd_grouped: group =
+    blockIdx.z, plans from a device array; 11 groups = two launches) against PermutoHashEncoder.forward
+    per segment: features bit for bit, lattice gradients to 1e-5 of their scale (float atomics, and the
+    coarse levels' fixed-point tables, sum in a different order).  Every encoder has its own shift."""
+    from volsurfs_amd.encodings import get_encoder, permuto_hash_encode_grouped, permuto_hash_encoders_groupable
+    g = torch.Generator().manual_seed(4)
+    encs = []
+    for i in range(len(sizes)):
+        e = get_encoder("permutohash", input_dim=3, nr_levels=24, nr_iters_for_c2f=1000, bb_sides=2.0)
+        with torch.no_grad():
+            e.encoder.lattice_values.copy_(torch.randn(24, 1 << 18, 2, generator=g))
+            e.encoder.random_shift_per_level.copy_(torch.randn(24, 3, generator=g) * 10.0)
+        encs.append(e)
+    pts = ((torch.rand(sum(sizes), 3, generator=g) - 0.5) * 1.2).cuda()
+    gy = torch.randn(sum(sizes), 50, generator=g).cuda()
+    assert permuto_hash_encoders_groupable(encs, pts)
+    for it in (None, 300):
+        out = permuto_hash_encode_grouped(encs, pts, sizes, iter_nr=it)
+        out.backward(gy)
+        got = [e.encoder.lattice_values.grad.clone() for e in encs]
+        for e in encs:
+            e.encoder.lattice_values.grad = None
+        refs, a = [], 0
+        for e, n in zip(encs, sizes):
+            if n:
+                f, _ = e(pts[a:a + n], iter_nr=it)
+                f.backward(gy[a:a + n])
+                refs.append(f.detach())
+            a += n
+        assert torch.equal(out.detach(), torch.cat(refs, 0))
+        for e, n, ga in zip(encs, sizes, got):
+            gb = e.encoder.lattice_values.grad
+            if n == 0:
+                assert float(ga.abs().max()) == 0.0 and gb is None
+                continue
+            scale = float(gb.abs().max())
+            np.testing.assert_allclose(ga.cpu().numpy(), gb.cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
+            e.encoder.lattice_values.grad = None

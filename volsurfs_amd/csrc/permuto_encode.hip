@@ -109,15 +109,46 @@ __device__ __forceinline__ unsigned permuto_index(const Simplex<D>& s, int k, un
   return h % capacity;
 }
 
-template <int D>
-__global__ __launch_bounds__(256) void permuto_fwd_kernel(vsa_permuto_plan plan,
-                                                          const float2* __restrict__ values,
+// One launch covers up to PG_MAX encodings of one geometry (the position encoders of the K per-shell
+// models): group = blockIdx.z owns rows [row0, row0 + n) of x / out / g_out and its own lattice
+// values.  The per-level shifts may differ between the groups, so the DEV instances read their plan
+// from a device array (a plan is 1 KiB: eight do not fit the kernel arguments); the single-encoding
+// entry points keep the by-value plan.
+constexpr int PG_MAX = 8;
+struct PermutoGroups {
+  int n[PG_MAX];
+  long long row0[PG_MAX];
+  const float* values[PG_MAX];
+  float* grads[PG_MAX];
+};
+template <class T, int N>
+__device__ __forceinline__ T pg_pick(const T (&a)[N], int g) {      // no run-time index into kernel arguments
+  T r = a[0];
+#pragma unroll
+  for (int i = 1; i < N; ++i)
+    if (g == i) r = a[i];
+  return r;
+}
+
+template <int D, bool DEV>
+__global__ __launch_bounds__(256) void permuto_fwd_kernel(vsa_permuto_plan plan_val,
+                                                          const vsa_permuto_plan* __restrict__ plans_dev,
+                                                          PermutoGroups gp,
                                                           const float* __restrict__ x,
-                                                          const float* __restrict__ window, int B,
+                                                          const float* __restrict__ window,
                                                           float* __restrict__ out, int out_stride) {
+  const int grp = blockIdx.z;
+  const vsa_permuto_plan& plan = DEV ? plans_dev[grp] : plan_val;
+  const int B = pg_pick(gp.n, grp);
   const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
   const int l = blockIdx.y;
   if (b >= B) return;
+  {
+    const long long r0 = pg_pick(gp.row0, grp);
+    x += r0 * D;
+    out += r0 * out_stride;
+  }
+  const float2* values = reinterpret_cast<const float2*>(pg_pick(gp.values, grp));
   const Simplex<D> s = permuto_simplex<D>(plan, l, x + b * D);
   const float2* tab = values + (long long)l * plan.capacity;
   const float wl = window ? window[l] : 1.0f;
@@ -134,18 +165,28 @@ __global__ __launch_bounds__(256) void permuto_fwd_kernel(vsa_permuto_plan plan,
 
 // two lanes per (sample, level), one per feature: the two atomics of an entry leave the wave
 // as one request (as grid_encode_bwd)
-template <int D>
-__global__ __launch_bounds__(256) void permuto_bwd_kernel(vsa_permuto_plan plan,
+template <int D, bool DEV>
+__global__ __launch_bounds__(256) void permuto_bwd_kernel(vsa_permuto_plan plan_val,
+                                                          const vsa_permuto_plan* __restrict__ plans_dev,
+                                                          PermutoGroups gp,
                                                           const float* __restrict__ x,
                                                           const float* __restrict__ window,
                                                           const float* __restrict__ g_out,
-                                                          int g_stride, int B, int l0,
-                                                          float* __restrict__ g_values) {
+                                                          int g_stride, int l0) {
+  const int grp = blockIdx.z;
+  const vsa_permuto_plan& plan = DEV ? plans_dev[grp] : plan_val;
+  const int B = pg_pick(gp.n, grp);
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long b = t >> 1;
   const int f = (int)(t & 1);
   const int l = l0 + blockIdx.y;
   if (b >= B) return;
+  {
+    const long long r0 = pg_pick(gp.row0, grp);
+    x += r0 * D;
+    g_out += r0 * g_stride;
+  }
+  float* g_values = pg_pick(gp.grads, grp);
   const float wl = window ? window[l] : 1.0f;
   const float go = g_out[b * g_stride + 2 * l + f];
   if (go == 0.f || wl == 0.f) return;
@@ -188,18 +229,29 @@ __device__ __forceinline__ unsigned long long pl_fixed62(float v) {      // as g
   return ((unsigned long long)(unsigned)(int)hi << 32) + (unsigned long long)(unsigned)lo;
 }
 
-template <int D>
-__global__ __launch_bounds__(PL_THREADS) void permuto_bwd_lds_kernel(vsa_permuto_plan plan,
+template <int D, bool DEV>
+__global__ __launch_bounds__(PL_THREADS) void permuto_bwd_lds_kernel(vsa_permuto_plan plan_val,
+                                                                     const vsa_permuto_plan* __restrict__ plans_dev,
+                                                                     PermutoGroups gp,
                                                                      const float* __restrict__ x,
                                                                      const float* __restrict__ window,
                                                                      const float* __restrict__ g_out,
-                                                                     int g_stride, int B,
-                                                                     float* __restrict__ g_values) {
+                                                                     int g_stride) {
   __shared__ unsigned s_key[PL_SLOTS];
   __shared__ unsigned long long s_val[2 * PL_SLOTS];
   __shared__ float s_max[PL_THREADS / 64];
+  const int grp = blockIdx.z;
+  const vsa_permuto_plan& plan = DEV ? plans_dev[grp] : plan_val;
+  const int B = pg_pick(gp.n, grp);
   const int l = blockIdx.y;
   const long long p0 = (long long)blockIdx.x * PL_CHUNK;
+  if (p0 >= B) return;                        // uniform: this group has fewer chunks than the largest
+  {
+    const long long r0 = pg_pick(gp.row0, grp);
+    x += r0 * D;
+    g_out += r0 * g_stride;
+  }
+  float* g_values = pg_pick(gp.grads, grp);
   const int np = (int)min((long long)PL_CHUNK, (long long)B - p0);
   const float wl = window ? window[l] : 1.0f;
   if (wl == 0.f) return;
@@ -281,6 +333,85 @@ int plan_ok(const vsa_permuto_plan* p) {
 
 }  // namespace
 
+namespace {
+
+int make_permuto_groups(const vsa_permuto_plan* plan, int nr_groups, const int* nr_points,
+                        const float* const* values, float* const* grads, PermutoGroups* gp, int* max_n) {
+  int rc = plan_ok(plan);
+  if (rc) return rc;
+  if (nr_groups < 1 || nr_groups > PG_MAX || !nr_points) return VSA_ERR_ARG;
+  long long row = 0;
+  int mx = 0;
+  for (int g = 0; g < PG_MAX; ++g) {
+    const bool in = g < nr_groups;
+    if (in && nr_points[g] < 0) return VSA_ERR_ARG;
+    gp->n[g] = in ? nr_points[g] : 0;
+    gp->row0[g] = row;
+    gp->values[g] = in && values ? values[g] : nullptr;
+    gp->grads[g] = in && grads ? grads[g] : nullptr;
+    if (in) {
+      if (nr_points[g] > 0 && ((values && !values[g]) || (grads && !grads[g]))) return VSA_ERR_ARG;
+      row += nr_points[g];
+      mx = nr_points[g] > mx ? nr_points[g] : mx;
+    }
+  }
+  *max_n = mx;
+  return VSA_OK;
+}
+
+// plans_dev == nullptr: one group, plan by value
+int permuto_fwd_launch(const vsa_permuto_plan* plan, const vsa_permuto_plan* plans_dev,
+                       const PermutoGroups& gp, int nr_groups, int max_n, const float* x,
+                       const float* window, float* out, int out_stride, hipStream_t st) {
+  dim3 grid(vsa_div_up(max_n, 256), plan->n_levels, nr_groups);
+#define VSA_PERMUTO_FWD(D)                                                                          \
+  do {                                                                                              \
+    if (plans_dev)                                                                                  \
+      hipLaunchKernelGGL((permuto_fwd_kernel<D, true>), grid, dim3(256), 0, st, *plan, plans_dev, gp, x, \
+                         window, out, out_stride);                                                  \
+    else                                                                                            \
+      hipLaunchKernelGGL((permuto_fwd_kernel<D, false>), grid, dim3(256), 0, st, *plan, plans_dev, gp, x, \
+                         window, out, out_stride);                                                  \
+  } while (0)
+  if (plan->pos_dim == 2) VSA_PERMUTO_FWD(2);
+  else if (plan->pos_dim == 3) VSA_PERMUTO_FWD(3);
+  else VSA_PERMUTO_FWD(4);
+#undef VSA_PERMUTO_FWD
+  VSA_RETURN_LAUNCH_STATUS();
+}
+
+int permuto_bwd_launch(const vsa_permuto_plan* plan, const vsa_permuto_plan* plans_dev,
+                       const PermutoGroups& gp, int nr_groups, int max_n, const float* x,
+                       const float* window, const float* g_out, int g_stride, hipStream_t st) {
+  // the first PERMUTO_LDS_LEVELS levels (the coarse ones: levels are ordered coarse to fine) go
+  // through the LDS tables, the rest straight to memory
+  int n_lds = PERMUTO_LDS_LEVELS < plan->n_levels ? PERMUTO_LDS_LEVELS : plan->n_levels;
+  if (max_n < PERMUTO_LDS_MIN_POINTS) n_lds = 0;
+#define VSA_PERMUTO_BWD(D, DEV)                                                                     \
+  do {                                                                                              \
+    if (n_lds > 0)                                                                                  \
+      hipLaunchKernelGGL((permuto_bwd_lds_kernel<D, DEV>), dim3(vsa_div_up(max_n, PL_CHUNK), n_lds, nr_groups), \
+                         dim3(PL_THREADS), 0, st, *plan, plans_dev, gp, x, window, g_out, g_stride); \
+    if (n_lds < plan->n_levels)                                                                     \
+      hipLaunchKernelGGL((permuto_bwd_kernel<D, DEV>),                                              \
+                         dim3(vsa_div_up(2ll * max_n, 256), plan->n_levels - n_lds, nr_groups), dim3(256), 0, st, \
+                         *plan, plans_dev, gp, x, window, g_out, g_stride, n_lds);                  \
+  } while (0)
+  if (plans_dev) {
+    if (plan->pos_dim == 2) VSA_PERMUTO_BWD(2, true);
+    else if (plan->pos_dim == 3) VSA_PERMUTO_BWD(3, true);
+    else VSA_PERMUTO_BWD(4, true);
+  } else {
+    if (plan->pos_dim == 2) VSA_PERMUTO_BWD(2, false);
+    else if (plan->pos_dim == 3) VSA_PERMUTO_BWD(3, false);
+    else VSA_PERMUTO_BWD(4, false);
+  }
+#undef VSA_PERMUTO_BWD
+  VSA_RETURN_LAUNCH_STATUS();
+}
+
+}  // namespace
+
 extern "C" int vsa_permuto_encode_fwd(const vsa_permuto_plan* plan, const float* lattice_values,
                                       const float* x, const float* window, int nr_points,
                                       float* out, int out_stride, void* stream) {
@@ -289,16 +420,11 @@ extern "C" int vsa_permuto_encode_fwd(const vsa_permuto_plan* plan, const float*
   if (nr_points < 0 || out_stride < 2 * plan->n_levels || (out_stride & 1)) return VSA_ERR_ARG;
   if (nr_points == 0) return VSA_OK;
   if (!lattice_values || !x || !out) return VSA_ERR_ARG;
-  dim3 grid(vsa_div_up(nr_points, 256), plan->n_levels);
-  const float2* v = reinterpret_cast<const float2*>(lattice_values);
-#define VSA_PERMUTO_FWD(D)                                                                      \
-  hipLaunchKernelGGL(permuto_fwd_kernel<D>, grid, dim3(256), 0, (hipStream_t)stream, *plan, v, x, \
-                     window, nr_points, out, out_stride)
-  if (plan->pos_dim == 2) VSA_PERMUTO_FWD(2);
-  else if (plan->pos_dim == 3) VSA_PERMUTO_FWD(3);
-  else VSA_PERMUTO_FWD(4);
-#undef VSA_PERMUTO_FWD
-  VSA_RETURN_LAUNCH_STATUS();
+  PermutoGroups gp;
+  int mx = 0;
+  rc = make_permuto_groups(plan, 1, &nr_points, &lattice_values, nullptr, &gp, &mx);
+  if (rc) return rc;
+  return permuto_fwd_launch(plan, nullptr, gp, 1, mx, x, window, out, out_stride, (hipStream_t)stream);
 }
 
 extern "C" int vsa_permuto_encode_bwd(const vsa_permuto_plan* plan, const float* x,
@@ -309,24 +435,50 @@ extern "C" int vsa_permuto_encode_bwd(const vsa_permuto_plan* plan, const float*
   if (nr_points < 0 || g_stride < 2 * plan->n_levels) return VSA_ERR_ARG;
   if (nr_points == 0) return VSA_OK;
   if (!x || !g_out || !grad_values) return VSA_ERR_ARG;
-  // the first PERMUTO_LDS_LEVELS levels (the coarse ones: levels are ordered coarse to fine) go
-  // through the LDS tables, the rest straight to memory
-  int n_lds = PERMUTO_LDS_LEVELS < plan->n_levels ? PERMUTO_LDS_LEVELS : plan->n_levels;
-  if (nr_points < PERMUTO_LDS_MIN_POINTS) n_lds = 0;
-#define VSA_PERMUTO_BWD(D)                                                                          \
-  do {                                                                                              \
-    if (n_lds > 0)                                                                                  \
-      hipLaunchKernelGGL(permuto_bwd_lds_kernel<D>, dim3(vsa_div_up(nr_points, PL_CHUNK), n_lds),   \
-                         dim3(PL_THREADS), 0, (hipStream_t)stream, *plan, x, window, g_out, g_stride, \
-                         nr_points, grad_values);                                                   \
-    if (n_lds < plan->n_levels)                                                                     \
-      hipLaunchKernelGGL(permuto_bwd_kernel<D>, dim3(vsa_div_up(2ll * nr_points, 256), plan->n_levels - n_lds), \
-                         dim3(256), 0, (hipStream_t)stream, *plan, x, window, g_out, g_stride,       \
-                         nr_points, n_lds, grad_values);                                            \
-  } while (0)
-  if (plan->pos_dim == 2) VSA_PERMUTO_BWD(2);
-  else if (plan->pos_dim == 3) VSA_PERMUTO_BWD(3);
-  else VSA_PERMUTO_BWD(4);
-#undef VSA_PERMUTO_BWD
-  VSA_RETURN_LAUNCH_STATUS();
+  PermutoGroups gp;
+  int mx = 0;
+  rc = make_permuto_groups(plan, 1, &nr_points, nullptr, &grad_values, &gp, &mx);
+  if (rc) return rc;
+  return permuto_bwd_launch(plan, nullptr, gp, 1, mx, x, window, g_out, g_stride, (hipStream_t)stream);
+}
+
+// Up to 8 encodings of one geometry in one launch each way.  plan_host: group 0's plan (levels,
+// dimension, capacity: shared); plans_dev: the nr_groups plans in DEVICE memory (their shifts may
+// differ); lattice_values / grad_values: HOST arrays of nr_groups device pointers; group g owns the
+// rows after the first g groups' in x / out / g_out.
+extern "C" int vsa_permuto_encode_fwd_grouped(const vsa_permuto_plan* plan_host,
+                                              const vsa_permuto_plan* plans_dev,
+                                              const float* const* lattice_values, int nr_groups,
+                                              const int* nr_points, const float* x,
+                                              const float* window, float* out, int out_stride,
+                                              void* stream) {
+  int rc = plan_ok(plan_host);
+  if (rc) return rc;
+  if (!plans_dev || !lattice_values || out_stride < 2 * plan_host->n_levels || (out_stride & 1)) return VSA_ERR_ARG;
+  PermutoGroups gp;
+  int mx = 0;
+  rc = make_permuto_groups(plan_host, nr_groups, nr_points, lattice_values, nullptr, &gp, &mx);
+  if (rc) return rc;
+  if (mx == 0) return VSA_OK;
+  if (!x || !out) return VSA_ERR_ARG;
+  return permuto_fwd_launch(plan_host, plans_dev, gp, nr_groups, mx, x, window, out, out_stride,
+                            (hipStream_t)stream);
+}
+
+extern "C" int vsa_permuto_encode_bwd_grouped(const vsa_permuto_plan* plan_host,
+                                              const vsa_permuto_plan* plans_dev, int nr_groups,
+                                              const int* nr_points, const float* x,
+                                              const float* window, const float* g_out, int g_stride,
+                                              float* const* grad_values, void* stream) {
+  int rc = plan_ok(plan_host);
+  if (rc) return rc;
+  if (!plans_dev || !grad_values || g_stride < 2 * plan_host->n_levels) return VSA_ERR_ARG;
+  PermutoGroups gp;
+  int mx = 0;
+  rc = make_permuto_groups(plan_host, nr_groups, nr_points, nullptr, grad_values, &gp, &mx);
+  if (rc) return rc;
+  if (mx == 0) return VSA_OK;
+  if (!x || !g_out) return VSA_ERR_ARG;
+  return permuto_bwd_launch(plan_host, plans_dev, gp, nr_groups, mx, x, window, g_out, g_stride,
+                            (hipStream_t)stream);
 }

@@ -310,11 +310,40 @@ class _PermutoEncode(torch.autograd.Function):
         return (None if direct is not None else g_values), None, None, None, None   # positions: no gradient here
 
 
+_PERMUTO_MAX_GROUPS = 8
+_plans_dev_cache = {}
+
+
+def _plans_on_device(encs, device):
+    """The encoders' plans as one device array (vsa_permuto_encode_*_grouped read the per-group
+    shifts from there: eight 1 KiB plans do not fit the kernel arguments).  Cached on the identity of
+    the plan objects, which an encoder replaces when its shift buffer changes."""
+    plans = [e.plan for e in encs]
+    key = (tuple(id(p) for p in plans), str(device))
+    hit = _plans_dev_cache.get(key)
+    if hit is None:
+        raw = b"".join(bytes(p) for p in plans)
+        dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        if len(_plans_dev_cache) > 64:
+            _plans_dev_cache.clear()
+        hit = _plans_dev_cache[key] = (dev, plans)       # (keeps the plan objects alive: ids stay unique)
+    return hit[0]
+
+
 class _PermutoEncodeGrouped(torch.autograd.Function):
     """G encodings of one geometry (the per-shell models' position encoders) on G consecutive row
-    segments of x as ONE autograd node writing one output matrix: the C entry points are the
-    single-encoding ones, called per group on row slices, but torch sees one op instead of G x
-    (apply, output allocation, point columns, slice and cat bookkeeping forward and backward)."""
+    segments of x as ONE autograd node, one output matrix and one launch each way for up to 8 groups
+    (`vsa_permuto_encode_fwd_grouped` / `_bwd_grouped`: group = blockIdx.z) instead of G x (apply,
+    output allocation, point columns, slice and cat bookkeeping, launches)."""
+
+    @staticmethod
+    def _runs(sizes):
+        out, a = [], 0
+        for g0 in range(0, len(sizes), _PERMUTO_MAX_GROUPS):
+            n = sum(sizes[g0:g0 + _PERMUTO_MAX_GROUPS])
+            out.append((g0, min(_PERMUTO_MAX_GROUPS, len(sizes) - g0), a, n))
+            a += n
+        return out
 
     @staticmethod
     def forward(ctx, x, sizes, window, extra, encs, *values):
@@ -323,12 +352,14 @@ class _PermutoEncodeGrouped(torch.autograd.Function):
         width = 2 * plan0.n_levels + extra
         stride = width + (width & 1)                  # float2 stores: even row stride
         buf = torch.empty(x.shape[0], stride, device=x.device)
-        a = 0
-        for enc, v, n in zip(encs, values, sizes):
-            if n:
-                _lib.call("vsa_permuto_encode_fwd", ctypes.byref(enc.plan), v, x[a:a + n], window, n, buf[a:a + n],
-                          stride, _lib.stream_ptr())
-            a += n
+        for g0, ng, a, n in _PermutoEncodeGrouped._runs(sizes):
+            if n == 0:
+                continue
+            run = encs[g0:g0 + ng]
+            ptrs = (ctypes.c_void_p * ng)(*[v.data_ptr() for v in values[g0:g0 + ng]])
+            cnt = (ctypes.c_int * ng)(*sizes[g0:g0 + ng])
+            _lib.call("vsa_permuto_encode_fwd_grouped", ctypes.byref(run[0].plan), _plans_on_device(run, x.device),
+                      ptrs, ng, cnt, x[a:a + n], window, buf[a:a + n], stride, _lib.stream_ptr())
         if extra:                       # concatenated points (no gradient path: hit points)
             buf[:, 2 * plan0.n_levels:width] = x * encs[0].concat_points_scaling
         ctx.save_for_backward(x, window)
@@ -340,15 +371,20 @@ class _PermutoEncodeGrouped(torch.autograd.Function):
         x, window = ctx.saved_tensors
         from .optim import accumulate_into_grad
         g_out = g_out.contiguous()
-        grads, a = [], 0
-        for enc, n in zip(ctx.encs, ctx.sizes):
+        encs, sizes = ctx.encs, ctx.sizes
+        g_values, grads = [], []
+        for enc in encs:
             direct = accumulate_into_grad(enc.lattice_values)
-            g_values = direct if direct is not None else torch.zeros_like(enc.lattice_values)
-            if n:
-                _lib.call("vsa_permuto_encode_bwd", ctypes.byref(enc.plan), x[a:a + n], window, g_out[a:a + n],
-                          g_out.shape[1], n, g_values, _lib.stream_ptr())
-            grads.append(None if direct is not None else g_values)
-            a += n
+            g_values.append(direct if direct is not None else torch.zeros_like(enc.lattice_values))
+            grads.append(None if direct is not None else g_values[-1])
+        for g0, ng, a, n in _PermutoEncodeGrouped._runs(sizes):
+            if n == 0:
+                continue
+            run = encs[g0:g0 + ng]
+            ptrs = (ctypes.c_void_p * ng)(*[v.data_ptr() for v in g_values[g0:g0 + ng]])
+            cnt = (ctypes.c_int * ng)(*sizes[g0:g0 + ng])
+            _lib.call("vsa_permuto_encode_bwd_grouped", ctypes.byref(run[0].plan), _plans_on_device(run, x.device),
+                      ng, cnt, x[a:a + n], window, g_out[a:a + n], g_out.shape[1], ptrs, _lib.stream_ptr())
         return (None, None, None, None, None, *grads)      # positions: no gradient here
 
 
