@@ -136,16 +136,31 @@ class _FusedMLP(torch.autograd.Function):
 
 
 def _direct_grads(params):
-    """The parameters' own .grad buffers if EVERY one of them has a usable one (optim.accumulate_into_grad),
-    else None (then the Function returns freshly allocated gradients as usual)."""
-    from .optim import accumulate_into_grad
-    if not params or not all(isinstance(p_, torch.nn.Parameter) and p_.requires_grad for p_ in params):
+    """The parameters' own .grad buffers if EVERY one of them has a usable one (the conditions of
+    optim.accumulate_into_grad, checked in one pass; the optimisers are told once that their
+    gradients are dirty), else None (then the Function returns freshly allocated gradients as usual)."""
+    if not params:
         return None
-    got = [accumulate_into_grad(p_) for p_ in params]
-    return got if all(g is not None for g in got) else None
+    got, opts = [], set()
+    for p_ in params:
+        if not (isinstance(p_, torch.nn.Parameter) and p_.requires_grad):
+            return None
+        g = p_.grad
+        if g is None or g.dtype != torch.float32 or g.shape != p_.shape or not g.is_contiguous():
+            return None
+        got.append(g)
+        o = getattr(p_, "_vsa_optimizer", None)
+        if o is not None:
+            opts.add(o)
+    for o in opts:
+        o = o()
+        if o is not None:
+            o.mark_grads_dirty()
+    return got
 
 
 MLP_MAX_GROUPS = 8
+_NO_CACHE = __import__("os").environ.get("VSA_NO_DESC_CACHE", "0") == "1"     # A/B switch
 
 
 class _FusedMLPGrouped(torch.autograd.Function):
@@ -166,44 +181,67 @@ class _FusedMLPGrouped(torch.autograd.Function):
             a += n
         return out
 
+    # The ctypes descriptors of a set of networks (plans: weight / bias pointers; gradient pointer
+    # tables) are kept between calls, keyed on the parameter objects and validated by their data
+    # pointers: building them field by field for 5 x 8 tensors cost the host ~0.3 ms per iteration
+    # of a loop that is bound by it.
+    _desc_cache = {}
+
+    @staticmethod
+    def _descriptors(params, nl, has_bias, G):
+        """(plans per run of <= 8 groups, shapes of group 0's weights) for contiguous parameters."""
+        key = (tuple(map(id, params)), nl, has_bias)
+        ptrs = tuple(p_.data_ptr() for p_ in params)
+        hit = _FusedMLPGrouped._desc_cache.get(key)
+        if hit is None or hit[0] != ptrs or _NO_CACHE:
+            per = nl * (2 if has_bias else 1)
+            groups = []
+            for g in range(G):
+                ps = params[g * per:(g + 1) * per]
+                ws = [ps[2 * l] if has_bias else ps[l] for l in range(nl)]
+                bs = [ps[2 * l + 1] if has_bias else None for l in range(nl)]
+                groups.append((ws, bs))
+            runs = []
+            for g0 in range(0, G, MLP_MAX_GROUPS):
+                ng = min(MLP_MAX_GROUPS, G - g0)
+                runs.append((MlpPlan * ng)(*[_mlp_plan(*groups[g0 + i]) for i in range(ng)]))
+            w0 = groups[0][0]
+            dims = (w0[-1].shape[0], sum(w.shape[0] for w in w0[:-1]),
+                    sum(((w.shape[0] + 31) // 32) * ((w.shape[1] + 31) // 32) * 1024 for w in w0))
+            if len(_FusedMLPGrouped._desc_cache) > 32:
+                _FusedMLPGrouped._desc_cache.clear()
+            hit = _FusedMLPGrouped._desc_cache[key] = (ptrs, runs, dims, {}, tuple(params))
+        return hit
+
     @staticmethod
     def forward(ctx, x, sizes, has_bias, nl, *params):
         x = x.contiguous()
-        per = nl * (2 if has_bias else 1)
         G = len(sizes)
-        groups = []
-        for g in range(G):
-            ps = params[g * per:(g + 1) * per]
-            ws = [(ps[2 * l] if has_bias else ps[l]).contiguous() for l in range(nl)]
-            bs = [ps[2 * l + 1].contiguous() if has_bias else None for l in range(nl)]
-            groups.append((ws, bs))
+        if not all(p_.is_contiguous() for p_ in params):
+            raise _lib.VolsurfsHipError("fused_mlp_grouped: contiguous parameters only")
+        _, runs, (out_dim, hidden, packed_n), _, _ = _FusedMLPGrouped._descriptors(params, nl, has_bias, G)
         need = x.requires_grad or any(p_.requires_grad for p_ in params)
         dev = x.device
-        out_dim = groups[0][0][-1].shape[0]
-        hidden = sum(w.shape[0] for w in groups[0][0][:-1])
-        packed_n = sum(((w.shape[0] + 31) // 32) * ((w.shape[1] + 31) // 32) * 1024 for w in groups[0][0])
         M = x.shape[0]
         y = torch.empty(M, out_dim, device=dev)
         z = torch.empty(max(M * hidden, 1), device=dev) if need else None
         packed = torch.empty(max(packed_n, 1) * min(G, MLP_MAX_GROUPS), device=dev)
-        for g0, ng, a, n in _FusedMLPGrouped._batches(sizes):
+        for (g0, ng, a, n), plans in zip(_FusedMLPGrouped._batches(sizes), runs):
             if n == 0:
                 continue
-            plans = (MlpPlan * ng)(*[_mlp_plan(*groups[g0 + i]) for i in range(ng)])
             cnt = (ctypes.c_int * ng)(*sizes[g0:g0 + ng])
             _lib.call("vsa_mlp_fwd_grouped", plans, ng, cnt, x[a:a + n], x.shape[1], y[a:a + n], out_dim,
                       z[a * hidden:] if z is not None else None, packed, _lib.stream_ptr())
-        ctx.save_for_backward(x, z, *[t for ws, bs in groups for t in ws + [b for b in bs if b is not None]])
+        ctx.save_for_backward(x, z)
         ctx.meta = (tuple(sizes), has_bias, nl, hidden, packed_n)
-        ctx.param_objs = params        # the Parameter objects themselves: backward may add into their .grad
+        ctx.param_objs = params        # the Parameter objects themselves: backward reads their weights and may add into their .grad
         return y
 
     @staticmethod
     def backward(ctx, gy):
         sizes, has_bias, nl, hidden, packed_n = ctx.meta
-        x, z = ctx.saved_tensors[:2]
-        flat = list(ctx.saved_tensors[2:])
-        per = nl * (2 if has_bias else 1)
+        x, z = ctx.saved_tensors
+        params = ctx.param_objs
         G = len(sizes)
         dev = x.device
         gy = gy.contiguous()
@@ -212,53 +250,54 @@ class _FusedMLPGrouped(torch.autograd.Function):
         dz = torch.empty(max(x.shape[0] * hidden, 1), device=dev)
         av = torch.empty(max(x.shape[0] * hidden, 1), device=dev)
         packed = torch.empty(max(packed_n, 1) * min(G, MLP_MAX_GROUPS), device=dev)
+        _, runs, _, grad_cache, _ = _FusedMLPGrouped._descriptors(params, nl, has_bias, G)
         # parameters that own a persistent .grad (FusedAdam): the reduce kernel adds straight into it
         # and autograd gets None — one accumulation kernel per parameter less (80 per step).  One
         # setting for the whole launch: every parameter of every group has to qualify.
-        direct = _direct_grads(list(ctx.param_objs))
-        per_group = []
-        for g in range(G):
-            ps = flat[g * per:(g + 1) * per]
-            ws, bs = ps[:nl], (ps[nl:] if has_bias else [None] * nl)
+        direct = _direct_grads(list(params))
+        if direct is not None:
+            targets = direct
+        else:
+            targets = [torch.empty_like(p_) for p_ in params]
+        # gradient pointer tables: kept while the target buffers stay where they are (persistent .grad)
+        tptrs = tuple(t.data_ptr() for t in targets)
+        got = grad_cache.get(direct is not None)
+        if got is None or got[0] != tptrs or _NO_CACHE:
+            per = nl * (2 if has_bias else 1)
+            tables = []
+            for g0 in range(0, G, MLP_MAX_GROUPS):
+                ng = min(MLP_MAX_GROUPS, G - g0)
+                arr = (MlpGrads * ng)()
+                for i in range(ng):
+                    ts = tptrs[(g0 + i) * per:(g0 + i + 1) * per]
+                    arr[i].accumulate = 1 if direct is not None else 0
+                    for l in range(nl):
+                        arr[i].dw[l] = ts[2 * l] if has_bias else ts[l]
+                        arr[i].db[l] = ts[2 * l + 1] if has_bias else None
+                tables.append(arr)
+            got = (tptrs, tables)
             if direct is not None:
-                objs = ctx.param_objs[g * per:(g + 1) * per]
-                gw = [(objs[2 * l] if has_bias else objs[l]).grad for l in range(nl)]
-                gb = [objs[2 * l + 1].grad if has_bias else None for l in range(nl)]
-            else:
-                gw = [torch.empty_like(w) for w in ws]
-                gb = [None if b is None else torch.empty_like(b) for b in bs]
-            per_group.append((ws, bs, gw, gb))
+                grad_cache[True] = got
         partial = None
-        for g0, ng, a, n in _FusedMLPGrouped._batches(sizes):
+        for (g0, ng, a, n), plans, grads in zip(_FusedMLPGrouped._batches(sizes), runs, got[1]):
             if n == 0:
                 if direct is None:
-                    for ws, bs, gw, gb in per_group[g0:g0 + ng]:
-                        for t in gw + [b for b in gb if b is not None]:
-                            t.zero_()
+                    per = nl * (2 if has_bias else 1)
+                    for t in targets[g0 * per:(g0 + ng) * per]:
+                        t.zero_()
                 continue
-            plans = (MlpPlan * ng)(*[_mlp_plan(ws, bs) for ws, bs, _, _ in per_group[g0:g0 + ng]])
             cnt = (ctypes.c_int * ng)(*sizes[g0:g0 + ng])
             if partial is None:
                 sz = ctypes.c_longlong()
                 _lib.call("vsa_mlp_workspace", ctypes.byref(plans[0]), ctypes.c_longlong(nmax), None, None,
                           ctypes.byref(sz))
                 partial = torch.empty(max(sz.value, 1) * min(G, MLP_MAX_GROUPS), device=dev)
-            grads = (MlpGrads * ng)()
-            for i, (_, _, gw, gb) in enumerate(per_group[g0:g0 + ng]):
-                grads[i].accumulate = 1 if direct is not None else 0
-                for l in range(nl):
-                    grads[i].dw[l] = gw[l].data_ptr()
-                    grads[i].db[l] = gb[l].data_ptr() if gb[l] is not None else None
             _lib.call("vsa_mlp_bwd_grouped", plans, ng, cnt, x[a:a + n], x.shape[1], gy[a:a + n], gy.shape[1],
                       z[a * hidden:], dz[a * hidden:], av[a * hidden:], packed, partial,
                       dx[a:a + n] if dx is not None else None, x.shape[1], grads, _lib.stream_ptr())
-        grads_out = []
-        for _, _, gw, gb in per_group:
-            for l in range(nl):
-                grads_out.append(None if direct is not None else gw[l])
-                if has_bias:
-                    grads_out.append(None if direct is not None else gb[l])
-        return (dx, None, None, None, *grads_out)
+        if direct is not None:
+            return (dx, None, None, None, *([None] * len(params)))
+        return (dx, None, None, None, *targets)
 
 
 def fused_mlp_grouped(mlps, x, sizes):

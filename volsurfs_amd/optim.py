@@ -25,6 +25,9 @@ class AdamTensor(ctypes.Structure):
                 ("exp_avg_sq", ctypes.c_void_p), ("param_f16", ctypes.c_void_p), ("n", ctypes.c_int64)]
 
 
+_NO_CACHE = __import__("os").environ.get("VSA_NO_DESC_CACHE", "0") == "1"     # A/B switch
+
+
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.99), eps=1e-15, weight_decay=0.0,
                  amsgrad=False, half_copies=None):
@@ -33,7 +36,8 @@ class FusedAdam(torch.optim.Optimizer):
                                         "reference (base_method.py:87-94) and not built")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0.0, amsgrad=False))
         self._half = {id(p): h for p, h in (half_copies or {}).items()}
-        self._plans = {}          # group index -> (key, descriptor tensor, chunk tensor, nr_chunks)
+        self._plans = {}          # group index -> (key, descriptor tensor, chunk tensor, nr_chunks, tensor objects)
+        self._plan_age = {}
         self._grads_clean = False
         for g in self.param_groups:
             g.setdefault("step", 0)
@@ -55,11 +59,27 @@ class FusedAdam(torch.optim.Optimizer):
         return st
 
     def _plan(self, gi, group):
+        # Fast path: the tensors behind the cached descriptors are still the same OBJECTS (a
+        # parameter's .grad or a state tensor that gets replaced is a new object) and the parameters
+        # sit where they sat; the full pointer-level check below runs every 64th step and whenever one of these differs.  (Four data_ptr() calls
+        # per parameter and step were 0.2 ms of host time with the 90 tensors of BASELINE configs[2].)
+        cur = self._plans.get(gi)
+        if cur is not None and not _NO_CACHE:
+            self._plan_age[gi] = self._plan_age.get(gi, 0) + 1
+            if self._plan_age[gi] % 64:
+                state = self.state
+                for p, g, ea, eas, ptr in cur[4]:
+                    st = state.get(p)
+                    if p.grad is not g or st is None or st.get("exp_avg") is not ea or st.get("exp_avg_sq") is not eas \
+                            or not p.requires_grad or p.data_ptr() != ptr:
+                        break
+                else:
+                    if len(cur[4]) == sum(1 for p in group["params"] if p.requires_grad):
+                        return cur
         ps = [p for p in group["params"] if p.requires_grad]
         sts = [self._ensure(p) for p in ps]
         key = tuple((p.data_ptr(), p.grad.data_ptr(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr())
                     for p, s in zip(ps, sts))
-        cur = self._plans.get(gi)
         if cur is not None and cur[0] == key:
             return cur
         chunk = _lib.lib().vsa_adam_chunk_elems()
@@ -78,7 +98,8 @@ class FusedAdam(torch.optim.Optimizer):
         dev = ps[0].device if ps else "cuda"
         desc = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
         ck = torch.tensor(chunks, dtype=torch.int32).reshape(-1, 2).to(dev)
-        self._plans[gi] = (key, desc, ck, len(chunks))
+        self._plans[gi] = (key, desc, ck, len(chunks),
+                           [(p, p.grad, s["exp_avg"], s["exp_avg_sq"], p.data_ptr()) for p, s in zip(ps, sts)])
         return self._plans[gi]
 
     def zero_grad(self, set_to_none=False):
@@ -110,7 +131,7 @@ class FusedAdam(torch.optim.Optimizer):
             stream.wait_stream(torch.cuda.current_stream())
         sp = ctypes.c_void_p(stream.cuda_stream) if stream is not None else _lib.stream_ptr()
         for gi, group in enumerate(self.param_groups):
-            _, desc, ck, n = self._plan(gi, group)
+            _, desc, ck, n, _ = self._plan(gi, group)
             group["step"] += 1
             b1, b2 = group["betas"]
             _lib.call("vsa_adam_step", desc, ck, n, float(group["lr"]), float(b1), float(b2),
