@@ -408,12 +408,15 @@ int vsa_mlp_bwd(const vsa_mlp_plan* plan, const float* x, int x_stride, int nr_p
  * grads are HOST arrays.  vsa_mlp_fwd / vsa_mlp_bwd are the one-group case. */
 int vsa_mlp_fwd_grouped(const vsa_mlp_plan* plans, int nr_groups, const int* nr_points,
                         const float* x, int x_stride, float* y, int y_stride, float* z_ws,
-                        float* packed_ws, void* stream);
+                        float* packed_ws, float* packed_bwd_ws, void* stream);
+/* packed_bwd_ws (optional, as large as packed_ws): the forward's packing launch also writes the
+ * transposed fragment order the backward needs; handed to vsa_mlp_bwd_grouped as packed_ws with
+ * packed_ready = 1 (the weights must not have changed in between) it saves that pass its own. */
 int vsa_mlp_bwd_grouped(const vsa_mlp_plan* plans, int nr_groups, const int* nr_points,
                         const float* x, int x_stride, const float* dy, int dy_stride,
                         const float* z_ws, float* dz_ws, float* a_ws, float* packed_ws,
-                        float* partial_ws, float* dx, int dx_stride, const vsa_mlp_grads* grads,
-                        void* stream);
+                        int packed_ready, float* partial_ws, float* dx, int dx_stride,
+                        const vsa_mlp_grads* grads, void* stream);
 
 /* A13  Fused multi-tensor Adam step: apex.optimizers.FusedAdam(betas (0.9, 0.99), eps 1e-15,
  * weight_decay 0) of volsurfs_py/methods/base_method.py:87-94, stepped at trainer.py:278 (the

@@ -844,7 +844,7 @@ long long hidden_width(const vsa_mlp_plan& p) {
 
 extern "C" int vsa_mlp_fwd_grouped(const vsa_mlp_plan* plans, int nr_groups, const int* nr_points,
                                    const float* x, int x_stride, float* y, int y_stride, float* z_ws,
-                                   float* packed_ws, void* stream) {
+                                   float* packed_ws, float* packed_bwd_ws, void* stream) {
   MlpGroups gp;
   long long rows = 0;
   int mx = 0;
@@ -856,8 +856,10 @@ extern "C" int vsa_mlp_fwd_grouped(const vsa_mlp_plan* plans, int nr_groups, con
   if (!x || !y || !packed_ws) return VSA_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const long long packed_stride = pack_offsets(*plan).fwd[plan->n_layers];
+  // (packed_bwd_ws: the transposed fragment order the backward pass needs, written by the same
+  //  launch when the caller will run one — vsa_mlp_bwd_grouped(packed_ready = 1) then skips its own)
   hipLaunchKernelGGL(mlp_pack_kernel, dim3(16, plan->n_layers, nr_groups), dim3(256), 0, st, *plan, gp,
-                     packed_stride, packed_ws, (float*)nullptr);
+                     packed_stride, packed_ws, packed_bwd_ws);
   int nr_cus = 0;
   rc = vsa_cu_count(&nr_cus);
   if (rc) return rc;
@@ -877,13 +879,13 @@ extern "C" int vsa_mlp_fwd_grouped(const vsa_mlp_plan* plans, int nr_groups, con
 
 extern "C" int vsa_mlp_fwd(const vsa_mlp_plan* plan, const float* x, int x_stride, int nr_points,
                            float* y, int y_stride, float* z_ws, float* packed_ws, void* stream) {
-  return vsa_mlp_fwd_grouped(plan, 1, &nr_points, x, x_stride, y, y_stride, z_ws, packed_ws, stream);
+  return vsa_mlp_fwd_grouped(plan, 1, &nr_points, x, x_stride, y, y_stride, z_ws, packed_ws, nullptr, stream);
 }
 
 extern "C" int vsa_mlp_bwd_grouped(const vsa_mlp_plan* plans, int nr_groups, const int* nr_points,
                                    const float* x, int x_stride, const float* dy, int dy_stride,
                                    const float* z_ws, float* dz_ws, float* a_ws, float* packed_ws,
-                                   float* partial_ws, float* dx, int dx_stride,
+                                   int packed_ready, float* partial_ws, float* dx, int dx_stride,
                                    const vsa_mlp_grads* grads, void* stream) {
   MlpGroups gp;
   long long rows = 0;
@@ -910,8 +912,9 @@ extern "C" int vsa_mlp_bwd_grouped(const vsa_mlp_plan* plans, int nr_groups, con
   hipStream_t st = (hipStream_t)stream;
   const long long packed_stride = pack_offsets(*plan).fwd[L];
   const long long hidden = hidden_width(*plan);
-  hipLaunchKernelGGL(mlp_pack_kernel, dim3(16, L, nr_groups), dim3(256), 0, st, *plan, gp, packed_stride,
-                     (float*)nullptr, packed_ws);
+  if (!packed_ready)
+    hipLaunchKernelGGL(mlp_pack_kernel, dim3(16, L, nr_groups), dim3(256), 0, st, *plan, gp, packed_stride,
+                       (float*)nullptr, packed_ws);
   int nr_cus = 0;
   rc = vsa_cu_count(&nr_cus);
   if (rc) return rc;
@@ -950,6 +953,6 @@ extern "C" int vsa_mlp_bwd(const vsa_mlp_plan* plan, const float* x, int x_strid
                            const float* dy, int dy_stride, const float* z_ws, float* dz_ws,
                            float* a_ws, float* packed_ws, float* partial_ws, float* dx,
                            int dx_stride, const vsa_mlp_grads* grads, void* stream) {
-  return vsa_mlp_bwd_grouped(plan, 1, &nr_points, x, x_stride, dy, dy_stride, z_ws, dz_ws, a_ws, packed_ws,
+  return vsa_mlp_bwd_grouped(plan, 1, &nr_points, x, x_stride, dy, dy_stride, z_ws, dz_ws, a_ws, packed_ws, 0,
                              partial_ws, dx, dx_stride, grads, stream);
 }

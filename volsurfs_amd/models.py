@@ -226,12 +226,17 @@ class _FusedMLPGrouped(torch.autograd.Function):
         y = torch.empty(M, out_dim, device=dev)
         z = torch.empty(max(M * hidden, 1), device=dev) if need else None
         packed = torch.empty(max(packed_n, 1) * min(G, MLP_MAX_GROUPS), device=dev)
+        # one run of groups and a backward to come: the packing launch also writes the order the
+        # backward needs (kept on ctx: the parameters only change in the optimiser step after it)
+        packed_bwd = torch.empty_like(packed) if need and len(runs) == 1 else None
         for (g0, ng, a, n), plans in zip(_FusedMLPGrouped._batches(sizes), runs):
             if n == 0:
                 continue
             cnt = (ctypes.c_int * ng)(*sizes[g0:g0 + ng])
             _lib.call("vsa_mlp_fwd_grouped", plans, ng, cnt, x[a:a + n], x.shape[1], y[a:a + n], out_dim,
-                      z[a * hidden:] if z is not None else None, packed, _lib.stream_ptr())
+                      z[a * hidden:] if z is not None else None, packed, packed_bwd, _lib.stream_ptr())
+        ctx.packed_bwd = packed_bwd
+        ctx.param_versions = [p_._version for p_ in params] if packed_bwd is not None else None
         ctx.save_for_backward(x, z)
         ctx.meta = (tuple(sizes), has_bias, nl, hidden, packed_n)
         ctx.param_objs = params        # the Parameter objects themselves: backward reads their weights and may add into their .grad
@@ -249,8 +254,12 @@ class _FusedMLPGrouped(torch.autograd.Function):
         nmax = max(sizes) if sizes else 0
         dz = torch.empty(max(x.shape[0] * hidden, 1), device=dev)
         av = torch.empty(max(x.shape[0] * hidden, 1), device=dev)
-        packed = torch.empty(max(packed_n, 1) * min(G, MLP_MAX_GROUPS), device=dev)
         _, runs, _, grad_cache, _ = _FusedMLPGrouped._descriptors(params, nl, has_bias, G)
+        # the transposed weights the forward's packing launch left (unless a parameter was written since)
+        packed = ctx.packed_bwd
+        ready = packed is not None and ctx.param_versions == [p_._version for p_ in params]
+        if not ready:
+            packed = torch.empty(max(packed_n, 1) * min(G, MLP_MAX_GROUPS), device=dev)
         # parameters that own a persistent .grad (FusedAdam): the reduce kernel adds straight into it
         # and autograd gets None — one accumulation kernel per parameter less (80 per step).  One
         # setting for the whole launch: every parameter of every group has to qualify.
@@ -293,7 +302,7 @@ class _FusedMLPGrouped(torch.autograd.Function):
                           ctypes.byref(sz))
                 partial = torch.empty(max(sz.value, 1) * min(G, MLP_MAX_GROUPS), device=dev)
             _lib.call("vsa_mlp_bwd_grouped", plans, ng, cnt, x[a:a + n], x.shape[1], gy[a:a + n], gy.shape[1],
-                      z[a * hidden:], dz[a * hidden:], av[a * hidden:], packed, partial,
+                      z[a * hidden:], dz[a * hidden:], av[a * hidden:], packed, 1 if ready else 0, partial,
                       dx[a:a + n] if dx is not None else None, x.shape[1], grads, _lib.stream_ptr())
         if direct is not None:
             return (dx, None, None, None, *([None] * len(params)))
