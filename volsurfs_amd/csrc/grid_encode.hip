@@ -14,6 +14,9 @@
 
 namespace {
 
+#ifndef GRID_FWD_PAIRS
+#define GRID_FWD_PAIRS 1
+#endif
 constexpr unsigned GRID_PRIMES[3] = {1u, 2654435761u, 805459861u};
 
 struct GridLevel {
@@ -94,6 +97,42 @@ __global__ __launch_bounds__(256) void grid_encode_fwd_kernel(vsa_grid_plan plan
   const GridLevel g = grid_level(plan, l);
   const GridCell<D> cell = grid_cell<D>(g, x + b * D);
   float f0 = 0.f, f1 = 0.f;
+#if GRID_FWD_PAIRS
+  // The kernel is bound by the rate of divergent 8-byte gathers (~1 address per clock and CU).  On
+  // a hashed level the x coordinate enters the index with prime 1, so for an EVEN x the two
+  // x-neighbours of a corner pair differ in index bit 0 only: one aligned 16-byte load fetches both
+  // (level offsets are multiples of 8 entries).  Same values, same order of the sums.
+  bool hashed = false;
+  {
+    unsigned long long stride = 1;
+#pragma unroll
+    for (int d = 0; d < D; ++d) stride = stride <= g.size ? stride * g.res : stride;
+    hashed = g.size < stride && (g.size & (g.size - 1)) == 0;        // uniform per level
+  }
+  const bool pair_ok = hashed && (cell.c[0] & 1u) == 0u;
+#pragma unroll
+  for (int corner = 0; corner < (1 << D); corner += 2) {
+    unsigned c[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) c[d] = cell.c[d] + ((corner >> d) & 1);
+    const unsigned i0 = grid_index<D>(g, c);
+    float2 v0, v1;
+    if (pair_ok) {
+      const float4 q = *reinterpret_cast<const float4*>(tables + g.offset + (i0 & ~1u));
+      v0 = (i0 & 1u) ? make_float2(q.z, q.w) : make_float2(q.x, q.y);
+      v1 = (i0 & 1u) ? make_float2(q.x, q.y) : make_float2(q.z, q.w);
+    } else {
+      v0 = tables[g.offset + i0];
+      c[0] += 1u;
+      v1 = tables[g.offset + grid_index<D>(g, c)];
+    }
+    const float w0 = corner_weight<D>(cell, corner), w1 = corner_weight<D>(cell, corner + 1);
+    f0 = f0 + w0 * v0.x;
+    f1 = f1 + w0 * v0.y;
+    f0 = f0 + w1 * v1.x;
+    f1 = f1 + w1 * v1.y;
+  }
+#else
 #pragma unroll
   for (int corner = 0; corner < (1 << D); ++corner) {
     unsigned c[D];
@@ -104,6 +143,7 @@ __global__ __launch_bounds__(256) void grid_encode_fwd_kernel(vsa_grid_plan plan
     f0 = f0 + w * v.x;
     f1 = f1 + w * v.y;
   }
+#endif
   // out row = [2 L features | the D inputs when append_x] (GridHashEncoder's concat_points written
   // here instead of by a torch.cat over the whole feature matrix); rows of odd stride are not
   // 8-byte aligned
