@@ -369,11 +369,11 @@ int vsa_field_head_bwd(const float* y1, const float* dx2, const float* d_density
  * dims[l+1] with w[l] [dims[l+1]][dims[l]] row-major (torch.nn.Linear.weight) and b[l] [dims[l+1]]
  * or NULL; every width <= 128, hidden widths multiples of 32.  All pointers are device pointers.
  *   vsa_mlp_workspace: sizes (floats) of packed_ws (weights in MFMA fragment order, rewritten by
- *     every call), of each of z_ws / dz_ws / a_ws (nr_points x sum of hidden widths) and of
+ *     every call), of each of z_ws / a_ws / dz_ws (nr_points x sum of hidden widths) and of
  *     partial_ws (per-workgroup weight-gradient blocks).
- *   vsa_mlp_fwd: y [nr_points][y_stride] = MLP(x [nr_points][x_stride]); z_ws receives the hidden
- *     pre-activations (pass NULL for inference).
- *   vsa_mlp_bwd: from dy = dL/dy and the z_ws of the matching forward: dx (optional), and
+ *   vsa_mlp_fwd: y [nr_points][y_stride] = MLP(x [nr_points][x_stride]); z_ws / a_ws receive the
+ *     hidden pre-activations and activations GELU(z) (both, or NULL for both: inference).
+ *   vsa_mlp_bwd: from dy = dL/dy and the z_ws / a_ws of the matching forward: dx (optional), and
  *     grads->dw[l] / db[l] (NULL entries are skipped): overwritten, or added to what the buffers
  *     hold when grads->accumulate != 0 (a caller that owns persistent .grad buffers lets the
  *     kernel add into them instead of running one accumulation kernel per parameter). */
@@ -393,9 +393,9 @@ typedef struct vsa_mlp_grads {
 int vsa_mlp_workspace(const vsa_mlp_plan* plan, long long nr_points, long long* packed_floats,
                       long long* act_floats, long long* partial_floats);
 int vsa_mlp_fwd(const vsa_mlp_plan* plan, const float* x, int x_stride, int nr_points, float* y,
-                int y_stride, float* z_ws, float* packed_ws, void* stream);
+                int y_stride, float* z_ws, float* a_ws, float* packed_ws, void* stream);
 int vsa_mlp_bwd(const vsa_mlp_plan* plan, const float* x, int x_stride, int nr_points,
-                const float* dy, int dy_stride, const float* z_ws, float* dz_ws, float* a_ws,
+                const float* dy, int dy_stride, const float* z_ws, float* dz_ws, const float* a_ws,
                 float* packed_ws, float* partial_ws, float* dx, int dx_stride,
                 const vsa_mlp_grads* grads, void* stream);
 
@@ -408,13 +408,13 @@ int vsa_mlp_bwd(const vsa_mlp_plan* plan, const float* x, int x_stride, int nr_p
  * grads are HOST arrays.  vsa_mlp_fwd / vsa_mlp_bwd are the one-group case. */
 int vsa_mlp_fwd_grouped(const vsa_mlp_plan* plans, int nr_groups, const int* nr_points,
                         const float* x, int x_stride, float* y, int y_stride, float* z_ws,
-                        float* packed_ws, float* packed_bwd_ws, void* stream);
+                        float* a_ws, float* packed_ws, float* packed_bwd_ws, void* stream);
 /* packed_bwd_ws (optional, as large as packed_ws): the forward's packing launch also writes the
  * transposed fragment order the backward needs; handed to vsa_mlp_bwd_grouped as packed_ws with
  * packed_ready = 1 (the weights must not have changed in between) it saves that pass its own. */
 int vsa_mlp_bwd_grouped(const vsa_mlp_plan* plans, int nr_groups, const int* nr_points,
                         const float* x, int x_stride, const float* dy, int dy_stride,
-                        const float* z_ws, float* dz_ws, float* a_ws, float* packed_ws,
+                        const float* z_ws, float* dz_ws, const float* a_ws, float* packed_ws,
                         int packed_ready, float* partial_ws, float* dx, int dx_stride,
                         const vsa_mlp_grads* grads, void* stream);
 

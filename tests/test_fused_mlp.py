@@ -30,7 +30,7 @@ def test_mlp_plan_layout_and_argument_checks():
     assert L.vsa_mlp_workspace(ctypes.byref(p), ctypes.c_longlong(10), ctypes.byref(sz), None, None) == -2
     p.n_layers = 7
     assert L.vsa_mlp_workspace(ctypes.byref(p), ctypes.c_longlong(10), ctypes.byref(sz), None, None) == -1
-    assert L.vsa_mlp_fwd(None, None, 0, 0, None, 0, None, None, None) == -1
+    assert L.vsa_mlp_fwd(None, None, 0, 0, None, 0, None, None, None, None) == -1
     x = torch.zeros(4, 66)
     assert not fused_mlp_supported([66, 128, 3], x)         # CPU tensors take the torch path
     assert not fused_mlp_supported([66, 48, 3], x.to(torch.float64))

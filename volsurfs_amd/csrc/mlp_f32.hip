@@ -183,7 +183,7 @@ template <bool RESIDENT, int NB>
 __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_fwd_kernel(
     vsa_mlp_plan plan, MlpGroups gp, long long packed_stride, long long hidden,
     const float* __restrict__ packed, const float* __restrict__ x, int x_stride,
-    float* __restrict__ y, int y_stride, float* __restrict__ z_ws) {
+    float* __restrict__ y, int y_stride, float* __restrict__ z_ws, float* __restrict__ a_ws) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];
   __shared__ LayerMeta s_meta;
   const int grp = blockIdx.y;
@@ -196,6 +196,7 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_fwd_kernel(
     x += r0 * x_stride;
     y += r0 * y_stride;
     if (z_ws) z_ws += r0 * hidden;
+    if (a_ws) a_ws += r0 * hidden;
   }
   if (RESIDENT) {
     stage_layer(packed, s_w, meta_fwd(s_meta, L));
@@ -288,6 +289,12 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_fwd_kernel(
                 *reinterpret_cast<float4*>(z_ws + z_off + pt * out + n0) = make_float4(v[0], v[1], v[2], v[3]);
 #pragma unroll
               for (int i = 0; i < 4; ++i) act[m][4 * g + i] = gelu_f(v[i]);
+              // the activations the weight gradients will contract with: stored here, where the
+              // kernel has time to spare (it is bound by its MFMAs and the GELU), instead of by
+              // mlp_dgrad, which is bound by its traffic (1.50 -> 1.21 ms without these stores)
+              if (a_ws && valid)
+                *reinterpret_cast<float4*>(a_ws + z_off + pt * out + n0) =
+                    make_float4(act[m][4 * g], act[m][4 * g + 1], act[m][4 * g + 2], act[m][4 * g + 3]);
             }
           }
         } else if (!last) {
@@ -301,14 +308,15 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_fwd_kernel(
 }
 
 // ------------------------------------------------------------------ backward 1: data gradients
-// dZ_l and A_l = GELU(z_l) of every hidden layer are written to dz_ws / a_ws ([point][width],
-// same offsets as z_ws); dX [point][dims[0]] optional.
+// dZ_l of every hidden layer is written to dz_ws ([point][width], same offsets as z_ws); dX
+// [point][dims[0]] optional.  (A_l = GELU(z_l), the other operand of the weight gradients, was
+// stored by the forward pass.)
 template <bool RESIDENT, int NB>
 __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_dgrad_kernel(
     vsa_mlp_plan plan, MlpGroups gp, long long packed_stride, long long hidden,
     const float* __restrict__ packed_t, const float* __restrict__ dy,
     int dy_stride, const float* __restrict__ z_ws, float* __restrict__ dz_ws,
-    float* __restrict__ a_ws, float* __restrict__ dx, int dx_stride) {
+    float* __restrict__ dx, int dx_stride) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];
   __shared__ LayerMeta s_meta;
   const int grp = blockIdx.y;
@@ -321,7 +329,6 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_dgrad_kernel(
     dy += r0 * dy_stride;
     z_ws += r0 * hidden;
     dz_ws += r0 * hidden;
-    a_ws += r0 * hidden;
     if (dx) dx += r0 * dx_stride;
   }
   if (RESIDENT) {
@@ -418,19 +425,15 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_dgrad_kernel(
                 if (valid) z4 = *reinterpret_cast<const float4*>(z_ws + o);
               }
               const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
-              float a4[4], d4[4];
+              float d4[4];
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
                 const float cdf = 0.5f * (1.0f + erff(zz[i] * 0.70710678118654752440f));
                 const float pdf = 0.39894228040143267794f * __expf(-0.5f * zz[i] * zz[i]);
-                a4[i] = zz[i] * cdf;
                 d4[i] = da[b][4 * g + i] * (cdf + zz[i] * pdf);
                 dz[b][4 * g + i] = d4[i];
               }
-              if (valid) {
-                *reinterpret_cast<float4*>(dz_ws + o) = make_float4(d4[0], d4[1], d4[2], d4[3]);
-                *reinterpret_cast<float4*>(a_ws + o) = make_float4(a4[0], a4[1], a4[2], a4[3]);
-              }
+              if (valid) *reinterpret_cast<float4*>(dz_ws + o) = make_float4(d4[0], d4[1], d4[2], d4[3]);
             }
           } else {
 #pragma unroll
@@ -844,7 +847,7 @@ long long hidden_width(const vsa_mlp_plan& p) {
 
 extern "C" int vsa_mlp_fwd_grouped(const vsa_mlp_plan* plans, int nr_groups, const int* nr_points,
                                    const float* x, int x_stride, float* y, int y_stride, float* z_ws,
-                                   float* packed_ws, float* packed_bwd_ws, void* stream) {
+                                   float* a_ws, float* packed_ws, float* packed_bwd_ws, void* stream) {
   MlpGroups gp;
   long long rows = 0;
   int mx = 0;
@@ -853,7 +856,7 @@ extern "C" int vsa_mlp_fwd_grouped(const vsa_mlp_plan* plans, int nr_groups, con
   const vsa_mlp_plan* plan = &plans[0];
   if (x_stride < plan->dims[0] || y_stride < plan->dims[plan->n_layers]) return VSA_ERR_ARG;
   if (rows == 0) return VSA_OK;
-  if (!x || !y || !packed_ws) return VSA_ERR_ARG;
+  if (!x || !y || !packed_ws || ((z_ws != nullptr) != (a_ws != nullptr))) return VSA_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const long long packed_stride = pack_offsets(*plan).fwd[plan->n_layers];
   // (packed_bwd_ws: the transposed fragment order the backward pass needs, written by the same
@@ -873,18 +876,18 @@ extern "C" int vsa_mlp_fwd_grouped(const vsa_mlp_plan* plans, int nr_groups, con
   const int cap = vsa_div_up(2 * nr_cus, nr_groups);          // two workgroups per CU over all groups
   if (grid > cap) grid = cap;
   VSA_MLP_DISPATCH(mlp_fwd_kernel, resident, max_blocks(*plan), dim3(grid, nr_groups), dim3(MLP_BLOCK), lds, st,
-                   *plan, gp, packed_stride, hidden_width(*plan), packed_ws, x, x_stride, y, y_stride, z_ws);
+                   *plan, gp, packed_stride, hidden_width(*plan), packed_ws, x, x_stride, y, y_stride, z_ws, a_ws);
   VSA_RETURN_LAUNCH_STATUS();
 }
 
 extern "C" int vsa_mlp_fwd(const vsa_mlp_plan* plan, const float* x, int x_stride, int nr_points,
-                           float* y, int y_stride, float* z_ws, float* packed_ws, void* stream) {
-  return vsa_mlp_fwd_grouped(plan, 1, &nr_points, x, x_stride, y, y_stride, z_ws, packed_ws, nullptr, stream);
+                           float* y, int y_stride, float* z_ws, float* a_ws, float* packed_ws, void* stream) {
+  return vsa_mlp_fwd_grouped(plan, 1, &nr_points, x, x_stride, y, y_stride, z_ws, a_ws, packed_ws, nullptr, stream);
 }
 
 extern "C" int vsa_mlp_bwd_grouped(const vsa_mlp_plan* plans, int nr_groups, const int* nr_points,
                                    const float* x, int x_stride, const float* dy, int dy_stride,
-                                   const float* z_ws, float* dz_ws, float* a_ws, float* packed_ws,
+                                   const float* z_ws, float* dz_ws, const float* a_ws, float* packed_ws,
                                    int packed_ready, float* partial_ws, float* dx, int dx_stride,
                                    const vsa_mlp_grads* grads, void* stream) {
   MlpGroups gp;
@@ -929,7 +932,7 @@ extern "C" int vsa_mlp_bwd_grouped(const vsa_mlp_plan* plans, int nr_groups, con
   if (grid > cap) grid = cap;
   if (L > 1 || dx)
     VSA_MLP_DISPATCH(mlp_dgrad_kernel, resident, max_blocks(*plan), dim3(grid, nr_groups), dim3(MLP_BLOCK), lds, st,
-                     *plan, gp, packed_stride, hidden, packed_ws, dy, dy_stride, z_ws, dz_ws, a_ws, dx, dx_stride);
+                     *plan, gp, packed_stride, hidden, packed_ws, dy, dy_stride, z_ws, dz_ws, dx, dx_stride);
   // the weight-gradient workgroups of ONE group (every group gets the same split; the co-resident
   // budget is shared between the groups)
   const WgradLayers wl = wgrad_layers(*plan, wgrad_total_wgs(*plan, mx, nr_cus, nr_groups));
@@ -951,7 +954,7 @@ extern "C" int vsa_mlp_bwd_grouped(const vsa_mlp_plan* plans, int nr_groups, con
 
 extern "C" int vsa_mlp_bwd(const vsa_mlp_plan* plan, const float* x, int x_stride, int nr_points,
                            const float* dy, int dy_stride, const float* z_ws, float* dz_ws,
-                           float* a_ws, float* packed_ws, float* partial_ws, float* dx,
+                           const float* a_ws, float* packed_ws, float* partial_ws, float* dx,
                            int dx_stride, const vsa_mlp_grads* grads, void* stream) {
   return vsa_mlp_bwd_grouped(plan, 1, &nr_points, x, x_stride, dy, dy_stride, z_ws, dz_ws, a_ws, packed_ws, 0,
                              partial_ws, dx, dx_stride, grads, stream);

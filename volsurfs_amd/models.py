@@ -96,23 +96,24 @@ class _FusedMLP(torch.autograd.Function):
         dev = x.device
         packed = torch.empty(max(sizes[0].value, 1), device=dev)
         z = torch.empty(max(sizes[1].value, 1), device=dev) if need else None
+        act = torch.empty_like(z) if need else None       # GELU(z): the weight gradients' other operand
         y = torch.empty(M, ws[-1].shape[0], device=dev)
-        _lib.call("vsa_mlp_fwd", ctypes.byref(plan), x, x.shape[1], M, y, y.shape[1], z, packed,
+        _lib.call("vsa_mlp_fwd", ctypes.byref(plan), x, x.shape[1], M, y, y.shape[1], z, act, packed,
                   _lib.stream_ptr())
-        ctx.save_for_backward(x, z, *ws, *[b for b in bs if b is not None])
+        ctx.save_for_backward(x, z, act, *ws, *[b for b in bs if b is not None])
         ctx.meta = (nl, has_bias, sizes[1].value, sizes[2].value)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         nl, has_bias, act_n, part_n = ctx.meta
-        x, z = ctx.saved_tensors[:2]
-        ws = list(ctx.saved_tensors[2:2 + nl])
-        bs = list(ctx.saved_tensors[2 + nl:]) if has_bias else [None] * nl
+        x, z, act = ctx.saved_tensors[:3]
+        ws = list(ctx.saved_tensors[3:3 + nl])
+        bs = list(ctx.saved_tensors[3 + nl:]) if has_bias else [None] * nl
         M, dev = x.shape[0], x.device
         plan = _mlp_plan(ws, bs)
         gy = gy.contiguous()
-        dz, a = torch.empty(max(act_n, 1), device=dev), torch.empty(max(act_n, 1), device=dev)
+        dz = torch.empty(max(act_n, 1), device=dev)
         packed = torch.empty(sum(((w.shape[0] + 31) // 32) * ((w.shape[1] + 31) // 32) * 1024 for w in ws),
                              device=dev)
         partial = torch.empty(max(part_n, 1), device=dev)
@@ -125,7 +126,7 @@ class _FusedMLP(torch.autograd.Function):
         for l in range(nl):
             grads.dw[l] = gw[l].data_ptr()
             grads.db[l] = gb[l].data_ptr() if gb[l] is not None else None
-        _lib.call("vsa_mlp_bwd", ctypes.byref(plan), x, x.shape[1], M, gy, gy.shape[1], z, dz, a,
+        _lib.call("vsa_mlp_bwd", ctypes.byref(plan), x, x.shape[1], M, gy, gy.shape[1], z, dz, act,
                   packed, partial, dx, x.shape[1], ctypes.byref(grads), _lib.stream_ptr())
         out = []
         for l in range(nl):
@@ -225,6 +226,7 @@ class _FusedMLPGrouped(torch.autograd.Function):
         M = x.shape[0]
         y = torch.empty(M, out_dim, device=dev)
         z = torch.empty(max(M * hidden, 1), device=dev) if need else None
+        act = torch.empty_like(z) if need else None       # GELU(z): the weight gradients' other operand
         packed = torch.empty(max(packed_n, 1) * min(G, MLP_MAX_GROUPS), device=dev)
         # one run of groups and a backward to come: the packing launch also writes the order the
         # backward needs (kept on ctx: the parameters only change in the optimiser step after it)
@@ -234,10 +236,11 @@ class _FusedMLPGrouped(torch.autograd.Function):
                 continue
             cnt = (ctypes.c_int * ng)(*sizes[g0:g0 + ng])
             _lib.call("vsa_mlp_fwd_grouped", plans, ng, cnt, x[a:a + n], x.shape[1], y[a:a + n], out_dim,
-                      z[a * hidden:] if z is not None else None, packed, packed_bwd, _lib.stream_ptr())
+                      z[a * hidden:] if z is not None else None, act[a * hidden:] if act is not None else None,
+                      packed, packed_bwd, _lib.stream_ptr())
         ctx.packed_bwd = packed_bwd
         ctx.param_versions = [p_._version for p_ in params] if packed_bwd is not None else None
-        ctx.save_for_backward(x, z)
+        ctx.save_for_backward(x, z, act)
         ctx.meta = (tuple(sizes), has_bias, nl, hidden, packed_n)
         ctx.param_objs = params        # the Parameter objects themselves: backward reads their weights and may add into their .grad
         return y
@@ -245,7 +248,7 @@ class _FusedMLPGrouped(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         sizes, has_bias, nl, hidden, packed_n = ctx.meta
-        x, z = ctx.saved_tensors
+        x, z, act = ctx.saved_tensors
         params = ctx.param_objs
         G = len(sizes)
         dev = x.device
@@ -253,7 +256,6 @@ class _FusedMLPGrouped(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         nmax = max(sizes) if sizes else 0
         dz = torch.empty(max(x.shape[0] * hidden, 1), device=dev)
-        av = torch.empty(max(x.shape[0] * hidden, 1), device=dev)
         _, runs, _, grad_cache, _ = _FusedMLPGrouped._descriptors(params, nl, has_bias, G)
         # the transposed weights the forward's packing launch left (unless a parameter was written since)
         packed = ctx.packed_bwd
@@ -302,7 +304,7 @@ class _FusedMLPGrouped(torch.autograd.Function):
                           ctypes.byref(sz))
                 partial = torch.empty(max(sz.value, 1) * min(G, MLP_MAX_GROUPS), device=dev)
             _lib.call("vsa_mlp_bwd_grouped", plans, ng, cnt, x[a:a + n], x.shape[1], gy[a:a + n], gy.shape[1],
-                      z[a * hidden:], dz[a * hidden:], av[a * hidden:], packed, 1 if ready else 0, partial,
+                      z[a * hidden:], dz[a * hidden:], act[a * hidden:], packed, 1 if ready else 0, partial,
                       dx[a:a + n] if dx is not None else None, x.shape[1], grads, _lib.stream_ptr())
         if direct is not None:
             return (dx, None, None, None, *([None] * len(params)))
