@@ -626,8 +626,19 @@ __global__ void mlp_reduce_kernel(vsa_mlp_plan plan, WgradLayers wl, long long p
       db = pick2(grads.db, g, k);
     }
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < per; idx += gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < nwg; ++k) s += partial[wl.part_off[l] + (long long)k * per + idx];
+    // four independent running sums: the loads of a thread's ~250 partials are then in flight four
+    // at a time instead of one dependent add after the other (fixed order: still deterministic)
+    const float* pp = partial + wl.part_off[l] + idx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < nwg; k += 4) {
+      s0 += pp[(long long)k * per];
+      s1 += pp[(long long)(k + 1) * per];
+      s2 += pp[(long long)(k + 2) * per];
+      s3 += pp[(long long)(k + 3) * per];
+    }
+    for (; k < nwg; ++k) s0 += pp[(long long)k * per];
+    const float s = (s0 + s1) + (s2 + s3);
     if (idx < out_pad * in_pad) {
       const int row = idx / in_pad, col = idx - row * in_pad;
       if (row < out && col < in && dw) {
