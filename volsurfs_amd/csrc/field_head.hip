@@ -23,73 +23,103 @@ __device__ __forceinline__ float head_gelu_grad(float x, float dy) {
   return dy * (cdf + x * pdf);
 }
 
-// one thread per element of x2 [B][F + E]
-__global__ __launch_bounds__(256) void field_head_fwd_kernel(const float* __restrict__ y1,
-                                                             const float* __restrict__ dirs_enc,
-                                                             int B, int F, int E,
-                                                             float* __restrict__ x2,
-                                                             float* __restrict__ density) {
-  // 32-bit index arithmetic (the host splits batches of 2^31 elements or more): a 64-bit division
-  // per element made this pass 2.4x slower than its memory traffic
-  const unsigned t = blockIdx.x * 256u + threadIdx.x;
-  const unsigned W = (unsigned)(F + E);
-  if (t >= (unsigned)B * W) return;
-  const unsigned b = t / W;
-  const int j = (int)(t - b * W);
-  if (j < F) {
-    x2[t] = head_gelu(y1[b * (unsigned)(1 + F) + 1 + j]);
-  } else {
-    x2[t] = dirs_enc[b * (unsigned)E + (j - F)];
-  }
-  if (j == 0) {
-    const float a = y1[b * (unsigned)(1 + F)];
-    density[b] = a > 20.0f ? a : log1pf(expf(a));
+// A wave walks rows: its lanes are the feature columns (64 per pass), so a row is one contiguous
+// load, one GELU per lane with no column arithmetic, one contiguous store; then the first E lanes
+// copy the encoded direction.  (One thread per element of x2 spent more instructions on the 64-bit
+// row / column division and on waves that mix GELU and copy lanes than on the GELU: 850 us for
+// 2.1 M rows against 340 us of traffic.)
+constexpr int FH_BLOCK = 256;
+#ifndef FH_ROWS_PER_TRIP
+#define FH_ROWS_PER_TRIP 8
+#endif
+constexpr int FH_ROWS = FH_ROWS_PER_TRIP;
+
+__global__ __launch_bounds__(FH_BLOCK) void field_head_fwd_kernel(const float* __restrict__ y1,
+                                                                 const float* __restrict__ dirs_enc,
+                                                                 long long B, int F, int E,
+                                                                 float* __restrict__ x2,
+                                                                 float* __restrict__ density) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * FH_BLOCK + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * FH_BLOCK) >> 6;
+  const int W = F + E;
+  // FH_ROWS rows per trip, all their loads issued before the first GELU: with one 4-byte load in
+  // flight per lane the 32 waves of a CU keep 8 KiB on the way and the pass ran at 1.6 TB/s
+  for (long long b0 = wave * FH_ROWS; b0 < B; b0 += nwaves * FH_ROWS) {
+    for (int j = lane; j < F; j += 64) {
+      float v[FH_ROWS];
+#pragma unroll
+      for (int r = 0; r < FH_ROWS; ++r) v[r] = b0 + r < B ? y1[(b0 + r) * (1 + F) + 1 + j] : 0.f;
+#pragma unroll
+      for (int r = 0; r < FH_ROWS; ++r)
+        if (b0 + r < B) x2[(b0 + r) * W + j] = head_gelu(v[r]);
+    }
+    for (int j = lane; j < E; j += 64) {
+      float v[FH_ROWS];
+#pragma unroll
+      for (int r = 0; r < FH_ROWS; ++r) v[r] = b0 + r < B ? dirs_enc[(b0 + r) * E + j] : 0.f;
+#pragma unroll
+      for (int r = 0; r < FH_ROWS; ++r)
+        if (b0 + r < B) x2[(b0 + r) * W + F + j] = v[r];
+    }
+    if (lane < FH_ROWS && b0 + lane < B) {
+      const float a = y1[(b0 + lane) * (1 + F)];
+      density[b0 + lane] = a > 20.0f ? a : log1pf(expf(a));
+    }
   }
 }
 
-// one thread per element of dy1 [B][1 + F]
-__global__ __launch_bounds__(256) void field_head_bwd_kernel(const float* __restrict__ y1,
-                                                             const float* __restrict__ dx2,
-                                                             const float* __restrict__ d_density,
-                                                             int B, int F, int E,
-                                                             float* __restrict__ dy1) {
-  const unsigned t = blockIdx.x * 256u + threadIdx.x;
-  const unsigned W = 1u + (unsigned)F;
-  if (t >= (unsigned)B * W) return;
-  const unsigned b = t / W;
-  const int j = (int)(t - b * W);
-  const float y = y1[t];
-  if (j == 0) {
-    float g = 0.f;
-    if (d_density) {
-      const float dy = d_density[b];
-      const float z = expf(y);
-      g = y > 20.0f ? dy : dy * z / (z + 1.0f);
+__global__ __launch_bounds__(FH_BLOCK) void field_head_bwd_kernel(const float* __restrict__ y1,
+                                                                 const float* __restrict__ dx2,
+                                                                 const float* __restrict__ d_density,
+                                                                 long long B, int F, int E,
+                                                                 float* __restrict__ dy1) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * FH_BLOCK + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * FH_BLOCK) >> 6;
+  const int W = F + E;
+  for (long long b0 = wave * FH_ROWS; b0 < B; b0 += nwaves * FH_ROWS) {
+    for (int j = lane; j < F; j += 64) {
+      float v[FH_ROWS], d[FH_ROWS];
+#pragma unroll
+      for (int r = 0; r < FH_ROWS; ++r) {
+        const bool in = b0 + r < B;
+        v[r] = in ? y1[(b0 + r) * (1 + F) + 1 + j] : 0.f;
+        d[r] = in && dx2 ? dx2[(b0 + r) * W + j] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < FH_ROWS; ++r)
+        if (b0 + r < B) dy1[(b0 + r) * (1 + F) + 1 + j] = dx2 ? head_gelu_grad(v[r], d[r]) : 0.f;
     }
-    dy1[t] = g;
-  } else {
-    dy1[t] = dx2 ? head_gelu_grad(y, dx2[b * (unsigned)(F + E) + (j - 1)]) : 0.f;
+    if (lane < FH_ROWS && b0 + lane < B) {
+      const long long b = b0 + lane;
+      float g = 0.f;
+      if (d_density) {
+        const float y = y1[b * (1 + F)], dy = d_density[b];
+        const float z = expf(y);
+        g = y > 20.0f ? dy : dy * z / (z + 1.0f);
+      }
+      dy1[b * (1 + F)] = g;
+    }
   }
 }
 
 }  // namespace
 
-// rows per launch: element indices stay below 2^31
-static long long head_chunk_rows(int width) { return ((1ll << 31) - 256) / width; }
+// persistent-ish grid: enough waves to fill the chip, each walking rows with a grid stride
+static int head_grid(long long rows) {
+  long long blocks = (rows + (FH_BLOCK / 64) * FH_ROWS - 1) / ((FH_BLOCK / 64) * FH_ROWS);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  return (int)(blocks < 1 ? 1 : blocks);
+}
 
 extern "C" int vsa_field_head_fwd(const float* y1, const float* dirs_enc, long long nr_points,
                                   int nr_feat, int nr_dir, float* x2, float* density, void* stream) {
   if (nr_points < 0 || nr_feat < 1 || nr_dir < 0) return VSA_ERR_ARG;
   if (nr_points == 0) return VSA_OK;
   if (!y1 || !x2 || !density || (nr_dir > 0 && !dirs_enc)) return VSA_ERR_ARG;
-  const int W = nr_feat + nr_dir;
-  const long long step = head_chunk_rows(W);
-  for (long long r0 = 0; r0 < nr_points; r0 += step) {
-    const long long n = nr_points - r0 < step ? nr_points - r0 : step;
-    hipLaunchKernelGGL(field_head_fwd_kernel, dim3((unsigned)vsa_div_up(n * W, 256)), dim3(256), 0,
-                       (hipStream_t)stream, y1 + r0 * (1 + nr_feat), dirs_enc ? dirs_enc + r0 * nr_dir : nullptr,
-                       (int)n, nr_feat, nr_dir, x2 + r0 * W, density + r0);
-  }
+  hipLaunchKernelGGL(field_head_fwd_kernel, dim3(head_grid(nr_points)), dim3(FH_BLOCK), 0, (hipStream_t)stream,
+                     y1, dirs_enc, nr_points, nr_feat, nr_dir, x2, density);
   VSA_RETURN_LAUNCH_STATUS();
 }
 
@@ -99,13 +129,7 @@ extern "C" int vsa_field_head_bwd(const float* y1, const float* dx2, const float
   if (nr_points < 0 || nr_feat < 1 || nr_dir < 0) return VSA_ERR_ARG;
   if (nr_points == 0) return VSA_OK;
   if (!y1 || !dy1) return VSA_ERR_ARG;
-  const int W = 1 + nr_feat;
-  const long long step = head_chunk_rows(nr_feat + nr_dir);
-  for (long long r0 = 0; r0 < nr_points; r0 += step) {
-    const long long n = nr_points - r0 < step ? nr_points - r0 : step;
-    hipLaunchKernelGGL(field_head_bwd_kernel, dim3((unsigned)vsa_div_up(n * W, 256)), dim3(256), 0,
-                       (hipStream_t)stream, y1 + r0 * W, dx2 ? dx2 + r0 * (nr_feat + nr_dir) : nullptr,
-                       d_density ? d_density + r0 : nullptr, (int)n, nr_feat, nr_dir, dy1 + r0 * W);
-  }
+  hipLaunchKernelGGL(field_head_bwd_kernel, dim3(head_grid(nr_points)), dim3(FH_BLOCK), 0, (hipStream_t)stream,
+                     y1, dx2, d_density, nr_points, nr_feat, nr_dir, dy1);
   VSA_RETURN_LAUNCH_STATUS();
 }
