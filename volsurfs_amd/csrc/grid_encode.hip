@@ -469,7 +469,7 @@ __global__ __launch_bounds__(1024) void grid_bin_scan_kernel(const unsigned long
 template <int D>
 __global__ __launch_bounds__(GB_SAMPLES) void grid_bin_scatter_kernel(
     vsa_grid_plan plan, const float* __restrict__ x, const float2* __restrict__ g_lm, int B,
-    unsigned long long* __restrict__ cursors, unsigned* __restrict__ rec_idx,
+    unsigned long long* __restrict__ cursors, unsigned short* __restrict__ rec_idx,
     float* __restrict__ rec_x, float* __restrict__ rec_y) {
   constexpr int NC = 1 << D;
   extern __shared__ unsigned s_raw[];
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(GB_SAMPLES) void grid_bin_scatter_kernel(
       const unsigned id = s_idx[p];
       const unsigned sl = id >> GS_SLICE_LOG2;
       const unsigned long long dst = s_base[sl] + (p - s_off[sl]);
-      rec_idx[dst] = id & (GS_SLICE - 1);
+      rec_idx[dst] = (unsigned short)(id & (GS_SLICE - 1));      // 13 bits: 10 B per record instead of 12
       rec_x[dst] = s_vx[p];
       rec_y[dst] = s_vy[p];
     }
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(GB_SAMPLES) void grid_bin_scatter_kernel(
 
 __global__ __launch_bounds__(GS_THREADS) void grid_bin_accumulate_kernel(
     vsa_grid_plan plan, const unsigned long long* __restrict__ offsets,
-    const unsigned* __restrict__ rec_idx, const float* __restrict__ rec_x,
+    const unsigned short* __restrict__ rec_idx, const float* __restrict__ rec_x,
     const float* __restrict__ rec_y, const unsigned* __restrict__ max_bits, int count_bits,
     float* __restrict__ g_tables) {
   extern __shared__ unsigned long long s_acc[];    // [GS_SLICE][2] fixed point
@@ -580,7 +580,8 @@ __global__ __launch_bounds__(GS_THREADS) void grid_bin_accumulate_kernel(
     float vx[GB_RPL], vy[GB_RPL];
 #pragma unroll
     for (int q = 0; q < GB_RPL / 4; ++q) {
-      const uint4 e4 = *reinterpret_cast<const uint4*>(rec_idx + base + 4 * q);
+      const uint2 e2 = *reinterpret_cast<const uint2*>(rec_idx + base + 4 * q);      // four 16-bit entries
+      const uint4 e4 = make_uint4(e2.x & 0xffffu, e2.x >> 16, e2.y & 0xffffu, e2.y >> 16);
       const float4 x4 = *reinterpret_cast<const float4*>(rec_x + base + 4 * q);
       const float4 y4 = *reinterpret_cast<const float4*>(rec_y + base + 4 * q);
       ent[4 * q] = e4.x, ent[4 * q + 1] = e4.y, ent[4 * q + 2] = e4.z, ent[4 * q + 3] = e4.w;
@@ -806,7 +807,7 @@ extern "C" int vsa_grid_encode_bwd_binned_ld(const vsa_grid_plan* plan, const fl
   float2* g_lm = reinterpret_cast<float2*>(workspace);
   if (reinterpret_cast<size_t>(workspace) & 15) return VSA_ERR_ARG;
   const long long g_floats = (2 * B * L + 3) & ~3ll;
-  unsigned* rec_idx = reinterpret_cast<unsigned*>(workspace + g_floats);
+  unsigned short* rec_idx = reinterpret_cast<unsigned short*>(workspace + g_floats);   // (uses half of its nrec floats)
   float* rec_x = workspace + g_floats + nrec;
   float* rec_y = rec_x + nrec;
   unsigned* max_bits = reinterpret_cast<unsigned*>(rec_y + nrec);
