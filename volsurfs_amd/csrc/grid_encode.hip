@@ -626,6 +626,8 @@ __global__ void sh_encode_kernel(const float* __restrict__ dirs, int B, int degr
   const float x = dirs[3 * b], y = dirs[3 * b + 1], z = dirs[3 * b + 2];
   const int n = (degree + 1) * (degree + 1);
   float r[25];
+#pragma unroll
+  for (int i = 1; i < 25; ++i) r[i] = 0.f;
   r[0] = 0.28209479177387814f;
   if (degree > 0) {
     const float C1 = 0.4886025119029199f;
@@ -661,7 +663,18 @@ __global__ void sh_encode_kernel(const float* __restrict__ dirs, int B, int degr
       }
     }
   }
-  for (int i = 0; i < n; ++i) out[b * n + i] = r[i];
+  // (compile-time indices: a run-time loop over r[] moved the array to scratch memory.  Degree 1
+  //  and 3 rows are 16 / 64 bytes: whole float4 stores)
+  float* o = out + b * n;
+  if ((n & 3) == 0) {
+#pragma unroll
+    for (int i = 0; i < 24; i += 4)
+      if (i < n) *reinterpret_cast<float4*>(o + i) = make_float4(r[i], r[i + 1], r[i + 2], r[i + 3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 25; ++i)
+      if (i < n) o[i] = r[i];
+  }
 }
 
 int plan_ok(const vsa_grid_plan* p) {
