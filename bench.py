@@ -69,8 +69,16 @@ def parse():
     return args
 
 
-FRAME_PATH_SOURCES = ("common.h", "nt_common.h", "nt_quant_table.h", "nt_texels.hip", "nt_encode.hip",
-                      "nt_mlp.hip", "nt_shade.hip", "trace.hip", "composite_dense.hip", "raygen.hip")
+def dist_info(dist, args):
+    """What the line's n_gpus rests on: the size of the process group the ranks really formed."""
+    if dist is None:
+        return {"ranks_seen": 1, "dist_backend": None}
+    return {"ranks_seen": dist.get_world_size(), "dist_backend": dist.get_backend()}
+
+
+FRAME_PATH_SOURCES = ("common.h", "nt_common.h", "nt_enc_common.h", "nt_mlp_common.h", "nt_quant_table.h",
+                      "nt_texels.hip", "nt_encode.hip", "nt_mlp.hip", "nt_fused.hip", "nt_shade.hip", "trace.hip",
+                      "composite_dense.hip", "raygen.hip")
 
 
 def kernel_source_hash():
@@ -141,8 +149,12 @@ def run_train(args, world, rank, dev, dist):
     max_rays = 1 << 17
     kw = dict(using_neural_textures=False, rgb_pos_encoder_type="permutohash",
               rgb_mlp_layers_dims=(128, 128, 64)) if legacy else {}
-    method = VolSurfs(meshes, max_rays=max_rays, nr_warmup_iters=500, seed=42 + rank, **kw)
+    # data-parallel replicas are ONE model: every rank builds it from the same seeds (the legacy
+    # MLPs / encoders draw from the global torch RNG); only the data (reel) differs per rank
+    torch.manual_seed(42)
+    method = VolSurfs(meshes, max_rays=max_rays, nr_warmup_iters=500, seed=42, **kw)
     method.init_optim()
+    torch.manual_seed(42 + rank)
     reel = synthetic_reel(args.views, args.res, dev, seed=42 + rank)
     target = args.target_hits // world               # each rank draws its share of the global batch
     state = {"nr_rays": 512, "it": 0, "rays": 0, "hits": 0}
@@ -186,11 +198,18 @@ def run_train(args, world, rank, dev, dist):
     barrier()
     fixed_ms = (time.perf_counter() - t1) / 50 * 1e3
     state["nr_rays"] = keep
+    in_sync = None
     if dist is not None:
         t = torch.tensor([dt, float(state["rays"]), float(state["hits"])], device=dev, dtype=torch.float64)
         dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
         dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
         dt, state["rays"], state["hits"] = t[0].item(), t[1].item(), t[2].item()
+        # the replicas must still be one model after the run: same parameters bit for bit
+        ck = torch.stack([p.detach().double().sum() for g in method.optimizer.param_groups for p in g["params"]])
+        hi, lo = ck.clone(), ck.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        in_sync = bool((hi == lo).all().item())
     if rank == 0:
         ms = dt / args.steps * 1e3
         nparams = sum(p.numel() for g in method.optimizer.param_groups for p in g["params"])
@@ -204,6 +223,7 @@ def run_train(args, world, rank, dev, dist):
             # (capped: the 64-ray loop forfeits the traversal look-ahead, whose prefetch is sized for the
             #  dynamic ray count, so on a host-bound loop it can be SLOWER than the real iterations)
             "fixed_ms_per_iter": fixed_ms, "fixed_share": min(1.0, fixed_ms / ms),
+            "replicas_in_sync": in_sync,
             "config": {"workload": ("BASELINE configs[2]: legacy permutohash (24x2, 2^18) + MLP [128,128,64] appearance"
                                     if legacy else "SH neural-texture appearance (configs[1]'s model)")
                        + f", K={args.shells} subdiv-{args.subdiv} shells, {args.views} views of {args.res}x{args.res}"
@@ -212,6 +232,7 @@ def run_train(args, world, rank, dev, dist):
                          f"{args.warmup}..{args.warmup + args.steps}",
                        "parameters": nparams, "parallelism": f"data-parallel x{world}"},
         }
+        out.update(dist_info(dist, args))
         print(json.dumps(out))
 
 
@@ -277,7 +298,8 @@ def run_dtu(args, world, rank, dev, dist):
                                    "shells with SH neural textures, NerfHash background (3-D hash grid 24x2 2^18 + "
                                    "MLPs 51-64-64-64-65 / 80-64-64-3 on the fp32 matrix cores), 32 contracted samples "
                                    f"per ray through the packed ops, {nb} batches of {batch} random pixels per frame",
-                       "bg_samples_per_frame": N * 32, "parallelism": f"data-parallel x{world}"}}))
+                       "bg_samples_per_frame": N * 32, "parallelism": f"data-parallel x{world}"},
+            **dist_info(dist, args)}))
 
 
 def run_render(args, world, rank, dev, dist):
@@ -318,8 +340,41 @@ def run_render(args, world, rank, dev, dist):
                                    "shells, SH neural textures, white background, one chunk"}}))
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here —
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` on 127.0.0.1, a free port — as a
+    CHILD process (this parent has not touched the GPU and never does), pass rank 0's JSON line
+    through and exit with the launcher's status."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    for l in r.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if r.returncode != 0 or len(lines) != 1:
+        print(f"[bench] the {args.gpus}-rank launch failed (status {r.returncode}, {len(lines)} result lines)",
+              file=sys.stderr)
+        sys.exit(r.returncode or 1)
+    print(lines[0])
+    sys.exit(0)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            self_launch(args)          # does not return
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks",
+              file=sys.stderr)
+        sys.exit(2)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -467,6 +522,7 @@ def main():
             out["roofline"]["traffic_note"] = traffic_note
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pipe, args.cpu_sample_rays)
+        out.update(dist_info(dist, args))
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

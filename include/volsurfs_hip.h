@@ -241,6 +241,17 @@ int vsa_nt_encode_fwd(const vsa_nt_plan* plan, const void* tables_h, const float
 int vsa_nt_mlp_fwd(const vsa_nt_plan* plan, const void* weights_h, const void* features,
                    const int32_t* seg_start, uint8_t* texels, void* pre_out, void* stream);
 
+/* Steps 3 + 4 in ONE launch (the reference's `Sequential(encoding, network)` is one tiny-cuda-nn
+ * call per corner batch, models/neural_texture.py:63-79, 153): a wave hash-grid encodes 64
+ * consecutive slots (a lane per slot, all levels, table entries gathered through L2) and runs
+ * the MLP on them straight from registers (csrc/nt_fused.hip).  Bit-identical to
+ * vsa_nt_encode_fwd + vsa_nt_mlp_fwd.  features: NULL, or the blocked feature planes of
+ * vsa_nt_encode_fwd, which are then written as well (vsa_nt_mlp_bwd recomputes the forward
+ * from them).  pre_out: as vsa_nt_mlp_fwd (optional, tests). */
+int vsa_nt_encode_mlp_fwd(const vsa_nt_plan* plan, const void* tables_h, const void* weights_h,
+                          const float* slot_xy, const int32_t* seg_start, void* features,
+                          uint8_t* texels, void* pre_out, void* stream);
+
 /* Backward of step 4: recomputes the forward per 32-slot tile, back-propagates
  * grad_rows (f16, already multiplied by grad_scale) through sigmoid (round = STE)
  * and the three layers on MFMA.  Overwrites `features` IN PLACE with the feature

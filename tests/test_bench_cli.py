@@ -59,3 +59,43 @@ def test_training_workload_lines(workload):
 def test_render_workload_line():
     d = _run("--workload", "render", "--res", "128", "--shells", "2", "--subdiv", "3", "--steps", "3", "--warmup", "1")
     assert d["unit"] == "Mrays/s" and d["value"] > 0 and d["baked"]["Mrays/s"] > 0
+
+
+def test_world_size_that_contradicts_gpus_is_refused():
+    """A launcher that started a different number of ranks than --gpus says: exit non-zero before
+    anything touches a GPU (runs on CPU)."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True,
+                       text=True, timeout=120, cwd=ROOT, env=env)
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr and r.stdout.strip() == ""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_gpus_flag_launches_the_ranks_itself(scaling):
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks (gloo on one device
+    here: the pool gives one GPU per box) and reports what the process group really was."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
+                        "--single-device", "--scaling", scaling, "--res", "128", "--shells", "2", "--subdiv", "3",
+                        "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["dist_backend"] == "gloo"
+    assert d["scaling"] == scaling and d["value"] > 0
+    assert d["config"]["global_rays"] == (128 * 128 if scaling == "strong" else 2 * 128 * 128)
+
+
+@pytest.mark.gpu
+def test_data_parallel_training_replicas_stay_one_model():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
+                        "--single-device", "--workload", "train-permuto", "--res", "128", "--views", "3",
+                        "--shells", "2", "--subdiv", "3", "--steps", "6", "--warmup", "3", "--target-hits", "4096"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["replicas_in_sync"] is True

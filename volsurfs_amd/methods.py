@@ -22,8 +22,7 @@ class _ShadeStage(torch.autograd.Function):
     def forward(ctx, tables, weights, method, hit_slot, hit_uv, rays_d):
         bank = method.bank
         tex_uv = bank.mark_and_compact(hit_slot, hit_uv, method.face_uvs)
-        bank.encode()
-        bank.mlp()
+        bank.evaluate(need_features=tables.requires_grad or weights.requires_grad)
         # (torch.is_grad_enabled() is always False inside Function.forward: decide from the inputs)
         act = torch.empty(hit_slot.shape[0], hit_slot.shape[1], 4, device=hit_slot.device) \
             if (tables.requires_grad or weights.requires_grad) else None
@@ -519,8 +518,7 @@ class VolSurfs(torch.nn.Module):
         hit_t, hit_slot, hit_uv = self.raytracer.trace_all(rays_o, rays_d)
         nr_hits = (hit_slot >= 0).sum()
         tex_uv = bank.mark_and_compact(hit_slot, hit_uv, self.face_uvs)
-        bank.encode()
-        bank.mlp()
+        bank.evaluate()
         act = torch.empty(self.nr_meshes, N, 4, device=rays_o.device)
         tris = self.raytracer.tris
         rgb_k, alpha_k, _, _ = bank.shade(hit_slot, tex_uv, rays_d, tris, act_out=act)

@@ -13,6 +13,7 @@ x = (shell*2 + type)*4 + degree.
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -22,6 +23,7 @@ from . import _lib
 MAX_SHELLS, MAX_DEG, MAX_LEVELS = 16, 4, 16
 DOM_BLOCK = 4096
 WEIGHTS_PER_TEX = 8192
+FUSED_FORWARD = os.environ.get("VSA_NT_FUSED", "1") != "0"
 
 
 class Plan(ctypes.Structure):
@@ -206,8 +208,7 @@ class NeuralTextureBank(torch.nn.Module):
         _lib.call("vsa_nt_compact", ctypes.byref(self.plan), self.marks, self.slot_of,
                   self.texel_of_slot, self.slot_xy, self.seg_start, self.block_scratch,
                   _lib.stream_ptr())
-        self.encode()
-        self.mlp()
+        self.evaluate(need_features=False)
         self.baked = True
         return self
 
@@ -266,6 +267,26 @@ class NeuralTextureBank(torch.nn.Module):
         _lib.call("vsa_nt_mlp_fwd", ctypes.byref(self.plan), self.weights_h, self.features,
                   self.seg_start, self.texels, pre, _lib.stream_ptr())
         return (self.rows_dense(self.texels), pre) if want_pre else self.texels
+
+    def encode_mlp(self, write_features=True, want_pre=False):
+        """encode() + mlp() as ONE launch (csrc/nt_fused.hip; bit-identical results).
+        write_features=False: inference — the feature planes are neither written nor read."""
+        self.wait_params()
+        pre = None
+        if want_pre:
+            pre = torch.zeros(self.slot_capacity, 32, dtype=torch.float16, device=self.texels.device)
+        _lib.call("vsa_nt_encode_mlp_fwd", ctypes.byref(self.plan), self.tables_h, self.weights_h,
+                  self.slot_xy, self.seg_start, self.features if write_features else None,
+                  self.texels, pre, _lib.stream_ptr())
+        return (self.rows_dense(self.texels), pre) if want_pre else self.texels
+
+    def evaluate(self, need_features=True):
+        """Texel rows of the compacted slots: the fused launch, or — VSA_NT_FUSED=0 — the
+        level-major encode kernel followed by the MLP kernel (A/B switch, tools/README)."""
+        if FUSED_FORWARD:
+            return self.encode_mlp(write_features=need_features)
+        self.encode()
+        return self.mlp()
 
     def rows_dense(self, buf):
         """Tests / export: the per-degree rows of `texels` or `grad_rows` re-laid as

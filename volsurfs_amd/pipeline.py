@@ -186,6 +186,8 @@ class KShellPipeline:
             "nt_mark_compact": N * K * 20 + bank.dom_total * (1 + 1 + 1 + 4) + P * 12,
             "nt_encode_fwd": P * 8 + feats + ntex * bank.n_entries * 4,
             "nt_mlp_fwd": feats + rows_u8 + ntex * 8192 * 2,
+            # fused: texel centre in (per texture), feature planes + texel rows out, parameters once
+            "nt_encode_mlp_fwd": slot_models * 8 + feats + rows_u8 + ntex * (bank.n_entries * 4 + 8192 * 2),
             "nt_shade_fwd": gathers + N * K * 16,
             "nt_shade_bwd": gathers + N * K * 16 + rows_f16,
             "nt_mlp_bwd": 2 * feats + 2 * rows_f16 + ntex * 8192 * (2 + 4),
@@ -243,10 +245,15 @@ class KShellPipeline:
         tex_uv = T.run("nt_mark_compact",
                        lambda: bank.mark_and_compact(hit_slot, hit_uv, self.face_uvs), record,
                        bytes=acct.get("nt_mark_compact", 0))
-        T.run("nt_encode_fwd", bank.encode, record, bytes=acct.get("nt_encode_fwd", 0))
         mlp_flops = getattr(self, "mlp_flops_fwd", 0)
-        T.run("nt_mlp_fwd", bank.mlp, record, bytes=acct.get("nt_mlp_fwd", 0), flops=mlp_flops,
-              bound="mfma")
+        from . import neural_textures as _nt
+        if _nt.FUSED_FORWARD:      # encode + MLP as one launch (csrc/nt_fused.hip)
+            T.run("nt_encode_mlp_fwd", bank.encode_mlp, record, bytes=acct.get("nt_encode_mlp_fwd", 0),
+                  flops=mlp_flops, bound="mfma")
+        else:
+            T.run("nt_encode_fwd", bank.encode, record, bytes=acct.get("nt_encode_fwd", 0))
+            T.run("nt_mlp_fwd", bank.mlp, record, bytes=acct.get("nt_mlp_fwd", 0), flops=mlp_flops,
+                  bound="mfma")
         rgb_k, alpha_k, _, _ = T.run(
             "nt_shade_fwd", lambda: bank.shade(hit_slot, tex_uv, rays_d, self.tracer.tris,
                                                act_out=self._act),
