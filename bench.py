@@ -49,6 +49,14 @@ def parse():
     ap.add_argument("--shells", type=int, default=5)
     ap.add_argument("--subdiv", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--noise", type=float, default=0.0, help="frame workload: radial noise of the shells (0: perfect spheres)")
+    ap.add_argument("--atlas-charts", type=int, default=0,
+                    help="frame workload: cut every shell's uv parameterisation into G x G randomly packed charts")
+    ap.add_argument("--init", default="tcnn", choices=["tcnn", "spread"],
+                    help="frame workload: parameter initialisation (tcnn: U(+-1e-4) tables; spread: U(+-1))")
+    ap.add_argument("--no-noisy", action="store_true",
+                    help="skip the second, non-ideal scene (noise 0.05, 6x6 uv charts, spread parameters) "
+                         "that the default frame line reports as value_noisy")
     ap.add_argument("--no-graph", action="store_true", help="time the eager path instead of the HIP-graph replay")
     ap.add_argument("--by-shell", action="store_true",
                     help="1 GPU: run the multi-GPU schedule (shell-by-shell hash-grid backward, eager) "
@@ -340,6 +348,41 @@ def run_render(args, world, rank, dev, dist):
                                    "shells, SH neural textures, white background, one chunk"}}))
 
 
+def noisy_scene(args, dev, use_graph, steps=50):
+    """The same step on a NON-IDEAL scene: BASELINE's frame on perfect
+    spheres with one continuous uv chart and near-zero parameters is a best case — real shells
+    are bumpy marching-cubes meshes whose xatlas charts fragment the texel footprint.  Here:
+    radial noise 0.05, every shell's parameterisation cut into 6x6 randomly packed charts,
+    U(+-1) table entries.  Reported beside the headline, never instead of it."""
+    from volsurfs_amd.pipeline import KShellPipeline
+    pipe = KShellPipeline.synthetic(K=args.shells, subdiv=args.subdiv, res=args.res, device=dev, seed=42,
+                                    noise=0.05, atlas_charts=6, init="spread")
+    for _ in range(3):
+        pipe.step()
+    pipe.stats()
+    run = pipe.step
+    if use_graph:
+        try:
+            pipe.capture_graph()
+            run = pipe.replay
+        except Exception:
+            run = pipe.step
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    N = pipe.nr_rays
+    return {"value_noisy": N / dt / 1e6,
+            "noisy": {"scene": pipe.scene_desc, "ms_per_step": dt * 1e3, "steps": steps,
+                      "h": (pipe.last_hits or 0) / float(N * pipe.K), "hits_per_frame": pipe.last_hits,
+                      "unique_texels_per_frame": pipe.last_slots,
+                      "Mhits/s": (pipe.last_hits or 0) / dt / 1e6}}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here —
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` on 127.0.0.1, a free port — as a
@@ -404,7 +447,8 @@ def main():
         from volsurfs_amd.parallel import shard_bands
         rows = shard_bands(args.res, rank, world)
     pipe = KShellPipeline.synthetic(K=args.shells, subdiv=args.subdiv, res=args.res, device=dev,
-                                    seed=42, gt_seed=42 if strong else 42 + rank, rows=rows)
+                                    seed=42, gt_seed=42 if strong else 42 + rank, rows=rows,
+                                    noise=args.noise, atlas_charts=args.atlas_charts, init=args.init)
     N = pipe.nr_rays
 
     def barrier():
@@ -508,7 +552,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": pipe.dtype_desc, "data": "synthetic",
-            "config": dict(pipe.config_desc(world), launch="hip-graph replay" if use_graph else "eager"),
+            "config": dict(pipe.config_desc(world), launch="hip-graph replay" if use_graph else "eager",
+                           scene=getattr(pipe, "scene_desc", None)),
             "roofline": roof,
             # hit fraction per (ray, shell) and the rate per hit: 71 % of the (ray, shell) pairs of this
             # frame are misses that cost almost nothing, so Mrays/s alone overstates the shading rate
@@ -520,6 +565,8 @@ def main():
         }
         if traffic_note:
             out["roofline"]["traffic_note"] = traffic_note
+        if world == 1 and not args.no_noisy and not (args.noise or args.atlas_charts):
+            out.update(noisy_scene(args, dev, use_graph))
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pipe, args.cpu_sample_rays)
         out.update(dist_info(dist, args))

@@ -14,7 +14,14 @@ published algorithm (Instant-NGP / tiny-cuda-nn `GridEncoding` with
             fmaf — immaterial for an unpinned restatement) ; cell = floor(pos) ; frac = pos - cell
   index   = dense (x + y*res_l) while the stride fits size_l, else
             XOR_d(cell_d * prime_d), primes (1, 2654435761) ; index %= size_l
-  feature = sum_corners w_c * table[index_c]   (bilinear)
+  feature = bilinear over the 4 corners, ACCUMULATED IN THE PARAMETER TYPE (half), as the
+            published kernel does (tiny-cuda-nn include/tiny-cuda-nn/encodings/grid.h,
+            kernel_grid: `result = fma((T)weight, grid_val(pos_grid_local), result)` with
+            T = __half, weight = prod_d (1 - frac_d | frac_d) in float, corners in index
+            order, bit 0 = x): four half-precision FMAs, one rounding each.
+            `accumulate="f32"` keeps round 1-2's restatement (fp32 sum, rounded once) so that
+            the texel-flip rate between the two can be reported (tests/test_parity_report.py).
+            The backward follows kernel_grid_backward: d table[index_c] += weight (float) * dL/dfeature.
   MLP     = bias-free, ReLU hidden, no output activation, fp16 weights and
             activations (this restatement accumulates each layer in fp32 and
             rounds the activations to fp16; tiny-cuda-nn accumulates in fp16 —
@@ -66,35 +73,103 @@ class GridGeometry:
         return idx % size
 
 
-def hashgrid_forward(geom, table, x):
+GRID_ACCUMULATE = "f16"     # module default: the published kernel's half-precision FMA chain
+
+
+def _grid_cells(geom, l, x):
+    """Level l: corner indices [4,B] int64 and corner weights [4,B] fp32 (index order, bit 0 = x)."""
+    pos = x * np.float32(geom.scale[l]) + np.float32(0.5)
+    cell = torch.floor(pos)
+    frac = pos - cell
+    c = cell.to(torch.int64) & 0xFFFFFFFF
+    idx, w = [], []
+    for corner in range(4):
+        dx, dy = corner & 1, (corner >> 1) & 1
+        wx = frac[:, 0] if dx else 1 - frac[:, 0]
+        wy = frac[:, 1] if dy else 1 - frac[:, 1]
+        idx.append(geom.index(l, (c[:, 0] + dx) & 0xFFFFFFFF, (c[:, 1] + dy) & 0xFFFFFFFF))
+        w.append(wx * wy)
+    return torch.stack(idx), torch.stack(w)
+
+
+class _HashGridF16(torch.autograd.Function):
+    """Forward: per level `acc = fma(half(w_c), table_h[idx_c], acc)` over the corners in half
+    precision (each FMA evaluated exactly in float64 — an 11-bit x 11-bit product plus an 11-bit
+    addend of comparable exponent fits 53 bits — and rounded ONCE to half by numpy's direct
+    double -> half conversion).  Backward: float corner weights, as kernel_grid_backward."""
+
+    @staticmethod
+    def forward(ctx, geom, table, x):
+        tab = table.detach().half().numpy()
+        outs, saved = [], []
+        for l in range(geom.n_levels):
+            idx, w = _grid_cells(geom, l, x.detach())
+            w16 = w.numpy().astype(np.float16).astype(np.float64)
+            acc = np.zeros((x.shape[0], 2), dtype=np.float16)
+            for corner in range(4):
+                val = tab[geom.offset[l] + idx[corner].numpy()].astype(np.float64)
+                acc = (w16[corner][:, None] * val + acc.astype(np.float64)).astype(np.float16)
+            outs.append(torch.from_numpy(acc))
+            saved.append((idx, w))
+        ctx.geom, ctx.saved, ctx.shape, ctx.dtype = geom, saved, table.shape, table.dtype
+        return torch.cat(outs, dim=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        geom = ctx.geom
+        gt = torch.zeros(ctx.shape, dtype=torch.float32)
+        g = g.float()
+        for l, (idx, w) in enumerate(ctx.saved):
+            gl = g[:, 2 * l:2 * l + 2]
+            for corner in range(4):
+                gt.index_add_(0, geom.offset[l] + idx[corner], w[corner][:, None] * gl)
+        return None, gt.to(ctx.dtype), None
+
+
+def hashgrid_forward(geom, table, x, accumulate=None):
     """table [n_entries, 2] (any float dtype; used as fp16 values), x [B,2] fp32.
-    Returns features [B, 32] fp16 (level-major)."""
+    Returns features [B, 32] fp16 (level-major).  accumulate: "f16" (the published kernel's
+    half FMA chain; module default GRID_ACCUMULATE) or "f32" (fp32 sum rounded once)."""
+    accumulate = accumulate or GRID_ACCUMULATE
+    if accumulate == "f16":
+        return _HashGridF16.apply(geom, table, x)
+    assert accumulate == "f32"
     tab = table.half().float()
     outs = []
     for l in range(geom.n_levels):
-        pos = x * np.float32(geom.scale[l]) + np.float32(0.5)
-        cell = torch.floor(pos)
-        frac = pos - cell
-        c = cell.to(torch.int64) & 0xFFFFFFFF
+        idx, w = _grid_cells(geom, l, x)
         feat = torch.zeros(x.shape[0], 2, dtype=torch.float32)
         for corner in range(4):
-            dx, dy = corner & 1, (corner >> 1) & 1
-            wx = frac[:, 0] if dx else 1 - frac[:, 0]
-            wy = frac[:, 1] if dy else 1 - frac[:, 1]
-            idx = geom.index(l, (c[:, 0] + dx) & 0xFFFFFFFF, (c[:, 1] + dy) & 0xFFFFFFFF)
-            feat = feat + (wx * wy)[:, None] * tab[geom.offset[l] + idx]
+            feat = feat + w[corner][:, None] * tab[geom.offset[l] + idx[corner]]
         outs.append(feat)
     return torch.cat(outs, dim=1).half()
 
 
-def mlp_forward(w1, w2, w3, x_h, n_out):
-    """w1 [64,32], w2 [64,64], w3 [P,64] (fp16 values), x_h [B,32] fp16.
-    fp32 accumulate, fp16 activations.  Returns [B, n_out] fp16."""
+def mlp_forward(w1, w2, w3, x_h, n_out, accumulate="f32"):
+    """w1 [64,32], w2 [64,64], w3 [P,64] (fp16 values), x_h [B,32] fp16.  fp16 activations.
+    accumulate="f32" (default, what the MFMA path does): each layer's dot products in fp32,
+    rounded to fp16 once.  accumulate="f16": a MODEL of FullyFusedMLP's half accumulator
+    fragments (wmma m16n16k16 with `fragment<accumulator, ..., __half>`): the running sum is
+    rounded to half after every 16-deep k-step, products inside a step summed in fp32 — the
+    tensor core's internal order is not published, so this only brackets the effect (the
+    texel-flip rate between the two modes is reported by tests/test_parity_report.py).
+    Returns [B, n_out] fp16."""
     f = lambda t: t.half().float()
-    h = torch.relu(f(x_h) @ f(w1).t()).half()
-    h = torch.relu(f(h) @ f(w2).t()).half()
-    o = (f(h) @ f(w3).t()).half()
-    return o[:, :n_out]
+
+    def layer(a_h, w, relu):
+        a, wf = f(a_h), f(w)
+        if accumulate == "f32":
+            o = a @ wf.t()
+        else:
+            assert accumulate == "f16"
+            o = torch.zeros(a.shape[0], wf.shape[0])
+            for k in range(0, a.shape[1], 16):
+                o = (o + a[:, k:k + 16] @ wf[:, k:k + 16].t()).half().float()
+        return (torch.relu(o) if relu else o).half()
+
+    h = layer(x_h, w1, True)
+    h = layer(h, w2, True)
+    return layer(h, w3, False)[:, :n_out]
 
 
 PRIMES = (1, 2654435761, 805459861)

@@ -43,6 +43,9 @@ def test_frame_workload_line():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert 0 < d["h"] <= 1
+    # the non-ideal scene beside the headline (noisy shells, fragmented uv charts, spread parameters)
+    assert d["value_noisy"] > 0 and d["noisy"]["unique_texels_per_frame"] > 0 and 0 < d["noisy"]["h"] <= 1
+    assert "charts" in d["noisy"]["scene"] and "perfect spheres" in d["config"]["scene"]
 
 
 @pytest.mark.gpu

@@ -3,6 +3,8 @@ import numpy as np
 import pytest
 import torch
 
+CONFIG0_GRAD_REL_MAX = 2e-6      # 2x measured: 7.7e-7 (fp32 models; profiles/r03/measured_bounds.txt)
+
 
 def _method(K=2, max_rays=4096):
     from volsurfs_amd.mesh import nested_shells
@@ -536,7 +538,9 @@ def test_baseline_config0_plumbing_case_matches_cpu_restatement():
         for l, (w, b) in zip(lin, layers):
             for got, want in ((l.weight.grad.cpu(), w.grad), (l.bias.grad.cpu(), b.grad)):
                 assert want.abs().max() > 0
-                assert (got - want).abs().max() <= 2e-2 * want.abs().max()        # fp16 composite backward
+                rel0 = float((got - want).abs().max() / want.abs().max())
+                print(f"MEASURED config0 {key} grad_rel_max={rel0:.3e}")
+                assert rel0 <= CONFIG0_GRAD_REL_MAX                               # fp16 composite backward
                 assert torch.nn.functional.cosine_similarity(got.flatten(), want.flatten(), dim=0) > 0.999
 
 

@@ -7,6 +7,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+TWO_RANK_GRAD_REL_MAX = 4e-4     # 2x measured: 1.6e-4 (profiles/r03/measured_bounds.txt)
+
 from volsurfs_amd.parallel import (GradientOverlap, allreduce_gradients, gather_frame, shard_chunks,
                                    shard_indices)
 
@@ -246,5 +248,6 @@ def test_two_rank_strong_scaling_on_the_hip_pipeline_equals_one_rank():
         assert (bands[r].reshape(len(rows), res, 3) == rgb[rows]).all()          # forward: bit-identical
     for got, ref in ((gw, one.bank.weights.grad.cpu().numpy()), (gt, one.bank.tables.grad.cpu().numpy())):
         s = abs(ref).max()
-        assert s > 0 and abs(got - ref).max() <= 2e-2 * s                          # f16 chain, two partial sums
+        print(f"MEASURED two_rank grad_rel_max={abs(got - ref).max() / s:.3e}")
+        assert s > 0 and abs(got - ref).max() <= TWO_RANK_GRAD_REL_MAX * s        # f16 chain, two partial sums
         assert (got * ref).sum() / ((got ** 2).sum() ** 0.5 * (ref ** 2).sum() ** 0.5) > 0.9995

@@ -4,6 +4,10 @@ import numpy as np
 import pytest
 import torch
 
+# per K: (MLP weights, hash tables) max gradient error relative to the tensor's largest entry against
+# the independent oracle: 2x the values measured on MI355X (profiles/r03/measured_bounds.txt)
+GRAD_BOUND = {1: (8e-4, 1.4e-3), 3: (9e-4, 4e-3), 9: (0.28, 0.12)}
+
 
 def _oracle(pipe):
     from oracle import pipeline as opipe
@@ -34,8 +38,9 @@ def test_pipeline_matches_oracle(K, subdiv, res):
     e_a = np.abs(pipe.to_ray_order(pipe.surfs_alpha).cpu().numpy() - ref["surfs_alpha"])
     # identical except where an 8-bit texel flipped by one step (fp32 summation
     # order inside the MLP: MFMA vs torch-CPU) — see tests/test_nt_shade.py
-    assert (e_rgb > 1e-5).mean() < 0.05 and e_rgb.max() < 0.05
-    assert (e_a > 1e-5).mean() < 0.05 and e_a.max() < 0.05
+    # (measured: <= 2.6e-4 of the values differ, by <= 3.7e-3; bounds = 2x)
+    assert (e_rgb > 1e-5).mean() < 6e-4 and e_rgb.max() < 8e-3
+    assert (e_a > 1e-5).mean() < 6e-4 and e_a.max() < 8e-3
     # composited colour: BASELINE north_star asks 1e-4 on RGB; fp16 composite => the
     # bulk is bit-identical, the flipped-texel pixels move by a few fp16 ulps
     # (measured, profiles/r02/parity_report.json: 8e-5 .. 7e-4 of the pixels above 1e-4, max 1.5e-3 —
@@ -43,12 +48,13 @@ def test_pipeline_matches_oracle(K, subdiv, res):
     # tests/test_parity_report.py, which removes the MLP's summation order, is bit-exact)
     e = np.abs(rgb.cpu().numpy() - ref["rgb"])
     assert np.median(e) == 0.0
-    assert (e <= 1e-4).mean() > 0.99
-    assert e.max() < 1e-2
+    assert (e <= 1e-4).mean() > 0.999        # measured: <= 4.3e-4 of the values above 1e-4, max 1.5e-3
+    assert e.max() < 3e-3
     # gradients w.r.t. every hash table and MLP (north_star: 1e-3 on grads, here as a
     # relative bound on each tensor plus direction)
     gw, gt = pipe.bank.weights.grad.cpu(), pipe.bank.tables.grad.cpu()
     assert len(ref["grads"]) == K * 8
+    worst_w = worst_t = 0.0
     for x, (g_t, g_w) in ref["grads"].items():
         cw = torch.nn.functional.cosine_similarity(gw[x], g_w, dim=0)
         ct = torch.nn.functional.cosine_similarity(gt[x].flatten(), g_t.flatten(), dim=0)
@@ -57,7 +63,13 @@ def test_pipeline_matches_oracle(K, subdiv, res):
         # with the scalar and the per-lane work split)
         cos_min = 0.995 if K <= 3 else 0.98
         assert cw > cos_min and ct > cos_min, (x, cw, ct)
-        assert (gw[x] - g_w).abs().max() <= (5e-2 if K <= 3 else 0.25) * g_w.abs().max()
+        worst_w = max(worst_w, float((gw[x] - g_w).abs().max() / g_w.abs().max()))
+        worst_t = max(worst_t, float((gt[x] - g_t).abs().max() / g_t.abs().max()))
+    print(f"MEASURED pipeline_e2e K={K} res={res} rgb_max={e.max():.3e} rgb_frac_over_1e-4={(e > 1e-4).mean():.3e} "
+          f"surfs_rgb_max={e_rgb.max():.3e} surfs_frac={(e_rgb > 1e-5).mean():.3e} gw_rel_max={worst_w:.3e} gt_rel_max={worst_t:.3e}")
+    # 2x the measured error against the independent oracle (whose gradients are the reference's own
+    # fp16 autograd, loss scale 128: itself noisy, and K = 9 puts the inner shells behind eight others)
+    assert worst_w <= GRAD_BOUND[K][0] and worst_t <= GRAD_BOUND[K][1]
 
 
 @pytest.mark.gpu

@@ -164,4 +164,44 @@ __device__ __forceinline__ CellCorners cell_corners(const LevelGeom& g, float x,
   return c;
 }
 
+// The feature of one level at one texel: bilinear blend of the cell's four table entries
+// (packed f16x2 words e[], corner weights w[] in fp32).
+// NT_ENC_ACC_F16 = 1 (default): tiny-cuda-nn's published kernel_grid —
+// `result = fma((T)weight, grid_val(corner), result)` with T = __half over the corners in index
+// order — i.e. four packed half FMAs (v_pk_fma_f16: one rounding each) on the weight rounded to
+// half; oracle/tcnn_like.py hashgrid_forward(accumulate="f16").  4 conversions + 4 FMAs.
+// NT_ENC_ACC_F16 = 0: the fp32 sum rounded once that rounds 1-2 restated (accumulate="f32"):
+// 8 mixed-precision multiplies + 8 adds + 1 pack.
+#ifndef NT_ENC_ACC_F16
+#define NT_ENC_ACC_F16 1
+#endif
+__device__ __forceinline__ unsigned enc_blend(const unsigned e[4], const float w[4]) {
+#if NT_ENC_ACC_F16
+  half2_t acc = {(_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    // (pinned: hipcc would fold (half)(fx * fy) into v_fma_mixlo_f16, ONE rounding of the exact
+    // product; the published kernel rounds the float product first, then casts it to half)
+    const _Float16 wh = (_Float16)vsa_pin_f32(w[k]);
+    const half2_t w2 = {wh, wh};
+    acc = __builtin_elementwise_fma(w2, __builtin_bit_cast(half2_t, e[k]), acc);
+  }
+  return __builtin_bit_cast(unsigned, acc);
+#else
+  float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    // w * (float)entry in ONE instruction per feature (v_fma_mix_f32 with a zero addend: the
+    // f16 -> f32 conversion is exact, so the product is the same single rounding as
+    // convert-then-multiply)
+    f0 = f0 + enc_mul_mix<0>(e[k], w[k]);
+    f1 = f1 + enc_mul_mix<1>(e[k], w[k]);
+  }
+  half2_t r;
+  r.x = (_Float16)f0;
+  r.y = (_Float16)f1;
+  return __builtin_bit_cast(unsigned, r);
+#endif
+}
+
 }  // namespace

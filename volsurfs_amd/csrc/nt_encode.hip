@@ -157,25 +157,10 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[u][k] = v[u - 1][k];
           }
-          float f0 = 0.f, f1 = 0.f;
+          unsigned ew[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-#if NT_ENC_MIX
-            // w * (float)entry in ONE instruction per feature (v_fma_mix_f32 with a zero addend:
-            // the f16 -> f32 conversion is exact, so the product is the same single rounding as
-            // convert-then-multiply; saves the 8 conversions of a (slot, level))
-            const unsigned eb = __builtin_bit_cast(unsigned, v[u][k]);
-            f0 = f0 + enc_mul_mix<0>(eb, cr[u].w[k]);
-            f1 = f1 + enc_mul_mix<1>(eb, cr[u].w[k]);
-#else
-            f0 = f0 + cr[u].w[k] * (float)v[u][k].x;
-            f1 = f1 + cr[u].w[k] * (float)v[u][k].y;
-#endif
-          }
-          half2_t r;
-          r.x = (_Float16)f0;
-          r.y = (_Float16)f1;
-          outw[u] = __builtin_bit_cast(unsigned, r);
+          for (int k = 0; k < 4; ++k) ew[k] = __builtin_bit_cast(unsigned, v[u][k]);
+          outw[u] = enc_blend(ew, cr[u].w);
         }
         unsigned* op = reinterpret_cast<unsigned*>(out) + nt_feat_in_plane(nl, s0);
         if (s0 >= first && s0 + ENC_UNROLL_FWD <= last) {

@@ -39,7 +39,7 @@ namespace {
 constexpr int FU_BLOCK = 256;
 constexpr int FU_WAVES = FU_BLOCK / 64;
 #ifndef NT_FU_WGS_PER_CU
-#define NT_FU_WGS_PER_CU 3
+#define NT_FU_WGS_PER_CU 2
 #endif
 constexpr int FU_WGS_PER_CU = NT_FU_WGS_PER_CU;
 #ifndef NT_FU_BATCH
@@ -49,60 +49,141 @@ constexpr int FU_BATCH = NT_FU_BATCH;
 #ifndef NT_FU_W_PER_GROUP
 #define NT_FU_W_PER_GROUP 1      /* 1/16 unit per further 8-channel output group */
 #endif
+#ifndef NT_FU_DIAG
+#define NT_FU_DIAG 0             /* diagnostic builds (WRONG results): 1 no table gathers, 2 no MLP, 4 no XCD grouping */
+#endif
 
-// the packed f16x2 feature of one level at the lane's slot (nt_encode_fwd's inner expression)
-__device__ __forceinline__ unsigned fu_blend(const unsigned e[4], const CellRefS& c) {
-  float f0 = 0.f, f1 = 0.f;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    f0 = f0 + enc_mul_mix<0>(e[k], c.w[k]);
-    f1 = f1 + enc_mul_mix<1>(e[k], c.w[k]);
-  }
-  half2_t r;
-  r.x = (_Float16)f0;
-  r.y = (_Float16)f1;
-  return __builtin_bit_cast(unsigned, r);
-}
+// Row-run staging (NT_FU_STAGE=1; built, bit-exact, measured SLOWER — off by default).
+// A 64-lane dword gather costs the vector cache at least 16 tag look-ups (it works a quad of lanes
+// at a time: PMC TCP_TOTAL_CACHE_ACCESSES = 25 per gather instruction here, 299 M per launch),
+// however few lines the lanes share.  But the wave's 64 slots are neighbouring texels of ONE
+// texture row: at a level they touch the cells cx0 .. cx63 + 1 of the grid rows cy and cy + 1, and
+// the hash leaves x un-multiplied, so cells 4B .. 4B + 3 of a row are the aligned 16-byte block
+// ((4B ^ h) & mask & ~3) of the table, permuted by t ^ (h & 3).  So lane j < nb fetches block j of
+// each of the two rows with one 16-byte LDS-DMA (nb = blocks covering the run: 2 .. 57 at 2048^2)
+// and every lane then picks its four corners out of the wave's LDS scratch.  Taken when the wave's
+// slots lie in one texel row in ascending x (checked per unit) and the run fits 64 blocks (per
+// level); the per-lane gathers remain for the rest (row changes, the finest levels of the small
+// textures, dense rows that wrap at the table's end).
+// Measured (profiles/r03/fused_forward.md): look-ups 299 M -> 186 M (an LDS-DMA still costs its
+// quads whatever its active lanes), VALU instructions 188 M -> 210 M, issue cycles +37 %, two
+// dependent waits per batch instead of one: 0.65 -> 0.85 ms.
+#ifndef NT_FU_STAGE
+#define NT_FU_STAGE 0     /* measured: see the comment above and DESIGN.md 9.1a */
+#endif
+typedef __attribute__((address_space(3))) void* fu_lds_vp;
+constexpr int FU_ROW_DWORDS = 256;                         // 64 blocks x 4 entries per staged row
+constexpr int FU_SCR_DWORDS = FU_BATCH * 2 * FU_ROW_DWORDS; // one wave's scratch (FU_BATCH levels x 2 rows)
 
-// levels [L0, L0 + FU_BATCH) of the lane's slot: all gathers first, then the blends
+// levels [L0, L0 + FU_BATCH) of the lane's slot: all fetches first, then the blends
 template <int LH, int L0>
 __device__ __forceinline__ void fu_encode_batch(const vsa_nt_plan& plan, int lh,
                                                 const unsigned* __restrict__ tab, float x, float y,
+                                                bool run_ok, unsigned* scr, int lane,
                                                 unsigned F[16]) {
   CellRefS c[FU_BATCH];
   unsigned e[FU_BATCH][4];
+  bool fast[FU_BATCH];          // wave-uniform
+  int base0[FU_BATCH], base1[FU_BATCH];    // cell coordinate of a staged row's first entry (scalars)
+  unsigned sw0[FU_BATCH], sw1[FU_BATCH];   // the rows' position swizzles (h & 3), scalars
+#if NT_FU_STAGE
+  // the previous batch's corner reads have left the scratch before it is written again
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
 #pragma unroll
   for (int b = 0; b < FU_BATCH; ++b) {
     const int l = L0 + b;
     const LevelGeom g = level_geom(plan, l);
     c[b] = cell_ref_s(g, x, y);
-    unsigned idx[4];
     const bool hashed = LH >= 0 ? l >= LH : l >= lh;   // wave-uniform
-    if (hashed)
-      cell_indices<true>(g, c[b].cx, c[b].cy, idx);
-    else
-      cell_indices<false>(g, c[b].cx, c[b].cy, idx);
     const unsigned* tl = tab + plan.level_offset[l];
+    fast[b] = false;
+#if NT_FU_STAGE
+    if (run_ok) {
+      const int cx0 = __builtin_amdgcn_readlane((int)c[b].cx, 0), cx63 = __builtin_amdgcn_readlane((int)c[b].cx, 63);
+      const int cy0 = __builtin_amdgcn_readfirstlane((int)c[b].cy);
+      int b0, b1, nb;
+      unsigned a0, a1;          // this lane's block of row 0 / row 1 (entry index)
+      bool ok;
+      if (hashed) {
+        const unsigned h0 = (unsigned)cy0 * PRIME_Y, h1 = h0 + PRIME_Y;
+        b0 = b1 = cx0 & ~3;
+        nb = ((cx63 + 1 - b0) >> 2) + 1;
+        const unsigned cell4 = (unsigned)(b0 + 4 * lane);
+        a0 = (cell4 ^ h0) & g.mask & ~3u;
+        a1 = (cell4 ^ h1) & g.mask & ~3u;
+        sw0[b] = h0 & 3u, sw1[b] = h1 & 3u;
+        ok = nb <= 64;
+      } else {
+        // dense: entry = cx + cy * res; each row is staged from its own 16-byte aligned start
+        const int r0 = cx0 + cy0 * (int)g.res, r1 = r0 + (int)g.res;
+        const int st0 = r0 & ~3, st1 = r1 & ~3;
+        b0 = cx0 - (r0 - st0), b1 = cx0 - (r1 - st1);
+        const int n0 = ((cx63 + 1 - b0) >> 2) + 1, n1 = ((cx63 + 1 - b1) >> 2) + 1;
+        nb = n0 > n1 ? n0 : n1;
+        a0 = (unsigned)(st0 + 4 * lane), a1 = (unsigned)(st1 + 4 * lane);
+        sw0[b] = sw1[b] = 0u;
+        // no wrap at the table's end (grid_index's % size: the per-lane path handles it), no negative cell
+        ok = nb <= 64 && cx0 >= 0 && cy0 >= 0 && (long long)r1 + (cx63 - cx0) + 1 < (long long)g.size &&
+             (long long)st1 + 4 * nb <= (long long)g.size;
+      }
+      base0[b] = b0, base1[b] = b1;
+      if (ok) {
+        fast[b] = true;
+        if (lane < nb) {
+          __builtin_amdgcn_global_load_lds((const void*)(tl + a0), (fu_lds_vp)(scr + (2 * b) * FU_ROW_DWORDS), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((const void*)(tl + a1), (fu_lds_vp)(scr + (2 * b + 1) * FU_ROW_DWORDS), 16, 0, 0);
+        }
+      }
+    }
+#endif
+    if (!fast[b]) {
+      unsigned idx[4];
+      if (hashed)
+        cell_indices<true>(g, c[b].cx, c[b].cy, idx);
+      else
+        cell_indices<false>(g, c[b].cx, c[b].cy, idx);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) e[b][k] = tl[idx[k]];
+      for (int k = 0; k < 4; ++k) e[b][k] = (NT_FU_DIAG & 1) ? (idx[k] & 0x03ff03ffu) | ((unsigned)(size_t)tl & 1u) : tl[idx[k]];
+    }
   }
+#if NT_FU_STAGE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the staged rows have landed (LDS-DMA is ordered by vmcnt only)
 #pragma unroll
-  for (int b = 0; b < FU_BATCH; ++b) F[L0 + b] = fu_blend(e[b], c[b]);
+  for (int b = 0; b < FU_BATCH; ++b) {
+    if (fast[b]) {
+      const unsigned* r0 = scr + (2 * b) * FU_ROW_DWORDS;
+      const unsigned* r1 = r0 + FU_ROW_DWORDS;
+      const unsigned p0 = (unsigned)((int)c[b].cx - base0[b]), p1 = (unsigned)((int)c[b].cx - base1[b]);
+      e[b][0] = r0[p0 ^ sw0[b]];
+      e[b][1] = r0[(p0 + 1u) ^ sw0[b]];
+      e[b][2] = r1[p1 ^ sw1[b]];
+      e[b][3] = r1[(p1 + 1u) ^ sw1[b]];
+    }
+  }
+#endif
+#pragma unroll
+  for (int b = 0; b < FU_BATCH; ++b) F[L0 + b] = enc_blend(e[b], c[b].w);
 }
 
 template <int LH, int L0 = 0>
 __device__ __forceinline__ void fu_encode(const vsa_nt_plan& plan, int lh,
                                           const unsigned* __restrict__ tab, float x, float y,
-                                          unsigned F[16]) {
+                                          bool run_ok, unsigned* scr, int lane, unsigned F[16]) {
   static_assert(16 % FU_BATCH == 0, "batch");
-  fu_encode_batch<LH, L0>(plan, lh, tab, x, y, F);
-  if constexpr (L0 + FU_BATCH < 16) fu_encode<LH, L0 + FU_BATCH>(plan, lh, tab, x, y, F);
+  fu_encode_batch<LH, L0>(plan, lh, tab, x, y, run_ok, scr, lane, F);
+  if constexpr (L0 + FU_BATCH < 16) fu_encode<LH, L0 + FU_BATCH>(plan, lh, tab, x, y, run_ok, scr, lane, F);
 }
 
 // lanes p (lower half) and p + 32 (upper half) exchange: afterwards `a` holds, on BOTH halves, what
 // tile A's lane needs (lower: its own a, upper: the lower lane's b) and `b` what tile B's lane needs
+// (the builtin, not inline asm: v_permlane32_swap needs wait states after a VALU write of its
+// operands and before a VALU read of its results that only the compiler's hazard pass inserts —
+// the asm form produced wrong tiles at one register allocation and right ones at another)
 __device__ __forceinline__ void fu_swap(unsigned& a, unsigned& b) {
-  asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
 }
 
 // Work split.  The launch's work = every active texture's slots in 64-slot units, laid on one
@@ -117,7 +198,7 @@ __device__ __forceinline__ void fu_for_each_piece(const vsa_nt_plan& plan,
                                                   const int* __restrict__ seg_start, Body&& body) {
   const int n_all = plan.nr_shells * 2 * VSA_NT_MAX_DEG;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n_x = (gridDim.x % 8 == 0) ? 8 : 1;           // groups of workgroups that share an L2
+  const int n_x = (gridDim.x % 8 == 0 && !(NT_FU_DIAG & 4)) ? 8 : 1;   // groups of workgroups that share an L2
   const int x = blockIdx.x % n_x, j = blockIdx.x / n_x, J = gridDim.x / n_x;
   const int gw = j * FU_WAVES + wave, GW = J * FU_WAVES;  // this wave among its group's waves
   const int rgb_deg = plan.rgb_degrees, alpha_deg = plan.alpha_degrees;
@@ -183,6 +264,12 @@ __global__ __launch_bounds__(FU_BLOCK, FU_WGS_PER_CU) void nt_encmlp_fwd_kernel(
     const int* __restrict__ seg_start, unsigned* __restrict__ features,
     unsigned* __restrict__ texels, _Float16* __restrict__ pre_out) {
   __shared__ unsigned s_qt[257];      // thresholds of the 8-bit quantisation (nt_quant_table.h)
+#if NT_FU_STAGE
+  __shared__ __attribute__((aligned(16))) unsigned s_scr[FU_WAVES * FU_SCR_DWORDS];
+  unsigned* scr = s_scr + (threadIdx.x >> 6) * FU_SCR_DWORDS;
+#else
+  unsigned* scr = nullptr;
+#endif
   const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
   for (int i = threadIdx.x; i < 257; i += FU_BLOCK) s_qt[i] = NT_QUANT_THR[i];
   __syncthreads();
@@ -211,8 +298,13 @@ __global__ __launch_bounds__(FU_BLOCK, FU_WGS_PER_CU) void nt_encmlp_fwd_kernel(
           xy_next = centre(un < u_end ? un : u);
         }
         const int slot0 = begin + u * 64;
+        // one texel row, ascending x (slots are in texel order: vsa_nt_compact): the row-run staging applies
+        const float x_lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xy.x), 0));
+        const float x_hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xy.x), 63));
+        const float y_lo = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, xy.y)));
+        const bool run_ok = __all(xy.y == y_lo && xy.x >= x_lo && xy.x <= x_hi) != 0;
         unsigned F[16];
-        fu_encode<LH>(plan, lh, tab, xy.x, xy.y, F);
+        fu_encode<LH>(plan, lh, tab, xy.x, xy.y, run_ok, scr, lane, F);
         if constexpr (FEAT) {
           const int s = slot0 + lane;
           if (s < end) {
@@ -232,6 +324,10 @@ __global__ __launch_bounds__(FU_BLOCK, FU_WGS_PER_CU) void nt_encmlp_fwd_kernel(
           bxa[s] = __builtin_bit_cast(half8_t, make_uint4(F[8 * s], F[8 * s + 1], F[8 * s + 2], F[8 * s + 3]));
           bxb[s] = __builtin_bit_cast(half8_t, make_uint4(F[8 * s + 4], F[8 * s + 5], F[8 * s + 6], F[8 * s + 7]));
         }
+#if NT_FU_DIAG & 2
+        asm volatile("" ::"v"(bxa[0]), "v"(bxa[1]), "v"(bxb[0]), "v"(bxb[1]));
+        continue;
+#endif
         half8_t b2[4], b3[4];
         float16_t acc3;
         mlp_tile_fwd(wf, bxa, b2, b3, acc3);

@@ -107,7 +107,8 @@ __global__ void integrate_fwd_kernel(const int* __restrict__ start_end,
 }
 
 // VolumeRenderingGPU.cuh:945-1033.  bug_compat reproduces :1021 (the z lane of
-// `values` reads column 1), off by default.
+// `values` reads column 1); the Python mirror passes it ON by default
+// (VolumeRendering.bug_compat = True: compute what the reference computes).
 template <int D>
 __global__ void integrate_bwd_kernel(const int* __restrict__ start_end,
                                      const float* __restrict__ g_out,

@@ -76,7 +76,8 @@ class _GridEncode(torch.autograd.Function):
         direct = accumulate_into_grad(ctx.owner) if ctx.owner is not None else None
         g_tables = direct if direct is not None else torch.zeros(ctx.shape, device=x.device)
         g_out = g_out.contiguous()
-        if x.shape[0] >= BINNED_BWD_MIN_POINTS:
+        # (the binned path slices a level into <= 32 runs of 2^13 entries: tables up to 2^18 entries)
+        if x.shape[0] >= BINNED_BWD_MIN_POINTS and max(ctx.plan.level_size[:ctx.plan.n_levels]) <= (1 << 18):
             # very large batches: bin the contributions by table slice once, accumulate densely
             n = ctypes.c_longlong()
             _lib.call("vsa_grid_encode_bwd_binned_workspace", ctypes.byref(ctx.plan), x.shape[0],
@@ -440,7 +441,7 @@ class PermutoEncoding(torch.nn.Module):
 
     def __init__(self, pos_dim, capacity, nr_levels, nr_feat_per_level, scale_list,
                  appply_random_shift_per_level=True, concat_points=False,
-                 concat_points_scaling=1.0, init_scale=1e-5, seed=0, device="cuda"):
+                 concat_points_scaling=1.0, init_scale=1e-5, seed=None, device="cuda"):
         super().__init__()
         if nr_feat_per_level != 2 or not 2 <= pos_dim <= 4 or nr_levels > GRID_MAX_LEVELS:
             raise _lib.VolsurfsHipError("PermutoEncoding: 2 features per level, pos_dim 2..4, "
@@ -451,6 +452,11 @@ class PermutoEncoding(torch.nn.Module):
         self.nr_feat_per_level = nr_feat_per_level
         self.scale_list = np.asarray(scale_list, np.float64)
         self.concat_points, self.concat_points_scaling = concat_points, concat_points_scaling
+        if seed is None:
+            # every instance draws its own values and per-level shifts from the global torch RNG, as
+            # the wrapped package does (the per-shell rgb / alpha models must not share their hash
+            # collisions); torch.manual_seed(...) before construction makes a model reproducible
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
         self.init_scale, self._seed = init_scale, seed
         g = torch.Generator().manual_seed(seed)
         self.lattice_values = torch.nn.Parameter(

@@ -59,9 +59,35 @@ def octahedral_uv(p):
     return np.stack([u * 0.5 + 0.5, v * 0.5 + 0.5], -1)
 
 
-def nested_shells(K=5, subdiv=6, r0=0.30, dr=0.01, noise=0.0, seed=0, device="cuda"):
+def chart_atlas(uv, charts, seed=0, gutter=0.02):
+    """Re-pack a continuous per-corner parameterisation [F,3,2] into charts x charts separate
+    charts, the way an atlas packer (xatlas in the reference's baker, baker.py:151) leaves real
+    shells: a face belongs to the cell of the charts x charts grid that holds its centroid; every
+    cell is moved to a random tile of the atlas, with a random flip / transposition and a gutter.
+    Neighbouring pixels that cross a chart border then touch texels far apart."""
+    rng = np.random.default_rng(seed)
+    G = int(charts)
+    cen = uv.mean(1)                                             # [F,2]
+    cell = np.clip(np.floor(cen * G), 0, G - 1).astype(np.int64)
+    cid = cell[:, 1] * G + cell[:, 0]
+    local = uv * G - cell[:, None, :]                            # ~[0,1] inside the cell (corners may poke out)
+    local = np.clip(local, -gutter / (1 - 2 * gutter) * 0.9, 1 + gutter / (1 - 2 * gutter) * 0.9)
+    perm = rng.permutation(G * G)
+    flip_u, flip_v, swap = (rng.integers(0, 2, G * G).astype(bool) for _ in range(3))
+    lu, lv = local[..., 0].copy(), local[..., 1].copy()
+    lu = np.where(flip_u[cid][:, None], 1 - lu, lu)
+    lv = np.where(flip_v[cid][:, None], 1 - lv, lv)
+    lu, lv = np.where(swap[cid][:, None], lv, lu), np.where(swap[cid][:, None], lu, lv)
+    tile = perm[cid]
+    tu, tv = (tile % G)[:, None], (tile // G)[:, None]
+    out = np.stack([(tu + gutter + lu * (1 - 2 * gutter)) / G, (tv + gutter + lv * (1 - 2 * gutter)) / G], -1)
+    return np.clip(out, 0.0, 1.0).astype(np.float32)
+
+
+def nested_shells(K=5, subdiv=6, r0=0.30, dr=0.01, noise=0.0, seed=0, device="cuda", atlas_charts=0):
     """K nested (optionally noisy) icospheres, inner -> outer, with per-corner
-    octahedral UVs (radii 0.30 + 0.01 k)."""
+    octahedral UVs (radii 0.30 + 0.01 k).  atlas_charts = G > 0 cuts the
+    parameterisation of every shell into G x G charts packed at random (chart_atlas)."""
     rng = np.random.default_rng(seed)
     base_v, f = icosphere(subdiv, 1.0)
     meshes = []
@@ -77,6 +103,8 @@ def nested_shells(K=5, subdiv=6, r0=0.30, dr=0.01, noise=0.0, seed=0, device="cu
         # pulled towards the face centroid's hemisphere so that no face straddles
         # the octahedral fold with wildly different uvs
         uv = octahedral_uv(base_v.astype(np.float64))[f].astype(np.float32)  # [F,3,2]
+        if atlas_charts:
+            uv = chart_atlas(uv.astype(np.float64), atlas_charts, seed=seed + 17 * k)
         meshes.append(TensorMesh(vv, f, uv, device=device))
     return meshes
 

@@ -22,10 +22,11 @@ class _ShadeStage(torch.autograd.Function):
     def forward(ctx, tables, weights, method, hit_slot, hit_uv, rays_d):
         bank = method.bank
         tex_uv = bank.mark_and_compact(hit_slot, hit_uv, method.face_uvs)
-        bank.evaluate(need_features=tables.requires_grad or weights.requires_grad)
-        # (torch.is_grad_enabled() is always False inside Function.forward: decide from the inputs)
-        act = torch.empty(hit_slot.shape[0], hit_slot.shape[1], 4, device=hit_slot.device) \
-            if (tables.requires_grad or weights.requires_grad) else None
+        # (torch.is_grad_enabled() is always False inside Function.forward and parameters keep
+        # requires_grad under no_grad: render_rays records whether the call is differentiated)
+        need = getattr(method, "_grad_on", True) and (tables.requires_grad or weights.requires_grad)
+        bank.evaluate(need_features=need)
+        act = torch.empty(hit_slot.shape[0], hit_slot.shape[1], 4, device=hit_slot.device) if need else None
         rgb, alpha, normals, _ = bank.shade(hit_slot, tex_uv, rays_d, method.raytracer.tris,
                                             want_normals=True, act_out=act)
         # backward reads the bank's per-frame state (slot_of, seg_start, texels, features): stamp it
@@ -197,6 +198,13 @@ class VolSurfs(torch.nn.Module):
             self.bank._params_event = self.optimizer.step(stream=self._optim_stream)
         else:
             self.optimizer.step()    # (refreshes bank.tables_h / weights_h inside the kernel)
+
+    def sync_params(self):
+        """Every reader of the parameters or the optimiser state outside the texture kernels
+        (save / load / bake / state_dict) goes through here: an `optim_step(overlap=True)` may
+        still be writing them on its side stream."""
+        if self.bank is not None:
+            self.bank.wait_params()
 
     legacy_grouped = True     # class-wide switch: False = the per-shell loop (tests compare the two)
 
@@ -402,6 +410,7 @@ class VolSurfs(torch.nn.Module):
             prof.end("meshes_raytracing")
             prof.start("ray_color_inference")
         if self.using_neural_textures:
+            self._grad_on = torch.is_grad_enabled()
             rgb_k, alpha_k, normals, tex_uv = _ShadeStage.apply(self.bank.tables, self.bank.weights,
                                                                 self, hit_slot, hit_uv, rays_d)
         else:
@@ -447,6 +456,7 @@ class VolSurfs(torch.nn.Module):
     @torch.no_grad()
     def bake(self):
         """Evaluate all texels of all 2K neural textures once into 8-bit texel rows."""
+        self.sync_params()
         b = self.bank
         full = NeuralTextureBank.full_capacity_rays(b.tex_res)
         baked = NeuralTextureBank(self.nr_meshes, full, sh_degree=b.rgb_degrees - 1,
@@ -564,6 +574,7 @@ class VolSurfs(torch.nn.Module):
             return None
         path = os.path.join(self.save_checkpoints_path, format(iter_nr, "07d"), "models")
         os.makedirs(path, exist_ok=True)
+        self.sync_params()       # parameters and moments are final on the current stream
         for key, (t, w) in self._model_states().items():
             torch.save({"tables": t.detach().cpu(), "weights": w.detach().cpu()}, os.path.join(path, f"{key}.pt"))
         for key, model in self.models.items():
@@ -582,6 +593,7 @@ class VolSurfs(torch.nn.Module):
         if getattr(self, "load_checkpoints_path", None) is None:
             return None
         path = os.path.join(self.load_checkpoints_path, format(iter_nr, "07d"), "models")
+        self.sync_params()       # no optimiser step is still writing what is about to be overwritten
         with torch.no_grad():
             for key, (t, w) in self._model_states().items():
                 f = os.path.join(path, f"{key}.pt")

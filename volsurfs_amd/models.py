@@ -68,6 +68,17 @@ def _mlp_plan(weights, biases):
     return p
 
 
+# torch.is_grad_enabled() is always False INSIDE Function.forward, and parameters keep
+# requires_grad=True under torch.no_grad(): the callers of the fused nodes record here whether the
+# call is being differentiated, so that inference (render, render_camera, background evaluation)
+# does not allocate and write the backward workspaces (z and GELU(z): M x sum(hidden) fp32 each).
+_CALL = {"grad": True}
+
+
+def _needs_backward(x, params):
+    return _CALL["grad"] and (x.requires_grad or any(p_.requires_grad for p_ in params if p_ is not None))
+
+
 def fused_mlp_supported(dims, x):
     """csrc/mlp_f32.hip: <= 6 linear layers, widths <= 128, hidden widths multiples of 32."""
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and 1 <= len(dims) - 1 <= MLP_MAX_LAYERS
@@ -92,7 +103,7 @@ class _FusedMLP(torch.autograd.Function):
         sizes = [ctypes.c_longlong() for _ in range(3)]
         _lib.call("vsa_mlp_workspace", ctypes.byref(plan), ctypes.c_longlong(M),
                   *[ctypes.byref(v) for v in sizes])
-        need = x.requires_grad or any(p_.requires_grad for p_ in params if p_ is not None)
+        need = _needs_backward(x, params)
         dev = x.device
         packed = torch.empty(max(sizes[0].value, 1), device=dev)
         z = torch.empty(max(sizes[1].value, 1), device=dev) if need else None
@@ -221,7 +232,7 @@ class _FusedMLPGrouped(torch.autograd.Function):
         if not all(p_.is_contiguous() for p_ in params):
             raise _lib.VolsurfsHipError("fused_mlp_grouped: contiguous parameters only")
         _, runs, (out_dim, hidden, packed_n), _, _ = _FusedMLPGrouped._descriptors(params, nl, has_bias, G)
-        need = x.requires_grad or any(p_.requires_grad for p_ in params)
+        need = _needs_backward(x, params)
         dev = x.device
         M = x.shape[0]
         y = torch.empty(M, out_dim, device=dev)
@@ -323,6 +334,7 @@ def fused_mlp_grouped(mlps, x, sizes):
             params.append(m.weight)
             if has_bias:
                 params.append(m.bias)
+    _CALL["grad"] = torch.is_grad_enabled()
     return _FusedMLPGrouped.apply(x, tuple(int(n) for n in sizes), has_bias, nl, *params)
 
 
@@ -366,6 +378,7 @@ class MLP(torch.nn.Module):
                 params.append(m.weight)
                 if self.bias:
                     params.append(m.bias)
+            _CALL["grad"] = torch.is_grad_enabled()
             return _FusedMLP.apply(x, bool(self.bias), *params)
         if MLP.fused and x.is_cuda and not getattr(self, "_warned_unfused", False):
             # not silent: a CUDA MLP outside what csrc/mlp_f32.hip covers (wider than 128, hidden

@@ -23,7 +23,10 @@ from . import _lib
 MAX_SHELLS, MAX_DEG, MAX_LEVELS = 16, 4, 16
 DOM_BLOCK = 4096
 WEIGHTS_PER_TEX = 8192
-FUSED_FORWARD = os.environ.get("VSA_NT_FUSED", "1") != "0"
+# encode + MLP as one launch (csrc/nt_fused.hip): bit-identical, measured a tie with the two-kernel
+# path on the training step (0.65 vs 0.64 ms: the vector cache's look-up rate bounds its gathers,
+# DESIGN.md 9.1a) -> opt-in
+FUSED_FORWARD = os.environ.get("VSA_NT_FUSED", "0") != "0"
 
 
 class Plan(ctypes.Structure):
@@ -281,8 +284,8 @@ class NeuralTextureBank(torch.nn.Module):
         return (self.rows_dense(self.texels), pre) if want_pre else self.texels
 
     def evaluate(self, need_features=True):
-        """Texel rows of the compacted slots: the fused launch, or — VSA_NT_FUSED=0 — the
-        level-major encode kernel followed by the MLP kernel (A/B switch, tools/README)."""
+        """Texel rows of the compacted slots: the level-major encode kernel followed by the MLP
+        kernel, or — VSA_NT_FUSED=1 — the fused launch (A/B switch, tools/README)."""
         if FUSED_FORWARD:
             return self.encode_mlp(write_features=need_features)
         self.encode()

@@ -100,11 +100,12 @@ class KShellPipeline:
         return out
 
     @classmethod
-    def synthetic(cls, K=5, subdiv=6, res=800, device="cuda", seed=42, rows=None, gt_seed=None, **kw):
+    def synthetic(cls, K=5, subdiv=6, res=800, device="cuda", seed=42, rows=None, gt_seed=None,
+                  noise=0.0, atlas_charts=0, **kw):
         """res: an int (square frame) or (H, W).  rows: optional LongTensor of image rows (whole
         8-row bands, parallel.shard_bands): the pipeline then renders only those rows of the
         frame — one rank's share under strong scaling — with the loss still the frame's mean."""
-        meshes = nested_shells(K=K, subdiv=subdiv, device=device)
+        meshes = nested_shells(K=K, subdiv=subdiv, device=device, noise=noise, atlas_charts=atlas_charts)
         H, W = (res, res) if isinstance(res, int) else res
         o, d = pinhole_rays(H, W, focal=1111.1 * min(H, W) / 800.0, cam_pos=(0.0, 0.0, -1.5),
                             device=device)
@@ -121,6 +122,9 @@ class KShellPipeline:
         p.grad_scale = float(n_frame)      # the f16 gradient chain is conditioned for 1 / (3 n_frame) per ray
         p.res = res
         p.subdiv = subdiv
+        p.scene_desc = (f"noise {noise}, {atlas_charts}x{atlas_charts} randomly packed uv charts per shell, "
+                        f"parameters {kw.get('init', 'tcnn')}-initialised") if (noise or atlas_charts) else \
+            "perfect spheres, one continuous octahedral uv chart, tcnn-initialised parameters"
         return p
 
     def reset_stage_timers(self):

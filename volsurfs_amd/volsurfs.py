@@ -162,7 +162,7 @@ def _check_pack(p, *tensors):
 class VolumeRendering:
     """include/volsurfs/VolumeRendering.cuh:69-97: static methods, same order of arguments."""
     # True (default) = compute what the reference computes, including its two slips:
-    # integrate_with_weights_3d_backward reads the y lane of grad_result for the z lane
+    # integrate_with_weights_3d_backward reads the y lane of `values` for the z lane of grad_weights
     # (kernels/volsurfs/VolumeRenderingGPU.cuh:1021) and median_depth_over_rays falls back to the
     # reference's value when no sample crosses the threshold (:407).  Opt out with
     # `VolumeRendering.bug_compat = False` for the mathematically intended result.
