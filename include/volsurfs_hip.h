@@ -521,6 +521,21 @@ int vsa_packed_integrate_fwd(const int32_t* start_end, const float* values, cons
 int vsa_packed_integrate_bwd(const int32_t* start_end, const float* g_out, const float* values,
                              const float* weights, float* g_values, float* g_weights,
                              int nr_rays, int dim, int bug_compat, void* stream);
+/* The background composite of render_contracted_bg (volsurfs_py/utils/background.py:93-111) as one
+ * launch each way: alpha = 1 - exp(-density dt), T = cumprod_one_minus_alpha_to_transmittance(
+ * (1 - alpha) + 1e-6) (VolumeRenderingGPU.cuh:28-78), w = alpha T, pred_rgb =
+ * integrate_with_weights_3d(rgb, w) (:127-177); backward = integrate_with_weights_3d_backward
+ * (:987-1033, bug_compat as above), the suffix sums of cumsum_over_rays(inverse) (:305-361) and
+ * cumprod_..._backward (:896-943) with a zero bg-transmittance gradient.  Bit-identical to the chain
+ * of the single ops above.  density, dt: [S] (or [S,1]); rgb, g_rgb: [S,3]; weights (optional out,
+ * what median_depth_over_rays takes): [S]; scratch: 2 S floats. */
+int vsa_packed_composite_fwd(const int32_t* start_end, const float* density, const float* dt,
+                             const float* rgb, float* pred_rgb, float* weights, int nr_rays,
+                             void* stream);
+int vsa_packed_composite_bwd(const int32_t* start_end, const float* density, const float* dt,
+                             const float* rgb, const float* g_pred_rgb, float* g_rgb,
+                             float* g_density, float* scratch, int nr_rays, int bug_compat,
+                             void* stream);
 /* median_depth_over_rays (:372-416); fallback_compat=1 reproduces VolumeRenderingGPU.cuh:407. */
 int vsa_packed_median_depth(const int32_t* start_end, const float* samples_z,
                             const float* weights, float threshold, float* out, int nr_rays,

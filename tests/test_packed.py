@@ -182,6 +182,54 @@ def test_hip_glue_matches_reference_fixture(golden_dir):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("bug_compat", [True, False])
+def test_fused_bg_composite_equals_the_op_sequence(golden_dir, bug_compat):
+    """vsa_packed_composite_fwd / _bwd (one launch each way) against the chain of single ops it
+    replaces in render_contracted_bg (background.py:93-111), on ragged rays (0, 1, 32, 33 .. 69
+    samples) and on the reference's own fixture: same fp32 operations in the same order, so the
+    colours, the weights and both gradients are bit-identical."""
+    from volsurfs_amd import volsurfs as V
+    from volsurfs_amd.background import _FusedBgComposite
+    z = np.load(os.path.join(golden_dir, "packed_glue.npz"))
+    se_r, S_r = _ragged(2000, 11)
+    g = np.random.default_rng(12)
+    cases = [(z["start_end"], z["density"], z["rgb"], z["dt"]),
+             (se_r, g.uniform(0.0, 30.0, (S_r, 1)).astype(np.float32), g.uniform(0, 1, (S_r, 3)).astype(np.float32),
+              g.uniform(1e-3, 0.2, (S_r, 1)).astype(np.float32))]
+    V.VolumeRendering.bug_compat = bug_compat
+    try:
+        for se, dens, col, dts in cases:
+            p = _pack(se)
+            p.samples_dt = torch.from_numpy(dts).cuda()
+            gp = torch.from_numpy(g.standard_normal((se.shape[0], 3)).astype(np.float32)).cuda()
+            outs = []
+            for fused in (False, True):
+                density = torch.from_numpy(dens).cuda().requires_grad_(True)
+                rgb = torch.from_numpy(col).cuda().requires_grad_(True)
+                if fused:
+                    pred, w = _FusedBgComposite.apply(p, rgb, density)
+                else:
+                    alpha = 1.0 - torch.exp(-density.view(-1, 1) * p.samples_dt)
+                    T, _ = V.CumprodOneMinusAlphaToTransmittanceFunc.apply(p, (1 - alpha) + 1e-6)
+                    w = alpha * T
+                    pred = V.IntegrateWithWeights3DFunc.apply(p, rgb, w)
+                (pred * gp).sum().backward()
+                outs.append((pred.detach(), w.detach(), rgb.grad, density.grad))
+            for a, b, name in zip(outs[0], outs[1], ("pred_rgb", "weights", "g_rgb", "g_density")):
+                assert torch.equal(a, b), (name, float((a - b).abs().max()))
+        # and against the fixture of the reference's own glue (bug_compat on: what the reference computes)
+        if bug_compat:
+            p = _pack(z["start_end"])
+            p.samples_dt = torch.from_numpy(z["dt"]).cuda()
+            density = torch.from_numpy(z["density"]).cuda().requires_grad_(True)
+            rgb = torch.from_numpy(z["rgb"]).cuda().requires_grad_(True)
+            pred, _ = _FusedBgComposite.apply(p, rgb, density)
+            np.testing.assert_allclose(pred.detach().cpu().numpy(), z["pred"], rtol=1e-5, atol=1e-6)
+    finally:
+        V.VolumeRendering.bug_compat = True
+
+
+@pytest.mark.gpu
 def test_render_contracted_bg_end_to_end_vs_oracle():
     """background.py:31-141 with a tiny stand-in radiance model: HIP packed path vs the
     oracle's serial restatement, values and gradients."""

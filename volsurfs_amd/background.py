@@ -60,6 +60,41 @@ def intersect_bounding_primitive(bounding_primitive, rays_o, rays_d):
             "is_hit": is_hit}
 
 
+FUSED_COMPOSITE = True      # False: the reference's chain of single ops (tests hold the two together)
+
+
+class _FusedBgComposite(torch.autograd.Function):
+    """background.py:93-111 (alpha from density, transmittance, NeRF weights, weighted sum of the
+    sample colours) as ONE launch forward and ONE backward — vsa_packed_composite_fwd / _bwd,
+    bit-identical to the chain of single ops below.  Returns (pred_rgb [N,3], weights [S,1])."""
+
+    @staticmethod
+    def forward(ctx, pack, rgb, density):
+        rgb, density = _lib.check_f32(rgb.contiguous()), _lib.check_f32(density.contiguous())
+        S, N = rgb.shape[0], pack.get_nr_rays()
+        if density.numel() != S or pack.samples_dt.numel() != S or rgb.shape[1] != 3:
+            raise _lib.VolsurfsHipError("fused bg composite: rgb [S,3], density [S,1], pack with S samples")
+        pred = torch.empty(N, 3, device=rgb.device)
+        weights = torch.empty(S, 1, device=rgb.device)
+        _lib.call("vsa_packed_composite_fwd", pack.ray_start_end_idx, density, pack.samples_dt, rgb, pred,
+                  weights, N, _lib.stream_ptr())
+        ctx.save_for_backward(rgb, density)
+        ctx.pack = pack
+        ctx.mark_non_differentiable(weights)
+        return pred, weights
+
+    @staticmethod
+    def backward(ctx, g_pred, _g_weights):
+        rgb, density = ctx.saved_tensors
+        pack, ctx.pack = ctx.pack, None
+        g_rgb, g_density = torch.empty_like(rgb), torch.empty_like(density)
+        scratch = torch.empty(2 * rgb.shape[0], device=rgb.device)
+        _lib.call("vsa_packed_composite_bwd", pack.ray_start_end_idx, density, pack.samples_dt, rgb,
+                  g_pred.contiguous(), g_rgb, g_density, scratch, pack.get_nr_rays(),
+                  bool(VolumeRendering.bug_compat), _lib.stream_ptr())
+        return None, g_rgb, g_density
+
+
 def render_contracted_bg(model_bg, raycast, nr_samples_bg, jitter_samples=False, iter_nr=None,
                          render_expected_depth=False, render_median_depth=True):
     """background.py:31-141: 32 inverse-depth samples behind t_far, scene contraction,
@@ -68,10 +103,13 @@ def render_contracted_bg(model_bg, raycast, nr_samples_bg, jitter_samples=False,
                                          nr_samples_bg, jitter_samples)          # sampling.py:62-86
     cpack = RaySampler.contract_samples(pack)                                   # background.py:72
     rgb, density = model_bg(cpack.samples_3d, cpack.samples_dirs, iter_nr)      # :86-90
-    alpha = 1.0 - torch.exp(-density.view(-1, 1) * cpack.samples_dt)            # :93-95
-    T, _ = CumprodOneMinusAlphaToTransmittanceFunc.apply(cpack, (1 - alpha) + 1e-6)   # :99-104
-    weights = alpha * T
-    pred_rgb = IntegrateWithWeights3DFunc.apply(cpack, rgb, weights)            # :109-111
+    if FUSED_COMPOSITE and rgb.dtype == torch.float32 and rgb.dim() == 2 and rgb.shape[1] == 3:
+        pred_rgb, weights = _FusedBgComposite.apply(cpack, rgb, density.view(-1, 1))   # :93-111
+    else:
+        alpha = 1.0 - torch.exp(-density.view(-1, 1) * cpack.samples_dt)            # :93-95
+        T, _ = CumprodOneMinusAlphaToTransmittanceFunc.apply(cpack, (1 - alpha) + 1e-6)   # :99-104
+        weights = alpha * T
+        pred_rgb = IntegrateWithWeights3DFunc.apply(cpack, rgb, weights)            # :109-111
     expected = median = None
     if render_expected_depth:
         expected = VolumeRendering.integrate_with_weights_1d(pack, pack.samples_z, weights.detach())

@@ -73,7 +73,7 @@ constexpr int FU_BATCH = NT_FU_BATCH;
 #endif
 typedef __attribute__((address_space(3))) void* fu_lds_vp;
 constexpr int FU_ROW_DWORDS = 256;                         // 64 blocks x 4 entries per staged row
-constexpr int FU_SCR_DWORDS = FU_BATCH * 2 * FU_ROW_DWORDS; // one wave's scratch (FU_BATCH levels x 2 rows)
+[[maybe_unused]] constexpr int FU_SCR_DWORDS = FU_BATCH * 2 * FU_ROW_DWORDS; // one wave's scratch (FU_BATCH levels x 2 rows)
 
 // levels [L0, L0 + FU_BATCH) of the lane's slot: all fetches first, then the blends
 template <int LH, int L0>
@@ -84,9 +84,9 @@ __device__ __forceinline__ void fu_encode_batch(const vsa_nt_plan& plan, int lh,
   CellRefS c[FU_BATCH];
   unsigned e[FU_BATCH][4];
   bool fast[FU_BATCH];          // wave-uniform
+#if NT_FU_STAGE
   int base0[FU_BATCH], base1[FU_BATCH];    // cell coordinate of a staged row's first entry (scalars)
   unsigned sw0[FU_BATCH], sw1[FU_BATCH];   // the rows' position swizzles (h & 3), scalars
-#if NT_FU_STAGE
   // the previous batch's corner reads have left the scratch before it is written again
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif

@@ -155,6 +155,115 @@ __global__ void cumprod_bwd_kernel(const int* __restrict__ start_end,
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// The background composite as ONE launch each way.  render_contracted_bg
+// (utils/background.py:93-111) chains  alpha = 1 - exp(-density dt);  T = cumprod_to_transmittance(
+// (1 - alpha) + 1e-6);  w = alpha T;  rgb = integrate_with_weights_3d(rgb_s, w)  through four
+// elementwise torch kernels and two packed launches (and twice that in backward, with T, w, lv and
+// the suffix sums written and re-read).  Here the half-wave that owns a ray keeps all of it in
+// registers.  Every fp32 operation is the one the op sequence performs, in its order — the scans
+// are sub_scan_mul / sub_scan_add of the stand-alone kernels, the suffix sums run over the reversed
+// ray exactly as cumsum_kernel(inverse) does — so results are bit-identical to the chain
+// (tests/test_packed.py::test_fused_bg_composite_equals_the_op_sequence).
+__global__ void composite_packed_fwd_kernel(const int* __restrict__ start_end,
+                                            const float* __restrict__ density,
+                                            const float* __restrict__ dt,
+                                            const float* __restrict__ rgb, float* __restrict__ pred,
+                                            float* __restrict__ weights, int N) {
+  PK_RAY_PROLOGUE();
+  float acc[3] = {0.f, 0.f, 0.f};
+  float carry = 1.0f;
+  for (int c = 0; c < n; c += SUB) {
+    const int i = c + l;
+    const bool in = i < n;
+    const long long s = i0 + (in ? i : 0);
+    const float e = expf((-density[s]) * dt[s]);
+    const float alpha = 1.0f - e;
+    const float a1 = (1.0f - alpha) + 1e-6f;
+    const float incl = sub_scan_mul(in ? a1 : 1.0f, l);
+    float excl = __shfl_up(incl, 1, SUB);
+    if (l == 0) excl = 1.0f;
+    const float T = carry * excl;
+    carry *= __shfl(incl, SUB - 1, SUB);
+    if (in) {
+      const float w = alpha * T;
+      if (weights) weights[s] = w;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) acc[d] += w * rgb[s * 3 + d];
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float r = sub_reduce_add(acc[d]);
+    if (l == 0) pred[ray * 3 + d] = r;        // (a ray without samples: 0, as integrate's zero-initialised output)
+  }
+}
+
+// scratch: 2 floats per sample (lv = g_T T and g_w T of the forward sweep, read back by the
+// reversed sweep; a ray of the background path is one 32-sample chunk each way)
+__global__ void composite_packed_bwd_kernel(const int* __restrict__ start_end,
+                                            const float* __restrict__ density,
+                                            const float* __restrict__ dt,
+                                            const float* __restrict__ rgb,
+                                            const float* __restrict__ g_pred,
+                                            float* __restrict__ g_rgb, float* __restrict__ g_density,
+                                            float* __restrict__ scratch, int N, int bug_compat) {
+  PK_RAY_PROLOGUE();
+  if (n <= 0) return;
+  float g[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) g[d] = g_pred[ray * 3 + d];
+  float carry = 1.0f;
+  for (int c = 0; c < n; c += SUB) {      // forward sweep: T, then everything local to a sample
+    const int i = c + l;
+    const bool in = i < n;
+    const long long s = i0 + (in ? i : 0);
+    const float e = expf((-density[s]) * dt[s]);
+    const float alpha = 1.0f - e;
+    const float a1 = (1.0f - alpha) + 1e-6f;
+    const float incl = sub_scan_mul(in ? a1 : 1.0f, l);
+    float excl = __shfl_up(incl, 1, SUB);
+    if (l == 0) excl = 1.0f;
+    const float T = carry * excl;
+    carry *= __shfl(incl, SUB - 1, SUB);
+    if (in) {
+      const float w = alpha * T;
+      float gw = 0.f;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        g_rgb[s * 3 + d] = g[d] * w;                                     // integrate_bwd_kernel
+        const int col = (bug_compat && d == 2) ? 1 : d;
+        gw += g[d] * rgb[s * 3 + col];
+      }
+      const float gT = gw * alpha;                                       // w = alpha T
+      scratch[2 * s] = gT * T;                                           // lv (volume_rendering_funcs.py:152)
+      scratch[2 * s + 1] = gw * T;                                       // d w / d alpha
+    }
+  }
+  float csum = 0.0f;
+  for (int c = 0; c < n; c += SUB) {      // reversed sweep: suffix sums of lv, cumprod backward, the exp
+    const int i = c + l;
+    const bool in = i < n;
+    const long long s = in ? (long long)i1 - 1 - i : (long long)i0;
+    const float incl = sub_scan_add(in ? scratch[2 * s] : 0.0f, l);
+    const float cs = csum + incl;                                        // cumsumLV at this sample
+    float cs_next = __shfl_up(cs, 1, SUB);                               // ... at the sample after it on the ray
+    if (l == 0) cs_next = csum;
+    csum += __shfl(incl, SUB - 1, SUB);
+    if (in) {
+      const float dts = dt[s];
+      const float e = expf((-density[s]) * dts);
+      const float alpha = 1.0f - e;
+      const float a1 = (1.0f - alpha) + 1e-6f;
+      float ga1 = 0.f;
+      if (i > 0) ga1 = cs_next / fmaxf(a1, 1e-6f);                      // cumprod_bwd_kernel (g_bgT = 0); 0 for the last sample
+      const float g_alpha = scratch[2 * s + 1] + (-ga1);
+      const float gu = (-g_alpha) * e;                                   // alpha = 1 - e, e = exp(u)
+      g_density[s] = -(gu * dts);                                        // u = (-density) dt
+    }
+  }
+}
+
 // VolumeRenderingGPU.cuh:364-409.  fallback_compat reproduces :407
 // (samples_z[nr_samples-1] without idx_start); default is the ray's last sample.
 __global__ void median_depth_kernel(const int* __restrict__ start_end, const float* __restrict__ z,
@@ -718,6 +827,22 @@ extern "C" int vsa_packed_integrate_bwd(const int32_t* start_end, const float* g
   }
   PK_LAUNCH(integrate_bwd_kernel<3>, nr_rays, start_end, g_out, values, weights, g_values,
             g_weights, nr_rays, bug_compat);
+}
+extern "C" int vsa_packed_composite_fwd(const int32_t* start_end, const float* density,
+                                        const float* dt, const float* rgb, float* pred_rgb,
+                                        float* weights, int nr_rays, void* stream) {
+  PK_CHECK(nr_rays >= 0 && start_end && density && dt && rgb && pred_rgb);
+  PK_LAUNCH(composite_packed_fwd_kernel, nr_rays, start_end, density, dt, rgb, pred_rgb, weights,
+            nr_rays);
+}
+extern "C" int vsa_packed_composite_bwd(const int32_t* start_end, const float* density,
+                                        const float* dt, const float* rgb, const float* g_pred_rgb,
+                                        float* g_rgb, float* g_density, float* scratch, int nr_rays,
+                                        int bug_compat, void* stream) {
+  PK_CHECK(nr_rays >= 0 && start_end && density && dt && rgb && g_pred_rgb && g_rgb && g_density &&
+           scratch);
+  PK_LAUNCH(composite_packed_bwd_kernel, nr_rays, start_end, density, dt, rgb, g_pred_rgb, g_rgb,
+            g_density, scratch, nr_rays, bug_compat);
 }
 extern "C" int vsa_packed_median_depth(const int32_t* start_end, const float* samples_z,
                                        const float* weights, float threshold, float* out,

@@ -285,6 +285,132 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_q_kernel(
   hit_uv[2 * o + 1] = best.v;
 }
 
+// ---- persistent lanes.  With one (ray, shell) per lane for the lifetime of a wave, a wave lasts
+// as long as its slowest ray: PMC showed 37 % lane utilisation (a tile at the silhouette has a few
+// deep traversals and sixty-odd immediate misses; 71 % of the (ray, shell) pairs are misses).  Here
+// a wave owns the K x 64 (ray, shell) items of one 64-ray tile and a lane that finishes its item
+// takes the next one at the top of the next round (ballot + prefix count, no atomics: the pool is
+// the wave's own), so finished lanes go back to work instead of idling.  An item is traversed by
+// exactly the code above (same boxes, same triangle arithmetic, same order-independent closest hit),
+// so results are bit-identical.  The per-mesh constants (root, quantisation frame) are indexed per
+// lane, so they live in LDS.
+// MEASURED AND NOT ADOPTED (round 3, same box, profiles/r03/trace_persistent.txt): 0.28 -> 0.43 ms at
+// 800x800, K=5 (refilling only once 16 / 32 lanes are idle: 0.42 / 0.39).  A refilled lane starts at the
+// root while its neighbours are deep in their trees, so the "walk inner nodes until the whole wave
+// holds a leaf" rounds get longer for everybody, and the launch has a fifth of the waves (10 k) to
+// balance over the chip.  Kept behind -DTRACE_PERSISTENT=1 with its tests (tests/test_raytrace.py runs
+// whichever is built).
+#ifndef TRACE_REFILL_MIN
+#define TRACE_REFILL_MIN 1      /* idle lanes that trigger a refill round */
+#endif
+template <int STACK>
+__global__ __launch_bounds__(TRACE_BLOCK) void trace_q_persistent_kernel(
+    const uint4* __restrict__ qnodes, const float4* __restrict__ tris, Roots roots, Frames frames,
+    int K, const float* __restrict__ rays_o, const float* __restrict__ rays_d, int N, float t_min,
+    float* __restrict__ hit_t, int* __restrict__ hit_slot, float* __restrict__ hit_uv) {
+  __shared__ int s_stack[STACK][TRACE_BLOCK];
+  __shared__ float s_frame[VSA_MAX_SHELLS][8];    // lo.xyz, step.xyz, root (as int bits)
+  const int lane = threadIdx.x;
+  if (lane < K) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) s_frame[lane][j] = frames.f[lane][j];
+    s_frame[lane][6] = __int_as_float(roots.root[lane]);
+  }
+  __syncthreads();
+  const long long ray0 = (long long)blockIdx.x * TRACE_BLOCK;
+  const int rays_here = (int)min((long long)TRACE_BLOCK, (long long)N - ray0);
+  const int total = K * TRACE_BLOCK;              // items: shell-major, item = shell * 64 + ray of the tile
+  int next_item = 0;
+  // lane state
+  float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+  QRay qr = {};
+  Hit best = {};
+  long long out = 0;
+  int cur = TRACE_EMPTY, sp = 0;
+  bool busy = false;
+  while (true) {
+    // hand the next items to the idle lanes
+    const unsigned long long idle = __ballot(!busy);
+    if ((__popcll(idle) >= TRACE_REFILL_MIN || __ballot(busy) == 0ull) && next_item < total) {
+      const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+      const int item = next_item + rank;
+      if (!busy && item < total) {
+        const int mesh = item >> 6, r = item & 63;
+        if (r < rays_here) {
+          const long long n = ray0 + r;
+          ox = rays_o[3 * n], oy = rays_o[3 * n + 1], oz = rays_o[3 * n + 2];
+          dx = rays_d[3 * n], dy = rays_d[3 * n + 1], dz = rays_d[3 * n + 2];
+          const float* fr = s_frame[mesh];
+          const float gx = (ox - fr[0]) / fr[3] + 1.0f, gy = (oy - fr[1]) / fr[4] + 1.0f,
+                      gz = (oz - fr[2]) / fr[5] + 1.0f;
+          const float ix = 1.0f / (dx / fr[3]), iy = 1.0f / (dy / fr[4]), iz = 1.0f / (dz / fr[5]);
+          qr.ix = f32x2_t{ix, ix}, qr.iy = f32x2_t{iy, iy}, qr.iz = f32x2_t{iz, iz};
+          qr.cx = f32x2_t{-(gx * ix), -(gx * ix)};
+          qr.cy = f32x2_t{-(gy * iy), -(gy * iy)};
+          qr.cz = f32x2_t{-(gz * iz), -(gz * iz)};
+          best.t = INFINITY;
+          best.u = best.v = 0.f;
+          best.slot = -1;
+          best.id = 0x7fffffff;
+          cur = __float_as_int(fr[6]);
+          sp = 0;
+          out = (long long)mesh * N + n;
+          busy = true;
+        }
+      }
+      next_item += __popcll(idle);
+    }
+    if (__ballot(busy) == 0ull) {
+      if (next_item >= total) break;
+      continue;                       // (a tile's tail past N: items without a ray)
+    }
+    while ((unsigned)cur < (unsigned)TRACE_EMPTY) {
+      const uint4 a = qnodes[2 * (long long)cur], b = qnodes[2 * (long long)cur + 1];
+      float tn0, tn1;
+      const bool h0 = qbox_test(a.x, a.y, a.z, qr, t_min, best.t, tn0);
+      const bool h1 = qbox_test(a.w, b.x, b.y, qr, t_min, best.t, tn1);
+      const int c0 = (int)b.z, c1 = (int)b.w;
+      if (h0 && h1) {
+        const bool swap = tn1 < tn0;
+        s_stack[sp++][lane] = swap ? c0 : c1;
+        cur = swap ? c1 : c0;
+      } else if (h0) {
+        cur = c0;
+      } else if (h1) {
+        cur = c1;
+      } else {
+        cur = sp ? s_stack[--sp][lane] : TRACE_EMPTY;
+      }
+    }
+    if (cur != TRACE_EMPTY) {
+      const int code = ~cur;
+      const int first = code >> 4, cnt = code & 15;
+      for (int i0 = 0; i0 < cnt; i0 += 4) {
+        float4 tv[4][3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const long long s = first + min(i0 + i, cnt - 1);
+          tv[i][0] = tris[3 * s];
+          tv[i][1] = tris[3 * s + 1];
+          tv[i][2] = tris[3 * s + 2];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i0 + i < cnt)
+            tri_test(tv[i][0], tv[i][1], tv[i][2], ox, oy, oz, dx, dy, dz, t_min, first + i0 + i, best);
+      }
+      cur = sp ? s_stack[--sp][lane] : TRACE_EMPTY;
+    }
+    if (busy && cur == TRACE_EMPTY) {   // this lane's item is finished
+      hit_t[out] = best.slot >= 0 ? best.t : 0.0f;
+      hit_slot[out] = best.slot;
+      hit_uv[2 * out] = best.u;
+      hit_uv[2 * out + 1] = best.v;
+      busy = false;
+    }
+  }
+}
+
 // Per-hit attributes in the shape raytracelib returns them
 // (volsurfs.py:496-501): positions, face normals, barycentrics, original ids.
 __global__ void hit_attributes_kernel(const float4* __restrict__ tris,
@@ -365,6 +491,23 @@ extern "C" int vsa_trace_q(const uint32_t* qnodes, const float* tris, const int3
     r.root[i] = i < nr_meshes ? mesh_roots[i] : 0;
     for (int j = 0; j < 6; ++j) fr.f[i][j] = i < nr_meshes ? mesh_frames[6 * i + j] : 1.0f;
   }
+#ifndef TRACE_PERSISTENT
+#define TRACE_PERSISTENT 0     /* measured slower (0.28 -> 0.43 ms): see the kernel's comment */
+#endif
+#if TRACE_PERSISTENT
+  if (nr_meshes > 1) {     // a wave per 64-ray tile, its lanes shared out over the tile's K x 64 (ray, shell) items
+    dim3 grid(vsa_div_up(nr_rays, TRACE_BLOCK)), block(TRACE_BLOCK);
+    if (max_depth < 24)
+      hipLaunchKernelGGL(trace_q_persistent_kernel<24>, grid, block, 0, (hipStream_t)stream,
+                         reinterpret_cast<const uint4*>(qnodes), reinterpret_cast<const float4*>(tris),
+                         r, fr, nr_meshes, rays_o, rays_d, nr_rays, t_min, hit_t, hit_slot, hit_uv);
+    else
+      hipLaunchKernelGGL(trace_q_persistent_kernel<TRACE_STACK>, grid, block, 0, (hipStream_t)stream,
+                         reinterpret_cast<const uint4*>(qnodes), reinterpret_cast<const float4*>(tris),
+                         r, fr, nr_meshes, rays_o, rays_d, nr_rays, t_min, hit_t, hit_slot, hit_uv);
+    VSA_RETURN_LAUNCH_STATUS();
+  }
+#endif
   dim3 grid(vsa_div_up(nr_rays, TRACE_BLOCK), nr_meshes), block(TRACE_BLOCK);
   if (max_depth < 24)
     hipLaunchKernelGGL(trace_q_kernel<24>, grid, block, 0, (hipStream_t)stream,
