@@ -43,6 +43,9 @@ def parse():
                          "dealt to the ranks in 8-row bands, round-robin (parallel.shard_bands)")
     ap.add_argument("--grad-wire-dtype", default="f32", choices=["f32", "bf16"],
                     help="N > 1: width of the gradient all-reduce on the wire (bf16 halves the bytes, rounds the sum)")
+    ap.add_argument("--sharded-adam", action="store_true",
+                    help="N > 1, train workloads: reduce-scatter the gradients, Adam on each rank's slice of every "
+                         "tensor, all-gather the f16 copies (optim.ShardedFusedAdam) instead of all-reduce + full Adam")
     ap.add_argument("--target-hits", type=int, default=49152)
     ap.add_argument("--views", type=int, default=50)
     ap.add_argument("--res", type=int, default=800)
@@ -61,7 +64,9 @@ def parse():
     ap.add_argument("--by-shell", action="store_true",
                     help="1 GPU: run the multi-GPU schedule (shell-by-shell hash-grid backward, eager) "
                          "without the collectives, to price it")
-    ap.add_argument("--cpu-sample-rays", type=int, default=4096)
+    ap.add_argument("--cpu-sample-rays", type=int, default=16384,
+                    help="rays of the cpu_baseline sample: one evaluation chunk of the reference "
+                         "(test_rays_batch_size = 16 384, config/volsurfs/base_5.cfg:8; SURVEY 8d)")
     ap.add_argument("--dist-backend", default="nccl",
                     help="functional tests of the multi-rank path on one GPU: gloo + --single-device")
     ap.add_argument("--single-device", action="store_true",
@@ -124,10 +129,11 @@ def cpu_baseline(pipe, sample_rays):
     opipe.render_step(meshes, tabs, wts, bank.tex_index, bank.tex_res, o, d, gt)
     dt = time.perf_counter() - t0
     return {"value": n / dt / 1e6, "unit": "Mrays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} rays spread over the same frame, K={pipe.K}: brute-force closest hit "
-                      f"(oracle/raytrace_ref.c, 1 thread) + per-hit SH neural textures fwd+bwd "
-                      f"(oracle/neural_texture.py on torch-CPU, {torch.get_num_threads()} threads) + "
-                      f"composite fwd+bwd (oracle/composite.py); {dt:.1f} s"}
+            "frame_extrapolation_s": dt * pipe.nr_rays / n,
+            "sample": f"{n} rays (one evaluation chunk of the reference) spread over the same frame, K={pipe.K}: "
+                      f"brute-force closest hit (oracle/raytrace_ref.c, OpenMP over the host's cores) + per-hit SH "
+                      f"neural textures fwd+bwd (oracle/neural_texture.py on torch-CPU, {torch.get_num_threads()} "
+                      f"threads) + composite fwd+bwd (oracle/composite.py); {dt:.1f} s"}
 
 
 def synthetic_reel(n_views, res, device, seed=42):
@@ -161,7 +167,7 @@ def run_train(args, world, rank, dev, dist):
     # MLPs / encoders draw from the global torch RNG); only the data (reel) differs per rank
     torch.manual_seed(42)
     method = VolSurfs(meshes, max_rays=max_rays, nr_warmup_iters=500, seed=42, **kw)
-    method.init_optim()
+    method.init_optim(world=world, rank=rank, sharded=args.sharded_adam)
     torch.manual_seed(42 + rank)
     reel = synthetic_reel(args.views, args.res, dev, seed=42 + rank)
     target = args.target_hits // world               # each rank draws its share of the global batch
@@ -213,6 +219,7 @@ def run_train(args, world, rank, dev, dist):
         dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
         dt, state["rays"], state["hits"] = t[0].item(), t[1].item(), t[2].item()
         # the replicas must still be one model after the run: same parameters bit for bit
+        method.sync_params()
         ck = torch.stack([p.detach().double().sum() for g in method.optimizer.param_groups for p in g["params"]])
         hi, lo = ck.clone(), ck.clone()
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
@@ -238,7 +245,8 @@ def run_train(args, world, rank, dev, dist):
                          f" in a TensorReel, dynamic ray count -> {args.target_hits} hits per iteration, "
                          "L1 + FusedAdam(0.9, 0.99, 1e-15) + warm-up 500, iterations "
                          f"{args.warmup}..{args.warmup + args.steps}",
-                       "parameters": nparams, "parallelism": f"data-parallel x{world}"},
+                       "parameters": nparams, "parallelism": f"data-parallel x{world}"
+                       + (", sharded Adam (reduce-scatter / slice update / all-gather)" if args.sharded_adam and world > 1 else "")},
         }
         out.update(dist_info(dist, args))
         print(json.dumps(out))

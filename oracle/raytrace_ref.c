@@ -27,6 +27,9 @@ static float dot3(float ax, float ay, float az, float bx, float by, float bz) {
 void oracle_trace_bruteforce(const float* verts, const int32_t* faces, int nf,
                              const float* rays_o, const float* rays_d, int n, float t_min,
                              float* out_t, int32_t* out_tri, float* out_uv) {
+  /* rays are independent: the loop is shared out over the host's cores (same results);
+   * bench.py's cpu_baseline reports how many threads ran */
+#pragma omp parallel for schedule(static)
   for (int r = 0; r < n; ++r) {
     const float ox = rays_o[3 * r], oy = rays_o[3 * r + 1], oz = rays_o[3 * r + 2];
     const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz = rays_d[3 * r + 2];

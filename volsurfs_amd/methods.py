@@ -168,8 +168,11 @@ class VolSurfs(torch.nn.Module):
 
     # -- optimiser: apex FusedAdam(betas (0.9, 0.99), eps 1e-15, wd 0) of
     # base_method.py:87-94 == Adam with the same hyper-parameters
-    def init_optim(self):
-        from .optim import FusedAdam
+    def init_optim(self, world=1, rank=0, group=None, sharded=False):
+        """sharded=True (world > 1): optimiser state and update sharded over the ranks
+        (optim.ShardedFusedAdam: reduce-scatter -> Adam on a slice -> all-gather of the f16 copies);
+        its step() replaces the gradient all-reduce + step of trainer.train_step."""
+        from .optim import FusedAdam, ShardedFusedAdam
         half = {}
         if self.bank is not None:
             params = [self.bank.tables, self.bank.weights]
@@ -180,8 +183,12 @@ class VolSurfs(torch.nn.Module):
             params += list(self.bg_model.parameters())
         # one HIP launch per step for every tensor, fused with the f16 refresh of the texture
         # parameters and the next iteration's zero_grad (volsurfs_amd/optim.py, csrc/adam.hip)
-        self.optimizer = FusedAdam(params, lr=self.lr, betas=(0.9, 0.99), eps=1e-15,
-                                   weight_decay=0.0, half_copies=half)
+        if sharded and world > 1:
+            self.optimizer = ShardedFusedAdam(params, world, rank, group, lr=self.lr, betas=(0.9, 0.99),
+                                              eps=1e-15, weight_decay=0.0, half_copies=half)
+        else:
+            self.optimizer = FusedAdam(params, lr=self.lr, betas=(0.9, 0.99), eps=1e-15,
+                                       weight_decay=0.0, half_copies=half)
         from .schedulers import MultiStepLR
         self.scheduler_lr_decay = MultiStepLR(self.optimizer, milestones=self.lr_milestones, gamma=0.3)
         return self.optimizer
@@ -205,6 +212,8 @@ class VolSurfs(torch.nn.Module):
         still be writing them on its side stream."""
         if self.bank is not None:
             self.bank.wait_params()
+        if hasattr(getattr(self, "optimizer", None), "gather_masters"):
+            self.optimizer.gather_masters()      # sharded Adam: fp32 masters are per-slice until gathered
 
     legacy_grouped = True     # class-wide switch: False = the per-shell loop (tests compare the two)
 

@@ -144,6 +144,143 @@ class FusedAdam(torch.optim.Optimizer):
         return loss
 
 
+class ShardedFusedAdam(FusedAdam):
+    """Data-parallel Adam with the optimiser state and the update SHARDED over the ranks (ZeRO
+    stage 1) — DESIGN.md 8: instead of all-reducing 114 MB of fp32 texture gradients and running the
+    same Adam over all 28.7 M parameters on every rank,
+
+      1. reduce-scatter the gradients: rank r receives the SUM of slice r of every tensor
+         (RCCL: (w-1)/w x 114 MB on the ring instead of 2 (w-1)/w x 114 MB),
+      2. Adam on that slice only (moments exist for the slice only: 1/w of the state, 1/w of the
+         HBM traffic of the update),
+      3. all-gather what the kernels read — the f16 compute copies where a parameter has one (half
+         the bytes), the fp32 values otherwise.
+
+    The fp32 masters are current on their owner's slice only; `gather_masters()` (called by
+    VolSurfs.sync_params before save / bake) completes them.  The update is elementwise, so the
+    result equals FusedAdam after an all-reduce bit for bit wherever the summed gradients do
+    (tests/test_parallel.py::test_sharded_adam_equals_allreduce_adam).  A tensor whose size is not a
+    multiple of world x 4 elements is all-reduced and updated in full on every rank.
+    Backends without reduce_scatter (gloo) get all-reduce + slice: same numbers."""
+
+    def __init__(self, params, world, rank, group=None, **kw):
+        super().__init__(params, **kw)
+        self.world, self.rank, self.group = int(world), int(rank), group
+        self._shards = {}            # id(param) -> (a, b, grad shard, param slice, f16 slice | None)
+
+    def _shard(self, p):
+        s = self._shards.get(id(p))
+        if s is None:
+            n = p.numel()
+            if self.world == 1 or n % (self.world * 4):
+                # not divisible: all-reduced and updated in full on every rank, through a private
+                # gradient buffer like the slices (the descriptors never hold p.grad's address)
+                h = self._half.get(id(p))
+                s = (0, n, torch.zeros(n, device=p.device), p.detach().view(-1), h.view(-1) if h is not None else None)
+                self._full = getattr(self, "_full", set()) | {id(p)}
+            else:
+                per = n // self.world
+                a = self.rank * per
+                h = self._half.get(id(p))
+                s = (a, a + per, torch.zeros(per, device=p.device), p.detach().view(-1)[a:a + per],
+                     h.view(-1)[a:a + per] if h is not None else None)
+            self._shards[id(p)] = s
+        return s
+
+    def _plan(self, gi, group):
+        cur = self._plans.get(gi)
+        if cur is not None:
+            return cur
+        ps = [p for p in group["params"] if p.requires_grad]
+        chunk = _lib.lib().vsa_adam_chunk_elems()
+        arr = (AdamTensor * max(len(ps), 1))()
+        chunks = []
+        for i, p in enumerate(ps):
+            st = self.state[p]
+            sh = self._shard(p)
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            if True:
+                a, b, g, ps_, hs = sh
+                st.setdefault("exp_avg", torch.zeros(b - a, device=p.device))       # the slice's moments only
+                st.setdefault("exp_avg_sq", torch.zeros(b - a, device=p.device))
+                arr[i] = AdamTensor(ps_.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
+                                    st["exp_avg_sq"].data_ptr(), hs.data_ptr() if hs is not None else None, b - a)
+                n = b - a
+            chunks += [(i, c) for c in range((n + chunk - 1) // chunk)]
+        dev = ps[0].device if ps else "cuda"
+        desc = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        ck = torch.tensor(chunks, dtype=torch.int32).reshape(-1, 2).to(dev)
+        self._plans[gi] = (None, desc, ck, len(chunks), None)
+        return self._plans[gi]
+
+    def _reduce_scatter(self, p, sh):
+        import torch.distributed as dist
+        a, b, g = sh[0], sh[1], sh[2]
+        flat = p.grad.view(-1)
+        try:
+            if dist.get_backend(self.group) == "gloo":
+                raise RuntimeError("gloo has no reduce_scatter")
+            dist.reduce_scatter_tensor(g, flat, op=dist.ReduceOp.SUM, group=self.group)
+        except RuntimeError:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            g.copy_(flat[a:b])
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0, stream=None):
+        """Gradients of THIS rank's backward in p.grad -> parameters (and f16 copies) updated on
+        every rank.  Replaces `allreduce_gradients` + `FusedAdam.step`."""
+        import torch.distributed as dist
+        if stream is not None:
+            raise _lib.VolsurfsHipError("ShardedFusedAdam: the collectives order the step; no side stream")
+        ps = [p for g in self.param_groups for p in g["params"] if p.requires_grad]
+        for g in self.param_groups:
+            self._plan(self.param_groups.index(g), g)        # state and slices exist
+        full = getattr(self, "_full", set())
+        for p in ps:
+            sh = self._shard(p)
+            if id(p) in full:
+                if self.world > 1:
+                    dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)
+                sh[2].copy_(p.grad.view(-1))
+            else:
+                self._reduce_scatter(p, sh)
+        sp = _lib.stream_ptr()
+        for gi, group in enumerate(self.param_groups):
+            _, desc, ck, n, _ = self._plan(gi, group)
+            group["step"] += 1
+            b1, b2 = group["betas"]
+            _lib.call("vsa_adam_step", desc, ck, n, float(group["lr"]), float(b1), float(b2),
+                      float(group["eps"]), int(group["step"]), float(grad_scale), 1, sp)
+        for p in ps:                       # what the kernels read, complete on every rank again
+            sh = self._shard(p)
+            p.grad.zero_()                 # the kernel cleared the slice buffer; the full-size buffer is this rank's backward target
+            if id(p) in full:
+                continue
+            a, b, _, p_slice, h_slice = sh
+            h = self._half.get(id(p))
+            whole = (h if h is not None else p.detach()).view(-1)
+            mine = (h_slice if h is not None else p_slice).clone()
+            per = b - a
+            dist.all_gather([whole[r * per:(r + 1) * per] for r in range(self.world)], mine, group=self.group)
+        self._grads_clean = True
+        return None
+
+    @torch.no_grad()
+    def gather_masters(self):
+        """Complete the fp32 masters on every rank (before a checkpoint or a bake)."""
+        import torch.distributed as dist
+        for g in self.param_groups:
+            for p in g["params"]:
+                sh = self._shard(p)
+                if id(p) in getattr(self, "_full", set()) or self._half.get(id(p)) is None:
+                    continue
+                a, b, _, p_slice, _ = sh
+                full, per = p.detach().view(-1), b - a
+                dist.all_gather([full[r * per:(r + 1) * per] for r in range(self.world)], p_slice.clone(),
+                                group=self.group)
+
+
 def accumulate_into_grad(param):
     """For autograd Functions whose backward kernel ACCUMULATES (+=) into a table-sized gradient:
     if `param` already owns a contiguous fp32 `.grad` (the persistent buffers FusedAdam keeps),

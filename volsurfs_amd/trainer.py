@@ -123,7 +123,7 @@ def train_step(method, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first
             (l["loss"] * (w * share)).backward()                            # :264
         for k, v in l.items():
             losses[k] = losses.get(k, 0.0) + (v.detach() if isinstance(v, torch.Tensor) else v) * w
-    if world > 1:
+    if world > 1 and not hasattr(method.optimizer, "gather_masters"):     # (a sharded optimiser reduces inside step())
         from .parallel import allreduce_gradients
         allreduce_gradients([p for g in method.optimizer.param_groups for p in g["params"]], world, group)
     if overlap_optimizer and use_fused:                                      # :278
