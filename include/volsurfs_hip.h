@@ -115,6 +115,13 @@ int vsa_bvh_export(const vsa_bvh* bvh, float* nodes_out, float* tris_out, int no
  * frame_out [6] = grid origin xyz and step xyz, tris_out as vsa_bvh_export. */
 int vsa_bvh_export_q(const vsa_bvh* bvh, uint32_t* qnodes_out, float* tris_out, int node_base,
                      int tri_base, float* frame_out);
+/* 4-wide quantised export for vsa_trace_q4: the binary tree collapsed so that a node holds up to
+ * four child boxes (half the dependent node fetches per ray).  qnodes4_out [nr_nodes (the binary
+ * count: an upper bound), 16] u32: slot s = box in dwords 3s..3s+2 (as vsa_bvh_export_q), reference
+ * in dword 12+s (node index into this array >= 0, leaf code, or 0x7fffffff = empty slot); the
+ * root is entry 0.  *nr_nodes4 = entries written, *max_depth4 = depth of the collapsed tree. */
+int vsa_bvh_export_q4(const vsa_bvh* bvh, uint32_t* qnodes4_out, float* tris_out, int node_base,
+                      int tri_base, float* frame_out, int* nr_nodes4, int* max_depth4);
 int vsa_bvh_destroy(vsa_bvh* bvh);
 
 /* vsa_trace: closest hit of every ray against each of nr_meshes BVHs in ONE
@@ -138,6 +145,13 @@ int vsa_trace_q(const uint32_t* qnodes, const float* tris, const int32_t* mesh_r
                 const float* mesh_frames, int nr_meshes, int max_depth, const float* rays_o,
                 const float* rays_d, int nr_rays, float t_min, float* hit_t, int32_t* hit_slot,
                 float* hit_uv, void* stream);
+/* vsa_trace_q on the 4-wide nodes of vsa_bvh_export_q4 (identical results; the LDS stack holds
+ * 3 x (max_depth4 - 1) entries, <= 96). */
+int vsa_trace_q4(const uint32_t* qnodes4, const float* tris, const int32_t* mesh_roots,
+                 const float* mesh_frames, int nr_meshes, int max_depth4, const float* rays_o,
+                 const float* rays_d, int nr_rays, float t_min, float* hit_t, int32_t* hit_slot,
+                 float* hit_uv, void* stream);
+
 
 /* vsa_hit_attributes: expands one mesh's hit records [N] into the dict
  * raytracelib returns (volsurfs.py:496-501): is_hit [N] u8, triangles_id [N]

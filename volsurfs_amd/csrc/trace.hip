@@ -285,6 +285,106 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_q_kernel(
   hit_uv[2 * o + 1] = best.v;
 }
 
+// ---- 4-wide nodes (vsa_bvh_export_q4).  PMC of trace_q_kernel at 800x800, K=5 (profiles/r03/pmc):
+// 53 % of the wave cycles in s_waitcnt, 47 % VALU-busy, the vector cache at 26 % of its look-up
+// rate, 10 resident waves per CU — the kernel waits for its chain of dependent node fetches.  A
+// node of the collapsed tree holds four child boxes, so the chain is half as long; the four slab
+// tests of a visit are the two-by-two tests of two binary visits, the hit children are visited
+// nearest first (a 5-comparator sort of (t_near, reference) pairs; misses carry +inf), the other
+// hits go on the LDS stack farthest first.  Triangles are tested exactly as before, and the closest
+// hit is order independent, so results stay bit-identical to the oracle.
+// MEASURED (round 3, same box, profiles/r03/trace_q4.txt): 0.300 -> 0.325 ms at 800x800 K=5, 0.264 ->
+// 0.283 on the noisy scene, 0.656 -> 0.745 at 1080p K=7 subdiv 7: the shorter chain does not pay
+// for testing all four grandchildren at every visit (the binary walk never loads the children of a
+// box it missed) plus the sort and up to three stack pushes.  Not the default (raytrace.py).
+__device__ __forceinline__ void q4_cswap(float& ta, int& ra, float& tb, int& rb) {
+  const bool sw = tb < ta;
+  const float t0 = sw ? tb : ta, t1 = sw ? ta : tb;
+  const int r0 = sw ? rb : ra, r1 = sw ? ra : rb;
+  ta = t0, tb = t1, ra = r0, rb = r1;
+}
+
+template <int STACK>
+__global__ __launch_bounds__(TRACE_BLOCK) void trace_q4_kernel(
+    const uint4* __restrict__ qnodes, const float4* __restrict__ tris, Roots roots, Frames frames,
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, int N, float t_min,
+    float* __restrict__ hit_t, int* __restrict__ hit_slot, float* __restrict__ hit_uv) {
+  __shared__ int s_stack[STACK][TRACE_BLOCK];
+  const int lane = threadIdx.x;
+  const long long n = (long long)blockIdx.x * TRACE_BLOCK + lane;
+  const int mesh = blockIdx.y;
+  if (n >= N) return;
+  const float ox = rays_o[3 * n], oy = rays_o[3 * n + 1], oz = rays_o[3 * n + 2];
+  const float dx = rays_d[3 * n], dy = rays_d[3 * n + 1], dz = rays_d[3 * n + 2];
+  const float* fr = frames.f[mesh];
+  QRay qr;
+  {
+    const float gx = (ox - fr[0]) / fr[3] + 1.0f, gy = (oy - fr[1]) / fr[4] + 1.0f,
+                gz = (oz - fr[2]) / fr[5] + 1.0f;
+    const float ix = 1.0f / (dx / fr[3]), iy = 1.0f / (dy / fr[4]), iz = 1.0f / (dz / fr[5]);
+    qr.ix = f32x2_t{ix, ix}, qr.iy = f32x2_t{iy, iy}, qr.iz = f32x2_t{iz, iz};
+    qr.cx = f32x2_t{-(gx * ix), -(gx * ix)};
+    qr.cy = f32x2_t{-(gy * iy), -(gy * iy)};
+    qr.cz = f32x2_t{-(gz * iz), -(gz * iz)};
+  }
+  Hit best;
+  best.t = INFINITY;
+  best.u = best.v = 0.f;
+  best.slot = -1;
+  best.id = 0x7fffffff;
+
+  int cur = roots.root[mesh];
+  int sp = 0;
+  while (cur != TRACE_EMPTY) {
+    while ((unsigned)cur < (unsigned)TRACE_EMPTY) {
+      const uint4* np = qnodes + 4 * (long long)cur;
+      const uint4 a = np[0], b = np[1], c = np[2], d = np[3];
+      float t0, t1, t2, t3;
+      const bool h0 = qbox_test(a.x, a.y, a.z, qr, t_min, best.t, t0);
+      const bool h1 = qbox_test(a.w, b.x, b.y, qr, t_min, best.t, t1);
+      const bool h2 = qbox_test(b.z, b.w, c.x, qr, t_min, best.t, t2);
+      const bool h3 = qbox_test(c.y, c.z, c.w, qr, t_min, best.t, t3);
+      int r0 = h0 ? (int)d.x : TRACE_EMPTY, r1 = h1 ? (int)d.y : TRACE_EMPTY;
+      int r2 = h2 ? (int)d.z : TRACE_EMPTY, r3 = h3 ? (int)d.w : TRACE_EMPTY;
+      t0 = h0 ? t0 : INFINITY, t1 = h1 ? t1 : INFINITY, t2 = h2 ? t2 : INFINITY, t3 = h3 ? t3 : INFINITY;
+      q4_cswap(t0, r0, t1, r1);
+      q4_cswap(t2, r2, t3, r3);
+      q4_cswap(t0, r0, t2, r2);
+      q4_cswap(t1, r1, t3, r3);
+      q4_cswap(t1, r1, t2, r2);
+      // (an empty slot's reference is TRACE_EMPTY whether or not its inverted box "hit")
+      if (r3 != TRACE_EMPTY) s_stack[sp++][lane] = r3;
+      if (r2 != TRACE_EMPTY) s_stack[sp++][lane] = r2;
+      if (r1 != TRACE_EMPTY) s_stack[sp++][lane] = r1;
+      cur = r0 != TRACE_EMPTY ? r0 : (sp ? s_stack[--sp][lane] : TRACE_EMPTY);
+    }
+    if (cur != TRACE_EMPTY) {
+      const int code = ~cur;
+      const int first = code >> 4, cnt = code & 15;
+      for (int i0 = 0; i0 < cnt; i0 += 4) {
+        float4 tv[4][3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const long long s = first + min(i0 + i, cnt - 1);
+          tv[i][0] = tris[3 * s];
+          tv[i][1] = tris[3 * s + 1];
+          tv[i][2] = tris[3 * s + 2];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i0 + i < cnt)
+            tri_test(tv[i][0], tv[i][1], tv[i][2], ox, oy, oz, dx, dy, dz, t_min, first + i0 + i, best);
+      }
+      cur = sp ? s_stack[--sp][lane] : TRACE_EMPTY;
+    }
+  }
+  const long long o = (long long)mesh * N + n;
+  hit_t[o] = best.slot >= 0 ? best.t : 0.0f;
+  hit_slot[o] = best.slot;
+  hit_uv[2 * o] = best.u;
+  hit_uv[2 * o + 1] = best.v;
+}
+
 // ---- persistent lanes.  With one (ray, shell) per lane for the lifetime of a wave, a wave lasts
 // as long as its slowest ray: PMC showed 37 % lane utilisation (a tile at the silhouette has a few
 // deep traversals and sixty-odd immediate misses; 71 % of the (ray, shell) pairs are misses).  Here
@@ -517,6 +617,36 @@ extern "C" int vsa_trace_q(const uint32_t* qnodes, const float* tris, const int3
     hipLaunchKernelGGL(trace_q_kernel<TRACE_STACK>, grid, block, 0, (hipStream_t)stream,
                        reinterpret_cast<const uint4*>(qnodes), reinterpret_cast<const float4*>(tris),
                        r, fr, rays_o, rays_d, nr_rays, t_min, hit_t, hit_slot, hit_uv);
+  VSA_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int vsa_trace_q4(const uint32_t* qnodes4, const float* tris, const int32_t* mesh_roots,
+                            const float* mesh_frames, int nr_meshes, int max_depth4,
+                            const float* rays_o, const float* rays_d, int nr_rays, float t_min,
+                            float* hit_t, int32_t* hit_slot, float* hit_uv, void* stream) {
+  if (nr_meshes < 1 || nr_meshes > VSA_MAX_SHELLS || nr_rays < 0 || !mesh_roots || !mesh_frames)
+    return VSA_ERR_ARG;
+  // a visit pushes at most three references and descends into the fourth: the stack never holds
+  // more than 3 x (depth - 1) entries
+  const int need = 3 * (max_depth4 > 0 ? max_depth4 - 1 : 0);
+  if (need > 96) return VSA_ERR_UNSUPPORTED;
+  if (nr_rays == 0) return VSA_OK;
+  if (!qnodes4 || !tris || !rays_o || !rays_d || !hit_t || !hit_slot || !hit_uv) return VSA_ERR_ARG;
+  Roots r;
+  Frames fr;
+  for (int i = 0; i < VSA_MAX_SHELLS; ++i) {
+    r.root[i] = i < nr_meshes ? mesh_roots[i] : 0;
+    for (int j = 0; j < 6; ++j) fr.f[i][j] = i < nr_meshes ? mesh_frames[6 * i + j] : 1.0f;
+  }
+  dim3 grid(vsa_div_up(nr_rays, TRACE_BLOCK), nr_meshes), block(TRACE_BLOCK);
+#define Q4_GO(S)                                                                                      \
+  hipLaunchKernelGGL(trace_q4_kernel<S>, grid, block, 0, (hipStream_t)stream,                         \
+                     reinterpret_cast<const uint4*>(qnodes4), reinterpret_cast<const float4*>(tris), r, fr, \
+                     rays_o, rays_d, nr_rays, t_min, hit_t, hit_slot, hit_uv)
+  if (need <= 32) Q4_GO(32);
+  else if (need <= 48) Q4_GO(48);
+  else Q4_GO(96);
+#undef Q4_GO
   VSA_RETURN_LAUNCH_STATUS();
 }
 
