@@ -264,7 +264,10 @@ __device__ __forceinline__ void shade_hit(const vsa_nt_plan& plan, const HitCtx&
   }
 }
 
-__global__ __launch_bounds__(SH_BLOCK, 3) void nt_shade_fwd_kernel(
+#ifndef NT_SHADE_FWD_OCC
+#define NT_SHADE_FWD_OCC 4     /* 128 VGPRs, 4 waves per SIMD: 0.163 -> 0.152 ms (round 3; 5 waves spill: 0.22) */
+#endif
+__global__ __launch_bounds__(SH_BLOCK, NT_SHADE_FWD_OCC) void nt_shade_fwd_kernel(
     vsa_nt_plan plan, const int* __restrict__ hit_slot, const float* __restrict__ tex_uv,
     const float* __restrict__ rays_d, const float4* __restrict__ tris,
     const int* __restrict__ slot_of, const int* __restrict__ seg_start,
@@ -340,7 +343,10 @@ __device__ __forceinline__ void atomic_pk_add_f16(const _Float16* base, unsigned
 #define NT_SHB_PREFETCH 1
 #endif
 template <bool RECOMPUTE>
-__global__ __launch_bounds__(SHB_BLOCK, RECOMPUTE ? 2 : 4) void nt_shade_bwd_kernel(
+#ifndef NT_SHADE_BWD_OCC
+#define NT_SHADE_BWD_OCC 4
+#endif
+__global__ __launch_bounds__(SHB_BLOCK, RECOMPUTE ? 2 : NT_SHADE_BWD_OCC) void nt_shade_bwd_kernel(
     vsa_nt_plan plan, const int* __restrict__ hit_slot, const float* __restrict__ tex_uv,
     const float* __restrict__ rays_d, const float4* __restrict__ tris,
     const int* __restrict__ slot_of, const int* __restrict__ seg_start,
