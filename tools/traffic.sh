@@ -4,7 +4,7 @@
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c --output-format csv -d $root/gpurun_out/traffic_$c -- python3 $root/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $root/gpurun_out/traffic_$c.log 2>&1
+  timeout 300 rocprofv3 --pmc $c --output-format csv -d $root/gpurun_out/traffic_$c -- python3 $root/bench.py --no-cpu-baseline --no-noisy --steps 3 --warmup 1 > $root/gpurun_out/traffic_$c.log 2>&1
   echo "$c rc=$?"
 done
 python3 - <<PY

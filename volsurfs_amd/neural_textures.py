@@ -23,11 +23,13 @@ from . import _lib
 MAX_SHELLS, MAX_DEG, MAX_LEVELS = 16, 4, 16
 DOM_BLOCK = 4096
 WEIGHTS_PER_TEX = 8192
-# encode + MLP as one launch (csrc/nt_fused.hip): bit-identical, measured a tie with the two-kernel
-# path on the training step (0.65 vs 0.64 ms: the vector cache's look-up rate bounds its gathers,
-# DESIGN.md 9.1a) -> opt-in
-FUSED_FORWARD = os.environ.get("VSA_NT_FUSED", "0") != "0"
-
+# encode + MLP as one launch (csrc/nt_fused.hip; bit-identical to the two kernels).  Measured on
+# MI355X (profiles/r03): forward-only evaluation, where the 730 MB of feature planes are neither
+# written nor read, 1.30 -> 1.18 ms per 800x800 frame (+10.5 % Mrays/s); the training step, whose
+# backward needs the planes, 0.65 vs 0.61-0.64 ms and 1 043 vs 1 061 it/s — the vector cache's
+# look-up rate bounds the gathers.  Hence "auto": fused exactly when the feature
+# planes are not needed.  VSA_NT_FUSED=1 / 0 force it on / off (A/B switch, tools/README).
+FUSED_FORWARD = {"0": False, "1": True}.get(os.environ.get("VSA_NT_FUSED", "auto"), "auto")
 
 class Plan(ctypes.Structure):
     """Mirror of `vsa_nt_plan` (include/volsurfs_hip.h)."""
@@ -284,9 +286,9 @@ class NeuralTextureBank(torch.nn.Module):
         return (self.rows_dense(self.texels), pre) if want_pre else self.texels
 
     def evaluate(self, need_features=True):
-        """Texel rows of the compacted slots: the level-major encode kernel followed by the MLP
-        kernel, or — VSA_NT_FUSED=1 — the fused launch (A/B switch, tools/README)."""
-        if FUSED_FORWARD:
+        """Texel rows of the compacted slots.  need_features=False (inference, baking): the fused
+        launch; True (a backward pass follows): the level-major encode kernel, then the MLP kernel."""
+        if FUSED_FORWARD is True or (FUSED_FORWARD == "auto" and not need_features):
             return self.encode_mlp(write_features=need_features)
         self.encode()
         return self.mlp()

@@ -251,7 +251,7 @@ class KShellPipeline:
                        bytes=acct.get("nt_mark_compact", 0))
         mlp_flops = getattr(self, "mlp_flops_fwd", 0)
         from . import neural_textures as _nt
-        if _nt.FUSED_FORWARD:      # encode + MLP as one launch (csrc/nt_fused.hip)
+        if _nt.FUSED_FORWARD is True:      # encode + MLP as one launch (csrc/nt_fused.hip): VSA_NT_FUSED=1
             T.run("nt_encode_mlp_fwd", bank.encode_mlp, record, bytes=acct.get("nt_encode_mlp_fwd", 0),
                   flops=mlp_flops, bound="mfma")
         else:
