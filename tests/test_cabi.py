@@ -64,6 +64,16 @@ def test_argument_errors_are_reported_not_ignored():
     assert L.vsa_tile_order(null, null, 16, 16, 3, 0, null) == ERR_ARG                              # null arrays
     assert L.vsa_reel_next_rays_batch(null, null, null, null, 0, 4, 4, 8, 1, 0, u64, u64, null, null, null,
                                       null, null, null, null) == ERR_ARG                             # no cameras
+    # round-3 entry points
+    assert L.vsa_nt_encode_mlp_fwd(null, null, null, null, null, null, null, null, null) == ERR_ARG
+    assert L.vsa_packed_composite_fwd(null, null, null, null, null, null, 10, null) == ERR_ARG
+    assert L.vsa_packed_composite_fwd(null, null, null, null, null, null, -1, null) == ERR_ARG
+    assert L.vsa_packed_composite_bwd(null, null, null, null, null, null, null, null, 10, 1, null) == ERR_ARG
+    assert L.vsa_trace_q4(null, null, roots, null, 1, 10, null, null, 10, ctypes.c_float(0), null, null, null, null) == ERR_ARG
+    fr = (ctypes.c_float * 6)(0, 0, 0, 1, 1, 1)
+    assert L.vsa_trace_q4(null, null, roots, fr, 1, 99, null, null, 10, ctypes.c_float(0), null, null, null, null) == ERR_UNSUPPORTED   # 3 x 98 stack entries
+    assert L.vsa_trace_q4(null, null, roots, fr, 1, 10, null, null, 0, ctypes.c_float(0), null, null, null, null) == 0
+    assert L.vsa_bvh_export_q4(null, null, null, 0, 0, null, null, null) == ERR_ARG
     # round-2 entry points
     assert L.vsa_intersect_primitive(null, null, 10, 0, f1, null, null, null, null, null, null) == ERR_ARG
     assert L.vsa_intersect_primitive(null, null, 10, 2, f1, null, null, null, null, null, null) == ERR_ARG     # kind
