@@ -440,7 +440,13 @@ __global__ __launch_bounds__(SHB_BLOCK, RECOMPUTE ? 2 : NT_SHADE_BWD_OCC) void n
   const int c0 = div_nn(e0), c1 = div_nn(e0 + 1);
   const int ch0 = is_alpha ? 3 : c0, ch1 = is_alpha ? 3 : c1;
   const int m0 = d * d + (is_alpha ? e0 : e0 - c0 * nn), m1 = on1 ? d * d + (is_alpha ? e0 + 1 : e0 + 1 - c1 * nn) : 0;
-  const float span = plan.sh_span[d];
+  float span = plan.sh_span[d];
+  // `d` differs per lane, so this is a VECTOR load from the kernel-argument segment; its first use
+  // is inside the hit loop below, and the compiler put the `s_waitcnt vmcnt(0)` for it THERE — where,
+  // on every trip, it also waited for every gradient atomic the wave had in flight (no-return
+  // atomics stay counted in vmcnt until the memory side acknowledges them: ~1-3 k cycles).  Using
+  // the value once here retires the load in front of the loop.
+  asm volatile("" : "+v"(span));
   // Consecutive hits of a wave are neighbouring pixels: their 2x2 footprints fall on the same
   // or on neighbouring lines.  Each lane keeps up to four lines open with a running sum (the
   // lines the previous footprint touched: {x0, x1} x {y0, y1}, fewer when corners share a
