@@ -93,6 +93,17 @@ __device__ __forceinline__ void build_lut(const vsa_nt_plan& plan, float* s_lut)
   }
 }
 
+// FULL4: both texture types carry all four SH bands (the shipped configuration, base_5.cfg:12-20):
+// the band counts become compile-time constants, so the per-band `if (d >= D) continue` branches go
+// and the compiler issues the slot-id loads of all four bands together — with the run-time counts
+// every band was its own load -> wait round (four dependent memory latencies in a kernel that PMC
+// shows waiting 74 % of its wave cycles).
+template <bool FULL4>
+__device__ __forceinline__ int rgb_degs(const vsa_nt_plan& p) { return FULL4 ? VSA_NT_MAX_DEG : p.rgb_degrees; }
+template <bool FULL4>
+__device__ __forceinline__ int alpha_degs(const vsa_nt_plan& p) { return FULL4 ? VSA_NT_MAX_DEG : p.alpha_degrees; }
+
+template <bool FULL4 = false>
 __device__ __forceinline__ bool load_ctx(const vsa_nt_plan& plan, int s, long long n, int N,
                                          const int* hit_slot, const float* tex_uv,
                                          const float* rays_d, const float4* tris,
@@ -121,7 +132,7 @@ __device__ __forceinline__ bool load_ctx(const vsa_nt_plan& plan, int s, long lo
     c.decay = sigmoidf_(10.0f * dot) * 2.0f - 1.0f;
   }
   const float u = tex_uv[2 * o], v = tex_uv[2 * o + 1];
-  const int D = max(plan.rgb_degrees, plan.alpha_degrees);
+  const int D = max(rgb_degs<FULL4>(plan), alpha_degs<FULL4>(plan));
 #pragma unroll
   for (int d = 0; d < VSA_NT_MAX_DEG; ++d) {   // static indices: the arrays stay in registers
     if (d >= D) {
@@ -203,6 +214,7 @@ __device__ __forceinline__ void gather_coeffs(const vsa_nt_plan& plan, const Hit
 // order — the same additions sh_raw performs, so the result is bit-identical, but only one
 // band's coefficients are live (the all-bands-first form needed 197 VGPRs = two waves per
 // SIMD on a kernel that PMC shows waiting on gathers: 16 % VALU-busy).
+template <bool FULL4 = false>
 __device__ __forceinline__ void shade_hit(const vsa_nt_plan& plan, const HitCtx& c,
                                           const unsigned* __restrict__ texels, const float* s_lut,
                                           bool has_alpha, const float b[16], float raw[4],
@@ -211,7 +223,7 @@ __device__ __forceinline__ void shade_hit(const vsa_nt_plan& plan, const HitCtx&
 #pragma unroll
   for (int d = 0; d < VSA_NT_MAX_DEG; ++d) {
     const int n = 2 * d + 1, m0 = d * d;
-    const bool do_rgb = d < plan.rgb_degrees, do_a = has_alpha && d < plan.alpha_degrees;
+    const bool do_rgb = d < rgb_degs<FULL4>(plan), do_a = has_alpha && d < alpha_degs<FULL4>(plan);
     if (!do_rgb && !do_a) {
       if (coeffs_out) {
 #pragma unroll
@@ -265,8 +277,9 @@ __device__ __forceinline__ void shade_hit(const vsa_nt_plan& plan, const HitCtx&
 }
 
 #ifndef NT_SHADE_FWD_OCC
-#define NT_SHADE_FWD_OCC 4     /* 128 VGPRs, 4 waves per SIMD: 0.163 -> 0.152 ms (round 3; 5 waves spill: 0.22) */
+#define NT_SHADE_FWD_OCC 3     /* round 3: 4 waves per SIMD (128 VGPRs) gave 0.163 -> 0.152 ms with run-time band counts; with FULL4 the hoisted slot-id loads spill there (0.19) and 3 waves run 0.139 */
 #endif
+template <bool FULL4>
 __global__ __launch_bounds__(SH_BLOCK, NT_SHADE_FWD_OCC) void nt_shade_fwd_kernel(
     vsa_nt_plan plan, const int* __restrict__ hit_slot, const float* __restrict__ tex_uv,
     const float* __restrict__ rays_d, const float4* __restrict__ tris,
@@ -284,22 +297,22 @@ __global__ __launch_bounds__(SH_BLOCK, NT_SHADE_FWD_OCC) void nt_shade_fwd_kerne
   float nrm[3];
   float rgb[3] = {0.f, 0.f, 0.f}, alpha = 0.f;
   float4 act = make_float4(0.f, 0.f, 0.f, 0.f);   // the four sigmoids, for the backward pass
-  if (load_ctx(plan, s, n, N, hit_slot, tex_uv, rays_d, tris, slot_of, seg_start, c, nrm)) {
+  if (load_ctx<FULL4>(plan, s, n, N, hit_slot, tex_uv, rays_d, tris, slot_of, seg_start, c, nrm)) {
     const bool has_alpha = !(plan.inner_solid && s == 0);
     float b[16], raw[4];
     sh_basis(c.dir[0], c.dir[1], c.dir[2], b);
-    shade_hit(plan, c, texels, s_lut, has_alpha, b, raw,
+    shade_hit<FULL4>(plan, c, texels, s_lut, has_alpha, b, raw,
               coeffs_out ? coeffs_out + ((long long)s * N + n) * 64 : nullptr);
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
       const float sg = sigmoidf_(raw[ch]);
       (ch == 0 ? act.x : ch == 1 ? act.y : act.z) = sg;
-      rgb[ch] = plan.rgb_degrees > 1 ? sg : vsa_round_f16(sg);
+      rgb[ch] = rgb_degs<FULL4>(plan) > 1 ? sg : vsa_round_f16(sg);
     }
     if (has_alpha) {
       const float sg = sigmoidf_(raw[3]);
       act.w = sg;
-      const float a = plan.alpha_degrees > 1 ? sg : vsa_round_f16(sg);
+      const float a = alpha_degs<FULL4>(plan) > 1 ? sg : vsa_round_f16(sg);
       alpha = a * c.decay;
     } else {
       alpha = 1.0f;
@@ -342,7 +355,7 @@ __device__ __forceinline__ void atomic_pk_add_f16(const _Float16* base, unsigned
 #ifndef NT_SHB_PREFETCH
 #define NT_SHB_PREFETCH 1
 #endif
-template <bool RECOMPUTE>
+template <bool RECOMPUTE, bool FULL4>
 #ifndef NT_SHADE_BWD_OCC
 #define NT_SHADE_BWD_OCC 4
 #endif
@@ -369,7 +382,7 @@ __global__ __launch_bounds__(SHB_BLOCK, RECOMPUTE ? 2 : NT_SHADE_BWD_OCC) void n
   c.hit = false;
   float nrm[3];
   const bool has_alpha = !(plan.inner_solid && s == 0);
-  if (n < N && load_ctx(plan, s, n, N, hit_slot, tex_uv, rays_d, tris, slot_of, seg_start, c, nrm)) {
+  if (n < N && load_ctx<FULL4>(plan, s, n, N, hit_slot, tex_uv, rays_d, tris, slot_of, seg_start, c, nrm)) {
     float b[16];
     sh_basis(c.dir[0], c.dir[1], c.dir[2], b);
     const long long o = n * K + s;
@@ -435,7 +448,7 @@ __global__ __launch_bounds__(SHB_BLOCK, RECOMPUTE ? 2 : NT_SHADE_BWD_OCC) void n
   const int qd = nt_row_quads(d), qsh = d == 0 ? 1 : (d == 1 ? 2 : 3);
   // position of the pair in its line, in halfs (even: a 4-byte aligned f16 pair)
   const int lofs = 4 * (q * qd + (is_alpha ? nt_alpha_quad(d) : 0)) + e0;
-  const bool band_on = lane < 52 && (is_alpha ? (has_alpha && d < plan.alpha_degrees) : d < plan.rgb_degrees);
+  const bool band_on = lane < 52 && (is_alpha ? (has_alpha && d < alpha_degs<FULL4>(plan)) : d < rgb_degs<FULL4>(plan));
   const bool on1 = band_on && e0 + 1 < part;
   const int c0 = div_nn(e0), c1 = div_nn(e0 + 1);
   const int ch0 = is_alpha ? 3 : c0, ch1 = is_alpha ? 3 : c1;
@@ -566,10 +579,16 @@ extern "C" int vsa_nt_shade_fwd(const vsa_nt_plan* plan, const int32_t* hit_slot
       !surfs_alpha)
     return VSA_ERR_ARG;
   dim3 grid(vsa_div_up(nr_rays, SH_BLOCK), plan->nr_shells);
-  hipLaunchKernelGGL(nt_shade_fwd_kernel, grid, dim3(SH_BLOCK), 0, (hipStream_t)stream, *plan,
-                     hit_slot, tex_uv, rays_d, reinterpret_cast<const float4*>(tris), slot_of,
-                     seg_start, reinterpret_cast<const unsigned*>(texels), nr_rays, surfs_rgb,
-                     surfs_alpha, surfs_normals, coeffs_out, reinterpret_cast<float4*>(act_out));
+  if (plan->rgb_degrees == VSA_NT_MAX_DEG && plan->alpha_degrees == VSA_NT_MAX_DEG)
+    hipLaunchKernelGGL(nt_shade_fwd_kernel<true>, grid, dim3(SH_BLOCK), 0, (hipStream_t)stream, *plan,
+                       hit_slot, tex_uv, rays_d, reinterpret_cast<const float4*>(tris), slot_of,
+                       seg_start, reinterpret_cast<const unsigned*>(texels), nr_rays, surfs_rgb,
+                       surfs_alpha, surfs_normals, coeffs_out, reinterpret_cast<float4*>(act_out));
+  else
+    hipLaunchKernelGGL(nt_shade_fwd_kernel<false>, grid, dim3(SH_BLOCK), 0, (hipStream_t)stream, *plan,
+                       hit_slot, tex_uv, rays_d, reinterpret_cast<const float4*>(tris), slot_of,
+                       seg_start, reinterpret_cast<const unsigned*>(texels), nr_rays, surfs_rgb,
+                       surfs_alpha, surfs_normals, coeffs_out, reinterpret_cast<float4*>(act_out));
   VSA_RETURN_LAUNCH_STATUS();
 }
 
@@ -586,14 +605,21 @@ extern "C" int vsa_nt_shade_bwd(const vsa_nt_plan* plan, const int32_t* hit_slot
     return VSA_ERR_ARG;
   if (plan->row_base[VSA_MAX_SHELLS * VSA_NT_MAX_DEG] * 8 >= (1ll << 32)) return VSA_ERR_UNSUPPORTED;   // 32-bit atomic offsets
   dim3 grid(vsa_div_up(nr_rays, SHB_BLOCK), plan->nr_shells);
-  if (act_in)
-    hipLaunchKernelGGL(nt_shade_bwd_kernel<false>, grid, dim3(SHB_BLOCK), 0, (hipStream_t)stream, *plan,
+  const bool full4 = plan->rgb_degrees == VSA_NT_MAX_DEG && plan->alpha_degrees == VSA_NT_MAX_DEG;
+  if (act_in && full4)
+    hipLaunchKernelGGL((nt_shade_bwd_kernel<false, true>), grid, dim3(SHB_BLOCK), 0, (hipStream_t)stream, *plan,
+                       hit_slot, tex_uv, rays_d, reinterpret_cast<const float4*>(tris), slot_of,
+                       seg_start, reinterpret_cast<const unsigned*>(texels), nr_rays, g_surfs_rgb,
+                       g_surfs_alpha, grad_scale, reinterpret_cast<_Float16*>(grad_rows),
+                       reinterpret_cast<const float4*>(act_in));
+  else if (act_in)
+    hipLaunchKernelGGL((nt_shade_bwd_kernel<false, false>), grid, dim3(SHB_BLOCK), 0, (hipStream_t)stream, *plan,
                        hit_slot, tex_uv, rays_d, reinterpret_cast<const float4*>(tris), slot_of,
                        seg_start, reinterpret_cast<const unsigned*>(texels), nr_rays, g_surfs_rgb,
                        g_surfs_alpha, grad_scale, reinterpret_cast<_Float16*>(grad_rows),
                        reinterpret_cast<const float4*>(act_in));
   else
-    hipLaunchKernelGGL(nt_shade_bwd_kernel<true>, grid, dim3(SHB_BLOCK), 0, (hipStream_t)stream, *plan,
+    hipLaunchKernelGGL((nt_shade_bwd_kernel<true, false>), grid, dim3(SHB_BLOCK), 0, (hipStream_t)stream, *plan,
                        hit_slot, tex_uv, rays_d, reinterpret_cast<const float4*>(tris), slot_of,
                        seg_start, reinterpret_cast<const unsigned*>(texels), nr_rays, g_surfs_rgb,
                        g_surfs_alpha, grad_scale, reinterpret_cast<_Float16*>(grad_rows), nullptr);
