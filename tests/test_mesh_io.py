@@ -101,3 +101,27 @@ def test_run_meshes_are_copied_at_start_and_reloaded_on_resume(tmp_path):
     assert len(resumed) == 2
     for a, b in zip(first, resumed):
         assert torch.allclose(a.vertices, b.vertices, atol=1e-7) and torch.equal(a.faces, b.faces)
+
+
+def test_chart_atlas_fragments_the_parameterisation_deterministically():
+    """mesh.chart_atlas (the non-ideal scene of bench.py): every face lands in ONE tile of the G x G
+    atlas, uvs stay in [0, 1], neighbouring faces of different charts end up far apart, and the
+    same seed gives the same atlas."""
+    import numpy as np
+    from volsurfs_amd.mesh import chart_atlas, icosphere, octahedral_uv
+    v, f = icosphere(3, 1.0)
+    uv = octahedral_uv(v.astype(np.float64))[f]
+    G = 4
+    a = chart_atlas(uv, G, seed=3)
+    b = chart_atlas(uv, G, seed=3)
+    c = chart_atlas(uv, G, seed=4)
+    assert a.shape == uv.shape and a.dtype == np.float32
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    assert a.min() >= 0.0 and a.max() <= 1.0
+    tile = np.floor(np.clip(a.mean(1), 0, 1 - 1e-6) * G).astype(int)
+    inside = np.floor(np.clip(a, 0, 1 - 1e-6) * G).astype(int) == tile[:, None, :]
+    assert inside.all(axis=(1, 2)).mean() > 0.9        # a face stays inside its tile (fold faces excepted)
+    # the packing is a permutation of the charts: every tile that holds faces holds ONE source cell
+    src = np.floor(np.clip(uv.mean(1), 0, 1 - 1e-9) * G).astype(int)
+    pairs = {(tuple(t_), tuple(s_)) for t_, s_ in zip(tile.tolist(), src.tolist())}
+    assert len({p[0] for p in pairs}) == len(pairs)

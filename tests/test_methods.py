@@ -592,3 +592,38 @@ def test_legacy_grouped_shading_equals_the_per_shell_loop(cfg):
             s_ = b.abs().max().item()
             assert (a - b).abs().max().item() <= 1e-5 * s_ + 1e-12
     assert n_with_grad >= 6
+
+
+@pytest.mark.gpu
+def test_inference_takes_the_fused_forward_and_equals_the_two_kernel_path(monkeypatch):
+    """`render_rays` under no_grad needs no feature planes, so `NeuralTextureBank.evaluate` takes the
+    one-launch encode + MLP there (neural_textures.FUSED_FORWARD = "auto"); a differentiated call takes
+    the two kernels.  Same pixels either way, bit for bit."""
+    from volsurfs_amd import neural_textures as NT
+    from volsurfs_amd.camera import pinhole_rays
+    from volsurfs_amd.mesh import nested_shells
+    from volsurfs_amd.methods import VolSurfs
+    m = VolSurfs(nested_shells(K=3, subdiv=3, noise=0.05, atlas_charts=4), max_rays=4096, seed=11)
+    with torch.no_grad():
+        m.bank.tables.uniform_(-1.0, 1.0)
+    m.bank.refresh_half_params()
+    o, d = pinhole_rays(64, 64, focal=90.0, cam_pos=(0.0, 0.0, -1.5))
+    calls = []
+    real = NT.NeuralTextureBank.encode_mlp
+    monkeypatch.setattr(NT.NeuralTextureBank, "encode_mlp",
+                        lambda self, **kw: (calls.append(kw.get("write_features")), real(self, **kw))[1])
+    out = {}
+    for mode in ("auto", False, True):
+        monkeypatch.setattr(NT, "FUSED_FORWARD", mode)
+        calls.clear()
+        with torch.no_grad():
+            out[mode] = m.render_rays(o, d, return_samples=False)["renders"]["ray_traced"]["rgb"].clone()
+        assert calls == ([] if mode is False else [False])
+    assert torch.equal(out["auto"], out[False]) and torch.equal(out[True], out[False])
+    assert float(out["auto"].std()) > 0.01
+    monkeypatch.setattr(NT, "FUSED_FORWARD", "auto")
+    calls.clear()
+    gt = torch.rand(4096, 3, device="cuda")
+    losses, _, _ = m(o, d, gt, None, 0)         # a differentiated call: the feature planes are needed
+    losses["loss"].backward()
+    assert calls == []
