@@ -132,8 +132,34 @@ __device__ __forceinline__ const float* meta_bias(const LayerMeta& m, int l) {
   return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
 }
 
-// packed_fwd[l][((m * inb + b) * 16 + s) * 64 + lane] = W_l[32 m + (lane & 31)][32 b + rho(s, lane >> 5)]
-// packed_bwd[l][((b * outb + m) * 16 + s) * 64 + lane] = W_l[32 m + rho(s, lane >> 5)][32 b + (lane & 31)]
+// packed_fwd[l][(m * inb + b) * 1024 + mlp_frag_pos(s, lane)] = W_l[32 m + (lane & 31)][32 b + rho(s, lane >> 5)]
+// packed_bwd[l][(b * outb + m) * 1024 + mlp_frag_pos(s, lane)] = W_l[32 m + rho(s, lane >> 5)][32 b + (lane & 31)]
+// mlp_frag_pos: with MLP_FRAG_B128 = 1 a lane's four consecutive k-steps are one 16-byte run
+// ([s / 4][lane][s % 4]), so ONE ds_read_b128 (lanes 16 B apart: conflict-free) feeds four MFMAs instead
+// of a 4-byte ds_read per v_mfma_f32_32x32x2_f32 (1199 -> 271 narrow reads in the ISA).  Measured on
+// tools/bench_bg.py (one box, two runs each): fwd 881 / 873 us, dgrad 1189-1212 / 1186-1216 us - no
+// difference, so the issue stalls of DESIGN.md 9.5 are not the fragment reads; the k-step-major layout
+// of rounds 1-2 stays the default.
+#ifndef MLP_FRAG_B128
+#define MLP_FRAG_B128 0
+#endif
+__host__ __device__ inline int mlp_frag_pos(int s, int lane) {
+  return MLP_FRAG_B128 ? ((s >> 2) * 64 + lane) * 4 + (s & 3) : s * 64 + lane;
+}
+// the 16 fragments of one 32x32 block pair for this lane
+__device__ __forceinline__ void mlp_load_frags(const float* blk, int lane, float w[16]) {
+#if MLP_FRAG_B128
+  const float4* f4 = reinterpret_cast<const float4*>(blk) + lane;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 v = f4[q * 64];
+    w[4 * q] = v.x, w[4 * q + 1] = v.y, w[4 * q + 2] = v.z, w[4 * q + 3] = v.w;
+  }
+#else
+#pragma unroll
+  for (int s = 0; s < 16; ++s) w[s] = blk[s * 64 + lane];
+#endif
+}
 __global__ void mlp_pack_kernel(vsa_mlp_plan plan, MlpGroups gp, long long packed_stride,
                                 float* __restrict__ packed_fwd, float* __restrict__ packed_bwd) {
   const PackOffsets off = pack_offsets(plan);
@@ -150,15 +176,16 @@ __global__ void mlp_pack_kernel(vsa_mlp_plan plan, MlpGroups gp, long long packe
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
     const int lane = idx & 63, s = (idx >> 6) & 15, blk = idx >> 10;
     const int i = lane & 31, h = lane >> 5;
+    const long long dst = off.fwd[l] + (long long)blk * 1024 + mlp_frag_pos(s, lane);
     if (packed_fwd) {
       const int m = blk / inb, b = blk - m * inb;
       const int row = 32 * m + i, col = 32 * b + rho(s, h);
-      packed_fwd[off.fwd[l] + idx] = (row < out && col < in) ? W[(long long)row * in + col] : 0.f;
+      packed_fwd[dst] = (row < out && col < in) ? W[(long long)row * in + col] : 0.f;
     }
     if (packed_bwd) {
       const int b = blk / outb, m = blk - b * outb;
       const int row = 32 * m + rho(s, h), col = 32 * b + i;
-      packed_bwd[off.fwd[l] + idx] = (row < out && col < in) ? W[(long long)row * in + col] : 0.f;
+      packed_bwd[dst] = (row < out && col < in) ? W[(long long)row * in + col] : 0.f;
     }
   }
 }
@@ -257,10 +284,11 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_fwd_kernel(
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
             if (b < inb) {
-              const float* frag = s_l + ((m * inb + b) * 16) * 64 + lane;
+              float wv[16];
+              mlp_load_frags(s_l + ((m * inb + b) * 16) * 64, lane, wv);
 #pragma unroll
               for (int s = 0; s < 16; ++s)
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(frag[s * 64], act[b][s], acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[s], act[b][s], acc[m], 0, 0, 0);
             }
           }
         }
@@ -391,10 +419,11 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_dgrad_kernel(
 #pragma unroll
           for (int m = 0; m < NB; ++m) {
             if (m < outb) {
-              const float* frag = s_w + (RESIDENT ? w_off : 0) + ((b * outb + m) * 16) * 64 + lane;
+              float wv[16];
+              mlp_load_frags(s_w + (RESIDENT ? w_off : 0) + ((b * outb + m) * 16) * 64, lane, wv);
 #pragma unroll
               for (int s = 0; s < 16; ++s)
-                da[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(frag[s * 64], dz[m][s], da[b], 0, 0, 0);
+                da[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[s], dz[m][s], da[b], 0, 0, 0);
             }
           }
         }
