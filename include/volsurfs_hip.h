@@ -145,6 +145,41 @@ int vsa_trace_q(const uint32_t* qnodes, const float* tris, const int32_t* mesh_r
                 const float* mesh_frames, int nr_meshes, int max_depth, const float* rays_o,
                 const float* rays_d, int nr_rays, float t_min, float* hit_t, int32_t* hit_slot,
                 float* hit_uv, void* stream);
+/* vsa_trace_q as three launches that cut long walks into pieces (identical results): pass A is
+ * vsa_trace_q's kernel, but a wave stops after round_budget (>= 1) trips of its walk loop and hands every
+ * subtree its lanes still hold (node in hand + stack entries, each with the ray's best t so far as
+ * bound) to pass B, which walks one subtree per lane in dense persistent waves; pass C merges the
+ * pieces of a ray (smallest t, ties -> smallest face id) and writes its hit record.  Why: a few
+ * grazing rays per wave otherwise keep 4 % of the waves alive for 10x the median walk and leave the
+ * chip draining for a third of the launch.  workspace: device memory, 16-byte
+ * aligned, >= 400 bytes, contents irrelevant on entry, not preserved;
+ * vsa_trace_q_workspace_bytes(nr_rays, nr_meshes) (< 0 on bad arguments) is the recommended size
+ * (room for a quarter of the (ray, shell) pairs); a hand-over that does not fit the workspace is not
+ * made (those waves walk on), so the result never depends on its size.  max_depth < 48. */
+long long vsa_trace_q_workspace_bytes(int nr_rays, int nr_meshes);
+int vsa_trace_q_budgeted(const uint32_t* qnodes, const float* tris, const int32_t* mesh_roots,
+                         const float* mesh_frames, int nr_meshes, int max_depth, const float* rays_o,
+                         const float* rays_d, int nr_rays, float t_min, float* hit_t,
+                         int32_t* hit_slot, float* hit_uv, int round_budget, void* workspace,
+                         long long workspace_bytes, void* stream);
+/* vsa_trace_q with the launch order taken from the previous call's measured cost (identical results):
+ * every wave files itself, by the trips its walk took, into one of three lists of the NEXT call's
+ * order; the next call dispatches the lists first (longest walks first), then everything else in the
+ * natural order.  A wave's trips depend on its rays only, so for the same rays the prediction is
+ * exact, and for a camera that moved a little it is close; for unrelated rays it is as good as any
+ * order.  Why: the few waves that hold grazing rays walk 10-20x the median; dispatched late they leave
+ * the chip draining for a third of the launch.  feedback: device memory, 16-byte
+ * aligned, >= vsa_trace_feedback_bytes(nr_rays, nr_meshes) (< 0 on bad arguments), ZEROED by the
+ * caller before its first use, then owned by this sequence of calls with the SAME feedback_bytes
+ * (a buffer sized for more rays serves fewer: a half written for another item count is recognised
+ * and ignored): phase alternates 0, 1, 0, ... (the half written by one call is read by the next);
+ * calls that share a feedback buffer must be ordered on one stream.  The lists and flags a
+ * call reads always partition the items, so the hits do not depend on what they were measured on. */
+long long vsa_trace_feedback_bytes(int nr_rays, int nr_meshes);
+int vsa_trace_q_fb(const uint32_t* qnodes, const float* tris, const int32_t* mesh_roots,
+                   const float* mesh_frames, int nr_meshes, int max_depth, const float* rays_o,
+                   const float* rays_d, int nr_rays, float t_min, float* hit_t, int32_t* hit_slot,
+                   float* hit_uv, void* feedback, long long feedback_bytes, int phase, void* stream);
 /* vsa_trace_q on the 4-wide nodes of vsa_bvh_export_q4 (identical results; the LDS stack holds
  * 3 x (max_depth4 - 1) entries, <= 96). */
 int vsa_trace_q4(const uint32_t* qnodes4, const float* tris, const int32_t* mesh_roots,

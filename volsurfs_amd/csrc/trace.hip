@@ -16,6 +16,7 @@
 // id) with the triangle test evaluated by one fixed fp32 formula, so the result
 // is bit-identical to the brute-force oracle (oracle/raytrace_ref.c).
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -91,6 +92,28 @@ __device__ __forceinline__ bool box_test(float lx, float ly, float lz, float hx,
 // leaf triangles together -- lanes no longer sit idle through other lanes' triangle
 // loops at every node visit.
 constexpr int TRACE_EMPTY = 0x7fffffff;
+
+// Diagnostic build only (tools/build_variant.sh span "-DTRACE_SPAN"; tools/trace_span.py): wall-clock
+// begin / end of every wave of trace_q_kernel and WAVE-level counts (an elected lane adds to LDS; a
+// per-lane variable would only count that lane's own trips): trips of the walk loop, lane visits, leaf
+// phases.  g_torder, when set, replaces the dispatch order (the launch-order experiments of DESIGN.md 9.4).
+#ifdef TRACE_SPAN
+constexpr int TRACE_SPAN_WAVES = 1 << 17;
+static __device__ unsigned long long g_tspan[TRACE_SPAN_WAVES][3];
+static __device__ int g_torder[TRACE_SPAN_WAVES];
+static __device__ int g_torder_on;
+__device__ __forceinline__ unsigned long long trace_now() {
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+enum { SP_ROUNDS, SP_VISITS, SP_OUTER };
+#define SPAN_ADD(k, v)                                                                        \
+  do {                                                                                        \
+    const unsigned v__ = (unsigned)(v);                                                       \
+    if ((int)threadIdx.x == __builtin_ctzll(__builtin_amdgcn_read_exec())) s_span[k] += v__;  \
+  } while (0)
+#endif
 
 template <int STACK>
 __global__ __launch_bounds__(TRACE_BLOCK) void trace_ww_kernel(
@@ -214,8 +237,18 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_q_kernel(
     float* __restrict__ hit_t, int* __restrict__ hit_slot, float* __restrict__ hit_uv) {
   __shared__ int s_stack[STACK][TRACE_BLOCK];
   const int lane = threadIdx.x;
+#ifndef TRACE_SPAN
   const long long n = (long long)blockIdx.x * TRACE_BLOCK + lane;
   const int mesh = blockIdx.y;
+#else
+  int item = blockIdx.y * gridDim.x + blockIdx.x;
+  if (g_torder_on) item = g_torder[item];
+  const int mesh = item / (int)gridDim.x;
+  const long long n = (long long)(item - mesh * (int)gridDim.x) * TRACE_BLOCK + lane;
+  const unsigned long long span_t0 = trace_now();
+  __shared__ unsigned s_span[8];
+  if (threadIdx.x < 8) s_span[threadIdx.x] = 0;
+#endif
   if (n >= N) return;
   const float ox = rays_o[3 * n], oy = rays_o[3 * n + 1], oz = rays_o[3 * n + 2];
   const float dx = rays_d[3 * n], dy = rays_d[3 * n + 1], dz = rays_d[3 * n + 2];
@@ -240,7 +273,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_q_kernel(
   int cur = roots.root[mesh];
   int sp = 0;
   while (cur != TRACE_EMPTY) {
+#ifdef TRACE_SPAN
+    SPAN_ADD(SP_OUTER, 1);
+#endif
     while ((unsigned)cur < (unsigned)TRACE_EMPTY) {
+#ifdef TRACE_SPAN
+      SPAN_ADD(SP_ROUNDS, 1);
+      SPAN_ADD(SP_VISITS, __builtin_popcountll(__builtin_amdgcn_read_exec()));
+#endif
       const uint4 a = qnodes[2 * (long long)cur], b = qnodes[2 * (long long)cur + 1];
       float tn0, tn1;
       const bool h0 = qbox_test(a.x, a.y, a.z, qr, t_min, best.t, tn0);
@@ -278,11 +318,335 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_q_kernel(
       cur = sp ? s_stack[--sp][lane] : TRACE_EMPTY;
     }
   }
+#ifdef TRACE_SPAN
+  if (lane == __builtin_ctzll(__builtin_amdgcn_read_exec()) && item < TRACE_SPAN_WAVES) {
+    g_tspan[item][0] = span_t0;
+    g_tspan[item][1] = trace_now();
+    g_tspan[item][2] = ((unsigned long long)s_span[SP_ROUNDS] << 48) | ((unsigned long long)(s_span[SP_OUTER] & 0xffff) << 32) | s_span[SP_VISITS];
+  }
+#endif
   const long long o = (long long)mesh * N + n;
   hit_t[o] = best.slot >= 0 ? best.t : 0.0f;
   hit_slot[o] = best.slot;
   hit_uv[2 * o] = best.u;
   hit_uv[2 * o + 1] = best.v;
+}
+
+// ---- budgeted walk + continuation (vsa_trace_q_budgeted).  Wave-level stamps of trace_q_kernel at
+// 800x800, K = 5 (tools/trace_span.py, profiles/r03/trace_span.txt): the chip is full for the first
+// 155 us of the launch and then drains for another 145 us -- 4 % of the waves walk for more than 32
+// trips (p99 105, max 210 against a median of 9) because a few of their rays graze a shell (a near
+// miss prunes nothing and visits every box along its tangent), at 35 % lane utilisation over the whole
+// launch; a trip is ~0.5 us of dependent latency (node fetch from L2 ~470 cycles + tests + stack), so
+// no order of issue inside a wave shortens that chain.  Here a wave stops after `round_budget` trips
+// of the walk loop: the lanes still holding work hand every pending subtree (the node in hand + every
+// stack entry) to a second pass as ITS OWN work item, so a long ray's chain is cut into independent
+// pieces that run side by side in dense waves, and a third pass merges the pieces of a ray.  The
+// closest hit is order independent (smallest t, ties -> smallest face id) and every item carries the
+// ray's best t so far as its bound, so the result is bit-identical to the one-pass walk.
+struct TraceWs {
+  unsigned* counters;   // [0] items, [1] ray records (zeroed on the stream before pass A)
+  int4* ray_rec;        // 4 x int4 per handed-over ray: {n, mesh, first item, nr items}, {t, u, v, slot},
+                        // {id, ix, iy, iz}, {cx, cy, cz, -} (the ray on the mesh's 16-bit grid)
+  int2* items;          // {ray record, node reference}
+  int4* results;        // 2 x int4 per item: {t, u, v, slot}, {id, -, -, -}
+  unsigned cap_items, cap_rays;
+};
+
+template <int STACK, bool BUDGETED>
+__device__ __forceinline__ int q_walk(const uint4* __restrict__ qnodes, const float4* __restrict__ tris,
+                                       const QRay& qr, float ox, float oy, float oz, float dx, float dy,
+                                       float dz, float t_min, int& cur, int& sp, Hit& best,
+                                       int (*s_stack)[TRACE_BLOCK], int lane, int budget) {
+  // The loops are written on ballots, i.e. as the wave-level loops they are, so that the trip count
+  // is a scalar of the WAVE (a per-lane counter would only count that lane's own trips).
+  int trips = 0;
+  while (__builtin_amdgcn_ballot_w64(cur != TRACE_EMPTY) != 0) {
+    if (BUDGETED && trips >= budget) break;
+    while (__builtin_amdgcn_ballot_w64((unsigned)cur < (unsigned)TRACE_EMPTY) != 0) {
+      ++trips;
+      if (!((unsigned)cur < (unsigned)TRACE_EMPTY)) continue;
+      const uint4 a = qnodes[2 * (long long)cur], b = qnodes[2 * (long long)cur + 1];
+      float tn0, tn1;
+      const bool h0 = qbox_test(a.x, a.y, a.z, qr, t_min, best.t, tn0);
+      const bool h1 = qbox_test(a.w, b.x, b.y, qr, t_min, best.t, tn1);
+      const int c0 = (int)b.z, c1 = (int)b.w;
+      if (h0 && h1) {
+        const bool swap = tn1 < tn0;
+        s_stack[sp++][lane] = swap ? c0 : c1;
+        cur = swap ? c1 : c0;
+      } else if (h0) {
+        cur = c0;
+      } else if (h1) {
+        cur = c1;
+      } else {
+        cur = sp ? s_stack[--sp][lane] : TRACE_EMPTY;
+      }
+    }
+    if (cur != TRACE_EMPTY) {
+      const int code = ~cur;
+      const int first = code >> 4, cnt = code & 15;
+      for (int i0 = 0; i0 < cnt; i0 += 4) {
+        float4 tv[4][3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const long long s = first + min(i0 + i, cnt - 1);
+          tv[i][0] = tris[3 * s];
+          tv[i][1] = tris[3 * s + 1];
+          tv[i][2] = tris[3 * s + 2];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i0 + i < cnt)
+            tri_test(tv[i][0], tv[i][1], tv[i][2], ox, oy, oz, dx, dy, dz, t_min, first + i0 + i, best);
+      }
+      cur = sp ? s_stack[--sp][lane] : TRACE_EMPTY;
+    }
+  }
+  return trips;
+}
+
+__device__ __forceinline__ void write_hit(const Hit& best, long long o, float* __restrict__ hit_t,
+                                          int* __restrict__ hit_slot, float* __restrict__ hit_uv) {
+  hit_t[o] = best.slot >= 0 ? best.t : 0.0f;
+  hit_slot[o] = best.slot;
+  hit_uv[2 * o] = best.u;
+  hit_uv[2 * o + 1] = best.v;
+}
+
+// Pass A: trace_q_kernel with a trip budget.
+template <int STACK>
+__global__ __launch_bounds__(TRACE_BLOCK) void trace_qa_kernel(
+    const uint4* __restrict__ qnodes, const float4* __restrict__ tris, Roots roots, Frames frames,
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, int N, float t_min, int budget,
+    TraceWs ws, float* __restrict__ hit_t, int* __restrict__ hit_slot, float* __restrict__ hit_uv) {
+  __shared__ int s_stack[STACK][TRACE_BLOCK];
+  const int lane = threadIdx.x;
+  const long long n_raw = (long long)blockIdx.x * TRACE_BLOCK + lane;
+  const bool alive = n_raw < N;                 // no early return: the hand-over below is a wave operation
+  const long long n = alive ? n_raw : N - 1;
+  const int mesh = blockIdx.y;
+  const float ox = rays_o[3 * n], oy = rays_o[3 * n + 1], oz = rays_o[3 * n + 2];
+  const float dx = rays_d[3 * n], dy = rays_d[3 * n + 1], dz = rays_d[3 * n + 2];
+  const float* fr = frames.f[mesh];
+  QRay qr;
+  {
+    const float gx = (ox - fr[0]) / fr[3] + 1.0f, gy = (oy - fr[1]) / fr[4] + 1.0f,
+                gz = (oz - fr[2]) / fr[5] + 1.0f;
+    const float ix = 1.0f / (dx / fr[3]), iy = 1.0f / (dy / fr[4]), iz = 1.0f / (dz / fr[5]);
+    qr.ix = f32x2_t{ix, ix}, qr.iy = f32x2_t{iy, iy}, qr.iz = f32x2_t{iz, iz};
+    qr.cx = f32x2_t{-(gx * ix), -(gx * ix)};
+    qr.cy = f32x2_t{-(gy * iy), -(gy * iy)};
+    qr.cz = f32x2_t{-(gz * iz), -(gz * iz)};
+  }
+  Hit best;
+  best.t = INFINITY;
+  best.u = best.v = 0.f;
+  best.slot = -1;
+  best.id = 0x7fffffff;
+  int cur = alive ? roots.root[mesh] : TRACE_EMPTY;
+  int sp = 0;
+  q_walk<STACK, true>(qnodes, tris, qr, ox, oy, oz, dx, dy, dz, t_min, cur, sp, best, s_stack, lane, budget);
+
+  const bool pending = cur != TRACE_EMPTY;
+  const unsigned long long pm = __builtin_amdgcn_ballot_w64(pending);
+  if (pm != 0) {   // wave-uniform
+    // one reservation per wave: items = node in hand + stack entries of every pending lane
+    const int mine = pending ? sp + 1 : 0;
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(incl, off);
+      if (lane >= off) incl += v;
+    }
+    const int total = __shfl(incl, 63);
+    const int nrays = __builtin_popcountll(pm);
+    unsigned base = 0, rbase = 0;
+    if (lane == 0) {
+      base = atomicAdd(&ws.counters[0], (unsigned)total);
+      rbase = atomicAdd(&ws.counters[1], (unsigned)nrays);
+    }
+    base = __builtin_amdgcn_readfirstlane(base);
+    rbase = __builtin_amdgcn_readfirstlane(rbase);
+    const bool fits = (unsigned long long)base + total <= ws.cap_items && (unsigned long long)rbase + nrays <= ws.cap_rays;
+    const unsigned my_first = base + (unsigned)(incl - mine);
+    const unsigned my_rec = rbase + (unsigned)__builtin_popcountll(pm & ((1ull << lane) - 1ull));
+    if (pending) {
+      // (a reservation that does not fit is filled with empty items / records and the wave walks on below)
+      if (my_rec < ws.cap_rays) {
+        int4* r = ws.ray_rec + 4ll * my_rec;
+        r[0] = int4{fits ? (int)n : -1, mesh, (int)my_first, fits ? mine : 0};
+        r[1] = int4{__float_as_int(best.t), __float_as_int(best.u), __float_as_int(best.v), best.slot};
+        r[2] = int4{best.id, __float_as_int(qr.ix.x), __float_as_int(qr.iy.x), __float_as_int(qr.iz.x)};
+        r[3] = int4{__float_as_int(qr.cx.x), __float_as_int(qr.cy.x), __float_as_int(qr.cz.x), 0};
+      }
+      for (int j = 0; j < mine; ++j) {
+        const unsigned it = my_first + (unsigned)j;
+        if (it < ws.cap_items)
+          ws.items[it] = int2{(int)my_rec, fits ? (j == 0 ? cur : s_stack[j - 1][lane]) : TRACE_EMPTY};
+      }
+    }
+    if (fits) {
+      if (alive && !pending) write_hit(best, (long long)mesh * N + n, hit_t, hit_slot, hit_uv);
+      return;
+    }
+    q_walk<STACK, false>(qnodes, tris, qr, ox, oy, oz, dx, dy, dz, t_min, cur, sp, best, s_stack, lane, 0);
+  }
+  if (alive) write_hit(best, (long long)mesh * N + n, hit_t, hit_slot, hit_uv);
+}
+
+// Pass B: one lane per handed-over subtree, 64 of them per trip of a persistent wave.
+template <int STACK>
+__global__ __launch_bounds__(TRACE_BLOCK) void trace_qb_kernel(
+    const uint4* __restrict__ qnodes, const float4* __restrict__ tris, const float* __restrict__ rays_o,
+    const float* __restrict__ rays_d, float t_min, TraceWs ws) {
+  __shared__ int s_stack[STACK][TRACE_BLOCK];
+  const int lane = threadIdx.x;
+  const unsigned n_items = min(ws.counters[0], ws.cap_items);
+  for (unsigned chunk = blockIdx.x; (unsigned long long)chunk * TRACE_BLOCK < n_items; chunk += gridDim.x) {
+    const unsigned it = chunk * TRACE_BLOCK + lane;
+    const bool valid = it < n_items;
+    const int2 item = valid ? ws.items[it] : int2{0, TRACE_EMPTY};
+    int cur = item.y;
+    const int4* r = ws.ray_rec + 4ll * (cur != TRACE_EMPTY ? item.x : 0);
+    const int4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+    const long long n = r0.x < 0 ? 0 : r0.x;
+    if (r0.x < 0) cur = TRACE_EMPTY;
+    const float ox = rays_o[3 * n], oy = rays_o[3 * n + 1], oz = rays_o[3 * n + 2];
+    const float dx = rays_d[3 * n], dy = rays_d[3 * n + 1], dz = rays_d[3 * n + 2];
+    QRay qr;
+    {
+      const float ix = __int_as_float(r2.y), iy = __int_as_float(r2.z), iz = __int_as_float(r2.w);
+      const float cx = __int_as_float(r3.x), cy = __int_as_float(r3.y), cz = __int_as_float(r3.z);
+      qr.ix = f32x2_t{ix, ix}, qr.iy = f32x2_t{iy, iy}, qr.iz = f32x2_t{iz, iz};
+      qr.cx = f32x2_t{cx, cx}, qr.cy = f32x2_t{cy, cy}, qr.cz = f32x2_t{cz, cz};
+    }
+    // the ray's best t so far bounds the subtree; a tie on t is settled by the face id in pass C
+    Hit best;
+    best.t = __int_as_float(r1.x);
+    best.u = best.v = 0.f;
+    best.slot = -1;
+    best.id = 0x7fffffff;
+    int sp = 0;
+    const bool had_work = cur != TRACE_EMPTY;
+    q_walk<STACK, false>(qnodes, tris, qr, ox, oy, oz, dx, dy, dz, t_min, cur, sp, best, s_stack, lane, 0);
+    if (valid && had_work) {
+      ws.results[2ll * it] = int4{__float_as_int(best.t), __float_as_int(best.u), __float_as_int(best.v), best.slot};
+      ws.results[2ll * it + 1] = int4{best.id, 0, 0, 0};
+    }
+  }
+}
+
+// Pass C: a lane per handed-over ray merges its items' candidates with what pass A had found.
+__global__ __launch_bounds__(256) void trace_qc_kernel(TraceWs ws, int N, float* __restrict__ hit_t,
+                                                       int* __restrict__ hit_slot, float* __restrict__ hit_uv) {
+  const unsigned n_rays = min(ws.counters[1], ws.cap_rays);
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n_rays; i += gridDim.x * 256) {
+    const int4* r = ws.ray_rec + 4ll * i;
+    const int4 r0 = r[0], r1 = r[1], r2 = r[2];
+    if (r0.x < 0) continue;
+    Hit best;
+    best.t = __int_as_float(r1.x), best.u = __int_as_float(r1.y), best.v = __int_as_float(r1.z);
+    best.slot = r1.w, best.id = r2.x;
+    for (int j = 0; j < r0.w; ++j) {
+      const int4 a = ws.results[2ll * (r0.z + j)], b = ws.results[2ll * (r0.z + j) + 1];
+      const float t = __int_as_float(a.x);
+      if (a.w >= 0 && (t < best.t || (t == best.t && b.x < best.id))) {
+        best.t = t, best.u = __int_as_float(a.y), best.v = __int_as_float(a.z);
+        best.slot = a.w, best.id = b.x;
+      }
+    }
+    write_hit(best, (long long)r0.y * N + r0.x, hit_t, hit_slot, hit_uv);
+  }
+}
+
+// ---- cost-feedback launch order (vsa_trace_q_fb).  The one-pass kernel's launch is full for its first
+// 155 us and then drains for 100 us (tools/trace_span.py): the waves that hold grazing rays
+// walk 100-200 trips against a median of 9, and those that happen to be dispatched late are still walking
+// when everything else has finished.  With the heaviest waves dispatched FIRST (sorted by their measured
+// trips: the upper bound of any predictor) the same kernel takes 203 us instead of 300 with stamps.  A
+// wave's trip count depends on its rays only, not on the order, so the previous launch over the same
+// rays is an exact predictor, and a good one for a camera that moves a little: every wave files itself
+// into one of three "heavy" lists (by trips) of the NEXT launch's order and sets its flag; the next
+// launch runs the lists first (heaviest list first) and then the remaining items in their natural
+// order, skipping the flagged ones.  Lists + flags always form a partition of the items, whatever rays
+// they were measured on, so the hits never depend on the feedback - only the order of issue does.
+struct TraceFeedback {
+  const int* prev;                 // header {tag = items of the launch that wrote it, n0, n1, n2}
+  const unsigned char* prev_flag;  // [items] 1 = in a list
+  const int* prev_lists;           // 3 x cap
+  int* next;
+  unsigned char* next_flag;
+  int* next_lists;
+  int cap;
+};
+#ifndef TRACE_FB_T
+#define TRACE_FB_T 160, 128, 64     /* same-box sweep in profiles/r03/trace_feedback.txt */
+#endif
+constexpr int TRACE_FB_TS[3] = {TRACE_FB_T};
+constexpr int TRACE_FB_T0 = TRACE_FB_TS[0], TRACE_FB_T1 = TRACE_FB_TS[1], TRACE_FB_T2 = TRACE_FB_TS[2];   // trips: list 0 / 1 / 2
+
+template <int STACK>
+__global__ __launch_bounds__(TRACE_BLOCK) void trace_qf_kernel(
+    const uint4* __restrict__ qnodes, const float4* __restrict__ tris, Roots roots, Frames frames,
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, int N, int G, int nr_items, float t_min,
+    TraceFeedback fb, float* __restrict__ hit_t, int* __restrict__ hit_slot, float* __restrict__ hit_uv) {
+  __shared__ int s_stack[STACK][TRACE_BLOCK];
+  const int lane = threadIdx.x;
+  // dispatch slot -> item (all wave-uniform)
+  int item = blockIdx.x;
+  {
+    int n0 = 0, n1 = 0, n2 = 0;
+    if (fb.prev[0] == nr_items) n0 = min(fb.prev[1], fb.cap), n1 = min(fb.prev[2], fb.cap), n2 = min(fb.prev[3], fb.cap);
+    const int heavy = n0 + n1 + n2;
+    if (item < heavy) {
+      const int l = item < n0 ? 0 : item < n0 + n1 ? 1 : 2;
+      item = fb.prev_lists[l * fb.cap + (item - (l == 0 ? 0 : l == 1 ? n0 : n0 + n1))];
+    } else {
+      item -= heavy;
+      if (item >= nr_items) return;
+      if (heavy && fb.prev_flag[item]) return;   // ran from a list
+    }
+  }
+  const int mesh = item / G;
+  const long long n_raw = (long long)(item - mesh * G) * TRACE_BLOCK + lane;
+  const bool alive = n_raw < N;
+  const long long n = alive ? n_raw : N - 1;
+  const float ox = rays_o[3 * n], oy = rays_o[3 * n + 1], oz = rays_o[3 * n + 2];
+  const float dx = rays_d[3 * n], dy = rays_d[3 * n + 1], dz = rays_d[3 * n + 2];
+  const float* fr = frames.f[mesh];
+  QRay qr;
+  {
+    const float gx = (ox - fr[0]) / fr[3] + 1.0f, gy = (oy - fr[1]) / fr[4] + 1.0f,
+                gz = (oz - fr[2]) / fr[5] + 1.0f;
+    const float ix = 1.0f / (dx / fr[3]), iy = 1.0f / (dy / fr[4]), iz = 1.0f / (dz / fr[5]);
+    qr.ix = f32x2_t{ix, ix}, qr.iy = f32x2_t{iy, iy}, qr.iz = f32x2_t{iz, iz};
+    qr.cx = f32x2_t{-(gx * ix), -(gx * ix)};
+    qr.cy = f32x2_t{-(gy * iy), -(gy * iy)};
+    qr.cz = f32x2_t{-(gz * iz), -(gz * iz)};
+  }
+  Hit best;
+  best.t = INFINITY;
+  best.u = best.v = 0.f;
+  best.slot = -1;
+  best.id = 0x7fffffff;
+  int cur = alive ? roots.root[mesh] : TRACE_EMPTY;
+  int sp = 0;
+  const int trips = q_walk<STACK, true>(qnodes, tris, qr, ox, oy, oz, dx, dy, dz, t_min, cur, sp, best, s_stack,
+                                        lane, 0x7fffffff);
+  if (alive) write_hit(best, (long long)mesh * N + n, hit_t, hit_slot, hit_uv);
+  // file this wave for the next launch
+  if (lane == 0) {
+    const int l = trips >= TRACE_FB_T0 ? 0 : trips >= TRACE_FB_T1 ? 1 : trips >= TRACE_FB_T2 ? 2 : 3;
+    bool listed = false;
+    if (l < 3) {
+      const int idx = atomicAdd(&fb.next[1 + l], 1);
+      listed = idx < fb.cap;                     // a full list: the item stays in the natural order
+      if (listed) fb.next_lists[l * fb.cap + idx] = item;
+    }
+    fb.next_flag[item] = listed ? 1 : 0;
+    if (item == 0) fb.next[0] = nr_items;
+  }
 }
 
 // ---- 4-wide nodes (vsa_bvh_export_q4).  PMC of trace_q_kernel at 800x800, K=5 (profiles/r03/pmc):
@@ -620,6 +984,124 @@ extern "C" int vsa_trace_q(const uint32_t* qnodes, const float* tris, const int3
   VSA_RETURN_LAUNCH_STATUS();
 }
 
+// Workspace of vsa_trace_q_budgeted: 256 B of counters, then per ray record 64 B + two items of 8 B +
+// their two results of 32 B = 144 B.  The recommended size holds a quarter of the (ray, shell) pairs.
+extern "C" long long vsa_trace_q_workspace_bytes(int nr_rays, int nr_meshes) {
+  if (nr_rays < 0 || nr_meshes < 1) return -1;
+  const long long pairs = (long long)nr_rays * nr_meshes;
+  return 256 + 144ll * std::min<long long>(pairs / 4 + 4096, 1ll << 29);
+}
+
+extern "C" int vsa_trace_q_budgeted(const uint32_t* qnodes, const float* tris, const int32_t* mesh_roots,
+                                    const float* mesh_frames, int nr_meshes, int max_depth,
+                                    const float* rays_o, const float* rays_d, int nr_rays, float t_min,
+                                    float* hit_t, int32_t* hit_slot, float* hit_uv, int round_budget,
+                                    void* workspace, long long workspace_bytes, void* stream) {
+  if (nr_meshes < 1 || nr_meshes > VSA_MAX_SHELLS || nr_rays < 0 || !mesh_roots || !mesh_frames || round_budget < 1)
+    return VSA_ERR_ARG;
+  if (max_depth >= TRACE_STACK) return VSA_ERR_UNSUPPORTED;
+  if (nr_rays == 0) return VSA_OK;
+  if (!qnodes || !tris || !rays_o || !rays_d || !hit_t || !hit_slot || !hit_uv || !workspace) return VSA_ERR_ARG;
+  if (workspace_bytes < 256 + 144 || ((uintptr_t)workspace & 15)) return VSA_ERR_ARG;
+  Roots r;
+  Frames fr;
+  for (int i = 0; i < VSA_MAX_SHELLS; ++i) {
+    r.root[i] = i < nr_meshes ? mesh_roots[i] : 0;
+    for (int j = 0; j < 6; ++j) fr.f[i][j] = i < nr_meshes ? mesh_frames[6 * i + j] : 1.0f;
+  }
+  TraceWs ws;
+  ws.cap_rays = (unsigned)std::min<long long>((workspace_bytes - 256) / 144, 1ll << 29);   // any size works: what
+  ws.cap_items = 2 * ws.cap_rays;                                                            // does not fit is not handed over
+  char* w = static_cast<char*>(workspace);
+  ws.counters = reinterpret_cast<unsigned*>(w);
+  ws.ray_rec = reinterpret_cast<int4*>(w + 256);
+  ws.items = reinterpret_cast<int2*>(w + 256 + 64ll * ws.cap_rays);
+  ws.results = reinterpret_cast<int4*>(w + 256 + 64ll * ws.cap_rays + 8ll * ws.cap_items);
+  hipStream_t s = (hipStream_t)stream;
+  VSA_HIP_TRY(hipMemsetAsync(ws.counters, 0, 16, s));
+  const uint4* qn = reinterpret_cast<const uint4*>(qnodes);
+  const float4* tr = reinterpret_cast<const float4*>(tris);
+  dim3 grid(vsa_div_up(nr_rays, TRACE_BLOCK), nr_meshes), block(TRACE_BLOCK);
+  // pass B: a fixed number of persistent one-wave workgroups (the item count is only known on the device)
+  int cus = 256;
+  { const int rc = vsa_cu_count(&cus); if (rc != VSA_OK) return rc; }
+  const int nb = 8 * cus;
+  if (max_depth < 24) {
+    hipLaunchKernelGGL(trace_qa_kernel<24>, grid, block, 0, s, qn, tr, r, fr, rays_o, rays_d, nr_rays, t_min,
+                       round_budget, ws, hit_t, hit_slot, hit_uv);
+    hipLaunchKernelGGL(trace_qb_kernel<24>, dim3(nb), block, 0, s, qn, tr, rays_o, rays_d, t_min, ws);
+  } else {
+    hipLaunchKernelGGL(trace_qa_kernel<TRACE_STACK>, grid, block, 0, s, qn, tr, r, fr, rays_o, rays_d, nr_rays,
+                       t_min, round_budget, ws, hit_t, hit_slot, hit_uv);
+    hipLaunchKernelGGL(trace_qb_kernel<TRACE_STACK>, dim3(nb), block, 0, s, qn, tr, rays_o, rays_d, t_min, ws);
+  }
+  hipLaunchKernelGGL(trace_qc_kernel, dim3(2 * cus), dim3(256), 0, s, ws, nr_rays, hit_t, hit_slot, hit_uv);
+  VSA_RETURN_LAUNCH_STATUS();
+}
+
+// Feedback buffer of vsa_trace_q_fb: two halves (written / read alternately) at offsets 0 and bytes / 2,
+// each: 16 B of header, one flag byte per item (rounded up to 16), three lists of cap ints.  The header
+// offsets depend on the buffer only, so a buffer sized for more rays serves fewer (the tag in the header
+// tells a half that was written for another item count).
+static long long trace_fb_half_bytes(long long items, int* cap_out) {
+  const int cap = (int)std::min<long long>(items / 8 + 64, 1 << 27);
+  if (cap_out) *cap_out = cap;
+  return (16 + (items + 15) / 16 * 16 + 12ll * cap + 255) / 256 * 256;
+}
+
+extern "C" long long vsa_trace_feedback_bytes(int nr_rays, int nr_meshes) {
+  if (nr_rays < 0 || nr_meshes < 1) return -1;
+  return 2 * trace_fb_half_bytes((long long)vsa_div_up(nr_rays, TRACE_BLOCK) * nr_meshes, nullptr);
+}
+
+extern "C" int vsa_trace_q_fb(const uint32_t* qnodes, const float* tris, const int32_t* mesh_roots,
+                              const float* mesh_frames, int nr_meshes, int max_depth, const float* rays_o,
+                              const float* rays_d, int nr_rays, float t_min, float* hit_t, int32_t* hit_slot,
+                              float* hit_uv, void* feedback, long long feedback_bytes, int phase, void* stream) {
+  if (nr_meshes < 1 || nr_meshes > VSA_MAX_SHELLS || nr_rays < 0 || !mesh_roots || !mesh_frames || (phase & ~1))
+    return VSA_ERR_ARG;
+  if (max_depth >= TRACE_STACK) return VSA_ERR_UNSUPPORTED;
+  if (nr_rays == 0) return VSA_OK;
+  if (!qnodes || !tris || !rays_o || !rays_d || !hit_t || !hit_slot || !hit_uv || !feedback) return VSA_ERR_ARG;
+  const int G = vsa_div_up(nr_rays, TRACE_BLOCK);
+  const long long items = (long long)G * nr_meshes;
+  int cap = 0;
+  if (items > 0x7fffffff / 2 || feedback_bytes < 2 * trace_fb_half_bytes(items, &cap) || ((uintptr_t)feedback & 15))
+    return VSA_ERR_ARG;
+  const long long half = (feedback_bytes / 2) & ~255ll;
+  const long long flags_bytes = (items + 15) / 16 * 16;
+  Roots r;
+  Frames fr;
+  for (int i = 0; i < VSA_MAX_SHELLS; ++i) {
+    r.root[i] = i < nr_meshes ? mesh_roots[i] : 0;
+    for (int j = 0; j < 6; ++j) fr.f[i][j] = i < nr_meshes ? mesh_frames[6 * i + j] : 1.0f;
+  }
+  char* b = static_cast<char*>(feedback);
+  char* prev = b + (phase ? half : 0);
+  char* next = b + (phase ? 0 : half);
+  TraceFeedback fb;
+  fb.prev = reinterpret_cast<const int*>(prev);
+  fb.prev_flag = reinterpret_cast<const unsigned char*>(prev + 16);
+  fb.prev_lists = reinterpret_cast<const int*>(prev + 16 + flags_bytes);
+  fb.next = reinterpret_cast<int*>(next);
+  fb.next_flag = reinterpret_cast<unsigned char*>(next + 16);
+  fb.next_lists = reinterpret_cast<int*>(next + 16 + flags_bytes);
+  fb.cap = cap;
+  hipStream_t s = (hipStream_t)stream;
+  VSA_HIP_TRY(hipMemsetAsync(next, 0, 16, s));
+  const uint4* qn = reinterpret_cast<const uint4*>(qnodes);
+  const float4* tr = reinterpret_cast<const float4*>(tris);
+  // every item once, plus room for the listed ones' second (skipped) appearance
+  dim3 grid((unsigned)(items + 3ll * cap)), block(TRACE_BLOCK);
+  if (max_depth < 24)
+    hipLaunchKernelGGL(trace_qf_kernel<24>, grid, block, 0, s, qn, tr, r, fr, rays_o, rays_d, nr_rays, G, (int)items,
+                       t_min, fb, hit_t, hit_slot, hit_uv);
+  else
+    hipLaunchKernelGGL(trace_qf_kernel<TRACE_STACK>, grid, block, 0, s, qn, tr, r, fr, rays_o, rays_d, nr_rays, G,
+                       (int)items, t_min, fb, hit_t, hit_slot, hit_uv);
+  VSA_RETURN_LAUNCH_STATUS();
+}
+
 extern "C" int vsa_trace_q4(const uint32_t* qnodes4, const float* tris, const int32_t* mesh_roots,
                             const float* mesh_frames, int nr_meshes, int max_depth4,
                             const float* rays_o, const float* rays_d, int nr_rays, float t_min,
@@ -664,3 +1146,18 @@ extern "C" int vsa_hit_attributes(const float* tris, const float* rays_o, const 
                      barycentric);
   VSA_RETURN_LAUNCH_STATUS();
 }
+
+#ifdef TRACE_SPAN
+extern "C" int vsa_span_set_order(const void* order, int n) {
+  VSA_HIP_TRY(hipDeviceSynchronize());
+  const int on = order != nullptr;
+  if (on) VSA_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_torder), order, sizeof(int) * n));
+  VSA_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_torder_on), &on, sizeof(int)));
+  return 0;
+}
+extern "C" int vsa_span_read_trace(void* dst) {
+  VSA_HIP_TRY(hipDeviceSynchronize());
+  VSA_HIP_TRY(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_tspan), sizeof(g_tspan)));
+  return 0;
+}
+#endif

@@ -26,6 +26,17 @@ class RayTracer:
         self.node_format = node_format or os.environ.get("VSA_TRACE_NODES", "q16")
         if self.node_format not in ("q16x4", "q16", "f32"):
             raise _lib.VolsurfsHipError(f"unknown node_format {self.node_format}")
+        # q16 only: trips of the walk loop after which a wave hands its unfinished rays' subtrees to a
+        # second pass (vsa_trace_q_budgeted; identical results).  0 = the one-pass kernel, the default:
+        # measured at 800x800, K = 5: one pass 0.258 ms; budget 96 / 64 / 48 / 24: 0.256 / 0.287 / 0.354 /
+        # 0.818 ms (pass A loses its tail, 0.185 ms at 48, but a ray that has no hit yet
+        # hands over subtrees the one-pass walk would have pruned after its first hit)
+        self.round_budget = int(os.environ.get("VSA_TRACE_BUDGET", "0"))
+        self._ws = None
+        self.workspace_bytes = None
+        # q16 only: launch order from the previous call's measured cost (vsa_trace_q_fb; identical hits)
+        self.cost_feedback = os.environ.get("VSA_TRACE_FEEDBACK", "1") != "0"
+        self._fb = None
         self.nr_meshes = len(tensor_meshes)
         if not 1 <= self.nr_meshes <= 16:
             raise _lib.VolsurfsHipError("RayTracer supports 1..16 meshes")
@@ -95,6 +106,19 @@ class RayTracer:
         self._roots = (ctypes.c_int32 * self.nr_meshes)(*roots)
         self.roots = roots
 
+    def _workspace(self, N, device):
+        """Scratch of vsa_trace_q_budgeted for N rays (kept between calls; contents are not)."""
+        if self._ws is None or self._ws[1] != N or self._ws[0].device != device:
+            fn = _lib.lib().vsa_trace_q_workspace_bytes
+            fn.restype = ctypes.c_longlong
+            nbytes = int(fn(ctypes.c_int(N), ctypes.c_int(self.nr_meshes)))
+            if nbytes < 0:
+                raise _lib.VolsurfsHipError("vsa_trace_q_workspace_bytes failed")
+            if self.workspace_bytes is not None:     # tests: a workspace too small for the hand-overs
+                nbytes = int(self.workspace_bytes)
+            self._ws = (torch.empty(nbytes, dtype=torch.uint8, device=device), N, nbytes)
+        return self._ws[0], self._ws[2]
+
     def trace_all(self, rays_o, rays_d, t_min=0.0):
         """All K shells, one launch.  Returns hit_t [K,N] f32, hit_slot [K,N]
         i32 (global index into self.tris, -1 = miss), hit_uv [K,N,2] f32."""
@@ -109,6 +133,23 @@ class RayTracer:
             _lib.call("vsa_trace_q4", self.qnodes4, self.tris, self._roots4, self._frames, K,
                       self.max_depth4, rays_o, rays_d, N, float(t_min), hit_t, hit_slot, hit_uv,
                       _lib.stream_ptr())
+        elif self.node_format == "q16" and self.round_budget > 0 and self.max_depth < 48:
+            ws, ws_bytes = self._workspace(N, rays_o.device)
+            _lib.call("vsa_trace_q_budgeted", self.qnodes, self.tris, self._roots, self._frames, K,
+                      self.max_depth, rays_o, rays_d, N, float(t_min), hit_t, hit_slot, hit_uv,
+                      self.round_budget, ws, ctypes.c_longlong(ws_bytes), _lib.stream_ptr())
+        elif self.node_format == "q16" and self.cost_feedback and self.max_depth < 48:
+            if self._fb is None or self._fb[1] < N or self._fb[0].device != rays_o.device:   # grows only
+                fn = _lib.lib().vsa_trace_feedback_bytes
+                fn.restype = ctypes.c_longlong
+                nbytes = int(fn(ctypes.c_int(N), ctypes.c_int(K)))
+                if nbytes < 0:
+                    raise _lib.VolsurfsHipError("vsa_trace_feedback_bytes failed")
+                self._fb = [torch.zeros(nbytes, dtype=torch.uint8, device=rays_o.device), N, nbytes, 0]
+            _lib.call("vsa_trace_q_fb", self.qnodes, self.tris, self._roots, self._frames, K,
+                      self.max_depth, rays_o, rays_d, N, float(t_min), hit_t, hit_slot, hit_uv,
+                      self._fb[0], ctypes.c_longlong(self._fb[2]), self._fb[3], _lib.stream_ptr())
+            self._fb[3] ^= 1
         elif self.node_format == "q16":
             _lib.call("vsa_trace_q", self.qnodes, self.tris, self._roots, self._frames, K,
                       self.max_depth, rays_o, rays_d, N, float(t_min), hit_t, hit_slot, hit_uv,
