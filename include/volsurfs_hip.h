@@ -262,7 +262,8 @@ typedef struct vsa_nt_plan {
  *   hit_slot [K,N] i32, hit_uv [K,N,2] f32 from vsa_trace; face_uvs [nr_tris,6]
  *   f32 = per-corner uvs in leaf (slot) order.  Writes tex_uv [K,N,2] and sets
  *   marks[dom_off[..] + texel] = 1 for the 4 lerp corners of every degree.
- *   marks (u8 [dom_off[K*4]]) must be zero on entry. */
+ *   marks (u8 [dom_off[K*4]]) must be zero on entry; marks == NULL: tex_uv only (shading from
+ *   baked textures needs no compaction). */
 int vsa_nt_mark(const vsa_nt_plan* plan, const int32_t* hit_slot, const float* hit_uv,
                 const float* face_uvs, int nr_rays, float* tex_uv, uint8_t* marks, void* stream);
 
@@ -274,6 +275,14 @@ int vsa_nt_mark(const vsa_nt_plan* plan, const int32_t* hit_slot, const float* h
 int vsa_nt_compact(const vsa_nt_plan* plan, const uint8_t* marks, int32_t* slot_of,
                    int32_t* texel_of_slot, float* slot_xy, int32_t* seg_start,
                    int32_t* block_scratch, void* stream);
+/* vsa_nt_compact for a frame loop: the same slots, seg_start and slot_xy, but slot_of is written only
+ * where a texel is marked (entries of untouched texels keep whatever they held: nothing on the path
+ * reads them - shading only looks up the corners it marked), the marks are CLEARED on the way (the
+ * next vsa_nt_mark needs no fill), and texel_of_slot may be NULL.  At 800x800, K = 5 that is 112 MB
+ * of -1 and a 28 MB fill less per frame. */
+int vsa_nt_compact_frame(const vsa_nt_plan* plan, uint8_t* marks, int32_t* slot_of,
+                         int32_t* texel_of_slot, float* slot_xy, int32_t* seg_start,
+                         int32_t* block_scratch, void* stream);
 
 /* Step 3: hash-grid encode every slot of every texture, level-major with the
  * level table in LDS.  tables_h: f16 [n_tex][level_offset[n]*2];

@@ -74,6 +74,7 @@ def test_argument_errors_are_reported_not_ignored():
     assert L.vsa_trace_q4(null, null, roots, fr, 1, 99, null, null, 10, ctypes.c_float(0), null, null, null, null) == ERR_UNSUPPORTED   # 3 x 98 stack entries
     assert L.vsa_trace_q4(null, null, roots, fr, 1, 10, null, null, 0, ctypes.c_float(0), null, null, null, null) == 0
     assert L.vsa_bvh_export_q4(null, null, null, 0, 0, null, null, null) == ERR_ARG
+    assert L.vsa_nt_compact_frame(null, null, null, null, null, null, null, null) == ERR_ARG
     ll = ctypes.c_longlong
     assert L.vsa_trace_q_budgeted(null, null, roots, fr, 1, 10, null, null, 10, ctypes.c_float(0), null, null, null, 24,
                                   null, ll(1 << 20), null) == ERR_ARG                                  # null arrays

@@ -57,7 +57,8 @@ def _setup(K=2, N=3000, seed=0):
 def test_mark_compact_encode_bit_exact():
     bank, face_uvs, hit_slot, hit_uv = _setup()
     K, N = hit_slot.shape
-    tex_uv = bank.mark_and_compact(hit_slot.cuda(), hit_uv.cuda(), face_uvs.cuda())
+    tex_uv = bank.mark_and_compact(hit_slot.cuda(), hit_uv.cuda(), face_uvs.cuda(), want_texel_of_slot=True)
+    assert not bank.marks.any()          # the frame compaction clears the marks it consumed
     bank.encode()
     feats = bank.features_level_major()
     torch.cuda.synchronize()

@@ -22,7 +22,7 @@ __global__ void nt_mark_kernel(vsa_nt_plan plan, const int* __restrict__ hit_slo
   float2 uv = make_float2(0.f, 0.f);
   if (slot >= 0) {
     uv = nt_interp_uv(face_uvs + 6 * (long long)slot, hit_uv[2 * o], hit_uv[2 * o + 1]);
-    const int D = max(plan.rgb_degrees, plan.alpha_degrees);
+    const int D = marks ? max(plan.rgb_degrees, plan.alpha_degrees) : 0;   // marks == NULL: uv only
     for (int d = 0; d < D; ++d) {
       const int R = plan.tex_res[d];
       const int W = R + 2;
@@ -98,8 +98,12 @@ __global__ __launch_bounds__(1024) void nt_scan_blocks_kernel(vsa_nt_plan plan,
 // (1024 threads = one 4096-texel domain block): the marks come in as one dword and
 // slot_of goes out as one int4 per lane, i.e. every wave instruction moves a contiguous
 // 256 B / 1 KiB (16 texels per thread made each store touch 64 lines at 16 B).
+// SPARSE (vsa_nt_compact_frame): slot_of is only written where a texel is marked (nothing reads the
+// slot of an untouched texel: 112 MB of -1 per 800x800 frame otherwise), the marks are cleared on the
+// way (the next frame needs no 28 MB fill), texel_of_slot is optional.
+template <bool SPARSE>
 __global__ __launch_bounds__(1024) void nt_assign_kernel(vsa_nt_plan plan,
-                                                         const unsigned* __restrict__ marks,
+                                                         unsigned* __restrict__ marks,
                                                          const int* __restrict__ block_prefix,
                                                          int4* __restrict__ slot_of,
                                                          int* __restrict__ texel_of_slot,
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(1024) void nt_assign_kernel(vsa_nt_plan plan,
     out[i] = m ? slot : -1;
     if (m) {
       if (slot < slot_capacity) {
-        texel_of_slot[slot] = (int)(vec * 4 + i);
+        if (!SPARSE || texel_of_slot) texel_of_slot[slot] = (int)(vec * 4 + i);
         // texel centre, normalised exactly like normalize_uv_coord(corner) in the reference
         slot_xy[slot] = make_float2(((float)(ix - 1) + 0.5f) / Rf, ((float)(iy - 1) + 0.5f) / Rf);
       }
@@ -148,7 +152,8 @@ __global__ __launch_bounds__(1024) void nt_assign_kernel(vsa_nt_plan plan,
       ++iy;
     }
   }
-  slot_of[vec] = make_int4(out[0], out[1], out[2], out[3]);
+  if (!SPARSE || word) slot_of[vec] = make_int4(out[0], out[1], out[2], out[3]);
+  if (SPARSE && word) marks[vec] = 0;
 }
 
 }  // namespace
@@ -174,19 +179,18 @@ extern "C" int vsa_nt_mark(const vsa_nt_plan* plan, const int32_t* hit_slot, con
   if (rc) return rc;
   if (nr_rays < 0) return VSA_ERR_ARG;
   if (nr_rays == 0) return VSA_OK;
-  if (!hit_slot || !hit_uv || !face_uvs || !tex_uv || !marks) return VSA_ERR_ARG;
+  if (!hit_slot || !hit_uv || !face_uvs || !tex_uv) return VSA_ERR_ARG;
   dim3 grid(vsa_div_up(nr_rays, 256), plan->nr_shells);
   hipLaunchKernelGGL(nt_mark_kernel, grid, dim3(256), 0, (hipStream_t)stream, *plan, hit_slot,
                      hit_uv, face_uvs, nr_rays, tex_uv, marks);
   VSA_RETURN_LAUNCH_STATUS();
 }
 
-extern "C" int vsa_nt_compact(const vsa_nt_plan* plan, const uint8_t* marks, int32_t* slot_of,
-                              int32_t* texel_of_slot, float* slot_xy, int32_t* seg_start,
-                              int32_t* block_scratch, void* stream) {
+static int nt_compact(const vsa_nt_plan* plan, uint8_t* marks, int32_t* slot_of, int32_t* texel_of_slot,
+                      float* slot_xy, int32_t* seg_start, int32_t* block_scratch, bool sparse, void* stream) {
   int rc = plan_check(plan);
   if (rc) return rc;
-  if (!marks || !slot_of || !texel_of_slot || !slot_xy || !seg_start || !block_scratch)
+  if (!marks || !slot_of || (!texel_of_slot && !sparse) || !slot_xy || !seg_start || !block_scratch)
     return VSA_ERR_ARG;
   const long long total = plan->dom_off[plan->nr_shells * VSA_NT_MAX_DEG];
   const int nr_blocks = (int)(total / NT_DOM_BLOCK);
@@ -196,9 +200,26 @@ extern "C" int vsa_nt_compact(const vsa_nt_plan* plan, const uint8_t* marks, int
                      reinterpret_cast<const uint4*>(marks), block_scratch);
   hipLaunchKernelGGL(nt_scan_blocks_kernel, dim3(1), dim3(1024), 0, st, *plan, block_scratch,
                      nr_blocks, seg_start);
-  hipLaunchKernelGGL(nt_assign_kernel, dim3(nr_blocks), dim3(1024), 0, st, *plan,
-                     reinterpret_cast<const unsigned*>(marks), block_scratch,
-                     reinterpret_cast<int4*>(slot_of), texel_of_slot,
-                     reinterpret_cast<float2*>(slot_xy), (long long)plan->slot_capacity);
+  if (sparse)
+    hipLaunchKernelGGL(nt_assign_kernel<true>, dim3(nr_blocks), dim3(1024), 0, st, *plan,
+                       reinterpret_cast<unsigned*>(marks), block_scratch, reinterpret_cast<int4*>(slot_of),
+                       texel_of_slot, reinterpret_cast<float2*>(slot_xy), (long long)plan->slot_capacity);
+  else
+    hipLaunchKernelGGL(nt_assign_kernel<false>, dim3(nr_blocks), dim3(1024), 0, st, *plan,
+                       reinterpret_cast<unsigned*>(marks), block_scratch, reinterpret_cast<int4*>(slot_of),
+                       texel_of_slot, reinterpret_cast<float2*>(slot_xy), (long long)plan->slot_capacity);
   VSA_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int vsa_nt_compact(const vsa_nt_plan* plan, const uint8_t* marks, int32_t* slot_of,
+                              int32_t* texel_of_slot, float* slot_xy, int32_t* seg_start,
+                              int32_t* block_scratch, void* stream) {
+  return nt_compact(plan, const_cast<uint8_t*>(marks), slot_of, texel_of_slot, slot_xy, seg_start, block_scratch,
+                    false, stream);
+}
+
+extern "C" int vsa_nt_compact_frame(const vsa_nt_plan* plan, uint8_t* marks, int32_t* slot_of,
+                                    int32_t* texel_of_slot, float* slot_xy, int32_t* seg_start,
+                                    int32_t* block_scratch, void* stream) {
+  return nt_compact(plan, marks, slot_of, texel_of_slot, slot_xy, seg_start, block_scratch, true, stream);
 }

@@ -29,6 +29,7 @@ WEIGHTS_PER_TEX = 8192
 # backward needs the planes, 0.65 vs 0.61-0.64 ms and 1 043 vs 1 061 it/s — the vector cache's
 # look-up rate bounds the gathers.  Hence "auto": fused exactly when the feature
 # planes are not needed.  VSA_NT_FUSED=1 / 0 force it on / off (A/B switch, tools/README).
+_DENSE_COMPACT = os.environ.get("VSA_NT_DENSE_COMPACT", "0") == "1"    # A/B switch: rounds 1-2's fill + dense slot_of
 FUSED_FORWARD = {"0": False, "1": True}.get(os.environ.get("VSA_NT_FUSED", "auto"), "auto")
 
 class Plan(ctypes.Structure):
@@ -150,7 +151,7 @@ class NeuralTextureBank(torch.nn.Module):
         i32, u8 = torch.int32, torch.uint8
         cap, K = self.slot_capacity, self.K
         self.marks = torch.zeros(self.dom_total, dtype=u8, device=dev)
-        self.slot_of = torch.empty(self.dom_total, dtype=i32, device=dev)
+        self.slot_of = torch.full((self.dom_total,), -1, dtype=i32, device=dev)
         self.texel_of_slot = torch.zeros(cap, dtype=i32, device=dev)
         self.slot_xy = torch.zeros(cap, 2, device=dev)
         self.seg_start = torch.zeros(K * MAX_DEG + 1, dtype=i32, device=dev)
@@ -172,20 +173,28 @@ class NeuralTextureBank(torch.nn.Module):
         self.weights_h.copy_(self.weights)
 
     # -- stages --------------------------------------------------------------
-    def mark_and_compact(self, hit_slot, hit_uv, face_uvs):
+    def mark_and_compact(self, hit_slot, hit_uv, face_uvs, want_texel_of_slot=False):
         """hit_slot [K,N] i32, hit_uv [K,N,2], face_uvs [nr_tris,6] (leaf order).
-        Returns tex_uv [K,N,2]."""
+        Returns tex_uv [K,N,2].  slot_of is valid for the touched texels only (vsa_nt_compact_frame);
+        texel_of_slot (the inverse map: nothing on the path reads it) is written on request."""
         K, N = hit_slot.shape
         assert K == self.K and N <= self.max_rays
         if getattr(self, "baked", False):
             raise _lib.VolsurfsHipError("this bank holds baked textures: use tex_uv_only + shade")
         st = _lib.stream_ptr()
         tex_uv = torch.empty(K, N, 2, device=hit_slot.device)
-        self.marks.zero_()
+        # the marks are zero here: allocated so, and every compaction clears what it reads
+        if _DENSE_COMPACT:
+            self.marks.zero_()
         _lib.call("vsa_nt_mark", ctypes.byref(self.plan), hit_slot, hit_uv, face_uvs, N, tex_uv,
                   self.marks, st)
-        _lib.call("vsa_nt_compact", ctypes.byref(self.plan), self.marks, self.slot_of,
-                  self.texel_of_slot, self.slot_xy, self.seg_start, self.block_scratch, st)
+        if _DENSE_COMPACT:
+            _lib.call("vsa_nt_compact", ctypes.byref(self.plan), self.marks, self.slot_of,
+                      self.texel_of_slot, self.slot_xy, self.seg_start, self.block_scratch, st)
+            return tex_uv
+        _lib.call("vsa_nt_compact_frame", ctypes.byref(self.plan), self.marks, self.slot_of,
+                  self.texel_of_slot if want_texel_of_slot else None, self.slot_xy, self.seg_start,
+                  self.block_scratch, st)
         return tex_uv
 
     # -- baking (SURVEY §8f row 3: the deploy format, sh_neural_textures.py:99-114 /
@@ -213,6 +222,7 @@ class NeuralTextureBank(torch.nn.Module):
         _lib.call("vsa_nt_compact", ctypes.byref(self.plan), self.marks, self.slot_of,
                   self.texel_of_slot, self.slot_xy, self.seg_start, self.block_scratch,
                   _lib.stream_ptr())
+        self.marks.zero_()
         self.evaluate(need_features=False)
         self.baked = True
         return self
@@ -242,7 +252,7 @@ class NeuralTextureBank(torch.nn.Module):
         K, N = hit_slot.shape
         tex_uv = torch.empty(K, N, 2, device=hit_slot.device)
         _lib.call("vsa_nt_mark", ctypes.byref(self.plan), hit_slot, hit_uv, face_uvs, N, tex_uv,
-                  self.marks, _lib.stream_ptr())
+                  None, _lib.stream_ptr())
         return tex_uv
 
     def wait_params(self):

@@ -158,6 +158,10 @@ class KShellPipeline:
             "parallelism": f"tile-parallel x{world}",
             "hits_per_frame": getattr(self, "last_hits", None),
             "unique_texels_per_frame": getattr(self, "last_slots", None),
+            # the traversal's launch order comes from the previous frame's measured wave cost (same hits;
+            # VSA_TRACE_FEEDBACK=0 = the stateless launch: DESIGN.md 9.4)
+            "trace_launch_order": "cost feedback from the previous frame" if self.tracer.cost_feedback and
+                                  self.tracer.node_format == "q16" and not self.tracer.round_budget else "natural",
         }
 
     def stats(self):
