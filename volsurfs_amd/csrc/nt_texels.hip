@@ -110,6 +110,9 @@ __global__ __launch_bounds__(1024) void nt_assign_kernel(vsa_nt_plan plan,
                                                          float2* __restrict__ slot_xy,
                                                          long long slot_capacity) {
   __shared__ int s_w[16];
+  // an untouched block (a training batch touches a few per cent of the 28 M texels; the back of every
+  // shell is never seen): no marks to clear, no slot to write
+  if (SPARSE && block_prefix[blockIdx.x + 1] == block_prefix[blockIdx.x]) return;
   // the (shell, degree) domain this block lies in (domains are block aligned)
   const long long blk0 = (long long)blockIdx.x * NT_DOM_BLOCK;
   int sd = 0;
