@@ -256,7 +256,19 @@ typedef struct vsa_nt_plan {
   int64_t row_base[VSA_MAX_SHELLS * VSA_NT_MAX_DEG + 1]; /* quads; multiples of 8; segment sd
                                         reserves min(4*max_rays,(R_d+2)^2)*VSA_NT_ROW_QUADS(d);
                                         the last entry is the allocation size */
+  void* balance;                     /* NULL, or device memory of vsa_nt_balance_bytes() bytes, ZEROED before
+                                        its first use: the persistent kernels (encode / MLP, forward and
+                                        backward) stamp every workgroup's busy time there and split their
+                                        work by the shares vsa_nt_rebalance derived from the previous
+                                        launch's times (same pieces, same results: only who does which) */
 } vsa_nt_plan;
+
+/* Measured-time rebalancing of the persistent kernels' work split: once per frame,
+ * before the first of them, turns the busy times the previous frame's launches stamped into
+ * plan->balance into per-workgroup shares of each kernel's cost axis (a workgroup that took longer
+ * than the mean gets a smaller share, damped).  No-op while nothing has been stamped. */
+long long vsa_nt_balance_bytes(void);
+int vsa_nt_rebalance(const vsa_nt_plan* plan, void* stream);
 
 /* Step 1 (per frame): per-hit texture uv + mark touched texels.
  *   hit_slot [K,N] i32, hit_uv [K,N,2] f32 from vsa_trace; face_uvs [nr_tris,6]

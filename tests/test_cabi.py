@@ -75,6 +75,10 @@ def test_argument_errors_are_reported_not_ignored():
     assert L.vsa_trace_q4(null, null, roots, fr, 1, 10, null, null, 0, ctypes.c_float(0), null, null, null, null) == 0
     assert L.vsa_bvh_export_q4(null, null, null, 0, 0, null, null, null) == ERR_ARG
     assert L.vsa_nt_compact_frame(null, null, null, null, null, null, null, null) == ERR_ARG
+    assert L.vsa_nt_rebalance(null, null) == ERR_ARG
+    L.vsa_nt_balance_bytes.restype = ctypes.c_longlong
+    assert L.vsa_nt_balance_bytes() == 4 * (6 * 1025 + 6 * 1024 + 12 + 6 * 1024)
+    L.vsa_nt_balance_bytes.restype = ctypes.c_int
     ll = ctypes.c_longlong
     assert L.vsa_trace_q_budgeted(null, null, roots, fr, 1, 10, null, null, 10, ctypes.c_float(0), null, null, null, 24,
                                   null, ll(1 << 20), null) == ERR_ARG                                  # null arrays

@@ -101,11 +101,52 @@ struct NtUnitWeight16 {
   __device__ int operator()(int, int, int) const { return 16; }
 };
 
+// ---- measured-time rebalancing of the work split (plan.balance; vsa_nt_rebalance).  The cost axis is
+// a fitted model; what it cannot know (which CU a workgroup shares with whom, table locality, the
+// scene) shows up as 4-11 % of span lost to the slowest workgroup (tools/wg_span.py).  Every
+// persistent kernel stamps its workgroups' busy times; once per frame nt_rebalance_kernel turns the
+// previous frame's times into shares of the axis.  Pieces and arithmetic are unchanged - only the
+// [lo, hi) a workgroup takes - so results are bit-identical to the equal split.
+constexpr int NT_BAL_KERNELS = 6, NT_BAL_MAX_WG = 1024, NT_BAL_ONE = 1 << 24;
+enum { NT_BAL_ENC_FWD_D, NT_BAL_ENC_FWD_H, NT_BAL_ENC_BWD_D, NT_BAL_ENC_BWD_H, NT_BAL_MLP_FWD, NT_BAL_MLP_BWD };
+struct NtBalance {
+  unsigned frac[NT_BAL_KERNELS][NT_BAL_MAX_WG + 1];   // cumulative share, NT_BAL_ONE = the whole axis
+  unsigned ticks[NT_BAL_KERNELS][NT_BAL_MAX_WG];      // busy time per workgroup of the last launch (100 MHz)
+  int frac_wgs[NT_BAL_KERNELS];                       // grid size frac[k] was made for (0: equal shares)
+  int tick_wgs[NT_BAL_KERNELS];                       // grid size of the launch that wrote ticks[k]
+  float ema[NT_BAL_KERNELS][NT_BAL_MAX_WG];           // running mean of the times (nt_rebalance_kernel)
+};
+
+__device__ __forceinline__ void nt_split_range(const vsa_nt_plan& plan, int bal_id, long long total,
+                                               long long& lo, long long& hi) {
+  const NtBalance* b = static_cast<const NtBalance*>(plan.balance);
+  if (b && bal_id >= 0 && b->frac_wgs[bal_id] == (int)gridDim.x) {
+    lo = (total * b->frac[bal_id][blockIdx.x]) >> 24;        // total < 2^38: no overflow
+    hi = (total * b->frac[bal_id][blockIdx.x + 1]) >> 24;
+  } else {
+    lo = total * blockIdx.x / gridDim.x;
+    hi = total * (blockIdx.x + 1) / gridDim.x;
+  }
+}
+
+__device__ __forceinline__ unsigned long long nt_bal_now() {
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define NT_BAL_BEGIN() const unsigned long long bal_t0__ = plan.balance ? nt_bal_now() : 0ull
+#define NT_BAL_END(id)                                                                   \
+  if (plan.balance && threadIdx.x == 0 && gridDim.x <= NT_BAL_MAX_WG) {                  \
+    NtBalance* b__ = static_cast<NtBalance*>(plan.balance);                              \
+    b__->ticks[id][blockIdx.x] = (unsigned)(nt_bal_now() - bal_t0__);                    \
+    if (blockIdx.x == 0) b__->tick_wgs[id] = (int)gridDim.x;                             \
+  }
+
 template <int UNIT, typename Body, typename Weight = NtUnitWeight16>
 __device__ __forceinline__ void nt_for_each_piece_scalar(const vsa_nt_plan& plan,
                                                   const int* __restrict__ seg_start, int n_planes,
                                                   int ovh, Body&& body, int tex_begin = 0,
-                                                  int tex_end = 1 << 30, Weight wt = Weight()) {
+                                                  int tex_end = 1 << 30, Weight wt = Weight(), int bal_id = -1) {
   const int n_all = plan.nr_shells * 2 * VSA_NT_MAX_DEG;
   const int n_tex = tex_end < n_all ? tex_end : n_all;   // textures [tex_begin, n_tex) only
   // units per (type, degree) class.  Only ever indexed with compile-time constants (the update
@@ -136,7 +177,8 @@ __device__ __forceinline__ void nt_for_each_piece_scalar(const vsa_nt_plan& plan
   };
   long long total = 0;
   for (int pl = 0; pl < n_planes; ++pl) total += plane_cost(pl);
-  const long long lo = total * blockIdx.x / gridDim.x, hi = total * (blockIdx.x + 1) / gridDim.x;
+  long long lo, hi;
+  nt_split_range(plan, bal_id, total, lo, hi);
   if (hi <= lo) return;
   long long c0 = 0;
   for (int pl = 0; pl < n_planes && c0 < hi; ++pl) {
@@ -190,10 +232,10 @@ template <int UNIT, typename Body, typename Weight = NtUnitWeight16>
 __device__ __forceinline__ void nt_for_each_piece(const vsa_nt_plan& plan,
                                                   const int* __restrict__ seg_start, int n_planes,
                                                   int ovh, Body&& body, int tex_begin = 0,
-                                                  int tex_end = 1 << 30, Weight wt = Weight()) {
+                                                  int tex_end = 1 << 30, Weight wt = Weight(), int bal_id = -1) {
   const int n_all = plan.nr_shells * 2 * VSA_NT_MAX_DEG;
   if (n_all > 64) {
-    nt_for_each_piece_scalar<UNIT>(plan, seg_start, n_planes, ovh, body, tex_begin, tex_end, wt);
+    nt_for_each_piece_scalar<UNIT>(plan, seg_start, n_planes, ovh, body, tex_begin, tex_end, wt, bal_id);
     return;
   }
   const int n_tex = tex_end < n_all ? tex_end : n_all;   // textures [tex_begin, n_tex) only
@@ -223,7 +265,8 @@ __device__ __forceinline__ void nt_for_each_piece(const vsa_nt_plan& plan,
   };
   long long total = 0;
   for (int pl = 0; pl < n_planes; ++pl) total += plane_cost(pl);
-  const long long lo = total * blockIdx.x / gridDim.x, hi = total * (blockIdx.x + 1) / gridDim.x;
+  long long lo, hi;
+  nt_split_range(plan, bal_id, total, lo, hi);
   if (hi <= lo) return;
   long long c0 = 0;
   for (int pl = 0; pl < n_planes && c0 < hi; ++pl) {

@@ -57,6 +57,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
   const long long n_entries = plan.level_offset[plan.n_levels];
   const int nl = plan.n_levels;
   NT_SPAN_MARK(HASHED ? 1 : 0, 0);
+  NT_BAL_BEGIN();
   // per-piece overheads and unit weights: fitted from per-workgroup timings (tools/fit_cost.py):
   // a piece costs 87 (hashed: a 128 KiB table to stage) / 27 (dense) units of 256 slots, and a
   // unit of a level finer than the texture (no reuse of the previous slot's cell) 0.92 of one
@@ -182,9 +183,10 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
       run(std::true_type{});
     else
       run(std::false_type{});
-  }, 0, 1 << 30, unit_weight);
+  }, 0, 1 << 30, unit_weight, HASHED ? NT_BAL_ENC_FWD_H : NT_BAL_ENC_FWD_D);
   __syncthreads();
   NT_SPAN_MARK(HASHED ? 1 : 0, 1);
+  NT_BAL_END(HASHED ? NT_BAL_ENC_FWD_H : NT_BAL_ENC_FWD_D);
 }
 
 // Backward: grad_table[tex][level entries][feature] += w * dF[slot]; one
@@ -489,6 +491,8 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   int* s_g = reinterpret_cast<int*>(s_raw);
   NT_SPAN_MARK(HASHED ? 3 : 2, 0);
+  NT_BAL_BEGIN();
+  const bool full_range = tex_begin <= 0 && tex_end >= plan.nr_shells * 2 * VSA_NT_MAX_DEG;
   // fitted (tools/fit_cost.py): 145 (hashed) / 64 (dense) units per piece (zeroing + flushing the
   // LDS plane), and a unit on the no-merge path (level finer than the texture) costs 0.875
   auto unit_weight = [&](int pl, int deg, int) {
@@ -516,9 +520,12 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
     else
       enc_bwd_piece<HASHED, 1, false>(plan, s_g, level, r, tex, first, last, single, dfeatures,
                                       dfeat_abs_sum, dscale_inv, slot_xy, grad_tables);
-  }, tex_begin, tex_end, unit_weight);
+  }, tex_begin, tex_end, unit_weight,
+     // a launch over a sub-range of the textures (the sliced backward of parallel.py) keeps equal shares
+     full_range ? (HASHED ? NT_BAL_ENC_BWD_H : NT_BAL_ENC_BWD_D) : -1);
   __syncthreads();
   NT_SPAN_MARK(HASHED ? 3 : 2, 1);
+  if (full_range) { NT_BAL_END(HASHED ? NT_BAL_ENC_BWD_H : NT_BAL_ENC_BWD_D); }
 }
 
 }  // namespace

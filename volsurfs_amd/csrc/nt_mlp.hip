@@ -68,6 +68,7 @@ __global__ __launch_bounds__(MLP_BLOCK, MLP_FWD_WGS_PER_CU) void nt_mlp_fwd_kern
   for (int i = threadIdx.x; i < 257; i += MLP_BLOCK) s_qt[i] = NT_QUANT_THR[i];
   __syncthreads();
   NT_SPAN_MARK(0, 0);
+  NT_BAL_BEGIN();
   // a tile's cost grows with the number of 8-channel groups the quantiser has to form and store
   // (tools/wg_span.py: 0.85-0.88 span efficiency with equal weights)
   auto unit_weight = [&](int, int deg, int type) {
@@ -110,8 +111,9 @@ __global__ __launch_bounds__(MLP_BLOCK, MLP_FWD_WGS_PER_CU) void nt_mlp_fwd_kern
     else if (ti.channels <= 16) run(std::integral_constant<int, 2>{});
     else if (ti.channels <= 24) run(std::integral_constant<int, 3>{});
     else run(std::integral_constant<int, 4>{});
-  }, 0, 1 << 30, unit_weight);
+  }, 0, 1 << 30, unit_weight, NT_BAL_MLP_FWD);
   NT_SPAN_MARK(0, 1);
+  NT_BAL_END(NT_BAL_MLP_FWD);
 }
 
 // ------------------------------------------------------------------ backward
@@ -895,6 +897,7 @@ __global__ __launch_bounds__(PC_BLOCK, 2) void nt_mlp_bwd_pc_kernel(
     float* __restrict__ dfeat_abs_sum, float gw_scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   NT_SPAN_MARK(1, 0);
+  NT_BAL_BEGIN();
   nt_for_each_piece<32>(plan, seg_start, 1, PC_RUN_COST,
                         [&](int, int tex, int first, int last, int seg_begin, int seg_end) {
     Work wk;
@@ -904,8 +907,9 @@ __global__ __launch_bounds__(PC_BLOCK, 2) void nt_mlp_bwd_pc_kernel(
     wk.last = last;
     pc_run(plan, wk, s_raw, weights, features, seg_start, grad_rows, grad_weights, dfeat_abs_sum, gw_scale);
     __syncthreads();   // the next run re-stages the fragments
-  });
+  }, 0, 1 << 30, NtUnitWeight16(), NT_BAL_MLP_BWD);
   NT_SPAN_MARK(1, 1);
+  NT_BAL_END(NT_BAL_MLP_BWD);
 }
 
 }  // namespace

@@ -159,6 +159,68 @@ __global__ __launch_bounds__(1024) void nt_assign_kernel(vsa_nt_plan plan,
   if (SPARSE && word) marks[vec] = 0;
 }
 
+// One workgroup per persistent kernel: last launch's busy times -> shares of its cost axis.
+// share' = share * clamp(mean / time, 0.8, 1.25) ^ 0.5 (damped: a workgroup's time is not linear in its
+// share, and the times carry noise), floored at a quarter of an equal share, renormalised.
+__global__ __launch_bounds__(1024) void nt_rebalance_kernel(NtBalance* __restrict__ b) {
+  __shared__ float s[1024];
+  const int k = blockIdx.x, t = threadIdx.x;
+  const int G = b->tick_wgs[k];
+  if (G <= 1 || G > NT_BAL_MAX_WG) return;
+  const bool have = b->frac_wgs[k] == G && b->frac[k][G] == (unsigned)NT_BAL_ONE;
+  const float equal = (float)NT_BAL_ONE / (float)G;
+  const float share = t < G ? (have ? (float)(b->frac[k][t + 1] - b->frac[k][t]) : equal) : 0.f;
+#ifndef NT_BAL_GAIN
+#define NT_BAL_GAIN 0.5f
+#endif
+#ifndef NT_BAL_EMA
+#define NT_BAL_EMA 1.0f       /* weight of the newest time in the running mean kept in ema[] */
+#endif
+#ifndef NT_BAL_MASK
+#define NT_BAL_MASK 0x30      /* kernels whose shares are corrected (bit = NT_BAL_* id): the two MLP kernels.
+                                 Measured (profiles/r03/rebalance.txt): nt_mlp_bwd 0.68-0.70 -> 0.64-0.65 ms as a
+                                 stage, nt_mlp_fwd unchanged; the encode kernels get SLOWER with their shares
+                                 corrected (backward 0.61-0.63 -> 0.63-0.65 at any gain 0.15-0.5, with or without a
+                                 running mean of the times): a piece's cost there is mostly its fixed part (table
+                                 staging / plane flush), which a moved boundary duplicates instead of moving */
+#endif
+  if (!((NT_BAL_MASK >> k) & 1)) return;
+  float time = t < G ? (float)b->ticks[k][t] : 0.f;
+  if (NT_BAL_EMA < 1.0f && t < G) {
+    const float prev = b->ema[k][t];
+    time = have && prev > 0.f ? (1.0f - NT_BAL_EMA) * prev + NT_BAL_EMA * time : time;
+    b->ema[k][t] = time;
+  }
+  auto scan = [&](float v) {          // inclusive, Hillis-Steele over the 1024 threads
+    s[t] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const float u = t >= off ? s[t - off] : 0.f;
+      __syncthreads();
+      s[t] += u;
+      __syncthreads();
+    }
+    const float r = s[t];
+    __syncthreads();
+    return r;
+  };
+  scan(time);
+  const float mean = s[1023] / (float)G;
+  __syncthreads();
+  float w = 0.f;
+  if (t < G) {
+    const float r = time > 0.f ? fminf(fmaxf(mean / time, 0.8f), 1.25f) : 1.25f;
+    w = fmaxf(share * powf(r, NT_BAL_GAIN), 0.25f * equal);
+  }
+  const float incl = scan(w);
+  const float total = s[1023];
+  if (t < G) b->frac[k][t + 1] = t == G - 1 ? (unsigned)NT_BAL_ONE : (unsigned)(incl / total * (float)NT_BAL_ONE);
+  if (t == 0) {
+    b->frac[k][0] = 0;
+    b->frac_wgs[k] = G;
+  }
+}
+
 }  // namespace
 
 static int plan_check(const vsa_nt_plan* p) {
@@ -173,6 +235,17 @@ static int plan_check(const vsa_nt_plan* p) {
       return VSA_ERR_ARG;
   if (p->dom_off[nseg] >= (1ll << 31)) return VSA_ERR_UNSUPPORTED;
   return VSA_OK;
+}
+
+extern "C" long long vsa_nt_balance_bytes(void) { return (long long)sizeof(NtBalance); }
+
+extern "C" int vsa_nt_rebalance(const vsa_nt_plan* plan, void* stream) {
+  int rc = plan_check(plan);
+  if (rc) return rc;
+  if (!plan->balance) return VSA_OK;
+  hipLaunchKernelGGL(nt_rebalance_kernel, dim3(NT_BAL_KERNELS), dim3(1024), 0, (hipStream_t)stream,
+                     static_cast<NtBalance*>(plan->balance));
+  VSA_RETURN_LAUNCH_STATUS();
 }
 
 extern "C" int vsa_nt_mark(const vsa_nt_plan* plan, const int32_t* hit_slot, const float* hit_uv,

@@ -29,6 +29,9 @@ WEIGHTS_PER_TEX = 8192
 # backward needs the planes, 0.65 vs 0.61-0.64 ms and 1 043 vs 1 061 it/s — the vector cache's
 # look-up rate bounds the gathers.  Hence "auto": fused exactly when the feature
 # planes are not needed.  VSA_NT_FUSED=1 / 0 force it on / off (A/B switch, tools/README).
+# work split of the persistent kernels corrected by the previous frame's measured workgroup times
+# (vsa_nt_rebalance; same results); "0" = the fitted cost model alone
+REBALANCE = os.environ.get("VSA_NT_REBALANCE", "1") != "0"
 _DENSE_COMPACT = os.environ.get("VSA_NT_DENSE_COMPACT", "0") == "1"    # A/B switch: rounds 1-2's fill + dense slot_of
 FUSED_FORWARD = {"0": False, "1": True}.get(os.environ.get("VSA_NT_FUSED", "auto"), "auto")
 
@@ -46,6 +49,7 @@ class Plan(ctypes.Structure):
         ("slot_capacity", ctypes.c_int64),
         ("max_rays", ctypes.c_int32), ("reserved0", ctypes.c_int32),
         ("row_base", ctypes.c_int64 * (MAX_SHELLS * MAX_DEG + 1)),
+        ("balance", ctypes.c_void_p),
     ]
 
 
@@ -150,6 +154,11 @@ class NeuralTextureBank(torch.nn.Module):
     def _alloc(self, dev, training):
         i32, u8 = torch.int32, torch.uint8
         cap, K = self.slot_capacity, self.K
+        if REBALANCE:
+            fn = _lib.lib().vsa_nt_balance_bytes
+            fn.restype = ctypes.c_longlong
+            self.balance = torch.zeros(int(fn()), dtype=u8, device=dev)
+            self.plan.balance = self.balance.data_ptr()
         self.marks = torch.zeros(self.dom_total, dtype=u8, device=dev)
         self.slot_of = torch.full((self.dom_total,), -1, dtype=i32, device=dev)
         self.texel_of_slot = torch.zeros(cap, dtype=i32, device=dev)
@@ -183,6 +192,8 @@ class NeuralTextureBank(torch.nn.Module):
             raise _lib.VolsurfsHipError("this bank holds baked textures: use tex_uv_only + shade")
         st = _lib.stream_ptr()
         tex_uv = torch.empty(K, N, 2, device=hit_slot.device)
+        if self.plan.balance:
+            _lib.call("vsa_nt_rebalance", ctypes.byref(self.plan), st)
         # the marks are zero here: allocated so, and every compaction clears what it reads
         if _DENSE_COMPACT:
             self.marks.zero_()
