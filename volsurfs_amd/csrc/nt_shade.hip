@@ -343,6 +343,16 @@ __global__ __launch_bounds__(SH_BLOCK, NT_SHADE_FWD_OCC) void nt_shade_fwd_kerne
 // that phase 2 reads is 39 dwords (4 g_raw, 16 basis, 2 row ids + 2 lerp fractions per band)
 // so that a 128-thread workgroup needs 20 KiB of LDS and 16 waves fit a CU: halving the
 // occupancy of this atomic-bound kernel cost 27 % (measured), i.e. it is latency-sensitive.
+// Diagnostic build only (-DSHADE_SPAN; tools/shade_span.py): begin / end of every workgroup of the
+// shading backward, to see whether the launch has idle stretches or a tail.
+#ifdef SHADE_SPAN
+static __device__ unsigned long long g_sspan[1 << 16][2];
+__device__ __forceinline__ unsigned long long shade_now() {
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#endif
 constexpr int SHB_BLOCK = 128;
 
 // no-return packed f16 add at the memory side (global_atomic_pk_add_f16: one dword per lane)
@@ -371,6 +381,9 @@ __global__ __launch_bounds__(SHB_BLOCK, RECOMPUTE ? 2 : NT_SHADE_BWD_OCC) void n
   __shared__ float s_basis[SHB_BLOCK][17];
   __shared__ int s_row[SHB_BLOCK][9];    // corners (x0,y0) and (x0,y1) per band; x1 = the next slot's row
   __shared__ float s_f[SHB_BLOCK][9];
+#ifdef SHADE_SPAN
+  const unsigned long long span_t0 = shade_now();
+#endif
   if (RECOMPUTE) {
     build_lut(plan, s_lut);
     __syncthreads();
@@ -563,6 +576,12 @@ __global__ __launch_bounds__(SHB_BLOCK, RECOMPUTE ? 2 : NT_SHADE_BWD_OCC) void n
     for (int k = 0; k < 4; ++k)
       if (cur[k] >= 0) atomic_pk_add_f16(grad_rows, (unsigned)cur[k] * 64u + lofs_b, acc[k].x, acc[k].y);
   }
+#ifdef SHADE_SPAN
+  {
+    const int w = blockIdx.y * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0 && w < (1 << 16)) g_sspan[w][0] = span_t0, g_sspan[w][1] = shade_now();
+  }
+#endif
 }
 
 }  // namespace
@@ -625,3 +644,11 @@ extern "C" int vsa_nt_shade_bwd(const vsa_nt_plan* plan, const int32_t* hit_slot
                        g_surfs_alpha, grad_scale, reinterpret_cast<_Float16*>(grad_rows), nullptr);
   VSA_RETURN_LAUNCH_STATUS();
 }
+
+#ifdef SHADE_SPAN
+extern "C" int vsa_span_read_shade(void* dst) {
+  VSA_HIP_TRY(hipDeviceSynchronize());
+  VSA_HIP_TRY(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_sspan), sizeof(g_sspan)));
+  return 0;
+}
+#endif
