@@ -191,7 +191,9 @@ class KShellPipeline:
         nodes_b = self.tracer.nodes.numel() * 4 + self.tracer.tris.numel() * 4
         self.acct = {
             "trace": N * (24 + 16 * K) + nodes_b,
-            "nt_mark_compact": N * K * 20 + bank.dom_total * (1 + 1 + 1 + 4) + P * 12,
+            # marks read twice (count, assign); per slot: mark set + cleared, slot_of, slot_xy
+            # (vsa_nt_compact_frame: nothing is written for untouched texels)
+            "nt_mark_compact": N * K * 20 + bank.dom_total * (1 + 1) + P * (1 + 1 + 4 + 8),
             "nt_encode_fwd": P * 8 + feats + ntex * bank.n_entries * 4,
             "nt_mlp_fwd": feats + rows_u8 + ntex * 8192 * 2,
             # fused: texel centre in (per texture), feature planes + texel rows out, parameters once
