@@ -304,3 +304,21 @@ def test_trace_full_frame_properties():
         assert (~(t[k + 1][both] < t[k][both])).sum().item() <= 64
     t2, s2, _ = rt.trace_all(o[:16384].contiguous(), d[:16384].contiguous())
     assert torch.equal(t2, t[:, :16384]) and torch.equal(s2, s[:, :16384])
+    # the three ways the q16 tree is launched agree bit for bit at the full size: stateless, ordered by
+    # the previous call's cost (three calls: no feedback yet / measured on the same rays / again), and
+    # the budgeted walk + continuation
+    rt.cost_feedback = False
+    ref = rt.trace_all(o, d)
+    rt.cost_feedback = True
+    rt._fb = None
+    for _ in range(3):
+        got = rt.trace_all(o, d)
+        assert all(torch.equal(a, b) for a, b in zip(got, ref))
+    half = (rt._fb[2] // 2) & ~255
+    hdr = rt._fb[0][rt._fb[3] * half:][:16].view(torch.int32).cpu().tolist()
+    assert hdr[0] == 10000 * 5 and 0 < sum(hdr[1:]) < 10000      # a few per cent of the waves are listed
+    rt.round_budget = 64
+    got = rt.trace_all(o, d)
+    assert all(torch.equal(a, b) for a, b in zip(got, ref))
+    handed = rt._ws[0][:8].view(torch.int32).cpu().tolist()
+    assert handed[1] > 1000 and handed[0] >= handed[1]             # rays really were handed over
