@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--target-hits", type=int, default=49152)
     ap.add_argument("--views", type=int, default=50)
     ap.add_argument("--res", type=int, default=800)
+    ap.add_argument("--width", type=int, default=None,
+                    help="frame workload: frame width when it is not square (--res is then the height), e.g. "
+                         "--res 1080 --width 1920 --shells 7 --subdiv 7 = BASELINE configs[4]'s per-GPU frame")
     ap.add_argument("--shells", type=int, default=5)
     ap.add_argument("--subdiv", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -363,7 +366,8 @@ def noisy_scene(args, dev, use_graph, steps=50):
     radial noise 0.05, every shell's parameterisation cut into 6x6 randomly packed charts,
     U(+-1) table entries.  Reported beside the headline, never instead of it."""
     from volsurfs_amd.pipeline import KShellPipeline
-    pipe = KShellPipeline.synthetic(K=args.shells, subdiv=args.subdiv, res=args.res, device=dev, seed=42,
+    pipe = KShellPipeline.synthetic(K=args.shells, subdiv=args.subdiv,
+                                    res=args.res if args.width is None else (args.res, args.width), device=dev, seed=42,
                                     noise=0.05, atlas_charts=6, init="spread")
     for _ in range(3):
         pipe.step()
@@ -454,7 +458,10 @@ def main():
     if strong:       # every rank sees the same frame (same seed) and renders its own bands of it
         from volsurfs_amd.parallel import shard_bands
         rows = shard_bands(args.res, rank, world)
-    pipe = KShellPipeline.synthetic(K=args.shells, subdiv=args.subdiv, res=args.res, device=dev,
+    if args.width is not None and strong:
+        raise SystemExit("--width is for weak scaling / one GPU")
+    pipe = KShellPipeline.synthetic(K=args.shells, subdiv=args.subdiv,
+                                    res=args.res if args.width is None else (args.res, args.width), device=dev,
                                     seed=42, gt_seed=42 if strong else 42 + rank, rows=rows,
                                     noise=args.noise, atlas_charts=args.atlas_charts, init=args.init)
     N = pipe.nr_rays
@@ -555,7 +562,8 @@ def main():
             roof = {"bound": "hbm", "kernel": name, "kernel_ms": k_ms, "achieved": ach, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic}
         out = {
-            "metric": "Mrays/s (fwd+bwd) at 800x800, K=5 shells",
+            "metric": "Mrays/s (fwd+bwd) at 800x800, K=5 shells" if (args.res, args.width, args.shells) == (800, None, 5)
+            else f"Mrays/s (fwd+bwd) at {args.width or args.res}x{args.res}, K={args.shells} shells",
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
