@@ -497,7 +497,7 @@ class VolSurfs(torch.nn.Module):
             out = composite_dense(rgb_k, alpha_k, bg)
             out["surfs_normals"] = normals
             outs.append(out)
-        return {k: torch.cat([o_[k] for o_ in outs], 0) for k in outs[0]}
+        return outs[0] if len(outs) == 1 else {k: torch.cat([o_[k] for o_ in outs], 0) for k in outs[0]}
 
     # -- fused training path: the same forward + mean-L1 + backward as `forward(...)` followed by
     # `loss.backward()`, as ONE sequence of C-ABI launches on the current stream (no autograd
@@ -654,7 +654,10 @@ class VolSurfs(torch.nn.Module):
             r = self.render_rays(rays_o[a:a + chunk], rays_d[a:a + chunk], return_samples=False)
             outs.append(r["renders"]["ray_traced"])
         # keys a configuration does not produce are None (surfs_uvs on the legacy branch)
-        full = {k: None if outs[0][k] is None else torch.cat([o[k] for o in outs], 0) for k in outs[0]}
+        # (one chunk: the buffers as they are - `torch.cat` of a single tensor is a copy, and the output
+        # dict holds a dozen per-ray buffers: 8 % of a one-chunk frame's time in rocprofv3)
+        full = outs[0] if len(outs) == 1 else \
+            {k: None if outs[0][k] is None else torch.cat([o[k] for o in outs], 0) for k in outs[0]}
         if nr_rays_per_pixel > 1:
             full = {k: None if v is None else v.reshape(-1, nr_rays_per_pixel, *v.shape[1:]).mean(1)
                     for k, v in full.items()}
