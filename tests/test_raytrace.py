@@ -166,6 +166,32 @@ def test_cost_feedback_order_keeps_the_hits_bit_exact_whatever_it_was_measured_o
 
 
 @pytest.mark.gpu
+def test_cost_feedback_random_call_sequences_equal_the_stateless_launch():
+    """Forty calls on one RayTracer with ray counts and ray sets drawn at random (growing, shrinking,
+    repeating, 1 ray ... 9000 rays, some interleaved with the budgeted walk): whatever the feedback buffer
+    holds from the calls before, every call's hits equal the stateless kernel's bit for bit."""
+    from volsurfs_amd.mesh import TensorMesh
+    from volsurfs_amd.raytrace import RayTracer
+    g = np.random.default_rng(2)
+    meshes_np = [icosphere(5, 0.3 + 0.015 * k) for k in range(4)]
+    meshes_np = [((v * (1 + 0.04 * g.standard_normal((v.shape[0], 1)))).astype(np.float32), f)
+                 for v, f in meshes_np]
+    rt = RayTracer([TensorMesh(v, f) for v, f in meshes_np], node_format="q16")
+    ref_rt = RayTracer([TensorMesh(v, f) for v, f in meshes_np], node_format="q16")
+    ref_rt.cost_feedback = False
+    sets = [tuple(torch.from_numpy(a).cuda() for a in _rays(9000, 20 + i)) for i in range(3)]
+    last = None
+    for call in range(40):
+        o, d = sets[int(g.integers(0, 3))]
+        n = int(g.choice([1, 63, 64, 65, 1000, 4097, 9000])) if g.random() < 0.7 or last is None else last
+        last = n
+        rt.round_budget = int(g.choice([0, 0, 0, 2, 40]))
+        got = rt.trace_all(o[:n].contiguous(), d[:n].contiguous())
+        ref = ref_rt.trace_all(o[:n].contiguous(), d[:n].contiguous())
+        assert all(torch.equal(a, b) for a, b in zip(got, ref)), (call, n, rt.round_budget)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("budget,ws_bytes", [(0, None), (1, None), (3, None), (24, None), (2, 400), (2, 256 + 144 * 700)])
 def test_budgeted_walk_hands_subtrees_over_and_stays_bit_exact(budget, ws_bytes):
     """vsa_trace_q_budgeted (csrc/trace.hip): a wave stops after `budget` trips of its walk loop and hands
