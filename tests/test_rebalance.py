@@ -71,3 +71,38 @@ def test_rebalance_without_a_buffer_or_before_any_launch_is_a_noop():
     bank.plan.balance = None
     _lib.call("vsa_nt_rebalance", ctypes.byref(bank.plan), st)
     bank.plan.balance = keep
+
+
+@pytest.mark.gpu
+def test_any_measured_times_give_a_valid_split():
+    """Adversarial times in the balance buffer (zeros, huge values, random) must still yield shares that
+    partition every cost axis: the frame's texels and colours stay bit-identical to the equal split."""
+    from volsurfs_amd.pipeline import KShellPipeline
+    torch.manual_seed(1)
+    p = KShellPipeline.synthetic(K=2, subdiv=4, res=192, init="spread")
+    bank = p.bank
+    keep = bank.plan.balance
+    bank.plan.balance = None
+    ref_rgb = p.step().clone()
+    ref_texels = bank.texels.clone()
+    bank.plan.balance = keep
+    p.step()                                                  # stamps tick_wgs for every kernel
+    n_frac = BAL_KERNELS * (BAL_MAX_WG + 1)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for trial in range(6):
+        ticks = bank.balance[4 * n_frac:4 * (n_frac + BAL_KERNELS * BAL_MAX_WG)].view(torch.int32)
+        if trial == 0:
+            ticks.zero_()
+        elif trial == 1:
+            ticks.fill_(0x7fffffff)
+        else:
+            r = torch.randint(0, 1 << 30, ticks.shape, generator=g, device="cuda", dtype=torch.int32)
+            ticks.copy_(torch.where(torch.rand(ticks.shape, generator=g, device="cuda") < 0.3, torch.zeros_like(r), r))
+        rgb = p.step()          # rebalance runs on the planted times, then the kernels restamp them
+        assert torch.equal(rgb, ref_rgb), trial
+        assert torch.equal(bank.texels, ref_texels), trial
+        frac, _, frac_wgs, tick_wgs = _balance_views(bank)
+        for k in (4, 5):
+            G = int(tick_wgs[k])
+            w = np.diff(frac[k][:G + 1].astype(np.int64))
+            assert frac_wgs[k] == G and frac[k][0] == 0 and frac[k][G] == BAL_ONE and (w > 0).all(), (trial, k)
