@@ -124,20 +124,27 @@ __global__ __launch_bounds__(1024) void nt_assign_kernel(vsa_nt_plan plan,
   const long long vec = (long long)blockIdx.x * 1024 + threadIdx.x;   // 4-texel group
   const unsigned word = marks[vec] & 0x01010101u;
   const int c = __popc(word);
-  // exclusive scan across the 1024 threads
-  int incl = c;
+  // exclusive scan across the 1024 threads (PMC had this kernel 59 % VALU-busy: the wave scan as six
+  // ds_bpermute steps and a generic 32-bit division per thread; now a DPP scan and a float-reciprocal
+  // quotient, exact below 2^24, with one correction step)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int off = 1; off < 64; off <<= 1) {
-    int up = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += up;
-  }
+  const int incl = nt_wave_incl_scan(c);
   if (lane == 63) s_w[wave] = incl;
   __syncthreads();
   int slot = block_prefix[blockIdx.x] + incl - c;
   for (int w = 0; w < wave; ++w) slot += s_w[w];
   int out[4];
   const int local0 = (int)(vec * 4 - dom0);
-  int iy = local0 / W, ix = local0 - iy * W;
+  int iy, ix;
+  if (local0 < (1 << 24)) {      // (R + 2)^2 <= 2^24 up to R = 4094: exact in fp32, off by at most one row
+    iy = (int)((float)local0 * (1.0f / (float)W));
+    ix = local0 - iy * W;
+    if (ix < 0) --iy, ix += W;
+    else if (ix >= W) ++iy, ix -= W;
+  } else {
+    iy = local0 / W;
+    ix = local0 - iy * W;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const bool m = (word >> (8 * i)) & 1u;
