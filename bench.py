@@ -26,7 +26,7 @@ HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak 
 MFMA_F16_PEAK_TFLOPS = 2500.0
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="default 200 (frame) / 500 (train*) / 3 frames (dtu)")
@@ -61,8 +61,20 @@ def parse():
     ap.add_argument("--init", default="tcnn", choices=["tcnn", "spread"],
                     help="frame workload: parameter initialisation (tcnn: U(+-1e-4) tables; spread: U(+-1))")
     ap.add_argument("--no-noisy", action="store_true",
-                    help="skip the second, non-ideal scene (noise 0.05, 6x6 uv charts, spread parameters) "
-                         "that the default frame line reports as value_noisy")
+                    help="skip the extra scenes the default frame line reports beside the headline: value_noisy "
+                         "(noise 0.05, 6x6 uv charts, spread parameters), value_stress (mesh.stress_shells: "
+                         "non-convex lobed shells, 12x triangle-area spread, 256 charts) and value_cold (the "
+                         "headline scene with NO inter-frame feedback and a camera that moves every step)")
+    ap.add_argument("--stress", action="store_true",
+                    help="frame workload: run the stress scene (mesh.stress_shells) as the main scene")
+    ap.add_argument("--cold", action="store_true",
+                    help="frame workload: no inter-frame feedback (stateless traversal launch order, fitted work "
+                         "split) and a camera that orbits --orbit-deg per step")
+    ap.add_argument("--orbit-deg", type=float, default=5.0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="--gpus 1: still form a one-rank process group (--dist-backend, default nccl = RCCL) and "
+                         "drive the data-parallel schedule through it: gradient all-reduce per shell during "
+                         "backward, as the N > 1 ranks do")
     ap.add_argument("--no-graph", action="store_true", help="time the eager path instead of the HIP-graph replay")
     ap.add_argument("--by-shell", action="store_true",
                     help="1 GPU: run the multi-GPU schedule (shell-by-shell hash-grid backward, eager) "
@@ -74,7 +86,7 @@ def parse():
                     help="functional tests of the multi-rank path on one GPU: gloo + --single-device")
     ap.add_argument("--single-device", action="store_true",
                     help="all ranks use cuda:0 (testing only; RCCL refuses two ranks on one GPU)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     training = args.workload.startswith("train")
     if args.steps is None:
         # frame: 200 steps = 0.64 s of back-to-back graph replays (the round-1 default of 20 was a 63 ms
@@ -107,6 +119,14 @@ def kernel_source_hash():
         h.update(n.encode())
         h.update(open(os.path.join(d, n), "rb").read())
     return h.hexdigest()
+
+
+def workload_key(args):
+    """What a PMC traffic collection was taken ON: profiles/traffic.json is valid for the kernel
+    sources (kernel_source_hash) AND this workload only — another frame size, shell count or scene
+    moves other bytes (VERDICT r3 weak #12)."""
+    return (f"frame {args.width or args.res}x{args.res} K={args.shells} subdiv={args.subdiv} noise={args.noise} "
+            f"charts={args.atlas_charts} init={args.init} stress={int(bool(args.stress))} cold={int(bool(args.cold))}")
 
 
 def cpu_baseline(pipe, sample_rays):
@@ -359,19 +379,46 @@ def run_render(args, world, rank, dev, dist):
                                    "shells, SH neural textures, white background, one chunk"}}))
 
 
-def noisy_scene(args, dev, use_graph, steps=50):
-    """The same step on a NON-IDEAL scene: BASELINE's frame on perfect
-    spheres with one continuous uv chart and near-zero parameters is a best case — real shells
-    are bumpy marching-cubes meshes whose xatlas charts fragment the texel footprint.  Here:
-    radial noise 0.05, every shell's parameterisation cut into 6x6 randomly packed charts,
-    U(+-1) table entries.  Reported beside the headline, never instead of it."""
+def orbit_views(o, d, n_views, deg):
+    """n_views ray sets of the same pinhole camera orbiting the scene centre about the y axis,
+    `deg` degrees apart (both origins and directions rotated)."""
+    out = []
+    for i in range(n_views):
+        a = np.deg2rad(deg * i)
+        R = torch.tensor([[np.cos(a), 0.0, np.sin(a)], [0.0, 1.0, 0.0], [-np.sin(a), 0.0, np.cos(a)]],
+                         dtype=torch.float32, device=o.device)
+        out.append(((o @ R.t()).contiguous(), (d @ R.t()).contiguous()))
+    return out
+
+
+def extra_scene(args, dev, use_graph, tag, steps=50, cold=False, orbit_deg=0.0, **synth):
+    """The same step on another scene / under another regime, reported BESIDE the headline, never
+    instead of it:
+
+      noisy   radial noise 0.05, 6x6 randomly packed charts, U(+-1) table entries;
+      stress  mesh.stress_shells: non-convex lobed shells (up to 6 crossings per ray), triangle areas
+              spread 12x, 256 randomly packed charts per shell;
+      cold    no inter-frame feedback at all — the traversal's stateless launch order
+              (VSA_TRACE_FEEDBACK=0), the persistent kernels' fitted work split (VSA_NT_REBALANCE=0) —
+              and a camera that orbits `orbit_deg` degrees per step, so that nothing a frame leaves
+              behind fits the next one: what the FIRST frame of a new view costs.
+    """
+    from volsurfs_amd import neural_textures as _nt
     from volsurfs_amd.pipeline import KShellPipeline
-    pipe = KShellPipeline.synthetic(K=args.shells, subdiv=args.subdiv,
-                                    res=args.res if args.width is None else (args.res, args.width), device=dev, seed=42,
-                                    noise=0.05, atlas_charts=6, init="spread")
+    keep = _nt.REBALANCE
+    if cold:
+        _nt.REBALANCE = False
+    try:
+        pipe = KShellPipeline.synthetic(K=args.shells, subdiv=args.subdiv,
+                                        res=args.res if args.width is None else (args.res, args.width), device=dev,
+                                        seed=42, **synth)
+    finally:
+        _nt.REBALANCE = keep
+    if cold:
+        pipe.tracer.cost_feedback = False
+    views = orbit_views(pipe.rays_o.clone(), pipe.rays_d.clone(), 8, orbit_deg) if orbit_deg else None
     for _ in range(3):
         pipe.step()
-    pipe.stats()
     run = pipe.step
     if use_graph:
         try:
@@ -379,20 +426,36 @@ def noisy_scene(args, dev, use_graph, steps=50):
             run = pipe.replay
         except Exception:
             run = pipe.step
-    for _ in range(3):
+
+    def frame(i):
+        if views is not None:       # the next frame's rays arrive (15 MB device-to-device, inside the timed region)
+            pipe.rays_o.copy_(views[i % len(views)][0])
+            pipe.rays_d.copy_(views[i % len(views)][1])
         run()
+    for i in range(3):
+        frame(i)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        run()
+    for i in range(steps):
+        frame(3 + i)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    pipe.stats()
+    pipe.reset_stage_timers()
+    pipe.step(record=True)
+    st = pipe.stage_report()
     N = pipe.nr_rays
-    return {"value_noisy": N / dt / 1e6,
-            "noisy": {"scene": pipe.scene_desc, "ms_per_step": dt * 1e3, "steps": steps,
-                      "h": (pipe.last_hits or 0) / float(N * pipe.K), "hits_per_frame": pipe.last_hits,
-                      "unique_texels_per_frame": pipe.last_slots,
-                      "Mhits/s": (pipe.last_hits or 0) / dt / 1e6}}
+    rep = {"scene": pipe.scene_desc, "ms_per_step": dt * 1e3, "steps": steps,
+           "h": (pipe.last_hits or 0) / float(N * pipe.K), "hits_per_frame": pipe.last_hits,
+           "unique_texels_per_frame": pipe.last_slots, "Mhits/s": (pipe.last_hits or 0) / dt / 1e6,
+           "trace_ms": round(st["trace"]["ms"], 4),
+           "launch": "hip-graph replay" if run == getattr(pipe, "replay", None) and use_graph else "eager"}
+    if cold:
+        rep["regime"] = (f"VSA_TRACE_FEEDBACK=0, VSA_NT_REBALANCE=0, camera orbits {orbit_deg} deg per step "
+                         "(8 views, rays copied in inside the timed region)")
+    del pipe
+    torch.cuda.empty_cache()
+    return {"value_" + tag: N / dt / 1e6, tag: rep}
 
 
 def self_launch(args):
@@ -434,13 +497,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dev_index = local_rank if (world > 1 and not args.single_device) else 0
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         torch.cuda.set_device(dev_index)
+        if world == 1:       # --force-dist: a one-rank group, rendezvous on a free local port
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(port))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), rank=rank, world_size=world)
         else:
-            dist.init_process_group(args.dist_backend)
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -460,10 +532,17 @@ def main():
         rows = shard_bands(args.res, rank, world)
     if args.width is not None and strong:
         raise SystemExit("--width is for weak scaling / one GPU")
+    from volsurfs_amd import neural_textures as _nt
+    if args.cold:
+        _nt.REBALANCE = False
     pipe = KShellPipeline.synthetic(K=args.shells, subdiv=args.subdiv,
                                     res=args.res if args.width is None else (args.res, args.width), device=dev,
                                     seed=42, gt_seed=42 if strong else 42 + rank, rows=rows,
-                                    noise=args.noise, atlas_charts=args.atlas_charts, init=args.init)
+                                    noise=args.noise, atlas_charts=args.atlas_charts, init=args.init,
+                                    stress=args.stress)
+    if args.cold:
+        pipe.tracer.cost_feedback = False
+    views = orbit_views(pipe.rays_o.clone(), pipe.rays_d.clone(), 8, args.orbit_deg) if args.cold and args.orbit_deg else None
     N = pipe.nr_rays
 
     def barrier():
@@ -474,10 +553,11 @@ def main():
 
     from volsurfs_amd.parallel import GradientOverlap
     params = [pipe.bank.tables, pipe.bank.weights]
-    overlap = GradientOverlap(world, wire_dtype=torch.bfloat16 if args.grad_wire_dtype == "bf16" else None)
+    overlap = GradientOverlap(world, wire_dtype=torch.bfloat16 if args.grad_wire_dtype == "bf16" else None,
+                              force=args.force_dist)
 
     def step(record=False):
-        if world == 1:
+        if dist is None:
             pipe.step(record=record, grad_ready=(lambda t: None) if args.by_shell else None)
             return
         # data-parallel training step: the parameter gradients are all-reduced (sum) over
@@ -504,7 +584,7 @@ def main():
         step()
     kernel_ms = _lib.kernel_ms()
     _lib.kernel_events = None
-    use_graph = not args.no_graph and world == 1 and not args.by_shell   # collectives interleave with the backward kernels
+    use_graph = not args.no_graph and dist is None and not args.by_shell   # collectives interleave with the backward kernels
     if use_graph:
         try:
             pipe.capture_graph()       # the step is ~25 launches on one stream with no host sync
@@ -514,15 +594,18 @@ def main():
             print(f"[bench] graph capture failed ({e}); timing the eager path", file=sys.stderr)
             use_graph = False
 
-    def timed_step():
+    def timed_step(i):
+        if views is not None:
+            pipe.rays_o.copy_(views[i % len(views)][0])
+            pipe.rays_d.copy_(views[i % len(views)][1])
         if use_graph:
             pipe.replay()
         else:
             step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        timed_step()
+    for i in range(args.steps):
+        timed_step(i)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -544,10 +627,12 @@ def main():
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             tj = json.load(open(tf))
-            if tj.get("_kernel_source_sha256") == kernel_source_hash():
-                traffic = tj.get(name)
-            else:
+            if tj.get("_kernel_source_sha256") != kernel_source_hash():
                 traffic_note = "profiles/traffic.json was collected at other kernel sources (stale): re-run tools/traffic.sh"
+            elif tj.get("_workload") != workload_key(args):
+                traffic_note = f"profiles/traffic.json was collected on another workload ({tj.get('_workload')})"
+            else:
+                traffic = tj.get(name)
         # the kernel's own duration: events directly around its launch (a stage also holds the
         # small torch kernels next to it); one launch per stage except the encode stages
         k_ms = kernel_ms.get("vsa_" + name, st["ms"]) if name not in launches else st["ms"]
@@ -581,8 +666,12 @@ def main():
         }
         if traffic_note:
             out["roofline"]["traffic_note"] = traffic_note
-        if world == 1 and not args.no_noisy and not (args.noise or args.atlas_charts):
-            out.update(noisy_scene(args, dev, use_graph))
+        if world == 1 and dist is None and not args.no_noisy and not (args.noise or args.atlas_charts or args.stress or args.cold):
+            out.update(extra_scene(args, dev, use_graph, "noisy", noise=0.05, atlas_charts=6, init="spread"))
+            out.update(extra_scene(args, dev, use_graph, "stress", stress=True, init="spread"))
+            out.update(extra_scene(args, dev, use_graph, "cold", cold=True, orbit_deg=args.orbit_deg))
+            out.update(extra_scene(args, dev, use_graph, "stress_cold", stress=True, init="spread", cold=True,
+                                   orbit_deg=args.orbit_deg))
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pipe, args.cpu_sample_rays)
         out.update(dist_info(dist, args))

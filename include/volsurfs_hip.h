@@ -172,7 +172,10 @@ int vsa_trace_q_budgeted(const uint32_t* qnodes, const float* tris, const int32_
  * aligned, >= vsa_trace_feedback_bytes(nr_rays, nr_meshes) (< 0 on bad arguments), ZEROED by the
  * caller before its first use, then owned by this sequence of calls with the SAME feedback_bytes
  * (a buffer sized for more rays serves fewer: a half written for another item count is recognised
- * and ignored): phase alternates 0, 1, 0, ... (the half written by one call is read by the next);
+ * and ignored): phase alternates 0, 1, 0, ... (the half written by one call is read by the next),
+ * or phase = 2: the phase lives in the buffer itself and a one-wave kernel in front of the launch
+ * flips it — the form to use inside a captured graph, where a host-side toggle would be frozen and
+ * every replay would read the half the last eager call wrote;
  * calls that share a feedback buffer must be ordered on one stream.  The lists and flags a
  * call reads always partition the items, so the hits do not depend on what they were measured on. */
 long long vsa_trace_feedback_bytes(int nr_rays, int nr_meshes);
@@ -291,7 +294,10 @@ int vsa_nt_compact(const vsa_nt_plan* plan, const uint8_t* marks, int32_t* slot_
  * where a texel is marked (entries of untouched texels keep whatever they held: nothing on the path
  * reads them - shading only looks up the corners it marked), the marks are CLEARED on the way (the
  * next vsa_nt_mark needs no fill), and texel_of_slot may be NULL.  At 800x800, K = 5 that is 112 MB
- * of -1 and a 28 MB fill less per frame. */
+ * of -1 and a 28 MB fill less per frame.  The frame loop's invariant is "marks are zero between
+ * frames": a vsa_nt_mark that is NOT followed by a successful vsa_nt_compact_frame (an error in
+ * between, or the dense vsa_nt_compact above, which leaves the marks as they are) must be followed by
+ * a fill of the marks before the next frame - stale marks inflate every later frame's slot counts. */
 int vsa_nt_compact_frame(const vsa_nt_plan* plan, uint8_t* marks, int32_t* slot_of,
                          int32_t* texel_of_slot, float* slot_xy, int32_t* seg_start,
                          int32_t* block_scratch, void* stream);

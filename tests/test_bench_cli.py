@@ -26,6 +26,11 @@ def test_kernel_source_hash_guards_the_traffic_file():
     assert len(h) == 64 and h == bench.kernel_source_hash()
     tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     assert "_kernel_source_sha256" in tj and "nt_mlp_bwd" in tj
+    # ... and by the workload it was collected on: the 1080p K = 7 line must not
+    # quote the 800x800 K = 5 collection
+    assert tj["_workload"] == bench.workload_key(bench.parse([]))
+    assert bench.workload_key(bench.parse(["--res", "1080", "--width", "1920", "--shells", "7"])) != tj["_workload"]
+    assert bench.workload_key(bench.parse(["--stress"])) != tj["_workload"]
 
 
 @pytest.mark.gpu
@@ -46,6 +51,23 @@ def test_frame_workload_line():
     # the non-ideal scene beside the headline (noisy shells, fragmented uv charts, spread parameters)
     assert d["value_noisy"] > 0 and d["noisy"]["unique_texels_per_frame"] > 0 and 0 < d["noisy"]["h"] <= 1
     assert "charts" in d["noisy"]["scene"] and "perfect spheres" in d["config"]["scene"]
+    # the stress scene (non-convex lobed shells, 256 charts, 12x triangle spread) and the figures
+    # WITHOUT any inter-frame feedback on a camera that moves every step
+    assert d["value_stress"] > 0 and "non-convex" in d["stress"]["scene"] and d["stress"]["hits_per_frame"] > 0
+    assert d["value_cold"] > 0 and "VSA_TRACE_FEEDBACK=0" in d["cold"]["regime"] and "orbits" in d["cold"]["regime"]
+    assert d["value_stress_cold"] > 0
+    assert d["roofline"]["traffic"] is None      # profiles/traffic.json is another workload's (800x800, K = 5)
+
+
+@pytest.mark.gpu
+def test_one_rank_rccl_group_drives_the_data_parallel_schedule():
+    """RCCL for real.  `--gpus 1 --force-dist` forms a ONE-rank `nccl` process group
+    on the MI355X (init_process_group(device_id=...)) and runs the data-parallel step through it: the
+    gradient slices are all-reduced by RCCL shell by shell while backward runs (GradientOverlap)."""
+    d = _run("--res", "128", "--shells", "2", "--subdiv", "3", "--steps", "3", "--warmup", "1",
+             "--no-cpu-baseline", "--force-dist", "--dist-backend", "nccl")
+    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["dist_backend"] == "nccl" and d["value"] > 0
+    assert "grad_allreduce" in d["stages_ms"] and d["config"]["launch"] == "eager"
 
 
 @pytest.mark.gpu

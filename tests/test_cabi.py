@@ -91,14 +91,14 @@ def test_argument_errors_are_reported_not_ignored():
     assert L.vsa_trace_q_fb(null, null, roots, fr, 1, 10, null, null, 10, ctypes.c_float(0), null, null, null,
                             null, ll(1 << 20), 0, null) == ERR_ARG                                        # null arrays
     assert L.vsa_trace_q_fb(null, null, roots, fr, 1, 10, null, null, 10, ctypes.c_float(0), null, null, null,
-                            null, ll(1 << 20), 2, null) == ERR_ARG                                        # phase
+                            null, ll(1 << 20), 3, null) == ERR_ARG                                        # phase
     assert L.vsa_trace_q_fb(null, null, roots, fr, 1, 48, null, null, 10, ctypes.c_float(0), null, null, null,
                             null, ll(1 << 20), 0, null) == ERR_UNSUPPORTED
     assert L.vsa_trace_q_fb(null, null, roots, fr, 1, 10, null, null, 0, ctypes.c_float(0), null, null, null,
                             null, ll(0), 1, null) == 0
     L.vsa_trace_feedback_bytes.restype = ctypes.c_longlong
     assert L.vsa_trace_feedback_bytes(-1, 1) < 0
-    assert L.vsa_trace_feedback_bytes(640000, 5) == 2 * ((16 + 50000 + 12 * (50000 // 8 + 64) + 255) // 256 * 256)
+    assert L.vsa_trace_feedback_bytes(640000, 5) == 2 * ((16 + 50000 + 12 * (50000 // 8 + 64) + 255) // 256 * 256) + 256
     L.vsa_trace_feedback_bytes.restype = ctypes.c_int
     L.vsa_trace_q_workspace_bytes.restype = ctypes.c_longlong
     assert L.vsa_trace_q_workspace_bytes(-1, 1) < 0

@@ -103,3 +103,67 @@ def test_volsurfs_trains_with_the_fused_optimiser_and_direct_gradient_accumulati
         assert torch.equal(m.bank.tables_h, m.bank.tables.detach().half())  # f16 copy refreshed in the kernel
         assert torch.equal(m.bank.weights_h, m.bank.weights.detach().half())
     assert losses[-1] < losses[0] - 1e-3, losses
+
+
+def _rand_grads(ps, seed):
+    g = torch.Generator().manual_seed(seed)
+    for p in ps:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        p.grad.copy_(torch.randn(p.shape, generator=g).cuda())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls_name", ["FusedAdam", "ShardedFusedAdam"])
+def test_optimiser_save_load_step_uses_the_loaded_moments(cls_name):
+    """`load_state_dict` replaces every state tensor; the cached kernel
+    descriptors must follow (they hold raw addresses).  An optimiser that loads a checkpoint and
+    steps must equal the one that never stopped, bit for bit, and a state dict written by either
+    class must load into the other (full-size moments in both)."""
+    import copy
+    from volsurfs_amd import optim
+    shapes = [(16, 1000, 2), (16, 8192), (1001,)]
+    g0 = torch.Generator().manual_seed(1)
+    init = [torch.randn(s, generator=g0).cuda() for s in shapes]
+
+    def make(name):
+        ps = [torch.nn.Parameter(x.clone()) for x in init]
+        hs = {ps[0]: ps[0].detach().half(), ps[1]: ps[1].detach().half()}
+        kw = dict(lr=1e-2, betas=(0.9, 0.99), eps=1e-15, half_copies=hs)
+        opt = optim.FusedAdam(ps, **kw) if name == "FusedAdam" else optim.ShardedFusedAdam(ps, 1, 0, **kw)
+        return ps, hs, opt
+
+    ps, hs, opt = make(cls_name)
+    for it in range(3):
+        _rand_grads(ps, 10 + it)
+        opt.mark_grads_dirty()
+        opt.step()
+    sd = copy.deepcopy(opt.state_dict())
+    saved = [p.detach().clone() for p in ps]
+    _rand_grads(ps, 99)
+    opt.mark_grads_dirty()
+    opt.step()                                   # the uninterrupted run's 4th step
+    torch.cuda.synchronize()
+    for k in ("exp_avg", "exp_avg_sq"):          # full-size moments whatever the class
+        assert all(sd["state"][i][k].shape == ps[i].shape for i in range(3))
+    for other in ("FusedAdam", "ShardedFusedAdam"):
+        qs, hq, opt2 = make(other)
+        _rand_grads(qs, 5)
+        opt2.mark_grads_dirty()
+        opt2.step()                              # a step BEFORE the load: descriptors cached on the old state
+        with torch.no_grad():
+            for q, s in zip(qs, saved):
+                q.copy_(s)
+        opt2.load_state_dict(copy.deepcopy(sd))
+        garbage = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(4)]   # reuse freed blocks
+        _rand_grads(qs, 99)
+        opt2.mark_grads_dirty()
+        opt2.step()
+        torch.cuda.synchronize()
+        del garbage
+        for p, q in zip(ps, qs):
+            assert torch.equal(p.detach(), q.detach()), (cls_name, other)
+        for p, q in zip(ps, qs):
+            for k in ("exp_avg", "exp_avg_sq"):
+                assert torch.equal(opt.state[p][k].view(-1), opt2.state[q][k].view(-1)), (cls_name, other, k)
+        assert torch.equal(hq[qs[0]], qs[0].detach().half())

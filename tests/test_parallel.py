@@ -334,3 +334,174 @@ def test_sharded_adam_equals_allreduce_adam():
         assert res[r]["moved"] > 0
     for x, y in zip(res[0]["trained"], res[1]["trained"]):
         assert np.array_equal(x, y)                # trained through the pipeline: the replicas are one model
+
+
+def _sharded_ckpt_rank(rank, world, port, tmp, q):
+    """checkpoints of a sharded run.  save() is a collective (both ranks call),
+    rank 0 writes ONE set of files with full-size moments; a resumed two-rank sharded run, and a
+    one-rank plain FusedAdam, both continue exactly where the run stopped."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from volsurfs_amd.mesh import nested_shells
+    from volsurfs_amd.methods import VolSurfs
+    from volsurfs_amd.optim import FusedAdam
+
+    def grads(m, seed):
+        g = torch.Generator().manual_seed(seed + rank)
+        for p_ in (m.bank.tables, m.bank.weights):
+            if p_.grad is None:
+                p_.grad = torch.zeros_like(p_)
+            p_.grad.copy_((torch.randn(p_.shape, generator=g) * (torch.rand(p_.shape, generator=g) < 0.3)).cuda())
+        m.optimizer.mark_grads_dirty()
+
+    def make():
+        m = VolSurfs(nested_shells(K=2, subdiv=2), max_rays=1024, nr_warmup_iters=0, seed=7)
+        m.save_checkpoints_path = m.load_checkpoints_path = tmp
+        return m
+
+    m = make()
+    m.init_optim(world=world, rank=rank, sharded=True)
+    for it in range(2):
+        grads(m, 100 * it)
+        m.optimizer.step()
+    path = m.save(2)                                 # collective; rank 0 writes
+    dist.barrier()
+    files = sorted(os.listdir(path))
+    grads(m, 300)
+    m.optimizer.step()                               # the uninterrupted run's third step
+    m.sync_params()
+    out = {"files": files}
+    # (a) resumed as a two-rank sharded run
+    r = make()
+    r.init_optim(world=world, rank=rank, sharded=True)
+    grads(r, 55)
+    r.optimizer.step()                               # descriptors cached on the pre-load state
+    r.load(2)
+    out["slice_numel"] = [int(r.optimizer.state[p_]["exp_avg"].numel()) for p_ in (r.bank.tables, r.bank.weights)]
+    grads(r, 300)
+    r.optimizer.step()
+    r.sync_params()
+    torch.cuda.synchronize()
+    out["sharded_resume_equal"] = all(torch.equal(a.detach(), b.detach()) for a, b in
+                                      ((m.bank.tables, r.bank.tables), (m.bank.weights, r.bank.weights),
+                                       (m.bank.tables_h, r.bank.tables_h), (m.bank.weights_h, r.bank.weights_h)))
+    # (b) resumed on ONE rank with the plain optimiser on the summed gradients
+    if rank == 0:
+        s = make()
+        s.init_optim()
+        assert isinstance(s.optimizer, FusedAdam)
+        s.load(2)
+        gsum = []
+        for rr in range(world):
+            g = torch.Generator().manual_seed(300 + rr)
+            gsum.append([(torch.randn(p_.shape, generator=g) * (torch.rand(p_.shape, generator=g) < 0.3)).cuda()
+                         for p_ in (s.bank.tables, s.bank.weights)])
+        for i, p_ in enumerate((s.bank.tables, s.bank.weights)):
+            if p_.grad is None:
+                p_.grad = torch.zeros_like(p_)
+            p_.grad.copy_(gsum[0][i] + gsum[1][i])
+        s.optimizer.mark_grads_dirty()
+        s.optimizer.step()
+        s.sync_params()
+        torch.cuda.synchronize()
+        out["plain_resume_equal"] = all(torch.equal(a.detach(), b.detach()) for a, b in
+                                        ((m.bank.tables, s.bank.tables), (m.bank.weights, s.bank.weights)))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_checkpoint_two_ranks_save_and_resume(tmp_path):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_ckpt_rank, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    for r in range(2):
+        assert res[r]["files"] == ["alpha_0.pt", "alpha_1.pt", "fusedadam.pt", "rgb_0.pt", "rgb_1.pt"]
+        assert res[r]["sharded_resume_equal"]
+    n_t = res[0]["slice_numel"]
+    assert n_t == res[1]["slice_numel"]
+    assert res[0]["plain_resume_equal"]
+
+
+def _rccl_one_rank(port, q):
+    """every collective of the multi-GPU design through RCCL itself, in a ONE-rank
+    `nccl` group on the MI355X (the pool leases one GPU per box): communicator init with device_id,
+    RCCL's stream against the kernels' stream, reduce_scatter_tensor / all_gather_into_tensor."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    out = {"dist_backend": dist.get_backend(), "world": dist.get_world_size()}
+    from volsurfs_amd.optim import FusedAdam, ShardedFusedAdam
+    from volsurfs_amd.parallel import GradientOverlap, gather_frame
+    from volsurfs_amd.pipeline import KShellPipeline
+    # (1) the frame step with the gradients all-reduced slice by slice during backward
+    pipe = KShellPipeline.synthetic(K=2, subdiv=3, res=64, init="spread", seed=3)
+    ref_rgb = pipe.step().clone()
+    ov = GradientOverlap(1, force=True)
+    snaps = []
+
+    def ready(t):
+        snaps.append((t, t.clone()))           # the value the collective is given ...
+        ov.reduce_async(t)
+    rgb = pipe.step(grad_ready=ready)
+    ov.wait()
+    torch.cuda.synchronize()
+    out["forward_equal"] = bool(torch.equal(rgb, ref_rgb))
+    out["allreduce_identity"] = all(bool(torch.equal(t, c)) for t, c in snaps)    # ... is what comes back (sum over one rank)
+    out["slices_reduced"] = len(snaps)
+    out["grad_nonzero"] = float(pipe.bank.tables.grad.abs().max()) > 0
+    # (2) sharded Adam: reduce_scatter_tensor -> vsa_adam_step on the slice -> all_gather_into_tensor
+    shapes = [(16, 1000, 2), (16, 8192), (1001,)]
+    res = {}
+    for name in ("plain", "sharded"):
+        g0 = torch.Generator().manual_seed(1)
+        ps = [torch.nn.Parameter(torch.randn(s, generator=g0).cuda()) for s in shapes]
+        hs = {ps[0]: ps[0].detach().half(), ps[1]: ps[1].detach().half()}
+        kw = dict(lr=1e-2, betas=(0.9, 0.99), eps=1e-15, half_copies=hs)
+        opt = FusedAdam(ps, **kw) if name == "plain" else ShardedFusedAdam(ps, 1, 0, force_collectives=True, **kw)
+        for it in range(3):
+            g = torch.Generator().manual_seed(100 * it)
+            for p_ in ps:
+                p_.grad = torch.randn(p_.shape, generator=g).cuda()
+            opt.mark_grads_dirty()
+            opt.step()
+        if name == "sharded":
+            opt.gather_masters()
+            sd = opt.state_dict()             # all_gather_into_tensor of the moment slices
+            out["state_full"] = all(tuple(sd["state"][i]["exp_avg"].shape) == shapes[i] for i in range(3))
+        torch.cuda.synchronize()
+        res[name] = [p_.detach().clone() for p_ in ps] + [hs[ps[0]].clone(), hs[ps[1]].clone()]
+    out["sharded_equals_plain"] = all(bool(torch.equal(a, b)) for a, b in zip(res["plain"], res["sharded"]))
+    # (3) frame gather
+    fr = gather_frame(rgb, rgb.shape[0], 0, 1, force=True)
+    torch.cuda.synchronize()
+    out["gather_equal"] = bool(torch.equal(fr, rgb))
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_one_rank_group_runs_every_collective_of_the_design():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank, args=(_free_port(), q))
+    p.start()
+    out = q.get(timeout=600)
+    p.join(timeout=300)
+    assert p.exitcode == 0
+    print("RCCL one-rank group:", out)
+    assert out["dist_backend"] == "nccl" and out["world"] == 1
+    assert out["forward_equal"] and out["allreduce_identity"] and out["slices_reduced"] == 3 and out["grad_nonzero"]
+    assert out["sharded_equals_plain"] and out["state_full"] and out["gather_equal"]

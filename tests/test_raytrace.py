@@ -153,8 +153,7 @@ def test_cost_feedback_order_keeps_the_hits_bit_exact_whatever_it_was_measured_o
     for _ in range(3):
         check(o, d)
     # the previous call listed some waves as heavy (grazing rays walk long)
-    half = (rt._fb[2] // 2) & ~255
-    hdr = rt._fb[0][(rt._fb[3]) * half:][:16].view(torch.int32).cpu().tolist()
+    hdr = rt.feedback_header()
     assert hdr[0] == -(-3001 // 64) * 3 and sum(hdr[1:]) > 0, hdr
     o2, d2 = _rays(3001, 4)
     check(o2, d2)
@@ -340,8 +339,7 @@ def test_trace_full_frame_properties():
     for _ in range(3):
         got = rt.trace_all(o, d)
         assert all(torch.equal(a, b) for a, b in zip(got, ref))
-    half = (rt._fb[2] // 2) & ~255
-    hdr = rt._fb[0][rt._fb[3] * half:][:16].view(torch.int32).cpu().tolist()
+    hdr = rt.feedback_header()
     assert hdr[0] == 10000 * 5 and 0 < sum(hdr[1:]) < 10000      # a few per cent of the waves are listed
     rt.round_budget = 64
     got = rt.trace_all(o, d)

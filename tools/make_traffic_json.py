@@ -22,6 +22,7 @@ for st, subs in stages.items():
 sys.path.insert(0, root)
 import bench  # noqa: E402  (kernel_source_hash: bench.py refuses the file once the kernels change)
 out["_kernel_source_sha256"] = bench.kernel_source_hash()
+out["_workload"] = bench.workload_key(bench.parse([]))      # tools/traffic.sh runs the default frame workload
 json.dump(out, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 shutil.copy(os.path.join(root, "gpurun_out", "traffic_raw.json"),

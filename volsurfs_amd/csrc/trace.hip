@@ -580,6 +580,36 @@ struct TraceFeedback {
   int* next_lists;
   int cap;
 };
+// The two halves of a feedback buffer and which one a launch reads: `phase` 0 / 1 from the host, or
+// (phase_word != nullptr) a word in the buffer itself that trace_fb_flip_kernel toggles in front of
+// every launch — a captured graph then alternates the halves on every REPLAY (a host-side toggle is
+// frozen at capture: every replay would read the half the last eager call wrote).
+struct TraceFeedbackBuf {
+  char* half[2];
+  long long flags_bytes;
+  const int* phase_word;
+  int phase, cap;
+};
+__device__ __forceinline__ TraceFeedback trace_fb_select(const TraceFeedbackBuf& b) {
+  const int ph = (b.phase_word ? __builtin_amdgcn_readfirstlane(*b.phase_word) : b.phase) & 1;
+  char* prev = b.half[ph];
+  char* next = b.half[ph ^ 1];
+  TraceFeedback fb;
+  fb.prev = reinterpret_cast<const int*>(prev);
+  fb.prev_flag = reinterpret_cast<const unsigned char*>(prev + 16);
+  fb.prev_lists = reinterpret_cast<const int*>(prev + 16 + b.flags_bytes);
+  fb.next = reinterpret_cast<int*>(next);
+  fb.next_flag = reinterpret_cast<unsigned char*>(next + 16);
+  fb.next_lists = reinterpret_cast<int*>(next + 16 + b.flags_bytes);
+  fb.cap = b.cap;
+  return fb;
+}
+// device-resident phase: flip it and clear the header of the half the coming launch writes
+__global__ void trace_fb_flip_kernel(int* phase_word, char* half0, char* half1) {
+  const int ph = (*phase_word ^ 1) & 1;
+  if (threadIdx.x == 0) *phase_word = ph;
+  if (threadIdx.x < 4) reinterpret_cast<int*>(ph ? half0 : half1)[threadIdx.x] = 0;
+}
 #ifndef TRACE_FB_T
 #define TRACE_FB_T 160, 128, 64     /* same-box sweep in profiles/r03/trace_feedback.txt */
 #endif
@@ -590,9 +620,10 @@ template <int STACK>
 __global__ __launch_bounds__(TRACE_BLOCK) void trace_qf_kernel(
     const uint4* __restrict__ qnodes, const float4* __restrict__ tris, Roots roots, Frames frames,
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, int N, int G, int nr_items, float t_min,
-    TraceFeedback fb, float* __restrict__ hit_t, int* __restrict__ hit_slot, float* __restrict__ hit_uv) {
+    TraceFeedbackBuf fbb, float* __restrict__ hit_t, int* __restrict__ hit_slot, float* __restrict__ hit_uv) {
   __shared__ int s_stack[STACK][TRACE_BLOCK];
   const int lane = threadIdx.x;
+  const TraceFeedback fb = trace_fb_select(fbb);
   // dispatch slot -> item (all wave-uniform)
   int item = blockIdx.x;
   {
@@ -1039,8 +1070,9 @@ extern "C" int vsa_trace_q_budgeted(const uint32_t* qnodes, const float* tris, c
   VSA_RETURN_LAUNCH_STATUS();
 }
 
-// Feedback buffer of vsa_trace_q_fb: two halves (written / read alternately) at offsets 0 and bytes / 2,
-// each: 16 B of header, one flag byte per item (rounded up to 16), three lists of cap ints.  The header
+// Feedback buffer of vsa_trace_q_fb: two halves (written / read alternately) at offsets 0 and H, then
+// 256 bytes that hold the device-resident phase word (phase = 2); H = ((bytes - 256) / 2) & ~255.  A half:
+// 16 B of header, one flag byte per item (rounded up to 16), three lists of cap ints.  The header
 // offsets depend on the buffer only, so a buffer sized for more rays serves fewer (the tag in the header
 // tells a half that was written for another item count).
 static long long trace_fb_half_bytes(long long items, int* cap_out) {
@@ -1051,14 +1083,14 @@ static long long trace_fb_half_bytes(long long items, int* cap_out) {
 
 extern "C" long long vsa_trace_feedback_bytes(int nr_rays, int nr_meshes) {
   if (nr_rays < 0 || nr_meshes < 1) return -1;
-  return 2 * trace_fb_half_bytes((long long)vsa_div_up(nr_rays, TRACE_BLOCK) * nr_meshes, nullptr);
+  return 2 * trace_fb_half_bytes((long long)vsa_div_up(nr_rays, TRACE_BLOCK) * nr_meshes, nullptr) + 256;
 }
 
 extern "C" int vsa_trace_q_fb(const uint32_t* qnodes, const float* tris, const int32_t* mesh_roots,
                               const float* mesh_frames, int nr_meshes, int max_depth, const float* rays_o,
                               const float* rays_d, int nr_rays, float t_min, float* hit_t, int32_t* hit_slot,
                               float* hit_uv, void* feedback, long long feedback_bytes, int phase, void* stream) {
-  if (nr_meshes < 1 || nr_meshes > VSA_MAX_SHELLS || nr_rays < 0 || !mesh_roots || !mesh_frames || (phase & ~1))
+  if (nr_meshes < 1 || nr_meshes > VSA_MAX_SHELLS || nr_rays < 0 || !mesh_roots || !mesh_frames || phase < 0 || phase > 2)
     return VSA_ERR_ARG;
   if (max_depth >= TRACE_STACK) return VSA_ERR_UNSUPPORTED;
   if (nr_rays == 0) return VSA_OK;
@@ -1066,10 +1098,9 @@ extern "C" int vsa_trace_q_fb(const uint32_t* qnodes, const float* tris, const i
   const int G = vsa_div_up(nr_rays, TRACE_BLOCK);
   const long long items = (long long)G * nr_meshes;
   int cap = 0;
-  if (items > 0x7fffffff / 2 || feedback_bytes < 2 * trace_fb_half_bytes(items, &cap) || ((uintptr_t)feedback & 15))
+  if (items > 0x7fffffff / 2 || feedback_bytes < 2 * trace_fb_half_bytes(items, &cap) + 256 || ((uintptr_t)feedback & 15))
     return VSA_ERR_ARG;
-  const long long half = (feedback_bytes / 2) & ~255ll;
-  const long long flags_bytes = (items + 15) / 16 * 16;
+  const long long half = ((feedback_bytes - 256) / 2) & ~255ll;
   Roots r;
   Frames fr;
   for (int i = 0; i < VSA_MAX_SHELLS; ++i) {
@@ -1077,18 +1108,18 @@ extern "C" int vsa_trace_q_fb(const uint32_t* qnodes, const float* tris, const i
     for (int j = 0; j < 6; ++j) fr.f[i][j] = i < nr_meshes ? mesh_frames[6 * i + j] : 1.0f;
   }
   char* b = static_cast<char*>(feedback);
-  char* prev = b + (phase ? half : 0);
-  char* next = b + (phase ? 0 : half);
-  TraceFeedback fb;
-  fb.prev = reinterpret_cast<const int*>(prev);
-  fb.prev_flag = reinterpret_cast<const unsigned char*>(prev + 16);
-  fb.prev_lists = reinterpret_cast<const int*>(prev + 16 + flags_bytes);
-  fb.next = reinterpret_cast<int*>(next);
-  fb.next_flag = reinterpret_cast<unsigned char*>(next + 16);
-  fb.next_lists = reinterpret_cast<int*>(next + 16 + flags_bytes);
+  TraceFeedbackBuf fb;
+  fb.half[0] = b, fb.half[1] = b + half;
+  fb.flags_bytes = (items + 15) / 16 * 16;
+  fb.phase_word = phase == 2 ? reinterpret_cast<const int*>(b + 2 * half) : nullptr;
+  fb.phase = phase & 1;
   fb.cap = cap;
   hipStream_t s = (hipStream_t)stream;
-  VSA_HIP_TRY(hipMemsetAsync(next, 0, 16, s));
+  if (phase == 2)
+    hipLaunchKernelGGL(trace_fb_flip_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<int*>(b + 2 * half),
+                       fb.half[0], fb.half[1]);
+  else
+    VSA_HIP_TRY(hipMemsetAsync(fb.half[phase ^ 1], 0, 16, s));
   const uint4* qn = reinterpret_cast<const uint4*>(qnodes);
   const float4* tr = reinterpret_cast<const float4*>(tris);
   // every item once, plus room for the listed ones' second (skipped) appearance

@@ -109,6 +109,51 @@ def nested_shells(K=5, subdiv=6, r0=0.30, dr=0.01, noise=0.0, seed=0, device="cu
     return meshes
 
 
+def stress_shells(K=5, subdiv=6, r0=0.30, dr=0.01, lobes=4, amplitude=0.3, warp=0.55, noise=0.05,
+                  charts=16, seed=0, device="cuda"):
+    """K nested shells that stress what real baked shells stress (the reference's shells are marching-
+    cubes meshes simplified to 2.5 % of their faces with xatlas atlases: baker.py:123,151 — hundreds of
+    charts, non-convex, uneven triangles):
+
+      * NON-CONVEX: the radius is modulated by `lobes` lobes of relative depth `amplitude` around an axis
+        that is tilted against the bench camera's view axis, so a ray crosses a shell up to `lobes` + 2
+        times (closest hit matters beyond front / back) and many rays graze lobe flanks;
+      * UNEVEN TRIANGLES: the unit sphere is warped towards a pole before the displacement
+        (v -> normalise(v + warp * axis)): triangle areas spread by ((1 + warp) / (1 - warp))^2 ~ 12x
+        at warp = 0.55, on top of the stretching along the lobe flanks;
+      * FRAGMENTED ATLAS: the parameterisation is cut into charts x charts (= 256) randomly packed,
+        flipped and transposed charts (chart_atlas) — neighbouring pixels touch texels far apart;
+      * the shell-to-shell noise of `nested_shells(noise=...)` on top.
+    """
+    rng = np.random.default_rng(seed)
+    base_v, f = icosphere(subdiv, 1.0)
+    base = base_v.astype(np.float64)
+    pole = np.array([0.45, 0.80, 0.40])
+    pole /= np.linalg.norm(pole)
+    vw = base + warp * pole
+    vw /= np.linalg.norm(vw, axis=1, keepdims=True)
+    axis = np.array([1.0, 0.3, 0.2])                 # lobes run around this axis: across the view axis (z)
+    axis /= np.linalg.norm(axis)
+    e1 = np.cross(axis, [0.0, 0.0, 1.0])
+    e1 /= np.linalg.norm(e1)
+    e2 = np.cross(axis, e1)
+    h = vw @ axis
+    phi = np.arctan2(vw @ e2, vw @ e1)
+    lobe = 1.0 + amplitude * np.sin(lobes * phi) * (1.0 - h * h) + 0.35 * amplitude * np.sin(3.0 * np.pi * h)
+    uv0 = octahedral_uv(base)[f]
+    meshes = []
+    for k in range(K):
+        r = r0 + dr * k
+        bump = lobe[:, None]
+        if noise > 0:
+            bump = bump * (1.0 + noise * np.sin(7.0 * vw[:, :1] + 0.15 * k) * np.cos(5.0 * vw[:, 1:2])
+                           + 0.1 * noise * rng.standard_normal((vw.shape[0], 1)))
+        vv = (vw * bump * r).astype(np.float32)
+        uv = chart_atlas(uv0.astype(np.float64), charts, seed=seed + 17 * k) if charts else uv0.astype(np.float32)
+        meshes.append(TensorMesh(vv, f, uv, device=device))
+    return meshes
+
+
 # ---------------------------------------------------------------------------
 # Mesh I/O (SURVEY §8f row 1): the baked shells of a run are
 # `<run>/meshes_simplified_uvs/<isolevel>.obj` with per-face-corner UVs from xatlas

@@ -173,6 +173,7 @@ class VolSurfs(torch.nn.Module):
         (optim.ShardedFusedAdam: reduce-scatter -> Adam on a slice -> all-gather of the f16 copies);
         its step() replaces the gradient all-reduce + step of trainer.train_step."""
         from .optim import FusedAdam, ShardedFusedAdam
+        self._dist_rank, self._dist_world = int(rank), int(world)
         half = {}
         if self.bank is not None:
             params = [self.bank.tables, self.bank.weights]
@@ -578,21 +579,28 @@ class VolSurfs(torch.nn.Module):
         return out
 
     def save(self, iter_nr):
+        """Data-parallel runs: a COLLECTIVE when the optimiser is sharded — every rank calls it
+        (`sync_params` all-gathers the fp32 masters, `ShardedFusedAdam.state_dict` the moment
+        slices); rank 0 alone writes the files, which hold full tensors and therefore load under
+        any world size, sharded or not.  Replicated (all-reduce) runs: rank 0's call suffices."""
         import os
         if getattr(self, "save_checkpoints_path", None) is None:
             return None
         path = os.path.join(self.save_checkpoints_path, format(iter_nr, "07d"), "models")
-        os.makedirs(path, exist_ok=True)
         self.sync_params()       # parameters and moments are final on the current stream
+        opt_state = self.optimizer.state_dict() if getattr(self, "optimizer", None) is not None else None
+        if getattr(self, "_dist_rank", 0) != 0:
+            return path          # took part in the collectives; the files are rank 0's
+        os.makedirs(path, exist_ok=True)
         for key, (t, w) in self._model_states().items():
             torch.save({"tables": t.detach().cpu(), "weights": w.detach().cpu()}, os.path.join(path, f"{key}.pt"))
         for key, model in self.models.items():
             torch.save(model.state_dict(), os.path.join(path, f"{key}.pt"))
         if isinstance(self.bg_model, torch.nn.Module):
             torch.save(self.bg_model.state_dict(), os.path.join(path, "bg.pt"))
-        if getattr(self, "optimizer", None) is not None:
-            torch.save(self.optimizer.state_dict(),
-                       os.path.join(path, f"{self.optimizer.__class__.__name__.lower()}.pt"))
+        if opt_state is not None:
+            # one file name for both optimiser classes (the reference's: base_method.py:246-253)
+            torch.save(opt_state, os.path.join(path, "fusedadam.pt"))
         return path
 
     def load(self, iter_nr):
@@ -626,7 +634,7 @@ class VolSurfs(torch.nn.Module):
         if isinstance(self.bg_model, torch.nn.Module) and os.path.exists(f):
             self.bg_model.load_state_dict(torch.load(f, map_location="cuda"))
         if getattr(self, "optimizer", None) is not None:
-            f = os.path.join(path, f"{self.optimizer.__class__.__name__.lower()}.pt")
+            f = os.path.join(path, "fusedadam.pt")
             if os.path.exists(f):
                 self.optimizer.load_state_dict(torch.load(f, map_location="cuda"))
         return path

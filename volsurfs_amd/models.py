@@ -372,7 +372,7 @@ class MLP(torch.nn.Module):
     def forward(self, x):
         linears = [m for m in self.layers if isinstance(m, torch.nn.Linear)]
         dims = [linears[0].in_features] + [m.out_features for m in linears]
-        if MLP.fused and self.last_layer_linear and fused_mlp_supported(dims, x):
+        if self.fused and self.last_layer_linear and fused_mlp_supported(dims, x):
             params = []
             for m in linears:
                 params.append(m.weight)
@@ -380,13 +380,14 @@ class MLP(torch.nn.Module):
                     params.append(m.bias)
             _CALL["grad"] = torch.is_grad_enabled()
             return _FusedMLP.apply(x, bool(self.bias), *params)
-        if MLP.fused and x.is_cuda and not getattr(self, "_warned_unfused", False):
-            # not silent: a CUDA MLP outside what csrc/mlp_f32.hip covers (wider than 128, hidden
-            # widths not multiples of 32, GELU after the last layer, non-fp32) runs as library GEMMs
-            import warnings
-            warnings.warn(f"volsurfs_amd.models.MLP {dims}: outside the fused HIP kernel's shapes; "
-                          "running the torch op sequence (rocBLAS GEMMs)", RuntimeWarning, stacklevel=2)
-            self._warned_unfused = True
+        if self.fused and x.is_cuda:
+            # No library fallback on the product path: a CUDA MLP outside what
+            # csrc/mlp_f32.hip covers (wider than 128, hidden widths not multiples of 32, GELU after the
+            # last layer, non-fp32) is an error unless the caller asks for the torch op sequence
+            # (rocBLAS GEMMs) explicitly with `MLP.fused = False` (class-wide) or `mlp.fused = False`.
+            raise _lib.VolsurfsHipError(
+                f"volsurfs_amd.models.MLP {dims} (last_layer_linear={self.last_layer_linear}, dtype {x.dtype}): "
+                "outside the fused HIP kernel's shapes; set `.fused = False` to run the torch op sequence")
         for layer in self.layers:
             if isinstance(layer, torch.nn.Linear) and layer.bias is not None and x.dim() == 2 \
                     and torch.is_grad_enabled():

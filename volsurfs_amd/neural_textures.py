@@ -194,18 +194,23 @@ class NeuralTextureBank(torch.nn.Module):
         tex_uv = torch.empty(K, N, 2, device=hit_slot.device)
         if self.plan.balance:
             _lib.call("vsa_nt_rebalance", ctypes.byref(self.plan), st)
-        # the marks are zero here: allocated so, and every compaction clears what it reads
-        if _DENSE_COMPACT:
+        # Invariant: the marks are zero between frames — allocated so, and vsa_nt_compact_frame clears
+        # what it reads.  `_marks_dirty` is set while a mark has not been followed by a compaction that
+        # returned OK (an exception between the two, a failed launch, the dense vsa_nt_compact, which
+        # does not clear): stale marks would silently inflate every later frame's slot counts.
+        if _DENSE_COMPACT or getattr(self, "_marks_dirty", False):
             self.marks.zero_()
+        self._marks_dirty = True
         _lib.call("vsa_nt_mark", ctypes.byref(self.plan), hit_slot, hit_uv, face_uvs, N, tex_uv,
                   self.marks, st)
         if _DENSE_COMPACT:
             _lib.call("vsa_nt_compact", ctypes.byref(self.plan), self.marks, self.slot_of,
                       self.texel_of_slot, self.slot_xy, self.seg_start, self.block_scratch, st)
-            return tex_uv
+            return tex_uv                  # (marks stay dirty: the next frame zeroes them)
         _lib.call("vsa_nt_compact_frame", ctypes.byref(self.plan), self.marks, self.slot_of,
                   self.texel_of_slot if want_texel_of_slot else None, self.slot_xy, self.seg_start,
                   self.block_scratch, st)
+        self._marks_dirty = False
         return tex_uv
 
     # -- baking (the deploy format, sh_neural_textures.py:99-114 /

@@ -102,6 +102,14 @@ class FusedAdam(torch.optim.Optimizer):
                            [(p, p.grad, s["exp_avg"], s["exp_avg_sq"], p.data_ptr()) for p, s in zip(ps, sts)])
         return self._plans[gi]
 
+    def load_state_dict(self, state_dict):
+        """Accepts its own state dicts and the world-size independent ones ShardedFusedAdam writes
+        (full-size moments + a "layout" tag).  The descriptor cache notices the replaced state
+        tensors by identity (`_plan`)."""
+        sd = dict(state_dict)
+        sd.pop("layout", None)
+        super().load_state_dict(sd)
+
     def zero_grad(self, set_to_none=False):
         """Gradients stay allocated (the step kernel holds their addresses and has already
         cleared them); only a backward without a following step leaves something to clear."""
@@ -163,16 +171,20 @@ class ShardedFusedAdam(FusedAdam):
     multiple of world x 4 elements is all-reduced and updated in full on every rank.
     Backends without reduce_scatter (gloo) get all-reduce + slice: same numbers."""
 
-    def __init__(self, params, world, rank, group=None, **kw):
+    def __init__(self, params, world, rank, group=None, force_collectives=False, **kw):
+        """force_collectives: shard (into ONE slice) and run reduce-scatter / all-gather even when
+        world == 1 — identities that put RCCL's real entry points, its stream and this class's
+        ordering against the Adam kernel under test on a single GPU."""
         super().__init__(params, **kw)
         self.world, self.rank, self.group = int(world), int(rank), group
+        self.force_collectives = bool(force_collectives)
         self._shards = {}            # id(param) -> (a, b, grad shard, param slice, f16 slice | None)
 
     def _shard(self, p):
         s = self._shards.get(id(p))
         if s is None:
             n = p.numel()
-            if self.world == 1 or n % (self.world * 4):
+            if (self.world == 1 and not self.force_collectives) or n % (self.world * 4):
                 # not divisible: all-reduced and updated in full on every rank, through a private
                 # gradient buffer like the slices (the descriptors never hold p.grad's address)
                 h = self._half.get(id(p))
@@ -188,9 +200,20 @@ class ShardedFusedAdam(FusedAdam):
         return s
 
     def _plan(self, gi, group):
+        # The cached descriptors hold raw addresses of the slice moments: they are only valid while
+        # the state tensors are the same OBJECTS (load_state_dict replaces them) and the set of
+        # trainable parameters is unchanged — the same identity check as the base class.
         cur = self._plans.get(gi)
         if cur is not None:
-            return cur
+            state = self.state
+            for p, ea, eas, ptr in cur[4]:
+                st = state.get(p)
+                if st is None or st.get("exp_avg") is not ea or st.get("exp_avg_sq") is not eas \
+                        or not p.requires_grad or p.data_ptr() != ptr:
+                    break
+            else:
+                if len(cur[4]) == sum(1 for p in group["params"] if p.requires_grad):
+                    return cur
         ps = [p for p in group["params"] if p.requires_grad]
         chunk = _lib.lib().vsa_adam_chunk_elems()
         arr = (AdamTensor * max(len(ps), 1))()
@@ -200,31 +223,93 @@ class ShardedFusedAdam(FusedAdam):
             sh = self._shard(p)
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
-            if True:
-                a, b, g, ps_, hs = sh
-                st.setdefault("exp_avg", torch.zeros(b - a, device=p.device))       # the slice's moments only
-                st.setdefault("exp_avg_sq", torch.zeros(b - a, device=p.device))
-                arr[i] = AdamTensor(ps_.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
-                                    st["exp_avg_sq"].data_ptr(), hs.data_ptr() if hs is not None else None, b - a)
-                n = b - a
+            a, b, g, ps_, hs = sh
+            for k in ("exp_avg", "exp_avg_sq"):                  # the slice's moments only
+                m = st.get(k)
+                if m is None:
+                    st[k] = torch.zeros(b - a, device=p.device)
+                elif m.numel() != b - a or m.dtype != torch.float32 or not m.is_contiguous():
+                    raise _lib.VolsurfsHipError(
+                        "ShardedFusedAdam: state '%s' holds %d elements, this rank's slice has %d "
+                        "(load checkpoints through load_state_dict)" % (k, m.numel(), b - a))
+            arr[i] = AdamTensor(ps_.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
+                                st["exp_avg_sq"].data_ptr(), hs.data_ptr() if hs is not None else None, b - a)
+            n = b - a
             chunks += [(i, c) for c in range((n + chunk - 1) // chunk)]
         dev = ps[0].device if ps else "cuda"
         desc = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
         ck = torch.tensor(chunks, dtype=torch.int32).reshape(-1, 2).to(dev)
-        self._plans[gi] = (None, desc, ck, len(chunks), None)
+        self._plans[gi] = (None, desc, ck, len(chunks),
+                           [(p, self.state[p]["exp_avg"], self.state[p]["exp_avg_sq"], p.data_ptr()) for p in ps])
         return self._plans[gi]
+
+    # ---- checkpoints: world-size independent.  state_dict() is a COLLECTIVE (every rank calls it):
+    # the moment slices are all-gathered into full tensors, so the result has the layout of a plain
+    # FusedAdam / torch.optim.Adam state dict and loads into either class under any world size;
+    # only rank 0 needs to write it (VolSurfs.save).  load_state_dict() takes that full layout (or
+    # this rank's own slices) and keeps the slice this rank owns.
+    @torch.no_grad()
+    def state_dict(self):
+        import torch.distributed as dist
+        sd = super().state_dict()
+        ps = [p for g in self.param_groups for p in g["params"]]
+        full = getattr(self, "_full", set())
+        state = {}
+        for idx, p in enumerate(ps):
+            st = sd["state"].get(idx)
+            if st is None:
+                continue
+            st = dict(st)
+            if id(p) not in full and (self.world > 1 or self.force_collectives):
+                for k in ("exp_avg", "exp_avg_sq"):
+                    mine = st[k].contiguous()
+                    whole = torch.empty(p.numel(), device=mine.device, dtype=mine.dtype)
+                    self._all_gather(whole, mine)
+                    st[k] = whole.view(p.shape)
+            else:
+                for k in ("exp_avg", "exp_avg_sq"):
+                    st[k] = st[k].view(p.shape)
+            state[idx] = st
+        sd["state"] = state
+        sd["layout"] = "full"
+        return sd
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        sd = dict(state_dict)
+        sd.pop("layout", None)
+        ps = [p for g in self.param_groups for p in g["params"]]
+        state = {}
+        for idx, st in sd["state"].items():
+            p = ps[int(idx)]
+            a, b = self._shard(p)[0], self._shard(p)[1]
+            st = dict(st)
+            for k in ("exp_avg", "exp_avg_sq"):
+                m = st[k]
+                if m.numel() == p.numel():
+                    st[k] = m.reshape(-1)[a:b].clone()
+                elif m.numel() != b - a:
+                    raise _lib.VolsurfsHipError(
+                        "ShardedFusedAdam.load_state_dict: '%s' of parameter %d holds %d elements; expected the "
+                        "full tensor (%d) or this rank's slice (%d)" % (k, int(idx), m.numel(), p.numel(), b - a))
+            state[idx] = st
+        sd["state"] = state
+        super().load_state_dict(sd)
+        self._plans.clear()           # the descriptors point at the replaced state tensors
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._plans = {}
 
     def _reduce_scatter(self, p, sh):
         import torch.distributed as dist
         a, b, g = sh[0], sh[1], sh[2]
         flat = p.grad.view(-1)
-        try:
-            if dist.get_backend(self.group) == "gloo":
-                raise RuntimeError("gloo has no reduce_scatter")
-            dist.reduce_scatter_tensor(g, flat, op=dist.ReduceOp.SUM, group=self.group)
-        except RuntimeError:
+        if dist.get_backend(self.group) == "gloo":      # gloo has no reduce_scatter: all-reduce + slice, same numbers
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             g.copy_(flat[a:b])
+        else:                                            # RCCL: an error here is an error (no silent fallback)
+            dist.reduce_scatter_tensor(g, flat, op=dist.ReduceOp.SUM, group=self.group)
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0, stream=None):
@@ -261,10 +346,19 @@ class ShardedFusedAdam(FusedAdam):
             h = self._half.get(id(p))
             whole = (h if h is not None else p.detach()).view(-1)
             mine = (h_slice if h is not None else p_slice).clone()
-            per = b - a
-            dist.all_gather([whole[r * per:(r + 1) * per] for r in range(self.world)], mine, group=self.group)
+            self._all_gather(whole, mine)
         self._grads_clean = True
         return None
+
+    def _all_gather(self, whole, mine):
+        """whole[r * per:(r + 1) * per] <- rank r's `mine`: the slices lie in rank order, so RCCL gathers
+        straight into the destination (all_gather_into_tensor); gloo takes the list form."""
+        import torch.distributed as dist
+        per = mine.numel()
+        if dist.get_backend(self.group) == "gloo":
+            dist.all_gather([whole[r * per:(r + 1) * per] for r in range(self.world)], mine, group=self.group)
+        else:
+            dist.all_gather_into_tensor(whole, mine, group=self.group)
 
     @torch.no_grad()
     def gather_masters(self):
@@ -276,9 +370,7 @@ class ShardedFusedAdam(FusedAdam):
                 if id(p) in getattr(self, "_full", set()) or self._half.get(id(p)) is None:
                     continue
                 a, b, _, p_slice, _ = sh
-                full, per = p.detach().view(-1), b - a
-                dist.all_gather([full[r * per:(r + 1) * per] for r in range(self.world)], p_slice.clone(),
-                                group=self.group)
+                self._all_gather(p.detach().view(-1), p_slice.clone())
 
 
 def accumulate_into_grad(param):

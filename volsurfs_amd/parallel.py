@@ -62,11 +62,14 @@ class GradientOverlap:
     gradients are what bounds strong scaling) at the price of a bf16-rounded SUM
     (~2^-9 relative per hop); the default (None) reduces the fp32 tensors in place, exactly."""
 
-    def __init__(self, world, group=None, wire_dtype=None):
-        self.world, self.group, self.works, self.wire_dtype = world, group, [], wire_dtype
+    def __init__(self, world, group=None, wire_dtype=None, force=False):
+        """force: issue the collectives even in a one-rank group (they are identities there) — how a
+        single MI355X exercises the real RCCL path: communicator init, RCCL's stream against the
+        kernels' stream (bench.py --force-dist, tests/test_parallel.py::test_rccl_one_rank_*)."""
+        self.world, self.group, self.works, self.wire_dtype, self.force = world, group, [], wire_dtype, force
 
     def reduce_async(self, t):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         import torch.distributed as dist
         if self.wire_dtype is None:
@@ -85,11 +88,11 @@ class GradientOverlap:
         self.works = []
 
 
-def gather_frame(local_rgb, nr_rays, rank, world, chunk=16384, group=None):
+def gather_frame(local_rgb, nr_rays, rank, world, chunk=16384, group=None, force=False):
     """Rank 0 receives the full [nr_rays,3] frame (rendering needs no other
-    collective: every rank writes its own tiles)."""
+    collective: every rank writes its own tiles).  force: run the collective in a one-rank group too."""
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not force:
         return local_rgb
     sizes = [sum(b - a for a, b in shard_chunks(nr_rays, r, world, chunk)) for r in range(world)]
     bufs = [torch.empty(s, 3, dtype=local_rgb.dtype, device=local_rgb.device) for s in sizes]

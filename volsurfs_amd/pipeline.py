@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 from .camera import pinhole_rays
-from .mesh import nested_shells
+from .mesh import nested_shells, stress_shells
 from .raytrace import RayTracer
 
 
@@ -101,14 +101,16 @@ class KShellPipeline:
 
     @classmethod
     def synthetic(cls, K=5, subdiv=6, res=800, device="cuda", seed=42, rows=None, gt_seed=None,
-                  noise=0.0, atlas_charts=0, **kw):
+                  noise=0.0, atlas_charts=0, stress=False, cam_pos=(0.0, 0.0, -1.5), **kw):
         """res: an int (square frame) or (H, W).  rows: optional LongTensor of image rows (whole
         8-row bands, parallel.shard_bands): the pipeline then renders only those rows of the
         frame — one rank's share under strong scaling — with the loss still the frame's mean."""
-        meshes = nested_shells(K=K, subdiv=subdiv, device=device, noise=noise, atlas_charts=atlas_charts)
+        if stress:      # non-convex lobed shells, 12x triangle-area spread, 256 randomly packed charts (mesh.stress_shells)
+            meshes = stress_shells(K=K, subdiv=subdiv, device=device)
+        else:
+            meshes = nested_shells(K=K, subdiv=subdiv, device=device, noise=noise, atlas_charts=atlas_charts)
         H, W = (res, res) if isinstance(res, int) else res
-        o, d = pinhole_rays(H, W, focal=1111.1 * min(H, W) / 800.0, cam_pos=(0.0, 0.0, -1.5),
-                            device=device)
+        o, d = pinhole_rays(H, W, focal=1111.1 * min(H, W) / 800.0, cam_pos=cam_pos, device=device)
         # (gt_seed: data-parallel ranks share the parameters — `seed` — and differ in their data)
         g = torch.Generator(device=device).manual_seed(seed if gt_seed is None else gt_seed)
         gt = torch.rand(o.shape[0], 3, device=device, generator=g)
@@ -122,8 +124,11 @@ class KShellPipeline:
         p.grad_scale = float(n_frame)      # the f16 gradient chain is conditioned for 1 / (3 n_frame) per ray
         p.res = res
         p.subdiv = subdiv
-        p.scene_desc = (f"noise {noise}, {atlas_charts}x{atlas_charts} randomly packed uv charts per shell, "
-                        f"parameters {kw.get('init', 'tcnn')}-initialised") if (noise or atlas_charts) else \
+        p.scene_desc = ("stress shells: 4 lobes of depth 0.3 r across the view axis (non-convex, up to 6 crossings per "
+                        "ray), triangle areas spread 12x, 256 randomly packed uv charts per shell, noise 0.05, "
+                        f"parameters {kw.get('init', 'tcnn')}-initialised") if stress else \
+            (f"noise {noise}, {atlas_charts}x{atlas_charts} randomly packed uv charts per shell, "
+             f"parameters {kw.get('init', 'tcnn')}-initialised") if (noise or atlas_charts) else \
             "perfect spheres, one continuous octahedral uv chart, tcnn-initialised parameters"
         return p
 
@@ -160,7 +165,9 @@ class KShellPipeline:
             "unique_texels_per_frame": getattr(self, "last_slots", None),
             # the traversal's launch order comes from the previous frame's measured wave cost (same hits;
             # VSA_TRACE_FEEDBACK=0 = the stateless launch: DESIGN.md 9.4)
-            "trace_launch_order": "cost feedback from the previous frame" if self.tracer.cost_feedback and
+            "trace_launch_order": "cost feedback from the previous frame (static camera: the previous frame has "
+                                  "the same rays; value_cold is the figure without any inter-frame feedback)"
+                                  if self.tracer.cost_feedback and
                                   self.tracer.node_format == "q16" and not self.tracer.round_budget else "natural",
         }
 

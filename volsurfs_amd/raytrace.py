@@ -69,16 +69,17 @@ class RayTracer:
             rc2 = L.vsa_bvh_export_q(h, qnodes.ctypes.data_as(ctypes.c_void_p),
                                      tris.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(node_base),
                                      ctypes.c_int(tri_base), frame.ctypes.data_as(ctypes.c_void_p))
-            q4 = np.empty((nn.value, 16), np.uint32)
-            n4, d4 = ctypes.c_int(), ctypes.c_int()
-            rc3 = L.vsa_bvh_export_q4(h, q4.ctypes.data_as(ctypes.c_void_p), tris.ctypes.data_as(ctypes.c_void_p),
-                                      ctypes.c_int(node4_base), ctypes.c_int(tri_base),
-                                      frame.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n4), ctypes.byref(d4))
-            rc = rc or rc3
-            q4_all.append(q4[:n4.value])
-            roots4.append(node4_base)
-            node4_base += n4.value
-            self.max_depth4 = max(self.max_depth4, d4.value)
+            if self.node_format == "q16x4":      # the 4-wide collapse (host time + a second node array) only when asked for
+                q4 = np.empty((nn.value, 16), np.uint32)
+                n4, d4 = ctypes.c_int(), ctypes.c_int()
+                rc3 = L.vsa_bvh_export_q4(h, q4.ctypes.data_as(ctypes.c_void_p), tris.ctypes.data_as(ctypes.c_void_p),
+                                          ctypes.c_int(node4_base), ctypes.c_int(tri_base),
+                                          frame.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n4), ctypes.byref(d4))
+                rc = rc or rc3
+                q4_all.append(q4[:n4.value])
+                roots4.append(node4_base)
+                node4_base += n4.value
+                self.max_depth4 = max(self.max_depth4, d4.value)
             L.vsa_bvh_destroy(h)
             if rc != 0 or rc2 != 0:
                 raise _lib.VolsurfsHipError(f"vsa_bvh_export failed with status {rc} / {rc2}")
@@ -96,8 +97,8 @@ class RayTracer:
         self.device = dev
         self.nodes = torch.from_numpy(np.concatenate(nodes_all, 0)).to(dev)
         self.qnodes = torch.from_numpy(np.concatenate(qnodes_all, 0).view(np.int32)).to(dev)
-        self.qnodes4 = torch.from_numpy(np.concatenate(q4_all, 0).view(np.int32)).to(dev)
-        self._roots4 = (ctypes.c_int32 * self.nr_meshes)(*roots4)
+        self.qnodes4 = torch.from_numpy(np.concatenate(q4_all, 0).view(np.int32)).to(dev) if q4_all else None
+        self._roots4 = (ctypes.c_int32 * self.nr_meshes)(*roots4) if q4_all else None
         self._frames = (ctypes.c_float * (6 * self.nr_meshes))(*np.concatenate(frames).tolist())
         tris_np = np.concatenate(tris_all, 0)
         self.tris = torch.from_numpy(tris_np).to(dev)
@@ -145,11 +146,12 @@ class RayTracer:
                 nbytes = int(fn(ctypes.c_int(N), ctypes.c_int(K)))
                 if nbytes < 0:
                     raise _lib.VolsurfsHipError("vsa_trace_feedback_bytes failed")
-                self._fb = [torch.zeros(nbytes, dtype=torch.uint8, device=rays_o.device), N, nbytes, 0]
+                self._fb = [torch.zeros(nbytes, dtype=torch.uint8, device=rays_o.device), N, nbytes]
+            # phase 2: the read / written halves alternate through a word in the buffer, flipped on the
+            # device in front of every launch, so a captured graph alternates them on every replay too
             _lib.call("vsa_trace_q_fb", self.qnodes, self.tris, self._roots, self._frames, K,
                       self.max_depth, rays_o, rays_d, N, float(t_min), hit_t, hit_slot, hit_uv,
-                      self._fb[0], ctypes.c_longlong(self._fb[2]), self._fb[3], _lib.stream_ptr())
-            self._fb[3] ^= 1
+                      self._fb[0], ctypes.c_longlong(self._fb[2]), 2, _lib.stream_ptr())
         elif self.node_format == "q16":
             _lib.call("vsa_trace_q", self.qnodes, self.tris, self._roots, self._frames, K,
                       self.max_depth, rays_o, rays_d, N, float(t_min), hit_t, hit_slot, hit_uv,
@@ -158,6 +160,12 @@ class RayTracer:
             _lib.call("vsa_trace", self.nodes, self.tris, self._roots, K, self.max_depth, rays_o,
                       rays_d, N, float(t_min), hit_t, hit_slot, hit_uv, _lib.stream_ptr())
         return hit_t, hit_slot, hit_uv
+
+    def feedback_header(self):
+        """{tag, n0, n1, n2} of the half the LAST cost-feedback launch wrote (tests, diagnostics)."""
+        half = ((self._fb[2] - 256) // 2) & ~255
+        ph = int(self._fb[0][2 * half:2 * half + 4].view(torch.int32).item()) & 1
+        return self._fb[0][(ph ^ 1) * half:][:16].view(torch.int32).cpu().tolist()
 
     def trace(self, rays_o, rays_d, mesh_id=0, t_min=0.0):
         """raytracelib-shaped single-mesh trace (volsurfs.py:480-501)."""
