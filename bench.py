@@ -97,6 +97,23 @@ def parse(argv=None):
     return args
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when its first communicator comes up; the contract is
+    ONE JSON line there.  File descriptor 1 is pointed at stderr while the process group forms."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._keep = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *a):
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)      # the banner sits in libc's stdio buffer (a pipe is fully buffered)
+        os.dup2(self._keep, 1)
+        os.close(self._keep)
+
+
 def dist_info(dist, args):
     """What the line's n_gpus rests on: the size of the process group the ranks really formed."""
     if dist is None:
@@ -509,10 +526,14 @@ def main():
             os.environ.setdefault("MASTER_PORT", str(port))
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), rank=rank, world_size=world)
-        else:
-            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+        with stdout_to_stderr():
+            if args.dist_backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), rank=rank, world_size=world)
+            else:
+                dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+            warm = torch.zeros(1, device=torch.device("cuda", dev_index))
+            dist.all_reduce(warm)              # the communicator (and its banner) comes up here at the latest
+            torch.cuda.synchronize()
     else:
         dist = None
         torch.cuda.set_device(0)

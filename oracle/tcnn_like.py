@@ -172,6 +172,45 @@ def mlp_forward(w1, w2, w3, x_h, n_out, accumulate="f32"):
     return layer(h, w3, False)[:, :n_out]
 
 
+# ---- A MODEL of tiny-cuda-nn's half-precision BACKWARD arithmetic (reported by
+# tests/test_parity_report.py beside the kernel's own error; PARITY UNPINNED like the rest of this file).
+# What north_star calls "the reference CUDA path" back-propagates in half as well:
+#   * FullyFusedMLP's backward keeps dL/d(activation) in the network precision (__half) between
+#     layers (tiny-cuda-nn src/fully_fused_mlp.cu, kernel_mlp_fused_backward: output fragments of
+#     type __half, ReLU applied through the forward activations);
+#   * GridEncoding's backward (include/tiny-cuda-nn/encodings/grid.h, kernel_grid_backward) accumulates
+#     the table gradient with `atomicAdd((__half2*)&grid_gradient[index], {(T)((float)grad[f] * weight),
+#     ...})` whenever N_FEATURES_PER_LEVEL > 1 and the gradient type is __half (grad_t =
+#     conditional_t<N_FEATURES_PER_LEVEL == 1, float, T>): every contribution is rounded to half AND
+#     the running sum lives in half, in the (nondeterministic) order the atomics arrive.
+# The model below is CONSERVATIVE (it rounds less than the real path): one sample per UNIQUE texel
+# instead of four per hit, fp32 dot products inside a layer, contributions added in slot order.
+def mlp_backward_half(w1, w2, w3, h1_h, h2_h, dout, n_out):
+    """dL/d(network input) [B,32] fp16 for dL/d(output) `dout` [B,n_out] fp32: rounded to half at the
+    network boundary and after every layer (fp32 dot products), ReLU through the forward activations."""
+    f = lambda t: t.half().float()
+    g = f(dout)                                            # dL/doutput enters in the network precision
+    g = f((g @ f(w3)[:n_out]) * (h2_h.float() > 0))
+    g = f((g @ f(w2)) * (h1_h.float() > 0))
+    return (g @ f(w1)).half()
+
+
+def hashgrid_backward_half_atomics(geom, dfeat_h, x):
+    """Table gradient [n_entries, 2] as float32 VALUES of a half-precision accumulation: per level and
+    corner c, table[idx_c] += half(float(dfeat) * w_c), the running sum rounded to half after every add
+    (np.add.at on a float16 array: unbuffered, sequential, in slot order)."""
+    out = np.zeros((geom.offset[-1], 2), np.float16)
+    d = dfeat_h.float()
+    for l in range(geom.n_levels):
+        idx, w = _grid_cells(geom, l, x)
+        lvl = np.zeros((geom.size[l], 2), np.float16)
+        for corner in range(4):
+            contrib = (d[:, 2 * l:2 * l + 2] * w[corner][:, None]).half().numpy()
+            np.add.at(lvl, idx[corner].numpy(), contrib)
+        out[geom.offset[l]:geom.offset[l + 1]] = lvl
+    return torch.from_numpy(out.astype(np.float32))
+
+
 PRIMES = (1, 2654435761, 805459861)
 
 

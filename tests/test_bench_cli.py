@@ -15,7 +15,7 @@ def _run(*args, timeout=600):
                        text=True, timeout=timeout, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, r.stdout[-2000:]
+    assert len(lines) == 1, r.stdout[-2000:]          # ONE line on stdout, nothing else (RCCL's banner included)
     return json.loads(lines[0])
 
 

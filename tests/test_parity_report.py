@@ -219,6 +219,7 @@ def test_order_matched_rgb_and_f32_gradients(K, subdiv, res, noise):
                 q_of[x] = q_ref
 
     # ---- B2 + C: the reference's op sequence from there on, fp32 autograd, forward values pinned
+    net_state = {}
     surfs_rgb = torch.zeros(N, K, 3)
     surfs_alpha = torch.zeros(N, K)
     for s in range(K):
@@ -240,10 +241,12 @@ def test_order_matched_rgb_and_f32_gradients(K, subdiv, res, noise):
                 # network at the touched texel centres (once per slot == 4x per hit, same function)
                 F = _pin(_grid_f32(geom, table, slot_xy[a:b]),
                          feats[typ, :, a:b].permute(1, 0, 2).reshape(-1, 32).float())
-                h = _ste_half(torch.relu(F @ w1.t()))
-                h = _ste_half(torch.relu(h @ w2.t()))
+                h1 = _ste_half(torch.relu(F @ w1.t()))
+                h = _ste_half(torch.relu(h1 @ w2.t()))
                 base = 0 if typ == 0 else 24
                 p = _pin((h @ w3.t())[:, :C], pre[a:b, base:base + C].float())
+                p.retain_grad()
+                net_state[x] = (h1.detach(), h.detach(), p, C, a, b)
                 o = torch.sigmoid(p)                                     # neural_texture.py:162
                 o = _pin(o, q_of[x].float() / 255.0)                     # x255, round_ste, /255 (:166-169)
                 o = _ste_half(o)                                         # :177
@@ -329,6 +332,22 @@ def test_order_matched_rgb_and_f32_gradients(K, subdiv, res, noise):
         cw = torch.nn.functional.cosine_similarity(gw[x], ref_w, dim=0)
         ct = torch.nn.functional.cosine_similarity(gt[x].flatten(), table.grad.flatten(), dim=0)
         assert cw > 0.9999 and ct > 0.9999, (x, float(cw), float(ct))
+    # ---- the same comparison for a MODEL of the reference CUDA path's own arithmetic (tiny-cuda-nn
+    # back-propagates in half and accumulates the table gradient with half2 atomics:
+    # oracle/tcnn_like.py mlp_backward_half / hashgrid_backward_half_atomics, a conservative model).
+    # north_star's "1e-3 on grads vs the reference CUDA path" cannot be tighter than the distance of
+    # that path's own arithmetic from exact arithmetic: where the kernel's tail exceeds 1e-3 (K = 7),
+    # the bound is justified by showing the model's tail is larger (VERDICT r3 next #1b).
+    rel_m = []
+    for x, (table, w1, w2, w3) in leaves.items():
+        h1, h2, p, C, a, b = net_state[x]
+        dX = tcnn_like.mlp_backward_half(w1.detach(), w2.detach(), w3.detach(), h1, h2,
+                                         p.grad * pipe.grad_scale, C)
+        gm = tcnn_like.hashgrid_backward_half_atomics(geom, dX, slot_xy[a:b]) / pipe.grad_scale
+        rel_m.append(((gm - table.grad).abs() / table.grad.abs().max()).flatten().numpy())
+    rel_m = np.concatenate(rel_m)
+    rep["tcnn_half_backward_model_tables_err_rel_to_tensor_max"] = _pcts(rel_m)
+    rep["tcnn_half_backward_model_tables_frac_over_1e-3"] = float((rel_m > 1e-3).mean())
     rep["grad_weights_err_rel_to_tensor_max"] = _pcts(np.concatenate(rel_w))
     rep["grad_tables_err_rel_to_tensor_max"] = _pcts(np.concatenate(rel_t))
     rep["grad_tables_worst_err_per_level"] = [float(x) for x in lvl_worst]
@@ -347,6 +366,16 @@ def test_order_matched_rgb_and_f32_gradients(K, subdiv, res, noise):
     # tiny-cuda-nn's backward rounds to half at the same places.  Bounds: north_star's where it is
     # met, 2x the measured value where it is not.
     assert rep["grad_weights_err_rel_to_tensor_max"]["max"] <= 1e-3
-    assert rep["grad_tables_err_rel_to_tensor_max"]["max"] <= (1e-3 if K <= 5 else 4.4e-3)
+    model = rep["tcnn_half_backward_model_tables_err_rel_to_tensor_max"]
+    if K <= 5:
+        assert rep["grad_tables_err_rel_to_tensor_max"]["max"] <= 1e-3          # north_star, every entry
+    else:
+        # K = 7: 7 of 11 M entries exceed 1e-3 (max 2.2e-3).  Justified by the reference path's own
+        # arithmetic, not by "2x measured": the half-atomics model's worst entry and its share of entries
+        # over 1e-3 must both be LARGER than the kernel's (measured: see profiles/r04/parity_report.json)
+        assert rep["grad_tables_err_rel_to_tensor_max"]["max"] <= min(4.4e-3, model["max"])
+        assert rep["grad_tables_frac_over_1e-3"] <= min(2e-6, rep["tcnn_half_backward_model_tables_frac_over_1e-3"])
+    assert model["max"] > rep["grad_tables_err_rel_to_tensor_max"]["max"]
+    assert model["p99"] > rep["grad_tables_err_rel_to_tensor_max"]["p99"]
     assert rep["grad_tables_frac_over_1e-3"] <= 2e-6
     assert rep["grad_tables_err_rel_to_tensor_max"]["p99"] <= 1e-4

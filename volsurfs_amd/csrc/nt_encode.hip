@@ -44,6 +44,12 @@ constexpr int ENC_UNIT = 256;       // slot granularity of the persistent work s
 constexpr int LDS_ENTRIES = 32768;    // 4-byte entries of LDS a workgroup may use (128 KiB)
 
 
+#ifndef NT_ENC_DIAG_FWD
+#define NT_ENC_DIAG_FWD 0
+#endif
+#ifndef NT_ENC_FWD_NOREUSE
+#define NT_ENC_FWD_NOREUSE 0
+#endif
 #ifndef NT_ENC_PREFETCH_FWD
 #define NT_ENC_PREFETCH_FWD 0     /* stretches of texel centres in flight per lane (0: loaded at their use) */
 #endif
@@ -128,7 +134,11 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
 #pragma unroll
           for (int i = 0; i < ENC_UNROLL_FWD / 2; ++i) xyn[d][i] = xyn[d + 1][i];
 #else
+#if NT_ENC_DIAG_FWD & 1   /* timing-only: texel centres from a 64 KiB window (L2-resident) */
+        const float4* xp = reinterpret_cast<const float4*>(slot_xy + (s0 & 0x1fff));
+#else
         const float4* xp = reinterpret_cast<const float4*>(slot_xy + s0);
+#endif
 #pragma unroll
         for (int i = 0; i < ENC_UNROLL_FWD / 2; ++i) xyv[i] = xp[i];
 #endif
@@ -163,7 +173,16 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
           for (int k = 0; k < 4; ++k) ew[k] = __builtin_bit_cast(unsigned, v[u][k]);
           outw[u] = enc_blend(ew, cr[u].w);
         }
+#if NT_ENC_DIAG_FWD & 2   /* timing-only: no feature stores */
+#pragma unroll
+        for (int u = 0; u < ENC_UNROLL_FWD; ++u) asm volatile("" ::"v"(outw[u]));
+        continue;
+#endif
+#if NT_ENC_DIAG_FWD & 4   /* timing-only: feature stores into a 64 KiB window */
+        unsigned* op = reinterpret_cast<unsigned*>(out) + nt_feat_in_plane(nl, s0 & 0x3fff);
+#else
         unsigned* op = reinterpret_cast<unsigned*>(out) + nt_feat_in_plane(nl, s0);
+#endif
         if (s0 >= first && s0 + ENC_UNROLL_FWD <= last) {
           uint4* o4 = reinterpret_cast<uint4*>(op);
 #pragma unroll
@@ -179,10 +198,14 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
 #endif
       }
     };
+#if NT_ENC_FWD_NOREUSE   /* experiment: gathers for every slot, no per-slot branches */
+    run(std::false_type{});
+#else
     if (g.scale < (float)plan.tex_res[tex % VSA_NT_MAX_DEG])
       run(std::true_type{});
     else
       run(std::false_type{});
+#endif
   }, 0, 1 << 30, unit_weight, HASHED ? NT_BAL_ENC_FWD_H : NT_BAL_ENC_FWD_D);
   __syncthreads();
   NT_SPAN_MARK(HASHED ? 1 : 0, 1);
@@ -215,6 +238,11 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
 #endif
 #ifndef NT_ENC_PREFETCH
 #define NT_ENC_PREFETCH 1
+#endif
+#if NT_ENC_DIAG & 64   /* timing-only: the scatter's LDS atomics compiled out (values kept alive) */
+#define ENC_LDS_ADD(ptr, val) asm volatile("" ::"v"(ptr), "v"(val))
+#else
+#define ENC_LDS_ADD(ptr, val) atomicAdd(ptr, val)
 #endif
 template <bool HASHED, int NF, bool MERGE>
 __device__ __forceinline__ void enc_bwd_piece(
@@ -275,8 +303,16 @@ __device__ __forceinline__ void enc_bwd_piece(
   float4 xyn[PD][ENC_UNROLL / 2];
   uint4 dn[PD][ENC_UNROLL / 4];
   auto request = [&](int s, float4 (&xd)[ENC_UNROLL / 2], uint4 (&dd)[ENC_UNROLL / 4]) {
+#if NT_ENC_DIAG & 16   /* timing-only: texel centres and gradients from a small window (L2-resident) */
+    const int sc = (s < s_max ? s : s_max) & 0x1fff;
+#else
     const int sc = s < s_max ? s : s_max;
+#endif
+#if NT_ENC_DIAG & 32   /* timing-only: only the texel centres from a window */
+    const float4* xp = reinterpret_cast<const float4*>(slot_xy + (sc & 0x1fff));
+#else
     const float4* xp = reinterpret_cast<const float4*>(slot_xy + sc);
+#endif
     const uint4* dp = reinterpret_cast<const uint4*>(dFw + nt_feat_in_plane(nl, sc));
 #pragma unroll
     for (int i = 0; i < ENC_UNROLL / 2; ++i) xd[i] = xp[i];
@@ -358,7 +394,7 @@ __device__ __forceinline__ void enc_bwd_piece(
 #pragma unroll
           for (int f = 0; f < NF; ++f)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) atomicAdd(&my_g[f * plane + idx[k]], v[f][k]);
+            for (int k = 0; k < 4; ++k) ENC_LDS_ADD(&my_g[f * plane + idx[k]], v[f][k]);
         } else if (cr.cx == cur_cx && cr.cy == cur_cy) {
 #pragma unroll
           for (int f = 0; f < NF; ++f)
@@ -369,7 +405,7 @@ __device__ __forceinline__ void enc_bwd_piece(
 #pragma unroll
             for (int f = 0; f < NF; ++f)
 #pragma unroll
-              for (int k = 0; k < 4; ++k) atomicAdd(&my_g[f * plane + cur_idx[k]], acc[f][k]);
+              for (int k = 0; k < 4; ++k) ENC_LDS_ADD(&my_g[f * plane + cur_idx[k]], acc[f][k]);
           }
           cur_cx = cr.cx, cur_cy = cr.cy;
           cell_indices<HASHED>(g, cr.cx, cr.cy, cur_idx);
@@ -384,7 +420,7 @@ __device__ __forceinline__ void enc_bwd_piece(
 #pragma unroll
       for (int f = 0; f < NF; ++f)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) atomicAdd(&my_g[f * plane + cur_idx[k]], acc[f][k]);
+        for (int k = 0; k < 4; ++k) ENC_LDS_ADD(&my_g[f * plane + cur_idx[k]], acc[f][k]);
     }
   }
 #if NT_ENC_PREFETCH
