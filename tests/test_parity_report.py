@@ -57,6 +57,9 @@ def _emit(tag, rep):
 CASES = [(3, 3, 56, 0.0), (1, 3, 64, 0.0), (5, 4, 128, 0.05), (7, 4, 128, 0.05)]
 
 
+INDEP_GRAD_MAX = {1: 8.1e-4, 3: 4.0e-3, 5: 1.7e-2, 7: 7.8e-2}      # 2x measured, per shell count
+
+
 def _pipe(K, subdiv, res, seed=5, noise=0.0):
     from volsurfs_amd.camera import pinhole_rays
     from volsurfs_amd.mesh import nested_shells
@@ -141,6 +144,12 @@ def test_parity_report_vs_independent_oracle(K, subdiv, res, noise):
     assert rep["rgb_abs_err"]["p99"] == 0.0 and rep["rgb_abs_err"]["max"] <= 1e-2      # measured <= 4.9e-3
     assert rep["rgb_frac_over_1e-4"] <= 2e-3
     assert rep["grad_err_rel_to_tensor_max"]["p99"] < 1e-2
+    # ... and the MAXIMUM, at 2x the measured value of each case (VERDICT r3 next #1c).  These bounds are
+    # loose because THIS oracle's gradients are the reference's own fp16 autograd (with the reference's
+    # loss scale of 128), noisy itself: measured max 4.0e-4 / 2.0e-3 / 8.5e-3 / 3.9e-2 at K = 1 / 3 / 5 /
+    # 7 (profiles/r03/parity_report.json).  The tight gradient bound (1e-3 of each tensor's largest entry,
+    # every element) is asserted against the fp32 oracle in test_order_matched_rgb_and_f32_gradients.
+    assert rep["grad_err_rel_to_tensor_max"]["max"] <= INDEP_GRAD_MAX[K], rep["grad_err_rel_to_tensor_max"]
 
 
 def _ste_half(x):

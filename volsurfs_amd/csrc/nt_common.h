@@ -228,11 +228,24 @@ __device__ __forceinline__ int nt_wave_incl_scan(int v) {
 // segment once (two vector loads per pass), the plane costs are wave sums, a texture's position in
 // a plane is a wave prefix sum, and the few textures that overlap the workgroup's stretch are
 // picked off a ballot.  Same axis, same integer arithmetic, same pieces.
+// paired = true (<= 64 textures only): a piece is a (shell, degree) PAIR — the colour and the alpha
+// texture of one shell and degree share their slots, texel centres, grid cells and corner weights
+// (models/sh_neural_textures.py:41-60: one resolution per degree for both), so the dense-level encode
+// kernels form cell, indices and weights once and gather / blend twice.  The pair is carried by the
+// lane of its colour texture (by the alpha texture's where the colour texture is inactive); its
+// weight is wt(plane, degree, 2) when both textures are active.  body() receives the carrying
+// texture; nt_pair_partner() tells whether (and which) second texture rides along.
+__device__ __forceinline__ int nt_pair_partner(const vsa_nt_plan& p, int tex) {
+  const int other = tex ^ VSA_NT_MAX_DEG;          // same shell and degree, the other type
+  return ((tex / VSA_NT_MAX_DEG) & 1) == 0 && tex_active(p, other) ? other : -1;
+}
+
 template <int UNIT, typename Body, typename Weight = NtUnitWeight16>
 __device__ __forceinline__ void nt_for_each_piece(const vsa_nt_plan& plan,
                                                   const int* __restrict__ seg_start, int n_planes,
                                                   int ovh, Body&& body, int tex_begin = 0,
-                                                  int tex_end = 1 << 30, Weight wt = Weight(), int bal_id = -1) {
+                                                  int tex_end = 1 << 30, Weight wt = Weight(), int bal_id = -1,
+                                                  bool paired = false) {
   const int n_all = plan.nr_shells * 2 * VSA_NT_MAX_DEG;
   if (n_all > 64) {
     nt_for_each_piece_scalar<UNIT>(plan, seg_start, n_planes, ovh, body, tex_begin, tex_end, wt, bal_id);
@@ -247,6 +260,12 @@ __device__ __forceinline__ void nt_for_each_piece(const vsa_nt_plan& plan,
   const bool solid0 = plan.inner_solid != 0;
   bool act = tex >= tex_begin && tex < n_tex &&
              (type == 0 ? deg < rgb_deg : (!(solid0 && shell == 0) && deg < alpha_deg));
+  int wtype = type;
+  if (paired) {
+    const bool rgb_act = deg < rgb_deg, alpha_act = !(solid0 && shell == 0) && deg < alpha_deg;
+    if (type == 1 && rgb_act) act = false;            // rides along with its colour texture
+    if (type == 0 && act && alpha_act) wtype = 2;     // a pair
+  }
   const int sd = shell * VSA_NT_MAX_DEG + deg;
   int begin = 0, end = 0;
   if (act) {
@@ -259,7 +278,7 @@ __device__ __forceinline__ void nt_for_each_piece(const vsa_nt_plan& plan,
   const long long pieces = __popcll(act_mask);
   if (pieces == 0) return;
   // a texture's cost in plane pl (1/16 units; < 2^31: at most 64 textures x (a few million slots / UNIT) x 16)
-  auto lane_cost = [&](int pl) { return act ? ovh * 16 + units * wt(pl, deg, type) : 0; };
+  auto lane_cost = [&](int pl) { return act ? ovh * 16 + units * wt(pl, deg, wtype) : 0; };
   auto plane_cost = [&](int pl) -> long long {
     return (long long)(unsigned)__builtin_amdgcn_readlane(nt_wave_incl_scan(lane_cost(pl)), 63);
   };
@@ -279,7 +298,7 @@ __device__ __forceinline__ void nt_for_each_piece(const vsa_nt_plan& plan,
     }
     // lane's texture occupies [t0, t0 + ovh*16 + units*w) of the axis; its units start at t0 + ovh*16
     const long long t0l = c0 + (long long)(incl - cl) + (long long)ovh * 16;
-    const int w = wt(pl, deg, type);
+    const int w = wt(pl, deg, wtype);
     const long long span = (long long)units * w;
     // the same tests as the scalar walk: t0 < hi, and [max(lo - t0, 0), min(hi - t0, span)) non-empty in whole units
     bool hit = act && t0l < hi;

@@ -175,6 +175,25 @@ __device__ __forceinline__ CellCorners cell_corners(const LevelGeom& g, float x,
 #ifndef NT_ENC_ACC_F16
 #define NT_ENC_ACC_F16 1
 #endif
+#if NT_ENC_ACC_F16
+// The blend in two steps, for callers that blend SEVERAL tables with one set of corner weights (the
+// colour and the alpha texture of a (shell, degree) pair): the four weights rounded to half once ...
+__device__ __forceinline__ void enc_weights_h(const float w[4], half2_t wh[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const _Float16 h = (_Float16)vsa_pin_f32(w[k]);     // (pinned: see enc_blend)
+    wh[k] = half2_t{h, h};
+  }
+}
+// ... and the four packed half FMAs per table (same operations, same order as enc_blend)
+__device__ __forceinline__ unsigned enc_blend_h(const unsigned e[4], const half2_t wh[4]) {
+  half2_t acc = {(_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc = __builtin_elementwise_fma(wh[k], __builtin_bit_cast(half2_t, e[k]), acc);
+  return __builtin_bit_cast(unsigned, acc);
+}
+#endif
+
 __device__ __forceinline__ unsigned enc_blend(const unsigned e[4], const float w[4]) {
 #if NT_ENC_ACC_F16
   half2_t acc = {(_Float16)0.f, (_Float16)0.f};

@@ -34,6 +34,9 @@ namespace {
 #ifndef NT_ENC_OVH_BD
 #define NT_ENC_OVH_BD 64
 #endif
+#ifndef NT_ENC_PAIR_W
+#define NT_ENC_PAIR_W 22       /* cost of a (colour, alpha) pair unit in 1/16 of a single texture's (forward, dense) */
+#endif
 constexpr int ENC_BLOCK = 1024;     // 16 waves: a 128 KiB level pins one workgroup per CU
 constexpr int ENC_UNROLL = 8;       // slots in flight per lane (backward)
 #ifndef ENC_UNROLL_FWD_N
@@ -53,6 +56,11 @@ constexpr int LDS_ENTRIES = 32768;    // 4-byte entries of LDS a workgroup may u
 #ifndef NT_ENC_PREFETCH_FWD
 #define NT_ENC_PREFETCH_FWD 0     /* stretches of texel centres in flight per lane (0: loaded at their use) */
 #endif
+#ifndef NT_ENC_PAIR_DENSE
+#define NT_ENC_PAIR_DENSE 1      /* dense levels: colour + alpha texture of a (shell, degree) in ONE piece (shared cell / weights) */
+#endif
+constexpr int ENC_PAIR_OFF = 15360;   // entries: the second table of a pair sits at a FIXED LDS offset (61 440 B: an
+                                      // immediate of the gathers); the largest dense level has 15 136 entries
 template <bool HASHED>
 __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
     vsa_nt_plan plan, int level0, int n_levels, const half2_t* __restrict__ tables,
@@ -64,26 +72,30 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
   const int nl = plan.n_levels;
   NT_SPAN_MARK(HASHED ? 1 : 0, 0);
   NT_BAL_BEGIN();
+  // dense levels: pieces are (shell, degree) pairs (nt_for_each_piece, paired) — both tables in LDS
+  const bool pair_mode = !HASHED && NT_ENC_PAIR_DENSE && NT_ENC_ACC_F16 && !NT_ENC_PREFETCH_FWD &&
+                         plan.nr_shells * 2 * VSA_NT_MAX_DEG <= 64;
   // per-piece overheads and unit weights: fitted from per-workgroup timings (tools/fit_cost.py):
   // a piece costs 87 (hashed: a 128 KiB table to stage) / 27 (dense) units of 256 slots, and a
   // unit of a level finer than the texture (no reuse of the previous slot's cell) 0.92 of one
-  // that goes through the reuse bookkeeping
-  auto unit_weight = [&](int pl, int deg, int) {
-    return !HASHED || plan.level_scale[level0 + pl] < (float)plan.tex_res[deg] ? 16 : 15;
+  // that goes through the reuse bookkeeping; a pair costs NT_ENC_PAIR_W / 16 of one texture
+  auto unit_weight = [&](int pl, int deg, int wtype) {
+    const int w = !HASHED || plan.level_scale[level0 + pl] < (float)plan.tex_res[deg] ? 16 : 15;
+    return wtype == 2 ? (w * NT_ENC_PAIR_W) >> 4 : w;
   };
   nt_for_each_piece<ENC_UNIT>(plan, seg_start, n_levels, HASHED ? NT_ENC_OVH_FH : NT_ENC_OVH_FD,
                               [&](int pl, int tex, int first, int last, int, int) {
     const int level = level0 + pl;
     const LevelGeom g = level_geom(plan, level);
-    const half2_t* tab = tables + (long long)tex * n_entries + plan.level_offset[level];
+    const int tex2 = pair_mode ? nt_pair_partner(plan, tex) : -1;
     __syncthreads();   // the previous piece is done with the table
-    {  // stage the level (size is a multiple of 8 entries = 32 B)
+    auto stage = [&](int t, half2_t* dst_h) {  // stage the level (size is a multiple of 8 entries = 32 B)
       // all of a thread's loads in flight together (a 2^15-entry level is 8 x 16 B per thread; one
       // load, wait, store per trip made staging eight memory latencies long).  Native vectors and
       // an unconditional (clamped) fill: HIP's uint4 struct, or a predicated fill, sends r[] to scratch.
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-      const u32x4* src = reinterpret_cast<const u32x4*>(tab);
-      u32x4* dst = reinterpret_cast<u32x4*>(s_tab);
+      const u32x4* src = reinterpret_cast<const u32x4*>(tables + (long long)t * n_entries + plan.level_offset[level]);
+      u32x4* dst = reinterpret_cast<u32x4*>(dst_h);
       constexpr int SB = 8;
       const int nvec = (int)(g.size / 4);
       for (int i0 = threadIdx.x; i0 < nvec; i0 += ENC_BLOCK * SB) {
@@ -97,18 +109,23 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
         for (int k = 0; k < SB; ++k)
           if (i0 + k * ENC_BLOCK < nvec) dst[i0 + k * ENC_BLOCK] = r[k];
       }
-    }
+    };
+    stage(tex, s_tab);
+    if (tex2 >= 0) stage(tex2, s_tab + ENC_PAIR_OFF);
     __syncthreads();
     const int type = (tex / VSA_NT_MAX_DEG) & 1;
     half2_t* out = features + nt_feat_plane_base(plan, type, level);
+    half2_t* out2 = features + nt_feat_plane_base(plan, 1, level);      // the alpha plane of a pair
     // A lane owns ENC_UNROLL_FWD consecutive slots (neighbouring texels of one texture
     // row): 32 B of texel centres in, 16 B of features out per lane as dwordx4 accesses.
     // REUSE (levels coarser than the texture): the 4 LDS gathers are skipped while
     // consecutive slots stay in one grid cell; at finer levels that never happens and the
     // bookkeeping (11 moves + 3 branches per slot in the ISA) is left out.
+    // PAIR: cell, corner indices and the half-rounded corner weights once, gathers + blend per table.
     const int a_first = first & ~(ENC_UNROLL_FWD - 1);
-    auto run = [&](auto reuse_tag) {
+    auto run = [&](auto reuse_tag, auto pair_tag) {
       constexpr bool REUSE = decltype(reuse_tag)::value;
+      constexpr bool PAIR = decltype(pair_tag)::value;
 #if NT_ENC_PREFETCH_FWD
       // NT_ENC_PREFETCH_FWD stretches of texel centres are in flight per lane, requested AFTER the
       // stores of the stretch that is being finished: the wait at the head of a trip then never
@@ -151,7 +168,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
           cr[u] = cell_ref_s(g, x, y);
           fresh[u] = !REUSE || u == 0 || cr[u].cx != cr[u - 1].cx || cr[u].cy != cr[u - 1].cy;
         }
-        half2_t v[ENC_UNROLL_FWD][4];
+        half2_t v[ENC_UNROLL_FWD][4], v2[PAIR ? ENC_UNROLL_FWD : 1][4];
 #pragma unroll
         for (int u = 0; u < ENC_UNROLL_FWD; ++u) {
           if (fresh[u]) {
@@ -159,19 +176,39 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
             cell_indices<HASHED>(g, cr[u].cx, cr[u].cy, idx);
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[u][k] = s_tab[idx[k]];
+            if constexpr (PAIR) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) v2[u][k] = s_tab[idx[k] + ENC_PAIR_OFF];
+            }
           }
         }
-        unsigned outw[ENC_UNROLL_FWD];
+        unsigned outw[ENC_UNROLL_FWD], outw2[PAIR ? ENC_UNROLL_FWD : 1];
 #pragma unroll
         for (int u = 0; u < ENC_UNROLL_FWD; ++u) {
           if (REUSE && u > 0 && !fresh[u]) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[u][k] = v[u - 1][k];
+            if constexpr (PAIR) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) v2[u][k] = v2[u - 1][k];
+            }
           }
           unsigned ew[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) ew[k] = __builtin_bit_cast(unsigned, v[u][k]);
-          outw[u] = enc_blend(ew, cr[u].w);
+#if NT_ENC_ACC_F16
+          if constexpr (PAIR) {
+            half2_t wh[4];
+            enc_weights_h(cr[u].w, wh);
+            outw[u] = enc_blend_h(ew, wh);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ew[k] = __builtin_bit_cast(unsigned, v2[u][k]);
+            outw2[u] = enc_blend_h(ew, wh);
+          } else
+#endif
+          {
+            outw[u] = enc_blend(ew, cr[u].w);
+          }
         }
 #if NT_ENC_DIAG_FWD & 2   /* timing-only: no feature stores */
 #pragma unroll
@@ -179,34 +216,45 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
         continue;
 #endif
 #if NT_ENC_DIAG_FWD & 4   /* timing-only: feature stores into a 64 KiB window */
-        unsigned* op = reinterpret_cast<unsigned*>(out) + nt_feat_in_plane(nl, s0 & 0x3fff);
+        const long long o_in = nt_feat_in_plane(nl, s0 & 0x3fff);
 #else
-        unsigned* op = reinterpret_cast<unsigned*>(out) + nt_feat_in_plane(nl, s0);
+        const long long o_in = nt_feat_in_plane(nl, s0);
 #endif
+        unsigned* op = reinterpret_cast<unsigned*>(out) + o_in;
+        unsigned* op2 = reinterpret_cast<unsigned*>(out2) + o_in;
         if (s0 >= first && s0 + ENC_UNROLL_FWD <= last) {
           uint4* o4 = reinterpret_cast<uint4*>(op);
 #pragma unroll
           for (int i = 0; i < ENC_UNROLL_FWD / 4; ++i)
             o4[i] = make_uint4(outw[4 * i], outw[4 * i + 1], outw[4 * i + 2], outw[4 * i + 3]);
+          if constexpr (PAIR) {
+            uint4* p4 = reinterpret_cast<uint4*>(op2);
+#pragma unroll
+            for (int i = 0; i < ENC_UNROLL_FWD / 4; ++i)
+              p4[i] = make_uint4(outw2[4 * i], outw2[4 * i + 1], outw2[4 * i + 2], outw2[4 * i + 3]);
+          }
         } else {
 #pragma unroll
           for (int u = 0; u < ENC_UNROLL_FWD; ++u)
-            if (s0 + u >= first && s0 + u < last) op[u] = outw[u];
+            if (s0 + u >= first && s0 + u < last) {
+              op[u] = outw[u];
+              if constexpr (PAIR) op2[u] = outw2[u];
+            }
         }
 #if NT_ENC_PREFETCH_FWD
         request(s0 + PD * ENC_BLOCK * ENC_UNROLL_FWD, xyn[PD - 1]);
 #endif
       }
     };
-#if NT_ENC_FWD_NOREUSE   /* experiment: gathers for every slot, no per-slot branches */
-    run(std::false_type{});
-#else
-    if (g.scale < (float)plan.tex_res[tex % VSA_NT_MAX_DEG])
-      run(std::true_type{});
-    else
-      run(std::false_type{});
-#endif
-  }, 0, 1 << 30, unit_weight, HASHED ? NT_BAL_ENC_FWD_H : NT_BAL_ENC_FWD_D);
+    const bool reuse = !NT_ENC_FWD_NOREUSE && g.scale < (float)plan.tex_res[tex % VSA_NT_MAX_DEG];
+    if (!HASHED && tex2 >= 0) {
+      if (reuse) run(std::true_type{}, std::true_type{});
+      else run(std::false_type{}, std::true_type{});
+    } else {
+      if (reuse) run(std::true_type{}, std::false_type{});
+      else run(std::false_type{}, std::false_type{});
+    }
+  }, 0, 1 << 30, unit_weight, HASHED ? NT_BAL_ENC_FWD_H : NT_BAL_ENC_FWD_D, pair_mode);
   __syncthreads();
   NT_SPAN_MARK(HASHED ? 1 : 0, 1);
   NT_BAL_END(HASHED ? NT_BAL_ENC_FWD_H : NT_BAL_ENC_FWD_D);
@@ -232,6 +280,9 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
 // shares the loads, the cell arithmetic and the indices between the features.
 #ifndef NT_ENC_DIAG
 #define NT_ENC_DIAG 0
+#endif
+#ifndef NT_ENC_FLUSH_ATOMIC
+#define NT_ENC_FLUSH_ATOMIC 1     /* every flush through no-return float atomics: no read-modify-write round trip (r4: bwd 0.626 -> 0.607 ms) */
 #endif
 #ifndef NT_ENC_FLUSH_BATCH
 #define NT_ENC_FLUSH_BATCH 8     /* table entries per thread whose read-modify-write is in flight together (0: one at a time) */
@@ -543,7 +594,13 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
       ++level;
       both = enc_both_features(plan, level, HASHED);
     }
+#if NT_ENC_FLUSH_ATOMIC   /* every flush through no-return float atomics: fire and forget, where the sole-writer form
+                            waits for a batch of table entries to come back before it can add and store them.
+                            A sole writer adds exactly once per entry, so its result is the same old + v either way */
+    const bool single = false;
+#else
     const bool single = first == seg_begin && last == seg_end;
+#endif
     // neighbouring texels are scale / R cells apart: from one cell per texel on, the
     // in-register merging of same-cell slots cannot fire and its bookkeeping is skipped
     const bool merge = plan.level_scale[level] < (float)plan.tex_res[tex % VSA_NT_MAX_DEG];
