@@ -76,3 +76,26 @@ def hit_attributes(verts, faces, rays_o, rays_d, hit):
         "normals": normals.astype(np.float32),
         "barycentric": bary.astype(np.float32),
     }
+
+
+def count_crossings(verts, faces, rays_o, rays_d, t_min=0.0):
+    """Number of triangles of the mesh each ray crosses (Moeller-Trumbore on every pair, numpy;
+    for small ray sets): how non-convex a shell is along the camera's rays — tests of the stress
+    scene (mesh.stress_shells) assert that closest hit has to choose among > 2 crossings."""
+    v = np.asarray(verts, np.float64)
+    f = np.asarray(faces, np.int64)
+    v0, e1, e2 = v[f[:, 0]], v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]]
+    out = np.zeros(len(rays_o), np.int64)
+    for i in range(len(rays_o)):
+        o, d = np.asarray(rays_o[i], np.float64), np.asarray(rays_d[i], np.float64)
+        p = np.cross(d, e2)
+        det = (e1 * p).sum(1)
+        ok = np.abs(det) > 1e-14
+        inv = 1.0 / np.where(ok, det, 1.0)
+        t = o - v0
+        u = (t * p).sum(1) * inv
+        q = np.cross(t, e1)
+        w = (q * d).sum(1) * inv
+        tt = (q * e2).sum(1) * inv
+        out[i] = int((ok & (u >= 0) & (w >= 0) & (u + w <= 1) & (tt > t_min)).sum())
+    return out
