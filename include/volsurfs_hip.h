@@ -151,7 +151,7 @@ int vsa_trace_q(const uint32_t* qnodes, const float* tris, const int32_t* mesh_r
  * bound) to pass B, which walks one subtree per lane in dense persistent waves; pass C merges the
  * pieces of a ray (smallest t, ties -> smallest face id) and writes its hit record.  Why: a few
  * grazing rays per wave otherwise keep 4 % of the waves alive for 10x the median walk and leave the
- * chip draining for a third of the launch.  workspace: device memory, 16-byte
+ * chip draining for a third of the launch (profiles/NOTEBOOK.md A9.4).  workspace: device memory, 16-byte
  * aligned, >= 400 bytes, contents irrelevant on entry, not preserved;
  * vsa_trace_q_workspace_bytes(nr_rays, nr_meshes) (< 0 on bad arguments) is the recommended size
  * (room for a quarter of the (ray, shell) pairs); a hand-over that does not fit the workspace is not
@@ -168,7 +168,7 @@ int vsa_trace_q_budgeted(const uint32_t* qnodes, const float* tris, const int32_
  * natural order.  A wave's trips depend on its rays only, so for the same rays the prediction is
  * exact, and for a camera that moved a little it is close; for unrelated rays it is as good as any
  * order.  Why: the few waves that hold grazing rays walk 10-20x the median; dispatched late they leave
- * the chip draining for a third of the launch.  feedback: device memory, 16-byte
+ * the chip draining for a third of the launch (profiles/NOTEBOOK.md A9.4).  feedback: device memory, 16-byte
  * aligned, >= vsa_trace_feedback_bytes(nr_rays, nr_meshes) (< 0 on bad arguments), ZEROED by the
  * caller before its first use, then owned by this sequence of calls with the SAME feedback_bytes
  * (a buffer sized for more rays serves fewer: a half written for another item count is recognised
@@ -266,7 +266,7 @@ typedef struct vsa_nt_plan {
                                         launch's times (same pieces, same results: only who does which) */
 } vsa_nt_plan;
 
-/* Measured-time rebalancing of the persistent kernels' work split: once per frame,
+/* Measured-time rebalancing of the persistent kernels' work split (profiles/NOTEBOOK.md A9.0): once per frame,
  * before the first of them, turns the busy times the previous frame's launches stamped into
  * plan->balance into per-workgroup shares of each kernel's cost axis (a workgroup that took longer
  * than the mean gets a smaller share, damped).  No-op while nothing has been stamped. */

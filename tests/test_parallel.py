@@ -311,7 +311,7 @@ def _sharded_rank(rank, world, port, q):
 
 @pytest.mark.gpu
 def test_sharded_adam_equals_allreduce_adam():
-    """DESIGN.md 8 "reduce-scatter + sharded Adam": two ranks (gloo, one device), the real kernels.
+    """DESIGN.md §8 "reduce-scatter + sharded Adam": two ranks (gloo, one device), the real kernels.
     On given per-rank gradients the parameters, their f16 compute copies and the (gathered) fp32
     masters equal the all-reduce + full-Adam run bit for bit on both ranks; each rank holds moments
     for its half only; trained through the pipeline the two replicas stay one model."""

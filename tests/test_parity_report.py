@@ -68,7 +68,7 @@ def _pipe(K, subdiv, res, seed=5, noise=0.0):
     o, d = pinhole_rays(res, res, focal=1.6 * res, cam_pos=(0.0, 0.0, -1.5))
     gt = torch.rand(o.shape[0], 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(seed))
     pipe = KShellPipeline(meshes, o, d, gt, seed=seed, init="spread")      # ray order = caller's order
-    pipe.grad_scale *= float(os.environ.get("VSA_TEST_GRAD_SCALE_MULT", "1"))   # experiments (DESIGN.md 7)
+    pipe.grad_scale *= float(os.environ.get("VSA_TEST_GRAD_SCALE_MULT", "1"))   # experiments (DESIGN.md §6)
     return pipe
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Lists `s_waitcnt vmcnt(0)` instructions that sit INSIDE a loop which also issues stores or
-atomics — the compiler-placed drains DESIGN.md §9 keeps finding: no-return atomics and stores stay
+atomics — the compiler-placed drains profiles/NOTEBOOK.md A9 keeps finding: no-return atomics and stores stay
 counted in vmcnt until the memory side acknowledges them (1-3 k cycles), so such a wait stalls every
 trip for all of them, although it was only meant for a load issued before the loop.
 Usage: python tools/isa_drains.py [file.hip ...]   (default: every kernel source; compiles with

@@ -138,7 +138,7 @@ __device__ __forceinline__ const float* meta_bias(const LayerMeta& m, int l) {
 // ([s / 4][lane][s % 4]), so ONE ds_read_b128 (lanes 16 B apart: conflict-free) feeds four MFMAs instead
 // of a 4-byte ds_read per v_mfma_f32_32x32x2_f32 (1199 -> 271 narrow reads in the ISA).  Measured on
 // tools/bench_bg.py (one box, two runs each): fwd 881 / 873 us, dgrad 1189-1212 / 1186-1216 us - no
-// difference, so the issue stalls of DESIGN.md 9.5 are not the fragment reads; the k-step-major layout
+// difference, so the issue stalls of profiles/NOTEBOOK.md A9.5 are not the fragment reads; the k-step-major layout
 // of rounds 1-2 stays the default.
 #ifndef MLP_FRAG_B128
 #define MLP_FRAG_B128 0

@@ -69,7 +69,7 @@ constexpr int FU_BATCH = NT_FU_BATCH;
 // quads whatever its active lanes), VALU instructions 188 M -> 210 M, issue cycles +37 %, two
 // dependent waits per batch instead of one: 0.65 -> 0.85 ms.
 #ifndef NT_FU_STAGE
-#define NT_FU_STAGE 0     /* measured: see the comment above and DESIGN.md 9.1a */
+#define NT_FU_STAGE 0     /* measured: see the comment above and profiles/NOTEBOOK.md A9.1a */
 #endif
 typedef __attribute__((address_space(3))) void* fu_lds_vp;
 constexpr int FU_ROW_DWORDS = 256;                         // 64 blocks x 4 entries per staged row

@@ -177,7 +177,7 @@ __device__ __forceinline__ void prefetch_features(const vsa_nt_plan& plan,
 // The tile loops are compiled once per output width (producer: 1..4 groups of 8 channels,
 // consumer: 1 or 2 k-steps of dH2); each instance owns its accumulators and its epilogue.
 // Round-2 stamps (NT_STAMP, tools/wg_timeline.py; cycles per tile, producer | consumer work):
-// 5050 | 3880 before, 2740 | 3460 now — see DESIGN.md 9.1 for what moved and what it cost.
+// 5050 | 3880 before, 2740 | 3460 now — see profiles/NOTEBOOK.md A9.1 for what moved and what it cost.
 #ifndef NT_PC_DW3_CONSUMER
 #define NT_PC_DW3_CONSUMER 0    /* dW3: 0 producer, 1 consumer (from the finished images), 2 split by 32-column block */
 #endif
@@ -550,7 +550,7 @@ __device__ __forceinline__ void pc_run(
     else run_producer(std::integral_constant<int, 4>{});
   } else {
     // the consumer is the later-dispatched wave of its SIMD (the arbitration loser at equal
-    // priority): raise it once, statically (measured against the other assignments)
+    // priority): raise it once, statically (measured against the other assignments, profiles/NOTEBOOK.md A9.1)
 #if NT_PC_PRIO == 0
     __builtin_amdgcn_s_setprio(1);
 #endif

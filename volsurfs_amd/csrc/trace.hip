@@ -96,7 +96,7 @@ constexpr int TRACE_EMPTY = 0x7fffffff;
 // Diagnostic build only (tools/build_variant.sh span "-DTRACE_SPAN"; tools/trace_span.py): wall-clock
 // begin / end of every wave of trace_q_kernel and WAVE-level counts (an elected lane adds to LDS; a
 // per-lane variable would only count that lane's own trips): trips of the walk loop, lane visits, leaf
-// phases.  g_torder, when set, replaces the dispatch order (the launch-order experiments of DESIGN.md 9.4).
+// phases.  g_torder, when set, replaces the dispatch order (the launch-order experiments of profiles/NOTEBOOK.md A9.4).
 #ifdef TRACE_SPAN
 constexpr int TRACE_SPAN_WAVES = 1 << 17;
 static __device__ unsigned long long g_tspan[TRACE_SPAN_WAVES][3];
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void trace_qc_kernel(TraceWs ws, int N, float*
 }
 
 // ---- cost-feedback launch order (vsa_trace_q_fb).  The one-pass kernel's launch is full for its first
-// 155 us and then drains for 100 us (tools/trace_span.py): the waves that hold grazing rays
+// 155 us and then drains for 100 us (tools/trace_span.py, profiles/NOTEBOOK.md A9.4): the waves that hold grazing rays
 // walk 100-200 trips against a median of 9, and those that happen to be dispatched late are still walking
 // when everything else has finished.  With the heaviest waves dispatched FIRST (sorted by their measured
 // trips: the upper bound of any predictor) the same kernel takes 203 us instead of 300 with stamps.  A

@@ -27,7 +27,7 @@ WEIGHTS_PER_TEX = 8192
 # MI355X (profiles/r03): forward-only evaluation, where the 730 MB of feature planes are neither
 # written nor read, 1.30 -> 1.18 ms per 800x800 frame (+10.5 % Mrays/s); the training step, whose
 # backward needs the planes, 0.65 vs 0.61-0.64 ms and 1 043 vs 1 061 it/s — the vector cache's
-# look-up rate bounds the gathers.  Hence "auto": fused exactly when the feature
+# look-up rate bounds the gathers (profiles/NOTEBOOK.md A9.1a).  Hence "auto": fused exactly when the feature
 # planes are not needed.  VSA_NT_FUSED=1 / 0 force it on / off (A/B switch, tools/README).
 # work split of the persistent kernels corrected by the previous frame's measured workgroup times
 # (vsa_nt_rebalance; same results); "0" = the fitted cost model alone

@@ -154,7 +154,7 @@ class FusedAdam(torch.optim.Optimizer):
 
 class ShardedFusedAdam(FusedAdam):
     """Data-parallel Adam with the optimiser state and the update SHARDED over the ranks (ZeRO
-    stage 1) — DESIGN.md 8: instead of all-reducing 114 MB of fp32 texture gradients and running the
+    stage 1) — DESIGN.md §8: instead of all-reducing 114 MB of fp32 texture gradients and running the
     same Adam over all 28.7 M parameters on every rank,
 
       1. reduce-scatter the gradients: rank r receives the SUM of slice r of every tensor

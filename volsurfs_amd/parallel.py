@@ -59,7 +59,7 @@ class GradientOverlap:
 
     wire_dtype (opt-in, e.g. torch.bfloat16): the tensor is converted, reduced at that width and
     converted back in `wait()` — half the bytes on the xGMI ring (the 114 MB of fp32 texture
-    gradients are what bounds strong scaling, DESIGN §8) at the price of a bf16-rounded SUM
+    gradients are what bounds strong scaling, DESIGN.md §8) at the price of a bf16-rounded SUM
     (~2^-9 relative per hop); the default (None) reduces the fp32 tensors in place, exactly."""
 
     def __init__(self, world, group=None, wire_dtype=None, force=False):

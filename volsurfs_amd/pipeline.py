@@ -164,7 +164,7 @@ class KShellPipeline:
             "hits_per_frame": getattr(self, "last_hits", None),
             "unique_texels_per_frame": getattr(self, "last_slots", None),
             # the traversal's launch order comes from the previous frame's measured wave cost (same hits;
-            # VSA_TRACE_FEEDBACK=0 = the stateless launch: DESIGN.md 9.4)
+            # VSA_TRACE_FEEDBACK=0 = the stateless launch: profiles/NOTEBOOK.md A9.4)
             "trace_launch_order": "cost feedback from the previous frame (static camera: the previous frame has "
                                   "the same rays; value_cold is the figure without any inter-frame feedback)"
                                   if self.tracer.cost_feedback and

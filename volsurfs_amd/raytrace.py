@@ -29,7 +29,7 @@ class RayTracer:
         # q16 only: trips of the walk loop after which a wave hands its unfinished rays' subtrees to a
         # second pass (vsa_trace_q_budgeted; identical results).  0 = the one-pass kernel, the default:
         # measured at 800x800, K = 5: one pass 0.258 ms; budget 96 / 64 / 48 / 24: 0.256 / 0.287 / 0.354 /
-        # 0.818 ms (pass A loses its tail, 0.185 ms at 48, but a ray that has no hit yet
+        # 0.818 ms (profiles/NOTEBOOK.md A9.4: pass A loses its tail, 0.185 ms at 48, but a ray that has no hit yet
         # hands over subtrees the one-pass walk would have pruned after its first hit)
         self.round_budget = int(os.environ.get("VSA_TRACE_BUDGET", "0"))
         self._ws = None
