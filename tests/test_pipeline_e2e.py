@@ -72,8 +72,10 @@ def test_pipeline_matches_oracle(K, subdiv, res):
     assert worst_w <= GRAD_BOUND[K][0] and worst_t <= GRAD_BOUND[K][1]
 
 
-# measured on MI355X (printed as MEASURED stress ...); bounds = 2x measured
-STRESS_GRAD_REL_MAX = {"weights": 2e-3, "tables": 2e-2}
+# measured on MI355X (printed as MEASURED stress ...): rgb max 1.95e-3 (fp16 ulps where an 8-bit texel flipped),
+# 4.1e-4 of the values above 1e-4; gradients against the oracle's fp16 autograd (loss scale 128): weights
+# 5.4e-4, tables 2.8e-3 of each tensor's largest entry.  Bounds = 2x measured.
+STRESS_GRAD_REL_MAX = {"weights": 1.1e-3, "tables": 5.7e-3}
 
 
 @pytest.mark.gpu
@@ -104,7 +106,7 @@ def test_stress_scene_matches_oracle():
     assert np.array_equal(hit.T, ref["hit"])                      # closest hit among several crossings
     e = np.abs(rgb - ref["rgb"])
     print(f"MEASURED stress rgb_max={e.max():.3e} frac_over_1e-4={(e > 1e-4).mean():.3e} hits={int(hit.sum())}")
-    assert (e <= 1e-4).mean() > 0.995 and e.max() < 1e-2          # an 8-bit texel flip shows as fp16 ulps
+    assert (e > 1e-4).mean() <= 8.2e-4 and e.max() < 4e-3         # an 8-bit texel flip shows as fp16 ulps
     bank = pipe.bank
     worst = {"weights": 0.0, "tables": 0.0}
     for x, (g_t, g_w) in ref["grads"].items():
