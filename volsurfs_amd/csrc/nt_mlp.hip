@@ -187,12 +187,21 @@ __device__ __forceinline__ void prefetch_features(const vsa_nt_plan& plan,
 #ifndef NT_PC_DW3_LATE
 #define NT_PC_DW3_LATE 1        /* the producer's dW3 blocks one trip late, from the set written before the last barrier */
 #endif
+#ifndef NT_PC_DABS_MOD
+#define NT_PC_DABS_MOD 0
+#endif
 #ifndef NT_PC_PRIO
 #define NT_PC_PRIO 2          /* issue priority: 0 consumer raised, 1 producer raised, 2 none, 3 producer at 3 */
 #endif
 constexpr int PC_BLOCK = 512;
 constexpr int PC_PAIRS = 4;
-constexpr int S64 = 68, S32 = 40;   // row strides (halfs): 136 B (8-B aligned, bank-spread), 80 B (16-B aligned)
+#ifndef NT_PC_S64
+#define NT_PC_S64 68
+#endif
+#ifndef NT_PC_S32
+#define NT_PC_S32 40
+#endif
+constexpr int S64 = NT_PC_S64, S32 = NT_PC_S32;   // row strides (halfs): 136 B (8-B aligned, bank-spread), 80 B (16-B aligned)
 constexpr int SET_DOUT = 0, SET_X = 32 * S32, SET_H2 = 2 * 32 * S32, SET_H1 = SET_H2 + 32 * S64;
 constexpr int SET_HALFS = SET_H1 + 32 * S64;          // one {dOut, X, H2, H1} set
 constexpr int PRIV_HALFS = 32 * S64;                  // consumer-private dH2 / dH1 image
@@ -778,7 +787,15 @@ __device__ __forceinline__ void pc_run(
 #endif
         if (valid) {
 #pragma unroll
+#if NT_PC_DABS_MOD   /* |x| as a source modifier of the add: 16 instructions instead of 16 and + 8 packed adds */
+          for (int reg = 0; reg < 16; ++reg) {
+            float a = dabs[reg];
+            asm("v_add_f32 %0, %0, |%1|" : "+v"(a) : "v"(dx[reg]));
+            dabs[reg] = a;
+          }
+#else
           for (int reg = 0; reg < 16; ++reg) dabs[reg] += fabsf(dx[reg]);
+#endif
           unsigned* base = features + nt_feat_plane_base(plan, ti.type, 2 * h) +
                            nt_feat_in_plane(plan.n_levels, slot);
 #pragma unroll
