@@ -29,28 +29,57 @@ struct Lds {
   static constexpr int SA = K | 1;        // odd ray stride for alpha
 };
 
-// Coalesced slab copy HBM -> LDS (rows of W floats -> stride S floats).
+// Coalesced slab copy HBM -> LDS (rows of W floats -> stride S floats).  Where the padded stride
+// equals the width (odd 3K / K: every shell count of the reference's configs that is odd, K = 5 and 7
+// among them) the slab is one contiguous run: whole tiles go HBM -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: 1 KiB per wave-instruction, no registers, no index arithmetic), ragged
+// tiles by 16-B register copies.
+#ifndef VSA_COMP_DMA
+#define VSA_COMP_DMA 1
+#endif
+#ifndef VSA_COMP_NT
+#define VSA_COMP_NT 0     /* aux of the LDS-DMA loads: 2 = nt */
+#endif
 template <int W, int S>
 __device__ __forceinline__ void slab_load(const float* __restrict__ g, float* __restrict__ s,
                                           int rows_valid) {
   const int total = rows_valid * W;
   const int nvec = total >> 2;
   const float4* g4 = reinterpret_cast<const float4*>(g);
-  for (int v = threadIdx.x; v < nvec; v += TILE) {
-    float4 x = g4[v];
-    int e = v << 2;
-    float xs[4] = {x.x, x.y, x.z, x.w};
+  if constexpr (W == S) {
+    if (VSA_COMP_DMA && rows_valid == TILE && (TILE * W) % 4 == 0) {
+      typedef __attribute__((address_space(3))) void* lds_vp;
+      typedef __attribute__((address_space(1))) const void* glb_vp;
+      const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+      constexpr int NV = TILE * W / 4, NC = (NV + 63) / 64;        // 64 x 16 B = 1 KiB per wave-instruction
+      for (int c = wave; c < NC; c += TILE / 64)
+        if (c * 64 + lane < NV)
+          __builtin_amdgcn_global_load_lds((glb_vp)(g4 + c * 64 + lane), (lds_vp)(s + c * 256), 16, 0, VSA_COMP_NT);
+      return;
+    }
+    float4* s4 = reinterpret_cast<float4*>(s);
+    for (int v = threadIdx.x; v < nvec; v += TILE) s4[v] = g4[v];
+  } else {
+    for (int v = threadIdx.x; v < nvec; v += TILE) {
+      float4 x = g4[v];
+      int e = v << 2;
+      float xs[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int r = (e + i) / W;
-      int j = (e + i) - r * W;
-      s[r * S + j] = xs[i];
+      for (int i = 0; i < 4; ++i) {
+        int r = (e + i) / W;
+        int j = (e + i) - r * W;
+        s[r * S + j] = xs[i];
+      }
     }
   }
   for (int e = (nvec << 2) + threadIdx.x; e < total; e += TILE) {
     int r = e / W;
     s[r * S + (e - r * W)] = g[e];
   }
+}
+// after the slab_load calls of a tile, before the barrier: the LDS-DMA writes are not tracked by the compiler
+__device__ __forceinline__ void slab_load_fence() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 template <int W, int S>
@@ -59,16 +88,21 @@ __device__ __forceinline__ void slab_store(float* __restrict__ g, const float* _
   const int total = rows_valid * W;
   const int nvec = total >> 2;
   float4* g4 = reinterpret_cast<float4*>(g);
-  for (int v = threadIdx.x; v < nvec; v += TILE) {
-    int e = v << 2;
-    float xs[4];
+  if constexpr (W == S) {
+    const float4* s4 = reinterpret_cast<const float4*>(s);
+    for (int v = threadIdx.x; v < nvec; v += TILE) g4[v] = s4[v];
+  } else {
+    for (int v = threadIdx.x; v < nvec; v += TILE) {
+      int e = v << 2;
+      float xs[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int r = (e + i) / W;
-      int j = (e + i) - r * W;
-      xs[i] = s[r * S + j];
+      for (int i = 0; i < 4; ++i) {
+        int r = (e + i) / W;
+        int j = (e + i) - r * W;
+        xs[i] = s[r * S + j];
+      }
+      g4[v] = make_float4(xs[0], xs[1], xs[2], xs[3]);
     }
-    g4[v] = make_float4(xs[0], xs[1], xs[2], xs[3]);
   }
   for (int e = (nvec << 2) + threadIdx.x; e < total; e += TILE) {
     int r = e / W;
@@ -118,14 +152,15 @@ __global__ __launch_bounds__(TILE) void composite_dense_fwd_kernel(
     float* __restrict__ out_rgb_fg, float* __restrict__ out_bgT, float* __restrict__ out_w,
     float* __restrict__ out_rgb_h, float* __restrict__ out_alpha_h, int N) {
   using L = Lds<K>;
-  __shared__ float s_c[TILE * L::SC];
-  __shared__ float s_a[TILE * L::SA];
-  __shared__ float s_o[TILE * 3];
+  __shared__ __attribute__((aligned(16))) float s_c[TILE * L::SC];
+  __shared__ __attribute__((aligned(16))) float s_a[TILE * L::SA];
+  __shared__ __attribute__((aligned(16))) float s_o[TILE * 3];
   const long long ray0 = (long long)blockIdx.x * TILE;
   const int rows = min(TILE, (int)(N - ray0));
   slab_load<3 * K, L::SC>(surfs_rgb + ray0 * 3 * K, s_c, rows);
   slab_load<K, L::SA>(surfs_alpha + ray0 * K, s_a, rows);
   if (!bg_bcast) slab_load<3, 3>(rgb_bg + ray0 * 3, s_o, rows);
+  slab_load_fence();
   __syncthreads();
   const int r = threadIdx.x;
   if (r < rows) {
@@ -171,11 +206,11 @@ __global__ __launch_bounds__(TILE) void composite_dense_bwd_kernel(
     float* __restrict__ g_rgb_bg, int N, const float* __restrict__ l1_gt, float l1_scale,
     float* __restrict__ pred_out) {
   using L = Lds<K>;
-  __shared__ float s_c[TILE * L::SC];
-  __shared__ float s_a[TILE * L::SA];
-  __shared__ float s_g[TILE * 3];
-  __shared__ float s_b[TILE * 3];
-  __shared__ float s_t[TILE * 3];
+  __shared__ __attribute__((aligned(16))) float s_c[TILE * L::SC];
+  __shared__ __attribute__((aligned(16))) float s_a[TILE * L::SA];
+  __shared__ __attribute__((aligned(16))) float s_g[TILE * 3];
+  __shared__ __attribute__((aligned(16))) float s_b[TILE * 3];
+  __shared__ __attribute__((aligned(16))) float s_t[TILE * 3];
   const long long ray0 = (long long)blockIdx.x * TILE;
   const int rows = min(TILE, (int)(N - ray0));
   slab_load<3 * K, L::SC>(surfs_rgb + ray0 * 3 * K, s_c, rows);
@@ -183,6 +218,7 @@ __global__ __launch_bounds__(TILE) void composite_dense_bwd_kernel(
   if (!pred_out) slab_load<3, 3>(g_rgb + ray0 * 3, s_g, rows);
   if (!bg_bcast) slab_load<3, 3>(rgb_bg + ray0 * 3, s_b, rows);
   if (l1_gt) slab_load<3, 3>(l1_gt + ray0 * 3, s_t, rows);
+  slab_load_fence();
   __syncthreads();
   const int r = threadIdx.x;
   if (r < rows) {
