@@ -6,8 +6,8 @@ import json, os, shutil, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 raw = json.load(open(os.path.join(root, "gpurun_out", "traffic_raw.json")))
 stages = {"nt_mlp_bwd": ["nt_mlp_bwd"], "nt_mlp_fwd": ["nt_mlp_fwd_kernel"],
-          "nt_encode_bwd": ["nt_encode_bwd_kernelILb0", "nt_encode_bwd_kernelILb1"],
-          "nt_encode_fwd": ["nt_encode_fwd_kernelILb0", "nt_encode_fwd_kernelILb1"],
+          "nt_encode_bwd": ["nt_encode_bwd_kernelILb0", "nt_encode_bwd_kernelILb1", "nt_encode_bwd_both_kernel"],
+          "nt_encode_fwd": ["nt_encode_fwd_kernelILb0", "nt_encode_fwd_kernelILb1", "nt_encode_fwd_both_kernel"],
           "nt_shade_bwd": ["nt_shade_bwd_kernel"], "nt_shade_fwd": ["nt_shade_fwd_kernel"],
           "trace": ["trace_qf_kernel", "trace_q_kernel", "trace_ww_kernel"],
           "composite_fwd_bwd": ["composite_dense_fwd_kernel", "composite_dense_bwd_kernel"]}   # the step's fused launch is the bwd kernel

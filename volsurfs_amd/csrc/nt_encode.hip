@@ -56,17 +56,19 @@ constexpr int LDS_ENTRIES = 32768;    // 4-byte entries of LDS a workgroup may u
 #ifndef NT_ENC_PREFETCH_FWD
 #define NT_ENC_PREFETCH_FWD 0     /* stretches of texel centres in flight per lane (0: loaded at their use) */
 #endif
+#ifndef NT_ENC_ONE_LAUNCH
+#define NT_ENC_ONE_LAUNCH 1      /* dense + hashed levels of a direction in one launch */
+#endif
 #ifndef NT_ENC_PAIR_DENSE
 #define NT_ENC_PAIR_DENSE 1      /* dense levels: colour + alpha texture of a (shell, degree) in ONE piece (shared cell / weights) */
 #endif
 constexpr int ENC_PAIR_OFF = 15360;   // entries: the second table of a pair sits at a FIXED LDS offset (61 440 B: an
                                       // immediate of the gathers); the largest dense level has 15 136 entries
 template <bool HASHED>
-__global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
-    vsa_nt_plan plan, int level0, int n_levels, const half2_t* __restrict__ tables,
+__device__ __forceinline__ void nt_encode_fwd_body(
+    const vsa_nt_plan& plan, int level0, int n_levels, const half2_t* __restrict__ tables,
     const float2* __restrict__ slot_xy, const int* __restrict__ seg_start,
-    half2_t* __restrict__ features) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    half2_t* __restrict__ features, unsigned char* s_raw) {
   half2_t* s_tab = reinterpret_cast<half2_t*>(s_raw);
   const long long n_entries = plan.level_offset[plan.n_levels];
   const int nl = plan.n_levels;
@@ -258,6 +260,29 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
   __syncthreads();
   NT_SPAN_MARK(HASHED ? 1 : 0, 1);
   NT_BAL_END(HASHED ? NT_BAL_ENC_FWD_H : NT_BAL_ENC_FWD_D);
+}
+
+template <bool HASHED>
+__global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_kernel(
+    vsa_nt_plan plan, int level0, int n_levels, const half2_t* __restrict__ tables,
+    const float2* __restrict__ slot_xy, const int* __restrict__ seg_start,
+    half2_t* __restrict__ features) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  nt_encode_fwd_body<HASHED>(plan, level0, n_levels, tables, slot_xy, seg_start, features, s_raw);
+}
+
+// Dense levels [0, lh) and hashed levels [lh, n) in ONE launch: a workgroup walks its share of the
+// dense cost axis, then its share of the hashed one (the two classes touch different planes: no
+// ordering between workgroups).  As two launches the dense one (0.1 ms) ended behind its slowest
+// workgroups (span efficiency 0.76-0.80: stragglers, not a slope of the axis) with the chip idle.
+__global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_both_kernel(
+    vsa_nt_plan plan, int lh, const half2_t* __restrict__ tables,
+    const float2* __restrict__ slot_xy, const int* __restrict__ seg_start,
+    half2_t* __restrict__ features) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  nt_encode_fwd_body<false>(plan, 0, lh, tables, slot_xy, seg_start, features, s_raw);
+  __syncthreads();
+  nt_encode_fwd_body<true>(plan, lh, plan.n_levels - lh, tables, slot_xy, seg_start, features, s_raw);
 }
 
 // Backward: grad_table[tex][level entries][feature] += w * dF[slot]; one
@@ -570,12 +595,11 @@ __device__ __host__ inline bool enc_both_features(const vsa_nt_plan& p, int leve
 }
 
 template <bool HASHED>
-__global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
-    vsa_nt_plan plan, int level0, int n_levels, int n_planes,
+__device__ __forceinline__ void nt_encode_bwd_body(
+    const vsa_nt_plan& plan, int level0, int n_levels, int n_planes,
     const half2_t* __restrict__ dfeatures, const float* __restrict__ dfeat_abs_sum,
     float dscale_inv, const float2* __restrict__ slot_xy, const int* __restrict__ seg_start,
-    float* __restrict__ grad_tables, int tex_begin, int tex_end) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    float* __restrict__ grad_tables, int tex_begin, int tex_end, unsigned char* s_raw) {
   int* s_g = reinterpret_cast<int*>(s_raw);
   NT_SPAN_MARK(HASHED ? 3 : 2, 0);
   NT_BAL_BEGIN();
@@ -619,6 +643,31 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
   __syncthreads();
   NT_SPAN_MARK(HASHED ? 3 : 2, 1);
   if (full_range) { NT_BAL_END(HASHED ? NT_BAL_ENC_BWD_H : NT_BAL_ENC_BWD_D); }
+}
+
+template <bool HASHED>
+__global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_kernel(
+    vsa_nt_plan plan, int level0, int n_levels, int n_planes,
+    const half2_t* __restrict__ dfeatures, const float* __restrict__ dfeat_abs_sum,
+    float dscale_inv, const float2* __restrict__ slot_xy, const int* __restrict__ seg_start,
+    float* __restrict__ grad_tables, int tex_begin, int tex_end) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  nt_encode_bwd_body<HASHED>(plan, level0, n_levels, n_planes, dfeatures, dfeat_abs_sum, dscale_inv, slot_xy,
+                             seg_start, grad_tables, tex_begin, tex_end, s_raw);
+}
+
+// dense planes, then hashed planes, in one launch (as nt_encode_fwd_both_kernel)
+__global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_both_kernel(
+    vsa_nt_plan plan, int lh, int n_planes_dense,
+    const half2_t* __restrict__ dfeatures, const float* __restrict__ dfeat_abs_sum,
+    float dscale_inv, const float2* __restrict__ slot_xy, const int* __restrict__ seg_start,
+    float* __restrict__ grad_tables, int tex_begin, int tex_end) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  nt_encode_bwd_body<false>(plan, 0, lh, n_planes_dense, dfeatures, dfeat_abs_sum, dscale_inv, slot_xy,
+                            seg_start, grad_tables, tex_begin, tex_end, s_raw);
+  __syncthreads();
+  nt_encode_bwd_body<true>(plan, lh, plan.n_levels - lh, 2 * (plan.n_levels - lh), dfeatures, dfeat_abs_sum,
+                           dscale_inv, slot_xy, seg_start, grad_tables, tex_begin, tex_end, s_raw);
 }
 
 }  // namespace
@@ -679,6 +728,7 @@ extern "C" int vsa_nt_encode_fwd(const vsa_nt_plan* plan, const void* tables_h,
   if (!attr_set) {
     if ((rc = set_lds_attr(nt_encode_fwd_kernel<false>))) return rc;
     if ((rc = set_lds_attr(nt_encode_fwd_kernel<true>))) return rc;
+    if ((rc = set_lds_attr(nt_encode_fwd_both_kernel))) return rc;
     attr_set = true;
   }
   const int lh = first_hashed_level(plan);
@@ -687,6 +737,11 @@ extern "C" int vsa_nt_encode_fwd(const vsa_nt_plan* plan, const void* tables_h,
   half2_t* out = reinterpret_cast<half2_t*>(features);
   int nr_cus = 0;
   if ((rc = vsa_cu_count(&nr_cus))) return rc;
+  if (NT_ENC_ONE_LAUNCH && lh > 0 && lh < plan->n_levels) {
+    hipLaunchKernelGGL(nt_encode_fwd_both_kernel, dim3(nr_cus), dim3(ENC_BLOCK), (size_t)LDS_ENTRIES * 4,
+                       (hipStream_t)stream, *plan, lh, tab, xy, seg_start, out);
+    VSA_RETURN_LAUNCH_STATUS();
+  }
   if (lh > 0)
     hipLaunchKernelGGL(nt_encode_fwd_kernel<false>, dim3(nr_cus), dim3(ENC_BLOCK),
                        (size_t)LDS_ENTRIES * 4, (hipStream_t)stream, *plan, 0, lh, tab, xy,
@@ -724,6 +779,7 @@ extern "C" int vsa_nt_encode_bwd_range(const vsa_nt_plan* plan, const void* dfea
   if (!attr_set) {
     if ((rc = set_lds_attr(nt_encode_bwd_kernel<false>))) return rc;
     if ((rc = set_lds_attr(nt_encode_bwd_kernel<true>))) return rc;
+    if ((rc = set_lds_attr(nt_encode_bwd_both_kernel))) return rc;
     attr_set = true;
   }
   const int lh = first_hashed_level(plan);
@@ -731,6 +787,14 @@ extern "C" int vsa_nt_encode_bwd_range(const vsa_nt_plan* plan, const void* dfea
   const float2* xy = reinterpret_cast<const float2*>(slot_xy);
   int nr_cus = 0;
   if ((rc = vsa_cu_count(&nr_cus))) return rc;
+  if (NT_ENC_ONE_LAUNCH && lh > 0 && lh < plan->n_levels) {
+    int n_planes = 0;
+    for (int l = 0; l < lh; ++l) n_planes += enc_both_features(*plan, l, false) ? 1 : 2;
+    hipLaunchKernelGGL(nt_encode_bwd_both_kernel, dim3(nr_cus), dim3(ENC_BLOCK), (size_t)LDS_ENTRIES * 4,
+                       (hipStream_t)stream, *plan, lh, n_planes, dF, dfeat_abs_sum, 1.0f / grad_scale, xy,
+                       seg_start, grad_tables, tex_begin, tex_end);
+    VSA_RETURN_LAUNCH_STATUS();
+  }
   if (lh > 0) {
     int n_planes = 0;
     for (int l = 0; l < lh; ++l) n_planes += enc_both_features(*plan, l, false) ? 1 : 2;
