@@ -269,7 +269,9 @@ typedef struct vsa_nt_plan {
 /* Measured-time rebalancing of the persistent kernels' work split (profiles/NOTEBOOK.md A9.0): once per frame,
  * before the first of them, turns the busy times the previous frame's launches stamped into
  * plan->balance into per-workgroup shares of each kernel's cost axis (a workgroup that took longer
- * than the mean gets a smaller share, damped).  No-op while nothing has been stamped. */
+ * than the mean gets a smaller share, damped).  No-op while nothing has been stamped.
+ * vsa_nt_compact_frame does the same inside its own scan launch when plan->balance is set: a frame loop
+ * built on it does not call vsa_nt_rebalance. */
 long long vsa_nt_balance_bytes(void);
 int vsa_nt_rebalance(const vsa_nt_plan* plan, void* stream);
 

@@ -56,12 +56,83 @@ __global__ __launch_bounds__(256) void nt_count_kernel(const uint4* __restrict__
   if (threadIdx.x == 0) block_count[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
+// One workgroup per persistent kernel: last launch's busy times -> shares of its cost axis.
+// share' = share * clamp(mean / time, 0.8, 1.25) ^ 0.5 (damped: a workgroup's time is not linear in its
+// share, and the times carry noise), floored at a quarter of an equal share, renormalised.
+__device__ __forceinline__ void nt_rebalance_body(NtBalance* __restrict__ b, int k, float* s) {
+  const int t = threadIdx.x;
+  const int G = b->tick_wgs[k];
+  if (G <= 1 || G > NT_BAL_MAX_WG) return;
+  const bool have = b->frac_wgs[k] == G && b->frac[k][G] == (unsigned)NT_BAL_ONE;
+  const float equal = (float)NT_BAL_ONE / (float)G;
+  const float share = t < G ? (have ? (float)(b->frac[k][t + 1] - b->frac[k][t]) : equal) : 0.f;
+#ifndef NT_BAL_GAIN
+#define NT_BAL_GAIN 0.5f
+#endif
+#ifndef NT_BAL_EMA
+#define NT_BAL_EMA 1.0f       /* weight of the newest time in the running mean kept in ema[] */
+#endif
+#ifndef NT_BAL_MASK
+#define NT_BAL_MASK 0x30      /* kernels whose shares are corrected (bit = NT_BAL_* id): the two MLP kernels.
+                                 Measured (profiles/r03/rebalance.txt): nt_mlp_bwd 0.68-0.70 -> 0.64-0.65 ms as a
+                                 stage, nt_mlp_fwd unchanged; the encode kernels get SLOWER with their shares
+                                 corrected (backward 0.61-0.63 -> 0.63-0.65 at any gain 0.15-0.5, with or without a
+                                 running mean of the times): a piece's cost there is mostly its fixed part (table
+                                 staging / plane flush), which a moved boundary duplicates instead of moving */
+#endif
+  if (!((NT_BAL_MASK >> k) & 1)) return;
+  float time = t < G ? (float)b->ticks[k][t] : 0.f;
+  if (NT_BAL_EMA < 1.0f && t < G) {
+    const float prev = b->ema[k][t];
+    time = have && prev > 0.f ? (1.0f - NT_BAL_EMA) * prev + NT_BAL_EMA * time : time;
+    b->ema[k][t] = time;
+  }
+  auto scan = [&](float v) {          // inclusive, Hillis-Steele over the 1024 threads
+    s[t] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const float u = t >= off ? s[t - off] : 0.f;
+      __syncthreads();
+      s[t] += u;
+      __syncthreads();
+    }
+    const float r = s[t];
+    __syncthreads();
+    return r;
+  };
+  scan(time);
+  const float mean = s[1023] / (float)G;
+  __syncthreads();
+  float w = 0.f;
+  if (t < G) {
+    const float r = time > 0.f ? fminf(fmaxf(mean / time, 0.8f), 1.25f) : 1.25f;
+    w = fmaxf(share * powf(r, NT_BAL_GAIN), 0.25f * equal);
+  }
+  const float incl = scan(w);
+  const float total = s[1023];
+  if (t < G) b->frac[k][t + 1] = t == G - 1 ? (unsigned)NT_BAL_ONE : (unsigned)(incl / total * (float)NT_BAL_ONE);
+  if (t == 0) {
+    b->frac[k][0] = 0;
+    b->frac_wgs[k] = G;
+  }
+}
+__global__ __launch_bounds__(1024) void nt_rebalance_kernel(NtBalance* __restrict__ b) {
+  __shared__ float s[1024];
+  nt_rebalance_body(b, blockIdx.x, s);
+}
+
 // pass B: exclusive scan of the block counts (single workgroup), segment starts
 __global__ __launch_bounds__(1024) void nt_scan_blocks_kernel(vsa_nt_plan plan,
                                                               int* __restrict__ block_count,
                                                               int nr_blocks,
                                                               int* __restrict__ seg_start) {
   __shared__ int s_part[1024];
+  // workgroups 1 .. NT_BAL_KERNELS of the launch (frame loop with a balance buffer) turn the last
+  // frame's workgroup times into shares meanwhile (a 7.8 us launch of its own before)
+  if (blockIdx.x > 0) {
+    nt_rebalance_body(static_cast<NtBalance*>(plan.balance), (int)blockIdx.x - 1, reinterpret_cast<float*>(s_part));
+    return;
+  }
   const int t = threadIdx.x;
   const int per = (nr_blocks + 1023) / 1024;
   const int b0 = t * per, b1 = min(nr_blocks, b0 + per);
@@ -166,68 +237,6 @@ __global__ __launch_bounds__(1024) void nt_assign_kernel(vsa_nt_plan plan,
   if (SPARSE && word) marks[vec] = 0;
 }
 
-// One workgroup per persistent kernel: last launch's busy times -> shares of its cost axis.
-// share' = share * clamp(mean / time, 0.8, 1.25) ^ 0.5 (damped: a workgroup's time is not linear in its
-// share, and the times carry noise), floored at a quarter of an equal share, renormalised.
-__global__ __launch_bounds__(1024) void nt_rebalance_kernel(NtBalance* __restrict__ b) {
-  __shared__ float s[1024];
-  const int k = blockIdx.x, t = threadIdx.x;
-  const int G = b->tick_wgs[k];
-  if (G <= 1 || G > NT_BAL_MAX_WG) return;
-  const bool have = b->frac_wgs[k] == G && b->frac[k][G] == (unsigned)NT_BAL_ONE;
-  const float equal = (float)NT_BAL_ONE / (float)G;
-  const float share = t < G ? (have ? (float)(b->frac[k][t + 1] - b->frac[k][t]) : equal) : 0.f;
-#ifndef NT_BAL_GAIN
-#define NT_BAL_GAIN 0.5f
-#endif
-#ifndef NT_BAL_EMA
-#define NT_BAL_EMA 1.0f       /* weight of the newest time in the running mean kept in ema[] */
-#endif
-#ifndef NT_BAL_MASK
-#define NT_BAL_MASK 0x30      /* kernels whose shares are corrected (bit = NT_BAL_* id): the two MLP kernels.
-                                 Measured (profiles/r03/rebalance.txt): nt_mlp_bwd 0.68-0.70 -> 0.64-0.65 ms as a
-                                 stage, nt_mlp_fwd unchanged; the encode kernels get SLOWER with their shares
-                                 corrected (backward 0.61-0.63 -> 0.63-0.65 at any gain 0.15-0.5, with or without a
-                                 running mean of the times): a piece's cost there is mostly its fixed part (table
-                                 staging / plane flush), which a moved boundary duplicates instead of moving */
-#endif
-  if (!((NT_BAL_MASK >> k) & 1)) return;
-  float time = t < G ? (float)b->ticks[k][t] : 0.f;
-  if (NT_BAL_EMA < 1.0f && t < G) {
-    const float prev = b->ema[k][t];
-    time = have && prev > 0.f ? (1.0f - NT_BAL_EMA) * prev + NT_BAL_EMA * time : time;
-    b->ema[k][t] = time;
-  }
-  auto scan = [&](float v) {          // inclusive, Hillis-Steele over the 1024 threads
-    s[t] = v;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-      const float u = t >= off ? s[t - off] : 0.f;
-      __syncthreads();
-      s[t] += u;
-      __syncthreads();
-    }
-    const float r = s[t];
-    __syncthreads();
-    return r;
-  };
-  scan(time);
-  const float mean = s[1023] / (float)G;
-  __syncthreads();
-  float w = 0.f;
-  if (t < G) {
-    const float r = time > 0.f ? fminf(fmaxf(mean / time, 0.8f), 1.25f) : 1.25f;
-    w = fmaxf(share * powf(r, NT_BAL_GAIN), 0.25f * equal);
-  }
-  const float incl = scan(w);
-  const float total = s[1023];
-  if (t < G) b->frac[k][t + 1] = t == G - 1 ? (unsigned)NT_BAL_ONE : (unsigned)(incl / total * (float)NT_BAL_ONE);
-  if (t == 0) {
-    b->frac[k][0] = 0;
-    b->frac_wgs[k] = G;
-  }
-}
-
 }  // namespace
 
 static int plan_check(const vsa_nt_plan* p) {
@@ -281,8 +290,8 @@ static int nt_compact(const vsa_nt_plan* plan, uint8_t* marks, int32_t* slot_of,
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(nt_count_kernel, dim3(nr_blocks), dim3(256), 0, st,
                      reinterpret_cast<const uint4*>(marks), block_scratch);
-  hipLaunchKernelGGL(nt_scan_blocks_kernel, dim3(1), dim3(1024), 0, st, *plan, block_scratch,
-                     nr_blocks, seg_start);
+  hipLaunchKernelGGL(nt_scan_blocks_kernel, dim3(sparse && plan->balance ? 1 + NT_BAL_KERNELS : 1), dim3(1024), 0, st,
+                     *plan, block_scratch, nr_blocks, seg_start);
   if (sparse)
     hipLaunchKernelGGL(nt_assign_kernel<true>, dim3(nr_blocks), dim3(1024), 0, st, *plan,
                        reinterpret_cast<unsigned*>(marks), block_scratch, reinterpret_cast<int4*>(slot_of),

@@ -192,7 +192,7 @@ class NeuralTextureBank(torch.nn.Module):
             raise _lib.VolsurfsHipError("this bank holds baked textures: use tex_uv_only + shade")
         st = _lib.stream_ptr()
         tex_uv = torch.empty(K, N, 2, device=hit_slot.device)
-        if self.plan.balance:
+        if self.plan.balance and _DENSE_COMPACT:     # (vsa_nt_compact_frame rebalances inside its scan launch)
             _lib.call("vsa_nt_rebalance", ctypes.byref(self.plan), st)
         # Invariant: the marks are zero between frames — allocated so, and vsa_nt_compact_frame clears
         # what it reads.  `_marks_dirty` is set while a mark has not been followed by a compaction that
