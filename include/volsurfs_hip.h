@@ -18,7 +18,9 @@
  *     <0 = VSA_ERR_* argument / support error.  Nothing is printed-and-ignored;
  *   - caller owns every buffer; the library keeps no global state except
  *     objects created by *_create and destroyed by *_destroy;
- *   - fp32 row-major tensors, int32 indices (reference layout).
+ *   - fp32 row-major tensors, int32 indices (reference layout);
+ *   - every device buffer starts 16-byte aligned (rows and slabs are moved with 16-byte loads,
+ *     stores and LDS-DMA; any allocator's base pointer qualifies, an odd view into one may not).
  */
 #ifndef VOLSURFS_HIP_H
 #define VOLSURFS_HIP_H
