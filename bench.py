@@ -77,8 +77,16 @@ def parse(argv=None):
                          "backward, as the N > 1 ranks do")
     ap.add_argument("--no-graph", action="store_true", help="time the eager path instead of the HIP-graph replay")
     ap.add_argument("--by-shell", action="store_true",
-                    help="1 GPU: run the multi-GPU schedule (shell-by-shell hash-grid backward, eager) "
+                    help="1 GPU: run the data-parallel step (phased hash-grid backward + device flags) "
                          "without the collectives, to price it")
+    ap.add_argument("--dp-phases", default=None,
+                    help="data-parallel step: shell-range ends of the hash-grid backward's phases, e.g. 3,5 "
+                         "(default: parallel.default_phases — 3 phases)")
+    ap.add_argument("--dp-wait", type=int, default=0, choices=[0, 1, 2],
+                    help="how the communication stream waits for a device flag: 1 hipStreamWaitValue32, "
+                         "2 a one-lane polling kernel, 0 the first where the device offers it")
+    ap.add_argument("--dp-split-launches", action="store_true",
+                    help="round 4's data-parallel schedule (K hash-grid backward launches, eager), for A/B")
     ap.add_argument("--cpu-sample-rays", type=int, default=16384,
                     help="rays of the cpu_baseline sample: one evaluation chunk of the reference "
                          "(test_rays_batch_size = 16 384, config/volsurfs/base_5.cfg:8; SURVEY 8d)")
@@ -572,19 +580,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    from volsurfs_amd.parallel import GradientOverlap
+    from volsurfs_amd.parallel import GradientOverlap, OverlappedStep
     params = [pipe.bank.tables, pipe.bank.weights]
-    overlap = GradientOverlap(world, wire_dtype=torch.bfloat16 if args.grad_wire_dtype == "bf16" else None,
-                              force=args.force_dist)
+    wire = torch.bfloat16 if args.grad_wire_dtype == "bf16" else None
+    overlap = GradientOverlap(world, wire_dtype=wire, force=args.force_dist)
+    # the data-parallel step: ONE stream of launches — the same graph as on one GPU plus a
+    # one-lane signal kernel — in which the device publishes "weights.grad final" and "phase p of
+    # tables.grad final"; a side stream waits on those flags and all-reduces (sum) over RCCL / xGMI
+    # while the rest of backward runs.  What is left exposed behind the last kernel is "grad_allreduce".
+    dp_on = (dist is not None or args.by_shell) and not args.dp_split_launches
+    ostep = None
+    if dp_on:
+        phases = [int(x) for x in args.dp_phases.split(",")] if args.dp_phases else None
+        ostep = OverlappedStep(pipe, world, wire_dtype=wire, force=args.force_dist, phases=phases,
+                               wait_mode=args.dp_wait)
+        ostep.active = dist is not None
 
     def step(record=False):
-        if dist is None:
-            pipe.step(record=record, grad_ready=(lambda t: None) if args.by_shell else None)
+        if ostep is not None:
+            ostep.run(record=record)
             return
-        # data-parallel training step: the parameter gradients are all-reduced (sum) over
-        # RCCL / xGMI shell by shell while the rest of backward still runs;
-        # what is left exposed after the last kernel is the "grad_allreduce" stage
-        pipe.step(record=record, grad_ready=overlap.reduce_async)
+        if dist is None:
+            pipe.step(record=record)
+            return
+        pipe.step(record=record, grad_ready=overlap.reduce_async)       # --dp-split-launches
         pipe.timer.run("grad_allreduce", overlap.wait, record,
                        bytes=sum(p.numel() for p in params) * 4)
 
@@ -605,12 +624,22 @@ def main():
         step()
     kernel_ms = _lib.kernel_ms()
     _lib.kernel_events = None
-    use_graph = not args.no_graph and dist is None and not args.by_shell   # collectives interleave with the backward kernels
+    use_graph = not args.no_graph and not args.dp_split_launches
     if use_graph:
         try:
-            pipe.capture_graph()       # the step is ~25 launches on one stream with no host sync
+            # the step is ~25 launches on one stream with no host sync; the data-parallel step is the
+            # same stream of launches (the collectives run beside the graph, released by device flags)
+            if ostep is not None:
+                # two graphs: the parameter-free head of a step (ray order, traversal, mark / compact) is
+                # launched before the wait for the previous step's gradient reduction (OverlappedStep.run_split)
+                pipe.capture_graph_split(dp=ostep.signals)
+                ostep.signals.epoch_host += 2          # the capture executed two warm-up steps (a capture pass only records)
+            else:
+                pipe.capture_graph()
             for _ in range(2):
-                pipe.replay()
+                ostep.run_split(pipe.replay_prefix, pipe.replay_rest) if ostep is not None else pipe.replay()
+            if ostep is not None:
+                ostep.finish()
         except Exception as e:         # fall back to the (equally fast) eager path
             print(f"[bench] graph capture failed ({e}); timing the eager path", file=sys.stderr)
             use_graph = False
@@ -619,7 +648,9 @@ def main():
         if views is not None:
             pipe.rays_o.copy_(views[i % len(views)][0])
             pipe.rays_d.copy_(views[i % len(views)][1])
-        if use_graph:
+        if use_graph and ostep is not None:
+            ostep.run_split(pipe.replay_prefix, pipe.replay_rest)
+        elif use_graph:
             pipe.replay()
         else:
             step()
@@ -627,6 +658,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         timed_step(i)
+    if ostep is not None:
+        ostep.finish()                 # the last step's reduction (inside the timed region)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -675,6 +708,11 @@ def main():
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": pipe.dtype_desc, "data": "synthetic",
             "config": dict(pipe.config_desc(world), launch="hip-graph replay" if use_graph else "eager",
+                           **({"dp_phases": ostep.signals.phase_end,
+                               "dp_schedule": "two graphs per step: the parameter-free head (ray order, traversal, "
+                                              "mark/compact) runs before the wait for the previous step's gradient "
+                                              "reduction; collectives on a side stream released by device flags"}
+                              if ostep is not None else {}),
                            scene=getattr(pipe, "scene_desc", None)),
             "roofline": roof,
             # hit fraction per (ray, shell) and the rate per hit: 71 % of the (ray, shell) pairs of this

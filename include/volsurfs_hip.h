@@ -387,6 +387,37 @@ int vsa_nt_encode_bwd_range(const vsa_nt_plan* plan, const void* dfeatures,
                             const int32_t* seg_start, float* grad_tables, int shell_begin,
                             int shell_end, void* stream);
 
+/* Data-parallel form of vsa_nt_encode_bwd (rays shard by tile, the ranks all-reduce the
+ * gradients; the reference is single-GPU, so this replaces nothing — it is what keeps the all-reduce
+ * of the 113 MB of table gradients off the critical path of trainer.py:249-264's backward).
+ * ONE launch: the shells are cut into n_phases groups, phase p = shells [phase_shell_end[p-1],
+ * phase_shell_end[p]) ([host] array, strictly increasing, last = nr_shells); every workgroup walks its
+ * share of the dense levels of all shells, then finishes its share of phase p's hashed levels before
+ * it touches phase p+1, and when the LAST workgroup is through phase p the
+ * kernel stores flags[p] = *epoch (system scope; that phase's slice of grad_tables — textures
+ * [8*begin, 8*end) — is final and visible).  counters: n_phases words, zero on entry, zero again on
+ * exit.  Results equal vsa_nt_encode_bwd's up to the order of the float atomics that join two
+ * workgroups' shares of one table plane (pieces are cut at other slots).
+ * Another stream waits for a phase with vsa_dp_stream_wait(flags + p, epoch value). */
+int vsa_nt_encode_bwd_phased(const vsa_nt_plan* plan, const void* dfeatures,
+                             const float* dfeat_abs_sum, float grad_scale, const float* slot_xy,
+                             const int32_t* seg_start, float* grad_tables, int n_phases,
+                             const int32_t* phase_shell_end, uint32_t* flags, uint32_t* counters,
+                             const uint32_t* epoch, void* stream);
+
+/* Stream-ordered signal: (*epoch += 1 when advance_epoch), then *flag = *epoch at system scope — a
+ * one-lane kernel, so it can sit inside a captured HIP graph (hipStreamWriteValue32 cannot).  The step
+ * calls it once behind vsa_nt_mlp_bwd (weights.grad is final), advancing the epoch the phased
+ * encode backward then publishes. */
+int vsa_dp_signal(uint32_t* flag, uint32_t* epoch, int advance_epoch, void* stream);
+
+/* Make `stream` wait until (int32)(*flag - value) >= 0.  mode 1: hipStreamWaitValue32 (the command
+ * processor polls; no compute resource), mode 2: a one-lane polling kernel, mode 0: 1 where
+ * hipDeviceAttributeCanUseStreamWaitValue says so, else 2.  ENQUEUE IT AFTER THE PRODUCER: HIP
+ * multiplexes streams onto a few hardware queues, and a wait queued ahead of the kernel that
+ * satisfies it on the same queue would never return. */
+int vsa_dp_stream_wait(uint32_t* flag, uint32_t value, int mode, void* stream);
+
 /* ------------------------------------------------------------------------
  * A5 / A10  Encoders of the legacy appearance branch and of the background field:
  * the 2-D / 3-D multiresolution hash grid behind GridHashEncoder

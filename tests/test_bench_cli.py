@@ -67,7 +67,8 @@ def test_one_rank_rccl_group_drives_the_data_parallel_schedule():
     d = _run("--res", "128", "--shells", "2", "--subdiv", "3", "--steps", "3", "--warmup", "1",
              "--no-cpu-baseline", "--force-dist", "--dist-backend", "nccl")
     assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["dist_backend"] == "nccl" and d["value"] > 0
-    assert "grad_allreduce" in d["stages_ms"] and d["config"]["launch"] == "eager"
+    # r5: the data-parallel step is the one-GPU graph + device flags; the collectives run beside it
+    assert "grad_allreduce" in d["stages_ms"] and d["config"]["launch"] == "hip-graph replay"
 
 
 @pytest.mark.gpu

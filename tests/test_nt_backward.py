@@ -138,3 +138,51 @@ def test_encode_backward_by_shell_equals_one_launch():
     assert ref.abs().max() > 0
     np.testing.assert_allclose(bank.tables.grad.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5,
                                atol=1e-6 * ref.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("phases,wait_mode", [(None, 1), ([2, 3], 2), ([3], 0)])
+def test_encode_backward_phased_equals_one_launch_and_publishes_its_phases(phases, wait_mode):
+    """vsa_nt_encode_bwd_phased (the data-parallel step's hash-grid backward: ONE launch whose workgroups
+    finish the shells phase by phase): same table gradients as the plain launch; flags[p] hold the epoch
+    afterwards, the workgroup counters are zero again; a second stream that waits on the flags
+    (hipStreamWaitValue32 / the polling kernel) reads each phase's FINAL slice while the launch is the
+    only thing that could still be writing it."""
+    from volsurfs_amd import _lib
+    from volsurfs_amd.parallel import StepSignals
+    K, N = 3, 2500
+    bank, face_uvs, hit_slot, hit_uv, tris, rays_d = _scene(K, N, 7, res=(256, 128, 64, 32))
+    tex_uv = bank.mark_and_compact(hit_slot, hit_uv, face_uvs)
+    g = torch.Generator().manual_seed(3)
+    g_rgb = (torch.randn(N, K, 3, generator=g) / N).cuda()
+    g_alpha = (torch.randn(N, K, generator=g) / N).cuda()
+    bank.encode(); bank.mlp()
+    bank.tables.grad = None
+    bank.weights.grad = None
+    bank.backward_shade(hit_slot, tex_uv, rays_d, tris, g_rgb, g_alpha, float(N))
+    bank.backward_mlp(float(N))
+    bank.backward_encode(float(N))
+    ref = bank.tables.grad.clone()
+    sg = StepSignals(K, "cuda", phases, wait_mode)
+    side = torch.cuda.Stream()
+    snaps = []
+    for epoch in (1, 2):
+        bank.tables.grad.zero_()
+        _lib.call("vsa_dp_signal", sg.flag_w, sg.epoch, 1, _lib.stream_ptr())
+        bank.backward_encode_phased(float(N), sg)
+        with torch.cuda.stream(side):           # queued AFTER the producer (vsa_dp_stream_wait's rule)
+            for p in range(sg.n):
+                a, b = sg.shell_range(p)
+                sg.stream_wait(sg.flags[p:p + 1], epoch)
+                snaps.append((a, b, bank.tables.grad[a * 8:b * 8].clone()))
+        torch.cuda.synchronize()
+        w = sg.words.cpu().tolist()
+        assert w[:sg.n] == [epoch] * sg.n and w[sg.n] == epoch and w[sg.n + 1] == epoch      # flags, flag_w, epoch
+        assert w[sg.n + 2:] == [0] * sg.n                                                     # counters
+        assert ref.abs().max() > 0
+        np.testing.assert_allclose(bank.tables.grad.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5,
+                                   atol=1e-6 * ref.abs().max().item())
+    for a, b, snap in snaps:                     # what the waiting stream saw of a phase = its final value
+        assert torch.equal(snap, bank.tables.grad[a * 8:b * 8])
+    with pytest.raises(ValueError):
+        StepSignals(K, "cuda", [2, 2, 3])

@@ -208,9 +208,13 @@ def _hip_rank(rank, world, port, res, q):
     torch.cuda.set_device(0)
     pipe = KShellPipeline.synthetic(K=2, subdiv=3, res=res, init="spread", seed=3,
                                     rows=shard_bands(res, rank, world))
-    ov = GradientOverlap(world)
-    rgb = pipe.step(grad_ready=ov.reduce_async)      # weights.grad, then one tables.grad slice per shell
-    ov.wait()
+    from volsurfs_amd.parallel import OverlappedStep
+    # weights.grad, then one tables.grad slice per shell, each all-reduced on a side stream as soon as the
+    # device publishes it (the step itself: one graph replay, as bench.py --gpus N times it)
+    ostep = OverlappedStep(pipe, world)
+    pipe.capture_graph(dp=ostep.signals)
+    ostep.signals.epoch_host += 2
+    rgb = ostep.run(pipe.replay)
     torch.cuda.synchronize()
     frame = gather_rows = None
     outs = [torch.empty_like(rgb) for _ in range(world)] if rank == 0 else None
@@ -448,14 +452,20 @@ def _rccl_one_rank(port, q):
     # (1) the frame step with the gradients all-reduced slice by slice during backward
     pipe = KShellPipeline.synthetic(K=2, subdiv=3, res=64, init="spread", seed=3)
     ref_rgb = pipe.step().clone()
-    ov = GradientOverlap(1, force=True)
+    from volsurfs_amd.parallel import OverlappedStep
+    ostep = OverlappedStep(pipe, 1, force=True)     # the collectives run although the group has one rank
     snaps = []
+    reduce_async = ostep.overlap.reduce_async
 
-    def ready(t):
-        snaps.append((t, t.clone()))           # the value the collective is given ...
-        ov.reduce_async(t)
-    rgb = pipe.step(grad_ready=ready)
-    ov.wait()
+    def spy(t):
+        snaps.append((t, t.clone()))           # the value the collective is given (read on the side stream,
+        reduce_async(t)                        #   behind the device flag: the FINAL gradient) ...
+    ostep.overlap.reduce_async = spy
+    pipe.capture_graph(dp=ostep.signals)       # the data-parallel step replays as ONE graph
+    ostep.signals.epoch_host += 2
+    for _ in range(2):
+        snaps.clear()
+        rgb = ostep.run(pipe.replay)
     torch.cuda.synchronize()
     out["forward_equal"] = bool(torch.equal(rgb, ref_rgb))
     out["allreduce_identity"] = all(bool(torch.equal(t, c)) for t, c in snaps)    # ... is what comes back (sum over one rank)

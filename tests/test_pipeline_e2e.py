@@ -133,6 +133,36 @@ def test_pipeline_is_deterministic_in_forward_and_chunk_independent():
 
 
 @pytest.mark.gpu
+def test_data_parallel_step_is_the_plain_step_plus_device_flags():
+    """pipe.step(dp=signals): the same launches as the plain step (graph-capturable) with the hash-grid
+    backward walking the shells phase by phase; gradients as the plain step's, and a graph replay of it
+    advances the device epoch the host counts."""
+    from volsurfs_amd.parallel import OverlappedStep
+    from volsurfs_amd.pipeline import KShellPipeline
+    pipe = KShellPipeline.synthetic(K=3, subdiv=3, res=64, init="spread", seed=2)
+    ref_rgb = pipe.step().clone()
+    gw, gt = pipe.bank.weights.grad.clone(), pipe.bank.tables.grad.clone()
+    o = OverlappedStep(pipe, 1)                  # one rank, no group: the flags are published, nothing waits
+    rgb = o.run()
+    torch.cuda.synchronize()
+    assert torch.equal(rgb, ref_rgb) and o.signals.epoch_host == 1
+    np.testing.assert_allclose(pipe.bank.weights.grad.cpu().numpy(), gw.cpu().numpy(), rtol=0,
+                               atol=2e-3 * gw.abs().max().item())
+    np.testing.assert_allclose(pipe.bank.tables.grad.cpu().numpy(), gt.cpu().numpy(), rtol=0,
+                               atol=2e-3 * gt.abs().max().item())
+    pipe.capture_graph(dp=o.signals)
+    o.signals.epoch_host += 2                    # capture_graph executes two warm-up steps
+    for _ in range(3):
+        rgb = o.run(pipe.replay)
+    torch.cuda.synchronize()
+    assert torch.equal(rgb, ref_rgb)
+    w = o.signals.words.cpu().tolist()
+    assert w[:o.signals.n + 2] == [o.signals.epoch_host] * (o.signals.n + 2) and o.signals.epoch_host == 6
+    np.testing.assert_allclose(pipe.bank.tables.grad.cpu().numpy(), gt.cpu().numpy(), rtol=0,
+                               atol=2e-3 * gt.abs().max().item())
+
+
+@pytest.mark.gpu
 def test_step_with_gradient_callbacks_matches_plain_step():
     """The multi-GPU schedule (weights.grad, then one tables.grad slice per shell handed
     to a callback as soon as it is final) computes the same gradients as the plain step
@@ -240,3 +270,25 @@ def test_degenerate_frames():
     h, sl = one.stats()
     assert r.shape == (1, 3) and h == 2 and 8 <= sl <= 32 and torch.isfinite(r).all()
     assert one.bank.weights.grad.abs().sum() > 0
+
+
+@pytest.mark.gpu
+def test_split_graphs_equal_the_one_graph_step():
+    """capture_graph_split: prefix (ray order, traversal, mark / compact) + rest replayed back to back =
+    the one-graph step, bit for bit in the colours; OverlappedStep.run_split drives them."""
+    from volsurfs_amd.parallel import OverlappedStep
+    from volsurfs_amd.pipeline import KShellPipeline
+    pipe = KShellPipeline.synthetic(K=3, subdiv=3, res=64, init="spread", seed=2)
+    ref_rgb = pipe.step().clone()
+    gt = pipe.bank.tables.grad.clone()
+    o = OverlappedStep(pipe, 1)
+    pipe.capture_graph_split(dp=o.signals)
+    o.signals.epoch_host += 2
+    for _ in range(3):
+        rgb = o.run_split(pipe.replay_prefix, pipe.replay_rest)
+    o.finish()
+    torch.cuda.synchronize()
+    assert torch.equal(rgb, ref_rgb)
+    assert o.signals.words.cpu().tolist()[:o.signals.n + 2] == [5] * (o.signals.n + 2)
+    np.testing.assert_allclose(pipe.bank.tables.grad.cpu().numpy(), gt.cpu().numpy(), rtol=0,
+                               atol=2e-3 * gt.abs().max().item())

@@ -670,6 +670,70 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_both_kernel(
                            dscale_inv, slot_xy, seg_start, grad_tables, tex_begin, tex_end, s_raw);
 }
 
+// The data-parallel form (vsa_nt_encode_bwd_phased): every workgroup first walks its share of the dense
+// planes of ALL shells (a quarter of the work in many small pieces; un-phased), then the shells' hashed
+// planes PHASE BY PHASE — its share of phase 0, then of phase 1, ... — so the table gradients of a phase's
+// shells are final roughly (1 + 3 (p + 1) / n_phases) / 4 into the ONE launch instead of all at its end.  A
+// workgroup that has finished its share of a phase makes its table atomics visible (agent-scope release)
+// and counts itself in; the last one publishes flags[phase] = *epoch at system scope, which a wait on
+// another stream (vsa_dp_stream_wait) releases that phase's all-reduce on.  No workgroup ever waits for
+// another: a phase boundary is not a barrier.  Price on one MI355X (800x800, K = 5; the walk re-splits
+// every phase over all 256 workgroups, i.e. 160 + 256 instead of 160 pieces per shell, each with its own
+// LDS plane to zero and to flush): 1 / 2 / 3 / 5 phases = 0.60 / 0.64 / 0.68 / 0.75 ms.
+struct EncPhases {
+  int n;
+  int shell_end[VSA_MAX_SHELLS];
+};
+
+__global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_phased_kernel(
+    vsa_nt_plan plan, int lh, int n_planes_dense,
+    const half2_t* __restrict__ dfeatures, const float* __restrict__ dfeat_abs_sum,
+    float dscale_inv, const float2* __restrict__ slot_xy, const int* __restrict__ seg_start,
+    float* __restrict__ grad_tables, EncPhases ph, unsigned* __restrict__ flags,
+    unsigned* __restrict__ counters, const unsigned* __restrict__ epoch) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  // the dense (coarse) planes of ALL shells first, un-phased: they are a quarter of the work in many small
+  // pieces, and a phase is final once its hashed planes are — the dense ones are long done by then
+  if (lh > 0)
+    nt_encode_bwd_body<false>(plan, 0, lh, n_planes_dense, dfeatures, dfeat_abs_sum, dscale_inv, slot_xy,
+                              seg_start, grad_tables, 0, 1 << 30, s_raw);
+  __syncthreads();
+  int shell0 = 0;
+  for (int p = 0; p < ph.n; ++p) {
+    const int tex_begin = shell0 * 2 * VSA_NT_MAX_DEG, tex_end = ph.shell_end[p] * 2 * VSA_NT_MAX_DEG;
+    shell0 = ph.shell_end[p];
+    if (lh < plan.n_levels)
+      nt_encode_bwd_body<true>(plan, lh, plan.n_levels - lh, 2 * (plan.n_levels - lh), dfeatures, dfeat_abs_sum,
+                               dscale_inv, slot_xy, seg_start, grad_tables, tex_begin, tex_end, s_raw);
+    // every wave's flush atomics have been acknowledged (vmcnt 0) before the workgroup counts itself in; ONE
+    // wave then issues the agent-scope release (as a fence in all 16 waves it cost 0.16 ms per phase:
+    // 4 096 L2 write-back requests per phase chip-wide, profiles/r05/dp_schedule_one_gpu.txt)
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      const unsigned done = __hip_atomic_fetch_add(&counters[p], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (done == gridDim.x - 1) {
+        __hip_atomic_store(&counters[p], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        __hip_atomic_store(&flags[p], *epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+}
+
+// ---- the small stream-side pieces of the same protocol
+__global__ void dp_signal_kernel(unsigned* __restrict__ flag, unsigned* __restrict__ epoch, int advance) {
+  unsigned e = *epoch;
+  if (advance) *epoch = ++e;
+  __hip_atomic_store(flag, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void dp_spin_wait_kernel(const unsigned* __restrict__ flag, unsigned value) {
+  // (one lane, no LDS: fits beside the persistent kernels, which leave half of a CU's wave slots free)
+  while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0)
+    __builtin_amdgcn_s_sleep(64);
+}
+
 }  // namespace
 
 static bool level_hashed(const vsa_nt_plan* p, int l) {
@@ -808,5 +872,64 @@ extern "C" int vsa_nt_encode_bwd_range(const vsa_nt_plan* plan, const void* dfea
                        (size_t)LDS_ENTRIES * 4, (hipStream_t)stream, *plan, lh, plan->n_levels - lh,
                        2 * (plan->n_levels - lh), dF, dfeat_abs_sum, 1.0f / grad_scale, xy,
                        seg_start, grad_tables, tex_begin, tex_end);
+  VSA_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int vsa_nt_encode_bwd_phased(const vsa_nt_plan* plan, const void* dfeatures,
+                                        const float* dfeat_abs_sum, float grad_scale,
+                                        const float* slot_xy, const int32_t* seg_start,
+                                        float* grad_tables, int n_phases, const int32_t* phase_shell_end,
+                                        uint32_t* flags, uint32_t* counters, const uint32_t* epoch,
+                                        void* stream) {
+  if (!plan || !dfeatures || !dfeat_abs_sum || !slot_xy || !seg_start || !grad_tables || !phase_shell_end ||
+      !flags || !counters || !epoch)
+    return VSA_ERR_ARG;
+  if (n_phases < 1 || n_phases > VSA_MAX_SHELLS || !(grad_scale > 0.f)) return VSA_ERR_ARG;
+  EncPhases ph;
+  int prev = 0;
+  for (int p = 0; p < n_phases; ++p) {       // strictly increasing, the last phase ends at the last shell
+    if (phase_shell_end[p] <= prev || phase_shell_end[p] > plan->nr_shells) return VSA_ERR_ARG;
+    ph.shell_end[p] = prev = phase_shell_end[p];
+  }
+  if (prev != plan->nr_shells) return VSA_ERR_ARG;
+  ph.n = n_phases;
+  int rc = check_levels(plan);
+  if (rc) return rc;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if ((rc = set_lds_attr(nt_encode_bwd_phased_kernel))) return rc;
+    attr_set = true;
+  }
+  const int lh = first_hashed_level(plan);
+  int n_planes = 0;
+  for (int l = 0; l < lh; ++l) n_planes += enc_both_features(*plan, l, false) ? 1 : 2;
+  int nr_cus = 0;
+  if ((rc = vsa_cu_count(&nr_cus))) return rc;
+  hipLaunchKernelGGL(nt_encode_bwd_phased_kernel, dim3(nr_cus), dim3(ENC_BLOCK), (size_t)LDS_ENTRIES * 4,
+                     (hipStream_t)stream, *plan, lh, n_planes, reinterpret_cast<const half2_t*>(dfeatures),
+                     dfeat_abs_sum, 1.0f / grad_scale, reinterpret_cast<const float2*>(slot_xy), seg_start,
+                     grad_tables, ph, flags, counters, epoch);
+  VSA_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int vsa_dp_signal(uint32_t* flag, uint32_t* epoch, int advance_epoch, void* stream) {
+  if (!flag || !epoch) return VSA_ERR_ARG;
+  hipLaunchKernelGGL(dp_signal_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, flag, epoch, advance_epoch);
+  VSA_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int vsa_dp_stream_wait(uint32_t* flag, uint32_t value, int mode, void* stream) {
+  if (!flag || mode < 0 || mode > 2) return VSA_ERR_ARG;
+  if (mode == 0) {      // auto: the command processor's wait where the device offers it
+    int dev = 0, can = 0;
+    VSA_HIP_TRY(hipGetDevice(&dev));
+    VSA_HIP_TRY(hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev));
+    mode = can ? 1 : 2;
+  }
+  if (mode == 1) {
+    VSA_HIP_TRY(hipStreamWaitValue32((hipStream_t)stream, flag, value, hipStreamWaitValueGte, 0xffffffffu));
+    return VSA_OK;
+  }
+  hipLaunchKernelGGL(dp_spin_wait_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, flag, value);
   VSA_RETURN_LAUNCH_STATUS();
 }

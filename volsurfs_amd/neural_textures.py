@@ -420,3 +420,10 @@ class NeuralTextureBank(torch.nn.Module):
             _lib.call("vsa_nt_encode_bwd_range", ctypes.byref(self.plan), self.features,
                       self._dfsum, float(grad_scale), self.slot_xy, self.seg_start,
                       self.tables.grad, int(shells[0]), int(shells[1]), _lib.stream_ptr())
+
+    def backward_encode_phased(self, grad_scale, signals):
+        """The hash-grid backward as ONE launch that finishes the shells phase by phase and publishes
+        each phase's completion in signals.flags (parallel.StepSignals; vsa_nt_encode_bwd_phased)."""
+        _lib.call("vsa_nt_encode_bwd_phased", ctypes.byref(self.plan), self.features, self._dfsum,
+                  float(grad_scale), self.slot_xy, self.seg_start, self.tables.grad, signals.n,
+                  signals.phase_end_c, signals.flags, signals.counters, signals.epoch, _lib.stream_ptr())

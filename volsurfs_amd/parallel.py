@@ -88,6 +88,119 @@ class GradientOverlap:
         self.works = []
 
 
+def default_phases(nr_shells, max_phases=3):
+    """Shell-range ends of the hash-grid backward's phases.  Every phase costs the one launch ~26 us on
+    one MI355X (each re-splits its shells' planes over all 256 workgroups: more, smaller LDS pieces) and
+    removes 1/P - 1/(P+1) of the all-reduce from behind the last kernel: with the 114 MB of table
+    gradients at 0.35-0.6 ms on the wire (8 GPUs, bf16 / fp32) the modelled exposed time is flat from 3
+    phases on, so 3 it is; K < 3 shells: one phase per shell."""
+    n = max(1, min(int(max_phases), int(nr_shells)))
+    # (rounded up: the LAST phase, whose all-reduce nothing hides, is the smallest)
+    return sorted({-(-nr_shells * (i + 1) // n) for i in range(n)})
+
+
+class StepSignals:
+    """Device-side completion flags of one data-parallel step (include/volsurfs_hip.h:
+    vsa_dp_signal, vsa_nt_encode_bwd_phased, vsa_dp_stream_wait).  The step itself stays ONE
+    stream of launches (so it captures into a HIP graph and replays): behind the MLP backward a
+    one-lane kernel advances the epoch and publishes it in `flag_w` (weights.grad is final); the
+    hash-grid backward is ONE launch whose workgroups walk the shells phase by phase and publish
+    the epoch in flags[p] when the last of them leaves phase p.  A communication stream waits for
+    `flag >= epoch` in front of each all-reduce.
+
+    phases: list of shell-range ends, strictly increasing, last = K (default: default_phases(K))."""
+
+    def __init__(self, nr_shells, device, phases=None, wait_mode=0):
+        self.phase_end = [int(x) for x in (phases or default_phases(nr_shells))]
+        if self.phase_end[-1] != nr_shells or any(b <= a for a, b in zip([0] + self.phase_end, self.phase_end)):
+            raise ValueError(f"phases {self.phase_end} do not cut shells 0..{nr_shells}")
+        n = len(self.phase_end)
+        self.n = n
+        # [flags (n) | flag_w | epoch | counters (n)], one allocation, zero
+        self.words = torch.zeros(2 * n + 2, dtype=torch.int32, device=device)
+        self.flags, self.flag_w = self.words[:n], self.words[n:n + 1]
+        self.epoch, self.counters = self.words[n + 1:n + 2], self.words[n + 2:]
+        self.epoch_host = 0          # the device epoch after the steps launched so far
+        self.wait_mode = int(wait_mode)
+        import ctypes
+        self.phase_end_c = (ctypes.c_int32 * n)(*self.phase_end)
+
+    def shell_range(self, p):
+        return (self.phase_end[p - 1] if p else 0), self.phase_end[p]
+
+    def stream_wait(self, flag, value):
+        """The CURRENT stream waits until `flag` (a one-element view of self.words) holds `value`."""
+        from . import _lib
+        _lib.call("vsa_dp_stream_wait", flag, int(value), self.wait_mode, _lib.stream_ptr())
+
+
+class OverlappedStep:
+    """The data-parallel training step: `launch()` enqueues one whole step built with
+    `pipe.step(dp=signals)` — eagerly or as a graph replay — and the gradients go out on a side
+    stream as the device publishes them: weights.grad behind the MLP backward, then each phase's
+    slice of tables.grad while the later phases still accumulate.  Nothing in the step is split,
+    re-ordered or synchronised with the host for this; on one GPU it costs what the phased walk of
+    the hash-grid backward costs (profiles/r05/dp_schedule_one_gpu.txt).
+
+    run() returns with the current stream waiting for the reduced gradients (as GradientOverlap.wait)."""
+
+    def __init__(self, pipe, world, group=None, wire_dtype=None, force=False, phases=None, wait_mode=0):
+        dev = pipe.bank.tables.device
+        self.pipe, self.world, self.force = pipe, world, force
+        self.signals = StepSignals(pipe.K, dev, phases, wait_mode)
+        self.overlap = GradientOverlap(world, group, wire_dtype, force)
+        self.side = torch.cuda.Stream(device=dev)
+        self.active = world > 1 or force
+
+    def eager(self, record=False):
+        return self.pipe.step(record=record, dp=self.signals)
+
+    def run_split(self, prefix, rest):
+        """The pipelined form (pipe.capture_graph_split): `prefix()` — the step's parameter- and
+        gradient-free head: ray order, traversal, mark / compact, 0.33 ms of the 2.5 — is enqueued BEFORE
+        the current stream waits for the previous step's reduction, so the tail of that reduction (its last
+        phase, the hand-offs between the streams; in training also the optimiser on its side stream) runs
+        beside it; then the wait, then `rest()`, then this step's collectives as in run().  Every step's
+        gradients are still fully reduced before anything reads them; call finish() behind the last step."""
+        prefix()
+        self.overlap.wait()
+        out = rest()
+        self._enqueue_reductions()
+        return out
+
+    def finish(self):
+        self.overlap.wait()
+
+    def _enqueue_reductions(self):
+        sg, bank = self.signals, self.pipe.bank
+        sg.epoch_host += 1
+        if not self.active:
+            return
+        e = sg.epoch_host
+        # (after the producer: a wait queued ahead of the kernel that satisfies it could share its hardware queue)
+        with torch.cuda.stream(self.side):
+            sg.stream_wait(sg.flag_w, e)
+            self.overlap.reduce_async(bank.weights.grad)
+            for p in range(sg.n - 1):
+                a, b = sg.shell_range(p)
+                sg.stream_wait(sg.flags[p:p + 1], e)
+                self.overlap.reduce_async(bank.tables.grad[a * 8:b * 8])
+        # the last phase is final when the launch ends: its all-reduce is simply stream-ordered behind the
+        # step (one cross-stream hand-off less on the only part of the reduction that nothing hides)
+        a, b = sg.shell_range(sg.n - 1)
+        self.overlap.reduce_async(bank.tables.grad[a * 8:b * 8])
+
+    def run(self, launch=None, record=False):
+        """launch: a callable that enqueues one step built with dp=self.signals (default: the eager
+        step; a graph's replay otherwise).  record: time the eager step's stages and the exposed wait."""
+        out = launch() if launch is not None else self.eager(record=record)
+        self._enqueue_reductions()
+        bank = self.pipe.bank
+        self.pipe.timer.run("grad_allreduce", self.overlap.wait, record,
+                            bytes=(bank.tables.numel() + bank.weights.numel()) * 4)
+        return out
+
+
 def gather_frame(local_rgb, nr_rays, rank, world, chunk=16384, group=None, force=False):
     """Rank 0 receives the full [nr_rays,3] frame (rendering needs no other
     collective: every rank writes its own tiles).  force: run the collective in a one-rank group too."""

@@ -212,7 +212,33 @@ class KShellPipeline:
         }
         return self.last_hits, self.last_slots
 
-    def capture_graph(self):
+    def capture_graph_split(self, **step_kw):
+        """The step as TWO graphs: `replay_prefix()` = what does not read a parameter or touch a
+        gradient (ray tile order, traversal, mark / compact), `replay_rest()` = everything else.  A
+        data-parallel caller launches the prefix while the previous step's gradient reduction (and, in
+        training, the optimiser) is still running, waits, then launches the rest
+        (parallel.OverlappedStep.run_split)."""
+        self._static_rgb = None
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self.step(**step_kw)
+        torch.cuda.current_stream().wait_stream(s)
+        self._graph_prefix, self._graph_rest = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph_prefix):
+            self.step(part="prefix", **step_kw)
+        with torch.cuda.graph(self._graph_rest, pool=self._graph_prefix.pool()):
+            self._static_rgb = self.step(part="rest", **step_kw)
+
+    def replay_prefix(self):
+        self._graph_prefix.replay()
+
+    def replay_rest(self):
+        self._graph_rest.replay()
+        return self._static_rgb
+
+    def capture_graph(self, **step_kw):
         """Capture one whole step (zero_grad .. backward: ~25 launches on one stream, no
         host sync) into a HIP graph; `replay()` then costs one graph launch instead of
         the per-kernel host overhead of the eager path."""
@@ -221,31 +247,49 @@ class KShellPipeline:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(2):
-                self.step()
+                self.step(**step_kw)
         torch.cuda.current_stream().wait_stream(s)
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
-            self._static_rgb = self.step()
+            self._static_rgb = self.step(**step_kw)
         return self._graph
 
     def replay(self):
         self._graph.replay()
         return self._static_rgb
 
-    def step(self, record=False, grad_ready=None):
+    def step(self, record=False, grad_ready=None, dp=None, part=None):
         """zero_grad -> forward -> L1 loss -> backward (trainer.py:118-264 without
         the optimiser step).  Returns the predicted rgb [N,3].
 
         grad_ready(tensor), if given, is called as soon as a gradient tensor is final on
         the current stream: once with weights.grad, then once per shell with that shell's
         contiguous slice of tables.grad (the hash-grid backward then runs shell by shell),
-        so a data-parallel caller can overlap its all-reduce with the rest of backward."""
+        so a data-parallel caller can overlap its all-reduce with the rest of backward.
+
+        dp (parallel.StepSignals): the same overlap WITHOUT splitting anything — the step stays one
+        stream of launches (graph-capturable); the device publishes "weights.grad final" and "phase p
+        of tables.grad final" in dp's flags and parallel.OverlappedStep's side stream waits on them.
+
+        part: None = the whole step; "prefix" = only its parameter- and gradient-free head (ray tile
+        order, traversal, mark / compact), "rest" = the remainder of a step whose prefix has run."""
         from .composite import composite_fwd_raw, composite_bwd_raw
         N, K = self.nr_rays, self.K
         T, bank = self.timer, self.bank
         acct = getattr(self, "acct", None) or {}     # algorithmic bytes per stage (stats())
 
+        if part == "rest":
+            rays_d, gt, hit_slot, tex_uv = self._prefix_out
+        else:
+            rays_d, gt, hit_slot, tex_uv = self._step_prefix(record, acct)
+            if part == "prefix":
+                self._prefix_out = (rays_d, gt, hit_slot, tex_uv)
+                return None
         T.run("zero_grad", bank.zero_grads, record, bytes=(bank.tables.numel() + bank.weights.numel()) * 4)
+        return self._step_rest(record, acct, grad_ready, dp, rays_d, gt, hit_slot, tex_uv)
+
+    def _step_prefix(self, record, acct):
+        N, T, bank = self.nr_rays, self.timer, self.bank
         rays_o, rays_d, gt = self.rays_o, self.rays_d, self.gt
         if self.image_hw is not None:
             H, W = self.image_hw
@@ -262,6 +306,11 @@ class KShellPipeline:
         tex_uv = T.run("nt_mark_compact",
                        lambda: bank.mark_and_compact(hit_slot, hit_uv, self.face_uvs), record,
                        bytes=acct.get("nt_mark_compact", 0))
+        return rays_d, gt, hit_slot, tex_uv
+
+    def _step_rest(self, record, acct, grad_ready, dp, rays_d, gt, hit_slot, tex_uv):
+        N, K = self.nr_rays, self.K
+        T, bank = self.timer, self.bank
         mlp_flops = getattr(self, "mlp_flops_fwd", 0)
         from . import neural_textures as _nt
         if _nt.FUSED_FORWARD is True:      # encode + MLP as one launch (csrc/nt_fused.hip): VSA_NT_FUSED=1
@@ -283,6 +332,11 @@ class KShellPipeline:
                               lambda: composite_fwd_bwd_l1_raw(rgb_k, alpha_k, self.bg, gt,
                                                                1.0 / (3.0 * self.loss_rays)),
                               record, bytes=N * (12 + 12 + 32 * K))
+        if self.image_hw is not None:      # colours back in the caller's (row-major) order
+            T.run("rgb_row_order", lambda: _lib.call("vsa_tile_order", rgb, self._rgb_out, self.image_hw[0],
+                                                     self.image_hw[1], 3, 1, _lib.stream_ptr()),
+                  record, bytes=N * 24)
+            rgb = self._rgb_out
         tris = self.tracer.tris
         T.run("nt_shade_bwd", lambda: bank.backward_shade(hit_slot, tex_uv, rays_d, tris, g_c, g_a,
                                                            self.grad_scale, self._act), record,
@@ -290,7 +344,11 @@ class KShellPipeline:
         T.run("nt_mlp_bwd", lambda: bank.backward_mlp(self.grad_scale), record,
               bytes=acct.get("nt_mlp_bwd", 0), flops=2 * mlp_flops, bound="mfma")
         enc_bytes = acct.get("nt_encode_bwd", 0)
-        if grad_ready is None:
+        if dp is not None:
+            _lib.call("vsa_dp_signal", dp.flag_w, dp.epoch, 1, _lib.stream_ptr())
+            T.run("nt_encode_bwd", lambda: bank.backward_encode_phased(self.grad_scale, dp), record,
+                  bytes=enc_bytes)
+        elif grad_ready is None:
             T.run("nt_encode_bwd", lambda: bank.backward_encode(self.grad_scale), record,
                   bytes=enc_bytes)
         else:
@@ -301,9 +359,4 @@ class KShellPipeline:
                     bank.backward_encode(self.grad_scale, shells=(s, s + 1))
                     grad_ready(bank.tables.grad[s * 8:(s + 1) * 8])
             T.run("nt_encode_bwd", by_shell, record, bytes=enc_bytes)
-        if self.image_hw is not None:      # colours back in the caller's (row-major) order
-            T.run("rgb_row_order", lambda: _lib.call("vsa_tile_order", rgb, self._rgb_out, self.image_hw[0],
-                                                     self.image_hw[1], 3, 1, _lib.stream_ptr()),
-                  record, bytes=N * 24)
-            return self._rgb_out
         return rgb
