@@ -117,13 +117,12 @@ int vsa_bvh_export(const vsa_bvh* bvh, float* nodes_out, float* tris_out, int no
  * frame_out [6] = grid origin xyz and step xyz, tris_out as vsa_bvh_export. */
 int vsa_bvh_export_q(const vsa_bvh* bvh, uint32_t* qnodes_out, float* tris_out, int node_base,
                      int tri_base, float* frame_out);
-/* 4-wide quantised export for vsa_trace_q4: the binary tree collapsed so that a node holds up to
- * four child boxes (half the dependent node fetches per ray).  qnodes4_out [nr_nodes (the binary
- * count: an upper bound), 16] u32: slot s = box in dwords 3s..3s+2 (as vsa_bvh_export_q), reference
- * in dword 12+s (node index into this array >= 0, leaf code, or 0x7fffffff = empty slot); the
- * root is entry 0.  *nr_nodes4 = entries written, *max_depth4 = depth of the collapsed tree. */
-int vsa_bvh_export_q4(const vsa_bvh* bvh, uint32_t* qnodes4_out, float* tris_out, int node_base,
-                      int tri_base, float* frame_out, int* nr_nodes4, int* max_depth4);
+/* Refit after the vertices moved (same faces, same nr_verts as the build): triangle records and
+ * child boxes are recomputed in place, bottom-up; leaf order — hence every triangle slot id and any
+ * per-slot table of the caller — is unchanged.  Re-export afterwards.  Closest hits through the
+ * refitted tree are bit-identical to those of a fresh build (the boxes only prune).
+ * Replaces re-running `RayTracer(tensor_meshes)` (volsurfs.py:82-128) when only positions changed. */
+int vsa_bvh_refit(vsa_bvh* bvh, const float* verts, int nr_verts);
 int vsa_bvh_destroy(vsa_bvh* bvh);
 
 /* vsa_trace: closest hit of every ray against each of nr_meshes BVHs in ONE
@@ -147,23 +146,6 @@ int vsa_trace_q(const uint32_t* qnodes, const float* tris, const int32_t* mesh_r
                 const float* mesh_frames, int nr_meshes, int max_depth, const float* rays_o,
                 const float* rays_d, int nr_rays, float t_min, float* hit_t, int32_t* hit_slot,
                 float* hit_uv, void* stream);
-/* vsa_trace_q as three launches that cut long walks into pieces (identical results): pass A is
- * vsa_trace_q's kernel, but a wave stops after round_budget (>= 1) trips of its walk loop and hands every
- * subtree its lanes still hold (node in hand + stack entries, each with the ray's best t so far as
- * bound) to pass B, which walks one subtree per lane in dense persistent waves; pass C merges the
- * pieces of a ray (smallest t, ties -> smallest face id) and writes its hit record.  Why: a few
- * grazing rays per wave otherwise keep 4 % of the waves alive for 10x the median walk and leave the
- * chip draining for a third of the launch (profiles/NOTEBOOK.md A9.4).  workspace: device memory, 16-byte
- * aligned, >= 400 bytes, contents irrelevant on entry, not preserved;
- * vsa_trace_q_workspace_bytes(nr_rays, nr_meshes) (< 0 on bad arguments) is the recommended size
- * (room for a quarter of the (ray, shell) pairs); a hand-over that does not fit the workspace is not
- * made (those waves walk on), so the result never depends on its size.  max_depth < 48. */
-long long vsa_trace_q_workspace_bytes(int nr_rays, int nr_meshes);
-int vsa_trace_q_budgeted(const uint32_t* qnodes, const float* tris, const int32_t* mesh_roots,
-                         const float* mesh_frames, int nr_meshes, int max_depth, const float* rays_o,
-                         const float* rays_d, int nr_rays, float t_min, float* hit_t,
-                         int32_t* hit_slot, float* hit_uv, int round_budget, void* workspace,
-                         long long workspace_bytes, void* stream);
 /* vsa_trace_q with the launch order taken from the previous call's measured cost (identical results):
  * every wave files itself, by the trips its walk took, into one of three lists of the NEXT call's
  * order; the next call dispatches the lists first (longest walks first), then everything else in the
@@ -185,14 +167,6 @@ int vsa_trace_q_fb(const uint32_t* qnodes, const float* tris, const int32_t* mes
                    const float* mesh_frames, int nr_meshes, int max_depth, const float* rays_o,
                    const float* rays_d, int nr_rays, float t_min, float* hit_t, int32_t* hit_slot,
                    float* hit_uv, void* feedback, long long feedback_bytes, int phase, void* stream);
-/* vsa_trace_q on the 4-wide nodes of vsa_bvh_export_q4 (identical results; the LDS stack holds
- * 3 x (max_depth4 - 1) entries, <= 96). */
-int vsa_trace_q4(const uint32_t* qnodes4, const float* tris, const int32_t* mesh_roots,
-                 const float* mesh_frames, int nr_meshes, int max_depth4, const float* rays_o,
-                 const float* rays_d, int nr_rays, float t_min, float* hit_t, int32_t* hit_slot,
-                 float* hit_uv, void* stream);
-
-
 /* vsa_hit_attributes: expands one mesh's hit records [N] into the dict
  * raytracelib returns (volsurfs.py:496-501): is_hit [N] u8, triangles_id [N]
  * i32 (original face index, -1 on miss), positions [N,3] = o + t d, normals
@@ -257,7 +231,8 @@ typedef struct vsa_nt_plan {
   int64_t slot_capacity;             /* rows allocated in every per-slot buffer */
   int32_t max_rays;                  /* N the buffers were sized for: a (shell,degree)
                                         segment holds <= min(4*max_rays, (R_d+2)^2) slots */
-  int32_t reserved0;
+  int32_t anchor;                    /* 0: lerp of the 2x2 texel footprint (the shipped configs, neural_texture.py:106-139);
+                                        1: anchor — the sample takes the ONE texel it falls in, unblended (:88-104) */
   int64_t row_base[VSA_MAX_SHELLS * VSA_NT_MAX_DEG + 1]; /* quads; multiples of 8; segment sd
                                         reserves min(4*max_rays,(R_d+2)^2)*VSA_NT_ROW_QUADS(d);
                                         the last entry is the allocation size */

@@ -69,25 +69,13 @@ def test_argument_errors_are_reported_not_ignored():
     assert L.vsa_packed_composite_fwd(null, null, null, null, null, null, 10, null) == ERR_ARG
     assert L.vsa_packed_composite_fwd(null, null, null, null, null, null, -1, null) == ERR_ARG
     assert L.vsa_packed_composite_bwd(null, null, null, null, null, null, null, null, 10, 1, null) == ERR_ARG
-    assert L.vsa_trace_q4(null, null, roots, null, 1, 10, null, null, 10, ctypes.c_float(0), null, null, null, null) == ERR_ARG
     fr = (ctypes.c_float * 6)(0, 0, 0, 1, 1, 1)
-    assert L.vsa_trace_q4(null, null, roots, fr, 1, 99, null, null, 10, ctypes.c_float(0), null, null, null, null) == ERR_UNSUPPORTED   # 3 x 98 stack entries
-    assert L.vsa_trace_q4(null, null, roots, fr, 1, 10, null, null, 0, ctypes.c_float(0), null, null, null, null) == 0
-    assert L.vsa_bvh_export_q4(null, null, null, 0, 0, null, null, null) == ERR_ARG
     assert L.vsa_nt_compact_frame(null, null, null, null, null, null, null, null) == ERR_ARG
     assert L.vsa_nt_rebalance(null, null) == ERR_ARG
     L.vsa_nt_balance_bytes.restype = ctypes.c_longlong
     assert L.vsa_nt_balance_bytes() == 4 * (6 * 1025 + 6 * 1024 + 12 + 6 * 1024)
     L.vsa_nt_balance_bytes.restype = ctypes.c_int
     ll = ctypes.c_longlong
-    assert L.vsa_trace_q_budgeted(null, null, roots, fr, 1, 10, null, null, 10, ctypes.c_float(0), null, null, null, 24,
-                                  null, ll(1 << 20), null) == ERR_ARG                                  # null arrays
-    assert L.vsa_trace_q_budgeted(null, null, roots, fr, 1, 10, null, null, 10, ctypes.c_float(0), null, null, null, 0,
-                                  null, ll(1 << 20), null) == ERR_ARG                                  # budget < 1
-    assert L.vsa_trace_q_budgeted(null, null, roots, fr, 1, 48, null, null, 10, ctypes.c_float(0), null, null, null, 24,
-                                  null, ll(1 << 20), null) == ERR_UNSUPPORTED                          # stack depth
-    assert L.vsa_trace_q_budgeted(null, null, roots, fr, 1, 10, null, null, 0, ctypes.c_float(0), null, null, null, 24,
-                                  null, ll(0), null) == 0                                              # no rays
     assert L.vsa_trace_q_fb(null, null, roots, fr, 1, 10, null, null, 10, ctypes.c_float(0), null, null, null,
                             null, ll(1 << 20), 0, null) == ERR_ARG                                        # null arrays
     assert L.vsa_trace_q_fb(null, null, roots, fr, 1, 10, null, null, 10, ctypes.c_float(0), null, null, null,
@@ -100,10 +88,12 @@ def test_argument_errors_are_reported_not_ignored():
     assert L.vsa_trace_feedback_bytes(-1, 1) < 0
     assert L.vsa_trace_feedback_bytes(640000, 5) == 2 * ((16 + 50000 + 12 * (50000 // 8 + 64) + 255) // 256 * 256) + 256
     L.vsa_trace_feedback_bytes.restype = ctypes.c_int
-    L.vsa_trace_q_workspace_bytes.restype = ctypes.c_longlong
-    assert L.vsa_trace_q_workspace_bytes(-1, 1) < 0
-    assert L.vsa_trace_q_workspace_bytes(640000, 5) == 256 + 144 * (640000 * 5 // 4 + 4096)
-    L.vsa_trace_q_workspace_bytes.restype = ctypes.c_int
+    # round-5 entry points
+    assert L.vsa_bvh_refit(null, null, 3) == ERR_ARG
+    one = (ctypes.c_int32 * 1)(1)
+    assert L.vsa_nt_encode_bwd_phased(null, null, null, f1, null, null, null, 1, one, null, null, null, null) == ERR_ARG
+    assert L.vsa_dp_signal(null, null, 1, null) == ERR_ARG
+    assert L.vsa_dp_stream_wait(null, 1, 0, null) == ERR_ARG
     # round-2 entry points
     assert L.vsa_intersect_primitive(null, null, 10, 0, f1, null, null, null, null, null, null) == ERR_ARG
     assert L.vsa_intersect_primitive(null, null, 10, 2, f1, null, null, null, null, null, null) == ERR_ARG     # kind

@@ -117,3 +117,72 @@ def test_shade_stage_end_to_end_vs_oracle_model():
         assert (err > 1e-5).float().mean() < 0.05
         assert err.max() < 0.05
         assert err.mean() < 1e-4
+
+
+@pytest.mark.gpu
+def test_anchor_branch_vs_oracle_model_and_its_gradients():
+    """VERDICT r4 missing #2: NeuralTexture(anchor=True, lerp=False) (models/neural_texture.py:88-104; the
+    oracle branch is pinned by tests/golden/sh_neural_textures_*_anchor.npz, produced by the reference class).
+    A hit marks and reads ONE texel per degree; forward and both gradients against the oracle model."""
+    from test_nt_backward import _oracle_grads
+    K, N = 2, 2000
+    bank, face_uvs, hit_slot, hit_uv, tris, rays_d = _scene(K, N, 5, anchor=True, lerp=False)
+    tex_uv = bank.mark_and_compact(hit_slot, hit_uv, face_uvs)
+    nhits = int((hit_slot >= 0).sum())
+    assert 0 < int(bank.seg_start[K * 4]) <= 4 * nhits          # one texel per (hit, degree): a quarter of lerp's
+    bank.encode()
+    bank.mlp()
+    rgb, alpha, normals, coeffs = bank.shade(hit_slot, tex_uv, rays_d, tris, True, True)
+    torch.cuda.synchronize()
+    for s in range(K):
+        hit = (hit_slot[s] >= 0).cpu()
+        uv, dirs = tex_uv[s].cpu()[hit], rays_d.cpu()[hit]
+        for typ, C in ((0, 3), (1, 1)):
+            texs = []
+            for d in range(4):
+                x = bank.tex_index(s, typ, d)
+                w1, w2, w3 = unpack_weights(bank.weights_h[x].cpu().float())
+                texs.append(ONT.NeuralTextureOracle(bank.tex_res[d], C * (2 * d + 1), (-15, 15),
+                                                    bank.tables_h[x].cpu().float(), w1, w2, w3,
+                                                    anchor=True, lerp=False))
+            ref = ONT.sh_neural_textures_forward(texs, uv, dirs, C, 3)
+            if typ == 0:
+                got = rgb[:, s].cpu()[hit]
+            else:
+                got = alpha[:, s].cpu()[hit][:, None]
+                ref = ref * ONT.alpha_decay(dirs, normals[:, s].cpu()[hit])
+            err = (got - ref).abs()
+            # as the lerp test: differences only where an 8-bit texel flipped (fp32 summation order of the MLP)
+            assert (err > 1e-5).float().mean() < 0.05 and err.max() < 0.05 and err.mean() < 1e-4
+    g = torch.Generator().manual_seed(0)
+    g_rgb = (torch.randn(N, K, 3, generator=g) / N).cuda()
+    g_alpha = (torch.randn(N, K, generator=g) / N).cuda()
+    bank.backward(hit_slot, tex_uv, rays_d, tris, g_rgb, g_alpha, grad_scale=float(N))
+    torch.cuda.synchronize()
+    gw, gt = bank.weights.grad.cpu(), bank.tables.grad.cpu()
+    import oracle.neural_texture as _o
+    keep = _o.NeuralTextureOracle.__init__.__defaults__
+    try:        # _oracle_grads builds default-flag textures: make anchor the default for this call
+        _o.NeuralTextureOracle.__init__.__defaults__ = (None, True, False, True, True)
+        for s in range(K):
+            leaves = _oracle_grads(bank, s, hit_slot, tex_uv, rays_d, normals, g_rgb, g_alpha, True)
+            for x, (table, w1, w2, w3) in leaves.items():
+                ref_w = torch.cat([w1.grad.flatten(), w2.grad.flatten(), w3.grad.flatten()])
+                assert (gw[x] - ref_w).abs().max() <= 2e-2 * ref_w.abs().max()
+                assert torch.nn.functional.cosine_similarity(gw[x], ref_w, dim=0) > 0.9995
+                assert (gt[x] - table.grad).abs().max() <= 3e-2 * table.grad.abs().max()
+                assert torch.nn.functional.cosine_similarity(gt[x].flatten(), table.grad.flatten(), dim=0) > 0.9995
+    finally:
+        _o.NeuralTextureOracle.__init__.__defaults__ = keep
+
+
+def test_texture_switches_are_never_silently_the_default():
+    """anchor and lerp together / neither; quantise without squeeze: the reference exits (neural_texture.py:47-51,
+    141-147; sh_neural_textures.py:32-36).  The f16-row variants are not built and say so."""
+    from volsurfs_amd.neural_textures import NeuralTextureBank
+    for kw, exc in ((dict(anchor=True, lerp=True), ValueError), (dict(anchor=False, lerp=False), ValueError),
+                    (dict(quantize_output=True, squeeze_output=False), ValueError),
+                    (dict(quantize_output=False), NotImplementedError),
+                    (dict(quantize_output=False, squeeze_output=False), NotImplementedError)):
+        with pytest.raises(exc):
+            NeuralTextureBank(1, 64, device="cpu", **kw)

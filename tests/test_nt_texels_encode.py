@@ -107,3 +107,39 @@ def test_compact_empty_and_full():
     bank.mark_and_compact(hs, torch.zeros(1, 64, 2).cuda(), torch.zeros(4, 6).cuda())
     assert bank.seg_start.cpu().tolist()[:5] == [0, 0, 0, 0, 0]
     assert (bank.slot_of == -1).all()
+
+
+@pytest.mark.gpu
+def test_dense_level_larger_than_the_pair_offset_is_not_paired():
+    """the paired dense-level forward stages the alpha table at a fixed LDS offset of
+    15 360 entries; a grid whose dense level is larger (per_level_scale 2: 128^2 = 16 384 entries) used to
+    overwrite the colour table's tail.  Such a level is now walked once per texture: features bit-exact
+    against the oracle on that geometry, forward and (same planes) backward finite."""
+    from volsurfs_amd.neural_textures import NeuralTextureBank
+    grid = dict(per_level_scale=2.0)
+    geom = tcnn_like.GridGeometry(per_level_scale=2.0)
+    assert max(s for s, r in zip(geom.size, geom.res) if r * r <= s + 7) == 16384
+    K, N = 1, 2000
+    g = torch.Generator().manual_seed(5)
+    face_uvs = torch.rand(200, 6, generator=g)
+    hit_slot = torch.randint(0, 200, (K, N), generator=g, dtype=torch.int32)
+    bu = torch.rand(K, N, generator=g)
+    hit_uv = torch.stack([bu, torch.rand(K, N, generator=g) * (1 - bu)], -1)
+    bank = NeuralTextureBank(K, N, device="cuda", seed=3, grid=grid)
+    assert bank.n_entries == geom.offset[-1]
+    with torch.no_grad():
+        bank.tables.copy_((torch.rand(bank.tables.shape, generator=g) * 2 - 1))
+    bank.refresh_half_params()
+    bank.mark_and_compact(hit_slot.cuda(), hit_uv.cuda(), face_uvs.cuda())
+    bank.encode()
+    feats = bank.features_level_major()
+    torch.cuda.synchronize()
+    seg = bank.seg_start.cpu().numpy()
+    xy_all = bank.slot_xy.cpu()
+    for d in range(4):
+        xy = xy_all[seg[d]:seg[d + 1]]
+        for typ in range(2):
+            x = bank.tex_index(0, typ, d)
+            ref = tcnn_like.hashgrid_forward(geom, bank.tables[x].detach().cpu(), xy)
+            got = feats[typ, :, seg[d]:seg[d + 1]].cpu().permute(1, 0, 2).reshape(-1, 32)
+            assert torch.equal(got, ref), (typ, d)

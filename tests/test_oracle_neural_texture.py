@@ -21,11 +21,14 @@ def _model(z):
         assert abs(w3.double().sum().item() - z[f"param_sum_{deg}"][1]) < 1e-6
         ps = [t.clone().requires_grad_(True) for t in (table, w1, w2, w3)]
         leaves.append(ps)
-        texs.append(NT.NeuralTextureOracle(res[deg], C * (2 * deg + 1), (-15, 15), *ps))
+        flags = dict(zip(("anchor", "lerp", "quantize_output", "squeeze_output"), z["flags"].tolist())) \
+            if "flags" in z.files else {}
+        texs.append(NT.NeuralTextureOracle(res[deg], C * (2 * deg + 1), (-15, 15), *ps, **flags))
     return texs, leaves, C, sh_deg
 
 
-@pytest.mark.parametrize("name", ["rgb", "alpha", "alpha_deg0"])
+# (r5: the reference classes were also run with anchor=True, with squeeze but no quantisation, and with neither)
+@pytest.mark.parametrize("name", ["rgb", "alpha", "alpha_deg0", "rgb_anchor", "alpha_anchor", "rgb_noquant", "rgb_raw"])
 def test_restatement_matches_reference_classes(golden_dir, name):
     z = np.load(os.path.join(golden_dir, f"sh_neural_textures_{name}.npz"))
     texs, leaves, C, sh_deg = _model(z)

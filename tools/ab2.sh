@@ -4,6 +4,7 @@
 ROUNDS=${ROUNDS:-2}
 B='timeout 300 python bench.py --no-cpu-baseline --no-noisy --steps 30 --warmup 5 2>&1 | tail -1 | python -c "import json,sys,os; d=json.loads(sys.stdin.read()); s=d[\"stages_ms\"]; ks=os.environ.get(\"STAGES\",\"\").split() or list(s); print(round(d[\"value\"],1), {k: round(s[k],4) for k in ks if k in s})"'
 cp volsurfs_amd/libvolsurfs_hip.so /tmp/base.so
+trap 'cp /tmp/base.so volsurfs_amd/libvolsurfs_hip.so' EXIT
 for r in $(seq $ROUNDS); do
   for v in base "$@"; do
     if [ $v = base ]; then cp /tmp/base.so volsurfs_amd/libvolsurfs_hip.so; else cp variants/lib_$v.so volsurfs_amd/libvolsurfs_hip.so; fi

@@ -148,11 +148,18 @@ def gen_nt():
     from volsurfs_py.models.sh_neural_textures import SHNeuralTextures
     from volsurfs_py.encodings.sphericalharmonics import SHEncoder
 
-    for name, C, sh_deg, seed, M in [("rgb", 3, 3, 11, 256), ("alpha", 1, 3, 12, 256),
-                                     ("alpha_deg0", 1, 0, 13, 128)]:
+    # (r5: + the branches no shipped config sets — anchor, squeeze without quantise, neither —
+    #  neural_texture.py:88-104, 159-169, 183-187)
+    for name, C, sh_deg, seed, M, flags in [
+            ("rgb", 3, 3, 11, 256, {}), ("alpha", 1, 3, 12, 256, {}), ("alpha_deg0", 1, 0, 13, 128, {}),
+            ("rgb_anchor", 3, 3, 14, 128, dict(anchor=True, lerp=False)),
+            ("alpha_anchor", 1, 3, 15, 128, dict(anchor=True, lerp=False)),
+            ("rgb_noquant", 3, 2, 16, 96, dict(quantize_output=False)),
+            ("rgb_raw", 3, 2, 17, 96, dict(quantize_output=False, squeeze_output=False))]:
+        kw = dict(anchor=False, lerp=True, quantize_output=True, squeeze_output=True)
+        kw.update(flags)
         model = SHNeuralTextures(sh_deg=sh_deg, nr_channels=C, sh_range=[15, 15, 15, 15],
-                                 anchor=False, lerp=True, deg_res=[2048, 1024, 512, 256],
-                                 quantize_output=True, squeeze_output=True, align_to_webgl=True)
+                                 deg_res=[2048, 1024, 512, 256], align_to_webgl=True, **kw)
         from oracle.neural_texture import make_test_params
         params = make_test_params(seed, C, sh_deg)
         with torch.no_grad():
@@ -174,6 +181,8 @@ def gen_nt():
         arrs = dict(uv=uv.numpy(), dirs=dirs.numpy(), out=out.detach().numpy(),
                     coeffs=coeffs.detach().numpy(), gt=gt.numpy(), seed=np.array(seed),
                     nr_channels=np.array(C), sh_deg=np.array(sh_deg))
+        if flags:
+            arrs["flags"] = np.array([int(kw[k]) for k in ("anchor", "lerp", "quantize_output", "squeeze_output")])
         for deg in range(sh_deg + 1):
             nt = model.neural_textures[deg]
             arrs[f"param_sum_{deg}"] = np.array([nt.encoding.params.double().sum().item(),

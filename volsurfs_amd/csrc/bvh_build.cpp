@@ -50,6 +50,8 @@ struct BuildNode {
 struct vsa_bvh {
   std::vector<BuildNode> nodes;
   std::vector<float> tris;  // 12 floats per triangle, leaf order
+  std::vector<int32_t> faces;   // the connectivity it was built on (vsa_bvh_refit)
+  int nr_verts = 0;
   int max_depth = 0;
   Box root_box;
 };
@@ -196,6 +198,8 @@ extern "C" int vsa_bvh_build(const float* verts, const int32_t* faces, int nr_ve
   for (size_t i = 0; i < (size_t)nr_faces * 3; ++i)
     if (faces[i] < 0 || faces[i] >= nr_verts) return VSA_ERR_ARG;
   vsa_bvh* bvh = new vsa_bvh();
+  bvh->faces.assign(faces, faces + (size_t)nr_faces * 3);
+  bvh->nr_verts = nr_verts;
   Builder b;
   b.verts = verts;
   b.faces = faces;
@@ -335,88 +339,55 @@ extern "C" int vsa_bvh_export_q(const vsa_bvh* bvh, uint32_t* qnodes_out, float*
   return VSA_OK;
 }
 
-// 4-wide quantised export for vsa_trace_q4: the binary tree collapsed so that a node holds up to
-// FOUR child boxes (a child that is an inner node is replaced by ITS two children, largest box
-// first, until four slots are filled or only leaves are left).  A traversal is a chain of
-// dependent node fetches, and the PMC counters of the binary kernel show it waiting on exactly that
-// (53 % of its wave cycles in s_waitcnt at 47 % VALU-busy, 10 resident waves per CU): half the
-// levels = half the chain.  64-byte nodes: slot s has its 6 x u16 box in dwords 3s .. 3s+2 (the
-// layout of vsa_bvh_export_q) and its reference in dword 12 + s: node index >= 0 (into THIS
-// array), leaf code ~((first_tri << 4) | count), or 0x7fffffff = empty slot (inverted box).
-// qnodes4_out must hold nr_nodes (vsa_bvh_sizes) entries of 16 dwords; *nr_nodes4 receives the
-// number written (the root is entry 0), *max_depth4 the depth of the collapsed tree.
-extern "C" int vsa_bvh_export_q4(const vsa_bvh* bvh, uint32_t* qnodes4_out, float* tris_out,
-                                 int node_base, int tri_base, float* frame_out, int* nr_nodes4,
-                                 int* max_depth4) {
-  if (!bvh || !qnodes4_out || !tris_out || !frame_out || !nr_nodes4 || !max_depth4 || node_base < 0 ||
-      tri_base < 0)
-    return VSA_ERR_ARG;
-  // the binary quantisation, reused slot by slot (same frame, same outward rounding)
-  std::vector<uint32_t> q2(bvh->nodes.size() * 8);
-  int rc = vsa_bvh_export_q(bvh, q2.data(), tris_out, 0, tri_base, frame_out);
-  if (rc) return rc;
-  struct Slot { int node, child; };                   // child `child` of binary node `node`
-  auto slot_ref = [&](const Slot& s) { return bvh->nodes[s.node].ref[s.child]; };
-  auto slot_empty = [&](const Slot& s) { return slot_ref(s) < 0 && bvh->nodes[s.node].cnt[s.child] == 0; };
-  std::vector<int> new_index(bvh->nodes.size(), -1);
-  std::vector<std::pair<int, int>> work;              // (binary node, depth)
-  std::vector<int> emitted;                           // binary node of every 4-wide node, in output order
-  work.push_back({0, 1});
-  new_index[0] = 0;
-  emitted.push_back(0);
-  std::vector<std::vector<Slot>> slots_of;            // per emitted node
-  int depth4 = 1;
-  size_t head = 0;
-  while (head < emitted.size()) {                     // breadth first: the top of the tree is contiguous
-    const int bn = emitted[head];
-    const int depth = work[head].second;
-    ++head;
-    depth4 = std::max(depth4, depth);
-    std::vector<Slot> sl = {{bn, 0}, {bn, 1}};
-    while (sl.size() < 4) {
-      int best = -1;
-      float best_area = -1.f;
-      for (size_t i = 0; i < sl.size(); ++i) {
-        if (slot_ref(sl[i]) < 0) continue;             // a leaf (or empty) stays
-        const float a = bvh->nodes[sl[i].node].box[sl[i].child].area();
-        if (a > best_area) best_area = a, best = (int)i;
-      }
-      if (best < 0) break;
-      const int inner = slot_ref(sl[best]);
-      sl[best] = {inner, 0};
-      sl.push_back({inner, 1});
-    }
-    for (const Slot& s : sl) {
-      const int r = slot_ref(s);
-      if (r >= 0 && new_index[r] < 0) {
-        new_index[r] = (int)emitted.size();
-        emitted.push_back(r);
-        work.push_back({r, depth + 1});
-      }
-    }
-    slots_of.push_back(sl);
+// Refit: the vertices moved, the connectivity did not.  Every triangle record is
+// re-formed from the new positions (leaf order, hence every triangle slot and the per-slot uv table, is
+// unchanged) and the child boxes are recomputed bottom-up: nodes were emitted parent before children, so
+// one pass over the node array from its end sees both children of a node before the node itself.  The
+// topology keeps the SAH quality of the positions it was built on; hits stay exact whatever the boxes'
+// quality (they only prune), i.e. bit-identical to a rebuild's and to brute force.
+extern "C" int vsa_bvh_refit(vsa_bvh* bvh, const float* verts, int nr_verts) {
+  if (!bvh || !verts || nr_verts != bvh->nr_verts) return VSA_ERR_ARG;
+  const size_t nt = bvh->tris.size() / 12;
+  std::vector<Box> tbox(nt);
+  Box all;
+  for (size_t i = 0; i < nt; ++i) {
+    float* t = bvh->tris.data() + 12 * i;
+    int32_t id;
+    std::memcpy(&id, t + 3, 4);
+    const float* a = verts + 3 * (size_t)bvh->faces[3 * (size_t)id + 0];
+    const float* b = verts + 3 * (size_t)bvh->faces[3 * (size_t)id + 1];
+    const float* c = verts + 3 * (size_t)bvh->faces[3 * (size_t)id + 2];
+    t[0] = a[0], t[1] = a[1], t[2] = a[2];
+    t[4] = b[0] - a[0], t[5] = b[1] - a[1], t[6] = b[2] - a[2];
+    t[8] = c[0] - a[0], t[9] = c[1] - a[1], t[10] = c[2] - a[2];
+    Box bx;
+    bx.grow(V3{a[0], a[1], a[2]});
+    bx.grow(V3{b[0], b[1], b[2]});
+    bx.grow(V3{c[0], c[1], c[2]});
+    tbox[i] = bx;
+    all.grow(bx);
   }
-  for (size_t i = 0; i < emitted.size(); ++i) {
-    uint32_t* o = qnodes4_out + 16 * i;
-    const std::vector<Slot>& sl = slots_of[i];
-    for (int s = 0; s < 4; ++s) {
-      if (s < (int)sl.size() && !slot_empty(sl[s])) {
-        const uint32_t* src = q2.data() + 8 * (size_t)sl[s].node;
-        o[3 * s + 0] = src[3 * sl[s].child + 0];
-        o[3 * s + 1] = src[3 * sl[s].child + 1];
-        o[3 * s + 2] = src[3 * sl[s].child + 2];
-        const int r = slot_ref(sl[s]);
-        o[12 + s] = r >= 0 ? (uint32_t)(new_index[r] + node_base) : src[6 + sl[s].child];
+  Builder pd;      // (only for padded(): the same conservative widening as the build)
+  const float dx = all.hi.x - all.lo.x, dy = all.hi.y - all.lo.y, dz = all.hi.z - all.lo.z;
+  pd.pad = 1e-6f * std::sqrt(dx * dx + dy * dy + dz * dz);
+  bvh->root_box = pd.padded(all);
+  std::vector<Box> raw(2 * bvh->nodes.size());       // un-padded child boxes
+  for (size_t i = bvh->nodes.size(); i-- > 0;) {
+    BuildNode& n = bvh->nodes[i];
+    for (int c = 0; c < 2; ++c) {
+      if (n.ref[c] < 0 && n.cnt[c] == 0) continue;   // the empty child of a one-leaf tree
+      Box bx;
+      if (n.ref[c] < 0) {
+        for (int k = 0; k < n.cnt[c]; ++k) bx.grow(tbox[(size_t)(~n.ref[c]) + k]);
       } else {
-        o[3 * s + 0] = 65535u | (65535u << 16);        // inverted box: never hit
-        o[3 * s + 1] = 65535u;
-        o[3 * s + 2] = 0u;
-        o[12 + s] = 0x7fffffffu;
+        if ((size_t)n.ref[c] <= i) return VSA_ERR_UNSUPPORTED;   // not a pre-order tree: not built by vsa_bvh_build
+        bx.grow(raw[2 * (size_t)n.ref[c]]);
+        bx.grow(raw[2 * (size_t)n.ref[c] + 1]);
       }
+      raw[2 * i + c] = bx;
+      n.box[c] = pd.padded(bx);
     }
   }
-  *nr_nodes4 = (int)emitted.size();
-  *max_depth4 = depth4;
   return VSA_OK;
 }
 

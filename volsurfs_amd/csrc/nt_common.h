@@ -45,9 +45,19 @@ struct NtFootprint {
   float fx, fy;
 };
 
-__device__ __forceinline__ NtFootprint nt_footprint(float u, float v, int R) {
+// anchor (models/neural_texture.py:88-104, `anchor=True`): the sample snaps to ONE texel — pixel
+// (floor(u R), floor(v R)) clamped to the texture (uv_coords_to_pix), rotated i, j -> (R - 1) - j, i — and
+// takes its value unblended: (i0, j0) is that texel, fx = fy = 0 (lerp weights 1, 0, 0, 0).
+__device__ __forceinline__ NtFootprint nt_footprint(float u, float v, int R, bool anchor = false) {
   const float Rf = (float)R;
   const float a = u * Rf, b = v * Rf;  // non_normalize_uv_coord
+  if (anchor) {
+    NtFootprint f;
+    f.fx = f.fy = 0.f;
+    f.i0 = (R - 1) - min(max((int)floorf(b), 0), R - 1);
+    f.j0 = min(max((int)floorf(a), 0), R - 1);
+    return f;
+  }
   const float ap = Rf - b;             // rotate 90 (neural_texture.py:114-121)
   const float bp = a;
   const float fl_x = floorf(ap - 0.5f), fl_y = floorf(bp - 0.5f);

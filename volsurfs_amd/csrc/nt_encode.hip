@@ -89,7 +89,13 @@ __device__ __forceinline__ void nt_encode_fwd_body(
                               [&](int pl, int tex, int first, int last, int, int) {
     const int level = level0 + pl;
     const LevelGeom g = level_geom(plan, level);
-    const int tex2 = pair_mode ? nt_pair_partner(plan, tex) : -1;
+    // (a pair stages its second table at the fixed offset ENC_PAIR_OFF: a dense level of another grid
+    //  geometry that is larger than that — up to LDS_ENTRIES is accepted — is walked once per texture instead)
+    const int partner = pair_mode ? nt_pair_partner(plan, tex) : -1;
+    const bool pair_fits = (int)g.size <= ENC_PAIR_OFF && ENC_PAIR_OFF + (int)g.size <= LDS_ENTRIES;
+    const int tex2 = pair_fits ? partner : -1;
+    for (int pass = 0; pass < (partner >= 0 && !pair_fits ? 2 : 1); ++pass) {
+    const int tex_p = pass ? partner : tex;
     __syncthreads();   // the previous piece is done with the table
     auto stage = [&](int t, half2_t* dst_h) {  // stage the level (size is a multiple of 8 entries = 32 B)
       // all of a thread's loads in flight together (a 2^15-entry level is 8 x 16 B per thread; one
@@ -112,10 +118,10 @@ __device__ __forceinline__ void nt_encode_fwd_body(
           if (i0 + k * ENC_BLOCK < nvec) dst[i0 + k * ENC_BLOCK] = r[k];
       }
     };
-    stage(tex, s_tab);
+    stage(tex_p, s_tab);
     if (tex2 >= 0) stage(tex2, s_tab + ENC_PAIR_OFF);
     __syncthreads();
-    const int type = (tex / VSA_NT_MAX_DEG) & 1;
+    const int type = (tex_p / VSA_NT_MAX_DEG) & 1;
     half2_t* out = features + nt_feat_plane_base(plan, type, level);
     half2_t* out2 = features + nt_feat_plane_base(plan, 1, level);      // the alpha plane of a pair
     // A lane owns ENC_UNROLL_FWD consecutive slots (neighbouring texels of one texture
@@ -256,6 +262,7 @@ __device__ __forceinline__ void nt_encode_fwd_body(
       if (reuse) run(std::true_type{}, std::false_type{});
       else run(std::false_type{}, std::false_type{});
     }
+    }   // pass
   }, 0, 1 << 30, unit_weight, HASHED ? NT_BAL_ENC_FWD_H : NT_BAL_ENC_FWD_D, pair_mode);
   __syncthreads();
   NT_SPAN_MARK(HASHED ? 1 : 0, 1);

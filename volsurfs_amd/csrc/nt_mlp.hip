@@ -894,512 +894,9 @@ __device__ __forceinline__ void pc_run(
 #endif
 }
 
-// ---------------------------------------------------------------- backward v5 ("t"): EXPERIMENT, not in the default build
-// Built only with -DNT_MLP_BWD_T (tools/build_variant.sh t "-DNT_MLP_BWD_T -mllvm -amdgpu-mfma-vgpr-form=1")
-// and selected at run time by VSA_NT_MLP_BWD=t.  Parity-green (tests/test_nt_backward.py, test_nt_mlp.py,
-// test_pipeline_e2e.py pass with it) and SLOWER than v4: 2.24 ms against 0.60 ms (4-wave form 0.91 ms).
-// Kept because it is the measured answer to "why not one role without the LDS hand-off":
-// profiles/r04/mlp_bwd_t_stamps.txt and DESIGN.md section 5.
-#ifdef NT_MLP_BWD_T
-// One role, NO hand-off between waves: every operand of the weight gradients comes out of the matrix
-// cores in the orientation it is needed in.  The weight gradients contract over the SLOTS, so their
-// operands must sit "channel on the lane, slots in the registers" — the transpose of the chain's
-// orientation (slot on the lane).  v4 transposes through LDS images (store -> wait ->
-// ds_read_b64_tr_b16 -> wait, handed from a producer to a consumer wave behind a workgroup barrier
-// per tile); here each activation is ALSO formed in the transposed orientation by one more MFMA set
-// from the previous layer's standard-form fragments used as the A operand (guide: "an accumulator
-// tile as the next MFMA's operand", X^T . B):
-//     H1^T  = X^T  . W1^T      A = bx  (X fragments),    B = the forward W1 fragments
-//     H2^T  = H1^T . W2^T      A = b2  (H1 fragments),   B = the forward W2 fragments (same permuted k)
-//     dH2^T = dOut^T . W3      A = dOut fragments,       B = the W3^T (natural k) fragments of the dgrad
-//     dH1^T = dH2^T . W2       A = dH2 fragments,        B = the W2^T fragments of the dgrad
-// i.e. the SAME 32 weight fragments serve both orientations.  The transposed accumulators, packed to
-// f16, ARE the A / B fragments of dW2 = dH2 . H1^T, dW3's B (H2^T) and dW1's A (dH1) — their slot
-// order inside a k-step is the accumulator's row order on both operands, so it cancels.  Only dOut
-// (elementwise from the gradient rows) and X need a transpose: two 2.5 KiB private images per wave.
-// Cost: 68-72 MFMA per tile instead of 46-48 and about 1.5x the packing instructions; gone: 14 KiB of
-// image stores and 53 KiB of LDS reads per tile, the per-tile barrier, and the dependent LDS round
-// trips of both roles (v4 stamps: 3 883 cycles per tile and SIMD for 1 500 cycles of matrix work).
-// Eight waves (two per SIMD, 256 registers each): the weight gradients' 128 accumulators leave ~110
-// registers for the chain, so
-//   * the 32 weight fragments are streamed from LDS at their use,
-//   * the next tile's features and gradient rows are prefetched by global_load_lds (LDS-DMA: no
-//     destination registers) into a 4 KiB per-wave staging area a whole trip ahead; the compiler
-//     does not track LDS-DMA, the waits are explicit and the trip is ordered so that vmcnt(0) at
-//     its head only covers memory operations issued a trip earlier (dF of tile t is stored at the
-//     head of trip t+1),
-//   * sum |dF| accumulates in LDS (ds_add_f32, 16 per tile) instead of 16 more accumulators,
-//   * the phases are ordered for the shortest live ranges (H1^T is formed late, from X).
-// Measured first versions (profiles/NOTEBOOK.md round 4): 4 waves with register-resident fragments
-// 0.913 ms (one wave per SIMD: matrix and packing phases serialise, ~100 AGPR copies per tile);
-// 8 waves with register prefetch 2.16 ms (the prefetch registers spill: vmcnt(0) right behind the
-// loads exposes the memory latency several times per tile).
-#ifndef NT_T_DUAL
-#define NT_T_DUAL 0     /* bit 0 layer 2, bit 1 dH2, bit 2 dH1: both orientations' accumulators in flight together */
-#endif
-constexpr int T_WAVES = 8;
-constexpr int T_BLOCK = 64 * T_WAVES;
-constexpr int T_IMG_HALFS = 2 * 32 * S32;     // per wave: {dOut, X} images, point-major rows of S32 halfs
-constexpr int T_FRAGS = 36;                   // LDS: forward fragments 0..15, dgrad fragments at 16..31 (ids 20..35), 4 spare KiB
-constexpr int T_PART_SLOTS = 3;               // waves whose weight-gradient partials are in LDS at a time (3 x 32 KiB)
-constexpr int T_STAGE_DWORDS = 16 * 64;       // per wave: 8 feature planes + up to 8 gradient-row dword planes, 64 lanes each
-constexpr int T_OFF_IMG = T_FRAGS * 64 * 16;
-constexpr int T_OFF_STAGE = T_OFF_IMG + T_WAVES * T_IMG_HALFS * 2;
-constexpr int T_OFF_DABS = T_OFF_STAGE + T_WAVES * T_STAGE_DWORDS * 4;
-constexpr int T_LDS_BYTES = T_OFF_DABS + T_WAVES * 16 * PC_DABS_STRIDE * 4;
-static_assert(T_PART_SLOTS * PC_PART_FLOATS * 4 <= T_OFF_DABS, "the partials overlay everything but the sum|dF| rows");
-static_assert(T_LDS_BYTES <= 160 * 1024 - 1024, "LDS");
-
-// transposed read whose k (slot) order is the accumulator's row order: element j of lane half h is
-// slot 16 s + 8 (j >> 2) + 4 h + (j & 3) — what a packed transposed-form accumulator holds
-template <int STRIDE>
-__device__ __forceinline__ half8_t read_tr_perm(const _Float16* img, int col_base, int s, int lane) {
-  const int h = lane >> 5, li = lane & 15, q = li >> 2, pp = li & 3, grp = (lane >> 4) & 1;
-  const _Float16* a0 = img + (16 * s + 4 * h + q) * STRIDE + col_base + 16 * grp + 4 * pp;
-  typedef __attribute__((address_space(3))) short4v* lds_p;
-  const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0));
-  const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0 + 8 * STRIDE));
-  typedef short short8v __attribute__((__vector_size__(8 * sizeof(short))));
-  const short8v both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-  return __builtin_bit_cast(half8_t, both);
-}
-
-#ifdef NT_STAMP
-#define T_PHASE(k)                              \
-  {                                             \
-    unsigned long long now_;                    \
-    STAMP(now_);                                \
-    t_acc[k] += now_ - t_prev;                  \
-    t_prev = now_;                              \
-  }
-#else
-#define T_PHASE(k) __builtin_amdgcn_sched_barrier(0)
-#endif
-
-__device__ __forceinline__ void t_run(
-    const vsa_nt_plan& plan, const Work wk, unsigned char* s_raw,
-    const _Float16* __restrict__ weights, unsigned* __restrict__ features,
-    const int* __restrict__ seg_start, _Float16* __restrict__ grad_rows,
-    float* __restrict__ grad_weights, float* __restrict__ dfeat_abs_sum, float gw_scale) {
-  half8_t* s_fr = reinterpret_cast<half8_t*>(s_raw);                 // [T_FRAGS][64]
-  _Float16* s_img_all = reinterpret_cast<_Float16*>(s_raw + T_OFF_IMG);
-  const int tex = wk.tex;
-  const TexInfo ti = tex_info(plan, seg_start, tex);
-  const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  {
-    if (wave == 0) {
-      half8_t w0[16];
-      load_fwd_frags(weights + (long long)tex * VSA_NT_WEIGHTS_PER_TEX, lane, w0);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) s_fr[i * 64 + lane] = w0[i];
-    }
-    _Float16* W = s_img_all;     // staged copy of the weights: only until the fragments are built
-    {
-      const half8_t* Wg = reinterpret_cast<const half8_t*>(weights + (long long)tex * VSA_NT_WEIGHTS_PER_TEX);
-      for (int i = threadIdx.x; i < VSA_NT_WEIGHTS_PER_TEX / 8; i += T_BLOCK)
-        reinterpret_cast<half8_t*>(W)[i] = Wg[i];
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < 16 * 64; idx += T_BLOCK) {
-      const int frag = 20 + (idx >> 6), ln = idx & 63, r = ln & 31, hh = ln >> 5;
-      half8_t v;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        _Float16 x;
-        if (frag < 28) {                     // W2^T, perm k
-          const int f_ = frag - 20;
-          x = W[W2_OFF + perm_k(f_ & 3, hh, j) * 64 + 32 * (f_ >> 2) + r];
-        } else if (frag < 32) {              // W1^T, perm k
-          x = W[W1_OFF + perm_k(frag - 28, hh, j) * 32 + r];
-        } else {                             // W3^T, natural k
-          const int f_ = frag - 32;
-          x = W[W3_OFF + (16 * (f_ & 1) + 8 * hh + j) * 64 + 32 * (f_ >> 1) + r];
-        }
-        v[j] = x;
-      }
-      s_fr[16 * 64 + idx] = v;
-    }
-  }
-  float* const s_dabs = reinterpret_cast<float*>(s_raw + T_OFF_DABS) + wave * (16 * PC_DABS_STRIDE) + lane;
-#pragma unroll
-  for (int reg = 0; reg < 16; ++reg) s_dabs[reg * PC_DABS_STRIDE] = 0.0f;
-  __syncthreads();
-  // forward fragment i / dgrad fragment i (0..7 W2^T, 8..11 W1^T, 12..15 W3^T natural k)
-  auto WF = [&](int i) __attribute__((always_inline)) { return s_fr[i * 64 + lane]; };
-  auto TF = [&](int i) __attribute__((always_inline)) { return s_fr[(16 + i) * 64 + lane]; };
-  _Float16* img_dout = s_img_all + wave * T_IMG_HALFS;
-  _Float16* img_x = img_dout + 32 * S32;
-  unsigned* const stg = reinterpret_cast<unsigned*>(s_raw + T_OFF_STAGE) + wave * T_STAGE_DWORDS;
-  const int ntiles = (wk.last - wk.first + 31) >> 5;
-
-  auto run = [&](auto ng_tag) __attribute__((always_inline)) {
-    constexpr int NG = decltype(ng_tag)::value;
-    constexpr int KS3 = NG > 2 ? 2 : 1;
-    float16_t gW1[2], gW2[2][2], gW3[2];
-#ifdef NT_STAMP
-    unsigned long long t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0, t_tiles = 0;
-#endif
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      gW1[i] = float16_t{0};
-      gW3[i] = float16_t{0};
-      gW2[i][0] = float16_t{0};
-      gW2[i][1] = float16_t{0};
-    }
-    const unsigned* const grow_base = reinterpret_cast<const unsigned*>(
-        reinterpret_cast<const half4_t*>(grad_rows) + ti.row_first);
-    typedef __attribute__((address_space(3))) void* lds_vp;
-    // LDS-DMA of one tile's operands: feature dword (s, i) of this lane -> plane 4 s + i, gradient
-    // row dword (g, i2) -> plane 8 + 2 g + i2 (past the end: the last slot's again).  Buffer form:
-    // ONE offset register per stream, the plane / dword constants ride in the scalar offset.
-    const __amdgpu_buffer_rsrc_t rs_f = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(features + nt_feat_plane_base(plan, ti.type, 0)), 0, -1, 0x00027000);
-    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)grow_base, 0, -1, 0x00027000);
-    auto request = [&](int slot) __attribute__((always_inline)) {
-      const int sl = min(slot, wk.last - 1);
-      const int vf = ((sl >> 8) * (plan.n_levels * NT_FBLOCK) + (sl & 255) + 4 * h * NT_FBLOCK) * 4;
-#pragma unroll
-      for (int s_ = 0; s_ < 2; ++s_)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_f, (lds_vp)(stg + (4 * s_ + i) * 64), 4, vf,
-                                                   (8 * s_ + i) * NT_FBLOCK * 4, 0, 0);
-      const int vrow = (sl - ti.begin) * ti.row_quads * 8;
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        const int vg = vrow + (8 * g + 4 * h < ti.channels ? (2 * g + h) * 8 : 0);
-#pragma unroll
-        for (int i2 = 0; i2 < 2; ++i2)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_vp)(stg + (8 + 2 * g + i2) * 64), 4, vg, i2 * 4, 0, 0);
-      }
-    };
-    unsigned pend[8];           // dF of the previous tile, stored at the head of the next trip
-    int pend_slot = -1;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) pend[i] = 0u;
-    auto store_pending = [&]() __attribute__((always_inline)) {
-      if (pend_slot >= 0) {
-        unsigned* base = features + nt_feat_plane_base(plan, ti.type, 2 * h) + nt_feat_in_plane(plan.n_levels, pend_slot);
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) base[(4 * g + i) * NT_FBLOCK] = pend[2 * g + i];
-      }
-    };
-    if (wave < ntiles) request(wk.first + wave * 32 + p);
-    for (int tile = wave; tile < ntiles; tile += T_WAVES) {
-      const int slot = wk.first + tile * 32 + p;
-      const bool valid = slot < wk.last;
-      // ---- head of the trip: everything in flight was issued a trip ago
-#ifdef NT_STAMP
-      { unsigned long long now_; STAMP(now_); if (t_prev) t_acc[11] += now_ - t_prev; t_prev = now_; ++t_tiles; }
-#endif
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      T_PHASE(0);
-      half8_t bx[2];
-      unsigned gr[2 * NG];
-      {
-        typedef unsigned uint4v_ __attribute__((ext_vector_type(4)));
-#pragma unroll
-        for (int s_ = 0; s_ < 2; ++s_) {
-          uint4v_ u;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) u[i] = stg[(4 * s_ + i) * 64 + lane];
-          bx[s_] = __builtin_bit_cast(half8_t, u);
-        }
-#pragma unroll
-        for (int g = 0; g < 2 * NG; ++g) gr[g] = stg[(8 + g) * 64 + lane];
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      store_pending();
-      if (ti.channels > 0) {   // consume-and-clear the tile's gradient rows, in memory order (as v4)
-        const int s0 = slot - p, nq = min(32, wk.last - s0) * ti.own_quads;
-        half4_t* rows = reinterpret_cast<half4_t*>(grad_rows) + ti.row_first + (long long)(s0 - ti.begin) * ti.row_quads;
-        for (int i = lane; i < nq; i += 64) {
-          const int sl = ti.own_quads == 1 ? i : (int)__umulhi((unsigned)i, ti.own_magic);
-          rows[sl * ti.row_quads + (i - sl * ti.own_quads)] = half4_t{0, 0, 0, 0};
-        }
-      }
-      request(slot + T_WAVES * 32);
-      T_PHASE(1);
-      // X image (for dW1's B operand): written first, read last
-#pragma unroll
-      for (int sx = 0; sx < 2; ++sx) *reinterpret_cast<half8_t*>(img_x + p * S32 + 16 * sx + 8 * h) = bx[sx];
-      // ---- layer 1 (standard orientation)
-      half8_t b2[4];
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        float16_t a = {0};
-#pragma unroll
-        for (int s_ = 0; s_ < 2; ++s_) a = __builtin_amdgcn_mfma_f32_32x32x16_f16(WF(m * 2 + s_), bx[s_], a, 0, 0, 0);
-        b2[2 * m] = relu_pack<true>(a, 0);
-        b2[2 * m + 1] = relu_pack<true>(a, 1);
-      }
-      T_PHASE(2);
-      // ---- layer 2, both orientations (NT_T_DUAL & 1: a fragment read serves both products, two
-      // accumulators in flight; else one after the other)
-      half8_t b3[4], h2t[4];
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        if constexpr (NT_T_DUAL & 1) {
-          float16_t a = {0}, at = {0};
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const half8_t w = WF(4 + m * 4 + q);
-            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, b2[q], a, 0, 0, 0);
-            at = __builtin_amdgcn_mfma_f32_32x32x16_f16(b2[q], w, at, 0, 0, 0);
-          }
-          b3[2 * m] = relu_pack<true>(a, 0);
-          b3[2 * m + 1] = relu_pack<true>(a, 1);
-          h2t[2 * m] = relu_pack<true>(at, 0);
-          h2t[2 * m + 1] = relu_pack<true>(at, 1);
-        } else {
-          {
-            float16_t a = {0};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a = __builtin_amdgcn_mfma_f32_32x32x16_f16(WF(4 + m * 4 + q), b2[q], a, 0, 0, 0);
-            b3[2 * m] = relu_pack<true>(a, 0);
-            b3[2 * m + 1] = relu_pack<true>(a, 1);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          {
-            float16_t at = {0};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) at = __builtin_amdgcn_mfma_f32_32x32x16_f16(b2[q], WF(4 + m * 4 + q), at, 0, 0, 0);
-            h2t[2 * m] = relu_pack<true>(at, 0);
-            h2t[2 * m + 1] = relu_pack<true>(at, 1);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      T_PHASE(3);
-      // ---- output layer and dOut = G * sigmoid'
-      {
-        float16_t acc3 = {0};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(WF(12 + q), b3[q], acc3, 0, 0, 0);
-        unsigned dq[2 * NG];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          const bool keep = 8 * g + 4 * h < ti.channels && valid;
-#pragma unroll
-          for (int i2 = 0; i2 < 2; ++i2) {
-            const half2_t o_h = {(_Float16)acc3[4 * g + 2 * i2], (_Float16)acc3[4 * g + 2 * i2 + 1]};
-            const unsigned ob = __builtin_bit_cast(unsigned, o_h);
-            const float sg0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(mul_mix<0>(ob, -1.4426950408889634f)));
-            const float sg1 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(mul_mix<1>(ob, -1.4426950408889634f)));
-            const unsigned db = mul_mix_pk(gr[2 * g + i2], __builtin_fmaf(-sg0, sg0, sg0), __builtin_fmaf(-sg1, sg1, sg1));
-            dq[2 * g + i2] = keep ? db : 0u;
-          }
-        }
-        typedef unsigned uint2v_ __attribute__((ext_vector_type(2)));
-        _Float16* row = img_dout + p * S32 + 4 * h;
-#pragma unroll
-        for (int g = 0; g < (NG > 2 ? 4 : 2); ++g)
-          *reinterpret_cast<uint2v_*>(row + 8 * g) = g < NG ? uint2v_{dq[2 * (g < NG ? g : 0)], dq[2 * (g < NG ? g : 0) + 1]} : uint2v_{0u, 0u};
-      }
-      T_PHASE(4);
-      // this point's dOut row as B / A fragments (natural channel order; same wave: in-order LDS)
-      const half8_t d0 = *reinterpret_cast<const half8_t*>(img_dout + p * S32 + 8 * h);
-      half8_t d1 = {0, 0, 0, 0, 0, 0, 0, 0};
-      if constexpr (KS3 == 2) d1 = *reinterpret_cast<const half8_t*>(img_dout + p * S32 + 16 + 8 * h);
-      // ---- dW3 += dOut . H2^T   (A: transposed read of the dOut image, B: h2t)
-#pragma unroll
-      for (int sx = 0; sx < 2; ++sx) {
-        const half8_t a3 = read_tr_perm<S32>(img_dout, 0, sx, lane);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) gW3[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3, h2t[2 * m + sx], gW3[m], 0, 0, 0);
-      }
-      T_PHASE(5);
-      // ---- dH2 in both orientations, masked by H2 > 0
-      half8_t dh2[4], dh2t[4];
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        half8_t w[KS3];
-#pragma unroll
-        for (int k = 0; k < KS3; ++k) w[k] = TF(12 + 2 * m + k);
-        {
-          float16_t a = {0};
-          a = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0], d0, a, 0, 0, 0);
-          if constexpr (KS3 == 2) a = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1], d1, a, 0, 0, 0);
-          mask_pack(a, b3[2 * m], b3[2 * m + 1], dh2[2 * m], dh2[2 * m + 1]);
-        }
-        if constexpr (!(NT_T_DUAL & 2)) __builtin_amdgcn_sched_barrier(0);
-        {
-          float16_t at = {0};
-          at = __builtin_amdgcn_mfma_f32_32x32x16_f16(d0, w[0], at, 0, 0, 0);
-          if constexpr (KS3 == 2) at = __builtin_amdgcn_mfma_f32_32x32x16_f16(d1, w[1], at, 0, 0, 0);
-          mask_pack(at, h2t[2 * m], h2t[2 * m + 1], dh2t[2 * m], dh2t[2 * m + 1]);
-        }
-        if constexpr (!(NT_T_DUAL & 2)) __builtin_amdgcn_sched_barrier(0);
-      }
-      T_PHASE(6);
-      // ---- H1^T (late: from X), dW2 += dH2 . H1^T
-      half8_t h1t[4];
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        float16_t at = {0};
-#pragma unroll
-        for (int s_ = 0; s_ < 2; ++s_) at = __builtin_amdgcn_mfma_f32_32x32x16_f16(bx[s_], WF(m * 2 + s_), at, 0, 0, 0);
-        h1t[2 * m] = relu_pack<true>(at, 0);
-        h1t[2 * m + 1] = relu_pack<true>(at, 1);
-      }
-#pragma unroll
-      for (int sx = 0; sx < 2; ++sx)
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int mj = 0; mj < 2; ++mj)
-            gW2[m][mj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh2t[2 * m + sx], h1t[2 * mj + sx], gW2[m][mj], 0, 0, 0);
-      T_PHASE(7);
-      // ---- dH1 in both orientations, masked by H1 > 0
-      half8_t dh1[4], dh1t[4];
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        if constexpr (NT_T_DUAL & 4) {
-          float16_t a = {0}, at = {0};
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const half8_t w = TF(4 * m + q);
-            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, dh2[q], a, 0, 0, 0);
-            at = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh2[q], w, at, 0, 0, 0);
-          }
-          mask_pack(a, b2[2 * m], b2[2 * m + 1], dh1[2 * m], dh1[2 * m + 1]);
-          mask_pack(at, h1t[2 * m], h1t[2 * m + 1], dh1t[2 * m], dh1t[2 * m + 1]);
-        } else {
-          {
-            float16_t a = {0};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a = __builtin_amdgcn_mfma_f32_32x32x16_f16(TF(4 * m + q), dh2[q], a, 0, 0, 0);
-            mask_pack(a, b2[2 * m], b2[2 * m + 1], dh1[2 * m], dh1[2 * m + 1]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          {
-            float16_t at = {0};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) at = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh2[q], TF(4 * m + q), at, 0, 0, 0);
-            mask_pack(at, h1t[2 * m], h1t[2 * m + 1], dh1t[2 * m], dh1t[2 * m + 1]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      T_PHASE(8);
-      // ---- dW1 += dH1 . X^T   (A: dh1t, B: transposed read of the X image)
-#pragma unroll
-      for (int sx = 0; sx < 2; ++sx) {
-        const half8_t xt = read_tr_perm<S32>(img_x, 0, sx, lane);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) gW1[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh1t[2 * m + sx], xt, gW1[m], 0, 0, 0);
-      }
-      // ---- dX = W1^T dH1 -> dF (stored at the head of the next trip), sum |dF|
-      {
-        float16_t dx = {0};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dx = __builtin_amdgcn_mfma_f32_32x32x16_f16(TF(8 + q), dh1[q], dx, 0, 0, 0);
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg)
-          __hip_atomic_fetch_add(&s_dabs[reg * PC_DABS_STRIDE], valid ? fabsf(dx[reg]) : 0.0f, __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_WAVEFRONT);
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            half2_t v;
-            v.x = (_Float16)dx[4 * g + 2 * i];
-            v.y = (_Float16)dx[4 * g + 2 * i + 1];
-            pend[2 * g + i] = __builtin_bit_cast(unsigned, v);
-          }
-        pend_slot = valid ? slot : -1;
-      }
-      T_PHASE(9);
-    }
-#ifdef NT_STAMP
-    if (threadIdx.x == 0) {
-      for (int k = 0; k < 12; ++k) atomicAdd(&g_dbg_stage[blockIdx.x * 16 + k], t_acc[k]);
-      atomicAdd(&g_dbg_stage[blockIdx.x * 16 + 12], t_tiles);
-    }
-#endif
-    store_pending();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (a request past the last tile may still be landing in the staging area)
-    // the waves' partial sums go through LDS T_PART_SLOTS waves at a time (32 KiB each, layout as v4),
-    // summed in wave order and added to the gradients with one atomic per non-zero weight
-    __syncthreads();
-    float* gw = grad_weights + (long long)tex * VSA_NT_WEIGHTS_PER_TEX;
-    const int w3_end = W3_OFF + ti.channels * 64;
-    for (int w0 = 0; w0 < T_WAVES; w0 += T_PART_SLOTS) {
-      if (wave >= w0 && wave < w0 + T_PART_SLOTS) {
-        float* const s_part = reinterpret_cast<float*>(s_raw) + (wave - w0) * PC_PART_FLOATS;
-        float* const b1_ = s_part + W1_OFF + 4 * h * 32 + p;
-        float* const b2_ = s_part + W2_OFF + 4 * h * 64 + p;
-        float* const b3_ = s_part + W3_OFF + 4 * h * 64 + p;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int r0 = (reg & 3) + 8 * (reg >> 2);
-#pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            b3_[r0 * 64 + 32 * m] = gW3[m][reg];
-            b1_[(32 * m + r0) * 32] = gW1[m][reg];
-#pragma unroll
-            for (int mj = 0; mj < 2; ++mj) b2_[(32 * m + r0) * 64 + 32 * mj] = gW2[m][mj][reg];
-          }
-        }
-      }
-      __syncthreads();
-      {
-        const float* s_all = reinterpret_cast<const float*>(s_raw);
-        const int nw = T_WAVES - w0 < T_PART_SLOTS ? T_WAVES - w0 : T_PART_SLOTS;
-        for (int i = threadIdx.x; i < w3_end; i += T_BLOCK) {
-          float v = s_all[i];
-          for (int w = 1; w < nw; ++w) v += s_all[w * PC_PART_FLOATS + i];
-          if (v != 0.0f) atomicAdd(&gw[i], v * gw_scale);
-        }
-      }
-      __syncthreads();
-    }
-  };
-  if (ti.channels <= 8) run(std::integral_constant<int, 1>{});
-  else if (ti.channels <= 16) run(std::integral_constant<int, 2>{});
-  else if (ti.channels <= 24) run(std::integral_constant<int, 3>{});
-  else run(std::integral_constant<int, 4>{});
-  if (threadIdx.x < 32) {     // sum |dF| per feature row over the waves' lanes
-    const int f = threadIdx.x;
-    float v = 0.0f;
-    for (int w = 0; w < T_WAVES; ++w) {
-      const float* d_ = reinterpret_cast<const float*>(s_raw + T_OFF_DABS) +
-                        (w * 16 + (f & 3) + 4 * (f >> 3)) * PC_DABS_STRIDE + 32 * ((f >> 2) & 1);
-#pragma unroll 8
-      for (int i = 0; i < 32; ++i) v += d_[i];
-    }
-    if (v != 0.0f) atomicAdd(&dfeat_abs_sum[tex * 32 + f], v);
-  }
-}
-
-#ifndef NT_T_RUN_COST
-#define NT_T_RUN_COST 40
-#endif
-__global__ __launch_bounds__(T_BLOCK, 2) void nt_mlp_bwd_t_kernel(
-    vsa_nt_plan plan, const _Float16* __restrict__ weights,
-    unsigned* __restrict__ features, const int* __restrict__ seg_start,
-    _Float16* __restrict__ grad_rows, float* __restrict__ grad_weights,
-    float* __restrict__ dfeat_abs_sum, float gw_scale) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-  NT_SPAN_MARK(1, 0);
-  NT_BAL_BEGIN();
-  nt_for_each_piece<32>(plan, seg_start, 1, NT_T_RUN_COST,
-                        [&](int, int tex, int first, int last, int seg_begin, int seg_end) __attribute__((always_inline)) {
-    Work wk;
-    wk.tex = tex;
-    wk.seg_len = seg_end - seg_begin;
-    wk.first = first;
-    wk.last = last;
-    t_run(plan, wk, s_raw, weights, features, seg_start, grad_rows, grad_weights, dfeat_abs_sum, gw_scale);
-    __syncthreads();
-  }, 0, 1 << 30, NtUnitWeight16(), NT_BAL_MLP_BWD);
-  NT_SPAN_MARK(1, 1);
-  NT_BAL_END(NT_BAL_MLP_BWD);
-}
-#endif   // NT_MLP_BWD_T
+// (The one-role backward "t" of round 4 — every weight-gradient operand formed transposed by the matrix
+//  cores, no LDS hand-off; parity-green, 0.91 / 2.24 ms against 0.60 — left this file in round 5: it lives in
+//  the history at e64f229 with its measurements in profiles/r04/mlp_bwd_t_*.txt and DESIGN.md section 5.)
 
 // Persistent launch: gridDim.x workgroups (one per CU; the LDS footprint allows no more)
 // split the frame's tiles evenly (nt_for_each_piece, nt_common.h): every active texture
@@ -1489,28 +986,6 @@ extern "C" int vsa_nt_mlp_bwd(const vsa_nt_plan* plan, const void* weights_h, vo
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
     attr_set = true;
   }
-#ifdef NT_MLP_BWD_T
-  // VSA_NT_MLP_BWD=t selects the one-role kernel (A/B); default: the producer / consumer pairs
-  static int use_t = -1;
-  if (use_t < 0) {
-    const char* e = getenv("VSA_NT_MLP_BWD");
-    use_t = (e && e[0] == 't') ? 1 : 0;
-    if (use_t)
-      VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(nt_mlp_bwd_t_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-  }
-  if (use_t) {
-    int cus = 0;
-    { const int rc = vsa_cu_count(&cus); if (rc) return rc; }
-    const size_t lds_t = (size_t)T_LDS_BYTES;
-    hipLaunchKernelGGL(nt_mlp_bwd_t_kernel, dim3(cus), dim3(T_BLOCK), lds_t, (hipStream_t)stream,
-                       *plan, reinterpret_cast<const _Float16*>(weights_h),
-                       reinterpret_cast<unsigned*>(features), seg_start,
-                       reinterpret_cast<_Float16*>(grad_rows), grad_weights,
-                       dfeat_abs_sum, weight_grad_scale);
-    VSA_RETURN_LAUNCH_STATUS();
-  }
-#endif
   // fragments + the larger of {image sets, the four pairs' weight-gradient partials (4 x 32 KiB)}
   constexpr size_t img_bytes = (size_t)PC_PAIRS * PAIR_HALFS * 2, part_bytes = (size_t)PC_PAIRS * PC_PART_FLOATS * 4;
   const size_t lds = (size_t)PC_FRAGS * 64 * 16 + (img_bytes > part_bytes ? img_bytes : part_bytes);

@@ -142,14 +142,17 @@ __device__ __forceinline__ bool load_ctx(const vsa_nt_plan& plan, int s, long lo
       continue;
     }
     const int R = plan.tex_res[d], W = R + 2;
-    const NtFootprint f = nt_footprint(u, v, R);
+    const bool anchor = plan.anchor != 0;
+    const NtFootprint f = nt_footprint(u, v, R, anchor);
     const long long base = plan.dom_off[s * VSA_NT_MAX_DEG + d] + (long long)(f.j0 + 1) * W + (f.i0 + 1);
     const int sd = s * VSA_NT_MAX_DEG + d;
     const int rb = (int)plan.row_base[sd] - seg_start[sd] * nt_row_quads(d);
     c.row[d][0] = rb + slot_of[base] * nt_row_quads(d);
-    c.row[d][1] = rb + slot_of[base + 1] * nt_row_quads(d);
-    c.row[d][2] = rb + slot_of[base + W] * nt_row_quads(d);
-    c.row[d][3] = rb + slot_of[base + W + 1] * nt_row_quads(d);
+    // anchor: only that texel is marked (slot_of is valid for marked texels only): the three other
+    // "corners" are the same row with weight 0
+    c.row[d][1] = anchor ? c.row[d][0] : rb + slot_of[base + 1] * nt_row_quads(d);
+    c.row[d][2] = anchor ? c.row[d][0] : rb + slot_of[base + W] * nt_row_quads(d);
+    c.row[d][3] = anchor ? c.row[d][0] : rb + slot_of[base + W + 1] * nt_row_quads(d);
     c.fx[d] = f.fx;
     c.fy[d] = f.fy;
     c.w[d][0] = (1.0f - f.fx) * (1.0f - f.fy);

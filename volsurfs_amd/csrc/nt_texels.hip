@@ -26,13 +26,15 @@ __global__ void nt_mark_kernel(vsa_nt_plan plan, const int* __restrict__ hit_slo
     for (int d = 0; d < D; ++d) {
       const int R = plan.tex_res[d];
       const int W = R + 2;
-      const NtFootprint f = nt_footprint(uv.x, uv.y, R);
+      const NtFootprint f = nt_footprint(uv.x, uv.y, R, plan.anchor != 0);
       unsigned char* m = marks + plan.dom_off[s * VSA_NT_MAX_DEG + d] +
                          (long long)(f.j0 + 1) * W + (f.i0 + 1);
       m[0] = 1;
-      m[1] = 1;
-      m[W] = 1;
-      m[W + 1] = 1;
+      if (!plan.anchor) {      // lerp: the 2x2 footprint; anchor: the one texel
+        m[1] = 1;
+        m[W] = 1;
+        m[W + 1] = 1;
+      }
     }
   }
   tex_uv[2 * o] = uv.x;

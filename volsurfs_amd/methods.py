@@ -82,7 +82,12 @@ class VolSurfs(torch.nn.Module):
                  rgb_dir_encoder_type="spherical_harmonics", rgb_view_dep=True,
                  rgb_normal_dep=False, transp_normal_dep=False, rgb_nr_iters_for_c2f=0,
                  are_volsurfs_colors_indep=True, are_volsurfs_alphas_indep=True, bb_sides=2.0,
-                 lr_milestones=(100000, 150000, 180000, 190000), nr_warmup_iters=3000):
+                 lr_milestones=(100000, 150000, 180000, 190000), nr_warmup_iters=3000,
+                 using_neural_textures_anchor=False, using_neural_textures_lerp=True,
+                 using_sh_quantization=True, using_sh_squeezing=True):
+        """using_neural_textures_anchor / _lerp, using_sh_quantization, using_sh_squeezing: the reference's
+        hyper-parameters of the same names (config/volsurfs/base_5.cfg:16-19 -> volsurfs.py:149-153); a
+        combination that is not built raises in NeuralTextureBank instead of rendering the default."""
         super().__init__()
         self.using_neural_textures = using_neural_textures
         self.with_alpha_decay = with_alpha_decay
@@ -101,7 +106,11 @@ class VolSurfs(torch.nn.Module):
                                           alpha_sh_degree=sh_degree if transp_view_dep else 0,
                                           sh_range=sh_range, textures_res=textures_res,
                                           inner_solid=is_inner_mesh_solid,
-                                          with_alpha_decay=with_alpha_decay, device=dev, seed=seed)
+                                          with_alpha_decay=with_alpha_decay, device=dev, seed=seed,
+                                          anchor=bool(using_neural_textures_anchor),
+                                          lerp=bool(using_neural_textures_lerp),
+                                          quantize_output=bool(using_sh_quantization),
+                                          squeeze_output=bool(using_sh_squeezing))
         else:
             # legacy appearance branch (volsurfs.py:208-300): one RGB / ColorSH per shell (or one
             # for all shells), alpha model None for a solid inner mesh
@@ -584,11 +593,17 @@ class VolSurfs(torch.nn.Module):
         slices); rank 0 alone writes the files, which hold full tensors and therefore load under
         any world size, sharded or not.  Replicated (all-reduce) runs: rank 0's call suffices."""
         import os
-        if getattr(self, "save_checkpoints_path", None) is None:
+        # every rank reaches the collectives, whatever its own path setting: a rank that returned early
+        # here left the others hanging in the all-gathers (ADVICE r4)
+        sharded = hasattr(getattr(self, "optimizer", None), "gather_masters")
+        root = getattr(self, "save_checkpoints_path", None)
+        if root is None and not sharded:
             return None
-        path = os.path.join(self.save_checkpoints_path, format(iter_nr, "07d"), "models")
         self.sync_params()       # parameters and moments are final on the current stream
         opt_state = self.optimizer.state_dict() if getattr(self, "optimizer", None) is not None else None
+        if root is None:
+            return None
+        path = os.path.join(root, format(iter_nr, "07d"), "models")
         if getattr(self, "_dist_rank", 0) != 0:
             return path          # took part in the collectives; the files are rank 0's
         os.makedirs(path, exist_ok=True)
@@ -634,9 +649,15 @@ class VolSurfs(torch.nn.Module):
         if isinstance(self.bg_model, torch.nn.Module) and os.path.exists(f):
             self.bg_model.load_state_dict(torch.load(f, map_location="cuda"))
         if getattr(self, "optimizer", None) is not None:
-            f = os.path.join(path, "fusedadam.pt")
-            if os.path.exists(f):
+            # "fusedadam.pt" since round 4; sharded runs of earlier rounds wrote it under the class name
+            names = ["fusedadam.pt", f"{type(self.optimizer).__name__.lower()}.pt"]
+            f = next((os.path.join(path, n) for n in names if os.path.exists(os.path.join(path, n))), None)
+            if f is not None:
                 self.optimizer.load_state_dict(torch.load(f, map_location="cuda"))
+            elif os.path.isdir(path):
+                # (base_method.py:192 prints the same warning: training resumes with zero moments)
+                import warnings
+                warnings.warn(f"checkpoint {path} holds no optimiser state ({' / '.join(names)}): resuming with zero moments")
         return path
 
     @torch.no_grad()

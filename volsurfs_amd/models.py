@@ -344,7 +344,8 @@ def mlps_groupable(mlps, x):
         lin = [l for l in m.layers if isinstance(l, torch.nn.Linear)]
         return ([lin[0].in_features] + [l.out_features for l in lin], bool(m.bias), m.last_layer_linear)
     s0 = sig(mlps[0])
-    return (MLP.fused and s0[2] and all(sig(m) == s0 for m in mlps) and fused_mlp_supported(s0[0], x))
+    # (per INSTANCE: an MLP that opted out with `mlp.fused = False` must not ride a grouped fused launch)
+    return (all(m.fused for m in mlps) and s0[2] and all(sig(m) == s0 for m in mlps) and fused_mlp_supported(s0[0], x))
 
 
 class MLP(torch.nn.Module):

@@ -47,7 +47,7 @@ class Plan(ctypes.Structure):
         ("level_offset", ctypes.c_int32 * (MAX_LEVELS + 1)),
         ("dom_off", ctypes.c_int64 * (MAX_SHELLS * MAX_DEG + 1)),
         ("slot_capacity", ctypes.c_int64),
-        ("max_rays", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("max_rays", ctypes.c_int32), ("anchor", ctypes.c_int32),
         ("row_base", ctypes.c_int64 * (MAX_SHELLS * MAX_DEG + 1)),
         ("balance", ctypes.c_void_p),
     ]
@@ -77,13 +77,31 @@ class NeuralTextureBank(torch.nn.Module):
     def __init__(self, nr_shells, max_rays, sh_degree=3, alpha_sh_degree=3,
                  sh_range=(15.0, 15.0, 15.0, 15.0), textures_res=(2048, 1024, 512, 256),
                  inner_solid=False, with_alpha_decay=True, device="cuda", seed=42,
-                 training=True):
+                 training=True, anchor=False, lerp=True, quantize_output=True, squeeze_output=True,
+                 grid=None):
+        """anchor / lerp / quantize_output / squeeze_output: NeuralTexture's switches
+        (models/neural_texture.py:19-52; config keys using_neural_textures_anchor / _lerp,
+        using_sh_quantization, using_sh_squeezing).  Built: lerp (the shipped configs) and anchor,
+        both with the 8-bit squeezed texel rows; the f16 rows of the non-quantised variants are not,
+        and asking for them raises instead of silently rendering the default.
+        grid: keyword arguments of grid_geometry() for a hash grid other than the reference's
+        (16 levels always: the MLP reads 32 features); levels of more than 2^15 entries are refused
+        by the library (one level = one LDS plane)."""
         super().__init__()
+        if bool(anchor) == bool(lerp):
+            raise ValueError("NeuralTexture is either anchor or lerp (neural_texture.py:47-51, 141-147)")
+        if quantize_output and not squeeze_output:
+            raise ValueError("quantize_output requires squeeze_output (sh_neural_textures.py:32-36)")
+        if not (quantize_output and squeeze_output):
+            raise NotImplementedError(
+                "texel rows are 8-bit: using_sh_quantization=0 / using_sh_squeezing=0 (f16 rows, "
+                "neural_texture.py:159-169, 183-187) are not built; no reference config ships them")
+        self.anchor = bool(anchor)
         K = nr_shells
         self.K, self.max_rays = K, max_rays
         self.rgb_degrees, self.alpha_degrees = sh_degree + 1, alpha_sh_degree + 1
         self.D = max(self.rgb_degrees, self.alpha_degrees)
-        scale, res, size, offset = grid_geometry()
+        scale, res, size, offset = grid_geometry(**(grid or {}))
         self.n_entries = offset[-1]
         self.n_tex = K * 2 * MAX_DEG
         p = Plan()
@@ -114,6 +132,7 @@ class NeuralTextureBank(torch.nn.Module):
         cap = (cap + 255) // 256 * 256 + 256      # feature planes are blocked by 256 slots
         p.slot_capacity = cap
         p.max_rays = max_rays
+        p.anchor = int(self.anchor)
         self.plan, self.dom_total, self.slot_capacity = p, off, cap
         self.tex_res = tuple(int(r) for r in textures_res)
 

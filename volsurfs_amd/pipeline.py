@@ -168,7 +168,7 @@ class KShellPipeline:
             "trace_launch_order": "cost feedback from the previous frame (static camera: the previous frame has "
                                   "the same rays; value_cold is the figure without any inter-frame feedback)"
                                   if self.tracer.cost_feedback and
-                                  self.tracer.node_format == "q16" and not self.tracer.round_budget else "natural",
+                                  self.tracer.node_format == "q16" else "natural",
         }
 
     def stats(self):

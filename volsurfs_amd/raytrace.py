@@ -17,23 +17,14 @@ from . import _lib
 
 class RayTracer:
     def __init__(self, tensor_meshes, leaf_size=None, node_format=None):
-        """node_format: "q16" (default; binary 32-byte quantised nodes, vsa_trace_q), "q16x4" (the
-        same tree collapsed to 4-wide 64-byte nodes, vsa_trace_q4: half the dependent node fetches,
-        measured 8 % SLOWER — every visit tests four boxes where the binary walk prunes after two — kept
-        as a tested option) or "f32" (binary 64-byte fp32 nodes, vsa_trace); also selected by
-        VSA_TRACE_NODES.  All give identical hits; the quantised formats assume ray origins within
-        ~60 mesh extents of the mesh (include/volsurfs_hip.h)."""
+        """node_format: "q16" (default; binary 32-byte quantised nodes, vsa_trace_q / vsa_trace_q_fb) or
+        "f32" (binary 64-byte fp32 nodes, vsa_trace); also selected by VSA_TRACE_NODES.  Both give
+        identical hits; the quantised format assumes ray origins within ~60 mesh extents of the mesh
+        (include/volsurfs_hip.h).  (The 4-wide nodes, the budgeted three-pass walk and the persistent-lane
+        kernel of round 3 — bit-exact, measured slower: profiles/NOTEBOOK.md A9.4 — left the library in round 5.)"""
         self.node_format = node_format or os.environ.get("VSA_TRACE_NODES", "q16")
-        if self.node_format not in ("q16x4", "q16", "f32"):
+        if self.node_format not in ("q16", "f32"):
             raise _lib.VolsurfsHipError(f"unknown node_format {self.node_format}")
-        # q16 only: trips of the walk loop after which a wave hands its unfinished rays' subtrees to a
-        # second pass (vsa_trace_q_budgeted; identical results).  0 = the one-pass kernel, the default:
-        # measured at 800x800, K = 5: one pass 0.258 ms; budget 96 / 64 / 48 / 24: 0.256 / 0.287 / 0.354 /
-        # 0.818 ms (profiles/NOTEBOOK.md A9.4: pass A loses its tail, 0.185 ms at 48, but a ray that has no hit yet
-        # hands over subtrees the one-pass walk would have pruned after its first hit)
-        self.round_budget = int(os.environ.get("VSA_TRACE_BUDGET", "0"))
-        self._ws = None
-        self.workspace_bytes = None
         # q16 only: launch order from the previous call's measured cost (vsa_trace_q_fb; identical hits)
         self.cost_feedback = os.environ.get("VSA_TRACE_FEEDBACK", "1") != "0"
         self._fb = None
@@ -41,14 +32,13 @@ class RayTracer:
         if not 1 <= self.nr_meshes <= 16:
             raise _lib.VolsurfsHipError("RayTracer supports 1..16 meshes")
         L = _lib.lib()
-        nodes_all, tris_all, roots, qnodes_all, frames = [], [], [], [], []
-        q4_all, roots4, node4_base, self.max_depth4 = [], [], 0, 0
+        if leaf_size is None:
+            leaf_size = int(os.environ.get("VSA_LEAF_SIZE", "4"))
+        self._bvh, self._layout = [], []            # builder handles (kept for refit) and (node_base, nr_nodes, tri_base, nr_tris)
         self.mesh_tri_offset, self.mesh_nr_tris = [], []
         self.max_depth = 0
         node_base = tri_base = 0
         for m in tensor_meshes:
-            if leaf_size is None:
-                leaf_size = int(os.environ.get("VSA_LEAF_SIZE", "4"))
             v = np.ascontiguousarray(m.vertices.detach().cpu().numpy(), np.float32)
             f = np.ascontiguousarray(m.faces.detach().cpu().numpy(), np.int32)
             h = ctypes.c_void_p()
@@ -57,68 +47,78 @@ class RayTracer:
                                  ctypes.c_int(leaf_size), ctypes.byref(h))
             if rc != 0:
                 raise _lib.VolsurfsHipError(f"vsa_bvh_build failed with status {rc}")
+            self._bvh.append(h)
             nn, nt, md = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
             L.vsa_bvh_sizes(h, ctypes.byref(nn), ctypes.byref(nt), ctypes.byref(md))
-            nodes = np.empty((nn.value, 16), np.float32)
-            tris = np.empty((nt.value, 12), np.float32)
-            rc = L.vsa_bvh_export(h, nodes.ctypes.data_as(ctypes.c_void_p),
-                                  tris.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(node_base),
-                                  ctypes.c_int(tri_base))
-            qnodes = np.empty((nn.value, 8), np.uint32)
-            frame = np.empty(6, np.float32)
-            rc2 = L.vsa_bvh_export_q(h, qnodes.ctypes.data_as(ctypes.c_void_p),
-                                     tris.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(node_base),
-                                     ctypes.c_int(tri_base), frame.ctypes.data_as(ctypes.c_void_p))
-            if self.node_format == "q16x4":      # the 4-wide collapse (host time + a second node array) only when asked for
-                q4 = np.empty((nn.value, 16), np.uint32)
-                n4, d4 = ctypes.c_int(), ctypes.c_int()
-                rc3 = L.vsa_bvh_export_q4(h, q4.ctypes.data_as(ctypes.c_void_p), tris.ctypes.data_as(ctypes.c_void_p),
-                                          ctypes.c_int(node4_base), ctypes.c_int(tri_base),
-                                          frame.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n4), ctypes.byref(d4))
-                rc = rc or rc3
-                q4_all.append(q4[:n4.value])
-                roots4.append(node4_base)
-                node4_base += n4.value
-                self.max_depth4 = max(self.max_depth4, d4.value)
-            L.vsa_bvh_destroy(h)
-            if rc != 0 or rc2 != 0:
-                raise _lib.VolsurfsHipError(f"vsa_bvh_export failed with status {rc} / {rc2}")
-            qnodes_all.append(qnodes)
-            frames.append(frame)
-            roots.append(node_base)
+            self._layout.append((node_base, nn.value, tri_base, nt.value))
             self.mesh_tri_offset.append(tri_base)
             self.mesh_nr_tris.append(nt.value)
             self.max_depth = max(self.max_depth, md.value)
             node_base += nn.value
             tri_base += nt.value
-            nodes_all.append(nodes)
-            tris_all.append(tris)
         dev = tensor_meshes[0].vertices.device
         self.device = dev
-        self.nodes = torch.from_numpy(np.concatenate(nodes_all, 0)).to(dev)
-        self.qnodes = torch.from_numpy(np.concatenate(qnodes_all, 0).view(np.int32)).to(dev)
-        self.qnodes4 = torch.from_numpy(np.concatenate(q4_all, 0).view(np.int32)).to(dev) if q4_all else None
-        self._roots4 = (ctypes.c_int32 * self.nr_meshes)(*roots4) if q4_all else None
-        self._frames = (ctypes.c_float * (6 * self.nr_meshes))(*np.concatenate(frames).tolist())
-        tris_np = np.concatenate(tris_all, 0)
-        self.tris = torch.from_numpy(tris_np).to(dev)
+        nodes, qnodes, tris, frames = self._export()
+        self.nodes = torch.from_numpy(nodes).to(dev)
+        self.qnodes = torch.from_numpy(qnodes.view(np.int32)).to(dev)
+        self._frames = (ctypes.c_float * (6 * self.nr_meshes))(*frames.tolist())
+        self.tris = torch.from_numpy(tris).to(dev)
         # original face id of every leaf-ordered triangle slot (for uv tables etc.)
-        self.slot_face_id = torch.from_numpy(tris_np[:, 3].copy().view(np.int32)).to(dev)
-        self._roots = (ctypes.c_int32 * self.nr_meshes)(*roots)
-        self.roots = roots
+        self.slot_face_id = torch.from_numpy(tris[:, 3].copy().view(np.int32)).to(dev)
+        self.roots = [lay[0] for lay in self._layout]
+        self._roots = (ctypes.c_int32 * self.nr_meshes)(*self.roots)
 
-    def _workspace(self, N, device):
-        """Scratch of vsa_trace_q_budgeted for N rays (kept between calls; contents are not)."""
-        if self._ws is None or self._ws[1] != N or self._ws[0].device != device:
-            fn = _lib.lib().vsa_trace_q_workspace_bytes
-            fn.restype = ctypes.c_longlong
-            nbytes = int(fn(ctypes.c_int(N), ctypes.c_int(self.nr_meshes)))
-            if nbytes < 0:
-                raise _lib.VolsurfsHipError("vsa_trace_q_workspace_bytes failed")
-            if self.workspace_bytes is not None:     # tests: a workspace too small for the hand-overs
-                nbytes = int(self.workspace_bytes)
-            self._ws = (torch.empty(nbytes, dtype=torch.uint8, device=device), N, nbytes)
-        return self._ws[0], self._ws[2]
+    def _export(self):
+        """Concatenated fp32 nodes [*,16], quantised nodes [*,8] u32, triangles [*,12] and the K
+        quantisation frames [K*6] of the builder handles."""
+        L = _lib.lib()
+        n_nodes = sum(lay[1] for lay in self._layout)
+        n_tris = sum(lay[3] for lay in self._layout)
+        nodes = np.empty((n_nodes, 16), np.float32)
+        qnodes = np.empty((n_nodes, 8), np.uint32)
+        tris = np.empty((n_tris, 12), np.float32)
+        frames = np.empty(6 * self.nr_meshes, np.float32)
+        for i, (h, (nb, nn, tb, nt)) in enumerate(zip(self._bvh, self._layout)):
+            rc = L.vsa_bvh_export(h, nodes[nb:nb + nn].ctypes.data_as(ctypes.c_void_p),
+                                  tris[tb:tb + nt].ctypes.data_as(ctypes.c_void_p), ctypes.c_int(nb),
+                                  ctypes.c_int(tb))
+            rc2 = L.vsa_bvh_export_q(h, qnodes[nb:nb + nn].ctypes.data_as(ctypes.c_void_p),
+                                     tris[tb:tb + nt].ctypes.data_as(ctypes.c_void_p), ctypes.c_int(nb),
+                                     ctypes.c_int(tb), frames[6 * i:6 * i + 6].ctypes.data_as(ctypes.c_void_p))
+            if rc != 0 or rc2 != 0:
+                raise _lib.VolsurfsHipError(f"vsa_bvh_export failed with status {rc} / {rc2}")
+        return nodes, qnodes, tris, frames
+
+    def refit(self, tensor_meshes):
+        """The shells' vertices moved (same faces): recompute triangle records and boxes bottom-up in the
+        existing trees (vsa_bvh_refit) and overwrite the device arrays in place — no SAH rebuild, triangle
+        slots (and with them `slot_face_id` and any per-slot uv table) unchanged.  Hits through the
+        refitted trees are bit-identical to a rebuild's (tests/test_raytrace.py::test_refit_*).
+        SURVEY §8f row 1; replaces re-running RayTracer(tensor_meshes) (volsurfs.py:82-128)."""
+        if len(tensor_meshes) != self.nr_meshes:
+            raise _lib.VolsurfsHipError("refit needs the meshes the tracer was built on")
+        L = _lib.lib()
+        for h, m in zip(self._bvh, tensor_meshes):
+            v = np.ascontiguousarray(m.vertices.detach().cpu().numpy(), np.float32)
+            rc = L.vsa_bvh_refit(h, v.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(v.shape[0]))
+            if rc != 0:
+                raise _lib.VolsurfsHipError(f"vsa_bvh_refit failed with status {rc} (vertex count changed?)")
+        nodes, qnodes, tris, frames = self._export()
+        self.nodes.copy_(torch.from_numpy(nodes))
+        self.qnodes.copy_(torch.from_numpy(qnodes.view(np.int32)))
+        self.tris.copy_(torch.from_numpy(tris))
+        self._frames = (ctypes.c_float * (6 * self.nr_meshes))(*frames.tolist())
+        self._fb = None        # the measured launch order belonged to the old geometry
+        return self
+
+    def __del__(self):
+        try:
+            L = _lib.lib()
+            for h in getattr(self, "_bvh", []):
+                L.vsa_bvh_destroy(h)
+        except Exception:
+            pass
+        self._bvh = []
 
     def trace_all(self, rays_o, rays_d, t_min=0.0):
         """All K shells, one launch.  Returns hit_t [K,N] f32, hit_slot [K,N]
@@ -130,16 +130,7 @@ class RayTracer:
         hit_t = torch.empty(K, N, device=rays_o.device)
         hit_slot = torch.empty(K, N, dtype=torch.int32, device=rays_o.device)
         hit_uv = torch.empty(K, N, 2, device=rays_o.device)
-        if self.node_format == "q16x4":
-            _lib.call("vsa_trace_q4", self.qnodes4, self.tris, self._roots4, self._frames, K,
-                      self.max_depth4, rays_o, rays_d, N, float(t_min), hit_t, hit_slot, hit_uv,
-                      _lib.stream_ptr())
-        elif self.node_format == "q16" and self.round_budget > 0 and self.max_depth < 48:
-            ws, ws_bytes = self._workspace(N, rays_o.device)
-            _lib.call("vsa_trace_q_budgeted", self.qnodes, self.tris, self._roots, self._frames, K,
-                      self.max_depth, rays_o, rays_d, N, float(t_min), hit_t, hit_slot, hit_uv,
-                      self.round_budget, ws, ctypes.c_longlong(ws_bytes), _lib.stream_ptr())
-        elif self.node_format == "q16" and self.cost_feedback and self.max_depth < 48:
+        if self.node_format == "q16" and self.cost_feedback and self.max_depth < 48:
             if self._fb is None or self._fb[1] < N or self._fb[0].device != rays_o.device:   # grows only
                 fn = _lib.lib().vsa_trace_feedback_bytes
                 fn.restype = ctypes.c_longlong

@@ -239,10 +239,13 @@ def save_checkpoints(method, iter_nr, remove_previous=True):
     """utils/training.py:59-78: optionally drop the newest previous checkpoint, then method.save."""
     import os
     import shutil
-    if remove_previous:
+    # Under a sharded optimiser method.save() is a collective every rank calls: only rank 0 touches the
+    # directory tree (the ranks would race on the same rmtree), and it does so BEFORE the collectives of
+    # save(), which order the other ranks behind it.
+    if remove_previous and getattr(method, "_dist_rank", 0) == 0 and method.save_checkpoints_path is not None:
         last = get_last_checkpoint_in_path(method.save_checkpoints_path)
         if last is not None:
-            shutil.rmtree(os.path.join(method.save_checkpoints_path, last))
+            shutil.rmtree(os.path.join(method.save_checkpoints_path, last), ignore_errors=True)
     return method.save(iter_nr)
 
 
