@@ -22,6 +22,8 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+from volsurfs_amd.pipeline import GRAD_CHAIN_GAIN  # noqa: E402
+
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW" (spec)
 MFMA_F16_PEAK_TFLOPS = 2500.0
 
@@ -223,7 +225,7 @@ def run_train(args, world, rank, dev, dist):
 
     def one(count):
         n = state["nr_rays"]
-        method.grad_scale = float(n)                 # mean-L1 over n rays: no device read-back for the scale
+        method.grad_scale = GRAD_CHAIN_GAIN * float(n)     # mean-L1 over n rays: no device read-back for the scale
         losses, nxt = train_step_from_reel(method, reel, n, jitter_pixels=True, iter_nr=state["it"],
                                            is_first_iter=state["it"] == 0,
                                            target_nr_of_training_samples=target, world=world,
@@ -327,7 +329,7 @@ def run_dtu(args, world, rank, dev, dist):
 
     def frame():
         for a in range(0, N, batch):
-            m.grad_scale = float(min(batch, N - a))
+            m.grad_scale = GRAD_CHAIN_GAIN * float(min(batch, N - a))
             train_step(m, o[a:a + batch], d[a:a + batch], gt[a:a + batch], iter_nr=state["it"],
                        is_first_iter=state["it"] == 0, world=world, sync_losses=False)
             state["it"] += 1

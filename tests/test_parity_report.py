@@ -125,6 +125,37 @@ def test_parity_report_vs_independent_oracle(K, subdiv, res, noise):
                 flips_grid += int((q_g.int() != q_ref.int()).sum())
                 flips_mlp += int((q_m.int() != q_ref.int()).sum())
     e = np.abs(rgb - ref["rgb"])
+    # ---- which rays touch a flipped texel: "RGB within 1e-4 except where an 8-bit texel
+    # flipped" as a TESTED statement — every value over 1e-4 must belong to a ray one of whose hits reads a
+    # slot whose quantised row differs from the oracle's
+    flipped_slot = torch.zeros(bank.slot_capacity, dtype=torch.bool)
+    for s in range(K):
+        for typ in range(2):
+            for d in range(4):
+                x = bank.tex_index(s, typ, d)
+                C = bank.tex_channels(x)
+                a, b = seg[s * 4 + d], seg[s * 4 + d + 1]
+                f = feats[typ, :, a:b].cpu().permute(1, 0, 2).reshape(-1, 32)
+                w1, w2, w3 = unpack_weights(bank.weights_h[x].cpu())
+                _, q_ref = ONT.quantise(tcnn_like.mlp_forward(w1, w2, w3, f, C))
+                base = 0 if typ == 0 else 24
+                flipped_slot[a:b] |= (texels[a:b, base:base + C].cpu() != q_ref).any(dim=1)
+    _, hs2, hit_uv = pipe.tracer.trace_all(pipe.rays_o, pipe.rays_d)
+    tex_uv = bank.tex_uv_only(hs2, hit_uv, pipe.face_uvs).cpu()
+    hs2, slot_of = hs2.cpu(), bank.slot_of.cpu()
+    ray_flip = torch.zeros(rgb.shape[0], dtype=torch.bool)
+    for s in range(K):
+        hit = hs2[s] >= 0
+        rows = hit.nonzero()[:, 0]
+        for d in range(4):
+            R = bank.tex_res[d]
+            W = R + 2
+            _, _, corners = ONT.texel_corners(tex_uv[s][hit].clone(), R)
+            ij = torch.floor(corners).long() + 1
+            sl = slot_of[int(bank.plan.dom_off[s * 4 + d]) + ij[..., 1] * W + ij[..., 0]].long()     # [M,4]
+            ray_flip[rows[flipped_slot[sl].any(dim=1)]] = True
+    over = torch.from_numpy(e > 1e-4).any(dim=1)
+    unexplained = over & ~ray_flip
     g_rel = []
     for x, (g_t, g_w) in ref["grads"].items():
         g_rel.append(((gw[x] - g_w).abs() / g_w.abs().max()).numpy())
@@ -135,11 +166,19 @@ def test_parity_report_vs_independent_oracle(K, subdiv, res, noise):
            "texel_flip_rate_grid_f16_chain_vs_f32_sum": flips_grid / total,
            "texel_flip_rate_mlp_f32_acc_vs_f16_acc_model": flips_mlp / total,
            "rgb_abs_err": _pcts(e), "rgb_frac_over_1e-4": float((e > 1e-4).mean()),
+           "rays_over_1e-4": int(over.sum()), "rays_touching_a_flipped_texel": int(ray_flip.sum()),
+           "rays_over_1e-4_without_a_flipped_texel": int(unexplained.sum()),
+           "max_err_without_a_flipped_texel": float(e[(~ray_flip).numpy()].max()) if (~ray_flip).any() else 0.0,
            "grad_err_rel_to_tensor_max": _pcts(g_rel),
            "note": "oracle gradients are the reference's fp16 autograd (itself noisy)"}
     _emit(f"independent_K{K}_res{res}", rep)
     # a texel flip moves one SH coefficient by 30/255: bounded, and rare (measured 1.2-1.5e-5)
-    assert rep["texel_flip_rate"] < 1e-4
+    assert rep["texel_flip_rate"] < 3e-5            # measured 0.6-1.7e-5 (profiles/r0[2-5]/parity_report.json)
+    # RGB is within north_star's 1e-4 on EVERY value of every ray that does not read a flipped texel — up to
+    # the one-fp16-ulp moves the order-matched test below bounds (an fp32 sigmoid's last bit straddling an
+    # fp16 rounding boundary of a composite input: measured 0 rays at K <= 5, <= 2 at K = 7)
+    assert rep["rays_over_1e-4_without_a_flipped_texel"] <= 2, rep
+    assert rep["max_err_without_a_flipped_texel"] <= 1e-3, rep
     # where no texel flipped the pixel is bit-identical; a flip shows as one or two fp16 ulps
     assert rep["rgb_abs_err"]["p99"] == 0.0 and rep["rgb_abs_err"]["max"] <= 1e-2      # measured <= 4.9e-3
     assert rep["rgb_frac_over_1e-4"] <= 2e-3
@@ -181,8 +220,10 @@ def _grid_f32(geom, table, xy):
     return torch.cat(outs, dim=1)
 
 
+# (r5: + K = 9, the largest shell count the reference configures — config/volsurfs/base_9.cfg — on noisy
+#  shells; 72 textures, i.e. the scalar work split of nt_for_each_piece_scalar)
 @pytest.mark.gpu
-@pytest.mark.parametrize("K,subdiv,res,noise", CASES)
+@pytest.mark.parametrize("K,subdiv,res,noise", CASES + [(9, 3, 96, 0.05)])
 def test_order_matched_rgb_and_f32_gradients(K, subdiv, res, noise):
     from volsurfs_amd.composite import composite_fwd_bwd_l1_raw
     pipe = _pipe(K, subdiv, res, noise=noise)
@@ -374,17 +415,20 @@ def test_order_matched_rgb_and_f32_gradients(K, subdiv, res, noise):
     # = 16 / 256 give the same numbers, so no underflow), not of the accumulation (asserted above);
     # tiny-cuda-nn's backward rounds to half at the same places.  Bounds: north_star's where it is
     # met, 2x the measured value where it is not.
-    assert rep["grad_weights_err_rel_to_tensor_max"]["max"] <= 1e-3
+    # (r5: K = 9 added.  At the round-4 scale of the f16 chain — 1 x N — its MLP-weight gradients were within
+    #  3.6e-3 only and 2.7e-5 of the table entries over 1e-3: the shells behind eight others underflowed f16;
+    #  pipeline.GRAD_CHAIN_GAIN = 16 brings the weights to 3.1e-4 and the entries over 1e-3 to 1.3e-6.)
+    assert rep["grad_weights_err_rel_to_tensor_max"]["max"] <= 1e-3             # north_star, every element, every K
     model = rep["tcnn_half_backward_model_tables_err_rel_to_tensor_max"]
     if K <= 5:
         assert rep["grad_tables_err_rel_to_tensor_max"]["max"] <= 1e-3          # north_star, every entry
     else:
-        # K = 7: 7 of 11 M entries exceed 1e-3 (max 2.2e-3).  Justified by the reference path's own
-        # arithmetic, not by "2x measured": the half-atomics model's worst entry and its share of entries
-        # over 1e-3 must both be LARGER than the kernel's (measured: see profiles/r04/parity_report.json)
-        assert rep["grad_tables_err_rel_to_tensor_max"]["max"] <= min(4.4e-3, model["max"])
-        assert rep["grad_tables_frac_over_1e-3"] <= min(2e-6, rep["tcnn_half_backward_model_tables_frac_over_1e-3"])
+        # K = 7: 7 of 11 M entries exceed 1e-3 (max 2.2e-3); K = 9: 1.3e-6 of them (max 4.6e-3).  Justified by
+        # the reference path's own arithmetic, not by "2x measured" alone: the half-atomics model's worst entry
+        # and its share of entries over 1e-3 must both be LARGER than the kernel's (profiles/r05/parity_report.json)
+        assert rep["grad_tables_err_rel_to_tensor_max"]["max"] <= min({7: 4.4e-3, 9: 9.2e-3}[K], model["max"])
+        assert rep["grad_tables_frac_over_1e-3"] <= min({7: 2e-6, 9: 2.7e-6}[K],
+                                                        rep["tcnn_half_backward_model_tables_frac_over_1e-3"])
     assert model["max"] > rep["grad_tables_err_rel_to_tensor_max"]["max"]
     assert model["p99"] > rep["grad_tables_err_rel_to_tensor_max"]["p99"]
-    assert rep["grad_tables_frac_over_1e-3"] <= 2e-6
     assert rep["grad_tables_err_rel_to_tensor_max"]["p99"] <= 1e-4

@@ -6,16 +6,25 @@ import torch
 
 # per K: (MLP weights, hash tables) max gradient error relative to the tensor's largest entry against
 # the independent oracle: 2x the values measured on MI355X (profiles/r03/measured_bounds.txt)
-GRAD_BOUND = {1: (8e-4, 1.4e-3), 3: (9e-4, 4e-3), 9: (0.28, 0.12)}
+GRAD_BOUND = {1: (8e-4, 1.4e-3), 3: (9e-4, 4e-3)}
+# K = 9 (r5): THIS oracle's gradients are the reference's fp16 autograd, whose own rounding noise behind eight
+# shells is the larger term — rounds 2-4 asserted (0.28, 0.12) here, a bound nothing could fail.  Now the
+# oracle calibrates itself: the same oracle back-propagated under another loss scale (1024 instead of the
+# reference's 128: different fp16 roundings, same mathematics) gives the oracle's own noise per tensor, and the
+# kernel's worst element must be within K9_NOISE_FACTOR x the oracle's own worst element (measured: oracle
+# against itself 0.129 / 0.055 of a tensor's largest entry for weights / tables, kernel against the oracle
+# 0.142 / 0.057, i.e. 1.10x / 1.04x; bound 2x).  The tight K = 9 bound — every element against exact
+# arithmetic: 3.1e-4 for the weights — is tests/test_parity_report.py's order-matched case.
+K9_NOISE_FACTOR = 2.0
 
 
-def _oracle(pipe):
+def _oracle(pipe, loss_scale=128.0):
     from oracle import pipeline as opipe
     bank = pipe.bank
     meshes = [(m.vertices.cpu().numpy(), m.faces.cpu().numpy(), m.faces_uvs.cpu()) for m in pipe.meshes]
     return opipe.render_step(meshes, bank.tables_h.cpu().float(), bank.weights_h.cpu().float(),
                              bank.tex_index, bank.tex_res, pipe.rays_o.cpu().numpy(),
-                             pipe.rays_d.cpu().numpy(), pipe.gt.cpu(), loss_scale=128.0)
+                             pipe.rays_d.cpu().numpy(), pipe.gt.cpu(), loss_scale=loss_scale)
 
 
 @pytest.mark.gpu
@@ -69,7 +78,24 @@ def test_pipeline_matches_oracle(K, subdiv, res):
           f"surfs_rgb_max={e_rgb.max():.3e} surfs_frac={(e_rgb > 1e-5).mean():.3e} gw_rel_max={worst_w:.3e} gt_rel_max={worst_t:.3e}")
     # 2x the measured error against the independent oracle (whose gradients are the reference's own
     # fp16 autograd, loss scale 128: itself noisy, and K = 9 puts the inner shells behind eight others)
-    assert worst_w <= GRAD_BOUND[K][0] and worst_t <= GRAD_BOUND[K][1]
+    if K in GRAD_BOUND:
+        assert worst_w <= GRAD_BOUND[K][0] and worst_t <= GRAD_BOUND[K][1]
+    else:
+        ref2 = _oracle(pipe, loss_scale=1024.0)
+        ratio_w = ratio_t = 0.0
+        noise_w = noise_t = 0.0
+        for x, (g_t, g_w) in ref["grads"].items():
+            g_t2, g_w2 = ref2["grads"][x]
+            nw = float((g_w2 - g_w).abs().max() / g_w.abs().max())
+            nt = float((g_t2 - g_t).abs().max() / g_t.abs().max())
+            kw = float((gw[x] - g_w).abs().max() / g_w.abs().max())
+            kt = float((gt[x] - g_t).abs().max() / g_t.abs().max())
+            noise_w, noise_t = max(noise_w, nw), max(noise_t, nt)
+            ratio_w, ratio_t = max(ratio_w, kw / max(nw, 1e-4)), max(ratio_t, kt / max(nt, 1e-4))
+        print(f"MEASURED pipeline_e2e K={K} oracle_self_noise weights={noise_w:.3e} tables={noise_t:.3e} "
+              f"kernel_over_noise weights={ratio_w:.2f} tables={ratio_t:.2f}")
+        assert noise_w > 1e-3 and noise_t > 1e-3          # (the two oracle runs really differ: the premise)
+        assert worst_w <= K9_NOISE_FACTOR * noise_w and worst_t <= K9_NOISE_FACTOR * noise_t
 
 
 # measured on MI355X (printed as MEASURED stress ...): rgb max 1.95e-3 (fp16 ulps where an 8-bit texel flipped),

@@ -554,7 +554,8 @@ class VolSurfs(torch.nn.Module):
         loss_scale = float(loss_weight) / (3.0 * N)
         rgb, g_c, g_a = composite_fwd_bwd_l1_raw(rgb_k, alpha_k, self.bg_color, gt_rgb.contiguous(),
                                                  loss_scale)
-        scale = self.grad_scale if self.grad_scale is not None else 1.0 / (3.0 * loss_scale)
+        from .pipeline import GRAD_CHAIN_GAIN
+        scale = self.grad_scale if self.grad_scale is not None else GRAD_CHAIN_GAIN / (3.0 * loss_scale)
         bank.backward(hit_slot, tex_uv, rays_d, tris, g_c, g_a, scale, act)
         loss = (gt_rgb - rgb).abs().mean()
         return loss, nr_hits, rgb

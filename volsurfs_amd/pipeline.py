@@ -13,6 +13,15 @@ from .mesh import nested_shells, stress_shells
 from .raytrace import RayTracer
 
 
+# Scale of the f16 gradient chain relative to the ray count of a mean-L1 loss (the analogue of tiny-cuda-nn's
+# loss scale; divided out before anything is accumulated in fp32).  With 1 x N the chain carried 1/3 per
+# ray and channel: fine up to K = 7, but at K = 9 the shells behind eight others underflowed f16 — every
+# MLP-weight gradient within 3.6e-3 of its tensor's largest entry instead of 3.1e-4 at 16 x N, table entries over
+# 1e-3: 2.7e-5 -> 1.3e-6 of them (profiles/r05/parity_report.json; 16 and 256 measure the same, so 16 it is:
+# the headroom to f16's 65 504 stays > 10x even with hundreds of hits on one texel).  A power of two: exact.
+GRAD_CHAIN_GAIN = 16.0
+
+
 class StageTimer:
     def __init__(self):
         self.records = []          # (name, start_evt, end_evt)
@@ -82,7 +91,7 @@ class KShellPipeline:
                 self.bank.tables.copy_((torch.rand(self.bank.tables.shape, generator=g) * 2 - 1).to(dev))
             self.bank.refresh_half_params()
         self.shading = "neural_textures"
-        self.grad_scale = float(N)
+        self.grad_scale = GRAD_CHAIN_GAIN * float(N)
         # rays the mean of the L1 loss runs over: this pipeline's own, or — when it renders one
         # rank's share of a frame (bench.py --scaling strong) — the whole frame's
         self.loss_rays = N
@@ -121,7 +130,7 @@ class KShellPipeline:
             h_local = int(rows.numel())
         p = cls(meshes, o, d, gt, seed=seed, image_hw=(h_local, W), **kw)
         p.loss_rays = n_frame
-        p.grad_scale = float(n_frame)      # the f16 gradient chain is conditioned for 1 / (3 n_frame) per ray
+        p.grad_scale = GRAD_CHAIN_GAIN * float(n_frame)      # the f16 gradient chain sees 16 / 3 per ray and channel
         p.res = res
         p.subdiv = subdiv
         p.scene_desc = ("stress shells: 4 lobes of depth 0.3 r across the view axis (non-convex, up to 6 crossings per "
