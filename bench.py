@@ -632,14 +632,14 @@ def main():
             # the step is ~25 launches on one stream with no host sync; the data-parallel step is the
             # same stream of launches (the collectives run beside the graph, released by device flags)
             if ostep is not None:
-                # two graphs: the parameter-free head of a step (ray order, traversal, mark / compact) is
+                # three graphs: the parameter-free head of a step (ray order, traversal, mark / compact) is
                 # launched before the wait for the previous step's gradient reduction (OverlappedStep.run_split)
                 pipe.capture_graph_split(dp=ostep.signals)
                 ostep.signals.epoch_host += 2          # the capture executed two warm-up steps (a capture pass only records)
             else:
                 pipe.capture_graph()
             for _ in range(2):
-                ostep.run_split(pipe.replay_prefix, pipe.replay_rest) if ostep is not None else pipe.replay()
+                ostep.run_split(pipe.replay_prefix, pipe.replay_mid, pipe.replay_tail) if ostep is not None else pipe.replay()
             if ostep is not None:
                 ostep.finish()
         except Exception as e:         # fall back to the (equally fast) eager path
@@ -651,7 +651,7 @@ def main():
             pipe.rays_o.copy_(views[i % len(views)][0])
             pipe.rays_d.copy_(views[i % len(views)][1])
         if use_graph and ostep is not None:
-            ostep.run_split(pipe.replay_prefix, pipe.replay_rest)
+            ostep.run_split(pipe.replay_prefix, pipe.replay_mid, pipe.replay_tail)
         elif use_graph:
             pipe.replay()
         else:
@@ -679,16 +679,17 @@ def main():
         name, st = dom
         # PMC-measured HBM bytes per launch (tools/traffic.sh -> profiles/traffic.json), valid only
         # for the kernel sources they were collected at: a stale file is reported as null
-        traffic, traffic_note = None, None
+        traffic, traffic_note, traffic_all = None, None, None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
-            tj = json.load(open(tf))
-            if tj.get("_kernel_source_sha256") != kernel_source_hash():
+            tj = json.load(open(tf)).get("workloads", {}).get(workload_key(args))
+            if tj is None:
+                traffic_note = "profiles/traffic.json holds no collection on this workload (tools/traffic.sh <tag> <bench args>)"
+            elif tj.get("_kernel_source_sha256") != kernel_source_hash():
                 traffic_note = "profiles/traffic.json was collected at other kernel sources (stale): re-run tools/traffic.sh"
-            elif tj.get("_workload") != workload_key(args):
-                traffic_note = f"profiles/traffic.json was collected on another workload ({tj.get('_workload')})"
             else:
                 traffic = tj.get(name)
+                traffic_all = {k: v for k, v in tj.items() if not k.startswith("_")}
         # the kernel's own duration: events directly around its launch (a stage also holds the
         # small torch kernels next to it); one launch per stage except the encode stages
         k_ms = kernel_ms.get("vsa_" + name, st["ms"]) if name not in launches else st["ms"]
@@ -711,9 +712,10 @@ def main():
             "dtype": pipe.dtype_desc, "data": "synthetic",
             "config": dict(pipe.config_desc(world), launch="hip-graph replay" if use_graph else "eager",
                            **({"dp_phases": ostep.signals.phase_end,
-                               "dp_schedule": "two graphs per step: the parameter-free head (ray order, traversal, "
+                               "dp_schedule": "three graphs per step: the parameter-free head (ray order, traversal, "
                                               "mark/compact) runs before the wait for the previous step's gradient "
-                                              "reduction; collectives on a side stream released by device flags"}
+                                              "reduction; then zero_grad .. MLP backward; then the hash-grid backward, "
+                                              "beside which a side stream all-reduces each phase as its device flag rises"}
                               if ostep is not None else {}),
                            scene=getattr(pipe, "scene_desc", None)),
             "roofline": roof,

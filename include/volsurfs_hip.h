@@ -328,8 +328,8 @@ int vsa_nt_mlp_bwd(const vsa_nt_plan* plan, const void* weights_h, void* feature
  * surfs_normals [N,K,3] and coeffs_out [K,N,64] (tests: 48 rgb [ch][16] + 16
  * alpha lerped fp16 SH coefficients).  tris = the tracer's triangle array.
  * act_out (optional, [K,N,4] f32): the three rgb sigmoids and the alpha sigmoid (before
- * the decay) of every hit, which vsa_nt_shade_bwd can take back as act_in instead of
- * re-gathering the texel rows and re-evaluating the SH sums. */
+ * the decay) of every hit (entries of misses are NOT written), which vsa_nt_shade_bwd can take
+ * back as act_in instead of re-gathering the texel rows and re-evaluating the SH sums. */
 int vsa_nt_shade_fwd(const vsa_nt_plan* plan, const int32_t* hit_slot, const float* tex_uv,
                      const float* rays_d, const float* tris, const int32_t* slot_of,
                      const int32_t* seg_start, const uint8_t* texels, int nr_rays,
@@ -365,33 +365,45 @@ int vsa_nt_encode_bwd_range(const vsa_nt_plan* plan, const void* dfeatures,
 /* Data-parallel form of vsa_nt_encode_bwd (rays shard by tile, the ranks all-reduce the
  * gradients; the reference is single-GPU, so this replaces nothing — it is what keeps the all-reduce
  * of the 113 MB of table gradients off the critical path of trainer.py:249-264's backward).
- * ONE launch: the shells are cut into n_phases groups, phase p = shells [phase_shell_end[p-1],
+ *
+ * vsa_dp_flags: n (<= VSA_MAX_SHELLS + 1) completion words, zero at creation, each its own 8-byte
+ * hipMallocSignalMemory allocation (plain device memory if the runtime refuses), so that another stream
+ * can wait for one through the command processor — a waiting KERNEL would park a wave on a CU whose
+ * registers the persistent MLP kernels need entirely.  vsa_dp_flags_read: [host] copy of the n words
+ * (synchronises the device; tests). */
+typedef struct vsa_dp_flags vsa_dp_flags;
+int vsa_dp_flags_create(int n, vsa_dp_flags** out);
+int vsa_dp_flags_destroy(vsa_dp_flags* flags);
+int vsa_dp_flags_read(const vsa_dp_flags* flags, uint32_t* host_out);
+
+/* ONE launch: the shells are cut into n_phases groups, phase p = shells [phase_shell_end[p-1],
  * phase_shell_end[p]) ([host] array, strictly increasing, last = nr_shells); every workgroup walks its
  * share of the dense levels of all shells, then finishes its share of phase p's hashed levels before
- * it touches phase p+1, and when the LAST workgroup is through phase p the
- * kernel stores flags[p] = *epoch (system scope; that phase's slice of grad_tables — textures
- * [8*begin, 8*end) — is final and visible).  counters: n_phases words, zero on entry, zero again on
- * exit.  Results equal vsa_nt_encode_bwd's up to the order of the float atomics that join two
+ * it touches phase p+1, and when the LAST workgroup is through phase p the kernel stores
+ * word p of `flags` = *epoch (system scope; that phase's slice of grad_tables — textures
+ * [8*begin, 8*end) — is final and visible).  counters: n_phases device words, zero on entry, zero again
+ * on exit.  Results equal vsa_nt_encode_bwd's up to the order of the float atomics that join two
  * workgroups' shares of one table plane (pieces are cut at other slots).
- * Another stream waits for a phase with vsa_dp_stream_wait(flags + p, epoch value). */
+ * Another stream waits for a phase with vsa_dp_stream_wait(flags, p, epoch value). */
 int vsa_nt_encode_bwd_phased(const vsa_nt_plan* plan, const void* dfeatures,
                              const float* dfeat_abs_sum, float grad_scale, const float* slot_xy,
                              const int32_t* seg_start, float* grad_tables, int n_phases,
-                             const int32_t* phase_shell_end, uint32_t* flags, uint32_t* counters,
+                             const int32_t* phase_shell_end, vsa_dp_flags* flags, uint32_t* counters,
                              const uint32_t* epoch, void* stream);
 
-/* Stream-ordered signal: (*epoch += 1 when advance_epoch), then *flag = *epoch at system scope — a
- * one-lane kernel, so it can sit inside a captured HIP graph (hipStreamWriteValue32 cannot).  The step
- * calls it once behind vsa_nt_mlp_bwd (weights.grad is final), advancing the epoch the phased
+/* Stream-ordered signal: (*epoch += 1 when advance_epoch), then word `index` of flags = *epoch at system
+ * scope — a one-lane kernel, so it can sit inside a captured HIP graph (hipStreamWriteValue32 cannot).
+ * The step calls it once behind vsa_nt_mlp_bwd (weights.grad is final), advancing the epoch the phased
  * encode backward then publishes. */
-int vsa_dp_signal(uint32_t* flag, uint32_t* epoch, int advance_epoch, void* stream);
+int vsa_dp_signal(vsa_dp_flags* flags, int index, uint32_t* epoch, int advance_epoch, void* stream);
 
-/* Make `stream` wait until (int32)(*flag - value) >= 0.  mode 1: hipStreamWaitValue32 (the command
- * processor polls; no compute resource), mode 2: a one-lane polling kernel, mode 0: 1 where
+/* Make `stream` wait until word `index` >= value.  mode 1: hipStreamWaitValue32 (on signal memory the
+ * command processor polls: no compute resource), mode 2: a one-lane polling kernel ((int32)(word - value)
+ * >= 0; it occupies registers of one SIMD: see above), mode 0: 1 where the words are signal memory and
  * hipDeviceAttributeCanUseStreamWaitValue says so, else 2.  ENQUEUE IT AFTER THE PRODUCER: HIP
  * multiplexes streams onto a few hardware queues, and a wait queued ahead of the kernel that
  * satisfies it on the same queue would never return. */
-int vsa_dp_stream_wait(uint32_t* flag, uint32_t value, int mode, void* stream);
+int vsa_dp_stream_wait(vsa_dp_flags* flags, int index, uint32_t value, int mode, void* stream);
 
 /* ------------------------------------------------------------------------
  * A5 / A10  Encoders of the legacy appearance branch and of the background field:

@@ -148,7 +148,6 @@ def test_encode_backward_phased_equals_one_launch_and_publishes_its_phases(phase
     afterwards, the workgroup counters are zero again; a second stream that waits on the flags
     (hipStreamWaitValue32 / the polling kernel) reads each phase's FINAL slice while the launch is the
     only thing that could still be writing it."""
-    from volsurfs_amd import _lib
     from volsurfs_amd.parallel import StepSignals
     K, N = 3, 2500
     bank, face_uvs, hit_slot, hit_uv, tris, rays_d = _scene(K, N, 7, res=(256, 128, 64, 32))
@@ -168,17 +167,17 @@ def test_encode_backward_phased_equals_one_launch_and_publishes_its_phases(phase
     snaps = []
     for epoch in (1, 2):
         bank.tables.grad.zero_()
-        _lib.call("vsa_dp_signal", sg.flag_w, sg.epoch, 1, _lib.stream_ptr())
+        sg.signal_weights()
         bank.backward_encode_phased(float(N), sg)
         with torch.cuda.stream(side):           # queued AFTER the producer (vsa_dp_stream_wait's rule)
             for p in range(sg.n):
                 a, b = sg.shell_range(p)
-                sg.stream_wait(sg.flags[p:p + 1], epoch)
+                sg.stream_wait(p, epoch)
                 snaps.append((a, b, bank.tables.grad[a * 8:b * 8].clone()))
         torch.cuda.synchronize()
-        w = sg.words.cpu().tolist()
-        assert w[:sg.n] == [epoch] * sg.n and w[sg.n] == epoch and w[sg.n + 1] == epoch      # flags, flag_w, epoch
-        assert w[sg.n + 2:] == [0] * sg.n                                                     # counters
+        flags, dev_epoch, counters = sg.read()
+        assert flags == [epoch] * (sg.n + 1) and dev_epoch == epoch      # phase words, weights word, epoch
+        assert counters == [0] * sg.n
         assert ref.abs().max() > 0
         np.testing.assert_allclose(bank.tables.grad.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5,
                                    atol=1e-6 * ref.abs().max().item())

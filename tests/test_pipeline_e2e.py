@@ -182,8 +182,8 @@ def test_data_parallel_step_is_the_plain_step_plus_device_flags():
         rgb = o.run(pipe.replay)
     torch.cuda.synchronize()
     assert torch.equal(rgb, ref_rgb)
-    w = o.signals.words.cpu().tolist()
-    assert w[:o.signals.n + 2] == [o.signals.epoch_host] * (o.signals.n + 2) and o.signals.epoch_host == 6
+    flags, dev_epoch, counters = o.signals.read()
+    assert flags == [6] * (o.signals.n + 1) and dev_epoch == 6 == o.signals.epoch_host and not any(counters)
     np.testing.assert_allclose(pipe.bank.tables.grad.cpu().numpy(), gt.cpu().numpy(), rtol=0,
                                atol=2e-3 * gt.abs().max().item())
 
@@ -311,10 +311,10 @@ def test_split_graphs_equal_the_one_graph_step():
     pipe.capture_graph_split(dp=o.signals)
     o.signals.epoch_host += 2
     for _ in range(3):
-        rgb = o.run_split(pipe.replay_prefix, pipe.replay_rest)
+        rgb = o.run_split(pipe.replay_prefix, pipe.replay_mid, pipe.replay_tail)
     o.finish()
     torch.cuda.synchronize()
     assert torch.equal(rgb, ref_rgb)
-    assert o.signals.words.cpu().tolist()[:o.signals.n + 2] == [5] * (o.signals.n + 2)
+    assert o.signals.read()[0] == [5] * (o.signals.n + 1)
     np.testing.assert_allclose(pipe.bank.tables.grad.cpu().numpy(), gt.cpu().numpy(), rtol=0,
                                atol=2e-3 * gt.abs().max().item())

@@ -690,13 +690,14 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_both_kernel(
 struct EncPhases {
   int n;
   int shell_end[VSA_MAX_SHELLS];
+  unsigned* flag[VSA_MAX_SHELLS];      // one word per phase (each its own signal allocation: vsa_dp_flags)
 };
 
 __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_phased_kernel(
     vsa_nt_plan plan, int lh, int n_planes_dense,
     const half2_t* __restrict__ dfeatures, const float* __restrict__ dfeat_abs_sum,
     float dscale_inv, const float2* __restrict__ slot_xy, const int* __restrict__ seg_start,
-    float* __restrict__ grad_tables, EncPhases ph, unsigned* __restrict__ flags,
+    float* __restrict__ grad_tables, EncPhases ph,
     unsigned* __restrict__ counters, const unsigned* __restrict__ epoch) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   // the dense (coarse) planes of ALL shells first, un-phased: they are a quarter of the work in many small
@@ -722,7 +723,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_bwd_phased_kernel(
       const unsigned done = __hip_atomic_fetch_add(&counters[p], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
       if (done == gridDim.x - 1) {
         __hip_atomic_store(&counters[p], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-        __hip_atomic_store(&flags[p], *epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(ph.flag[p], *epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
   }
@@ -737,8 +738,11 @@ __global__ void dp_signal_kernel(unsigned* __restrict__ flag, unsigned* __restri
 
 __global__ void dp_spin_wait_kernel(const unsigned* __restrict__ flag, unsigned value) {
   // (one lane, no LDS: fits beside the persistent kernels, which leave half of a CU's wave slots free)
-  while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0)
+  // RELAXED polls (a cache-bypassing load each), ONE acquire when the value is there: an acquire per poll
+  // invalidates the caches of the XCD the lane sits on every couple of microseconds, under the kernels it waits for
+  while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0)
     __builtin_amdgcn_s_sleep(64);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }
 
 }  // namespace
@@ -882,21 +886,70 @@ extern "C" int vsa_nt_encode_bwd_range(const vsa_nt_plan* plan, const void* dfea
   VSA_RETURN_LAUNCH_STATUS();
 }
 
+// Completion flags of the data-parallel step.  A stream that waits on a flag with a POLLING KERNEL parks a
+// wave on some CU — and nt_mlp_fwd / nt_mlp_bwd take every vector register of every SIMD, so that CU could
+// not host its persistent workgroup any more: the launch ran two rounds instead of one, +0.5-0.7 ms per step
+// (profiles/r05/dp_schedule_one_gpu.txt; HIP's own hipStreamWaitValue32 on plain device memory is such a
+// kernel too).  Words allocated with hipMallocSignalMemory are waited for by the command processor itself
+// (a barrier-value packet): no wave, no register, no LDS.
+struct vsa_dp_flags {
+  int n = 0;
+  bool signal_memory = false;
+  unsigned* word[VSA_MAX_SHELLS + 1] = {};
+};
+
+extern "C" int vsa_dp_flags_create(int n, vsa_dp_flags** out) {
+  if (!out || n < 1 || n > VSA_MAX_SHELLS + 1) return VSA_ERR_ARG;
+  vsa_dp_flags* f = new vsa_dp_flags();
+  f->n = n;
+  f->signal_memory = true;
+  for (int i = 0; i < n; ++i) {
+    void* p = nullptr;
+    if (f->signal_memory && hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory) != hipSuccess) {
+      (void)hipGetLastError();
+      f->signal_memory = false;            // (then every word is plain memory: one kind of wait for all)
+      for (int j = 0; j < i; ++j) (void)hipFree(f->word[j]);
+      i = -1;
+      continue;
+    }
+    if (!f->signal_memory) VSA_HIP_TRY(hipMalloc(&p, 8));
+    VSA_HIP_TRY(hipMemset(p, 0, 8));
+    f->word[i] = static_cast<unsigned*>(p);
+  }
+  *out = f;
+  return VSA_OK;
+}
+
+extern "C" int vsa_dp_flags_destroy(vsa_dp_flags* f) {
+  if (!f) return VSA_OK;
+  for (int i = 0; i < f->n; ++i) (void)hipFree(f->word[i]);
+  delete f;
+  return VSA_OK;
+}
+
+extern "C" int vsa_dp_flags_read(const vsa_dp_flags* f, uint32_t* host_out) {
+  if (!f || !host_out) return VSA_ERR_ARG;
+  VSA_HIP_TRY(hipDeviceSynchronize());
+  for (int i = 0; i < f->n; ++i) VSA_HIP_TRY(hipMemcpy(host_out + i, f->word[i], 4, hipMemcpyDeviceToHost));
+  return VSA_OK;
+}
+
 extern "C" int vsa_nt_encode_bwd_phased(const vsa_nt_plan* plan, const void* dfeatures,
                                         const float* dfeat_abs_sum, float grad_scale,
                                         const float* slot_xy, const int32_t* seg_start,
                                         float* grad_tables, int n_phases, const int32_t* phase_shell_end,
-                                        uint32_t* flags, uint32_t* counters, const uint32_t* epoch,
+                                        vsa_dp_flags* flags, uint32_t* counters, const uint32_t* epoch,
                                         void* stream) {
   if (!plan || !dfeatures || !dfeat_abs_sum || !slot_xy || !seg_start || !grad_tables || !phase_shell_end ||
       !flags || !counters || !epoch)
     return VSA_ERR_ARG;
-  if (n_phases < 1 || n_phases > VSA_MAX_SHELLS || !(grad_scale > 0.f)) return VSA_ERR_ARG;
+  if (n_phases < 1 || n_phases > VSA_MAX_SHELLS || flags->n < n_phases || !(grad_scale > 0.f)) return VSA_ERR_ARG;
   EncPhases ph;
   int prev = 0;
   for (int p = 0; p < n_phases; ++p) {       // strictly increasing, the last phase ends at the last shell
     if (phase_shell_end[p] <= prev || phase_shell_end[p] > plan->nr_shells) return VSA_ERR_ARG;
     ph.shell_end[p] = prev = phase_shell_end[p];
+    ph.flag[p] = flags->word[p];
   }
   if (prev != plan->nr_shells) return VSA_ERR_ARG;
   ph.n = n_phases;
@@ -915,28 +968,29 @@ extern "C" int vsa_nt_encode_bwd_phased(const vsa_nt_plan* plan, const void* dfe
   hipLaunchKernelGGL(nt_encode_bwd_phased_kernel, dim3(nr_cus), dim3(ENC_BLOCK), (size_t)LDS_ENTRIES * 4,
                      (hipStream_t)stream, *plan, lh, n_planes, reinterpret_cast<const half2_t*>(dfeatures),
                      dfeat_abs_sum, 1.0f / grad_scale, reinterpret_cast<const float2*>(slot_xy), seg_start,
-                     grad_tables, ph, flags, counters, epoch);
+                     grad_tables, ph, counters, epoch);
   VSA_RETURN_LAUNCH_STATUS();
 }
 
-extern "C" int vsa_dp_signal(uint32_t* flag, uint32_t* epoch, int advance_epoch, void* stream) {
-  if (!flag || !epoch) return VSA_ERR_ARG;
-  hipLaunchKernelGGL(dp_signal_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, flag, epoch, advance_epoch);
+extern "C" int vsa_dp_signal(vsa_dp_flags* flags, int index, uint32_t* epoch, int advance_epoch, void* stream) {
+  if (!flags || !epoch || index < 0 || index >= flags->n) return VSA_ERR_ARG;
+  hipLaunchKernelGGL(dp_signal_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, flags->word[index], epoch,
+                     advance_epoch);
   VSA_RETURN_LAUNCH_STATUS();
 }
 
-extern "C" int vsa_dp_stream_wait(uint32_t* flag, uint32_t value, int mode, void* stream) {
-  if (!flag || mode < 0 || mode > 2) return VSA_ERR_ARG;
-  if (mode == 0) {      // auto: the command processor's wait where the device offers it
+extern "C" int vsa_dp_stream_wait(vsa_dp_flags* flags, int index, uint32_t value, int mode, void* stream) {
+  if (!flags || index < 0 || index >= flags->n || mode < 0 || mode > 2) return VSA_ERR_ARG;
+  if (mode == 0) {      // auto: the command processor's wait where the words are signal memory and the device offers it
     int dev = 0, can = 0;
     VSA_HIP_TRY(hipGetDevice(&dev));
     VSA_HIP_TRY(hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev));
-    mode = can ? 1 : 2;
+    mode = can && flags->signal_memory ? 1 : 2;
   }
   if (mode == 1) {
-    VSA_HIP_TRY(hipStreamWaitValue32((hipStream_t)stream, flag, value, hipStreamWaitValueGte, 0xffffffffu));
+    VSA_HIP_TRY(hipStreamWaitValue32((hipStream_t)stream, flags->word[index], value, hipStreamWaitValueGte, 0xffffffffu));
     return VSA_OK;
   }
-  hipLaunchKernelGGL(dp_spin_wait_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, flag, value);
+  hipLaunchKernelGGL(dp_spin_wait_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, flags->word[index], value);
   VSA_RETURN_LAUNCH_STATUS();
 }

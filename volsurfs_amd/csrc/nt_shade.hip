@@ -14,6 +14,19 @@
 // wave instruction adds contiguous row segments instead of 64 scattered dwords.
 #include "nt_common.h"
 
+#ifndef NT_SHADE_SHELL_FAST
+#define NT_SHADE_SHELL_FAST 1      /* 0: round 1-4's grid (ray tile, shell), for A/B */
+#endif
+#if NT_SHADE_SHELL_FAST
+#define SHADE_TILE_IDX blockIdx.y
+#define SHADE_SHELL_IDX blockIdx.x
+#define SHADE_GRID(tiles, shells) dim3((shells), (tiles))
+#else
+#define SHADE_TILE_IDX blockIdx.x
+#define SHADE_SHELL_IDX blockIdx.y
+#define SHADE_GRID(tiles, shells) dim3((tiles), (shells))
+#endif
+
 namespace {
 
 constexpr int SH_BLOCK = 256;
@@ -293,8 +306,13 @@ __global__ __launch_bounds__(SH_BLOCK, NT_SHADE_FWD_OCC) void nt_shade_fwd_kerne
   __shared__ float s_lut[VSA_NT_MAX_DEG * 256];
   build_lut(plan, s_lut);
   __syncthreads();
-  const long long n = (long long)blockIdx.x * SH_BLOCK + threadIdx.x;
-  const int s = blockIdx.y, K = plan.nr_shells;
+  // grid = (shell, ray tile): workgroups are dispatched x-fastest, so the K workgroups of one ray tile run
+  // close together in time and their K partial writes into the tile's [N,K,3] / [N,K] lines (12 and 4 bytes
+  // at a stride of 12 K and 4 K) merge in L2.  With the shell on grid.y every line was written K times a
+  // whole pass over the frame apart: at 1920x1080, K = 7 the launch wrote 1.22 GB for 0.46 GB of outputs
+  // (profiles/r05/k7_*).
+  const long long n = (long long)SHADE_TILE_IDX * SH_BLOCK + threadIdx.x;
+  const int s = SHADE_SHELL_IDX, K = plan.nr_shells;
   if (n >= N) return;
   HitCtx c;
   float nrm[3];
@@ -320,11 +338,13 @@ __global__ __launch_bounds__(SH_BLOCK, NT_SHADE_FWD_OCC) void nt_shade_fwd_kerne
     } else {
       alpha = 1.0f;
     }
+    // (hits only: the backward reads act_in for hits only, and at 71 % misses the zeros were 165 MB of the
+    //  464 MB this launch wrote at 1920x1080, K = 7)
+    if (act_out) act_out[(long long)s * N + n] = act;
   } else if (coeffs_out) {
     float* co = coeffs_out + ((long long)s * N + n) * 64;
     for (int i = 0; i < 64; ++i) co[i] = 0.f;
   }
-  if (act_out) act_out[(long long)s * N + n] = act;
   const long long o = n * K + s;
   surfs_rgb[3 * o] = rgb[0];
   surfs_rgb[3 * o + 1] = rgb[1];
@@ -391,8 +411,8 @@ __global__ __launch_bounds__(SHB_BLOCK, RECOMPUTE ? 2 : NT_SHADE_BWD_OCC) void n
     build_lut(plan, s_lut);
     __syncthreads();
   }
-  const long long n = (long long)blockIdx.x * SHB_BLOCK + threadIdx.x;
-  const int s = blockIdx.y, K = plan.nr_shells;
+  const long long n = (long long)SHADE_TILE_IDX * SHB_BLOCK + threadIdx.x;     // (shell, ray tile) as in the forward:
+  const int s = SHADE_SHELL_IDX, K = plan.nr_shells;                          // the reads of g_surfs_* share lines
   const int t = threadIdx.x;
   HitCtx c;
   c.hit = false;
@@ -600,7 +620,7 @@ extern "C" int vsa_nt_shade_fwd(const vsa_nt_plan* plan, const int32_t* hit_slot
   if (!hit_slot || !tex_uv || !rays_d || !tris || !slot_of || !seg_start || !texels || !surfs_rgb ||
       !surfs_alpha)
     return VSA_ERR_ARG;
-  dim3 grid(vsa_div_up(nr_rays, SH_BLOCK), plan->nr_shells);
+  dim3 grid = SHADE_GRID(vsa_div_up(nr_rays, SH_BLOCK), plan->nr_shells);
   if (plan->rgb_degrees == VSA_NT_MAX_DEG && plan->alpha_degrees == VSA_NT_MAX_DEG)
     hipLaunchKernelGGL(nt_shade_fwd_kernel<true>, grid, dim3(SH_BLOCK), 0, (hipStream_t)stream, *plan,
                        hit_slot, tex_uv, rays_d, reinterpret_cast<const float4*>(tris), slot_of,
@@ -626,7 +646,7 @@ extern "C" int vsa_nt_shade_bwd(const vsa_nt_plan* plan, const int32_t* hit_slot
       !g_surfs_alpha || !grad_rows)
     return VSA_ERR_ARG;
   if (plan->row_base[VSA_MAX_SHELLS * VSA_NT_MAX_DEG] * 8 >= (1ll << 32)) return VSA_ERR_UNSUPPORTED;   // 32-bit atomic offsets
-  dim3 grid(vsa_div_up(nr_rays, SHB_BLOCK), plan->nr_shells);
+  dim3 grid = SHADE_GRID(vsa_div_up(nr_rays, SHB_BLOCK), plan->nr_shells);
   const bool full4 = plan->rgb_degrees == VSA_NT_MAX_DEG && plan->alpha_degrees == VSA_NT_MAX_DEG;
   if (act_in && full4)
     hipLaunchKernelGGL((nt_shade_bwd_kernel<false, true>), grid, dim3(SHB_BLOCK), 0, (hipStream_t)stream, *plan,

@@ -116,22 +116,56 @@ class StepSignals:
             raise ValueError(f"phases {self.phase_end} do not cut shells 0..{nr_shells}")
         n = len(self.phase_end)
         self.n = n
-        # [flags (n) | flag_w | epoch | counters (n)], one allocation, zero
-        self.words = torch.zeros(2 * n + 2, dtype=torch.int32, device=device)
-        self.flags, self.flag_w = self.words[:n], self.words[n:n + 1]
-        self.epoch, self.counters = self.words[n + 1:n + 2], self.words[n + 2:]
-        self.epoch_host = 0          # the device epoch after the steps launched so far
-        self.wait_mode = int(wait_mode)
         import ctypes
+        from . import _lib
+        # flags: n phase words + the weights word, each its own signal allocation (include/volsurfs_hip.h:
+        # vsa_dp_flags — the command processor waits on those, no wave is parked on a CU); epoch and the
+        # per-phase workgroup counters: plain device words
+        self._flags = ctypes.c_void_p()
+        rc = _lib.lib().vsa_dp_flags_create(ctypes.c_int(n + 1), ctypes.byref(self._flags))
+        if rc != 0:
+            raise _lib.VolsurfsHipError(f"vsa_dp_flags_create failed with status {rc}")
+        self.words = torch.zeros(n + 1, dtype=torch.int32, device=device)
+        self.epoch, self.counters = self.words[:1], self.words[1:]
+        self.epoch_host = 0          # the device epoch after the steps launched so far
+        self.on_weights_final = None   # eager steps call it behind the MLP backward (OverlappedStep: records an event)
+        self.wait_mode = int(wait_mode)
         self.phase_end_c = (ctypes.c_int32 * n)(*self.phase_end)
+
+    W = property(lambda self: self.n)     # index of the weights word in the flags
 
     def shell_range(self, p):
         return (self.phase_end[p - 1] if p else 0), self.phase_end[p]
 
-    def stream_wait(self, flag, value):
-        """The CURRENT stream waits until `flag` (a one-element view of self.words) holds `value`."""
+    def signal_weights(self):
+        """Stream-ordered: epoch += 1, weights word = epoch (a one-lane kernel: graph-capturable)."""
         from . import _lib
-        _lib.call("vsa_dp_stream_wait", flag, int(value), self.wait_mode, _lib.stream_ptr())
+        _lib.call("vsa_dp_signal", self._flags, self.n, self.epoch, 1, _lib.stream_ptr())
+
+    def stream_wait(self, index, value):
+        """The CURRENT stream waits until flag word `index` (0..n-1: phases, n: weights) holds `value`."""
+        from . import _lib
+        _lib.call("vsa_dp_stream_wait", self._flags, int(index), int(value), self.wait_mode, _lib.stream_ptr())
+
+    def read(self):
+        """(flag words [n + 1], device epoch, counters [n]) as Python ints; synchronises (tests)."""
+        import ctypes
+        from . import _lib
+        out = (ctypes.c_uint32 * (self.n + 1))()
+        rc = _lib.lib().vsa_dp_flags_read(self._flags, out)
+        if rc != 0:
+            raise _lib.VolsurfsHipError(f"vsa_dp_flags_read failed with status {rc}")
+        w = self.words.cpu().tolist()
+        return list(out), w[0], w[1:]
+
+    def __del__(self):
+        try:
+            from . import _lib
+            if getattr(self, "_flags", None):
+                _lib.lib().vsa_dp_flags_destroy(self._flags)
+        except Exception:
+            pass
+        self._flags = None
 
 
 class OverlappedStep:
@@ -151,39 +185,60 @@ class OverlappedStep:
         self.overlap = GradientOverlap(world, group, wire_dtype, force)
         self.side = torch.cuda.Stream(device=dev)
         self.active = world > 1 or force
+        self.signals.on_weights_final = self._weights_final
 
     def eager(self, record=False):
         return self.pipe.step(record=record, dp=self.signals)
 
-    def run_split(self, prefix, rest):
-        """The pipelined form (pipe.capture_graph_split): `prefix()` — the step's parameter- and
-        gradient-free head: ray order, traversal, mark / compact, 0.33 ms of the 2.5 — is enqueued BEFORE
-        the current stream waits for the previous step's reduction, so the tail of that reduction (its last
-        phase, the hand-offs between the streams; in training also the optimiser on its side stream) runs
-        beside it; then the wait, then `rest()`, then this step's collectives as in run().  Every step's
-        gradients are still fully reduced before anything reads them; call finish() behind the last step."""
+    def run_split(self, prefix, mid, tail):
+        """The pipelined form (pipe.capture_graph_split; replay_prefix / replay_mid / replay_tail):
+        `prefix()` — the step's parameter- and gradient-free head: ray order, traversal, mark / compact,
+        0.33 ms of the 2.5 — is enqueued BEFORE the current stream waits for the previous step's reduction, so
+        the tail of that reduction (its last phase, the hand-offs between the streams; in training also the
+        optimiser on its side stream) runs beside it; then the wait, then `mid()` (zero_grad .. MLP backward),
+        an event (weights.grad is final), `tail()` (the hash-grid backward, ONE launch) and this step's
+        collectives.  Every step's gradients are still fully reduced before anything reads them; call
+        finish() behind the last step."""
         prefix()
         self.overlap.wait()
-        out = rest()
+        mid()
+        self._weights_final()
+        out = tail()
         self._enqueue_reductions()
         return out
 
     def finish(self):
         self.overlap.wait()
 
+    def _weights_final(self):
+        if self.active:
+            self._mid_event = torch.cuda.Event()
+            self._mid_event.record()
+
     def _enqueue_reductions(self):
+        """The side stream's program for the step just launched.  It first waits for the EVENT behind the MLP
+        backward and only then for the phase flags: a flag wait that sits at the head of another hardware
+        queue while the step's twenty-odd launches go by costs the step 0.6-0.9 ms on this stack (whether the
+        command processor polls a signal word or a one-lane kernel does: profiles/r05/dp_schedule_one_gpu.txt);
+        a pending event wait costs nothing, and behind it the flag waits are only ever pending beside the
+        hash-grid backward itself."""
         sg, bank = self.signals, self.pipe.bank
         sg.epoch_host += 1
         if not self.active:
             return
         e = sg.epoch_host
+        ev = getattr(self, "_mid_event", None)
+        self._mid_event = None
         # (after the producer: a wait queued ahead of the kernel that satisfies it could share its hardware queue)
         with torch.cuda.stream(self.side):
-            sg.stream_wait(sg.flag_w, e)
+            if ev is not None:
+                self.side.wait_event(ev)
+            else:
+                sg.stream_wait(sg.W, e)         # a one-graph / un-instrumented launch: the weights word instead
             self.overlap.reduce_async(bank.weights.grad)
             for p in range(sg.n - 1):
                 a, b = sg.shell_range(p)
-                sg.stream_wait(sg.flags[p:p + 1], e)
+                sg.stream_wait(p, e)
                 self.overlap.reduce_async(bank.tables.grad[a * 8:b * 8])
         # the last phase is final when the launch ends: its all-reduce is simply stream-ordered behind the
         # step (one cross-stream hand-off less on the only part of the reduction that nothing hides)

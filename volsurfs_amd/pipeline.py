@@ -222,10 +222,12 @@ class KShellPipeline:
         return self.last_hits, self.last_slots
 
     def capture_graph_split(self, **step_kw):
-        """The step as TWO graphs: `replay_prefix()` = what does not read a parameter or touch a
-        gradient (ray tile order, traversal, mark / compact), `replay_rest()` = everything else.  A
-        data-parallel caller launches the prefix while the previous step's gradient reduction (and, in
-        training, the optimiser) is still running, waits, then launches the rest
+        """The step as THREE graphs: `replay_prefix()` = what does not read a parameter or touch a
+        gradient (ray tile order, traversal, mark / compact); `replay_mid()` = zero_grad .. MLP backward;
+        `replay_tail()` = the hash-grid backward (one launch).  A data-parallel caller launches the prefix
+        while the previous step's gradient reduction (and, in training, the optimiser) is still running,
+        waits, launches mid, records "weights.grad final", launches tail and queues its flag waits behind
+        that record — so that they are pending beside ONE kernel, not beside twenty
         (parallel.OverlappedStep.run_split)."""
         self._static_rgb = None
         s = torch.cuda.Stream()
@@ -234,17 +236,27 @@ class KShellPipeline:
             for _ in range(2):
                 self.step(**step_kw)
         torch.cuda.current_stream().wait_stream(s)
-        self._graph_prefix, self._graph_rest = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self._graph_prefix, self._graph_mid, self._graph_tail = (torch.cuda.CUDAGraph() for _ in range(3))
         with torch.cuda.graph(self._graph_prefix):
             self.step(part="prefix", **step_kw)
-        with torch.cuda.graph(self._graph_rest, pool=self._graph_prefix.pool()):
-            self._static_rgb = self.step(part="rest", **step_kw)
+        with torch.cuda.graph(self._graph_mid, pool=self._graph_prefix.pool()):
+            self.step(part="mid", **step_kw)
+        with torch.cuda.graph(self._graph_tail, pool=self._graph_prefix.pool()):
+            self._static_rgb = self.step(part="tail", **step_kw)
 
     def replay_prefix(self):
         self._graph_prefix.replay()
 
+    def replay_mid(self):
+        self._graph_mid.replay()
+
+    def replay_tail(self):
+        self._graph_tail.replay()
+        return self._static_rgb
+
     def replay_rest(self):
-        self._graph_rest.replay()
+        self._graph_mid.replay()
+        self._graph_tail.replay()
         return self._static_rgb
 
     def capture_graph(self, **step_kw):
@@ -281,13 +293,16 @@ class KShellPipeline:
         of tables.grad final" in dp's flags and parallel.OverlappedStep's side stream waits on them.
 
         part: None = the whole step; "prefix" = only its parameter- and gradient-free head (ray tile
-        order, traversal, mark / compact), "rest" = the remainder of a step whose prefix has run."""
+        order, traversal, mark / compact); "mid" = zero_grad .. MLP backward of a step whose prefix has run;
+        "tail" = the hash-grid backward of a step whose mid has run; "rest" = mid + tail."""
         from .composite import composite_fwd_raw, composite_bwd_raw
         N, K = self.nr_rays, self.K
         T, bank = self.timer, self.bank
         acct = getattr(self, "acct", None) or {}     # algorithmic bytes per stage (stats())
 
-        if part == "rest":
+        if part == "tail":
+            return self._step_tail(record, acct, grad_ready, dp, self._mid_out)
+        if part in ("rest", "mid"):
             rays_d, gt, hit_slot, tex_uv = self._prefix_out
         else:
             rays_d, gt, hit_slot, tex_uv = self._step_prefix(record, acct)
@@ -295,7 +310,13 @@ class KShellPipeline:
                 self._prefix_out = (rays_d, gt, hit_slot, tex_uv)
                 return None
         T.run("zero_grad", bank.zero_grads, record, bytes=(bank.tables.numel() + bank.weights.numel()) * 4)
-        return self._step_rest(record, acct, grad_ready, dp, rays_d, gt, hit_slot, tex_uv)
+        rgb = self._step_rest(record, acct, dp, rays_d, gt, hit_slot, tex_uv)
+        if part == "mid":
+            self._mid_out = rgb
+            return None
+        if dp is not None and dp.on_weights_final is not None and not torch.cuda.is_current_stream_capturing():
+            dp.on_weights_final()          # (eager step: weights.grad is final on the current stream here)
+        return self._step_tail(record, acct, grad_ready, dp, rgb)
 
     def _step_prefix(self, record, acct):
         N, T, bank = self.nr_rays, self.timer, self.bank
@@ -317,7 +338,7 @@ class KShellPipeline:
                        bytes=acct.get("nt_mark_compact", 0))
         return rays_d, gt, hit_slot, tex_uv
 
-    def _step_rest(self, record, acct, grad_ready, dp, rays_d, gt, hit_slot, tex_uv):
+    def _step_rest(self, record, acct, dp, rays_d, gt, hit_slot, tex_uv):
         N, K = self.nr_rays, self.K
         T, bank = self.timer, self.bank
         mlp_flops = getattr(self, "mlp_flops_fwd", 0)
@@ -352,9 +373,15 @@ class KShellPipeline:
               bytes=acct.get("nt_shade_bwd", 0), bound="atomic")
         T.run("nt_mlp_bwd", lambda: bank.backward_mlp(self.grad_scale), record,
               bytes=acct.get("nt_mlp_bwd", 0), flops=2 * mlp_flops, bound="mfma")
+        if dp is not None:
+            dp.signal_weights()            # epoch += 1 (the hash-grid backward publishes it), weights word = epoch
+        return rgb
+
+    def _step_tail(self, record, acct, grad_ready, dp, rgb):
+        """The hash-grid backward: the last launch of the step."""
+        K, T, bank = self.K, self.timer, self.bank
         enc_bytes = acct.get("nt_encode_bwd", 0)
         if dp is not None:
-            _lib.call("vsa_dp_signal", dp.flag_w, dp.epoch, 1, _lib.stream_ptr())
             T.run("nt_encode_bwd", lambda: bank.backward_encode_phased(self.grad_scale, dp), record,
                   bytes=enc_bytes)
         elif grad_ready is None:
