@@ -156,6 +156,60 @@ def workload_key(args):
             f"charts={args.atlas_charts} init={args.init} stress={int(bool(args.stress))} cold={int(bool(args.cold))}")
 
 
+def pmc_busy(args, kernel):
+    """PMC-derived pipe occupancy of a kernel on this workload (profiles/pmc_summary.json, written by
+    tools/make_pmc_json.py from separate rocprofv3 --pmc passes): {"mfma_busy", "valu_insts", ...}, or None when
+    the file holds nothing for this workload at these kernel sources."""
+    f = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if not os.path.exists(f):
+        return None
+    e = json.load(open(f)).get("workloads", {}).get(workload_key(args))
+    if not e or e.get("_kernel_source_sha256") != kernel_source_hash():
+        return None
+    return e.get(kernel)
+
+
+TRACE_TRIP_LATENCY_NS = 94.0     # one dependent 32-byte node fetch served by L2: ~225 cycles at 2.4 GHz
+                                 # (MI355X_MICROARCH.md "global_load_dword (L2-hit latency) ~180-225 cyc")
+
+
+def trace_ceiling(pipe, trace_ms, nr_cus=256):
+    """Where the traversal launch stands against what bounds it.  HBM bandwidth is the wrong
+    yardstick (5 % of it, traffic = algorithmic bytes): a ray's walk is a chain of DEPENDENT node fetches, so the
+    launch is bounded by (a) its longest wave's chain and (b) the rate at which the resident waves can take
+    trips, one L2 round trip each.  Counted with vsa_trace_q_stats (the same walk with counters)."""
+    ro, rd = (pipe._o_t, pipe._d_t) if pipe.image_hw is not None else (pipe.rays_o, pipe.rays_d)
+    st = pipe.tracer.walk_stats(ro, rd)
+    sec = trace_ms * 1e-3
+    waves_per_cu = 10            # one-wave workgroups, 6 KiB of LDS stack + 96 VGPRs each (PMC: 10 resident per CU)
+    trip_rate_peak = nr_cus * waves_per_cu / (TRACE_TRIP_LATENCY_NS * 1e-9)
+    l2_bytes = st["lane_visits"] * 32 + st["tri_tests"] * 48
+    return {
+        "lane_node_visits": st["lane_visits"], "lane_tri_tests": st["tri_tests"], "wave_trips": st["wave_trips"],
+        "waves": st["waves"], "max_wave_trips": st["max_wave_trips"],
+        "lane_utilisation": st["lane_visits"] / max(1.0, 64.0 * st["wave_trips"]),
+        "Gvisits/s": st["lane_visits"] / sec / 1e9, "Gtri_tests/s": st["tri_tests"] / sec / 1e9,
+        "L2_GB/s": l2_bytes / sec / 1e9, "L2_frac_of_17TB/s": l2_bytes / sec / 17e12,
+        "wave_trips/s": st["wave_trips"] / sec, "wave_trips/s_ceiling": trip_rate_peak,
+        "latency_frac": st["wave_trips"] / sec / trip_rate_peak,
+        "longest_chain_ms": st["max_wave_trips"] * TRACE_TRIP_LATENCY_NS * 1e-6,
+        "note": "latency roofline: 256 CUs x 10 resident waves, one L2 round trip (94 ns) per wave trip; "
+                "longest_chain_ms = the launch's floor whatever the occupancy"}
+
+
+def kernel_table(fn, iters):
+    """Per C-ABI entry point: ms per iteration and calls per iteration over `iters` calls of fn(), events directly
+    around every library launch (the torch glue in between is not in it)."""
+    from volsurfs_amd import _lib
+    _lib.kernel_events = {}
+    for _ in range(iters):
+        fn()
+    tot = _lib.kernel_totals()
+    _lib.kernel_events = None
+    return {k: {"ms_per_iter": round(ms / iters, 4), "calls_per_iter": round(n / iters, 2)}
+            for k, (ms, n) in sorted(tot.items(), key=lambda kv: -kv[1][0])}
+
+
 def cpu_baseline(pipe, sample_rays):
     """The oracle (oracle/pipeline.py: CPU restatement of the reference path,
     evaluated the reference's way — 4 network evaluations per hit, degree and
@@ -275,6 +329,27 @@ def run_train(args, world, rank, dev, dist):
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         in_sync = bool((hi == lo).all().item())
+    ktab = roof = None
+    if rank == 0 and dist is None:
+        ktab = kernel_table(lambda: one(False), 20)
+        top = next(iter(ktab))
+        roof = {"kernel": top, "kernel_ms": ktab[top]["ms_per_iter"] / max(1.0, ktab[top]["calls_per_iter"])}
+        if not legacy:        # algorithmic bytes of the neural-texture stages at THIS batch (neural_textures.stage_accounting)
+            from volsurfs_amd.neural_textures import stage_accounting
+            n_last = state["nr_rays"]
+            hits = int(getattr(method, "last_nr_samples", 0))
+            acct, fl, slots = stage_accounting(method.bank, n_last, hits)
+            key = top.replace("vsa_", "").replace("_phased", "")
+            if key in acct:
+                sec = roof["kernel_ms"] * 1e-3
+                if key in ("nt_mlp_fwd", "nt_mlp_bwd"):
+                    f = fl * (2 if key.endswith("bwd") else 1)
+                    roof.update(bound="mfma", achieved=f / sec / 1e12, peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s",
+                                frac=f / sec / 1e12 / MFMA_F16_PEAK_TFLOPS, traffic=None)
+                else:
+                    roof.update(bound="hbm", achieved=acct[key] / sec / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                                frac=acct[key] / sec / 1e9 / HBM_PEAK_GBS, traffic=None)
+                roof["units"] = {"rays": n_last, "hits": hits, "unique_texels": slots}
     if rank == 0:
         ms = dt / args.steps * 1e3
         nparams = sum(p.numel() for g in method.optimizer.param_groups for p in g["params"])
@@ -289,6 +364,9 @@ def run_train(args, world, rank, dev, dist):
             #  dynamic ray count, so on a host-bound loop it can be SLOWER than the real iterations)
             "fixed_ms_per_iter": fixed_ms, "fixed_share": min(1.0, fixed_ms / ms),
             "replicas_in_sync": in_sync,
+            # the library's launches of one iteration (events around each; the torch glue between them is the rest)
+            "kernels_ms": ktab, "kernels_ms_sum": None if ktab is None else round(sum(v["ms_per_iter"] for v in ktab.values()), 4),
+            "roofline": roof,
             "config": {"workload": ("BASELINE configs[2]: legacy permutohash (24x2, 2^18) + MLP [128,128,64] appearance"
                                     if legacy else "SH neural-texture appearance (configs[1]'s model)")
                        + f", K={args.shells} subdiv-{args.subdiv} shells, {args.views} views of {args.res}x{args.res}"
@@ -352,9 +430,29 @@ def run_dtu(args, world, rank, dev, dist):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+    ktab = roof = None
+    if rank == 0 and dist is None:
+        def one_batch():
+            m.grad_scale = GRAD_CHAIN_GAIN * float(batch)
+            train_step(m, o[:batch], d[:batch], gt[:batch], iter_nr=state["it"], is_first_iter=False, world=world,
+                       sync_losses=False)
+            state["it"] += 1
+        ktab = kernel_table(one_batch, 3)
+        # the fp32 matrix-core MLP of the background field: executed FLOPs of its two networks over the batch's samples
+        dims = [[l.in_features, l.out_features] for mm in (bg.mlp_feat_and_density, bg.mlp_rgb)
+                for l in mm.layers if isinstance(l, torch.nn.Linear)]
+        fl_fwd = 2 * sum(a * b for a, b in dims) * batch * 32
+        for key, mult in (("vsa_mlp_fwd", 1), ("vsa_mlp_bwd", 2)):
+            if key in ktab:
+                sec = ktab[key]["ms_per_iter"] * 1e-3
+                ktab[key].update({"TFLOP/s": round(fl_fwd * mult / sec / 1e12, 2), "mfma_f32_frac": round(fl_fwd * mult / sec / 1e12 / 157.3, 4)})
+        top = next(iter(ktab))
+        roof = {"kernel": top, "kernel_ms": ktab[top]["ms_per_iter"], "peak_f32_mfma_TFLOP/s": 157.3,
+                **{k: v for k, v in ktab[top].items() if k in ("TFLOP/s", "mfma_f32_frac")}}
     if rank == 0:
         nb = (N + batch - 1) // batch
         print(json.dumps({
+            "kernels_ms_per_batch": ktab, "roofline": roof,
             "metric": "Mrays/s (fwd+bwd+Adam) at 1600x1200, K=5 shells + learned background",
             "value": N * world * args.steps / dt / 1e6, "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": min(args.warmup, 2), "ms_per_step": dt / args.steps * 1e3,
@@ -672,10 +770,10 @@ def main():
     if rank == 0:
         total_rays = (pipe.loss_rays if strong else N * world) * args.steps
         value = total_rays / dt / 1e6
-        # dominant KERNEL: the two encode stages are two launches each (dense / hashed levels)
-        launches = {"nt_encode_fwd": 2, "nt_encode_bwd": 2}
-        dom = max(((k, v) for k, v in stages.items() if k != "grad_allreduce"),
-                  key=lambda kv: kv[1]["ms"] / launches.get(kv[0], 1))
+        # dominant KERNEL (every stage of the step is one library launch since round 4), by the kernels' own
+        # durations (events directly around the launches): a stage's eager time also holds the host's gaps
+        dom = max(((k, v) for k, v in stages.items() if k != "grad_allreduce" and "vsa_" + k in kernel_ms),
+                  key=lambda kv: kernel_ms["vsa_" + kv[0]])
         name, st = dom
         # PMC-measured HBM bytes per launch (tools/traffic.sh -> profiles/traffic.json), valid only
         # for the kernel sources they were collected at: a stale file is reported as null
@@ -692,13 +790,17 @@ def main():
                 traffic_all = {k: v for k, v in tj.items() if not k.startswith("_")}
         # the kernel's own duration: events directly around its launch (a stage also holds the
         # small torch kernels next to it); one launch per stage except the encode stages
-        k_ms = kernel_ms.get("vsa_" + name, st["ms"]) if name not in launches else st["ms"]
+        k_ms = kernel_ms.get("vsa_" + name, st["ms"])
         if st.get("flops") and st.get("bound") == "mfma":
             # executed, unpadded FLOPs of the texels this launch evaluates
             ach = st["flops"] / (k_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": name, "kernel_ms": k_ms, "achieved": ach,
                     "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F16_PEAK_TFLOPS,
-                    "traffic": traffic, "hbm_GB/s": st["bytes"] / (k_ms * 1e-3) / 1e9}
+                    "traffic": traffic, "hbm_GB/s": st["bytes"] / (k_ms * 1e-3) / 1e9,
+                    # `frac` counts the executed UNPADDED FLOPs of the texels (a third of this kernel's matrix work is
+                    # the forward recompute, a fifth of the rest W3 padded to 32 rows: even a saturated pipe reads 0.53);
+                    # `pmc` = what the matrix pipe itself saw (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs))
+                    "pmc": pmc_busy(args, name)}
         else:
             ach = st["bytes"] / (k_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": name, "kernel_ms": k_ms, "achieved": ach, "peak": HBM_PEAK_GBS,
@@ -729,6 +831,10 @@ def main():
         }
         if traffic_note:
             out["roofline"]["traffic_note"] = traffic_note
+        if traffic_all:
+            out["traffic_bytes_per_launch"] = traffic_all          # PMC, every kernel of the step on this workload
+        if dist is None and pipe.tracer.node_format == "q16":
+            out["stage_roofline"]["trace"].update(trace_ceiling(pipe, kernel_ms.get("vsa_trace_q_fb", stages["trace"]["ms"])))
         if world == 1 and dist is None and not args.no_noisy and not (args.noise or args.atlas_charts or args.stress or args.cold):
             out.update(extra_scene(args, dev, use_graph, "noisy", noise=0.05, atlas_charts=6, init="spread"))
             out.update(extra_scene(args, dev, use_graph, "stress", stress=True, init="spread"))

@@ -167,6 +167,13 @@ int vsa_trace_q_fb(const uint32_t* qnodes, const float* tris, const int32_t* mes
                    const float* mesh_frames, int nr_meshes, int max_depth, const float* rays_o,
                    const float* rays_d, int nr_rays, float t_min, float* hit_t, int32_t* hit_slot,
                    float* hit_uv, void* feedback, long long feedback_bytes, int phase, void* stream);
+/* Measurement aid (bench.py's stage_roofline.trace; not on the product path): the walk of vsa_trace_q with
+ * counters.  stats (device, 5 x u64, overwritten): lane-level node visits (one 32-byte node fetch each),
+ * lane-level triangle tests (48 bytes each), wave-level trips of the walk loop summed over the waves (one trip =
+ * one dependent node fetch of a whole wave), waves, and the longest wave's trips. */
+int vsa_trace_q_stats(const uint32_t* qnodes, const float* tris, const int32_t* mesh_roots,
+                      const float* mesh_frames, int nr_meshes, int max_depth, const float* rays_o,
+                      const float* rays_d, int nr_rays, float t_min, uint64_t* stats, void* stream);
 /* vsa_hit_attributes: expands one mesh's hit records [N] into the dict
  * raytracelib returns (volsurfs.py:496-501): is_hit [N] u8, triangles_id [N]
  * i32 (original face index, -1 on miss), positions [N,3] = o + t d, normals

@@ -16,12 +16,15 @@ python bench.py --workload dtu > gpurun_out/${tag}_dtu.json 2>/dev/null
 python bench.py --workload render > gpurun_out/${tag}_render.json 2>/dev/null
 python bench.py --res 1080 --width 1920 --shells 7 --subdiv 8 --no-cpu-baseline --no-noisy --steps 50 > gpurun_out/${tag}_bench_1080p_K7_subdiv8.json 2>/dev/null
 python bench.py --res 1080 --width 1920 --shells 7 --subdiv 8 --no-cpu-baseline --no-noisy --steps 50 --cold > gpurun_out/${tag}_bench_1080p_K7_subdiv8_cold.json 2>/dev/null
-python bench.py --gpus 1 --force-dist --dist-backend nccl --no-cpu-baseline --no-noisy --steps 50 > gpurun_out/${tag}_bench_rccl_one_rank.json 2>/dev/null
+python bench.py --gpus 1 --force-dist --dist-backend nccl --no-cpu-baseline --no-noisy > gpurun_out/${tag}_bench_rccl_one_rank.json 2>/dev/null
 bash tools/prof.sh ${tag}_prof_frame --steps 20 --warmup 5 --no-noisy | tail -3
 bash tools/prof.sh ${tag}_prof_render --workload render --steps 20 --warmup 5 | tail -3
 bash tools/prof.sh ${tag}_prof_train --workload train --steps 100 --warmup 30 | tail -3
-bash tools/traffic.sh | tail -12
-bash tools/pmc.sh ${tag}_pmc_mlp "nt_mlp_bwd" "SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" --steps 3 --warmup 1 --no-noisy | tail -10
-bash tools/pmc.sh ${tag}_pmc_mlp2 "nt_mlp_bwd" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" --steps 3 --warmup 1 --no-noisy | tail -10
-bash tools/pmc.sh ${tag}_pmc_enc "nt_encode" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" --steps 3 --warmup 1 --no-noisy | tail -40
+bash tools/traffic.sh frame | tail -12
+bash tools/traffic.sh k7 --res 1080 --width 1920 --shells 7 --subdiv 8 | tail -12
+P="--steps 3 --warmup 1 --no-noisy"
+bash tools/pmc.sh ${tag}_pmc_a "nt_mlp|nt_encode|nt_shade|trace_qf" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" $P | tail -4
+bash tools/pmc.sh ${tag}_pmc_b "nt_mlp|nt_encode|nt_shade|trace_qf" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" $P | tail -4
+K7="--res 1080 --width 1920 --shells 7 --subdiv 8"
+bash tools/pmc.sh ${tag}_pmck7_a "nt_mlp|nt_encode|nt_shade|trace_qf" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" $P $K7 | tail -4
 if [ -f variants/lib_stamp.so ]; then bash tools/stamp_ab.sh stamp > gpurun_out/${tag}_mlp_bwd_stamps.txt 2>&1; cat gpurun_out/${tag}_mlp_bwd_stamps.txt; fi

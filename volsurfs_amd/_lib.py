@@ -93,6 +93,13 @@ def kernel_ms():
     return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in (kernel_events or {}).items()}
 
 
+def kernel_totals():
+    """{entry point: (total ms, calls)} over the calls recorded in `kernel_events`."""
+    import torch
+    torch.cuda.synchronize()
+    return {k: (sum(a.elapsed_time(b) for a, b in v), len(v)) for k, v in (kernel_events or {}).items()}
+
+
 def call(name, *args):
     """Call a C-ABI entry point; raise on a non-zero status."""
     fn = getattr(lib(), name)

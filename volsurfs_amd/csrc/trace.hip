@@ -336,11 +336,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_q_kernel(
 // measures its cost that way; the rejected budgeted three-pass form, the 4-wide nodes and the
 // persistent-lane kernel of round 3 — all bit-exact, all slower: profiles/NOTEBOOK.md A9.4 — left the
 // library in round 5 and live in the history at e64f229).
-template <int STACK, bool BUDGETED>
+template <int STACK, bool BUDGETED, bool COUNT = false>
 __device__ __forceinline__ int q_walk(const uint4* __restrict__ qnodes, const float4* __restrict__ tris,
                                        const QRay& qr, float ox, float oy, float oz, float dx, float dy,
                                        float dz, float t_min, int& cur, int& sp, Hit& best,
-                                       int (*s_stack)[TRACE_BLOCK], int lane, int budget) {
+                                       int (*s_stack)[TRACE_BLOCK], int lane, int budget,
+                                       int* lane_visits = nullptr, int* lane_tests = nullptr) {
   // The loops are written on ballots, i.e. as the wave-level loops they are, so that the trip count
   // is a scalar of the WAVE (a per-lane counter would only count that lane's own trips).
   int trips = 0;
@@ -349,6 +350,7 @@ __device__ __forceinline__ int q_walk(const uint4* __restrict__ qnodes, const fl
     while (__builtin_amdgcn_ballot_w64((unsigned)cur < (unsigned)TRACE_EMPTY) != 0) {
       ++trips;
       if (!((unsigned)cur < (unsigned)TRACE_EMPTY)) continue;
+      if constexpr (COUNT) ++*lane_visits;
       const uint4 a = qnodes[2 * (long long)cur], b = qnodes[2 * (long long)cur + 1];
       float tn0, tn1;
       const bool h0 = qbox_test(a.x, a.y, a.z, qr, t_min, best.t, tn0);
@@ -369,6 +371,7 @@ __device__ __forceinline__ int q_walk(const uint4* __restrict__ qnodes, const fl
     if (cur != TRACE_EMPTY) {
       const int code = ~cur;
       const int first = code >> 4, cnt = code & 15;
+      if constexpr (COUNT) *lane_tests += cnt;
       for (int i0 = 0; i0 < cnt; i0 += 4) {
         float4 tv[4][3];
 #pragma unroll
@@ -515,6 +518,78 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_qf_kernel(
     fb.next_flag[item] = listed ? 1 : 0;
     if (item == 0) fb.next[0] = nr_items;
   }
+}
+
+// What a traversal launch DID, for its place against a ceiling (bench.py stage_roofline.trace): the walk of
+// trace_q_kernel / trace_qf_kernel (same boxes, same order) with counters — lane-level node visits (one 32-byte
+// node fetch each), lane-level triangle tests (48 bytes each), wave-level trips of the walk loop (a trip = one
+// dependent node fetch of the whole wave: the unit of the latency chain) and waves.  Not on the product path.
+template <int STACK>
+__global__ __launch_bounds__(TRACE_BLOCK) void trace_q_count_kernel(
+    const uint4* __restrict__ qnodes, const float4* __restrict__ tris, Roots roots, Frames frames,
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, int N, float t_min,
+    unsigned long long* __restrict__ stats) {
+  __shared__ int s_stack[STACK][TRACE_BLOCK];
+  const int lane = threadIdx.x;
+  const long long n = (long long)blockIdx.x * TRACE_BLOCK + lane;
+  const int mesh = blockIdx.y;
+  int visits = 0, tests = 0, trips = 0, max_trips = 0;
+  if (n < N) {
+    const float ox = rays_o[3 * n], oy = rays_o[3 * n + 1], oz = rays_o[3 * n + 2];
+    const float dx = rays_d[3 * n], dy = rays_d[3 * n + 1], dz = rays_d[3 * n + 2];
+    const float* fr = frames.f[mesh];
+    QRay qr;
+    const float gx = (ox - fr[0]) / fr[3] + 1.0f, gy = (oy - fr[1]) / fr[4] + 1.0f, gz = (oz - fr[2]) / fr[5] + 1.0f;
+    const float ix = 1.0f / (dx / fr[3]), iy = 1.0f / (dy / fr[4]), iz = 1.0f / (dz / fr[5]);
+    qr.ix = f32x2_t{ix, ix}, qr.iy = f32x2_t{iy, iy}, qr.iz = f32x2_t{iz, iz};
+    qr.cx = f32x2_t{-(gx * ix), -(gx * ix)};
+    qr.cy = f32x2_t{-(gy * iy), -(gy * iy)};
+    qr.cz = f32x2_t{-(gz * iz), -(gz * iz)};
+    Hit best;
+    best.t = INFINITY, best.u = best.v = 0.f, best.slot = -1, best.id = 0x7fffffff;
+    int cur = roots.root[mesh], sp = 0;
+    trips = q_walk<STACK, false, true>(qnodes, tris, qr, ox, oy, oz, dx, dy, dz, t_min, cur, sp, best, s_stack, lane, 0,
+                                       &visits, &tests);
+  }
+  // wave sums -> one atomic per counter and wave
+  for (int o = 32; o > 0; o >>= 1) {
+    visits += __shfl_down(visits, o);
+    tests += __shfl_down(tests, o);
+  }
+  max_trips = trips;      // (wave-uniform)
+  if (lane == 0) {
+    atomicAdd(&stats[0], (unsigned long long)visits);
+    atomicAdd(&stats[1], (unsigned long long)tests);
+    atomicAdd(&stats[2], (unsigned long long)trips);
+    atomicAdd(&stats[3], 1ull);
+    atomicMax(&stats[4], (unsigned long long)max_trips);
+  }
+}
+
+extern "C" int vsa_trace_q_stats(const uint32_t* qnodes, const float* tris, const int32_t* mesh_roots,
+                                 const float* mesh_frames, int nr_meshes, int max_depth,
+                                 const float* rays_o, const float* rays_d, int nr_rays, float t_min,
+                                 uint64_t* stats, void* stream) {
+  if (nr_meshes < 1 || nr_meshes > VSA_MAX_SHELLS || nr_rays < 1 || !mesh_roots || !mesh_frames) return VSA_ERR_ARG;
+  if (max_depth >= TRACE_STACK) return VSA_ERR_UNSUPPORTED;
+  if (!qnodes || !tris || !rays_o || !rays_d || !stats) return VSA_ERR_ARG;
+  Roots r;
+  Frames fr;
+  for (int i = 0; i < VSA_MAX_SHELLS; ++i) {
+    r.root[i] = i < nr_meshes ? mesh_roots[i] : 0;
+    for (int j = 0; j < 6; ++j) fr.f[i][j] = i < nr_meshes ? mesh_frames[6 * i + j] : 1.0f;
+  }
+  VSA_HIP_TRY(hipMemsetAsync(stats, 0, 5 * sizeof(uint64_t), (hipStream_t)stream));
+  dim3 grid(vsa_div_up(nr_rays, TRACE_BLOCK), nr_meshes), block(TRACE_BLOCK);
+  if (max_depth < 24)
+    hipLaunchKernelGGL(trace_q_count_kernel<24>, grid, block, 0, (hipStream_t)stream,
+                       reinterpret_cast<const uint4*>(qnodes), reinterpret_cast<const float4*>(tris), r, fr, rays_o,
+                       rays_d, nr_rays, t_min, reinterpret_cast<unsigned long long*>(stats));
+  else
+    hipLaunchKernelGGL(trace_q_count_kernel<TRACE_STACK>, grid, block, 0, (hipStream_t)stream,
+                       reinterpret_cast<const uint4*>(qnodes), reinterpret_cast<const float4*>(tris), r, fr, rays_o,
+                       rays_d, nr_rays, t_min, reinterpret_cast<unsigned long long*>(stats));
+  VSA_RETURN_LAUNCH_STATUS();
 }
 
 // Per-hit attributes in the shape raytracelib returns them

@@ -184,41 +184,11 @@ class KShellPipeline:
         """Host-side read-back of frame statistics (outside the timed region) and the
         ALGORITHMIC bytes / FLOPs of every stage for this frame: each
         operand counted once per stage at its stored width, gathers per hit."""
-        from .neural_textures import ROW_QUADS
+        from .neural_textures import stage_accounting
         bank, N, K = self.bank, self.nr_rays, self.K
-        self.last_slots = P = int(bank.seg_start[K * 4].item())
         self.last_hits = M = int((self._hit_slot >= 0).sum().item())
-        seg = bank.seg_start.cpu().tolist()
-        fl, row_quads, slot_models = 0, 0, 0
-        for s_ in range(K):
-            for d in range(4):
-                P_sd = seg[s_ * 4 + d + 1] - seg[s_ * 4 + d]
-                row_quads += P_sd * ROW_QUADS[d]
-                for typ in range(2):
-                    C = bank.tex_channels(bank.tex_index(s_, typ, d))
-                    if C:
-                        fl += P_sd * 2 * (32 * 64 + 64 * 64 + 64 * C)
-                        slot_models += P_sd
-        self.mlp_flops_fwd = fl          # unpadded FLOPs of one forward over the unique texels
-        ntex = sum(1 for x in range(bank.n_tex) if bank.tex_channels(x))
-        rows_u8, rows_f16 = row_quads * 4, row_quads * 8      # texel rows u8, gradient rows f16
-        feats = slot_models * 64                      # 16 levels x f16x2 per (slot, model)
-        gathers = M * (16 * 4 + 4 * sum(ROW_QUADS) * 4 + 8) + N * 12   # slot ids + 16 texel rows + uv, dirs
         nodes_b = self.tracer.nodes.numel() * 4 + self.tracer.tris.numel() * 4
-        self.acct = {
-            "trace": N * (24 + 16 * K) + nodes_b,
-            # marks read twice (count, assign); per slot: mark set + cleared, slot_of, slot_xy
-            # (vsa_nt_compact_frame: nothing is written for untouched texels)
-            "nt_mark_compact": N * K * 20 + bank.dom_total * (1 + 1) + P * (1 + 1 + 4 + 8),
-            "nt_encode_fwd": P * 8 + feats + ntex * bank.n_entries * 4,
-            "nt_mlp_fwd": feats + rows_u8 + ntex * 8192 * 2,
-            # fused: texel centre in (per texture), feature planes + texel rows out, parameters once
-            "nt_encode_mlp_fwd": slot_models * 8 + feats + rows_u8 + ntex * (bank.n_entries * 4 + 8192 * 2),
-            "nt_shade_fwd": gathers + N * K * 16,
-            "nt_shade_bwd": gathers + N * K * 16 + rows_f16,
-            "nt_mlp_bwd": 2 * feats + 2 * rows_f16 + ntex * 8192 * (2 + 4),
-            "nt_encode_bwd": feats + P * 8 + ntex * bank.n_entries * 8,
-        }
+        self.acct, self.mlp_flops_fwd, self.last_slots = stage_accounting(bank, N, M, nodes_b)
         return self.last_hits, self.last_slots
 
     def capture_graph_split(self, **step_kw):

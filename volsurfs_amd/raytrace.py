@@ -152,6 +152,18 @@ class RayTracer:
                       rays_d, N, float(t_min), hit_t, hit_slot, hit_uv, _lib.stream_ptr())
         return hit_t, hit_slot, hit_uv
 
+    def walk_stats(self, rays_o, rays_d, t_min=0.0):
+        """{lane_visits, tri_tests, wave_trips, waves, max_wave_trips} of one traversal of these rays
+        (vsa_trace_q_stats: the same walk with counters; q16 nodes).  Synchronises; measurement only."""
+        N = rays_o.shape[0]
+        rays_o = _lib.check_f32(rays_o.contiguous(), N, 3)
+        rays_d = _lib.check_f32(rays_d.contiguous(), N, 3)
+        st = torch.zeros(5, dtype=torch.int64, device=rays_o.device)
+        _lib.call("vsa_trace_q_stats", self.qnodes, self.tris, self._roots, self._frames, self.nr_meshes,
+                  self.max_depth, rays_o, rays_d, N, float(t_min), st, _lib.stream_ptr())
+        v = st.cpu().tolist()
+        return dict(zip(("lane_visits", "tri_tests", "wave_trips", "waves", "max_wave_trips"), v))
+
     def feedback_header(self):
         """{tag, n0, n1, n2} of the half the LAST cost-feedback launch wrote (tests, diagnostics)."""
         half = ((self._fb[2] - 256) // 2) & ~255
