@@ -515,3 +515,16 @@ def test_rccl_one_rank_group_runs_every_collective_of_the_design():
     assert out["dist_backend"] == "nccl" and out["world"] == 1
     assert out["forward_equal"] and out["allreduce_identity"] and out["slices_reduced"] == 3 and out["grad_nonzero"]
     assert out["sharded_equals_plain"] and out["state_full"] and out["gather_equal"]
+
+
+def test_default_phases_cut_the_shells_with_the_smallest_phase_last():
+    """parallel.default_phases: at most three phases, strictly increasing ends, the last = K, the last phase (whose
+    all-reduce nothing hides) never larger than the others (runs on CPU)."""
+    from volsurfs_amd.parallel import default_phases
+    assert [default_phases(k) for k in (1, 2, 3, 5, 7, 9, 16)] == [[1], [1, 2], [1, 2, 3], [2, 4, 5], [3, 5, 7], [3, 6, 9],
+                                                                    [6, 11, 16]]
+    for k in range(1, 17):
+        ends = default_phases(k)
+        sizes = [b - a for a, b in zip([0] + ends, ends)]
+        assert ends[-1] == k and all(s > 0 for s in sizes) and sizes[-1] <= min(sizes[:-1] or [sizes[-1]])
+    assert default_phases(5, max_phases=5) == [1, 2, 3, 4, 5] and default_phases(5, max_phases=1) == [5]

@@ -15,6 +15,7 @@ python bench.py --workload train-permuto --steps 1000 --warmup 100 > gpurun_out/
 python bench.py --workload dtu > gpurun_out/${tag}_dtu.json 2>/dev/null
 python bench.py --workload render > gpurun_out/${tag}_render.json 2>/dev/null
 python bench.py --res 1080 --width 1920 --shells 7 --subdiv 8 --no-cpu-baseline --no-noisy --steps 50 > gpurun_out/${tag}_bench_1080p_K7_subdiv8.json 2>/dev/null
+bash tools/prof.sh ${tag}_prof_k7 --res 1080 --width 1920 --shells 7 --subdiv 8 --no-noisy --steps 10 --warmup 2 | tail -3
 python bench.py --res 1080 --width 1920 --shells 7 --subdiv 8 --no-cpu-baseline --no-noisy --steps 50 --cold > gpurun_out/${tag}_bench_1080p_K7_subdiv8_cold.json 2>/dev/null
 python bench.py --gpus 1 --force-dist --dist-backend nccl --no-cpu-baseline --no-noisy > gpurun_out/${tag}_bench_rccl_one_rank.json 2>/dev/null
 bash tools/prof.sh ${tag}_prof_frame --steps 20 --warmup 5 --no-noisy | tail -3
@@ -27,4 +28,3 @@ bash tools/pmc.sh ${tag}_pmc_a "nt_mlp|nt_encode|nt_shade|trace_qf" "SQ_VALU_MFM
 bash tools/pmc.sh ${tag}_pmc_b "nt_mlp|nt_encode|nt_shade|trace_qf" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" $P | tail -4
 K7="--res 1080 --width 1920 --shells 7 --subdiv 8"
 bash tools/pmc.sh ${tag}_pmck7_a "nt_mlp|nt_encode|nt_shade|trace_qf" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" $P $K7 | tail -4
-if [ -f variants/lib_stamp.so ]; then bash tools/stamp_ab.sh stamp > gpurun_out/${tag}_mlp_bwd_stamps.txt 2>&1; cat gpurun_out/${tag}_mlp_bwd_stamps.txt; fi

@@ -14,18 +14,43 @@
 // wave instruction adds contiguous row segments instead of 64 scattered dwords.
 #include "nt_common.h"
 
-#ifndef NT_SHADE_SHELL_FAST
-#define NT_SHADE_SHELL_FAST 1      /* 0: round 1-4's grid (ray tile, shell), for A/B */
+// Launch geometry of the two shading kernels: a workgroup = (one shell, one tile of consecutive rays).
+// NT_SHADE_MAP 2 (default): 1-D grid, XCD-aware — workgroups are dealt to the 8 XCDs round-robin by their linear
+//   id, so (tile t, shell s) gets id = ((t / 8) * K + s) * 8 + t % 8: the K workgroups of one tile run on ONE XCD,
+//   back to back, and their K partial writes into the tile's [N,K,3] / [N,K] lines (12 and 4 bytes at a stride of
+//   12 K and 4 K) merge in that XCD's L2 before they leave it.
+// 1: grid (shell, tile) — the K workgroups close in time but on K different XCDs (each L2 then writes its partial
+//   line back by itself: at 1920x1080, K = 7 the launch wrote 0.98 GB for 0.30 GB of outputs);
+// 0: rounds 1-4's grid (tile, shell): every line written K times a whole pass over the frame apart (1.22 GB).
+#ifndef NT_SHADE_MAP
+#define NT_SHADE_MAP 2
 #endif
-#if NT_SHADE_SHELL_FAST
-#define SHADE_TILE_IDX blockIdx.y
-#define SHADE_SHELL_IDX blockIdx.x
-#define SHADE_GRID(tiles, shells) dim3((shells), (tiles))
+struct ShadeIdx {
+  long long tile;
+  int shell;
+  bool valid;
+};
+__device__ __forceinline__ ShadeIdx shade_idx(int K, int tiles) {
+#if NT_SHADE_MAP == 2
+  const unsigned id = blockIdx.x, x = id & 7u, q = id >> 3;
+  const unsigned s = q % (unsigned)K, tg = q / (unsigned)K;
+  const long long t = (long long)tg * 8 + x;
+  return {t, (int)s, t < tiles};
+#elif NT_SHADE_MAP == 1
+  return {(long long)blockIdx.y, (int)blockIdx.x, true};
 #else
-#define SHADE_TILE_IDX blockIdx.x
-#define SHADE_SHELL_IDX blockIdx.y
-#define SHADE_GRID(tiles, shells) dim3((tiles), (shells))
+  return {(long long)blockIdx.x, (int)blockIdx.y, true};
 #endif
+}
+static inline dim3 shade_grid(int tiles, int shells) {
+#if NT_SHADE_MAP == 2
+  return dim3((unsigned)(((tiles + 7) / 8) * 8 * shells));
+#elif NT_SHADE_MAP == 1
+  return dim3(shells, tiles);
+#else
+  return dim3(tiles, shells);
+#endif
+}
 
 namespace {
 
@@ -306,13 +331,11 @@ __global__ __launch_bounds__(SH_BLOCK, NT_SHADE_FWD_OCC) void nt_shade_fwd_kerne
   __shared__ float s_lut[VSA_NT_MAX_DEG * 256];
   build_lut(plan, s_lut);
   __syncthreads();
-  // grid = (shell, ray tile): workgroups are dispatched x-fastest, so the K workgroups of one ray tile run
-  // close together in time and their K partial writes into the tile's [N,K,3] / [N,K] lines (12 and 4 bytes
-  // at a stride of 12 K and 4 K) merge in L2.  With the shell on grid.y every line was written K times a
-  // whole pass over the frame apart: at 1920x1080, K = 7 the launch wrote 1.22 GB for 0.46 GB of outputs
-  // (profiles/r05/k7_*).
-  const long long n = (long long)SHADE_TILE_IDX * SH_BLOCK + threadIdx.x;
-  const int s = SHADE_SHELL_IDX, K = plan.nr_shells;
+  const int K = plan.nr_shells;
+  const ShadeIdx wi = shade_idx(K, (N + SH_BLOCK - 1) / SH_BLOCK);      // (shell, ray tile), XCD-aware: see NT_SHADE_MAP
+  const long long n = wi.tile * SH_BLOCK + threadIdx.x;
+  const int s = wi.shell;
+  if (!wi.valid) return;
   if (n >= N) return;
   HitCtx c;
   float nrm[3];
@@ -411,8 +434,10 @@ __global__ __launch_bounds__(SHB_BLOCK, RECOMPUTE ? 2 : NT_SHADE_BWD_OCC) void n
     build_lut(plan, s_lut);
     __syncthreads();
   }
-  const long long n = (long long)SHADE_TILE_IDX * SHB_BLOCK + threadIdx.x;     // (shell, ray tile) as in the forward:
-  const int s = SHADE_SHELL_IDX, K = plan.nr_shells;                          // the reads of g_surfs_* share lines
+  const int K = plan.nr_shells;
+  const ShadeIdx wi = shade_idx(K, (N + SHB_BLOCK - 1) / SHB_BLOCK);    // as in the forward: the reads of g_surfs_* share lines
+  const long long n = wi.valid ? wi.tile * SHB_BLOCK + threadIdx.x : (long long)N;
+  const int s = wi.shell;
   const int t = threadIdx.x;
   HitCtx c;
   c.hit = false;
@@ -620,7 +645,7 @@ extern "C" int vsa_nt_shade_fwd(const vsa_nt_plan* plan, const int32_t* hit_slot
   if (!hit_slot || !tex_uv || !rays_d || !tris || !slot_of || !seg_start || !texels || !surfs_rgb ||
       !surfs_alpha)
     return VSA_ERR_ARG;
-  dim3 grid = SHADE_GRID(vsa_div_up(nr_rays, SH_BLOCK), plan->nr_shells);
+  dim3 grid = shade_grid(vsa_div_up(nr_rays, SH_BLOCK), plan->nr_shells);
   if (plan->rgb_degrees == VSA_NT_MAX_DEG && plan->alpha_degrees == VSA_NT_MAX_DEG)
     hipLaunchKernelGGL(nt_shade_fwd_kernel<true>, grid, dim3(SH_BLOCK), 0, (hipStream_t)stream, *plan,
                        hit_slot, tex_uv, rays_d, reinterpret_cast<const float4*>(tris), slot_of,
@@ -646,7 +671,7 @@ extern "C" int vsa_nt_shade_bwd(const vsa_nt_plan* plan, const int32_t* hit_slot
       !g_surfs_alpha || !grad_rows)
     return VSA_ERR_ARG;
   if (plan->row_base[VSA_MAX_SHELLS * VSA_NT_MAX_DEG] * 8 >= (1ll << 32)) return VSA_ERR_UNSUPPORTED;   // 32-bit atomic offsets
-  dim3 grid = SHADE_GRID(vsa_div_up(nr_rays, SHB_BLOCK), plan->nr_shells);
+  dim3 grid = shade_grid(vsa_div_up(nr_rays, SHB_BLOCK), plan->nr_shells);
   const bool full4 = plan->rgb_degrees == VSA_NT_MAX_DEG && plan->alpha_degrees == VSA_NT_MAX_DEG;
   if (act_in && full4)
     hipLaunchKernelGGL((nt_shade_bwd_kernel<false, true>), grid, dim3(SHB_BLOCK), 0, (hipStream_t)stream, *plan,
