@@ -87,6 +87,8 @@ def parse(argv=None):
     ap.add_argument("--dp-wait", type=int, default=0, choices=[0, 1, 2],
                     help="how the communication stream waits for a device flag: 1 hipStreamWaitValue32, "
                          "2 a one-lane polling kernel, 0 the first where the device offers it")
+    ap.add_argument("--dp-reserve-cus", type=int, default=0,
+                    help="data-parallel step: compute units the hash-grid backward leaves free for the collectives' kernels")
     ap.add_argument("--dp-split-launches", action="store_true",
                     help="round 4's data-parallel schedule (K hash-grid backward launches, eager), for A/B")
     ap.add_argument("--cpu-sample-rays", type=int, default=16384,
@@ -169,32 +171,32 @@ def pmc_busy(args, kernel):
     return e.get(kernel)
 
 
-TRACE_TRIP_LATENCY_NS = 94.0     # one dependent 32-byte node fetch served by L2: ~225 cycles at 2.4 GHz
-                                 # (MI355X_MICROARCH.md "global_load_dword (L2-hit latency) ~180-225 cyc")
-
-
-def trace_ceiling(pipe, trace_ms, nr_cus=256):
+def trace_ceiling(pipe, trace_ms, args, nr_cus=256):
     """Where the traversal launch stands against what bounds it.  HBM bandwidth is the wrong
-    yardstick (5 % of it, traffic = algorithmic bytes): a ray's walk is a chain of DEPENDENT node fetches, so the
-    launch is bounded by (a) its longest wave's chain and (b) the rate at which the resident waves can take
-    trips, one L2 round trip each.  Counted with vsa_trace_q_stats (the same walk with counters)."""
+    yardstick (5 % of it, traffic = algorithmic bytes).  Counted with vsa_trace_q_stats (the same walk with
+    counters): lane-level node visits and triangle tests, wave-level trips (a trip = one node fetch + two slab tests
+    + the stack step of a whole wave).  With the PMC passes of profiles/pmc_summary.json: 95 % of the node fetches hit
+    the vector L1, the L1->L2 round trip of the rest is ~275 cycles, and the vector pipe is 71 % busy at a lane
+    utilisation of 0.50 — the launch is bound by VECTOR ISSUE UNDER DIVERGENCE (a trip costs a wave ~40 instructions
+    whatever the number of live lanes), with 1.4x of headroom to a saturated pipe, not by any memory level."""
     ro, rd = (pipe._o_t, pipe._d_t) if pipe.image_hw is not None else (pipe.rays_o, pipe.rays_d)
     st = pipe.tracer.walk_stats(ro, rd)
     sec = trace_ms * 1e-3
-    waves_per_cu = 10            # one-wave workgroups, 6 KiB of LDS stack + 96 VGPRs each (PMC: 10 resident per CU)
-    trip_rate_peak = nr_cus * waves_per_cu / (TRACE_TRIP_LATENCY_NS * 1e-9)
     l2_bytes = st["lane_visits"] * 32 + st["tri_tests"] * 48
-    return {
+    out = {
         "lane_node_visits": st["lane_visits"], "lane_tri_tests": st["tri_tests"], "wave_trips": st["wave_trips"],
         "waves": st["waves"], "max_wave_trips": st["max_wave_trips"],
         "lane_utilisation": st["lane_visits"] / max(1.0, 64.0 * st["wave_trips"]),
         "Gvisits/s": st["lane_visits"] / sec / 1e9, "Gtri_tests/s": st["tri_tests"] / sec / 1e9,
-        "L2_GB/s": l2_bytes / sec / 1e9, "L2_frac_of_17TB/s": l2_bytes / sec / 17e12,
-        "wave_trips/s": st["wave_trips"] / sec, "wave_trips/s_ceiling": trip_rate_peak,
-        "latency_frac": st["wave_trips"] / sec / trip_rate_peak,
-        "longest_chain_ms": st["max_wave_trips"] * TRACE_TRIP_LATENCY_NS * 1e-6,
-        "note": "latency roofline: 256 CUs x 10 resident waves, one L2 round trip (94 ns) per wave trip; "
-                "longest_chain_ms = the launch's floor whatever the occupancy"}
+        "requested_GB/s": l2_bytes / sec / 1e9, "wave_trips/s": st["wave_trips"] / sec,
+        "ns_per_trip_and_resident_wave": 1e9 * sec * nr_cus * 10 / max(1, st["wave_trips"]),
+        "bound": "vector issue under divergence"}
+    pm = pmc_busy(args, "trace")
+    if pm:
+        out["pmc"] = {k: v for k, v in pm.items() if k != "counters_per_launch"}
+        if "valu_issue_busy" in pm:
+            out["frac_of_vector_issue"] = pm["valu_issue_busy"]
+    return out
 
 
 def kernel_table(fn, iters):
@@ -693,7 +695,7 @@ def main():
     if dp_on:
         phases = [int(x) for x in args.dp_phases.split(",")] if args.dp_phases else None
         ostep = OverlappedStep(pipe, world, wire_dtype=wire, force=args.force_dist, phases=phases,
-                               wait_mode=args.dp_wait)
+                               wait_mode=args.dp_wait, reserve_cus=args.dp_reserve_cus)
         ostep.active = dist is not None
 
     def step(record=False):
@@ -834,7 +836,7 @@ def main():
         if traffic_all:
             out["traffic_bytes_per_launch"] = traffic_all          # PMC, every kernel of the step on this workload
         if dist is None and pipe.tracer.node_format == "q16":
-            out["stage_roofline"]["trace"].update(trace_ceiling(pipe, kernel_ms.get("vsa_trace_q_fb", stages["trace"]["ms"])))
+            out["stage_roofline"]["trace"].update(trace_ceiling(pipe, kernel_ms.get("vsa_trace_q_fb", stages["trace"]["ms"]), args))
         if world == 1 and dist is None and not args.no_noisy and not (args.noise or args.atlas_charts or args.stress or args.cold):
             out.update(extra_scene(args, dev, use_graph, "noisy", noise=0.05, atlas_charts=6, init="spread"))
             out.update(extra_scene(args, dev, use_graph, "stress", stress=True, init="spread"))

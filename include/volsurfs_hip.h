@@ -391,12 +391,17 @@ int vsa_dp_flags_read(const vsa_dp_flags* flags, uint32_t* host_out);
  * [8*begin, 8*end) — is final and visible).  counters: n_phases device words, zero on entry, zero again
  * on exit.  Results equal vsa_nt_encode_bwd's up to the order of the float atomics that join two
  * workgroups' shares of one table plane (pieces are cut at other slots).
- * Another stream waits for a phase with vsa_dp_stream_wait(flags, p, epoch value). */
+ * Another stream waits for a phase with vsa_dp_stream_wait(flags, p, epoch value).
+ * reserve_cus (>= 0): the launch uses that many workgroups fewer than the device has compute units.  A
+ * workgroup takes 16 waves, 128 KiB of LDS and most of a CU's vector registers: small kernels run beside it
+ * (measured: a 64-workgroup and a 256 MB elementwise kernel finish 0.1-0.3 ms into the 0.65 ms launch), a kernel
+ * whose waves need more than the ~64 registers per lane it leaves on a SIMD does not (the traversal: 96) — whether a
+ * collective's kernels do is the communication library's business, and this is the knob for it. */
 int vsa_nt_encode_bwd_phased(const vsa_nt_plan* plan, const void* dfeatures,
                              const float* dfeat_abs_sum, float grad_scale, const float* slot_xy,
                              const int32_t* seg_start, float* grad_tables, int n_phases,
                              const int32_t* phase_shell_end, vsa_dp_flags* flags, uint32_t* counters,
-                             const uint32_t* epoch, void* stream);
+                             const uint32_t* epoch, int reserve_cus, void* stream);
 
 /* Stream-ordered signal: (*epoch += 1 when advance_epoch), then word `index` of flags = *epoch at system
  * scope — a one-lane kernel, so it can sit inside a captured HIP graph (hipStreamWriteValue32 cannot).

@@ -91,7 +91,7 @@ def test_argument_errors_are_reported_not_ignored():
     # round-5 entry points
     assert L.vsa_bvh_refit(null, null, 3) == ERR_ARG
     one = (ctypes.c_int32 * 1)(1)
-    assert L.vsa_nt_encode_bwd_phased(null, null, null, f1, null, null, null, 1, one, null, null, null, null) == ERR_ARG
+    assert L.vsa_nt_encode_bwd_phased(null, null, null, f1, null, null, null, 1, one, null, null, null, 0, null) == ERR_ARG
     assert L.vsa_dp_flags_create(0, null) == ERR_ARG and L.vsa_dp_flags_destroy(null) == 0
     assert L.vsa_dp_flags_read(null, null) == ERR_ARG
     assert L.vsa_dp_signal(null, 0, null, 1, null) == ERR_ARG

@@ -26,5 +26,7 @@ bash tools/traffic.sh k7 --res 1080 --width 1920 --shells 7 --subdiv 8 | tail -1
 P="--steps 3 --warmup 1 --no-noisy"
 bash tools/pmc.sh ${tag}_pmc_a "nt_mlp|nt_encode|nt_shade|trace_qf" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" $P | tail -4
 bash tools/pmc.sh ${tag}_pmc_b "nt_mlp|nt_encode|nt_shade|trace_qf" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" $P | tail -4
+bash tools/pmc.sh ${tag}_pmc_c "nt_mlp|nt_encode|nt_shade|trace_qf" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" $P | tail -4
+bash tools/pmc.sh ${tag}_pmc_d "nt_mlp|nt_encode|nt_shade|trace_qf" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_ACCESSES_sum" $P | tail -4
 K7="--res 1080 --width 1920 --shells 7 --subdiv 8"
 bash tools/pmc.sh ${tag}_pmck7_a "nt_mlp|nt_encode|nt_shade|trace_qf" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" $P $K7 | tail -4

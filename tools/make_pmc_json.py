@@ -31,6 +31,13 @@ for stage, sub in names.items():
             e["valu_issue_busy"] = round(4.0 * c["SQ_ACTIVE_INST_VALU"] / simd_cycles, 4)
         if "SQ_WAVE_CYCLES" in c and "SQ_WAIT_INST_ANY" in c:
             e["wave_cycles_waiting_on_operands"] = round(c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 4)
+    # cache behaviour (separate passes): vector L1 (TCP) and L2 (TCC) hit rates, mean L1->L2 read round trip
+    if c.get("TCP_TOTAL_CACHE_ACCESSES_sum") and "TCP_TCC_READ_REQ_sum" in c:
+        e["l1_hit_rate"] = round(1.0 - c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"], 4)
+    if c.get("TCP_TCC_READ_REQ_sum") and "TCP_TCC_READ_REQ_LATENCY_sum" in c:
+        e["l2_read_round_trip_cycles"] = round(c["TCP_TCC_READ_REQ_LATENCY_sum"] / c["TCP_TCC_READ_REQ_sum"], 1)
+    if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum") is not None and (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) > 0:
+        e["l2_hit_rate"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
     out[stage] = e
 out["_kernel_source_sha256"] = bench.kernel_source_hash()
 path = os.path.join(root, "profiles", "pmc_summary.json")

@@ -939,7 +939,7 @@ extern "C" int vsa_nt_encode_bwd_phased(const vsa_nt_plan* plan, const void* dfe
                                         const float* slot_xy, const int32_t* seg_start,
                                         float* grad_tables, int n_phases, const int32_t* phase_shell_end,
                                         vsa_dp_flags* flags, uint32_t* counters, const uint32_t* epoch,
-                                        void* stream) {
+                                        int reserve_cus, void* stream) {
   if (!plan || !dfeatures || !dfeat_abs_sum || !slot_xy || !seg_start || !grad_tables || !phase_shell_end ||
       !flags || !counters || !epoch)
     return VSA_ERR_ARG;
@@ -965,6 +965,8 @@ extern "C" int vsa_nt_encode_bwd_phased(const vsa_nt_plan* plan, const void* dfe
   for (int l = 0; l < lh; ++l) n_planes += enc_both_features(*plan, l, false) ? 1 : 2;
   int nr_cus = 0;
   if ((rc = vsa_cu_count(&nr_cus))) return rc;
+  if (reserve_cus < 0 || reserve_cus >= nr_cus) return VSA_ERR_ARG;
+  nr_cus -= reserve_cus;       // workgroups = compute units left to this launch (the rest: the collectives' kernels)
   hipLaunchKernelGGL(nt_encode_bwd_phased_kernel, dim3(nr_cus), dim3(ENC_BLOCK), (size_t)LDS_ENTRIES * 4,
                      (hipStream_t)stream, *plan, lh, n_planes, reinterpret_cast<const half2_t*>(dfeatures),
                      dfeat_abs_sum, 1.0f / grad_scale, reinterpret_cast<const float2*>(slot_xy), seg_start,

@@ -445,7 +445,8 @@ class NeuralTextureBank(torch.nn.Module):
         each phase's completion in signals.flags (parallel.StepSignals; vsa_nt_encode_bwd_phased)."""
         _lib.call("vsa_nt_encode_bwd_phased", ctypes.byref(self.plan), self.features, self._dfsum,
                   float(grad_scale), self.slot_xy, self.seg_start, self.tables.grad, signals.n,
-                  signals.phase_end_c, signals._flags, signals.counters, signals.epoch, _lib.stream_ptr())
+                  signals.phase_end_c, signals._flags, signals.counters, signals.epoch, int(signals.reserve_cus),
+                  _lib.stream_ptr())
 
 
 def stage_accounting(bank, nr_rays, nr_hits, tracer_bytes=0):

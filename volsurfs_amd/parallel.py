@@ -110,7 +110,8 @@ class StepSignals:
 
     phases: list of shell-range ends, strictly increasing, last = K (default: default_phases(K))."""
 
-    def __init__(self, nr_shells, device, phases=None, wait_mode=0):
+    def __init__(self, nr_shells, device, phases=None, wait_mode=0, reserve_cus=0):
+        self.reserve_cus = int(reserve_cus)      # compute units the hash-grid backward leaves to the collectives' kernels
         self.phase_end = [int(x) for x in (phases or default_phases(nr_shells))]
         if self.phase_end[-1] != nr_shells or any(b <= a for a, b in zip([0] + self.phase_end, self.phase_end)):
             raise ValueError(f"phases {self.phase_end} do not cut shells 0..{nr_shells}")
@@ -178,10 +179,11 @@ class OverlappedStep:
 
     run() returns with the current stream waiting for the reduced gradients (as GradientOverlap.wait)."""
 
-    def __init__(self, pipe, world, group=None, wire_dtype=None, force=False, phases=None, wait_mode=0):
+    def __init__(self, pipe, world, group=None, wire_dtype=None, force=False, phases=None, wait_mode=0,
+                 reserve_cus=0):
         dev = pipe.bank.tables.device
         self.pipe, self.world, self.force = pipe, world, force
-        self.signals = StepSignals(pipe.K, dev, phases, wait_mode)
+        self.signals = StepSignals(pipe.K, dev, phases, wait_mode, reserve_cus)
         self.overlap = GradientOverlap(world, group, wire_dtype, force)
         self.side = torch.cuda.Stream(device=dev)
         self.active = world > 1 or force
