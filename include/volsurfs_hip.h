@@ -248,6 +248,13 @@ typedef struct vsa_nt_plan {
                                         backward) stamp every workgroup's busy time there and split their
                                         work by the shares vsa_nt_rebalance derived from the previous
                                         launch's times (same pieces, same results: only who does which) */
+  int32_t row_format;                /* 0: 8-bit quantised texel rows (using_sh_quantization = 1: every shipped config);
+                                        1: f16 rows holding sigmoid(x) un-quantised (using_sh_quantization = 0,
+                                        using_sh_squeezing = 1; neural_texture.py:159-164, 183-187) — `texels` is then an
+                                        f16 array with the SAME quad layout (a quad = 4 halves = 8 bytes); forward
+                                        kernels only differ, the backward is the quantised one's (round is a
+                                        straight-through estimator).  vsa_nt_encode_mlp_fwd supports format 0 only */
+  int32_t reserved1;
 } vsa_nt_plan;
 
 /* Measured-time rebalancing of the persistent kernels' work split (profiles/NOTEBOOK.md A9.0): once per frame,

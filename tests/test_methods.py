@@ -770,8 +770,8 @@ def test_config2_full_size_training_loop_properties():
 def test_reference_texture_switches_reach_the_renderer():
     """VERDICT r4 missing #2: VolSurfs takes the reference's four hyper-parameters
     (config/volsurfs/base_5.cfg:16-19 -> volsurfs.py:149-153).  anchor renders (and differs from lerp: one
-    texel per hit instead of a blend of four, trains too); the f16-row variants raise instead of silently
-    rendering the shipped default."""
+    texel per hit instead of a blend of four, trains too); un-quantised f16 rows render; the un-squeezed variant raises
+    instead of silently rendering the shipped default."""
     from volsurfs_amd.camera import pinhole_rays
     from volsurfs_amd.mesh import nested_shells
     from volsurfs_amd.methods import VolSurfs
@@ -793,8 +793,15 @@ def test_reference_texture_switches_reach_the_renderer():
             l["loss"].backward()
             assert m.bank.tables.grad.abs().sum() > 0
     assert torch.isfinite(outs["anchor"]).all() and not torch.equal(outs["anchor"], outs["lerp"])
-    for kw in (dict(using_sh_quantization=0), dict(using_sh_quantization=0, using_sh_squeezing=0)):
-        with pytest.raises(NotImplementedError):
-            VolSurfs(nested_shells(K=1, subdiv=2), max_rays=1024, **kw)
+    # un-quantised rows render (continuous texel values: differs from the 8-bit default, finite)
+    m = VolSurfs(nested_shells(K=2, subdiv=3), max_rays=4096, textures_res=(256, 128, 64, 32), seed=5, using_sh_quantization=0)
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        m.bank.tables.copy_((torch.rand(m.bank.tables.shape, generator=g) * 2 - 1).cuda())
+    m.bank.refresh_half_params()
+    nq = m.render_rays(o, d, iter_nr=0)["renders"]["ray_traced"]["rgb"]
+    assert torch.isfinite(nq).all() and not torch.equal(nq, outs["lerp"]) and (nq - outs["lerp"]).abs().max() < 0.1
+    with pytest.raises(NotImplementedError):
+        VolSurfs(nested_shells(K=1, subdiv=2), max_rays=1024, using_sh_quantization=0, using_sh_squeezing=0)
     with pytest.raises(ValueError):
         VolSurfs(nested_shells(K=1, subdiv=2), max_rays=1024, using_neural_textures_anchor=1)

@@ -178,11 +178,88 @@ def test_anchor_branch_vs_oracle_model_and_its_gradients():
 
 def test_texture_switches_are_never_silently_the_default():
     """anchor and lerp together / neither; quantise without squeeze: the reference exits (neural_texture.py:47-51,
-    141-147; sh_neural_textures.py:32-36).  The f16-row variants are not built and say so."""
+    141-147; sh_neural_textures.py:32-36).  The un-squeezed variant is not built and says so."""
     from volsurfs_amd.neural_textures import NeuralTextureBank
     for kw, exc in ((dict(anchor=True, lerp=True), ValueError), (dict(anchor=False, lerp=False), ValueError),
                     (dict(quantize_output=True, squeeze_output=False), ValueError),
-                    (dict(quantize_output=False), NotImplementedError),
                     (dict(quantize_output=False, squeeze_output=False), NotImplementedError)):
         with pytest.raises(exc):
             NeuralTextureBank(1, 64, device="cpu", **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("anchor", [False, True])
+def test_unquantised_rows_vs_oracle_model_and_its_gradients(anchor):
+    """using_sh_quantization = 0 (NeuralTexture(quantize_output=False, squeeze_output=True), models/neural_texture.py:
+    159-164, 183-187; the oracle branch is pinned by tests/golden/sh_neural_textures_rgb_noquant.npz from the reference
+    class): texel rows are f16 values of sigmoid(x) instead of 8-bit steps.  (1) every stored half = the fp32 sigmoid of
+    the kernel's own fp16 network output rounded to half, up to one half ulp on a few per mille (the kernel's exp is not
+    torch's); (2) the whole stage against the oracle model: no 8-bit flips any more, errors are half ulps of the texel
+    values; (3) both gradients against the oracle's autograd (the backward is the quantised one's: round is an STE)."""
+    from test_nt_backward import _oracle_grads
+    K, N = 2, 2000
+    kw = dict(anchor=True, lerp=False) if anchor else {}
+    bank, face_uvs, hit_slot, hit_uv, tris, rays_d = _scene(K, N, 6, quantize_output=False, **kw)
+    assert bank.row_format == 1 and bank.texels.dtype == torch.float16 and int(bank.plan.row_format) == 1
+    tex_uv = bank.mark_and_compact(hit_slot, hit_uv, face_uvs)
+    bank.evaluate(need_features=False)            # (never the fused launch for this format)
+    bank.encode()
+    rows, pre = bank.mlp(want_pre=True)
+    torch.cuda.synchronize()
+    seg = bank.seg_start.cpu().numpy()
+    for s in range(K):
+        for typ in range(2):
+            for d in range(4):
+                x = bank.tex_index(s, typ, d)
+                C = bank.tex_channels(x)
+                a, b = seg[s * 4 + d], seg[s * 4 + d + 1]
+                base = 0 if typ == 0 else 24
+                got = rows[a:b, base:base + C].cpu()
+                ref = torch.sigmoid(pre[a:b, base:base + C].cpu().float()).half()
+                ulp = (got.view(torch.int16).int() - ref.view(torch.int16).int()).abs()
+                assert ulp.max() <= 1 and (ulp > 0).float().mean() < 5e-3, (s, typ, d, int(ulp.max()))
+    rgb, alpha, normals, coeffs = bank.shade(hit_slot, tex_uv, rays_d, tris, True, True)
+    torch.cuda.synchronize()
+    flags = dict(quantize_output=False, anchor=anchor, lerp=not anchor)
+    for s in range(K):
+        hit = (hit_slot[s] >= 0).cpu()
+        uv, dirs = tex_uv[s].cpu()[hit], rays_d.cpu()[hit]
+        for typ, C in ((0, 3), (1, 1)):
+            texs = []
+            for d in range(4):
+                x = bank.tex_index(s, typ, d)
+                w1, w2, w3 = unpack_weights(bank.weights_h[x].cpu().float())
+                texs.append(ONT.NeuralTextureOracle(bank.tex_res[d], C * (2 * d + 1), (-15, 15),
+                                                    bank.tables_h[x].cpu().float(), w1, w2, w3, **flags))
+            ref = ONT.sh_neural_textures_forward(texs, uv, dirs, C, 3)
+            if typ == 0:
+                got = rgb[:, s].cpu()[hit]
+            else:
+                got = alpha[:, s].cpu()[hit][:, None]
+                ref = ref * ONT.alpha_decay(dirs, normals[:, s].cpu()[hit])
+            err = (got - ref).abs()
+            # an fp16 ulp of the network output (MFMA vs torch summation order) moves sigmoid by <= 2^-11 * 0.25 and an
+            # SH coefficient by 30x that; no 30/255 steps any more
+            assert err.max() < 5e-3 and err.mean() < 2e-5, (s, typ, float(err.max()), float(err.mean()))
+    g = torch.Generator().manual_seed(0)
+    g_rgb = (torch.randn(N, K, 3, generator=g) / N).cuda()
+    g_alpha = (torch.randn(N, K, generator=g) / N).cuda()
+    bank.backward(hit_slot, tex_uv, rays_d, tris, g_rgb, g_alpha, grad_scale=16.0 * N)      # act=None: the re-gathering backward
+    torch.cuda.synchronize()
+    gw, gt = bank.weights.grad.cpu(), bank.tables.grad.cpu()
+    import oracle.neural_texture as _o
+    keep = _o.NeuralTextureOracle.__init__.__defaults__
+    try:
+        _o.NeuralTextureOracle.__init__.__defaults__ = (None, anchor, not anchor, False, True)
+        for s in range(K):
+            leaves = _oracle_grads(bank, s, hit_slot, tex_uv, rays_d, normals, g_rgb, g_alpha, True)
+            for x, (table, w1, w2, w3) in leaves.items():
+                ref_w = torch.cat([w1.grad.flatten(), w2.grad.flatten(), w3.grad.flatten()])
+                assert (gw[x] - ref_w).abs().max() <= 2e-2 * ref_w.abs().max()
+                assert torch.nn.functional.cosine_similarity(gw[x], ref_w, dim=0) > 0.9995
+                assert (gt[x] - table.grad).abs().max() <= 3e-2 * table.grad.abs().max()
+                assert torch.nn.functional.cosine_similarity(gt[x].flatten(), table.grad.flatten(), dim=0) > 0.9995
+    finally:
+        _o.NeuralTextureOracle.__init__.__defaults__ = keep
+    with pytest.raises(Exception):
+        bank.bake_all()                                   # baked textures are the 8-bit deploy format

@@ -376,6 +376,7 @@ extern "C" int vsa_nt_encode_mlp_fwd(const vsa_nt_plan* plan, const void* tables
                                      const void* weights_h, const float* slot_xy,
                                      const int32_t* seg_start, void* features, uint8_t* texels,
                                      void* pre_out, void* stream) {
+  if (plan && plan->row_format != 0) return VSA_ERR_UNSUPPORTED;     // 8-bit rows only: use vsa_nt_encode_fwd + vsa_nt_mlp_fwd
   if (!plan || !tables_h || !weights_h || !slot_xy || !seg_start || !texels) return VSA_ERR_ARG;
   if (plan->n_levels != 16) return VSA_ERR_UNSUPPORTED;    // the MLP's input width is 16 levels x 2
   int lh = 0;

@@ -57,7 +57,7 @@ constexpr int MLP_FWD_RUN_COST = NT_FWD_RUN_COST;   // tiles: fitted 7.6 us per 
 constexpr int MLP_FWD_WGS_PER_CU = 3;   // 148 VGPRs -> 3 waves per SIMD, one per workgroup
 
 // PRE: also write the pre-sigmoid outputs (tests only; the production launch has no such stores).
-template <bool PRE>
+template <bool PRE, bool F16ROWS = false>
 __global__ __launch_bounds__(MLP_BLOCK, MLP_FWD_WGS_PER_CU) void nt_mlp_fwd_kernel(
     vsa_nt_plan plan, const _Float16* __restrict__ weights,
     const unsigned* __restrict__ features, const int* __restrict__ seg_start,
@@ -104,7 +104,10 @@ __global__ __launch_bounds__(MLP_BLOCK, MLP_FWD_WGS_PER_CU) void nt_mlp_fwd_kern
         half8_t b2[4], b3[4];
         float16_t acc3;
         mlp_tile_fwd(wf, bx, b2, b3, acc3);
-        quant_store_tile<NG, PRE>(acc3, ti, s_qt, texels, slot, valid, h, pre_out, pre_base);
+        if constexpr (F16ROWS)
+          half_store_tile<NG, PRE>(acc3, ti, reinterpret_cast<uint2*>(texels), slot, valid, h, pre_out, pre_base);
+        else
+          quant_store_tile<NG, PRE>(acc3, ti, s_qt, texels, slot, valid, h, pre_out, pre_base);
       }
     };
     if (ti.channels <= 8) run(std::integral_constant<int, 1>{});
@@ -959,8 +962,22 @@ extern "C" int vsa_nt_mlp_fwd(const vsa_nt_plan* plan, const void* weights_h, co
                               const int32_t* seg_start, uint8_t* texels, void* pre_out,
                               void* stream) {
   if (!plan || !weights_h || !features || !seg_start || !texels) return VSA_ERR_ARG;
+  if (plan->row_format != 0 && plan->row_format != 1) return VSA_ERR_UNSUPPORTED;
   int nr_cus = 0;
   { const int rc = vsa_cu_count(&nr_cus); if (rc) return rc; }
+  if (plan->row_format == 1) {       // f16 rows of sigmoid(x), un-quantised (using_sh_quantization = 0)
+    if (pre_out)
+      hipLaunchKernelGGL((nt_mlp_fwd_kernel<true, true>), dim3(nr_cus * MLP_FWD_WGS_PER_CU), dim3(MLP_BLOCK), 0,
+                         (hipStream_t)stream, *plan, reinterpret_cast<const _Float16*>(weights_h),
+                         reinterpret_cast<const unsigned*>(features), seg_start,
+                         reinterpret_cast<unsigned*>(texels), reinterpret_cast<_Float16*>(pre_out));
+    else
+      hipLaunchKernelGGL((nt_mlp_fwd_kernel<false, true>), dim3(nr_cus * MLP_FWD_WGS_PER_CU), dim3(MLP_BLOCK), 0,
+                         (hipStream_t)stream, *plan, reinterpret_cast<const _Float16*>(weights_h),
+                         reinterpret_cast<const unsigned*>(features), seg_start,
+                         reinterpret_cast<unsigned*>(texels), nullptr);
+    VSA_RETURN_LAUNCH_STATUS();
+  }
   if (pre_out)
     hipLaunchKernelGGL(nt_mlp_fwd_kernel<true>, dim3(nr_cus * MLP_FWD_WGS_PER_CU), dim3(MLP_BLOCK), 0,
                        (hipStream_t)stream, *plan, reinterpret_cast<const _Float16*>(weights_h),

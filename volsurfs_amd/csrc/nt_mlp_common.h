@@ -208,4 +208,30 @@ __device__ __forceinline__ void quant_store_tile(const float16_t& acc3, const Te
   }
 }
 
+// row_format 1: the same tile stored as f16 rows of sigmoid(x), un-quantised (neural_texture.py:159-164 with
+// quantize_output = False): the fp32 sigmoid of the fp16 network output, rounded to half (:177).  A quad = 4 halves.
+template <int NG, bool PRE>
+__device__ __forceinline__ void half_store_tile(const float16_t& acc3, const TexInfo& ti,
+                                                uint2* __restrict__ texels_h, int slot, bool valid, int h,
+                                                _Float16* __restrict__ pre_out, int pre_base) {
+  uint2* const trow = texels_h + ti.row_first + (long long)(slot - ti.begin) * ti.row_quads + h;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int row0 = 8 * g + 4 * h;
+    unsigned short hv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const _Float16 xh = (_Float16)acc3[4 * g + i];
+      if constexpr (PRE) {
+        if (valid && row0 + i < ti.channels) pre_out[(long long)slot * 32 + pre_base + row0 + i] = xh;
+      }
+      const float sg = 1.0f / (1.0f + expf(-(float)xh));          // accurate exp: this path is not the hot one
+      const _Float16 sh = (_Float16)sg;
+      hv[i] = row0 + i < ti.channels ? __builtin_bit_cast(unsigned short, sh) : (unsigned short)0;
+    }
+    if (valid && row0 < ti.channels)
+      trow[2 * g] = make_uint2((unsigned)hv[0] | ((unsigned)hv[1] << 16), (unsigned)hv[2] | ((unsigned)hv[3] << 16));
+  }
+}
+
 }  // namespace

@@ -201,7 +201,61 @@ __device__ __forceinline__ bool load_ctx(const vsa_nt_plan& plan, int s, long lo
   return true;
 }
 
+// One corner row of band d added into the band's 28 lerp sums (3 n colour + n alpha at 21).  F16ROWS = false: the
+// 8-bit quantised row through the expand LUT; true (row_format 1): f16 sigmoid values, expanded as the reference
+// does in half arithmetic — fl16(lo + fl16(span * o)) (neural_texture.py:183-187) — a quad being 4 halves (8 bytes).
+template <bool F16ROWS>
+__device__ __forceinline__ void add_corner_row(const vsa_nt_plan& plan, int d, const unsigned* __restrict__ texels,
+                                               int row, float wk, const float* s_lut, float acc[28]) {
+  const int n = 2 * d + 1;
+  if constexpr (!F16ROWS) {
+    unsigned wds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned* rp = texels + row;
+    if (d == 0) {
+      const uint2 v = *reinterpret_cast<const uint2*>(rp);
+      wds[0] = v.x, wds[1] = v.y;
+    } else {
+      const uint4 lo = *reinterpret_cast<const uint4*>(rp);
+      wds[0] = lo.x, wds[1] = lo.y, wds[2] = lo.z, wds[3] = lo.w;
+      if (d >= 2) {
+        const uint4 hi = *reinterpret_cast<const uint4*>(rp + 4);
+        wds[4] = hi.x, wds[5] = hi.y, wds[6] = hi.z, wds[7] = hi.w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 3 * n; ++i) {
+      const unsigned q = (wds[i >> 2] >> (8 * (i & 3))) & 255u;
+      acc[i] = acc[i] + s_lut[d * 256 + q] * wk;
+    }
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      const unsigned q = (wds[nt_alpha_quad(d) + (i >> 2)] >> (8 * (i & 3))) & 255u;
+      acc[21 + i] = acc[21 + i] + s_lut[d * 256 + q] * wk;
+    }
+  } else {
+    unsigned wds[16];
+    const uint4* rp = reinterpret_cast<const uint4*>(texels + 2 * (long long)row);     // quad = 2 dwords
+    const int nv = d == 0 ? 1 : d == 1 ? 2 : 4;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const uint4 x = v < nv ? rp[v] : make_uint4(0, 0, 0, 0);
+      wds[4 * v] = x.x, wds[4 * v + 1] = x.y, wds[4 * v + 2] = x.z, wds[4 * v + 3] = x.w;
+    }
+    const float lo = plan.sh_lo[d], span = plan.sh_span[d];
+    auto expand = [&](int elem) {
+      const unsigned short hb = (unsigned short)(wds[elem >> 1] >> (16 * (elem & 1)));
+      const float o = (float)__builtin_bit_cast(_Float16, hb);
+      return vsa_round_f16(lo + vsa_round_f16(vsa_pin_f32(span * o)));
+    };
+#pragma unroll
+    for (int i = 0; i < 3 * n; ++i) acc[i] = acc[i] + expand(i) * wk;
+#pragma unroll
+    for (int i = 0; i < n; ++i) acc[21 + i] = acc[21 + i] + expand(4 * nt_alpha_quad(d) + i) * wk;
+  }
+}
+
 // SH coefficients (fp16-rounded, as floats): sh_rgb[ch][16], sh_a[16]
+template <bool F16ROWS = false>
 __device__ __forceinline__ void gather_coeffs(const vsa_nt_plan& plan, const HitCtx& c,
                                               const unsigned* __restrict__ texels,
                                               const float* s_lut, bool has_alpha,
@@ -215,32 +269,7 @@ __device__ __forceinline__ void gather_coeffs(const vsa_nt_plan& plan, const Hit
 #pragma unroll
     for (int i = 0; i < 28; ++i) acc[i] = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      unsigned wds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      const unsigned* rp = texels + c.row[d][k];
-      if (d == 0) {
-        const uint2 v = *reinterpret_cast<const uint2*>(rp);
-        wds[0] = v.x, wds[1] = v.y;
-      } else {
-        const uint4 lo = *reinterpret_cast<const uint4*>(rp);
-        wds[0] = lo.x, wds[1] = lo.y, wds[2] = lo.z, wds[3] = lo.w;
-        if (d >= 2) {
-          const uint4 hi = *reinterpret_cast<const uint4*>(rp + 4);
-          wds[4] = hi.x, wds[5] = hi.y, wds[6] = hi.z, wds[7] = hi.w;
-        }
-      }
-      const float wk = c.w[d][k];
-#pragma unroll
-      for (int i = 0; i < 3 * n; ++i) {
-        const unsigned q = (wds[i >> 2] >> (8 * (i & 3))) & 255u;
-        acc[i] = acc[i] + s_lut[d * 256 + q] * wk;
-      }
-#pragma unroll
-      for (int i = 0; i < n; ++i) {
-        const unsigned q = (wds[nt_alpha_quad(d) + (i >> 2)] >> (8 * (i & 3))) & 255u;
-        acc[21 + i] = acc[21 + i] + s_lut[d * 256 + q] * wk;
-      }
-    }
+    for (int k = 0; k < 4; ++k) add_corner_row<F16ROWS>(plan, d, texels, c.row[d][k], c.w[d][k], s_lut, acc);
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
@@ -255,7 +284,7 @@ __device__ __forceinline__ void gather_coeffs(const vsa_nt_plan& plan, const Hit
 // order — the same additions sh_raw performs, so the result is bit-identical, but only one
 // band's coefficients are live (the all-bands-first form needed 197 VGPRs = two waves per
 // SIMD on a kernel that PMC shows waiting on gathers: 16 % VALU-busy).
-template <bool FULL4 = false>
+template <bool FULL4 = false, bool F16ROWS = false>
 __device__ __forceinline__ void shade_hit(const vsa_nt_plan& plan, const HitCtx& c,
                                           const unsigned* __restrict__ texels, const float* s_lut,
                                           bool has_alpha, const float b[16], float raw[4],
@@ -277,32 +306,7 @@ __device__ __forceinline__ void shade_hit(const vsa_nt_plan& plan, const HitCtx&
 #pragma unroll
     for (int i = 0; i < 28; ++i) acc[i] = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      unsigned wds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      const unsigned* rp = texels + c.row[d][k];
-      if (d == 0) {
-        const uint2 v = *reinterpret_cast<const uint2*>(rp);
-        wds[0] = v.x, wds[1] = v.y;
-      } else {
-        const uint4 lo = *reinterpret_cast<const uint4*>(rp);
-        wds[0] = lo.x, wds[1] = lo.y, wds[2] = lo.z, wds[3] = lo.w;
-        if (d >= 2) {
-          const uint4 hi = *reinterpret_cast<const uint4*>(rp + 4);
-          wds[4] = hi.x, wds[5] = hi.y, wds[6] = hi.z, wds[7] = hi.w;
-        }
-      }
-      const float wk = c.w[d][k];
-#pragma unroll
-      for (int i = 0; i < 3 * n; ++i) {
-        const unsigned q = (wds[i >> 2] >> (8 * (i & 3))) & 255u;
-        acc[i] = acc[i] + s_lut[d * 256 + q] * wk;
-      }
-#pragma unroll
-      for (int i = 0; i < n; ++i) {
-        const unsigned q = (wds[nt_alpha_quad(d) + (i >> 2)] >> (8 * (i & 3))) & 255u;
-        acc[21 + i] = acc[21 + i] + s_lut[d * 256 + q] * wk;
-      }
-    }
+    for (int k = 0; k < 4; ++k) add_corner_row<F16ROWS>(plan, d, texels, c.row[d][k], c.w[d][k], s_lut, acc);
 #pragma unroll
     for (int ch = 0; ch < 4; ++ch) {
       const bool on = ch < 3 ? do_rgb : do_a;
@@ -320,7 +324,7 @@ __device__ __forceinline__ void shade_hit(const vsa_nt_plan& plan, const HitCtx&
 #ifndef NT_SHADE_FWD_OCC
 #define NT_SHADE_FWD_OCC 3     /* round 3: 4 waves per SIMD (128 VGPRs) gave 0.163 -> 0.152 ms with run-time band counts; with FULL4 the hoisted slot-id loads spill there (0.19) and 3 waves run 0.139 */
 #endif
-template <bool FULL4>
+template <bool FULL4, bool F16ROWS = false>
 __global__ __launch_bounds__(SH_BLOCK, NT_SHADE_FWD_OCC) void nt_shade_fwd_kernel(
     vsa_nt_plan plan, const int* __restrict__ hit_slot, const float* __restrict__ tex_uv,
     const float* __restrict__ rays_d, const float4* __restrict__ tris,
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(SH_BLOCK, NT_SHADE_FWD_OCC) void nt_shade_fwd_kerne
     const bool has_alpha = !(plan.inner_solid && s == 0);
     float b[16], raw[4];
     sh_basis(c.dir[0], c.dir[1], c.dir[2], b);
-    shade_hit<FULL4>(plan, c, texels, s_lut, has_alpha, b, raw,
+    shade_hit<FULL4, F16ROWS>(plan, c, texels, s_lut, has_alpha, b, raw,
               coeffs_out ? coeffs_out + ((long long)s * N + n) * 64 : nullptr);
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
@@ -411,7 +415,7 @@ __device__ __forceinline__ void atomic_pk_add_f16(const _Float16* base, unsigned
 #ifndef NT_SHB_PREFETCH
 #define NT_SHB_PREFETCH 1
 #endif
-template <bool RECOMPUTE, bool FULL4>
+template <bool RECOMPUTE, bool FULL4, bool F16ROWS = false>
 #ifndef NT_SHADE_BWD_OCC
 #define NT_SHADE_BWD_OCC 4
 #endif
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(SHB_BLOCK, RECOMPUTE ? 2 : NT_SHADE_BWD_OCC) void n
       sg4[0] = a.x, sg4[1] = a.y, sg4[2] = a.z, sg4[3] = a.w;
     } else {
       float sh_rgb[3][16], sh_a[16];
-      gather_coeffs(plan, c, texels, s_lut, has_alpha, sh_rgb, sh_a);
+      gather_coeffs<F16ROWS>(plan, c, texels, s_lut, has_alpha, sh_rgb, sh_a);
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) sg4[ch] = sigmoidf_(sh_raw(b, sh_rgb[ch], plan.rgb_degrees));
       sg4[3] = has_alpha ? sigmoidf_(sh_raw(b, sh_a, plan.alpha_degrees)) : 0.f;
@@ -645,8 +649,14 @@ extern "C" int vsa_nt_shade_fwd(const vsa_nt_plan* plan, const int32_t* hit_slot
   if (!hit_slot || !tex_uv || !rays_d || !tris || !slot_of || !seg_start || !texels || !surfs_rgb ||
       !surfs_alpha)
     return VSA_ERR_ARG;
+  if (plan->row_format != 0 && plan->row_format != 1) return VSA_ERR_UNSUPPORTED;
   dim3 grid = shade_grid(vsa_div_up(nr_rays, SH_BLOCK), plan->nr_shells);
-  if (plan->rgb_degrees == VSA_NT_MAX_DEG && plan->alpha_degrees == VSA_NT_MAX_DEG)
+  if (plan->row_format == 1)          // f16 rows (using_sh_quantization = 0): the generic-band-count kernel
+    hipLaunchKernelGGL((nt_shade_fwd_kernel<false, true>), grid, dim3(SH_BLOCK), 0, (hipStream_t)stream, *plan,
+                       hit_slot, tex_uv, rays_d, reinterpret_cast<const float4*>(tris), slot_of,
+                       seg_start, reinterpret_cast<const unsigned*>(texels), nr_rays, surfs_rgb,
+                       surfs_alpha, surfs_normals, coeffs_out, reinterpret_cast<float4*>(act_out));
+  else if (plan->rgb_degrees == VSA_NT_MAX_DEG && plan->alpha_degrees == VSA_NT_MAX_DEG)
     hipLaunchKernelGGL(nt_shade_fwd_kernel<true>, grid, dim3(SH_BLOCK), 0, (hipStream_t)stream, *plan,
                        hit_slot, tex_uv, rays_d, reinterpret_cast<const float4*>(tris), slot_of,
                        seg_start, reinterpret_cast<const unsigned*>(texels), nr_rays, surfs_rgb,
@@ -671,6 +681,7 @@ extern "C" int vsa_nt_shade_bwd(const vsa_nt_plan* plan, const int32_t* hit_slot
       !g_surfs_alpha || !grad_rows)
     return VSA_ERR_ARG;
   if (plan->row_base[VSA_MAX_SHELLS * VSA_NT_MAX_DEG] * 8 >= (1ll << 32)) return VSA_ERR_UNSUPPORTED;   // 32-bit atomic offsets
+  if (plan->row_format != 0 && plan->row_format != 1) return VSA_ERR_UNSUPPORTED;
   dim3 grid = shade_grid(vsa_div_up(nr_rays, SHB_BLOCK), plan->nr_shells);
   const bool full4 = plan->rgb_degrees == VSA_NT_MAX_DEG && plan->alpha_degrees == VSA_NT_MAX_DEG;
   if (act_in && full4)
@@ -685,6 +696,11 @@ extern "C" int vsa_nt_shade_bwd(const vsa_nt_plan* plan, const int32_t* hit_slot
                        seg_start, reinterpret_cast<const unsigned*>(texels), nr_rays, g_surfs_rgb,
                        g_surfs_alpha, grad_scale, reinterpret_cast<_Float16*>(grad_rows),
                        reinterpret_cast<const float4*>(act_in));
+  else if (plan->row_format == 1)     // no kept sigmoids: re-gather the f16 rows
+    hipLaunchKernelGGL((nt_shade_bwd_kernel<true, false, true>), grid, dim3(SHB_BLOCK), 0, (hipStream_t)stream, *plan,
+                       hit_slot, tex_uv, rays_d, reinterpret_cast<const float4*>(tris), slot_of,
+                       seg_start, reinterpret_cast<const unsigned*>(texels), nr_rays, g_surfs_rgb,
+                       g_surfs_alpha, grad_scale, reinterpret_cast<_Float16*>(grad_rows), nullptr);
   else
     hipLaunchKernelGGL((nt_shade_bwd_kernel<true, false>), grid, dim3(SHB_BLOCK), 0, (hipStream_t)stream, *plan,
                        hit_slot, tex_uv, rays_d, reinterpret_cast<const float4*>(tris), slot_of,

@@ -87,7 +87,7 @@ class VolSurfs(torch.nn.Module):
                  using_sh_quantization=True, using_sh_squeezing=True):
         """using_neural_textures_anchor / _lerp, using_sh_quantization, using_sh_squeezing: the reference's
         hyper-parameters of the same names (config/volsurfs/base_5.cfg:16-19 -> volsurfs.py:149-153); a
-        combination that is not built raises in NeuralTextureBank instead of rendering the default."""
+        combination that is not built (using_sh_squeezing = 0) raises in NeuralTextureBank instead of rendering the default."""
         super().__init__()
         self.using_neural_textures = using_neural_textures
         self.with_alpha_decay = with_alpha_decay

@@ -50,6 +50,7 @@ class Plan(ctypes.Structure):
         ("max_rays", ctypes.c_int32), ("anchor", ctypes.c_int32),
         ("row_base", ctypes.c_int64 * (MAX_SHELLS * MAX_DEG + 1)),
         ("balance", ctypes.c_void_p),
+        ("row_format", ctypes.c_int32), ("reserved1", ctypes.c_int32),
     ]
 
 
@@ -81,9 +82,9 @@ class NeuralTextureBank(torch.nn.Module):
                  grid=None):
         """anchor / lerp / quantize_output / squeeze_output: NeuralTexture's switches
         (models/neural_texture.py:19-52; config keys using_neural_textures_anchor / _lerp,
-        using_sh_quantization, using_sh_squeezing).  Built: lerp (the shipped configs) and anchor,
-        both with the 8-bit squeezed texel rows; the f16 rows of the non-quantised variants are not,
-        and asking for them raises instead of silently rendering the default.
+        using_sh_quantization, using_sh_squeezing).  Built: lerp (the shipped configs) and anchor, with 8-bit
+        quantised texel rows or (quantize_output=False) f16 rows of the un-quantised sigmoid; the un-squeezed
+        variant is not, and asking for it raises instead of silently rendering the default.
         grid: keyword arguments of grid_geometry() for a hash grid other than the reference's
         (16 levels always: the MLP reads 32 features); levels of more than 2^15 entries are refused
         by the library (one level = one LDS plane)."""
@@ -92,10 +93,12 @@ class NeuralTextureBank(torch.nn.Module):
             raise ValueError("NeuralTexture is either anchor or lerp (neural_texture.py:47-51, 141-147)")
         if quantize_output and not squeeze_output:
             raise ValueError("quantize_output requires squeeze_output (sh_neural_textures.py:32-36)")
-        if not (quantize_output and squeeze_output):
+        if not squeeze_output:
             raise NotImplementedError(
-                "texel rows are 8-bit: using_sh_quantization=0 / using_sh_squeezing=0 (f16 rows, "
-                "neural_texture.py:159-169, 183-187) are not built; no reference config ships them")
+                "using_sh_squeezing=0 (raw, un-squeezed texel rows: neural_texture.py:159, 183) is not built; "
+                "no reference config ships it")
+        # 0: 8-bit quantised rows (every shipped config); 1: f16 rows of sigmoid(x), un-quantised
+        self.row_format = 0 if quantize_output else 1
         self.anchor = bool(anchor)
         K = nr_shells
         self.K, self.max_rays = K, max_rays
@@ -133,6 +136,7 @@ class NeuralTextureBank(torch.nn.Module):
         p.slot_capacity = cap
         p.max_rays = max_rays
         p.anchor = int(self.anchor)
+        p.row_format = int(self.row_format)
         self.plan, self.dom_total, self.slot_capacity = p, off, cap
         self.tex_res = tuple(int(r) for r in textures_res)
 
@@ -189,7 +193,9 @@ class NeuralTextureBank(torch.nn.Module):
         self.tables_h = torch.empty(self.n_tex, self.n_entries, 2, dtype=torch.float16, device=dev)
         self.weights_h = torch.empty(self.n_tex, WEIGHTS_PER_TEX, dtype=torch.float16, device=dev)
         # per-degree row widths (include/volsurfs_hip.h: VSA_NT_ROW_QUADS), 4 elements per quad
-        self.texels = torch.zeros(self.row_quads_total * 4, dtype=u8, device=dev)
+        # texel rows: 4 elements per quad — bytes (8-bit quantised) or halves (row_format 1)
+        self.texels = torch.zeros(self.row_quads_total * 4, dtype=u8 if self.row_format == 0 else torch.float16,
+                                  device=dev)
         self.grad_rows = torch.zeros(self.row_quads_total * 4, dtype=torch.float16, device=dev) if training else None
         self.refresh_half_params()
 
@@ -244,6 +250,8 @@ class NeuralTextureBank(torch.nn.Module):
         """Evaluate EVERY texel of every texture (instead of the texels a frame touches): after
         this, `shade` works for any ray without mark/compact/encode/mlp.  Needs a bank built
         with max_rays >= full_capacity_rays(textures_res)."""
+        if self.row_format != 0:
+            raise _lib.VolsurfsHipError("baked textures are the 8-bit deploy format: using_sh_quantization=1 only")
         self.marks.zero_()
         for s in range(self.K):
             for d in range(self.D):
@@ -333,7 +341,7 @@ class NeuralTextureBank(torch.nn.Module):
     def evaluate(self, need_features=True):
         """Texel rows of the compacted slots.  need_features=False (inference, baking): the fused
         launch; True (a backward pass follows): the level-major encode kernel, then the MLP kernel."""
-        if FUSED_FORWARD is True or (FUSED_FORWARD == "auto" and not need_features):
+        if self.row_format == 0 and (FUSED_FORWARD is True or (FUSED_FORWARD == "auto" and not need_features)):
             return self.encode_mlp(write_features=need_features)
         self.encode()
         return self.mlp()
