@@ -89,6 +89,9 @@ def parse(argv=None):
                          "2 a one-lane polling kernel, 0 the first where the device offers it")
     ap.add_argument("--dp-reserve-cus", type=int, default=0,
                     help="data-parallel step: compute units the hash-grid backward leaves free for the collectives' kernels")
+    ap.add_argument("--dp-comm", default="auto", choices=["auto", "rccl", "torch"],
+                    help="data-parallel step: all-reduces through RCCL called directly on the side stream (rccl), through "
+                         "torch.distributed (torch), or rccl when the backend is nccl (auto)")
     ap.add_argument("--dp-split-launches", action="store_true",
                     help="round 4's data-parallel schedule (K hash-grid backward launches, eager), for A/B")
     ap.add_argument("--cpu-sample-rays", type=int, default=16384,
@@ -695,7 +698,9 @@ def main():
     if dp_on:
         phases = [int(x) for x in args.dp_phases.split(",")] if args.dp_phases else None
         ostep = OverlappedStep(pipe, world, wire_dtype=wire, force=args.force_dist, phases=phases,
-                               wait_mode=args.dp_wait, reserve_cus=args.dp_reserve_cus)
+                               wait_mode=args.dp_wait, reserve_cus=args.dp_reserve_cus, rank=rank,
+                               direct_rccl={"auto": None, "rccl": True, "torch": False}[args.dp_comm]
+                               if dist is not None else False)
         ostep.active = dist is not None
 
     def step(record=False):
@@ -816,6 +821,8 @@ def main():
             "dtype": pipe.dtype_desc, "data": "synthetic",
             "config": dict(pipe.config_desc(world), launch="hip-graph replay" if use_graph else "eager",
                            **({"dp_phases": ostep.signals.phase_end,
+                               "dp_comm": "rccl called directly on the side stream" if ostep.rccl is not None
+                               else "torch.distributed",
                                "dp_schedule": "three graphs per step: the parameter-free head (ray order, traversal, "
                                               "mark/compact) runs before the wait for the previous step's gradient "
                                               "reduction; then zero_grad .. MLP backward; then the hash-grid backward, "

@@ -453,7 +453,31 @@ def _rccl_one_rank(port, q):
     pipe = KShellPipeline.synthetic(K=2, subdiv=3, res=64, init="spread", seed=3)
     ref_rgb = pipe.step().clone()
     from volsurfs_amd.parallel import OverlappedStep
-    ostep = OverlappedStep(pipe, 1, force=True)     # the collectives run although the group has one rank
+    # (1a) RCCL called directly on the side stream (volsurfs_amd.rccl; the default under the nccl backend): the
+    # binding itself — a sum over one rank is the identity, on the stream it is given — and the step through it
+    from volsurfs_amd.rccl import RcclComm
+    comm = RcclComm(0, 1)
+    t = torch.randn(1 << 20, device="cuda")
+    keep, side = t.clone(), torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    comm.all_reduce_sum_(t, side)
+    comm.all_reduce_sum_(t.half())                      # f16 on the current stream
+    torch.cuda.synchronize()
+    out["direct_identity"] = bool(torch.equal(t, keep))
+    comm.destroy()
+    direct = OverlappedStep(pipe, 1, force=True)
+    out["direct_default"] = direct.rccl is not None
+    pipe.capture_graph_split(dp=direct.signals)
+    direct.signals.epoch_host += 2
+    for _ in range(3):
+        rgb_d = direct.run_split(pipe.replay_prefix, pipe.replay_mid, pipe.replay_tail)
+    direct.finish()
+    torch.cuda.synchronize()
+    out["direct_forward_equal"] = bool(torch.equal(rgb_d, ref_rgb))
+    out["direct_flags"] = direct.signals.read()[0] == [direct.signals.epoch_host] * (direct.signals.n + 1)
+    out["direct_grad_nonzero"] = float(pipe.bank.tables.grad.abs().max()) > 0
+    # (1b) the same through torch.distributed's ProcessGroupNCCL
+    ostep = OverlappedStep(pipe, 1, force=True, direct_rccl=False)     # the collectives run although the group has one rank
     snaps = []
     reduce_async = ostep.overlap.reduce_async
 
@@ -513,6 +537,8 @@ def test_rccl_one_rank_group_runs_every_collective_of_the_design():
     assert p.exitcode == 0
     print("RCCL one-rank group:", out)
     assert out["dist_backend"] == "nccl" and out["world"] == 1
+    assert out["direct_identity"] and out["direct_default"] and out["direct_forward_equal"] and out["direct_flags"]
+    assert out["direct_grad_nonzero"]
     assert out["forward_equal"] and out["allreduce_identity"] and out["slices_reduced"] == 3 and out["grad_nonzero"]
     assert out["sharded_equals_plain"] and out["state_full"] and out["gather_equal"]
 

@@ -99,6 +99,16 @@ def default_phases(nr_shells, max_phases=3):
     return sorted({-(-nr_shells * (i + 1) // n) for i in range(n)})
 
 
+class _EventWork:
+    """What GradientOverlap.wait() needs of a Work: wait() makes the current stream wait."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
 class StepSignals:
     """Device-side completion flags of one data-parallel step (include/volsurfs_hip.h:
     vsa_dp_signal, vsa_nt_encode_bwd_phased, vsa_dp_stream_wait).  The step itself stays ONE
@@ -180,9 +190,20 @@ class OverlappedStep:
     run() returns with the current stream waiting for the reduced gradients (as GradientOverlap.wait)."""
 
     def __init__(self, pipe, world, group=None, wire_dtype=None, force=False, phases=None, wait_mode=0,
-                 reserve_cus=0):
+                 reserve_cus=0, direct_rccl=None, rank=0):
+        """direct_rccl: enqueue the all-reduces with RCCL itself on the side stream (volsurfs_amd.rccl: no
+        ProcessGroupNCCL stream, no hand-off per collective) — True / False, default: when the group's backend is
+        "nccl" and no wire dtype is asked for.  rank: this process's rank in `group` (forming the communicator)."""
         dev = pipe.bank.tables.device
         self.pipe, self.world, self.force = pipe, world, force
+        self.rccl = None
+        if world > 1 or force:
+            import torch.distributed as dist
+            if direct_rccl is None:
+                direct_rccl = dist.is_initialized() and dist.get_backend(group) == "nccl" and wire_dtype is None
+            if direct_rccl:
+                from .rccl import RcclComm
+                self.rccl = RcclComm(rank, world, group)
         self.signals = StepSignals(pipe.K, dev, phases, wait_mode, reserve_cus)
         self.overlap = GradientOverlap(world, group, wire_dtype, force)
         self.side = torch.cuda.Stream(device=dev)
@@ -231,6 +252,8 @@ class OverlappedStep:
         e = sg.epoch_host
         ev = getattr(self, "_mid_event", None)
         self._mid_event = None
+        if self.rccl is not None:
+            return self._enqueue_reductions_rccl(e, ev)
         # (after the producer: a wait queued ahead of the kernel that satisfies it could share its hardware queue)
         with torch.cuda.stream(self.side):
             if ev is not None:
@@ -246,6 +269,29 @@ class OverlappedStep:
         # step (one cross-stream hand-off less on the only part of the reduction that nothing hides)
         a, b = sg.shell_range(sg.n - 1)
         self.overlap.reduce_async(bank.tables.grad[a * 8:b * 8])
+
+    def _enqueue_reductions_rccl(self, e, ev):
+        """The same program with RCCL called directly: every all-reduce is a launch on the side stream itself, right
+        behind the wait that releases it; the current stream waits for ONE event behind the last of them."""
+        sg, bank = self.signals, self.pipe.bank
+        tail = torch.cuda.Event()
+        tail.record()                                   # the step's last launch (the hash-grid backward) is behind this
+        with torch.cuda.stream(self.side):
+            if ev is not None:
+                self.side.wait_event(ev)
+            else:
+                sg.stream_wait(sg.W, e)
+            self.rccl.all_reduce_sum_(bank.weights.grad, self.side)
+            for p in range(sg.n - 1):
+                a, b = sg.shell_range(p)
+                sg.stream_wait(p, e)
+                self.rccl.all_reduce_sum_(bank.tables.grad[a * 8:b * 8], self.side)
+            a, b = sg.shell_range(sg.n - 1)
+            self.side.wait_event(tail)                  # the last phase is final when the launch ends
+            self.rccl.all_reduce_sum_(bank.tables.grad[a * 8:b * 8], self.side)
+            done = torch.cuda.Event()
+            done.record()
+        self.overlap.works.append((_EventWork(done), None, None))
 
     def run(self, launch=None, record=False):
         """launch: a callable that enqueues one step built with dp=self.signals (default: the eager
