@@ -202,8 +202,21 @@ class OverlappedStep:
             if direct_rccl is None:
                 direct_rccl = dist.is_initialized() and dist.get_backend(group) == "nccl" and wire_dtype is None
             if direct_rccl:
-                from .rccl import RcclComm
-                self.rccl = RcclComm(rank, world, group)
+                # all ranks use the direct communicator or none does: a rank whose communicator did not come up
+                # makes everybody fall back to torch.distributed (agreed through the group itself)
+                try:
+                    from .rccl import RcclComm
+                    self.rccl = RcclComm(rank, world, group)
+                except Exception as exc:
+                    import warnings
+                    warnings.warn(f"direct RCCL communicator not formed ({exc}); all-reduces go through torch.distributed")
+                    self.rccl = None
+                if world > 1:
+                    ok = torch.tensor([1 if self.rccl is not None else 0], device=dev, dtype=torch.int32)
+                    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+                    if int(ok.item()) == 0 and self.rccl is not None:
+                        self.rccl.destroy()
+                        self.rccl = None
         self.signals = StepSignals(pipe.K, dev, phases, wait_mode, reserve_cus)
         self.overlap = GradientOverlap(world, group, wire_dtype, force)
         self.side = torch.cuda.Stream(device=dev)

@@ -47,17 +47,24 @@ class RcclComm:
     at the same point of the program (it is a collective: the unique id travels through the group)."""
 
     def __init__(self, rank, world, group=None):
-        L = lib()
         uid = _UniqueId()
+        err = None
         if rank == 0:
-            _check(L.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+            try:
+                _check(lib().ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+            except Exception as e:          # (the other ranks must still be told: they wait in the broadcast below)
+                err = e
         if world > 1:
             import torch.distributed as dist
-            box = [bytes(uid.internal) if rank == 0 else None]
+            box = [bytes(uid.internal) if (rank == 0 and err is None) else None]
             dist.broadcast_object_list(box, src=0, group=group)
+            if box[0] is None:
+                raise RcclError(f"rank 0 could not create an RCCL unique id ({err})")
             ctypes.memmove(ctypes.byref(uid), box[0], 128)
+        elif err is not None:
+            raise RcclError(str(err))
         self.comm = ctypes.c_void_p()
-        _check(L.ncclCommInitRank(ctypes.byref(self.comm), world, uid, rank), "ncclCommInitRank")
+        _check(lib().ncclCommInitRank(ctypes.byref(self.comm), world, uid, rank), "ncclCommInitRank")
         self.rank, self.world = rank, world
 
     def all_reduce_sum_(self, t, stream=None):
