@@ -21,6 +21,12 @@ from .raytrace import RayTracer
 # the headroom to f16's 65 504 stays > 10x even with hundreds of hits on one texel).  A power of two: exact.
 GRAD_CHAIN_GAIN = 16.0
 
+# Graph capture in "thread_local" error mode: under the default ("global") ANY thread's HIP call that is illegal during
+# a capture fails — and torch.distributed's ProcessGroupNCCL watchdog thread polls its Work events with hipEventQuery
+# whenever a collective is still outstanding: a step captured right after eager data-parallel warm-up steps aborted the
+# process about once in twenty runs ("operation not permitted when stream is capturing" from the watchdog).
+_CAPTURE_MODE = "thread_local"
+
 
 class StageTimer:
     def __init__(self):
@@ -207,11 +213,11 @@ class KShellPipeline:
                 self.step(**step_kw)
         torch.cuda.current_stream().wait_stream(s)
         self._graph_prefix, self._graph_mid, self._graph_tail = (torch.cuda.CUDAGraph() for _ in range(3))
-        with torch.cuda.graph(self._graph_prefix):
+        with torch.cuda.graph(self._graph_prefix, capture_error_mode=_CAPTURE_MODE):
             self.step(part="prefix", **step_kw)
-        with torch.cuda.graph(self._graph_mid, pool=self._graph_prefix.pool()):
+        with torch.cuda.graph(self._graph_mid, pool=self._graph_prefix.pool(), capture_error_mode=_CAPTURE_MODE):
             self.step(part="mid", **step_kw)
-        with torch.cuda.graph(self._graph_tail, pool=self._graph_prefix.pool()):
+        with torch.cuda.graph(self._graph_tail, pool=self._graph_prefix.pool(), capture_error_mode=_CAPTURE_MODE):
             self._static_rgb = self.step(part="tail", **step_kw)
 
     def replay_prefix(self):
@@ -241,7 +247,7 @@ class KShellPipeline:
                 self.step(**step_kw)
         torch.cuda.current_stream().wait_stream(s)
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        with torch.cuda.graph(self._graph, capture_error_mode=_CAPTURE_MODE):
             self._static_rgb = self.step(**step_kw)
         return self._graph
 
