@@ -87,8 +87,11 @@ def parse(argv=None):
     ap.add_argument("--dp-wait", type=int, default=0, choices=[0, 1, 2],
                     help="how the communication stream waits for a device flag: 1 hipStreamWaitValue32, "
                          "2 a one-lane polling kernel, 0 the first where the device offers it")
-    ap.add_argument("--dp-reserve-cus", type=int, default=0,
-                    help="data-parallel step: compute units the hash-grid backward leaves free for the collectives' kernels")
+    ap.add_argument("--dp-reserve-cus", type=int, default=None,
+                    help="data-parallel step: compute units the hash-grid backward leaves free for the collectives' kernels "
+                         "(default: 16 when more than one rank runs — whether RCCL's kernels fit BESIDE a workgroup that "
+                         "holds most of a CU's registers cannot be measured on one GPU, 16 whole CUs cost the launch 6 %% — "
+                         "else 0)")
     ap.add_argument("--dp-comm", default="auto", choices=["auto", "rccl", "torch"],
                     help="data-parallel step: all-reduces through RCCL called directly on the side stream (rccl), through "
                          "torch.distributed (torch), or rccl when the backend is nccl (auto)")
@@ -693,6 +696,8 @@ def main():
     # one-lane signal kernel — in which the device publishes "weights.grad final" and "phase p of
     # tables.grad final"; a side stream waits on those flags and all-reduces (sum) over RCCL / xGMI
     # while the rest of backward runs.  What is left exposed behind the last kernel is "grad_allreduce".
+    if args.dp_reserve_cus is None:
+        args.dp_reserve_cus = 16 if world > 1 else 0
     dp_on = (dist is not None or args.by_shell) and not args.dp_split_launches
     ostep = None
     if dp_on:
@@ -821,6 +826,7 @@ def main():
             "dtype": pipe.dtype_desc, "data": "synthetic",
             "config": dict(pipe.config_desc(world), launch="hip-graph replay" if use_graph else "eager",
                            **({"dp_phases": ostep.signals.phase_end,
+                               "dp_reserve_cus": ostep.signals.reserve_cus,
                                "dp_comm": "rccl called directly on the side stream" if ostep.rccl is not None
                                else "torch.distributed",
                                "dp_schedule": "three graphs per step: the parameter-free head (ray order, traversal, "

@@ -141,8 +141,8 @@ def test_encode_backward_by_shell_equals_one_launch():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("phases,wait_mode", [(None, 1), ([2, 3], 2), ([3], 0)])
-def test_encode_backward_phased_equals_one_launch_and_publishes_its_phases(phases, wait_mode):
+@pytest.mark.parametrize("phases,wait_mode,reserve", [(None, 1, 0), ([2, 3], 2, 16), ([3], 0, 200)])
+def test_encode_backward_phased_equals_one_launch_and_publishes_its_phases(phases, wait_mode, reserve):
     """vsa_nt_encode_bwd_phased (the data-parallel step's hash-grid backward: ONE launch whose workgroups
     finish the shells phase by phase): same table gradients as the plain launch; flags[p] hold the epoch
     afterwards, the workgroup counters are zero again; a second stream that waits on the flags
@@ -162,7 +162,7 @@ def test_encode_backward_phased_equals_one_launch_and_publishes_its_phases(phase
     bank.backward_mlp(float(N))
     bank.backward_encode(float(N))
     ref = bank.tables.grad.clone()
-    sg = StepSignals(K, "cuda", phases, wait_mode)
+    sg = StepSignals(K, "cuda", phases, wait_mode, reserve_cus=reserve)      # (reserve: workgroups left to the collectives' kernels)
     side = torch.cuda.Stream()
     snaps = []
     for epoch in (1, 2):
