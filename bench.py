@@ -48,6 +48,9 @@ def parse(argv=None):
     ap.add_argument("--sharded-adam", action="store_true",
                     help="N > 1, train workloads: reduce-scatter the gradients, Adam on each rank's slice of every "
                          "tensor, all-gather the f16 copies (optim.ShardedFusedAdam) instead of all-reduce + full Adam")
+    ap.add_argument("--adam-overlap", type=int, default=0, choices=[0, 1],
+                    help="train workload (neural textures, one rank): the Adam launch on a side stream as a bounded grid "
+                         "(vsa_adam_step_shared) beside the next iteration's ray batch, traversal and texel compaction")
     ap.add_argument("--target-hits", type=int, default=49152)
     ap.add_argument("--views", type=int, default=50)
     ap.add_argument("--res", type=int, default=800)
@@ -291,7 +294,7 @@ def run_train(args, world, rank, dev, dist):
         losses, nxt = train_step_from_reel(method, reel, n, jitter_pixels=True, iter_nr=state["it"],
                                            is_first_iter=state["it"] == 0,
                                            target_nr_of_training_samples=target, world=world,
-                                           sync_losses=False)
+                                           sync_losses=False, overlap_optimizer=bool(args.adam_overlap) and world == 1)
         if count:
             state["rays"] += n
             state["hits"] += int(getattr(method, "last_nr_samples", 0))

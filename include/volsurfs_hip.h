@@ -88,6 +88,19 @@ int vsa_composite_dense_fwd_bwd_l1(const float* surfs_rgb, const float* surfs_al
                                    float* g_surfs_alpha, int nr_rays, int nr_shells, int carry_f16,
                                    void* stream);
 
+/* The two scalar read-outs of a training iteration (csrc/reduce.hip), ONE launch each and no fill in front:
+ *   vsa_count_hits: *out (i64, device) = number of entries >= 0 among hit_slot[0..n) — the sample count that
+ *     steers the reference's dynamic ray count (trainer.py:293-304; there `samples_3d.shape[0]` after a
+ *     boolean-mask compaction, volsurfs.py:713-716);
+ *   vsa_l1_mean: *out (f32, device) = mean |pred[i] - gt[i]| over n elements (utils/losses.py:14-19, loss_l1
+ *     without mask), summed in f64 in a fixed order (the same bits every call).
+ * scratch: device memory of vsa_reduce_scratch_bytes() bytes, 8-byte aligned, ZEROED before its first use and
+ * left ready for the next call by every call; calls that share it must be ordered on one stream.
+ * hit_slot / pred / gt: 16-byte aligned. */
+long long vsa_reduce_scratch_bytes(void);
+int vsa_count_hits(const int32_t* hit_slot, long long n, void* scratch, int64_t* out, void* stream);
+int vsa_l1_mean(const float* pred, const float* gt, long long n, void* scratch, float* out, void* stream);
+
 /* ------------------------------------------------------------------------
  * A2  BVH build (host) + K-shell closest-hit traversal (device).
  * Replaces raytracelib.RayTracer(tensor_meshes) / .trace(rays_o, rays_d, mesh_id)
@@ -254,7 +267,11 @@ typedef struct vsa_nt_plan {
                                         f16 array with the SAME quad layout (a quad = 4 halves = 8 bytes); forward
                                         kernels only differ, the backward is the quantised one's (round is a
                                         straight-through estimator).  vsa_nt_encode_mlp_fwd supports format 0 only */
-  int32_t reserved1;
+  int32_t grads_zeroed;              /* 1: the caller vouches that grad_tables is ALL ZERO on entry to vsa_nt_encode_bwd /
+                                        _range / _phased (it cleared the buffer, or the fused Adam step did, and nothing
+                                        has been accumulated since): a table plane whose slots ONE workgroup walks is then
+                                        written with plain stores instead of float atomics (same values: 0 + v).  0: the
+                                        launch accumulates into whatever the buffer holds */
 } vsa_nt_plan;
 
 /* Measured-time rebalancing of the persistent kernels' work split (profiles/NOTEBOOK.md A9.0): once per frame,
@@ -363,7 +380,8 @@ int vsa_nt_shade_bwd(const vsa_nt_plan* plan, const int32_t* hit_slot, const flo
 
 /* Backward of step 3: grad_tables (f32 [n_tex][level_offset[n]][2]) +=
  * transpose-interpolation of dfeatures (f16x2, same layout as features, holding
- * grad * grad_scale).  Accumulates (caller zeroes grad_tables per optimiser step). */
+ * grad * grad_scale).  Accumulates (caller zeroes grad_tables per optimiser step; plan->grads_zeroed
+ * tells the launch that it has, see there). */
 int vsa_nt_encode_bwd(const vsa_nt_plan* plan, const void* dfeatures, const float* dfeat_abs_sum,
                       float grad_scale, const float* slot_xy, const int32_t* seg_start,
                       float* grad_tables, void* stream);
@@ -569,6 +587,14 @@ int vsa_adam_chunk_elems(void);
 int vsa_adam_step(const vsa_adam_tensor* tensors_dev, const int32_t* chunks_dev, int nr_chunks,
                   float lr, float beta1, float beta2, float eps, int step, float grad_scale,
                   int zero_grads, void* stream);
+/* The same update from at most max_workgroups workgroups (256 threads each) that stride over the chunks
+ * (0: one workgroup per chunk = vsa_adam_step).  One workgroup per chunk queues thousands of workgroups that
+ * take every wave slot of the chip until the update drains; a bounded grid leaves room on every CU for
+ * the kernels of ANOTHER stream — the next iteration's ray batch, traversal and texel compaction, which
+ * read no parameter (optim.FusedAdam.step(stream=...)). */
+int vsa_adam_step_shared(const vsa_adam_tensor* tensors_dev, const int32_t* chunks_dev, int nr_chunks,
+                         float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                         int zero_grads, int max_workgroups, void* stream);
 
 /* A5  Permutohedral-lattice hash encoding: `PermutoHashEncoder`
  * (volsurfs_py/encodings/permutohash.py:28-37, 68-96) = permutohedral_encoding.PermutoEncoding
@@ -768,7 +794,9 @@ int vsa_reel_next_rays_batch(const float* c2w_all, const float* intrinsics_inv_a
 
 /* Re-orders a row-major per-pixel array [height*width, channels] (channels 1..4, f32) into
  * 8x8-pixel-tile-major order (inverse = 0), or back (inverse = 1).  height and width must be
- * multiples of 8.  Used on the rays of a full frame before the traversal (a wave then covers
+ * multiples of 8.  Inside a tile the pixels run boustrophedon: element j of a tile is pixel row
+ * j/8 and pixel column j%8 on even rows, 7 - j%8 on odd rows, so consecutive elements are always
+ * neighbouring pixels.  Used on the rays of a full frame before the traversal (a wave then covers
  * a square patch of pixels instead of a 64x1 strip) and on the rendered colours after it. */
 int vsa_tile_order(const float* src, float* dst, int height, int width, int channels, int inverse,
                    void* stream);

@@ -64,6 +64,10 @@ def test_argument_errors_are_reported_not_ignored():
     assert L.vsa_tile_order(null, null, 16, 16, 3, 0, null) == ERR_ARG                              # null arrays
     assert L.vsa_reel_next_rays_batch(null, null, null, null, 0, 4, 4, 8, 1, 0, u64, u64, null, null, null,
                                       null, null, null, null) == ERR_ARG                             # no cameras
+    assert L.vsa_count_hits(null, ctypes.c_longlong(10), null, null, null) == ERR_ARG
+    assert L.vsa_l1_mean(null, null, ctypes.c_longlong(0), null, null, null) == ERR_ARG
+    L.vsa_reduce_scratch_bytes.restype = ctypes.c_longlong
+    assert 0 < L.vsa_reduce_scratch_bytes() <= 1 << 16
     # round-3 entry points
     assert L.vsa_nt_encode_mlp_fwd(null, null, null, null, null, null, null, null, null) == ERR_ARG
     assert L.vsa_packed_composite_fwd(null, null, null, null, null, null, 10, null) == ERR_ARG

@@ -214,3 +214,30 @@ def test_fused_forward_l1_backward_equals_the_two_kernels(K):
         gc, ga = composite_bwd_l1_raw(c, a, bg, rgb, gt, 1.0 / (3 * N))
         rgb2, gc2, ga2 = composite_fwd_bwd_l1_raw(c, a, bg, gt, 1.0 / (3 * N))
         assert torch.equal(rgb, rgb2) and torch.equal(gc, gc2) and torch.equal(ga, ga2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 3, 4, 1023, 4096, 49153 * 5, 3_200_003])
+def test_count_hits_and_l1_mean_equal_the_torch_expressions(n):
+    """vsa_count_hits == (hit_slot >= 0).sum() exactly and vsa_l1_mean == (pred - gt).abs().mean() (f64 sum:
+    within an ulp or two of torch's f32 tree), for empty tails, ragged lengths and many workgroups; the scratch
+    serves call after call; the same bits every time."""
+    from volsurfs_amd.composite import count_hits, l1_mean
+    g = torch.Generator(device="cuda").manual_seed(n)
+    slot = torch.randint(-1, 50, (n,), device="cuda", generator=g, dtype=torch.int32)
+    slot[torch.rand(n, device="cuda", generator=g) < 0.4] = -1
+    pred = torch.rand(n, device="cuda", generator=g)
+    gt = torch.rand(n, device="cuda", generator=g)
+    want_c = int((slot >= 0).sum().item())
+    want_l = (pred.double() - gt.double()).abs().mean().item()
+    first = None
+    for _ in range(3):
+        c, l = count_hits(slot), l1_mean(pred, gt)
+        assert c.dtype == torch.int64 and c.shape == () and int(c.item()) == want_c
+        assert abs(l.item() - want_l) <= 2e-7 * max(want_l, 1e-30) + 1e-12
+        first = l.item() if first is None else first
+        assert l.item() == first
+    assert int(count_hits(torch.full((n,), -1, device="cuda", dtype=torch.int32)).item()) == 0
+    if n >= 4096:                      # the [N,3] colours of a batch, as the training step calls it
+        p3, g3 = pred[:n - n % 3].view(-1, 3), gt[:n - n % 3].view(-1, 3)
+        assert abs(l1_mean(p3, g3).item() - (g3 - p3).abs().mean().item()) <= 1e-6

@@ -185,3 +185,54 @@ def test_encode_backward_phased_equals_one_launch_and_publishes_its_phases(phase
         assert torch.equal(snap, bank.tables.grad[a * 8:b * 8])
     with pytest.raises(ValueError):
         StepSignals(K, "cuda", [2, 2, 3])
+
+
+@pytest.mark.gpu
+def test_encode_bwd_stored_planes_equal_the_accumulated_ones():
+    """plan.grads_zeroed: a table plane one workgroup walks alone is stored instead of atomically added.  On a
+    zero buffer that is the same number (0 + v), in the full, the sliced and the phased launch; and with the
+    word withdrawn the launches accumulate into what the buffer holds, as before."""
+    from volsurfs_amd.parallel import StepSignals
+    K, N = 3, 2500
+    bank, face_uvs, hit_slot, hit_uv, tris, rays_d = _scene(K, N, 11, res=(256, 128, 64, 32))
+    tex_uv = bank.mark_and_compact(hit_slot, hit_uv, face_uvs)
+    g = torch.Generator().manual_seed(5)
+    g_rgb = (torch.randn(N, K, 3, generator=g) / N).cuda()
+    g_alpha = (torch.randn(N, K, generator=g) / N).cuda()
+    bank.encode(); bank.mlp()
+    bank.zero_grads()                                            # the bank's own clear vouches for ONE launch
+    bank.backward_shade(hit_slot, tex_uv, rays_d, tris, g_rgb, g_alpha, float(N))
+    bank.backward_mlp(float(N))
+    bank.backward_encode(float(N))
+    assert int(bank.plan.grads_zeroed) == 1
+    stored = bank.tables.grad.clone()
+    bank.backward_encode(float(N))                               # nobody vouches any more: accumulates
+    assert int(bank.plan.grads_zeroed) == 0
+    twice = bank.tables.grad.clone()
+    bank.tables.grad.zero_()
+    bank.backward_encode(float(N), grads_zeroed=False)           # every flush through atomics
+    ref = bank.tables.grad.clone()
+    assert ref.abs().max() > 0 and int(bank.plan.grads_zeroed) == 0
+
+    def close(a, b):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-6 * ref.abs().max().item())
+
+    close(stored, ref)
+    close(twice, 2 * ref)
+    bank.tables.grad.zero_()
+    bank.backward_encode(float(N), grads_zeroed=True)
+    assert int(bank.plan.grads_zeroed) == 1
+    close(bank.tables.grad, ref)
+    bank.tables.grad.zero_()
+    for s in range(K):                                           # sliced: every launch owns its shells' planes
+        bank.backward_encode(float(N), shells=(s, s + 1), grads_zeroed=True)
+    close(bank.tables.grad, ref)
+    sg = StepSignals(K, "cuda", [2, 3], 0)
+    bank.tables.grad.zero_()
+    sg.signal_weights()
+    bank.backward_encode_phased(float(N), sg, grads_zeroed=True)
+    torch.cuda.synchronize()
+    close(bank.tables.grad, ref)
+    bank.tables.grad.fill_(1.0)
+    bank.backward_encode(float(N), grads_zeroed=False)
+    close(bank.tables.grad, ref + 1.0)

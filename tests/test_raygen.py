@@ -140,7 +140,7 @@ def test_render_camera_and_reel_training_loop():
 
 @pytest.mark.gpu
 def test_hip_tile_order_round_trip_and_pipeline_equivalence():
-    """vsa_tile_order is a permutation (8x8 tiles, tile-major) with an exact inverse, and the
+    """vsa_tile_order is a permutation (8x8 tiles, tile-major, boustrophedon inside a tile) with an exact inverse, and the
     step in tile order returns what the step in the caller's order returns."""
     import ctypes
     from volsurfs_amd import _lib
@@ -151,7 +151,9 @@ def test_hip_tile_order_round_trip_and_pipeline_equivalence():
     _lib.call("vsa_tile_order", x, t, H, W, 3, 0, _lib.stream_ptr())
     _lib.call("vsa_tile_order", t, back, H, W, 3, 1, _lib.stream_ptr())
     assert torch.equal(back, x)
-    ref = x.reshape(H // 8, 8, W // 8, 8, 3).permute(0, 2, 1, 3, 4).reshape(-1, 3)
+    ref = x.reshape(H // 8, 8, W // 8, 8, 3).permute(0, 2, 1, 3, 4).clone()
+    ref[:, :, 1::2] = ref[:, :, 1::2].flip(3)                   # odd pixel rows of a tile run right to left
+    ref = ref.reshape(-1, 3)
     assert torch.equal(t, ref)
     with pytest.raises(_lib.VolsurfsHipError):
         _lib.call("vsa_tile_order", x, t, 20, 48, 3, 0, _lib.stream_ptr())      # 20 is not a multiple of 8

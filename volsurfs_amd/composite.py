@@ -113,3 +113,42 @@ def composite_fwd_bwd_l1_raw(surfs_rgb, surfs_alpha, rgb_bg, gt_rgb, loss_scale,
     _lib.call("vsa_composite_dense_fwd_bwd_l1", surfs_rgb, surfs_alpha, rgb_bg, bcast, gt_rgb,
               float(loss_scale), rgb, g_c, g_a, N, K, int(carry_f16), _lib.stream_ptr())
     return rgb, g_c, g_a
+
+
+_reduce_scratch = {}
+
+
+def reduce_scratch(device):
+    """The per-device scratch of vsa_count_hits / vsa_l1_mean (zeroed once; every call leaves it ready)."""
+    import ctypes
+    key = torch.device(device)
+    key = torch.device("cuda", torch.cuda.current_device()) if key.index is None else key
+    sc = _reduce_scratch.get(key)
+    if sc is None:
+        fn = _lib.lib().vsa_reduce_scratch_bytes
+        fn.restype = ctypes.c_longlong
+        sc = _reduce_scratch[key] = torch.zeros(int(fn()), dtype=torch.uint8, device=key)
+    return sc
+
+
+def l1_mean(pred, gt):
+    """mean |pred - gt| as a [] device tensor, one launch (vsa_l1_mean; utils/losses.py:14-19 without a mask)."""
+    import ctypes
+    pred, gt = _lib.check_f32(pred.contiguous()), _lib.check_f32(gt.contiguous(), *pred.shape)
+    pred, gt = (x if x.data_ptr() % 16 == 0 else x.clone() for x in (pred, gt))      # (a slice at an odd row)
+    out = torch.empty((), device=pred.device)
+    _lib.call("vsa_l1_mean", pred, gt, ctypes.c_longlong(pred.numel()), reduce_scratch(pred.device), out,
+              _lib.stream_ptr())
+    return out
+
+
+def count_hits(hit_slot):
+    """Number of entries >= 0 as a [] int64 device tensor, one launch (vsa_count_hits)."""
+    import ctypes
+    if hit_slot.dtype != torch.int32 or not hit_slot.is_contiguous() or not hit_slot.is_cuda:
+        raise _lib.VolsurfsHipError("count_hits: contiguous CUDA int32 tensor expected")
+    out = torch.empty((), dtype=torch.int64, device=hit_slot.device)
+    _lib.call("vsa_count_hits", hit_slot, ctypes.c_longlong(hit_slot.numel()), reduce_scratch(hit_slot.device), out,
+              _lib.stream_ptr())
+    return out
+

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void nt_encode_fwd_both_kernel(
 template <bool HASHED, int NF, bool MERGE>
 __device__ __forceinline__ void enc_bwd_piece(
     const vsa_nt_plan& plan, int* s_g, int level, int feat, int tex, int first, int last,
-    bool single, const half2_t* __restrict__ dfeatures, const float* __restrict__ dfeat_abs_sum,
+    bool single, bool store, const half2_t* __restrict__ dfeatures, const float* __restrict__ dfeat_abs_sum,
     float dscale_inv, const float2* __restrict__ slot_xy, float* __restrict__ grad_tables) {
   const int nl = plan.n_levels;
   const long long n_entries = plan.level_offset[plan.n_levels];
@@ -547,7 +547,27 @@ __device__ __forceinline__ void enc_bwd_piece(
   // two SEPARATE loops: with both modes in one loop body the compiler's wait-count bookkeeping
   // carried the other mode's pending loads around the back edge and put an s_waitcnt vmcnt(0)
   // in front of every atomic — each one then waited for the previous one's acknowledgement
-  if (single) {        // sole writer of this (texture, level, feature) plane: plain read-modify-write
+  if (store) {
+    // sole writer of this (texture, level, feature) plane AND the caller vouches that grad_tables was zero on
+    // entry (plan.grads_zeroed): plain stores.  A float atomic retires in the L2 at about one LANE per clock
+    // and channel — a 32 768-entry plane is 32 K of them, and at a training batch (49 k hits: 35 k slots per
+    // plane) the flushes were 0.136 of the launch's 0.231 ms (timing-only build, profiles/NOTEBOOK.md r5);
+    // ~700 of the ~1 215 pieces of a launch are sole writers whatever the batch (960 planes, 255 cuts).
+    for (int i0 = threadIdx.x; i0 < (int)g.size; i0 += ENC_BLOCK * FB) {
+      int vi[FB][NF];
+      plane_sums(i0, vi);
+#pragma unroll
+      for (int b = 0; b < FB; ++b) {
+        const long long i = i0 + b * ENC_BLOCK;
+        if constexpr (NF == 2) {      // both features of an entry: one 8-byte store (feat = 0: 8-byte aligned)
+          if ((vi[b][0] | vi[b][1]) != 0)
+            *reinterpret_cast<float2*>(&gt[2 * i]) = make_float2((float)vi[b][0] * S_inv[0], (float)vi[b][1] * S_inv[1]);
+        } else {
+          if (vi[b][0] != 0) gt[2 * i] = (float)vi[b][0] * S_inv[0];
+        }
+      }
+    }
+  } else if (single) {        // sole writer of this (texture, level, feature) plane: plain read-modify-write
     for (int i0 = threadIdx.x; i0 < (int)g.size; i0 += ENC_BLOCK * FB) {
       int vi[FB][NF];
       float old[FB][NF];
@@ -584,7 +604,9 @@ __device__ __forceinline__ void enc_bwd_piece(
       for (int cpy = 0; cpy < copies; ++cpy) vi += s_g[f * plane + cpy * g.size + i];
       if (vi == 0) continue;
       const float v = (float)vi * S_inv[f];
-      if (single) {
+      if (store) {
+        gt[2 * (long long)i + f] = v;
+      } else if (single) {
         gt[2 * (long long)i + f] += v;  // sole writer of this (texture, level, feature) plane
       } else {
         atomicAdd(&gt[2 * (long long)i + f], v);
@@ -632,17 +654,19 @@ __device__ __forceinline__ void nt_encode_bwd_body(
 #else
     const bool single = first == seg_begin && last == seg_end;
 #endif
+    // ... unless the caller vouches for a zero gradient buffer: then a sole writer's plane is simply stored
+    const bool store = plan.grads_zeroed != 0 && first == seg_begin && last == seg_end;
     // neighbouring texels are scale / R cells apart: from one cell per texel on, the
     // in-register merging of same-cell slots cannot fire and its bookkeeping is skipped
     const bool merge = plan.level_scale[level] < (float)plan.tex_res[tex % VSA_NT_MAX_DEG];
     if (both)
-      enc_bwd_piece<HASHED, 2, true>(plan, s_g, level, 0, tex, first, last, single, dfeatures,
+      enc_bwd_piece<HASHED, 2, true>(plan, s_g, level, 0, tex, first, last, single, store, dfeatures,
                                      dfeat_abs_sum, dscale_inv, slot_xy, grad_tables);
     else if (merge)
-      enc_bwd_piece<HASHED, 1, true>(plan, s_g, level, r, tex, first, last, single, dfeatures,
+      enc_bwd_piece<HASHED, 1, true>(plan, s_g, level, r, tex, first, last, single, store, dfeatures,
                                      dfeat_abs_sum, dscale_inv, slot_xy, grad_tables);
     else
-      enc_bwd_piece<HASHED, 1, false>(plan, s_g, level, r, tex, first, last, single, dfeatures,
+      enc_bwd_piece<HASHED, 1, false>(plan, s_g, level, r, tex, first, last, single, store, dfeatures,
                                       dfeat_abs_sum, dscale_inv, slot_xy, grad_tables);
   }, tex_begin, tex_end, unit_weight,
      // a launch over a sub-range of the textures (the sliced backward of parallel.py) keeps equal shares

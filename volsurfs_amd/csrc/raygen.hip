@@ -101,6 +101,12 @@ __global__ __launch_bounds__(256) void reel_rays_kernel(
 // BVH nodes / texel lines (measured on the 800x800 bench frame: trace -10 %, shade_fwd -12 %,
 // shade_bwd -7 %).  element i of the tile-major array = pixel (8 ty + j / 8, 8 tx + j % 8),
 // t = i / 64 = ty * (W / 8) + tx, j = i % 64.
+// Within a tile the pixels run boustrophedon (row 0 left to right, row 1 right to left, ...): consecutive
+// elements are always NEIGHBOURING pixels, also across the end of a pixel row — the shading backward keeps the
+// gradient lines of the previous hit's texel footprint open, and with raster rows every row end dropped all of them.
+// (nt_shade_bwd 0.348 -> 0.312 ms on the K=5 800x800 frame; neutral at 1080p K=7 — profiles/NOTEBOOK.md.)
+__device__ __forceinline__ int tile_x_of(int j) { return (j & 8) ? 7 - (j & 7) : (j & 7); }
+
 template <int C>
 __global__ __launch_bounds__(256) void tile_order_kernel(const float* __restrict__ src,
                                                          float* __restrict__ dst, int W, long long n,
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const float* __restrict
   const int tiles_x = W >> 3;
   const long long t = i >> 6;
   const int j = (int)(i & 63);
-  const long long row = (t / tiles_x) * 8 + (j >> 3), col = (t % tiles_x) * 8 + (j & 7);
+  const long long row = (t / tiles_x) * 8 + (j >> 3), col = (t % tiles_x) * 8 + tile_x_of(j);
   const long long px = row * W + col;
   const long long from = inverse ? i : px, to = inverse ? px : i;
 #pragma unroll
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(256) void tile_order_rays_kernel(
   const int tiles_x = W >> 3;
   const long long t = i >> 6;
   const int j = (int)(i & 63);
-  const long long px = ((t / tiles_x) * 8 + (j >> 3)) * W + (t % tiles_x) * 8 + (j & 7);
+  const long long px = ((t / tiles_x) * 8 + (j >> 3)) * W + (t % tiles_x) * 8 + tile_x_of(j);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     o_t[3 * i + c] = o[3 * px + c];

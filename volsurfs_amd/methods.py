@@ -50,6 +50,7 @@ class _ShadeStage(torch.autograd.Function):
         # for the two parameters: no 113 MB temporary, no second pass adding it to .grad.
         bank._ensure_grads()
         opt = getattr(method, "optimizer", None)
+        zeroed = bool(getattr(opt, "_grads_clean", False))     # the fused Adam step (or zero_grad) has just cleared them
         if hasattr(opt, "mark_grads_dirty"):
             opt.mark_grads_dirty()
         # scale of the fp16 gradient chain (tcnn's loss scale).  By default a power of two that
@@ -62,7 +63,7 @@ class _ShadeStage(torch.autograd.Function):
             gmax = max(g_rgb.abs().max().item(), g_alpha.abs().max().item())
             scale = 2.0 ** min(max(math.floor(math.log2(4.0 / gmax)), -24), 40) if gmax > 0 else 1.0
         bank.backward(hit_slot, tex_uv, rays_d, method.raytracer.tris, g_rgb.contiguous(),
-                      g_alpha.contiguous(), scale, act)
+                      g_alpha.contiguous(), scale, act, grads_zeroed=zeroed)
         return None, None, None, None, None, None
 
 
@@ -532,7 +533,7 @@ class VolSurfs(torch.nn.Module):
         """Gradients of `loss_weight * mean|gt_rgb - rgb|` (utils/losses.py:14-19) w.r.t. every
         texture parameter, accumulated into .grad.  Returns (loss [] device tensor — the
         unweighted mean, nr_hits [] int64 device tensor, rgb [N,3])."""
-        from .composite import composite_fwd_bwd_l1_raw
+        from .composite import composite_fwd_bwd_l1_raw, count_hits, l1_mean
         self._warmup_scheduler(is_first_iter)
         N = rays_o.shape[0]
         if N > self.max_rays:
@@ -540,12 +541,13 @@ class VolSurfs(torch.nn.Module):
         bank = self.bank
         bank._ensure_grads()
         opt = getattr(self, "optimizer", None)
+        zeroed = bool(getattr(opt, "_grads_clean", False))     # the fused Adam step (or zero_grad) has just cleared them
         if hasattr(opt, "mark_grads_dirty"):
             opt.mark_grads_dirty()
         bank.frame_generation = getattr(bank, "frame_generation", 0) + 1
         rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
         hit_t, hit_slot, hit_uv = self.raytracer.trace_all(rays_o, rays_d)
-        nr_hits = (hit_slot >= 0).sum()
+        nr_hits = count_hits(hit_slot)               # one launch (the torch expression: compare, cast, fill, reduce)
         tex_uv = bank.mark_and_compact(hit_slot, hit_uv, self.face_uvs)
         bank.evaluate()
         act = torch.empty(self.nr_meshes, N, 4, device=rays_o.device)
@@ -556,8 +558,8 @@ class VolSurfs(torch.nn.Module):
                                                  loss_scale)
         from .pipeline import GRAD_CHAIN_GAIN
         scale = self.grad_scale if self.grad_scale is not None else GRAD_CHAIN_GAIN / (3.0 * loss_scale)
-        bank.backward(hit_slot, tex_uv, rays_d, tris, g_c, g_a, scale, act)
-        loss = (gt_rgb - rgb).abs().mean()
+        bank.backward(hit_slot, tex_uv, rays_d, tris, g_c, g_a, scale, act, grads_zeroed=zeroed)
+        loss = l1_mean(rgb, gt_rgb)                  # the logged value, one launch
         return loss, nr_hits, rgb
 
     def forward(self, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first_iter=False,

@@ -50,7 +50,7 @@ class Plan(ctypes.Structure):
         ("max_rays", ctypes.c_int32), ("anchor", ctypes.c_int32),
         ("row_base", ctypes.c_int64 * (MAX_SHELLS * MAX_DEG + 1)),
         ("balance", ctypes.c_void_p),
-        ("row_format", ctypes.c_int32), ("reserved1", ctypes.c_int32),
+        ("row_format", ctypes.c_int32), ("grads_zeroed", ctypes.c_int32),
     ]
 
 
@@ -377,15 +377,16 @@ class NeuralTextureBank(torch.nn.Module):
         return rgb, alpha, normals, coeffs
 
     def backward(self, hit_slot, tex_uv, rays_d, tris, g_surfs_rgb, g_surfs_alpha, grad_scale,
-                 act=None):
+                 act=None, grads_zeroed=None):
         """Back-propagates d loss / d surfs_rgb [N,K,3], d surfs_alpha [N,K] to
         self.tables.grad / self.weights.grad (accumulating, like autograd).
         grad_scale keeps the fp16 intermediate gradients in range (the analogue of
-        tiny-cuda-nn's loss scale); it is divided out before accumulation."""
+        tiny-cuda-nn's loss scale); it is divided out before accumulation.
+        grads_zeroed: see backward_encode."""
         self.backward_shade(hit_slot, tex_uv, rays_d, tris, g_surfs_rgb, g_surfs_alpha, grad_scale,
                             act)
         self.backward_mlp(grad_scale)
-        self.backward_encode(grad_scale)
+        self.backward_encode(grad_scale, grads_zeroed=grads_zeroed)
 
     def _ensure_grads(self):
         if self.tables.grad is None:
@@ -407,6 +408,7 @@ class NeuralTextureBank(torch.nn.Module):
             self._dfsum = flat[nt + nw:].view(self.n_tex, 32)
         if self.tables.grad is None and self.weights.grad is None:
             self.tables.grad, self.weights.grad = self._flat_t, self._flat_w
+        self._tables_grad_zero = True        # (backward_encode: a sole writer's table plane is stored, not added)
         if self.tables.grad is self._flat_t and self.weights.grad is self._flat_w:
             flat.zero_()
             self._dfsum_clean = True
@@ -414,6 +416,14 @@ class NeuralTextureBank(torch.nn.Module):
         self.tables.grad.zero_()
         self.weights.grad.zero_()
         return False
+
+    def _take_grads_zeroed(self, grads_zeroed):
+        """plan.grads_zeroed of the next hash-grid backward launch: the caller's word (it knows its optimiser
+        has just cleared the gradients), else what zero_grads() left; either way the buffer holds something
+        after the launch."""
+        z = bool(getattr(self, "_tables_grad_zero", False) if grads_zeroed is None else grads_zeroed)
+        self._tables_grad_zero = False
+        self.plan.grads_zeroed = int(z)
 
     def backward_shade(self, hit_slot, tex_uv, rays_d, tris, g_surfs_rgb, g_surfs_alpha, grad_scale,
                        act=None):
@@ -436,9 +446,11 @@ class NeuralTextureBank(torch.nn.Module):
                   self.seg_start, self.grad_rows, self.weights.grad, self._dfsum,
                   1.0 / float(grad_scale), _lib.stream_ptr())
 
-    def backward_encode(self, grad_scale, shells=None):
+    def backward_encode(self, grad_scale, shells=None, grads_zeroed=None):
         """shells=(begin, end) restricts the launch to those shells' textures (their table
-        gradients are the contiguous slice tables.grad[begin*8:end*8])."""
+        gradients are the contiguous slice tables.grad[begin*8:end*8]).  grads_zeroed=True: the caller
+        vouches that tables.grad is all zero (vsa_nt_plan.grads_zeroed); None: true right after zero_grads()."""
+        self._take_grads_zeroed(grads_zeroed)
         if shells is None:
             _lib.call("vsa_nt_encode_bwd", ctypes.byref(self.plan), self.features, self._dfsum,
                       float(grad_scale), self.slot_xy, self.seg_start, self.tables.grad,
@@ -448,9 +460,10 @@ class NeuralTextureBank(torch.nn.Module):
                       self._dfsum, float(grad_scale), self.slot_xy, self.seg_start,
                       self.tables.grad, int(shells[0]), int(shells[1]), _lib.stream_ptr())
 
-    def backward_encode_phased(self, grad_scale, signals):
+    def backward_encode_phased(self, grad_scale, signals, grads_zeroed=None):
         """The hash-grid backward as ONE launch that finishes the shells phase by phase and publishes
         each phase's completion in signals.flags (parallel.StepSignals; vsa_nt_encode_bwd_phased)."""
+        self._take_grads_zeroed(grads_zeroed)
         _lib.call("vsa_nt_encode_bwd_phased", ctypes.byref(self.plan), self.features, self._dfsum,
                   float(grad_scale), self.slot_xy, self.seg_start, self.tables.grad, signals.n,
                   signals.phase_end_c, signals._flags, signals.counters, signals.epoch, int(signals.reserve_cus),

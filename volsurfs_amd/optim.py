@@ -12,6 +12,7 @@ iteration.  Gradients therefore live in persistent buffers (`p.grad` is allocate
 set to None): `zero_grad()` is free after a `step()`.
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -127,6 +128,8 @@ class FusedAdam(torch.optim.Optimizer):
     def _dirty_hook(self, _param):
         self._grads_clean = False
 
+    shared_workgroups = int(os.environ.get("VSA_ADAM_SHARED_WGS", "512"))   # step(stream=...): grid of the side-stream launch
+
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0, stream=None):
         """stream: a side `torch.cuda.Stream` to run the update on (ordered after everything
@@ -138,12 +141,14 @@ class FusedAdam(torch.optim.Optimizer):
         if stream is not None:
             stream.wait_stream(torch.cuda.current_stream())
         sp = ctypes.c_void_p(stream.cuda_stream) if stream is not None else _lib.stream_ptr()
+        # beside another stream's kernels: a bounded grid (vsa_adam_step_shared), else one workgroup per chunk
+        bound = int(self.shared_workgroups) if stream is not None else 0
         for gi, group in enumerate(self.param_groups):
             _, desc, ck, n, _ = self._plan(gi, group)
             group["step"] += 1
             b1, b2 = group["betas"]
-            _lib.call("vsa_adam_step", desc, ck, n, float(group["lr"]), float(b1), float(b2),
-                      float(group["eps"]), int(group["step"]), float(grad_scale), 1, sp)
+            _lib.call("vsa_adam_step_shared", desc, ck, n, float(group["lr"]), float(b1), float(b2),
+                      float(group["eps"]), int(group["step"]), float(grad_scale), 1, bound, sp)
         self._grads_clean = True
         if stream is not None:
             ev = torch.cuda.Event()

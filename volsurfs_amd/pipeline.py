@@ -77,8 +77,9 @@ class KShellPipeline:
             self._o_t, self._d_t, self._gt_t = (torch.empty_like(x) for x in (rays_o, rays_d, gt_rgb))
             self._rgb_out = torch.empty_like(gt_rgb)
             H, W = self.image_hw
-            self._tile_idx = torch.arange(H * W, device=rays_o.device).reshape(H // 8, 8, W // 8, 8) \
-                .permute(0, 2, 1, 3).reshape(-1)          # element i of a tile-major array = pixel _tile_idx[i]
+            tiles = torch.arange(H * W, device=rays_o.device).reshape(H // 8, 8, W // 8, 8).permute(0, 2, 1, 3).clone()
+            tiles[:, :, 1::2] = tiles[:, :, 1::2].flip(-1)          # odd pixel rows of a tile run right to left (raygen.hip)
+            self._tile_idx = tiles.reshape(-1)            # element i of a tile-major array = pixel _tile_idx[i]
         dev = rays_o.device
         self.bg = torch.tensor([bg_color], device=dev, dtype=torch.float32)
         self.timer = StageTimer()

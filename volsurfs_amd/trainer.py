@@ -121,8 +121,11 @@ def train_step(method, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first
                     nxt = dynamic_nr_rays(nr_rays, nr_samples, target_nr_of_training_samples)
                 prefetch(nxt)
             (l["loss"] * (w * share)).backward()                            # :264
-        for k, v in l.items():
-            losses[k] = losses.get(k, 0.0) + (v.detach() if isinstance(v, torch.Tensor) else v) * w
+        if len(bounds) == 1:          # w = 1: the values as they are (two elementwise launches per key otherwise)
+            losses = {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in l.items()}
+        else:
+            for k, v in l.items():
+                losses[k] = losses.get(k, 0.0) + (v.detach() if isinstance(v, torch.Tensor) else v) * w
     if world > 1 and not hasattr(method.optimizer, "gather_masters"):     # (a sharded optimiser reduces inside step())
         from .parallel import allreduce_gradients
         allreduce_gradients([p for g in method.optimizer.param_groups for p in g["params"]], world, group)
@@ -169,14 +172,14 @@ def train_step_from_reel(method, reel, nr_rays, jitter_pixels=True, nr_rays_per_
         kw = dict(kw, ahead=ahead, prefetch=prefetch)
         rays_o, rays_d = ahead.rays_o, ahead.rays_d     # the contiguous tensors the context was traced with
     gt_rgb = vals["rgb"]
-    gt_mask = vals["mask"] if "mask" in vals else torch.ones_like(gt_rgb[:, :1])
+    gt_mask = vals["mask"] if "mask" in vals else (torch.ones_like(gt_rgb[:, :1]) if is_training_masked else None)
     if is_training_masked:
         gt_rgb = gt_rgb * gt_mask
         if method.bg_color is not None:
             gt_rgb = gt_rgb + (1 - gt_mask) * method.bg_color.reshape(1, 3).to(gt_rgb)
     if nr_rays_per_pixel > 1:
         gt_rgb = gt_rgb.repeat_interleave(nr_rays_per_pixel, 0)
-        gt_mask = gt_mask.repeat_interleave(nr_rays_per_pixel, 0)
+        gt_mask = None if gt_mask is None else gt_mask.repeat_interleave(nr_rays_per_pixel, 0)
     return train_step(method, rays_o, rays_d, gt_rgb, gt_mask, iter_nr, nr_rays=nr_rays,
                       is_training_masked=is_training_masked, **kw)
 
