@@ -725,6 +725,11 @@ def main():
     for _ in range(max(1, args.warmup)):
         step()
     pipe.stats()                       # hit / unique-texel counts for the byte & flop accounting
+    # the stage / kernel tables below are taken at steady state: ten steps are 25 ms — neither the clocks nor the
+    # measured-time work split of the persistent kernels (vsa_nt_rebalance) have settled by then (the same box
+    # reported stage sums of 2.74 ms after 10 steps and 2.47 ms after 30, for a 2.44 ms step)
+    for _ in range(max(0, 40 - args.warmup)):
+        step()
     # per-kernel stage times: a few eager steps with events (outside the timed region)
     pipe.reset_stage_timers()
     for _ in range(3):

@@ -87,10 +87,13 @@ kernel_events = None   # bench.py: {} -> every call is bracketed by events on th
 
 
 def kernel_ms():
-    """Mean duration per C-ABI entry point over the calls recorded in `kernel_events`."""
+    """Median duration per C-ABI entry point over the calls recorded in `kernel_events` (the median: one call
+    that sat behind another stream's work — a communicator coming up, a collective of the previous step —
+    would otherwise own the mean of three)."""
+    import statistics
     import torch
     torch.cuda.synchronize()
-    return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in (kernel_events or {}).items()}
+    return {k: statistics.median(a.elapsed_time(b) for a, b in v) for k, v in (kernel_events or {}).items()}
 
 
 def kernel_totals():
