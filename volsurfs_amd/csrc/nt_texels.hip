@@ -192,7 +192,8 @@ __global__ __launch_bounds__(1024) void nt_assign_kernel(vsa_nt_plan plan,
   const int nseg = plan.nr_shells * VSA_NT_MAX_DEG;
   while (sd + 1 < nseg && plan.dom_off[sd + 1] <= blk0) ++sd;
   const int R = plan.tex_res[sd % VSA_NT_MAX_DEG], W = R + 2;
-  const float Rf = (float)R;
+  const float Rf = (float)R, inv_R = 1.0f / Rf;
+  const bool pow2 = (R & (R - 1)) == 0;
   const long long dom0 = plan.dom_off[sd];
   const long long vec = (long long)blockIdx.x * 1024 + threadIdx.x;   // 4-texel group
   const unsigned word = marks[vec] & 0x01010101u;
@@ -204,8 +205,10 @@ __global__ __launch_bounds__(1024) void nt_assign_kernel(vsa_nt_plan plan,
   const int incl = nt_wave_incl_scan(c);
   if (lane == 63) s_w[wave] = incl;
   __syncthreads();
-  int slot = block_prefix[blockIdx.x] + incl - c;
-  for (int w = 0; w < wave; ++w) slot += s_w[w];
+  // the waves in front of this one: a 16-lane scan of the wave totals (up to 15 dependent LDS reads and adds before)
+  const int wtot = nt_wave_incl_scan(lane < 16 ? s_w[lane] : 0);
+  const int before = wave ? __builtin_amdgcn_readlane(wtot, (wave - 1) & 15) : 0;
+  int slot = block_prefix[blockIdx.x] + incl - c + before;
   int out[4];
   const int local0 = (int)(vec * 4 - dom0);
   int iy, ix;
@@ -225,8 +228,11 @@ __global__ __launch_bounds__(1024) void nt_assign_kernel(vsa_nt_plan plan,
     if (m) {
       if (slot < slot_capacity) {
         if (!SPARSE || texel_of_slot) texel_of_slot[slot] = (int)(vec * 4 + i);
-        // texel centre, normalised exactly like normalize_uv_coord(corner) in the reference
-        slot_xy[slot] = make_float2(((float)(ix - 1) + 0.5f) / Rf, ((float)(iy - 1) + 0.5f) / Rf);
+        // texel centre, normalised exactly like normalize_uv_coord(corner) in the reference.  A power-of-two R
+        // (every shipped configuration): the quotient is an exact scaling, i.e. the same bits as a product with
+        // 1 / R — two IEEE divisions per marked texel were most of this kernel's vector work
+        const float cx = (float)(ix - 1) + 0.5f, cy = (float)(iy - 1) + 0.5f;
+        slot_xy[slot] = pow2 ? make_float2(cx * inv_R, cy * inv_R) : make_float2(cx / Rf, cy / Rf);
       }
       ++slot;
     }

@@ -107,6 +107,10 @@ __global__ __launch_bounds__(256) void reel_rays_kernel(
 // (nt_shade_bwd 0.348 -> 0.312 ms on the K=5 800x800 frame; neutral at 1080p K=7 — profiles/NOTEBOOK.md.)
 __device__ __forceinline__ int tile_x_of(int j) { return (j & 8) ? 7 - (j & 7) : (j & 7); }
 
+struct __attribute__((packed, aligned(4))) F3 {      // a [.,3] f32 record: 4-byte aligned, moved as one dwordx3
+  float x, y, z;
+};
+
 template <int C>
 __global__ __launch_bounds__(256) void tile_order_kernel(const float* __restrict__ src,
                                                          float* __restrict__ dst, int W, long long n,
@@ -119,8 +123,12 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const float* __restrict
   const long long row = (t / tiles_x) * 8 + (j >> 3), col = (t % tiles_x) * 8 + tile_x_of(j);
   const long long px = row * W + col;
   const long long from = inverse ? i : px, to = inverse ? px : i;
+  if constexpr (C == 3) {     // one 12-byte access each way (global_load / store_dwordx3) instead of three dwords
+    *reinterpret_cast<F3*>(dst + to * 3) = *reinterpret_cast<const F3*>(src + from * 3);
+  } else {
 #pragma unroll
-  for (int c = 0; c < C; ++c) dst[to * C + c] = src[from * C + c];
+    for (int c = 0; c < C; ++c) dst[to * C + c] = src[from * C + c];
+  }
 }
 
 // the three per-ray inputs of a training frame in one pass
@@ -133,12 +141,12 @@ __global__ __launch_bounds__(256) void tile_order_rays_kernel(
   const long long t = i >> 6;
   const int j = (int)(i & 63);
   const long long px = ((t / tiles_x) * 8 + (j >> 3)) * W + (t % tiles_x) * 8 + tile_x_of(j);
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    o_t[3 * i + c] = o[3 * px + c];
-    d_t[3 * i + c] = d[3 * px + c];
-    if (gt) gt_t[3 * i + c] = gt[3 * px + c];
-  }
+  const F3 vo = *reinterpret_cast<const F3*>(o + 3 * px), vd = *reinterpret_cast<const F3*>(d + 3 * px);
+  F3 vg = {0.f, 0.f, 0.f};
+  if (gt) vg = *reinterpret_cast<const F3*>(gt + 3 * px);
+  *reinterpret_cast<F3*>(o_t + 3 * i) = vo;
+  *reinterpret_cast<F3*>(d_t + 3 * i) = vd;
+  if (gt) *reinterpret_cast<F3*>(gt_t + 3 * i) = vg;
 }
 
 }  // namespace
