@@ -596,6 +596,32 @@ int vsa_adam_step_shared(const vsa_adam_tensor* tensors_dev, const int32_t* chun
                          float lr, float beta1, float beta2, float eps, int step, float grad_scale,
                          int zero_grads, int max_workgroups, void* stream);
 
+/* The glue of the legacy appearance branch around its encoders and MLPs, one launch each way (csrc/legacy_glue.hip;
+ * volsurfs.py:486-599; as torch expressions: 18 + 21 launches per training iteration of BASELINE configs[2]).
+ *   hit_shell / hit_ray [nr_hits] i64 = shell and ray of every hit, sorted by shell then ray (the two columns of
+ *   torch.nonzero(hit_slot >= 0), which torch lays out column by column).
+ * vsa_legacy_hit_prep: pts = rays_o + hit_t * rays_d (:507), dirs = rays_d of the hit's ray, normals =
+ *   normalize(cross(e1, e2)) of the hit triangle (tris as vsa_bvh_export; F.normalize's 1e-12 floor); [nr_hits,3] each.
+ * vsa_legacy_shade_out_fwd: into surfs_rgb [N,K,3] / surfs_alpha [N,K] / surfs_normals [N,K,3] — ZEROED by the caller
+ *   (entries where nothing was hit keep that zero, volsurfs.py:486-490; one fill of one allocation in the mirror) — at
+ *   every hit: sigmoid(y_rgb[i][0..3)) (row stride ld_rgb >= 3), the hit's normal, and alpha = 1 for rows < alpha_first_row
+ *   (a solid inner shell) or when y_alpha is NULL, else sigmoid(y_alpha[i - alpha_first_row][0]) times, if
+ *   with_alpha_decay, 2 sigmoid(10 clamp(-d.n, 0, 1)) - 1 (:585-594).  sig_rgb [nr_hits,3], sig_alpha / decay
+ *   [nr_hits - alpha_first_row]: what the backward needs.
+ * vsa_legacy_shade_out_bwd: dy_rgb / dy_alpha (same strides; channels beyond the used ones zeroed) from the gradients
+ *   of the dense arrays: g * s (1 - s), the alpha one through the decay. */
+int vsa_legacy_hit_prep(const float* rays_o, const float* rays_d, const float* hit_t, const int32_t* hit_slot,
+                        const float* tris, const int64_t* hit_shell, const int64_t* hit_ray, int nr_hits, int nr_rays,
+                        float* pts, float* dirs, float* normals, void* stream);
+int vsa_legacy_shade_out_fwd(const float* y_rgb, int ld_rgb, const float* y_alpha, int ld_alpha, int alpha_first_row,
+                             const int64_t* hit_shell, const int64_t* hit_ray, const float* dirs, const float* normals,
+                             int nr_hits, int nr_rays,
+                             int nr_shells, int with_alpha_decay, float* surfs_rgb, float* surfs_alpha,
+                             float* surfs_normals, float* sig_rgb, float* sig_alpha, float* decay, void* stream);
+int vsa_legacy_shade_out_bwd(const float* g_surfs_rgb, const float* g_surfs_alpha, const int64_t* hit_shell,
+                             const int64_t* hit_ray, const float* sig_rgb, const float* sig_alpha, const float* decay, int nr_hits, int nr_shells,
+                             int alpha_first_row, float* dy_rgb, int ld_rgb, float* dy_alpha, int ld_alpha, void* stream);
+
 /* A5  Permutohedral-lattice hash encoding: `PermutoHashEncoder`
  * (volsurfs_py/encodings/permutohash.py:28-37, 68-96) = permutohedral_encoding.PermutoEncoding
  * (un-vendored fork, .gitmodules:7-9; published algorithm restated, parity unpinned).

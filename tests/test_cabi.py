@@ -68,6 +68,11 @@ def test_argument_errors_are_reported_not_ignored():
     assert L.vsa_l1_mean(null, null, ctypes.c_longlong(0), null, null, null) == ERR_ARG
     L.vsa_reduce_scratch_bytes.restype = ctypes.c_longlong
     assert 0 < L.vsa_reduce_scratch_bytes() <= 1 << 16
+    assert L.vsa_legacy_hit_prep(null, null, null, null, null, null, null, 10, 10, null, null, null, null) == ERR_ARG
+    assert L.vsa_legacy_hit_prep(null, null, null, null, null, null, null, 0, 10, null, null, null, null) == 0          # no hits
+    assert L.vsa_legacy_shade_out_fwd(null, 2, null, 0, 0, null, null, null, null, 0, 0, 5, 1, null, null, null, null, null, null,
+                                      null) == ERR_ARG                                                              # < 3 colour channels
+    assert L.vsa_legacy_shade_out_bwd(null, null, null, null, null, null, null, 10, 5, 0, null, 3, null, 0, null) == ERR_ARG
     # round-3 entry points
     assert L.vsa_nt_encode_mlp_fwd(null, null, null, null, null, null, null, null, null) == ERR_ARG
     assert L.vsa_packed_composite_fwd(null, null, null, null, null, null, 10, null) == ERR_ARG

@@ -67,6 +67,46 @@ class _ShadeStage(torch.autograd.Function):
         return None, None, None, None, None, None
 
 
+class _LegacyShadeOut(torch.autograd.Function):
+    """Behind the legacy models (volsurfs.py:521-599): sigmoid of the colour / alpha outputs, the alpha decay, and the
+    scatter of every hit's values to the dense [N,K,.] arrays — one launch forward, one backward
+    (vsa_legacy_shade_out_fwd / _bwd) instead of 21 + 12 torch launches and as many autograd nodes.
+    y_rgb [M, >= 3], y_alpha [M - a0, >= 1] or None (pre-sigmoid), shell_of / ray_of [M] i64, dirs / nrm [M,3]."""
+
+    @staticmethod
+    def forward(ctx, y_rgb, y_alpha, shell_of, ray_of, dirs, nrm, N, K, a0, with_decay):
+        y_rgb = y_rgb.contiguous()
+        ya = None if y_alpha is None else y_alpha.contiguous()
+        M, dev = shell_of.shape[0], y_rgb.device
+        dense = torch.zeros(N * K * 7, device=dev)          # one fill for the three dense arrays
+        surfs_rgb, surfs_alpha = dense[:N * K * 3].view(N, K, 3), dense[N * K * 3:N * K * 4].view(N, K)
+        surfs_normals = dense[N * K * 4:].view(N, K, 3)
+        sig_rgb = torch.empty(M, 3, device=dev)
+        sig_a = torch.empty(max(M - a0, 1), device=dev) if ya is not None else None
+        dec = torch.empty_like(sig_a) if ya is not None else None
+        _lib.call("vsa_legacy_shade_out_fwd", y_rgb, y_rgb.shape[1], ya, ya.shape[1] if ya is not None else 0, int(a0),
+                  shell_of, ray_of, dirs, nrm, M, N, K, bool(with_decay), surfs_rgb, surfs_alpha, surfs_normals, sig_rgb,
+                  sig_a, dec, _lib.stream_ptr())
+        ctx.save_for_backward(shell_of, ray_of, sig_rgb, sig_a, dec)
+        ctx.meta = (M, N, K, int(a0), y_rgb.shape[1], ya.shape[1] if ya is not None else 0)
+        ctx.mark_non_differentiable(surfs_normals)
+        return surfs_rgb, surfs_alpha, surfs_normals
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_alpha, _g_normals):
+        shell_of, ray_of, sig_rgb, sig_a, dec = ctx.saved_tensors
+        M, N, K, a0, ld_rgb, ld_a = ctx.meta
+        dev = sig_rgb.device
+        # (a dense array that did not take part in the loss arrives as None: zeros of its shape)
+        g_rgb = torch.zeros(N, K, 3, device=dev) if g_rgb is None else g_rgb.contiguous()
+        g_alpha = torch.zeros(N, K, device=dev) if g_alpha is None else g_alpha.contiguous()
+        dy_rgb = torch.empty(M, ld_rgb, device=dev)
+        dy_a = torch.empty(M - a0, ld_a, device=dev) if ld_a else None
+        _lib.call("vsa_legacy_shade_out_bwd", g_rgb, g_alpha, shell_of, ray_of, sig_rgb, sig_a, dec, M, K, a0, dy_rgb,
+                  ld_rgb, dy_a, ld_a, _lib.stream_ptr())
+        return dy_rgb, dy_a, None, None, None, None, None, None, None, None
+
+
 class VolSurfs(torch.nn.Module):
     """K nested mesh shells with SH neural-texture appearance.
 
@@ -227,6 +267,8 @@ class VolSurfs(torch.nn.Module):
             self.optimizer.gather_masters()      # sharded Adam: fp32 masters are per-slice until gathered
 
     legacy_grouped = True     # class-wide switch: False = the per-shell loop (tests compare the two)
+    legacy_fused_glue = __import__("os").environ.get("VSA_LEGACY_FUSED_GLUE", "1") != "0"   # grouped path: hit preparation,
+    # sigmoid / decay / scatter and (forward()) composite + L1 as one launch each instead of torch expressions
 
     def _legacy_groupable(self, x_probe):
         """The grouped path covers the configuration BASELINE configs[2] trains: every model an `RGB`
@@ -254,9 +296,9 @@ class VolSurfs(torch.nn.Module):
         from .models import fused_mlp_grouped
         N, K = rays_o.shape[0], self.nr_meshes
         dev = rays_o.device
-        surfs_rgb = torch.zeros(N, K, 3, device=dev)
-        surfs_alpha = torch.zeros(N, K, device=dev)
-        surfs_normals = torch.zeros(N, K, 3, device=dev)
+
+        def dense_zeros():
+            return torch.zeros(N, K, 3, device=dev), torch.zeros(N, K, device=dev), torch.zeros(N, K, 3, device=dev)
         if ahead is not None:          # compacted when the traversal was queued (trace_ahead)
             counts = ahead.counts()
             M = int(sum(counts))
@@ -266,18 +308,28 @@ class VolSurfs(torch.nn.Module):
             counts = torch.bincount(shell_of, minlength=K).tolist()
             M = int(sum(counts))
         if M == 0:
-            return surfs_rgb, surfs_alpha, surfs_normals
+            return dense_zeros()
         begin = [0]
         for c in counts:
             begin.append(begin[-1] + c)
-        slots = hit_slot[shell_of, ray_of].long()
-        tri = self.raytracer.tris[slots]
-        nrm = torch.nn.functional.normalize(torch.cross(tri[:, 4:7], tri[:, 8:11], dim=1), dim=1)
-        d = rays_d[ray_of]
-        pts = rays_o[ray_of] + hit_t[shell_of, ray_of][:, None] * d
+        fused_glue = VolSurfs.legacy_fused_glue
+        if fused_glue:
+            # the hits' points, directions and face normals in one launch (18 torch launches otherwise)
+            # (torch.nonzero lays its [n, 2] result out column by column: the two columns are contiguous as they are)
+            shell_of, ray_of = shell_of.contiguous(), ray_of.contiguous()
+            pts, d, nrm = (torch.empty(M, 3, device=dev) for _ in range(3))
+            _lib.call("vsa_legacy_hit_prep", rays_o, rays_d, hit_t, hit_slot, self.raytracer.tris, shell_of, ray_of, M, N,
+                      pts, d, nrm, _lib.stream_ptr())
+        else:
+            slots = hit_slot[shell_of, ray_of].long()
+            tri = self.raytracer.tris[slots]
+            nrm = torch.nn.functional.normalize(torch.cross(tri[:, 4:7], tri[:, 8:11], dim=1), dim=1)
+            d = rays_d[ray_of]
+            pts = rays_o[ray_of] + hit_t[shell_of, ray_of][:, None] * d
 
         def evaluate(typ, indep, first_shell):
-            """sigmoid(MLP(cat(pos enc, dir enc, normals))) for the hits of shells >= first_shell."""
+            """sigmoid(MLP(cat(pos enc, dir enc, normals))) for the hits of shells >= first_shell (fused glue: the
+            MLP's output; the sigmoid is taken in _LegacyShadeOut)."""
             a0 = begin[first_shell]
             if a0 == M:
                 return None
@@ -305,12 +357,18 @@ class VolSurfs(torch.nn.Module):
             if m0.normal_dep:
                 parts.append(nrm[a0:])
             y = fused_mlp_grouped([mod.mlp for mod in mods], torch.cat(parts, 1), sizes)
-            return torch.sigmoid(y)
+            return y if fused_glue else torch.sigmoid(y)
+        first = 1 if self.solid_inner else 0
+        has_alpha = any(k.split("_")[0] == "alpha" for k in self.models)
+        if fused_glue:
+            y_rgb = evaluate("rgb", self.colors_indep, 0)
+            y_alpha = evaluate("alpha", self.alphas_indep, first) if has_alpha else None
+            return _LegacyShadeOut.apply(y_rgb, y_alpha, shell_of, ray_of, d, nrm, N, K, begin[first],
+                                         bool(self.with_alpha_decay))
+        surfs_rgb, surfs_alpha, surfs_normals = dense_zeros()
         pred = evaluate("rgb", self.colors_indep, 0)
         surfs_rgb = surfs_rgb.index_put((ray_of, shell_of), pred[:, :3])
-        first = 1 if self.solid_inner else 0
         alpha = torch.ones(M, device=dev)
-        has_alpha = any(k.split("_")[0] == "alpha" for k in self.models)
         if has_alpha:
             pa = evaluate("alpha", self.alphas_indep, first)
             if pa is not None:
@@ -569,8 +627,28 @@ class VolSurfs(torch.nn.Module):
         return_samples=False skips the boolean compaction of the hit points (two host syncs) when
         the caller has no use for them."""
         self._warmup_scheduler(is_first_iter)                                   # :774-783
+        want_samples = return_samples and (ahead is None or self.using_neural_textures)
+        if (VolSurfs.legacy_fused_glue and VolSurfs.legacy_grouped and not self.using_neural_textures and not want_samples
+                and self.bg_color is not None and not (is_training_masked and gt_mask is not None)
+                and rays_o.shape[0] <= self.max_rays and self._legacy_groupable(rays_o)):
+            # the legacy training step with its glue fused (BASELINE configs[2]): traversal (or the look-ahead
+            # context), grouped shading, then composite + L1 as ONE node (composite.composite_l1) — the same values as
+            # render_rays + (gt - pred).abs().mean(), 55 launches and autograd nodes less per iteration
+            from .composite import composite_l1
+            rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
+            if ahead is not None and (ahead.rays_o.data_ptr() != rays_o.data_ptr() or ahead.rays_o.shape != rays_o.shape):
+                ahead = None
+            if ahead is not None:
+                hit_t, hit_slot = ahead.hit_t, ahead.hit_slot
+            else:
+                hit_t, hit_slot, _ = self.raytracer.trace_all(rays_o, rays_d)
+            rgb_k, alpha_k, _ = self._shade_legacy(rays_o, rays_d, hit_t, hit_slot, iter_nr, ahead)
+            if ahead is not None:
+                self.last_nr_hits = int(sum(ahead.counts()))
+            loss_rgb, _ = composite_l1(rgb_k, alpha_k, self.bg_color, gt_rgb)
+            return {"loss": loss_rgb, "rgb": loss_rgb}, {}, None
         res = self.render_rays(rays_o=rays_o, rays_d=rays_d, iter_nr=iter_nr, ahead=ahead,
-                               return_samples=return_samples and (ahead is None or self.using_neural_textures))
+                               return_samples=want_samples)
         pred = res["renders"]["ray_traced"]["rgb"]
         if is_training_masked and gt_mask is not None:
             loss_rgb = ((gt_rgb - pred).abs() * gt_mask).mean()

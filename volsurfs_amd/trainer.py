@@ -120,7 +120,7 @@ def train_step(method, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first
                 if nr_rays is not None and target_nr_of_training_samples and nr_samples:
                     nxt = dynamic_nr_rays(nr_rays, nr_samples, target_nr_of_training_samples)
                 prefetch(nxt)
-            (l["loss"] * (w * share)).backward()                            # :264
+            (l["loss"] if w * share == 1.0 else l["loss"] * (w * share)).backward()      # :264
         if len(bounds) == 1:          # w = 1: the values as they are (two elementwise launches per key otherwise)
             losses = {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in l.items()}
         else:
