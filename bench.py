@@ -500,11 +500,14 @@ def run_render(args, world, rank, dev, dist):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / args.steps
     t_live = timed(lambda: m.render(o, d, chunk=res * res))
+    k_live = kernel_table(lambda: m.render(o, d, chunk=res * res), 3) if rank == 0 else None
     m.bake()
     t_baked = timed(lambda: m.render_baked(o, d))
+    k_baked = kernel_table(lambda: m.render_baked(o, d), 3) if rank == 0 else None
     if rank == 0:
         n = res * res
         print(json.dumps({
+            "kernels_ms": k_live, "kernels_ms_baked": k_baked,
             "metric": f"Mrays/s (forward only) at {res}x{res}, K={args.shells} shells", "value": n / t_live / 1e6,
             "unit": "Mrays/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": t_live * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
