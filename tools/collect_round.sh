@@ -30,3 +30,7 @@ bash tools/pmc.sh ${tag}_pmc_c "nt_mlp|nt_encode|nt_shade|trace_qf" "TCC_HIT_sum
 bash tools/pmc.sh ${tag}_pmc_d "nt_mlp|nt_encode|nt_shade|trace_qf" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_ACCESSES_sum" $P | tail -4
 K7="--res 1080 --width 1920 --shells 7 --subdiv 8"
 bash tools/pmc.sh ${tag}_pmck7_a "nt_mlp|nt_encode|nt_shade|trace_qf" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" $P $K7 | tail -4
+# the frame lines once more, now that traffic.json / pmc_summary.json can be rebuilt at these sources (on the box: only
+# gpurun_out/ travels back; run tools/finish_round.py again at home)
+python tools/finish_round.py $tag > /dev/null 2>&1
+bash tools/collect_lines.sh $tag | tail -4
