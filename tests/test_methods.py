@@ -812,3 +812,45 @@ def test_reference_texture_switches_reach_the_renderer():
         VolSurfs(nested_shells(K=1, subdiv=2), max_rays=1024, using_sh_quantization=0, using_sh_squeezing=0)
     with pytest.raises(ValueError):
         VolSurfs(nested_shells(K=1, subdiv=2), max_rays=1024, using_neural_textures_anchor=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [dict(), dict(is_inner_mesh_solid=True, rgb_normal_dep=True)])
+def test_fused_legacy_step_equals_the_autograd_step(cfg):
+    """VolSurfs.fused_legacy_forward / _backward (the legacy training step with every launch called directly: no
+    autograd graph, no engine pass) against forward() + loss.backward(): the same kernels in the same order — the
+    same loss and the same gradients, with and without persistent .grad buffers (optim.FusedAdam's)."""
+    from volsurfs_amd.camera import pinhole_rays
+    from volsurfs_amd.mesh import nested_shells
+    from volsurfs_amd.methods import VolSurfs
+    kw = dict(max_rays=4096, using_neural_textures=False, rgb_pos_encoder_type="permutohash",
+              rgb_mlp_layers_dims=(64, 32), bb_sides=1.0)
+    kw.update(cfg)
+    m = VolSurfs(nested_shells(K=3, subdiv=3), **kw)
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        for mod in m.models.values():
+            p = mod.pos_encoder.encoder.lattice_values
+            p.copy_((torch.rand(p.shape, generator=g) * 2 - 1).cuda())
+    o, d = pinhole_rays(40, 40, focal=70.0)
+    gt = torch.rand(1600, 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+    assert m.supports_fused_legacy_step(o)
+    for persistent in (False, True):
+        for p in m.parameters():
+            p.grad = torch.zeros_like(p) if persistent else None
+        losses, _, _ = m(o, d, gt, None, 3, return_samples=False)
+        (losses["loss"] * 0.5).backward()
+        want = [None if p.grad is None else p.grad.clone() for p in m.parameters()]
+        want_loss = losses["loss"].item()
+        for p in m.parameters():
+            p.grad = torch.zeros_like(p) if persistent else None
+        loss, state = m.fused_legacy_forward(o, d, gt, iter_nr=3, loss_weight=0.5)
+        m.fused_legacy_backward(state)
+        assert loss.item() == want_loss
+        n = 0
+        for p, w in zip(m.parameters(), want):
+            assert (p.grad is None) == (w is None)
+            if w is not None and w.abs().max() > 0:
+                n += 1
+                assert (p.grad - w).abs().max().item() <= 2e-6 * w.abs().max().item()
+        assert n >= 6

@@ -432,6 +432,49 @@ def permuto_hash_encode_grouped(encs, points, sizes, iter_nr=None):
     return enc
 
 
+class ManualCtx:
+    """What an autograd Function's forward / backward need from their ctx, for calling them WITHOUT the autograd
+    engine (the fused legacy training step, methods.VolSurfs.fused_legacy_forward: same kernels, same order, no
+    graph nodes, no engine pass — the loop of BASELINE configs[2] is as much host as device time)."""
+
+    def __init__(self, n_inputs=64):
+        self.needs_input_grad = (True,) * n_inputs
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+
+def permuto_hash_encode_grouped_manual(encs, points, sizes, iter_nr=None):
+    """permuto_hash_encode_grouped without autograd: returns (encoding, backward) where backward(g_encoding) adds the
+    lattice gradients into the encoders' .grad buffers (they must own persistent ones: optim.FusedAdam)."""
+    e0 = encs[0]
+    t = 1.0 if iter_nr is None or iter_nr < 0 else map_range_val(iter_nr, 0.0, e0.nr_iters_for_c2f, 0.3, 1.0)
+    window = e0.c2f(t)
+    window = None if e0.c2f.all_open else window.view(-1).to(points.device, torch.float32).contiguous()
+    if e0.bb_sides is not None:
+        points = points * _inv_half_sides(e0)
+        points = (points + 1) / 2
+    extra = e0.encoder.pos_dim if e0.concat_points else 0
+    inner = tuple(e.encoder for e in encs)
+    ctx = ManualCtx()
+    enc = _PermutoEncodeGrouped.forward(ctx, points.float(), tuple(int(n) for n in sizes), window, extra, inner,
+                                        *[e.lattice_values for e in inner])
+    drop = bool(e0.remove_last_element)
+
+    def backward(g_enc):
+        if drop:
+            g_enc = torch.nn.functional.pad(g_enc, (0, 1))
+        grads = _PermutoEncodeGrouped.backward(ctx, g_enc)[5:]
+        for e, g in zip(inner, grads):          # (None when the kernel added straight into .grad)
+            if g is not None:
+                e.lattice_values.grad = g if e.lattice_values.grad is None else e.lattice_values.grad + g
+    return (enc[:, :-1] if drop else enc), backward
+
+
 class PermutoEncoding(torch.nn.Module):
     """`permutohedral_encoding.PermutoEncoding(pos_dim, capacity, nr_levels, nr_feat_per_level,
     scale_list, appply_random_shift_per_level=, concat_points=, concat_points_scaling=)` shaped

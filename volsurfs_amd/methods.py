@@ -267,6 +267,7 @@ class VolSurfs(torch.nn.Module):
             self.optimizer.gather_masters()      # sharded Adam: fp32 masters are per-slice until gathered
 
     legacy_grouped = True     # class-wide switch: False = the per-shell loop (tests compare the two)
+    legacy_fused_step = __import__("os").environ.get("VSA_LEGACY_FUSED_STEP", "1") != "0"   # trainer: no autograd at all
     legacy_fused_glue = __import__("os").environ.get("VSA_LEGACY_FUSED_GLUE", "1") != "0"   # grouped path: hit preparation,
     # sigmoid / decay / scatter and (forward()) composite + L1 as one launch each instead of torch expressions
 
@@ -288,7 +289,7 @@ class VolSurfs(torch.nn.Module):
                 return False
         return True
 
-    def _shade_legacy_grouped(self, rays_o, rays_d, hit_t, hit_slot, iter_nr, ahead=None):
+    def _shade_legacy_grouped(self, rays_o, rays_d, hit_t, hit_slot, iter_nr, ahead=None, tape=None):
         """The same arithmetic as the per-shell loop with the hits of ALL shells prepared at once and
         each model type evaluated as one grouped op (models._FusedMLPGrouped): ~80 torch ops per
         call instead of ~350 — the legacy training loop is bound by the host's op dispatch."""
@@ -340,6 +341,21 @@ class VolSurfs(torch.nn.Module):
                 mods, sizes = [self.models[typ]], [M - a0]
             m0 = mods[0]
             pos_encs = [mod.pos_encoder for mod in mods]
+            if tape is not None:
+                # the autograd-free step (fused_legacy_forward): the same grouped launches called directly, their
+                # backward closures kept on the tape
+                from .encodings import permuto_hash_encode_grouped_manual
+                from .models import fused_mlp_grouped_manual
+                enc, enc_bwd = permuto_hash_encode_grouped_manual(pos_encs, pts[a0:], sizes, iter_nr=iter_nr)
+                parts = [enc]
+                if m0.view_dep:
+                    parts.append(m0.dir_encoder(d[a0:], iter_nr=iter_nr))
+                if m0.normal_dep:
+                    parts.append(nrm[a0:])
+                y, mlp_bwd = fused_mlp_grouped_manual([mod.mlp for mod in mods], torch.cat(parts, 1), sizes)
+                n_enc = enc.shape[1]
+                tape[typ] = lambda gy: enc_bwd(mlp_bwd(gy)[:, :n_enc])
+                return y
             if VolSurfs.legacy_grouped_encode and len(mods) > 1 and permuto_hash_encoders_groupable(pos_encs, pts):
                 # one autograd node for all shells' position encodings (encodings._PermutoEncodeGrouped)
                 parts = [permuto_hash_encode_grouped(pos_encs, pts[a0:], sizes, iter_nr=iter_nr)]
@@ -363,6 +379,13 @@ class VolSurfs(torch.nn.Module):
         if fused_glue:
             y_rgb = evaluate("rgb", self.colors_indep, 0)
             y_alpha = evaluate("alpha", self.alphas_indep, first) if has_alpha else None
+            if tape is not None:
+                from .encodings import ManualCtx
+                ctx = ManualCtx()
+                out = _LegacyShadeOut.forward(ctx, y_rgb, y_alpha, shell_of, ray_of, d, nrm, N, K, begin[first],
+                                              bool(self.with_alpha_decay))
+                tape["out"] = lambda g_rgb, g_alpha: _LegacyShadeOut.backward(ctx, g_rgb, g_alpha, None)[:2]
+                return out
             return _LegacyShadeOut.apply(y_rgb, y_alpha, shell_of, ray_of, d, nrm, N, K, begin[first],
                                          bool(self.with_alpha_decay))
         surfs_rgb, surfs_alpha, surfs_normals = dense_zeros()
@@ -383,11 +406,62 @@ class VolSurfs(torch.nn.Module):
         surfs_normals = surfs_normals.index_put((ray_of, shell_of), nrm)
         return surfs_rgb, surfs_alpha, surfs_normals
 
-    def _shade_legacy(self, rays_o, rays_d, hit_t, hit_slot, iter_nr, ahead=None):
+    def supports_fused_legacy_step(self, rays_o, gt_mask=None, is_training_masked=False):
+        """The legacy branch's training step without autograd (fused_legacy_forward / _backward): the configuration
+        the grouped launches cover (BASELINE configs[2]), constant background, unmasked L1, every model's encoder a
+        groupable permutohedral one."""
+        if (self.using_neural_textures or not (VolSurfs.legacy_fused_glue and VolSurfs.legacy_grouped
+                                               and VolSurfs.legacy_grouped_encode and VolSurfs.legacy_fused_step)
+                or self.bg_color is None or (is_training_masked and gt_mask is not None)
+                or rays_o.shape[0] > self.max_rays or not self._legacy_groupable(rays_o)):
+            return False
+        from .encodings import permuto_hash_encoders_groupable
+        for typ, indep in (("rgb", self.colors_indep), ("alpha", self.alphas_indep)):
+            mods = [m for k, m in self.models.items() if k.split("_")[0] == typ]
+            if mods and not permuto_hash_encoders_groupable([m.pos_encoder for m in mods], rays_o):
+                return False
+        return True
+
+    @torch.no_grad()
+    def fused_legacy_forward(self, rays_o, rays_d, gt_rgb, iter_nr=0, ahead=None, loss_weight=1.0, is_first_iter=False):
+        """Forward pass + loss of the legacy training step with every launch called directly (no autograd graph):
+        traversal (or the look-ahead context), hit preparation, grouped encoders / MLPs, sigmoid-decay-scatter,
+        composite + L1 (which already leaves the gradients w.r.t. the dense colour / alpha arrays, scaled by
+        loss_weight).  Returns (loss [] = the unweighted mean, state for fused_legacy_backward)."""
+        from .composite import composite_fwd_bwd_l1_raw, l1_mean
+        self._warmup_scheduler(is_first_iter)
+        rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
+        if ahead is not None and (ahead.rays_o.data_ptr() != rays_o.data_ptr() or ahead.rays_o.shape != rays_o.shape):
+            ahead = None
+        if ahead is not None:
+            hit_t, hit_slot = ahead.hit_t, ahead.hit_slot
+        else:
+            hit_t, hit_slot, _ = self.raytracer.trace_all(rays_o, rays_d)
+        tape = {}
+        rgb_k, alpha_k, _ = self._shade_legacy(rays_o, rays_d, hit_t, hit_slot, iter_nr, ahead, tape=tape)
+        if ahead is not None:
+            self.last_nr_hits = int(sum(ahead.counts()))
+        N = rays_o.shape[0]
+        rgb, g_c, g_a = composite_fwd_bwd_l1_raw(rgb_k, alpha_k, self.bg_color, gt_rgb.contiguous(),
+                                                 float(loss_weight) / (3.0 * N))
+        return l1_mean(rgb, gt_rgb), (tape, g_c, g_a)
+
+    @torch.no_grad()
+    def fused_legacy_backward(self, state):
+        """Backward pass of fused_legacy_forward: the gradients are added into the parameters' .grad buffers."""
+        tape, g_c, g_a = state
+        if "out" not in tape:            # no ray hit anything
+            return
+        dy_rgb, dy_alpha = tape["out"](g_c, g_a)
+        tape["rgb"](dy_rgb)
+        if "alpha" in tape and dy_alpha is not None:
+            tape["alpha"](dy_alpha)
+
+    def _shade_legacy(self, rays_o, rays_d, hit_t, hit_slot, iter_nr, ahead=None, tape=None):
         """volsurfs.py:486-599, legacy branch: per shell, the hit points / view directions /
         face normals go through that shell's RGB (or ColorSH) models; alpha decay; dense scatter."""
         if VolSurfs.legacy_grouped and self._legacy_groupable(rays_o):
-            return self._shade_legacy_grouped(rays_o, rays_d, hit_t, hit_slot, iter_nr, ahead)
+            return self._shade_legacy_grouped(rays_o, rays_d, hit_t, hit_slot, iter_nr, ahead, tape)
         N, K = rays_o.shape[0], self.nr_meshes
         dev = rays_o.device
         surfs_rgb = torch.zeros(N, K, 3, device=dev)

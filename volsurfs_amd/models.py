@@ -338,6 +338,31 @@ def fused_mlp_grouped(mlps, x, sizes):
     return _FusedMLPGrouped.apply(x, tuple(int(n) for n in sizes), has_bias, nl, *params)
 
 
+def fused_mlp_grouped_manual(mlps, x, sizes):
+    """fused_mlp_grouped without autograd (encodings.ManualCtx): returns (y, backward) where backward(gy) returns dx
+    and adds the weight / bias gradients into the parameters' .grad buffers."""
+    from .encodings import ManualCtx
+    first = [m for m in mlps[0].layers if isinstance(m, torch.nn.Linear)]
+    nl, has_bias = len(first), bool(mlps[0].bias)
+    params = []
+    for mlp in mlps:
+        for m in (l for l in mlp.layers if isinstance(l, torch.nn.Linear)):
+            params.append(m.weight)
+            if has_bias:
+                params.append(m.bias)
+    _CALL["grad"] = True
+    ctx = ManualCtx()
+    y = _FusedMLPGrouped.forward(ctx, x, tuple(int(n) for n in sizes), has_bias, nl, *params)
+
+    def backward(gy):
+        out = _FusedMLPGrouped.backward(ctx, gy)
+        for p_, g in zip(params, out[4:]):      # (None when the kernel added straight into .grad)
+            if g is not None:
+                p_.grad = g if p_.grad is None else p_.grad + g
+        return out[0]
+    return y, backward
+
+
 def mlps_groupable(mlps, x):
     """All MLPs share one architecture the fused kernel covers."""
     def sig(m):

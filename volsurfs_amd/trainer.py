@@ -102,6 +102,25 @@ def train_step(method, rays_o, rays_d, gt_rgb, gt_mask=None, iter_nr=0, is_first
             pool[ci].post(nr_hits)
             counts.append(pool[ci])
             l = {"loss": loss, "rgb": loss}
+        elif (fused and len(bounds) == 1 and hasattr(method, "supports_fused_legacy_step")
+              and (ahead is not None or not target_nr_of_training_samples)
+              and method.supports_fused_legacy_step(rays_o, gt_mask, is_training_masked)):
+            # the legacy branch without autograd (methods.VolSurfs.fused_legacy_forward / _backward): forward and
+            # loss, then — where the autograd path does it too — the NEXT batch's traversal, then backward
+            loss, state = method.fused_legacy_forward(rays_o, rays_d, gt_rgb, iter_nr=iter_nr, ahead=ahead,
+                                                      loss_weight=w * share, is_first_iter=is_first_iter)
+            if ahead is not None:
+                nr_samples += int(getattr(method, "last_nr_hits", 0))
+            if prefetch is not None:
+                nxt = nr_rays
+                if nr_rays is not None and target_nr_of_training_samples and nr_samples:
+                    nxt = dynamic_nr_rays(nr_rays, nr_samples, target_nr_of_training_samples)
+                prefetch(nxt)
+            opt = getattr(method, "optimizer", None)
+            if hasattr(opt, "mark_grads_dirty"):
+                opt.mark_grads_dirty()
+            method.fused_legacy_backward(state)
+            l = {"loss": loss, "rgb": loss}
         else:
             single = len(bounds) == 1
             extra = {"ahead": ahead} if (ahead is not None and single) else {}
