@@ -434,9 +434,10 @@ class VolSurfs(torch.nn.Module):
         if ahead is not None and (ahead.rays_o.data_ptr() != rays_o.data_ptr() or ahead.rays_o.shape != rays_o.shape):
             ahead = None
         if ahead is not None:
+            ahead.join()
             hit_t, hit_slot = ahead.hit_t, ahead.hit_slot
         else:
-            hit_t, hit_slot, _ = self.raytracer.trace_all(rays_o, rays_d)
+            hit_t, hit_slot, _ = self._trace_now(rays_o, rays_d)
         tape = {}
         rgb_k, alpha_k, _ = self._shade_legacy(rays_o, rays_d, hit_t, hit_slot, iter_nr, ahead, tape=tape)
         if ahead is not None:
@@ -504,6 +505,7 @@ class VolSurfs(torch.nn.Module):
 
     legacy_grouped_encode = __import__("os").environ.get("VSA_GROUPED_ENCODE", "1") != "0"   # A/B switch
     look_ahead = True      # trainer.train_step_from_reel queues the next batch's traversal a step ahead (legacy models)
+    look_ahead_stream = __import__("os").environ.get("VSA_LOOK_AHEAD_STREAM", "1") != "0"   # ... on a side stream
 
     class _TraceAhead:
         """The traversal and hit compaction of a batch, queued ahead of time (trace_ahead)."""
@@ -515,8 +517,20 @@ class VolSurfs(torch.nn.Module):
             self._host = torch.zeros(counts_dev.shape[0], dtype=torch.int64).pin_memory()
             self._host.copy_(counts_dev, non_blocking=True)
             self._event = torch.cuda.Event()
-            self._event.record()
+            self._event.record()                            # (on the stream the context was built on)
             self._counts = None
+            self._joined = False
+
+        def join(self):
+            """Built on a side stream (trace_ahead with look_ahead_stream): the consumer's stream waits for it once,
+            and the allocator is told that the context's arrays are now in use there."""
+            if self._joined:
+                return
+            self._joined = True
+            cur = torch.cuda.current_stream()
+            cur.wait_event(self._event)
+            for t in (self.hit_t, self.hit_slot, self.hit_uv, self.idx):
+                t.record_stream(cur)
 
         def counts(self):
             """Hits per shell as Python ints: waits for the traversal only, not for whatever was
@@ -525,6 +539,14 @@ class VolSurfs(torch.nn.Module):
                 self._event.synchronize()
                 self._counts = self._host.tolist()
             return self._counts
+
+    def _trace_now(self, rays_o, rays_d):
+        """The traversal on the current stream — behind whatever look-ahead traversal is still in flight on the side
+        stream: the tracer's launch-order feedback buffer belongs to one launch at a time."""
+        side = getattr(self, "_ahead_stream", None)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        return self.raytracer.trace_all(rays_o, rays_d)
 
     def trace_ahead(self, rays_o, rays_d):
         """Queue the traversal of a batch and the compaction of its hits NOW and read the hit
@@ -537,10 +559,26 @@ class VolSurfs(torch.nn.Module):
         no parameter, so the order does not matter).  No sync in here: `nonzero_static` over the
         whole [K, N] mask, padded."""
         rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
-        hit = self.raytracer.trace_all(rays_o, rays_d)
-        mask = hit[1] >= 0
-        idx = torch.nonzero_static(mask, size=mask.numel(), fill_value=0)
-        return VolSurfs._TraceAhead(rays_o, rays_d, hit, idx, mask.sum(1))
+        if not VolSurfs.look_ahead_stream:
+            hit = self.raytracer.trace_all(rays_o, rays_d)
+            mask = hit[1] >= 0
+            idx = torch.nonzero_static(mask, size=mask.numel(), fill_value=0)
+            ctx = VolSurfs._TraceAhead(rays_o, rays_d, hit, idx, mask.sum(1))
+            ctx._joined = True
+            return ctx
+        # on a side stream: the traversal of a training batch is one long latency chain on a nearly empty chip
+        # (profiles/NOTEBOOK.md round 5) — beside this batch's backward pass it costs the step nothing
+        side = getattr(self, "_ahead_stream", None)
+        if side is None:
+            side = self._ahead_stream = torch.cuda.Stream(device=rays_o.device)
+        ready = torch.cuda.Event()
+        ready.record()                                      # the rays were written on the current stream
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            hit = self.raytracer.trace_all(rays_o, rays_d)
+            mask = hit[1] >= 0
+            idx = torch.nonzero_static(mask, size=mask.numel(), fill_value=0)
+            return VolSurfs._TraceAhead(rays_o, rays_d, hit, idx, mask.sum(1))
 
     def render_rays(self, rays_o, rays_d, iter_nr=None, return_samples=True, ahead=None, **kwargs):
         """volsurfs.py:423-761: returns {"renders": {"ray_traced": {...}}, "samples_3d",
@@ -555,9 +593,10 @@ class VolSurfs(torch.nn.Module):
         if ahead is not None and (ahead.rays_o.data_ptr() != rays_o.data_ptr() or ahead.rays_o.shape != rays_o.shape):
             ahead = None                                                       # not this batch's: trace now
         if ahead is not None:
+            ahead.join()
             hit_t, hit_slot, hit_uv = ahead.hit_t, ahead.hit_slot, ahead.hit_uv
         else:
-            hit_t, hit_slot, hit_uv = self.raytracer.trace_all(rays_o, rays_d)     # :476-485, one launch
+            hit_t, hit_slot, hit_uv = self._trace_now(rays_o, rays_d)              # :476-485, one launch
         if prof is not None:
             prof.end("meshes_raytracing")
             prof.start("ray_color_inference")
@@ -632,7 +671,7 @@ class VolSurfs(torch.nn.Module):
         outs = []
         for a in range(0, rays_o.shape[0], chunk):
             o, d = rays_o[a:a + chunk].contiguous(), rays_d[a:a + chunk].contiguous()
-            hit_t, hit_slot, hit_uv = self.raytracer.trace_all(o, d)
+            hit_t, hit_slot, hit_uv = self._trace_now(o, d)
             tex_uv = self.baked.tex_uv_only(hit_slot, hit_uv, self.face_uvs)
             rgb_k, alpha_k, normals, _ = self.baked.shade(hit_slot, tex_uv, d, self.raytracer.tris,
                                                           want_normals=True)
@@ -678,7 +717,7 @@ class VolSurfs(torch.nn.Module):
             opt.mark_grads_dirty()
         bank.frame_generation = getattr(bank, "frame_generation", 0) + 1
         rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
-        hit_t, hit_slot, hit_uv = self.raytracer.trace_all(rays_o, rays_d)
+        hit_t, hit_slot, hit_uv = self._trace_now(rays_o, rays_d)
         nr_hits = count_hits(hit_slot)               # one launch (the torch expression: compare, cast, fill, reduce)
         tex_uv = bank.mark_and_compact(hit_slot, hit_uv, self.face_uvs)
         bank.evaluate()
@@ -713,9 +752,10 @@ class VolSurfs(torch.nn.Module):
             if ahead is not None and (ahead.rays_o.data_ptr() != rays_o.data_ptr() or ahead.rays_o.shape != rays_o.shape):
                 ahead = None
             if ahead is not None:
+                ahead.join()
                 hit_t, hit_slot = ahead.hit_t, ahead.hit_slot
             else:
-                hit_t, hit_slot, _ = self.raytracer.trace_all(rays_o, rays_d)
+                hit_t, hit_slot, _ = self._trace_now(rays_o, rays_d)
             rgb_k, alpha_k, _ = self._shade_legacy(rays_o, rays_d, hit_t, hit_slot, iter_nr, ahead)
             if ahead is not None:
                 self.last_nr_hits = int(sum(ahead.counts()))
