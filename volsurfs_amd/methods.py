@@ -268,6 +268,7 @@ class VolSurfs(torch.nn.Module):
 
     legacy_grouped = True     # class-wide switch: False = the per-shell loop (tests compare the two)
     legacy_fused_step = __import__("os").environ.get("VSA_LEGACY_FUSED_STEP", "1") != "0"   # trainer: no autograd at all
+    legacy_two_streams = __import__("os").environ.get("VSA_LEGACY_TWO_STREAMS", "1") != "0"  # ... colour / alpha chains side by side
     legacy_fused_glue = __import__("os").environ.get("VSA_LEGACY_FUSED_GLUE", "1") != "0"   # grouped path: hit preparation,
     # sigmoid / decay / scatter and (forward()) composite + L1 as one launch each instead of torch expressions
 
@@ -377,8 +378,25 @@ class VolSurfs(torch.nn.Module):
         first = 1 if self.solid_inner else 0
         has_alpha = any(k.split("_")[0] == "alpha" for k in self.models)
         if fused_glue:
-            y_rgb = evaluate("rgb", self.colors_indep, 0)
-            y_alpha = evaluate("alpha", self.alphas_indep, first) if has_alpha else None
+            two = tape is not None and has_alpha and VolSurfs.legacy_two_streams
+            if two:
+                # the colour and the alpha models are independent chains of small launches (49 k rows in ten groups
+                # fill the chip only in part): the alpha chain on a side stream beside the colour chain
+                side = getattr(self, "_alpha_stream", None)
+                if side is None:
+                    side = self._alpha_stream = torch.cuda.Stream(device=dev)
+                main = torch.cuda.current_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    y_alpha = evaluate("alpha", self.alphas_indep, first)
+                y_rgb = evaluate("rgb", self.colors_indep, 0)
+                main.wait_stream(side)
+                if y_alpha is not None:
+                    y_alpha.record_stream(main)
+                tape["side"] = side
+            else:
+                y_rgb = evaluate("rgb", self.colors_indep, 0)
+                y_alpha = evaluate("alpha", self.alphas_indep, first) if has_alpha else None
             if tape is not None:
                 from .encodings import ManualCtx
                 ctx = ManualCtx()
@@ -454,6 +472,16 @@ class VolSurfs(torch.nn.Module):
         if "out" not in tape:            # no ray hit anything
             return
         dy_rgb, dy_alpha = tape["out"](g_c, g_a)
+        side = tape.get("side")
+        if side is not None and "alpha" in tape and dy_alpha is not None:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            dy_alpha.record_stream(side)
+            with torch.cuda.stream(side):
+                tape["alpha"](dy_alpha)
+            tape["rgb"](dy_rgb)
+            main.wait_stream(side)
+            return
         tape["rgb"](dy_rgb)
         if "alpha" in tape and dy_alpha is not None:
             tape["alpha"](dy_alpha)
