@@ -266,12 +266,24 @@ typedef struct vsa_nt_plan {
                                         using_sh_squeezing = 1; neural_texture.py:159-164, 183-187) — `texels` is then an
                                         f16 array with the SAME quad layout (a quad = 4 halves = 8 bytes); forward
                                         kernels only differ, the backward is the quantised one's (round is a
-                                        straight-through estimator).  vsa_nt_encode_mlp_fwd supports format 0 only */
+                                        straight-through estimator);
+                                        2: f16 rows holding the RAW network output (using_sh_squeezing = 0: no sigmoid, no
+                                        quantiser, no expansion to val_range; neural_texture.py:157-169, 181-187) — layout as
+                                        format 1; the backward passes the row gradient through unchanged (no sigmoid', no span).
+                                        vsa_nt_encode_mlp_fwd supports format 0 only */
   int32_t grads_zeroed;              /* 1: the caller vouches that grad_tables is ALL ZERO on entry to vsa_nt_encode_bwd /
                                         _range / _phased (it cleared the buffer, or the fused Adam step did, and nothing
                                         has been accumulated since): a table plane whose slots ONE workgroup walks is then
                                         written with plain stores instead of float atomics (same values: 0 + v).  0: the
                                         launch accumulates into whatever the buffer holds */
+  int32_t shared_rgb;                /* 1: are_volsurfs_colors_indep = 0 (methods/volsurfs.py:159-165, 524-527): ONE colour model
+                                        `models["rgb"]` for all shells — every shell's colour textures read the parameters of
+                                        texture (0*2 + 0)*4 + degree and the gradients of all K shells accumulate there.  Slots,
+                                        feature planes and texel rows stay per (shell, degree): only the PARAMETER index maps */
+  int32_t shared_alpha;              /* 1: are_volsurfs_alphas_indep = 0 (volsurfs.py:200-206, 553-556): the same for the alpha
+                                        model (parameters of texture (0*2 + 1)*4 + degree).  With inner_solid the reference's
+                                        loop stores models["alpha"] = None and leaves: NO shell has an alpha model (alpha = 1,
+                                        no decay, on every shell) */
 } vsa_nt_plan;
 
 /* Measured-time rebalancing of the persistent kernels' work split (profiles/NOTEBOOK.md A9.0): once per frame,
@@ -517,12 +529,18 @@ int vsa_field_head_bwd(const float* y1, const float* dx2, const float* d_density
  *   vsa_mlp_workspace: sizes (floats) of packed_ws (weights in MFMA fragment order, rewritten by
  *     every call), of each of z_ws / a_ws / dz_ws (nr_points x sum of hidden widths) and of
  *     partial_ws (per-workgroup weight-gradient blocks).
- *   vsa_mlp_fwd: y [nr_points][y_stride] = MLP(x [nr_points][x_stride]); z_ws / a_ws receive the
- *     hidden pre-activations and activations GELU(z) (both, or NULL for both: inference).
- *   vsa_mlp_bwd: from dy = dL/dy and the z_ws / a_ws of the matching forward: dx (optional), and
+ *   vsa_mlp_fwd: y [nr_points][y_stride] = MLP(x [nr_points][x_stride]); z_ws receives the hidden
+ *     pre-activations (NULL: inference), a_ws the activations GELU(z) when the backward of this network is
+ *     the two-kernel one (vsa_mlp_bwd_needs_act() == 1; otherwise pass NULL: nothing is stored).
+ *   vsa_mlp_bwd: from dy = dL/dy and the z_ws (/ a_ws) of the matching forward: dx (optional), and
  *     grads->dw[l] / db[l] (NULL entries are skipped): overwritten, or added to what the buffers
  *     hold when grads->accumulate != 0 (a caller that owns persistent .grad buffers lets the
- *     kernel add into them instead of running one accumulation kernel per parameter). */
+ *     kernel add into them instead of running one accumulation kernel per parameter).
+ *     Networks up to 96 wide whose weights fit the LDS (NerfHash's two, models/nerfhash.py:44-56) take ONE fused
+ *     persistent launch — data gradients, weight gradients and bias sums from z alone (GELU and GELU' from one
+ *     evaluation), nothing but dx written per sample (csrc/mlp_f32_fused.h): a_ws and dz_ws are then not read and
+ *     may be NULL.  Wider networks (RGB / ColorSH: 128) run mlp_dgrad + mlp_wgrad as before.
+ *   vsa_mlp_bwd_needs_act: 1 if vsa_mlp_bwd of this plan reads a_ws / dz_ws, 0 if not, < 0: VSA_ERR_*. */
 #define VSA_MLP_MAX_LAYERS 6
 typedef struct vsa_mlp_plan {
   int32_t n_layers;
@@ -538,6 +556,7 @@ typedef struct vsa_mlp_grads {
 
 int vsa_mlp_workspace(const vsa_mlp_plan* plan, long long nr_points, long long* packed_floats,
                       long long* act_floats, long long* partial_floats);
+int vsa_mlp_bwd_needs_act(const vsa_mlp_plan* plan);
 int vsa_mlp_fwd(const vsa_mlp_plan* plan, const float* x, int x_stride, int nr_points, float* y,
                 int y_stride, float* z_ws, float* a_ws, float* packed_ws, void* stream);
 int vsa_mlp_bwd(const vsa_mlp_plan* plan, const float* x, int x_stride, int nr_points,

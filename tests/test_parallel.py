@@ -213,7 +213,6 @@ def _hip_rank(rank, world, port, res, q):
     # device publishes it (the step itself: one graph replay, as bench.py --gpus N times it)
     ostep = OverlappedStep(pipe, world)
     pipe.capture_graph(dp=ostep.signals)
-    ostep.signals.epoch_host += 2
     rgb = ostep.run(pipe.replay)
     torch.cuda.synchronize()
     frame = gather_rows = None
@@ -468,7 +467,6 @@ def _rccl_one_rank(port, q):
     direct = OverlappedStep(pipe, 1, force=True)
     out["direct_default"] = direct.rccl is not None
     pipe.capture_graph_split(dp=direct.signals)
-    direct.signals.epoch_host += 2
     for _ in range(3):
         rgb_d = direct.run_split(pipe.replay_prefix, pipe.replay_mid, pipe.replay_tail)
     direct.finish()
@@ -486,13 +484,22 @@ def _rccl_one_rank(port, q):
         reduce_async(t)                        #   behind the device flag: the FINAL gradient) ...
     ostep.overlap.reduce_async = spy
     pipe.capture_graph(dp=ostep.signals)       # the data-parallel step replays as ONE graph
-    ostep.signals.epoch_host += 2
-    for _ in range(2):
+    # EVERY replay, the first included (an event left behind by the capture's eager warm-ups released the
+    # first replay's weights.grad all-reduce before the replayed MLP backward).  The gradient buffers are poisoned
+    # before each replay: a collective released early is handed the poison, not the final gradient.
+    ident = []
+    for _ in range(3):
         snaps.clear()
+        torch.cuda.synchronize()
+        pipe.bank.weights.grad.fill_(7.0)
+        pipe.bank.tables.grad.fill_(7.0)
+        torch.cuda.synchronize()
         rgb = ostep.run(pipe.replay)
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        ident.append(all(bool(torch.equal(t, c)) for t, c in snaps) and
+                     float(pipe.bank.weights.grad.abs().max()) < 7.0)
     out["forward_equal"] = bool(torch.equal(rgb, ref_rgb))
-    out["allreduce_identity"] = all(bool(torch.equal(t, c)) for t, c in snaps)    # ... is what comes back (sum over one rank)
+    out["allreduce_identity"] = all(ident)    # ... is what comes back (sum over one rank)
     out["slices_reduced"] = len(snaps)
     out["grad_nonzero"] = float(pipe.bank.tables.grad.abs().max()) > 0
     # (2) sharded Adam: reduce_scatter_tensor -> vsa_adam_step on the slice -> all_gather_into_tensor

@@ -10,7 +10,7 @@ pipe = KShellPipeline.synthetic(K=5, subdiv=6, res=800, device="cuda", seed=42)
 for _ in range(3):
     pipe.step()
 sg = StepSignals(5, "cuda", wait_mode=int(os.environ.get("DPW", "0")))
-pipe.capture_graph_split(dp=sg); sg.epoch_host += 2
+pipe.capture_graph_split(dp=sg)
 cands = [torch.cuda.Stream() for _ in range(10)] + [torch.cuda.Stream(priority=-1) for _ in range(4)]
 
 def timed(fn, steps=30):
@@ -21,7 +21,7 @@ def timed(fn, steps=30):
 
 def make(side):
     def step():
-        pipe.replay_prefix(); pipe.replay_rest(); sg.epoch_host += 1
+        pipe.replay_prefix(); pipe.replay_rest()
         if side is not None:
             with torch.cuda.stream(side):
                 sg.stream_wait(sg.W, sg.epoch_host); sg.stream_wait(0, sg.epoch_host); sg.stream_wait(1, sg.epoch_host)

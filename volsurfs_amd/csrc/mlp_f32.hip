@@ -23,6 +23,7 @@
 // blocks in registers over their share of the points, partial sums are written per workgroup
 // and added up by mlp_reduce (deterministic, no float atomics).
 #include "common.h"
+#include "gelu_fast.h"
 
 namespace {
 
@@ -190,8 +191,17 @@ __global__ void mlp_pack_kernel(vsa_mlp_plan plan, MlpGroups gp, long long packe
   }
 }
 
-__device__ __forceinline__ float gelu_f(float z) {          // exact GELU (torch.nn.GELU default)
+// exact GELU (torch.nn.GELU default) = z Phi(z); Phi to 6.6e-8 absolute in ~13 instructions (gelu_fast.h; the device
+// library's erff: ~45 — the forward spent as long in its GELUs as in its matrix instructions)
+#ifndef MLP_GELU_ERFF
+#define MLP_GELU_ERFF 0
+#endif
+__device__ __forceinline__ float gelu_f(float z) {
+#if MLP_GELU_ERFF
   return 0.5f * z * (1.0f + erff(z * 0.70710678118654752440f));
+#else
+  return gelu_fast(z);
+#endif
 }
 
 // per-lane bias / saved-activation helpers: lane (p, h) owns rows 32 m + 8 g + 4 h + i of block m
@@ -457,8 +467,13 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_dgrad_kernel(
               float d4[4];
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
+#if MLP_GELU_ERFF
                 const float cdf = 0.5f * (1.0f + erff(zz[i] * 0.70710678118654752440f));
                 const float pdf = 0.39894228040143267794f * __expf(-0.5f * zz[i] * zz[i]);
+#else
+                float cdf, pdf;
+                gelu_cdf_pdf(zz[i], cdf, pdf);
+#endif
                 d4[i] = da[b][4 * g + i] * (cdf + zz[i] * pdf);
                 dz[b][4 * g + i] = d4[i];
               }
@@ -681,6 +696,8 @@ __global__ void mlp_reduce_kernel(vsa_mlp_plan plan, WgradLayers wl, long long p
   }
 }
 
+#include "mlp_f32_fused.h"
+
 int plan_ok(const vsa_mlp_plan* p) {
   if (!p) return VSA_ERR_ARG;
   if (p->n_layers < 1 || p->n_layers > VSA_MLP_MAX_LAYERS) return VSA_ERR_ARG;
@@ -820,7 +837,54 @@ WgradLayers wgrad_layers(const vsa_mlp_plan& p, int total_wgs) {
   return wl;
 }
 
+// The fused backward (mlp_f32_fused.h) serves a network when its transposed weights stay resident in LDS beside the
+// staging rows (<= 160 KiB), its layers are at most 96 wide and its block pairs fit five accumulators per wave.
+// MLP_BWD_FUSED=0 in the environment: the two-kernel backward of rounds 1-5 (A/B switch).
+constexpr size_t MLP_FUSED_LDS_MAX = 160 * 1024 - 512;
+bool bwd_is_fused(const vsa_mlp_plan& p) {
+  static const bool off = [] { const char* e = getenv("MLP_BWD_FUSED"); return e && e[0] == '0'; }();
+  if (off || p.n_layers < 2) return false;
+  const size_t all = (size_t)pack_offsets(p).fwd[p.n_layers] * sizeof(float);
+  for (int l = 1; l < p.n_layers; ++l)
+    if (p.dims[l] > 64) return false;          // hidden layers: two 32-blocks (the z registers of the data waves)
+  return all <= MLP_RESIDENT_BYTES && max_blocks(p) <= 3 && fb_pairs(p) <= 20 && fb_lds_bytes(p) <= MLP_FUSED_LDS_MAX;
+}
+
+// every workgroup holds partial blocks of every layer: layer l's nwg = total (only differences of wg_begin are read)
+WgradLayers fused_layers(const vsa_mlp_plan& p, int total_wgs) {
+  WgradLayers wl;
+  long long off = 0;
+  for (int l = 0; l < p.n_layers; ++l) {
+    wl.wg_begin[l] = l * total_wgs;
+    wl.part_off[l] = off;
+    const long long ip = 32 * blocks_of(p.dims[l]), op = 32 * blocks_of(p.dims[l + 1]);
+    off += (long long)total_wgs * (op * ip + op);
+  }
+  wl.wg_begin[p.n_layers] = p.n_layers * total_wgs;
+  wl.part_off[p.n_layers] = off;
+  return wl;
+}
+
+int set_fused_lds_attrs() {
+  static bool done = false;
+  if (!done) {
+    const int bytes = (int)MLP_FUSED_LDS_MAX;
+    VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_fused_kernel<2, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_fused_kernel<2, 2, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_fused_kernel<3, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    VSA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_fused_kernel<3, 2, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done = true;
+  }
+  return VSA_OK;
+}
+
 }  // namespace
+
+extern "C" int vsa_mlp_bwd_needs_act(const vsa_mlp_plan* plan) {
+  const int rc = plan_ok(plan);
+  if (rc) return rc < 0 ? rc : -rc;
+  return bwd_is_fused(*plan) ? 0 : 1;
+}
 
 extern "C" int vsa_mlp_workspace(const vsa_mlp_plan* plan, long long nr_points,
                                  long long* packed_floats, long long* act_floats,
@@ -836,8 +900,14 @@ extern "C" int vsa_mlp_workspace(const vsa_mlp_plan* plan, long long nr_points,
   int nr_cus = 0;
   rc = vsa_cu_count(&nr_cus);
   if (rc) return rc;
-  if (partial_floats)
-    *partial_floats = wgrad_layers(*plan, wgrad_total_wgs(*plan, nr_points, nr_cus)).part_off[plan->n_layers];
+  if (partial_floats) {
+    long long pf = wgrad_layers(*plan, wgrad_total_wgs(*plan, nr_points, nr_cus)).part_off[plan->n_layers];
+    if (bwd_is_fused(*plan)) {
+      const long long ff = fused_layers(*plan, nr_cus).part_off[plan->n_layers];
+      pf = ff > pf ? ff : pf;
+    }
+    *partial_floats = pf;
+  }
   return VSA_OK;
 }
 
@@ -896,7 +966,7 @@ extern "C" int vsa_mlp_fwd_grouped(const vsa_mlp_plan* plans, int nr_groups, con
   const vsa_mlp_plan* plan = &plans[0];
   if (x_stride < plan->dims[0] || y_stride < plan->dims[plan->n_layers]) return VSA_ERR_ARG;
   if (rows == 0) return VSA_OK;
-  if (!x || !y || !packed_ws || ((z_ws != nullptr) != (a_ws != nullptr))) return VSA_ERR_ARG;
+  if (!x || !y || !packed_ws || (a_ws && !z_ws)) return VSA_ERR_ARG;      // (a_ws: only the two-kernel backward reads it)
   hipStream_t st = (hipStream_t)stream;
   const long long packed_stride = pack_offsets(*plan).fwd[plan->n_layers];
   // (packed_bwd_ws: the transposed fragment order the backward pass needs, written by the same
@@ -941,7 +1011,8 @@ extern "C" int vsa_mlp_bwd_grouped(const vsa_mlp_plan* plans, int nr_groups, con
     return VSA_ERR_ARG;
   if (!grads) return VSA_ERR_ARG;
   if (rows == 0) return VSA_OK;
-  if (!x || !dy || !packed_ws || !partial_ws || (L > 1 && (!z_ws || !dz_ws || !a_ws)))
+  const bool fused = bwd_is_fused(*plan);
+  if (!x || !dy || !packed_ws || !partial_ws || (L > 1 && (!z_ws || (!fused && (!dz_ws || !a_ws)))))
     return VSA_ERR_ARG;
   MlpGroupGrads gg;
   gg.accumulate = grads[0].accumulate;
@@ -968,6 +1039,29 @@ extern "C" int vsa_mlp_bwd_grouped(const vsa_mlp_plan* plans, int nr_groups, con
   const size_t lds = resident ? all : max_layer_bytes(*plan);
   const int ntiles = vsa_div_up(mx, MLP_TILE);
   int grid = vsa_div_up(ntiles, 4);
+  if (fused) {
+    // ONE persistent launch: data gradients, weight gradients and bias sums (mlp_f32_fused.h); one workgroup per CU
+    const int fcap = nr_cus / nr_groups > 0 ? nr_cus / nr_groups : 1;
+    if (grid > fcap) grid = fcap;
+    const WgradLayers wl = fused_layers(*plan, grid);
+    const long long partial_stride = wl.part_off[L];
+    const size_t flds = fb_lds_bytes(*plan);
+    rc = set_fused_lds_attrs();
+    if (rc) return rc;
+    const int nb = max_blocks(*plan), q = (fb_pairs(*plan) + 3) / 4;
+#define VSA_FUSED_LAUNCH(NB_, NH_, Q_)                                                                                  \
+  hipLaunchKernelGGL((mlp_bwd_fused_kernel<NB_, NH_, Q_>), dim3(grid, nr_groups), dim3(FB_BLOCK), flds, st, *plan, wl, gp, \
+                     packed_stride, hidden, partial_stride, fb_rows_dz(*plan), packed_ws, x, x_stride, dy, dy_stride, \
+                     z_ws, dx, dx_stride, partial_ws)
+    if (nb == 2 && q <= 3) VSA_FUSED_LAUNCH(2, 2, 3);
+    else if (nb == 2) VSA_FUSED_LAUNCH(2, 2, 5);
+    else if (q <= 3) VSA_FUSED_LAUNCH(3, 2, 3);
+    else VSA_FUSED_LAUNCH(3, 2, 5);
+#undef VSA_FUSED_LAUNCH
+    hipLaunchKernelGGL(mlp_reduce_kernel, dim3(68, L, nr_groups), dim3(256), 0, st, *plan, wl, partial_stride,
+                       partial_ws, gg);
+    VSA_RETURN_LAUNCH_STATUS();
+  }
   const int cap = vsa_div_up(2 * nr_cus, nr_groups);
   if (grid > cap) grid = cap;
   if (L > 1 || dx)

@@ -80,12 +80,27 @@ __device__ __forceinline__ float2 nt_interp_uv(const float* __restrict__ fuv, fl
   return r;
 }
 
+// Which shells have an alpha model at all (methods/volsurfs.py:167-206): a solid inner mesh has none; with ONE alpha
+// model for all shells (shared_alpha) the reference's loop stores models["alpha"] = None at i = 0 and leaves, so a
+// solid inner mesh then switches the alpha model off on EVERY shell.
+__host__ __device__ inline bool nt_shell_has_alpha(const vsa_nt_plan& p, int shell) {
+  return !(p.inner_solid && (shell == 0 || p.shared_alpha));
+}
+
+// Parameter texture of logical texture `tex`: itself, or shell 0's texture of the same type and degree when the
+// models of that type are shared by all shells (plan.shared_rgb / shared_alpha; volsurfs.py:524-527, 553-556).
+// Slots, feature planes, texel rows and dfeat_abs_sum stay indexed by the LOGICAL texture.
+__device__ __forceinline__ int nt_param_tex(const vsa_nt_plan& p, int tex) {
+  const bool shared = ((tex / VSA_NT_MAX_DEG) & 1) ? p.shared_alpha != 0 : p.shared_rgb != 0;
+  return shared ? tex % (2 * VSA_NT_MAX_DEG) : tex;
+}
+
 __device__ __forceinline__ bool tex_active(const vsa_nt_plan& p, int tex) {
   const int deg = tex % VSA_NT_MAX_DEG;
   const int type = (tex / VSA_NT_MAX_DEG) & 1;
   const int shell = tex / (2 * VSA_NT_MAX_DEG);
   if (type == 0) return deg < p.rgb_degrees;
-  if (p.inner_solid && shell == 0) return false;
+  if (!nt_shell_has_alpha(p, shell)) return false;
   return deg < p.alpha_degrees;
 }
 
@@ -267,12 +282,12 @@ __device__ __forceinline__ void nt_for_each_piece(const vsa_nt_plan& plan,
   const int tex = lane;
   const int deg = tex % VSA_NT_MAX_DEG, type = (tex / VSA_NT_MAX_DEG) & 1, shell = tex / (2 * VSA_NT_MAX_DEG);
   const int rgb_deg = plan.rgb_degrees, alpha_deg = plan.alpha_degrees;
-  const bool solid0 = plan.inner_solid != 0;
+  const bool shell_alpha = nt_shell_has_alpha(plan, shell);
   bool act = tex >= tex_begin && tex < n_tex &&
-             (type == 0 ? deg < rgb_deg : (!(solid0 && shell == 0) && deg < alpha_deg));
+             (type == 0 ? deg < rgb_deg : (shell_alpha && deg < alpha_deg));
   int wtype = type;
   if (paired) {
-    const bool rgb_act = deg < rgb_deg, alpha_act = !(solid0 && shell == 0) && deg < alpha_deg;
+    const bool rgb_act = deg < rgb_deg, alpha_act = shell_alpha && deg < alpha_deg;
     if (type == 1 && rgb_act) act = false;            // rides along with its colour texture
     if (type == 0 && act && alpha_act) wtype = 2;     // a pair
   }

@@ -102,7 +102,7 @@ __device__ __forceinline__ void nt_encode_fwd_body(
       // load, wait, store per trip made staging eight memory latencies long).  Native vectors and
       // an unconditional (clamped) fill: HIP's uint4 struct, or a predicated fill, sends r[] to scratch.
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-      const u32x4* src = reinterpret_cast<const u32x4*>(tables + (long long)t * n_entries + plan.level_offset[level]);
+      const u32x4* src = reinterpret_cast<const u32x4*>(tables + (long long)nt_param_tex(plan, t) * n_entries + plan.level_offset[level]);
       u32x4* dst = reinterpret_cast<u32x4*>(dst_h);
       constexpr int SB = 8;
       const int nvec = (int)(g.size / 4);
@@ -524,7 +524,7 @@ __device__ __forceinline__ void enc_bwd_piece(
 #if NT_ENC_DIAG & 1
   return;
 #endif
-  float* gt = grad_tables + ((long long)tex * n_entries + plan.level_offset[level]) * 2 + feat;
+  float* gt = grad_tables + ((long long)nt_param_tex(plan, tex) * n_entries + plan.level_offset[level]) * 2 + feat;
 #if NT_ENC_FLUSH_BATCH
   // FB entries per thread and trip: their table values are all requested before the first one is
   // waited for.  (One entry at a time — LDS read, test, global load, add, store, with a branch in
@@ -652,10 +652,13 @@ __device__ __forceinline__ void nt_encode_bwd_body(
                             A sole writer adds exactly once per entry, so its result is the same old + v either way */
     const bool single = false;
 #else
-    const bool single = first == seg_begin && last == seg_end;
+    const bool single = first == seg_begin && last == seg_end &&
+                        !((((tex / VSA_NT_MAX_DEG) & 1) ? plan.shared_alpha : plan.shared_rgb) != 0);
 #endif
     // ... unless the caller vouches for a zero gradient buffer: then a sole writer's plane is simply stored
-    const bool store = plan.grads_zeroed != 0 && first == seg_begin && last == seg_end;
+    // (a plane that K shells share — plan.shared_rgb / shared_alpha — has K writers whoever walks the segment)
+    const bool shared_plane = (((tex / VSA_NT_MAX_DEG) & 1) ? plan.shared_alpha : plan.shared_rgb) != 0;
+    const bool store = plan.grads_zeroed != 0 && first == seg_begin && last == seg_end && !shared_plane;
     // neighbouring texels are scale / R cells apart: from one cell per texel on, the
     // in-register merging of same-cell slots cannot fire and its bookkeeping is skipped
     const bool merge = plan.level_scale[level] < (float)plan.tex_res[tex % VSA_NT_MAX_DEG];
@@ -870,6 +873,8 @@ extern "C" int vsa_nt_encode_bwd_range(const vsa_nt_plan* plan, const void* dfea
     return VSA_ERR_ARG;
   if (shell_begin < 0 || shell_end > plan->nr_shells || shell_begin > shell_end) return VSA_ERR_ARG;
   if (shell_begin == shell_end) return VSA_OK;
+  // shared models: every shell writes shell 0's planes, so "the slice of these shells is final" holds for the whole range only
+  if ((plan->shared_rgb || plan->shared_alpha) && !(shell_begin == 0 && shell_end == plan->nr_shells)) return VSA_ERR_UNSUPPORTED;
   const int tex_begin = shell_begin * 2 * VSA_NT_MAX_DEG, tex_end = shell_end * 2 * VSA_NT_MAX_DEG;
   if (!(grad_scale > 0.f)) return VSA_ERR_ARG;
   int rc = check_levels(plan);
@@ -968,6 +973,7 @@ extern "C" int vsa_nt_encode_bwd_phased(const vsa_nt_plan* plan, const void* dfe
       !flags || !counters || !epoch)
     return VSA_ERR_ARG;
   if (n_phases < 1 || n_phases > VSA_MAX_SHELLS || flags->n < n_phases || !(grad_scale > 0.f)) return VSA_ERR_ARG;
+  if ((plan->shared_rgb || plan->shared_alpha) && n_phases != 1) return VSA_ERR_UNSUPPORTED;   // (see vsa_nt_encode_bwd_range)
   EncPhases ph;
   int prev = 0;
   for (int p = 0; p < n_phases; ++p) {       // strictly increasing, the last phase ends at the last shell

@@ -202,10 +202,9 @@ __device__ __forceinline__ void fu_for_each_piece(const vsa_nt_plan& plan,
   const int x = blockIdx.x % n_x, j = blockIdx.x / n_x, J = gridDim.x / n_x;
   const int gw = j * FU_WAVES + wave, GW = J * FU_WAVES;  // this wave among its group's waves
   const int rgb_deg = plan.rgb_degrees, alpha_deg = plan.alpha_degrees;
-  const bool solid0 = plan.inner_solid != 0;
   auto lane_tex = [&](int tex, int& begin, int& end, int& w) {
     const int deg = tex % VSA_NT_MAX_DEG, type = (tex / VSA_NT_MAX_DEG) & 1, shell = tex / (2 * VSA_NT_MAX_DEG);
-    bool act = tex < n_all && (type == 0 ? deg < rgb_deg : (!(solid0 && shell == 0) && deg < alpha_deg));
+    bool act = tex < n_all && (type == 0 ? deg < rgb_deg : (nt_shell_has_alpha(plan, shell) && deg < alpha_deg));
     begin = end = 0;
     if (act) {
       const int sd = shell * VSA_NT_MAX_DEG + deg;
@@ -279,8 +278,9 @@ __global__ __launch_bounds__(FU_BLOCK, FU_WGS_PER_CU) void nt_encmlp_fwd_kernel(
     if (u_first >= u_end) return;
     const TexInfo ti = tex_info(plan, seg_start, tex);
     half8_t wf[16];
-    load_fwd_frags(weights + (long long)tex * VSA_NT_WEIGHTS_PER_TEX, lane, wf);
-    const unsigned* tab = tables + (long long)tex * n_entries;
+    const int ptex = nt_param_tex(plan, tex);      // (shared models: shell 0's parameters)
+    load_fwd_frags(weights + (long long)ptex * VSA_NT_WEIGHTS_PER_TEX, lane, wf);
+    const unsigned* tab = tables + (long long)ptex * n_entries;
     const int pre_base = ti.type == 0 ? 0 : 24;
     unsigned* fplane = nullptr;
     if constexpr (FEAT) fplane = features + nt_feat_plane_base(plan, ti.type, 0);

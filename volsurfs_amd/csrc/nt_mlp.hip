@@ -79,7 +79,7 @@ __global__ __launch_bounds__(MLP_BLOCK, MLP_FWD_WGS_PER_CU) void nt_mlp_fwd_kern
                         [&](int, int tex, int first, int last, int, int) {
     const TexInfo ti = tex_info(plan, seg_start, tex);
     half8_t wf[16];
-    load_fwd_frags(weights + (long long)tex * VSA_NT_WEIGHTS_PER_TEX, lane, wf);
+    load_fwd_frags(weights + (long long)nt_param_tex(plan, tex) * VSA_NT_WEIGHTS_PER_TEX, lane, wf);
     const int pre_base = ti.type == 0 ? 0 : 24;    // pre_out keeps the fixed 32-wide test layout
     const int ntiles = (last - first + 31) >> 5;
     // the tile loop, compiled once per number NG of 8-channel groups of the output (as the
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(MLP_BLOCK, MLP_FWD_WGS_PER_CU) void nt_mlp_fwd_kern
         float16_t acc3;
         mlp_tile_fwd(wf, bx, b2, b3, acc3);
         if constexpr (F16ROWS)
-          half_store_tile<NG, PRE>(acc3, ti, reinterpret_cast<uint2*>(texels), slot, valid, h, pre_out, pre_base);
+          half_store_tile<NG, PRE>(acc3, ti, reinterpret_cast<uint2*>(texels), slot, valid, h, pre_out, pre_base, plan.row_format == 2);
         else
           quant_store_tile<NG, PRE>(acc3, ti, s_qt, texels, slot, valid, h, pre_out, pre_base);
       }
@@ -290,13 +290,14 @@ __device__ __forceinline__ void pc_run(
   asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");
 #endif
   const int tex = wk.tex;
+  const int ptex = nt_param_tex(plan, tex);     // parameters: shell 0's when the models are shared
   const TexInfo ti = tex_info(plan, seg_start, tex);
   const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
   const int wave = threadIdx.x >> 6;
   const bool producer = wave < PC_PAIRS;
   // forward fragments: straight from memory into the producers' registers (load_fwd_frags)
   half8_t wf[16];
-  if (producer) load_fwd_frags(weights + (long long)tex * VSA_NT_WEIGHTS_PER_TEX, lane, wf);
+  if (producer) load_fwd_frags(weights + (long long)ptex * VSA_NT_WEIGHTS_PER_TEX, lane, wf);
   {
     // the transposed fragments 16..35 are gathers with a stride: the texture's 8192 weights come
     // in with 16-byte loads into the (still free) image area and the fragments are gathered from
@@ -304,7 +305,7 @@ __device__ __forceinline__ void pc_run(
     // rounds per thread at the head of every run)
     _Float16* W = s_img_all;
     {
-      const half8_t* Wg = reinterpret_cast<const half8_t*>(weights + (long long)tex * VSA_NT_WEIGHTS_PER_TEX);
+      const half8_t* Wg = reinterpret_cast<const half8_t*>(weights + (long long)ptex * VSA_NT_WEIGHTS_PER_TEX);
       for (int i = threadIdx.x; i < VSA_NT_WEIGHTS_PER_TEX / 8; i += PC_BLOCK)
         reinterpret_cast<half8_t*>(W)[i] = Wg[i];
     }
@@ -496,6 +497,17 @@ __device__ __forceinline__ void pc_run(
           // fused multiply-adds (conversion and fp32 product in one instruction), the last of
           // which rounds straight to the f16 half it is stored in.
           unsigned dq[2 * NG];     // dOut of this lane's point: channel pairs (8g + 4h + {0,1}, {2,3})
+          if (__builtin_expect(plan.row_format == 2, 0)) {
+            // raw rows (using_sh_squeezing = 0): the row IS the network output, dOut = G (wave-uniform branch)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+              typedef unsigned uint2v_ __attribute__((ext_vector_type(2)));
+              const uint2v_ gb = __builtin_bit_cast(uint2v_, gr[g]);
+              const bool keep = row_ok[g] && slot < wk.last;
+              dq[2 * g] = keep ? gb[0] : 0u;
+              dq[2 * g + 1] = keep ? gb[1] : 0u;
+            }
+          } else
 #pragma unroll
           for (int g = 0; g < NG; ++g) {
             typedef unsigned uint2v_ __attribute__((ext_vector_type(2)));
@@ -865,7 +877,7 @@ __device__ __forceinline__ void pc_run(
   __syncthreads();
   {
     const float* s_all = reinterpret_cast<const float*>(s_img_all);
-    float* gw = grad_weights + (long long)tex * VSA_NT_WEIGHTS_PER_TEX;
+    float* gw = grad_weights + (long long)ptex * VSA_NT_WEIGHTS_PER_TEX;   // (atomics: K shells may share it)
     const int w3_end = W3_OFF + ti.channels * 64;
     for (int i = threadIdx.x; i < w3_end; i += PC_BLOCK) {
       float v = s_all[i];
@@ -962,10 +974,10 @@ extern "C" int vsa_nt_mlp_fwd(const vsa_nt_plan* plan, const void* weights_h, co
                               const int32_t* seg_start, uint8_t* texels, void* pre_out,
                               void* stream) {
   if (!plan || !weights_h || !features || !seg_start || !texels) return VSA_ERR_ARG;
-  if (plan->row_format != 0 && plan->row_format != 1) return VSA_ERR_UNSUPPORTED;
+  if (plan->row_format < 0 || plan->row_format > 2) return VSA_ERR_UNSUPPORTED;
   int nr_cus = 0;
   { const int rc = vsa_cu_count(&nr_cus); if (rc) return rc; }
-  if (plan->row_format == 1) {       // f16 rows of sigmoid(x), un-quantised (using_sh_quantization = 0)
+  if (plan->row_format != 0) {       // f16 rows: sigmoid(x) un-quantised (using_sh_quantization = 0), or x itself (using_sh_squeezing = 0)
     if (pre_out)
       hipLaunchKernelGGL((nt_mlp_fwd_kernel<true, true>), dim3(nr_cus * MLP_FWD_WGS_PER_CU), dim3(MLP_BLOCK), 0,
                          (hipStream_t)stream, *plan, reinterpret_cast<const _Float16*>(weights_h),

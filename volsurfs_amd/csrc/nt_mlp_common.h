@@ -58,7 +58,7 @@ __device__ __forceinline__ TexInfo tex_info(const vsa_nt_plan& p, const int* seg
   t.channels = 0;
   if (type == 0) {
     if (deg < p.rgb_degrees) t.channels = 3 * (2 * deg + 1);
-  } else if (!(p.inner_solid && shell == 0) && deg < p.alpha_degrees) {
+  } else if (nt_shell_has_alpha(p, shell) && deg < p.alpha_degrees) {
     t.channels = 2 * deg + 1;
   }
   t.begin = seg_start[shell * VSA_NT_MAX_DEG + deg];
@@ -210,10 +210,11 @@ __device__ __forceinline__ void quant_store_tile(const float16_t& acc3, const Te
 
 // row_format 1: the same tile stored as f16 rows of sigmoid(x), un-quantised (neural_texture.py:159-164 with
 // quantize_output = False): the fp32 sigmoid of the fp16 network output, rounded to half (:177).  A quad = 4 halves.
+// raw (row_format 2, squeeze_output = False, :157-169 skipped): the fp16 network output itself.
 template <int NG, bool PRE>
 __device__ __forceinline__ void half_store_tile(const float16_t& acc3, const TexInfo& ti,
                                                 uint2* __restrict__ texels_h, int slot, bool valid, int h,
-                                                _Float16* __restrict__ pre_out, int pre_base) {
+                                                _Float16* __restrict__ pre_out, int pre_base, bool raw = false) {
   uint2* const trow = texels_h + ti.row_first + (long long)(slot - ti.begin) * ti.row_quads + h;
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
@@ -226,7 +227,7 @@ __device__ __forceinline__ void half_store_tile(const float16_t& acc3, const Tex
         if (valid && row0 + i < ti.channels) pre_out[(long long)slot * 32 + pre_base + row0 + i] = xh;
       }
       const float sg = 1.0f / (1.0f + expf(-(float)xh));          // accurate exp: this path is not the hot one
-      const _Float16 sh = (_Float16)sg;
+      const _Float16 sh = raw ? xh : (_Float16)sg;
       hv[i] = row0 + i < ti.channels ? __builtin_bit_cast(unsigned short, sh) : (unsigned short)0;
     }
     if (valid && row0 < ti.channels)

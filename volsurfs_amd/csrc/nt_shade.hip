@@ -242,10 +242,11 @@ __device__ __forceinline__ void add_corner_row(const vsa_nt_plan& plan, int d, c
       wds[4 * v] = x.x, wds[4 * v + 1] = x.y, wds[4 * v + 2] = x.z, wds[4 * v + 3] = x.w;
     }
     const float lo = plan.sh_lo[d], span = plan.sh_span[d];
+    const bool raw = plan.row_format == 2;     // using_sh_squeezing = 0: the row is the network output, no expansion (:181-187)
     auto expand = [&](int elem) {
       const unsigned short hb = (unsigned short)(wds[elem >> 1] >> (16 * (elem & 1)));
       const float o = (float)__builtin_bit_cast(_Float16, hb);
-      return vsa_round_f16(lo + vsa_round_f16(vsa_pin_f32(span * o)));
+      return raw ? o : vsa_round_f16(lo + vsa_round_f16(vsa_pin_f32(span * o)));
     };
 #pragma unroll
     for (int i = 0; i < 3 * n; ++i) acc[i] = acc[i] + expand(i) * wk;
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(SH_BLOCK, NT_SHADE_FWD_OCC) void nt_shade_fwd_kerne
   float rgb[3] = {0.f, 0.f, 0.f}, alpha = 0.f;
   float4 act = make_float4(0.f, 0.f, 0.f, 0.f);   // the four sigmoids, for the backward pass
   if (load_ctx<FULL4>(plan, s, n, N, hit_slot, tex_uv, rays_d, tris, slot_of, seg_start, c, nrm)) {
-    const bool has_alpha = !(plan.inner_solid && s == 0);
+    const bool has_alpha = nt_shell_has_alpha(plan, s);
     float b[16], raw[4];
     sh_basis(c.dir[0], c.dir[1], c.dir[2], b);
     shade_hit<FULL4, F16ROWS>(plan, c, texels, s_lut, has_alpha, b, raw,
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(SHB_BLOCK, RECOMPUTE ? 2 : NT_SHADE_BWD_OCC) void n
   HitCtx c;
   c.hit = false;
   float nrm[3];
-  const bool has_alpha = !(plan.inner_solid && s == 0);
+  const bool has_alpha = nt_shell_has_alpha(plan, s);
   if (n < N && load_ctx<FULL4>(plan, s, n, N, hit_slot, tex_uv, rays_d, tris, slot_of, seg_start, c, nrm)) {
     float b[16];
     sh_basis(c.dir[0], c.dir[1], c.dir[2], b);
@@ -518,7 +519,7 @@ __global__ __launch_bounds__(SHB_BLOCK, RECOMPUTE ? 2 : NT_SHADE_BWD_OCC) void n
   const int c0 = div_nn(e0), c1 = div_nn(e0 + 1);
   const int ch0 = is_alpha ? 3 : c0, ch1 = is_alpha ? 3 : c1;
   const int m0 = d * d + (is_alpha ? e0 : e0 - c0 * nn), m1 = on1 ? d * d + (is_alpha ? e0 + 1 : e0 + 1 - c1 * nn) : 0;
-  float span = plan.sh_span[d];
+  float span = plan.row_format == 2 ? 1.0f : plan.sh_span[d];     // (raw rows: d row / d output = 1)
   // `d` differs per lane, so this is a VECTOR load from the kernel-argument segment; its first use
   // is inside the hit loop below, and the compiler put the `s_waitcnt vmcnt(0)` for it THERE — where,
   // on every trip, it also waited for every gradient atomic the wave had in flight (no-return
@@ -649,9 +650,9 @@ extern "C" int vsa_nt_shade_fwd(const vsa_nt_plan* plan, const int32_t* hit_slot
   if (!hit_slot || !tex_uv || !rays_d || !tris || !slot_of || !seg_start || !texels || !surfs_rgb ||
       !surfs_alpha)
     return VSA_ERR_ARG;
-  if (plan->row_format != 0 && plan->row_format != 1) return VSA_ERR_UNSUPPORTED;
+  if (plan->row_format < 0 || plan->row_format > 2) return VSA_ERR_UNSUPPORTED;
   dim3 grid = shade_grid(vsa_div_up(nr_rays, SH_BLOCK), plan->nr_shells);
-  if (plan->row_format == 1)          // f16 rows (using_sh_quantization = 0): the generic-band-count kernel
+  if (plan->row_format != 0)          // f16 rows (using_sh_quantization = 0): the generic-band-count kernel
     hipLaunchKernelGGL((nt_shade_fwd_kernel<false, true>), grid, dim3(SH_BLOCK), 0, (hipStream_t)stream, *plan,
                        hit_slot, tex_uv, rays_d, reinterpret_cast<const float4*>(tris), slot_of,
                        seg_start, reinterpret_cast<const unsigned*>(texels), nr_rays, surfs_rgb,
@@ -681,7 +682,7 @@ extern "C" int vsa_nt_shade_bwd(const vsa_nt_plan* plan, const int32_t* hit_slot
       !g_surfs_alpha || !grad_rows)
     return VSA_ERR_ARG;
   if (plan->row_base[VSA_MAX_SHELLS * VSA_NT_MAX_DEG] * 8 >= (1ll << 32)) return VSA_ERR_UNSUPPORTED;   // 32-bit atomic offsets
-  if (plan->row_format != 0 && plan->row_format != 1) return VSA_ERR_UNSUPPORTED;
+  if (plan->row_format < 0 || plan->row_format > 2) return VSA_ERR_UNSUPPORTED;
   dim3 grid = shade_grid(vsa_div_up(nr_rays, SHB_BLOCK), plan->nr_shells);
   const bool full4 = plan->rgb_degrees == VSA_NT_MAX_DEG && plan->alpha_degrees == VSA_NT_MAX_DEG;
   if (act_in && full4)
@@ -696,7 +697,7 @@ extern "C" int vsa_nt_shade_bwd(const vsa_nt_plan* plan, const int32_t* hit_slot
                        seg_start, reinterpret_cast<const unsigned*>(texels), nr_rays, g_surfs_rgb,
                        g_surfs_alpha, grad_scale, reinterpret_cast<_Float16*>(grad_rows),
                        reinterpret_cast<const float4*>(act_in));
-  else if (plan->row_format == 1)     // no kept sigmoids: re-gather the f16 rows
+  else if (plan->row_format != 0)     // no kept sigmoids: re-gather the f16 rows
     hipLaunchKernelGGL((nt_shade_bwd_kernel<true, false, true>), grid, dim3(SHB_BLOCK), 0, (hipStream_t)stream, *plan,
                        hit_slot, tex_uv, rays_d, reinterpret_cast<const float4*>(tris), slot_of,
                        seg_start, reinterpret_cast<const unsigned*>(texels), nr_rays, g_surfs_rgb,

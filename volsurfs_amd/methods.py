@@ -127,8 +127,10 @@ class VolSurfs(torch.nn.Module):
                  using_neural_textures_anchor=False, using_neural_textures_lerp=True,
                  using_sh_quantization=True, using_sh_squeezing=True):
         """using_neural_textures_anchor / _lerp, using_sh_quantization, using_sh_squeezing: the reference's
-        hyper-parameters of the same names (config/volsurfs/base_5.cfg:16-19 -> volsurfs.py:149-153); a
-        combination that is not built (using_sh_squeezing = 0) raises in NeuralTextureBank instead of rendering the default."""
+        hyper-parameters of the same names (config/volsurfs/base_5.cfg:16-19 -> volsurfs.py:149-153); every
+        combination the reference accepts is built, the ones it exits on raise in NeuralTextureBank.
+        are_volsurfs_colors_indep / are_volsurfs_alphas_indep = 0 (volsurfs.py:159-165, 200-206): ONE colour / alpha
+        model for all shells, on both appearance branches (neural textures: NeuralTextureBank(shared_rgb / shared_alpha))."""
         super().__init__()
         self.using_neural_textures = using_neural_textures
         self.with_alpha_decay = with_alpha_decay
@@ -151,7 +153,10 @@ class VolSurfs(torch.nn.Module):
                                           anchor=bool(using_neural_textures_anchor),
                                           lerp=bool(using_neural_textures_lerp),
                                           quantize_output=bool(using_sh_quantization),
-                                          squeeze_output=bool(using_sh_squeezing))
+                                          squeeze_output=bool(using_sh_squeezing),
+                                          shared_rgb=not are_volsurfs_colors_indep,
+                                          shared_alpha=not are_volsurfs_alphas_indep)
+            self.colors_indep, self.alphas_indep = bool(are_volsurfs_colors_indep), bool(are_volsurfs_alphas_indep)
         else:
             # legacy appearance branch (volsurfs.py:208-300): one RGB / ColorSH per shell (or one
             # for all shells), alpha model None for a solid inner mesh
@@ -683,7 +688,8 @@ class VolSurfs(torch.nn.Module):
                                   sh_range=[-float(b.plan.sh_lo[d]) for d in range(4)],
                                   textures_res=b.tex_res, inner_solid=bool(b.plan.inner_solid),
                                   with_alpha_decay=bool(b.plan.with_alpha_decay),
-                                  device=b.tables.device, training=False)
+                                  device=b.tables.device, training=False, anchor=b.anchor, lerp=not b.anchor,
+                                  shared_rgb=b.shared_rgb, shared_alpha=b.shared_alpha)
         baked.tables.copy_(b.tables)
         baked.weights.copy_(b.weights)
         baked.refresh_half_params()
@@ -804,10 +810,13 @@ class VolSurfs(torch.nn.Module):
         out = {}
         if self.bank is not None:
             b = self.bank
-            for i in range(self.nr_meshes):
-                for typ, name in ((0, "rgb"), (1, "alpha")):
+            # the reference's keys (volsurfs.py:159-165, 200-206): rgb_i / alpha_i, or "rgb" / "alpha" for a model
+            # all shells share (its parameters are shell 0's rows of the bank)
+            for typ, name, shared in ((0, "rgb", b.shared_rgb), (1, "alpha", b.shared_alpha)):
+                for i in range(1 if shared else self.nr_meshes):
                     a = b.tex_index(i, typ, 0)
-                    out[f"{name}_{i}"] = (b.tables[a:a + 4], b.weights[a:a + 4])
+                    if any(b.tex_channels(a + d) for d in range(4)):
+                        out[name if shared else f"{name}_{i}"] = (b.tables[a:a + 4], b.weights[a:a + 4])
         return out
 
     def save(self, iter_nr):
@@ -856,8 +865,8 @@ class VolSurfs(torch.nn.Module):
                     st = torch.load(f, map_location=t.device)
                     from .checkpoint import is_reference_state_dict, load_reference_state_dict
                     if is_reference_state_dict(st):      # a checkpoint written by the reference itself
-                        name, i = key.rsplit("_", 1)
-                        load_reference_state_dict(self.bank, int(i), 0 if name == "rgb" else 1, st)
+                        name, _, i = key.partition("_")           # "rgb_3", or "rgb" (one model for all shells)
+                        load_reference_state_dict(self.bank, int(i or 0), 0 if name == "rgb" else 1, st)
                         continue
                     t.copy_(st["tables"])
                     w.copy_(st["weights"])

@@ -107,7 +107,10 @@ class _FusedMLP(torch.autograd.Function):
         dev = x.device
         packed = torch.empty(max(sizes[0].value, 1), device=dev)
         z = torch.empty(max(sizes[1].value, 1), device=dev) if need else None
-        act = torch.empty_like(z) if need else None       # GELU(z): the weight gradients' other operand
+        # GELU(z), the weight gradients' other operand: only the two-kernel backward reads it (the fused backward of
+        # networks up to 96 wide forms it from z: include/volsurfs_hip.h, vsa_mlp_bwd_needs_act)
+        needs_act = need and int(_lib.lib().vsa_mlp_bwd_needs_act(ctypes.byref(plan))) != 0
+        act = torch.empty_like(z) if needs_act else None
         y = torch.empty(M, ws[-1].shape[0], device=dev)
         _lib.call("vsa_mlp_fwd", ctypes.byref(plan), x, x.shape[1], M, y, y.shape[1], z, act, packed,
                   _lib.stream_ptr())
@@ -124,7 +127,7 @@ class _FusedMLP(torch.autograd.Function):
         M, dev = x.shape[0], x.device
         plan = _mlp_plan(ws, bs)
         gy = gy.contiguous()
-        dz = torch.empty(max(act_n, 1), device=dev)
+        dz = torch.empty(max(act_n, 1), device=dev) if act is not None else None
         packed = torch.empty(sum(((w.shape[0] + 31) // 32) * ((w.shape[1] + 31) // 32) * 1024 for w in ws),
                              device=dev)
         partial = torch.empty(max(part_n, 1), device=dev)

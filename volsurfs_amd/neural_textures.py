@@ -51,6 +51,7 @@ class Plan(ctypes.Structure):
         ("row_base", ctypes.c_int64 * (MAX_SHELLS * MAX_DEG + 1)),
         ("balance", ctypes.c_void_p),
         ("row_format", ctypes.c_int32), ("grads_zeroed", ctypes.c_int32),
+        ("shared_rgb", ctypes.c_int32), ("shared_alpha", ctypes.c_int32),
     ]
 
 
@@ -79,12 +80,17 @@ class NeuralTextureBank(torch.nn.Module):
                  sh_range=(15.0, 15.0, 15.0, 15.0), textures_res=(2048, 1024, 512, 256),
                  inner_solid=False, with_alpha_decay=True, device="cuda", seed=42,
                  training=True, anchor=False, lerp=True, quantize_output=True, squeeze_output=True,
-                 grid=None):
+                 grid=None, shared_rgb=False, shared_alpha=False):
         """anchor / lerp / quantize_output / squeeze_output: NeuralTexture's switches
         (models/neural_texture.py:19-52; config keys using_neural_textures_anchor / _lerp,
-        using_sh_quantization, using_sh_squeezing).  Built: lerp (the shipped configs) and anchor, with 8-bit
-        quantised texel rows or (quantize_output=False) f16 rows of the un-quantised sigmoid; the un-squeezed
-        variant is not, and asking for it raises instead of silently rendering the default.
+        using_sh_quantization, using_sh_squeezing).  Built: lerp (the shipped configs) and anchor, each with 8-bit
+        quantised texel rows (row_format 0), f16 rows of the un-quantised sigmoid (quantize_output=False: 1) or
+        f16 rows of the raw network output (squeeze_output=False: 2; neural_texture.py:157-169, 181-187 skipped).
+        shared_rgb / shared_alpha: are_volsurfs_colors_indep = 0 / are_volsurfs_alphas_indep = 0
+        (methods/volsurfs.py:159-165, 200-206, 524-527, 553-556): ONE model for all shells — every shell reads
+        the parameters of shell 0's textures of that type and the K shells' gradients accumulate there (the
+        other shells' rows of `tables` / `weights` are unused and stay zero).  With inner_solid, shared_alpha
+        means NO alpha model at all: the reference's loop stores models["alpha"] = None at i = 0 and leaves.
         grid: keyword arguments of grid_geometry() for a hash grid other than the reference's
         (16 levels always: the MLP reads 32 features); levels of more than 2^15 entries are refused
         by the library (one level = one LDS plane)."""
@@ -93,12 +99,9 @@ class NeuralTextureBank(torch.nn.Module):
             raise ValueError("NeuralTexture is either anchor or lerp (neural_texture.py:47-51, 141-147)")
         if quantize_output and not squeeze_output:
             raise ValueError("quantize_output requires squeeze_output (sh_neural_textures.py:32-36)")
-        if not squeeze_output:
-            raise NotImplementedError(
-                "using_sh_squeezing=0 (raw, un-squeezed texel rows: neural_texture.py:159, 183) is not built; "
-                "no reference config ships it")
-        # 0: 8-bit quantised rows (every shipped config); 1: f16 rows of sigmoid(x), un-quantised
-        self.row_format = 0 if quantize_output else 1
+        # 0: 8-bit quantised rows (every shipped config); 1: f16 rows of sigmoid(x), un-quantised; 2: f16 rows of x
+        self.row_format = 0 if quantize_output else (1 if squeeze_output else 2)
+        self.shared_rgb, self.shared_alpha = bool(shared_rgb), bool(shared_alpha)
         self.anchor = bool(anchor)
         K = nr_shells
         self.K, self.max_rays = K, max_rays
@@ -137,6 +140,7 @@ class NeuralTextureBank(torch.nn.Module):
         p.max_rays = max_rays
         p.anchor = int(self.anchor)
         p.row_format = int(self.row_format)
+        p.shared_rgb, p.shared_alpha = int(self.shared_rgb), int(self.shared_alpha)
         self.plan, self.dom_total, self.slot_capacity = p, off, cap
         self.tex_res = tuple(int(r) for r in textures_res)
 
@@ -147,6 +151,9 @@ class NeuralTextureBank(torch.nn.Module):
         weights = torch.zeros(self.n_tex, WEIGHTS_PER_TEX)
         for x in range(self.n_tex):
             C = self.tex_channels(x)
+            if C and self.param_tex(x) != x:     # (a shell that reads shell 0's shared model owns no parameters)
+                tables[x] = 0
+                continue
             if C == 0:
                 continue
 
@@ -166,9 +173,15 @@ class NeuralTextureBank(torch.nn.Module):
         deg, typ, shell = x % MAX_DEG, (x // MAX_DEG) & 1, x // (2 * MAX_DEG)
         if typ == 0:
             return 3 * (2 * deg + 1) if deg < self.rgb_degrees else 0
-        if self.plan.inner_solid and shell == 0:
+        if self.plan.inner_solid and (shell == 0 or self.shared_alpha):     # nt_shell_has_alpha (csrc/nt_common.h)
             return 0
         return (2 * deg + 1) if deg < self.alpha_degrees else 0
+
+    def param_tex(self, x):
+        """The texture whose rows of `tables` / `weights` (and of their gradients) logical texture x uses:
+        itself, or shell 0's of the same type and degree when that type's model is shared (nt_param_tex)."""
+        typ = (x // MAX_DEG) & 1
+        return x % (2 * MAX_DEG) if (self.shared_alpha if typ else self.shared_rgb) else x
 
     @staticmethod
     def tex_index(shell, typ, deg):
@@ -422,6 +435,7 @@ class NeuralTextureBank(torch.nn.Module):
         has just cleared the gradients), else what zero_grads() left; either way the buffer holds something
         after the launch."""
         z = bool(getattr(self, "_tables_grad_zero", False) if grads_zeroed is None else grads_zeroed)
+        # (shared models: the kernel itself keeps a shared plane's flushes atomic — K shells write it)
         self._tables_grad_zero = False
         self.plan.grads_zeroed = int(z)
 

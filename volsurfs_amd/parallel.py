@@ -138,7 +138,10 @@ class StepSignals:
             raise _lib.VolsurfsHipError(f"vsa_dp_flags_create failed with status {rc}")
         self.words = torch.zeros(n + 1, dtype=torch.int32, device=device)
         self.epoch, self.counters = self.words[:1], self.words[1:]
-        self.epoch_host = 0          # the device epoch after the steps launched so far
+        # the device epoch after the steps launched so far.  Kept in ONE place per kind of launch: signal_weights()
+        # counts an eager step, KShellPipeline.replay* a graph replay (capture passes only record) — callers never
+        # patch it (a missed bump released every all-reduce on the previous step's flag values: ADVICE r5)
+        self.epoch_host = 0
         self.on_weights_final = None   # eager steps call it behind the MLP backward (OverlappedStep: records an event)
         self.wait_mode = int(wait_mode)
         self.phase_end_c = (ctypes.c_int32 * n)(*self.phase_end)
@@ -152,6 +155,8 @@ class StepSignals:
         """Stream-ordered: epoch += 1, weights word = epoch (a one-lane kernel: graph-capturable)."""
         from . import _lib
         _lib.call("vsa_dp_signal", self._flags, self.n, self.epoch, 1, _lib.stream_ptr())
+        if not torch.cuda.is_current_stream_capturing():
+            self.epoch_host += 1
 
     def stream_wait(self, index, value):
         """The CURRENT stream waits until flag word `index` (0..n-1: phases, n: weights) holds `value`."""
@@ -259,10 +264,9 @@ class OverlappedStep:
         a pending event wait costs nothing, and behind it the flag waits are only ever pending beside the
         hash-grid backward itself."""
         sg, bank = self.signals, self.pipe.bank
-        sg.epoch_host += 1
         if not self.active:
             return
-        e = sg.epoch_host
+        e = sg.epoch_host          # (the launch itself counted: StepSignals.signal_weights / KShellPipeline.replay*)
         ev = getattr(self, "_mid_event", None)
         self._mid_event = None
         if self.rccl is not None:
@@ -309,6 +313,10 @@ class OverlappedStep:
     def run(self, launch=None, record=False):
         """launch: a callable that enqueues one step built with dp=self.signals (default: the eager
         step; a graph's replay otherwise).  record: time the eager step's stages and the exposed wait."""
+        if launch is not None:
+            # a graph replay never calls _weights_final: an event a warm-up or an earlier eager step left behind
+            # would release weights.grad's all-reduce before this step's MLP backward (ADVICE r5) -> the flag word
+            self._mid_event = None
         out = launch() if launch is not None else self.eager(record=record)
         self._enqueue_reductions()
         bank = self.pipe.bank

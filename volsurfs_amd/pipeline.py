@@ -58,15 +58,17 @@ class KShellPipeline:
     dtype_desc = "f16 (hash features, MLP on MFMA, composite: as the reference), f32 accumulate and I/O"
 
     def __init__(self, meshes, rays_o, rays_d, gt_rgb, bg_color=(1.0, 1.0, 1.0), seed=42,
-                 init="tcnn", image_hw=None):
+                 init="tcnn", image_hw=None, tracer=None):
         """image_hw = (H, W): the rays are the row-major pixels of one full frame; every step
         then first re-orders them (and the ground truth) into 8x8-pixel tiles, so that a wave
         of any per-ray kernel covers a square patch, and returns the colours in the caller's
-        order (vsa_tile_order; both passes are inside the step)."""
+        order (vsa_tile_order; both passes are inside the step).
+        tracer: a RayTracer already built over `meshes` (another pipeline's: the BVH of a 1.3 M-triangle
+        shell takes seconds to build) instead of building one."""
         from .neural_textures import NeuralTextureBank
         self.meshes = meshes
         self.K = len(meshes)
-        self.tracer = RayTracer(meshes)
+        self.tracer = RayTracer(meshes) if tracer is None else tracer
         self.rays_o, self.rays_d, self.gt = rays_o, rays_d, gt_rgb
         self.nr_rays = rays_o.shape[0]
         import os
@@ -207,11 +209,15 @@ class KShellPipeline:
         that record — so that they are pending beside ONE kernel, not beside twenty
         (parallel.OverlappedStep.run_split)."""
         self._static_rgb = None
+        self._graph_dp = dp = step_kw.get("dp")
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
+        hook, _ = (dp.on_weights_final, setattr(dp, "on_weights_final", None)) if dp is not None else (None, None)
         with torch.cuda.stream(s):
             for _ in range(2):
-                self.step(**step_kw)
+                self.step(**step_kw)      # (eager warm-ups: see capture_graph)
+        if dp is not None:
+            dp.on_weights_final = hook
         torch.cuda.current_stream().wait_stream(s)
         self._graph_prefix, self._graph_mid, self._graph_tail = (torch.cuda.CUDAGraph() for _ in range(3))
         with torch.cuda.graph(self._graph_prefix, capture_error_mode=_CAPTURE_MODE):
@@ -224,8 +230,14 @@ class KShellPipeline:
     def replay_prefix(self):
         self._graph_prefix.replay()
 
+    def _count_replay(self):
+        dp = getattr(self, "_graph_dp", None)
+        if dp is not None:
+            dp.epoch_host += 1       # the replayed graph holds one vsa_dp_signal (StepSignals.epoch_host)
+
     def replay_mid(self):
         self._graph_mid.replay()
+        self._count_replay()
 
     def replay_tail(self):
         self._graph_tail.replay()
@@ -233,6 +245,7 @@ class KShellPipeline:
 
     def replay_rest(self):
         self._graph_mid.replay()
+        self._count_replay()
         self._graph_tail.replay()
         return self._static_rgb
 
@@ -241,11 +254,15 @@ class KShellPipeline:
         host sync) into a HIP graph; `replay()` then costs one graph launch instead of
         the per-kernel host overhead of the eager path."""
         self._static_rgb = None
+        self._graph_dp = dp = step_kw.get("dp")
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
+        hook, _ = (dp.on_weights_final, setattr(dp, "on_weights_final", None)) if dp is not None else (None, None)
         with torch.cuda.stream(s):
             for _ in range(2):
-                self.step(**step_kw)
+                self.step(**step_kw)      # (eager warm-ups: they advance dp's epoch like any eager step, and leave no event behind)
+        if dp is not None:
+            dp.on_weights_final = hook
         torch.cuda.current_stream().wait_stream(s)
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph, capture_error_mode=_CAPTURE_MODE):
@@ -254,6 +271,7 @@ class KShellPipeline:
 
     def replay(self):
         self._graph.replay()
+        self._count_replay()
         return self._static_rgb
 
     def step(self, record=False, grad_ready=None, dp=None, part=None):
