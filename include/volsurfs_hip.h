@@ -515,10 +515,12 @@ int vsa_sh_encode(const float* dirs, int nr_dirs, int degree, float* out, void* 
  *   fwd: density [n] = softplus(y1[:, 0]);  x2 [n][nr_feat + nr_dir] = cat(gelu(y1[:, 1:1+nr_feat]), dirs_enc)
  *   bwd: dy1 [n][1 + nr_feat] from dx2 (gradient of x2; its dirs columns are ignored) and d_density
  *        (either may be NULL = zero).
- * y1 [n][1 + nr_feat] is the first MLP's output, dirs_enc [n][nr_dir] the encoded directions. */
-int vsa_field_head_fwd(const float* y1, const float* dirs_enc, long long nr_points, int nr_feat,
+ * y1 [n][y1_stride >= 1 + nr_feat] is the first MLP's output (r6: a row stride, so that the rows can be padded to a
+ * multiple of 4 floats — the MLP kernels then move them as 16-byte accesses), dy1 has the same stride and its padding
+ * columns are written as zeros; dirs_enc [n][nr_dir] the encoded directions. */
+int vsa_field_head_fwd(const float* y1, int y1_stride, const float* dirs_enc, long long nr_points, int nr_feat,
                        int nr_dir, float* x2, float* density, void* stream);
-int vsa_field_head_bwd(const float* y1, const float* dx2, const float* d_density, long long nr_points,
+int vsa_field_head_bwd(const float* y1, int y1_stride, const float* dx2, const float* d_density, long long nr_points,
                        int nr_feat, int nr_dir, float* dy1, void* stream);
 
 /* A5 / A10  Fused fp32 MLP (Linear + bias, exact GELU between layers, last layer linear) on the
@@ -539,8 +541,12 @@ int vsa_field_head_bwd(const float* y1, const float* dx2, const float* d_density
  *     Networks up to 96 wide whose weights fit the LDS (NerfHash's two, models/nerfhash.py:44-56) take ONE fused
  *     persistent launch — data gradients, weight gradients and bias sums from z alone (GELU and GELU' from one
  *     evaluation), nothing but dx written per sample (csrc/mlp_f32_fused.h): a_ws and dz_ws are then not read and
- *     may be NULL.  Wider networks (RGB / ColorSH: 128) run mlp_dgrad + mlp_wgrad as before.
- *   vsa_mlp_bwd_needs_act: 1 if vsa_mlp_bwd of this plan reads a_ws / dz_ws, 0 if not, < 0: VSA_ERR_*. */
+ *     may be NULL.  It needs 16-byte rows: x, dy (and dx) 16-byte aligned with a stride that is a multiple of 4 floats
+ *     (pad the rows: the padding columns of x are ignored, those of dx receive zeros).  Wider networks (RGB / ColorSH:
+ *     128) and unaligned rows run mlp_dgrad + mlp_wgrad as before.  Every kernel moves x / y / dy rows as 16-byte
+ *     groups when their stride allows it and element by element otherwise.
+ *   vsa_mlp_bwd_needs_act(plan, x_stride, dx_stride (0: no dx)): 1 if vsa_mlp_bwd of this plan with rows of these
+ *     strides (bases 16-byte aligned) reads a_ws / dz_ws, 0 if not, < 0: VSA_ERR_*. */
 #define VSA_MLP_MAX_LAYERS 6
 typedef struct vsa_mlp_plan {
   int32_t n_layers;
@@ -556,7 +562,7 @@ typedef struct vsa_mlp_grads {
 
 int vsa_mlp_workspace(const vsa_mlp_plan* plan, long long nr_points, long long* packed_floats,
                       long long* act_floats, long long* partial_floats);
-int vsa_mlp_bwd_needs_act(const vsa_mlp_plan* plan);
+int vsa_mlp_bwd_needs_act(const vsa_mlp_plan* plan, int x_stride, int dx_stride);
 int vsa_mlp_fwd(const vsa_mlp_plan* plan, const float* x, int x_stride, int nr_points, float* y,
                 int y_stride, float* z_ws, float* a_ws, float* packed_ws, void* stream);
 int vsa_mlp_bwd(const vsa_mlp_plan* plan, const float* x, int x_stride, int nr_points,

@@ -860,7 +860,7 @@ def test_fused_legacy_step_equals_the_autograd_step(cfg):
 
 
 # measured on MI355X (printed as MEASURED shared ...): bounds = 2x measured
-SHARED_GRAD_REL_MAX = {"weights": 4e-3, "tables": 1.6e-2}
+SHARED_GRAD_REL_MAX = {"weights": 4e-3, "tables": 3.1e-2}      # measured: 1.6e-3 / 1.5e-2 (the raw-row case; the others 1e-3 / 2.6e-3)
 
 
 @pytest.mark.gpu

@@ -17,7 +17,8 @@ args = ap.parse_args()
 torch.manual_seed(0)
 for name, din, dims in (("feat_and_density", 51, [64, 64, 64, 65]), ("rgb", 80, [64, 64, 3])):
     m = MLP(din, dims, last_layer_linear=True).cuda()
-    x = torch.randn(args.rows, din, device="cuda", requires_grad=True)
+    # rows padded to a multiple of 4 floats, as the encoder / the field head hand them over (models.padded_rows)
+    x = torch.randn(args.rows, (din + 3) // 4 * 4, device="cuda")[:, :din].detach().requires_grad_(True)
     flops = 2 * sum(a * b for a, b in zip([din] + dims[:-1], dims)) * args.rows
     tf, tb = [], []
     for it in range(args.iters + 2):
@@ -25,7 +26,7 @@ for name, din, dims in (("feat_and_density", 51, [64, 64, 64, 65]), ("rgb", 80, 
         e[0].record()
         y = m(x)
         e[1].record()
-        g = torch.ones_like(y)
+        g = torch.ones_like(y)          # (keeps y's padded rows)
         torch.cuda.synchronize()
         e[1].record()
         y.backward(g)

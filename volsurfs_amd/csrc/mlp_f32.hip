@@ -220,7 +220,7 @@ template <bool RESIDENT, int NB>
 __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_fwd_kernel(
     vsa_mlp_plan plan, MlpGroups gp, long long packed_stride, long long hidden,
     const float* __restrict__ packed, const float* __restrict__ x, int x_stride,
-    float* __restrict__ y, int y_stride, float* __restrict__ z_ws, float* __restrict__ a_ws) {
+    float* __restrict__ y, int y_stride, float* __restrict__ z_ws, float* __restrict__ a_ws, int io_aligned) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];
   __shared__ LayerMeta s_meta;
   const int grp = blockIdx.y;
@@ -253,6 +253,27 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_fwd_kernel(
     const bool valid = tile < ntiles && pt < M;
     const int in = plan.dims[0];
     const float* row = x + (valid ? pt : 0) * (long long)x_stride;
+    if (io_aligned & 1) {
+      // rows of a stride that is a multiple of 4 floats: 16-byte loads of columns 32 b + 8 g + 4 h .. + 3, a group
+      // beyond the row read at a clamped address and zeroed by a select — no per-element exec-mask branch (the
+      // element-wise form below costs ~8 instructions per element: the kernel was bound by them, not by its MFMAs)
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int k0 = 32 * b + 8 * g + 4 * h;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (32 * b < in) {                // uniform
+            const int kc = k0 < x_stride ? k0 : x_stride - 4;
+            v = *reinterpret_cast<const float4*>(row + kc);
+          }
+          dst[b][4 * g] = (valid && k0 < in) ? v.x : 0.f;
+          dst[b][4 * g + 1] = (valid && k0 + 1 < in) ? v.y : 0.f;
+          dst[b][4 * g + 2] = (valid && k0 + 2 < in) ? v.z : 0.f;
+          dst[b][4 * g + 3] = (valid && k0 + 3 < in) ? v.w : 0.f;
+        }
+      return;
+    }
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -317,9 +338,13 @@ __global__ __launch_bounds__(MLP_BLOCK, 2) void mlp_fwd_kernel(
               v[i] = acc[m][4 * g + i] + ((bias && n0 + i < out) ? bias[n0 + i] : 0.f);
             if (last) {
               if (valid) {
+                if (io_aligned & 2) {       // 16-byte rows: padding columns receive the zeros of the zero weight rows
+                  if (n0 < y_stride) *reinterpret_cast<float4*>(y + pt * y_stride + n0) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                  if (n0 + i < out) y[pt * y_stride + n0 + i] = v[i];
+                  for (int i = 0; i < 4; ++i)
+                    if (n0 + i < out) y[pt * y_stride + n0 + i] = v[i];
+                }
               }
             } else {
               // hidden widths are multiples of 32: aligned 16-byte rows
@@ -841,6 +866,9 @@ WgradLayers wgrad_layers(const vsa_mlp_plan& p, int total_wgs) {
 // staging rows (<= 160 KiB), its layers are at most 96 wide and its block pairs fit five accumulators per wave.
 // MLP_BWD_FUSED=0 in the environment: the two-kernel backward of rounds 1-5 (A/B switch).
 constexpr size_t MLP_FUSED_LDS_MAX = 160 * 1024 - 512;
+// a row-major matrix whose rows can be read / written as 16-byte groups
+bool rows_aligned(const void* ptr, int stride) { return stride % 4 == 0 && (reinterpret_cast<size_t>(ptr) & 15) == 0; }
+
 bool bwd_is_fused(const vsa_mlp_plan& p) {
   static const bool off = [] { const char* e = getenv("MLP_BWD_FUSED"); return e && e[0] == '0'; }();
   if (off || p.n_layers < 2) return false;
@@ -880,10 +908,10 @@ int set_fused_lds_attrs() {
 
 }  // namespace
 
-extern "C" int vsa_mlp_bwd_needs_act(const vsa_mlp_plan* plan) {
+extern "C" int vsa_mlp_bwd_needs_act(const vsa_mlp_plan* plan, int x_stride, int dx_stride) {
   const int rc = plan_ok(plan);
   if (rc) return rc < 0 ? rc : -rc;
-  return bwd_is_fused(*plan) ? 0 : 1;
+  return bwd_is_fused(*plan) && x_stride % 4 == 0 && (dx_stride == 0 || dx_stride % 4 == 0) ? 0 : 1;
 }
 
 extern "C" int vsa_mlp_workspace(const vsa_mlp_plan* plan, long long nr_points,
@@ -986,7 +1014,8 @@ extern "C" int vsa_mlp_fwd_grouped(const vsa_mlp_plan* plans, int nr_groups, con
   const int cap = vsa_div_up(2 * nr_cus, nr_groups);          // two workgroups per CU over all groups
   if (grid > cap) grid = cap;
   VSA_MLP_DISPATCH(mlp_fwd_kernel, resident, max_blocks(*plan), dim3(grid, nr_groups), dim3(MLP_BLOCK), lds, st,
-                   *plan, gp, packed_stride, hidden_width(*plan), packed_ws, x, x_stride, y, y_stride, z_ws, a_ws);
+                   *plan, gp, packed_stride, hidden_width(*plan), packed_ws, x, x_stride, y, y_stride, z_ws, a_ws,
+                   (rows_aligned(x, x_stride) ? 1 : 0) | (rows_aligned(y, y_stride) ? 2 : 0));
   VSA_RETURN_LAUNCH_STATUS();
 }
 
@@ -1011,7 +1040,7 @@ extern "C" int vsa_mlp_bwd_grouped(const vsa_mlp_plan* plans, int nr_groups, con
     return VSA_ERR_ARG;
   if (!grads) return VSA_ERR_ARG;
   if (rows == 0) return VSA_OK;
-  const bool fused = bwd_is_fused(*plan);
+  const bool fused = bwd_is_fused(*plan) && rows_aligned(x, x_stride) && rows_aligned(dy, dy_stride) && (!dx || rows_aligned(dx, dx_stride));
   if (!x || !dy || !packed_ws || !partial_ws || (L > 1 && (!z_ws || (!fused && (!dz_ws || !a_ws)))))
     return VSA_ERR_ARG;
   MlpGroupGrads gg;

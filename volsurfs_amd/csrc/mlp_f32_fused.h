@@ -61,8 +61,8 @@ template <int NB, int NH, int Q>
 __global__ __launch_bounds__(FB_BLOCK, 1) void mlp_bwd_fused_kernel(
     vsa_mlp_plan plan, WgradLayers wl, MlpGroups gp, long long packed_stride, long long hidden, long long partial_stride,
     int rows_dz, const float* __restrict__ packed_t, const float* __restrict__ x, int x_stride,
-    const float* __restrict__ dy, int dy_stride, const float* __restrict__ z_ws, float* __restrict__ dx, int dx_stride,
-    float* __restrict__ partial) {
+    const float* __restrict__ dy, int dy_stride, const float* __restrict__ z_ws, float* __restrict__ dx,
+    int dx_stride, float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];
   __shared__ LayerMeta s_meta;
   const int grp = blockIdx.y;
@@ -174,20 +174,33 @@ __global__ __launch_bounds__(FB_BLOCK, 1) void mlp_bwd_fused_kernel(
   // Loads run one step ahead of their use: `zq` / `xq` hold the NEXT layer's input — the z of the hidden layer below,
   // or x for layer 0 — requested behind the current layer's MFMAs; the next round's dy and top-layer z behind layer 0's.
   auto tile_of = [&](int rd) { return rd * per_round + (int)blockIdx.x * 4 + tw; };
-  auto load_dy = [&](int rd, float dst[NB][16]) {
+  // Rows whose stride is a multiple of 4 floats (x and dx always here: the host takes the two-kernel backward otherwise;
+  // dy when the caller could arrange it) move as 16-byte accesses in the layout the MFMAs want — lane (p, h) owns
+  // columns 32 b + 8 g + 4 h .. + 3 of its point's row — with no per-element branch: a column group beyond the row is
+  // read at a clamped address and zeroed by a select.  (The first version read every element behind its own predicate:
+  // ~150 exec-mask branch regions with 64-bit address arithmetic per round, 8 000 instructions for 290 MFMAs.)
+  auto load_rows4 = [&](const float* __restrict__ T, int st, int w, int rd, float dst[NB][16]) __attribute__((always_inline)) {
     const int tile = tile_of(rd);
     const long long pt = (long long)tile * MLP_TILE + p;
     const bool valid = tile < ntiles && pt < M;
-    const int out = meta_dim(s_meta, L);
-    const float* row = dy + (valid ? pt : 0) * (long long)dy_stride;
+    const float* row = T + (valid ? pt : 0) * (long long)st;
 #pragma unroll
-    for (int m = 0; m < NB; ++m)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = 32 * m + rho(r, h);
-        dst[m][r] = (valid && n < out) ? row[n] : 0.f;
+      for (int g = 0; g < 4; ++g) {
+        const int k0 = 32 * b + 8 * g + 4 * h;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (32 * b < w) {                   // uniform: the block exists
+          const int kc = k0 < st ? k0 : st - 4;
+          v = *reinterpret_cast<const float4*>(row + kc);
+        }
+        dst[b][4 * g] = (valid && k0 < w) ? v.x : 0.f;
+        dst[b][4 * g + 1] = (valid && k0 + 1 < w) ? v.y : 0.f;
+        dst[b][4 * g + 2] = (valid && k0 + 2 < w) ? v.z : 0.f;
+        dst[b][4 * g + 3] = (valid && k0 + 3 < w) ? v.w : 0.f;
       }
   };
+  auto load_dy = [&](int rd, float dst[NB][16]) __attribute__((always_inline)) { load_rows4(dy, dy_stride, meta_dim(s_meta, L), rd, dst); };
   auto load_z = [&](int rd, int l, long long z_off, float dst[NB][16]) {       // z_{l-1}, the input of layer l >= 1
     const int tile = tile_of(rd);
     const long long pt = (long long)tile * MLP_TILE + p;
@@ -203,20 +216,7 @@ __global__ __launch_bounds__(FB_BLOCK, 1) void mlp_bwd_fused_kernel(
         dst[b][4 * g] = z4.x, dst[b][4 * g + 1] = z4.y, dst[b][4 * g + 2] = z4.z, dst[b][4 * g + 3] = z4.w;
       }
   };
-  auto load_x = [&](int rd, float dst[NB][16]) {
-    const int tile = tile_of(rd);
-    const long long pt = (long long)tile * MLP_TILE + p;
-    const bool valid = tile < ntiles && pt < M;
-    const int in = meta_dim(s_meta, 0);
-    const float* row = x + (valid ? pt : 0) * (long long)x_stride;
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int k = 32 * b + rho(r, h);
-        dst[b][r] = (valid && k < in) ? row[k] : 0.f;
-      }
-  };
+  auto load_x = [&](int rd, float dst[NB][16]) __attribute__((always_inline)) { load_rows4(x, x_stride, meta_dim(s_meta, 0), rd, dst); };
   const long long z_top = L > 1 ? z_end - (long long)M * meta_dim(s_meta, L - 1) : 0;   // offset of z_{L-2}: the top layer's input
   float dz[NB][16];                   // dZ of the layer being processed (rows rho(r, h) of its OUTPUT blocks)
   float nq[NB][16];                   // the next layer's input, in flight: z (its first NH blocks) or, for layer 0, x
@@ -297,14 +297,16 @@ __global__ __launch_bounds__(FB_BLOCK, 1) void mlp_bwd_fused_kernel(
     }
     // ---- epilogue: dX (and the next round's dy), or dZ_{l-1} = dA * GELU'(z_{l-1})
     if constexpr (BOT) {
-      if (dx && valid) {
+      if (dx && valid) {      // (16-byte stores; the row's padding columns get the zeros the zero weight columns produce)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
           if (b < inb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int k = 32 * b + rho(r, h);
-              if (k < in) dx[pt * dx_stride + k] = da[b][r];
+            for (int g = 0; g < 4; ++g) {
+              const int k0 = 32 * b + 8 * g + 4 * h;
+              if (k0 < dx_stride)
+                *reinterpret_cast<float4*>(dx + pt * dx_stride + k0) =
+                    make_float4(da[b][4 * g], da[b][4 * g + 1], da[b][4 * g + 2], da[b][4 * g + 3]);
             }
           }
       }

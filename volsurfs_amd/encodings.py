@@ -62,8 +62,12 @@ class _GridEncode(torch.autograd.Function):
         x = _lib.check_f32(x.contiguous(), x.shape[0], plan.n_dims)
         ctx.owner = owner        # the nn.Parameter behind `tables` (direct gradient accumulation)
         width = plan.n_levels * 2 + (plan.n_dims if append else 0)
-        out = torch.empty(x.shape[0], width, device=x.device)
-        _lib.call("vsa_grid_encode_fwd_ld", ctypes.byref(plan), tables, x, x.shape[0], out, width,
+        # rows padded to a multiple of 4 floats (51 -> 52): the MLP that reads them — and writes their gradient —
+        # moves 16-byte groups (models.padded_rows; csrc/mlp_f32_fused.h), and an even stride keeps the float2 stores aligned
+        ld = (width + 3) // 4 * 4
+        buf = torch.empty(x.shape[0], ld, device=x.device)
+        out = buf[:, :width] if ld != width else buf
+        _lib.call("vsa_grid_encode_fwd_ld", ctypes.byref(plan), tables, x, x.shape[0], out, ld,
                   1 if append else 0, _lib.stream_ptr())
         ctx.save_for_backward(x)
         ctx.plan, ctx.shape, ctx.width = plan, tables.shape, width
@@ -75,7 +79,9 @@ class _GridEncode(torch.autograd.Function):
         from .optim import accumulate_into_grad
         direct = accumulate_into_grad(ctx.owner) if ctx.owner is not None else None
         g_tables = direct if direct is not None else torch.zeros(ctx.shape, device=x.device)
-        g_out = g_out.contiguous()
+        if not (g_out.dim() == 2 and g_out.stride(1) == 1 and g_out.stride(0) >= ctx.width):
+            g_out = g_out.contiguous()
+        g_ld = g_out.stride(0)          # (padded rows are read in place)
         # (the binned path slices a level into <= 32 runs of 2^13 entries: tables up to 2^18 entries)
         if x.shape[0] >= BINNED_BWD_MIN_POINTS and max(ctx.plan.level_size[:ctx.plan.n_levels]) <= (1 << 18):
             # very large batches: bin the contributions by table slice once, accumulate densely
@@ -83,15 +89,15 @@ class _GridEncode(torch.autograd.Function):
             _lib.call("vsa_grid_encode_bwd_binned_workspace", ctypes.byref(ctx.plan), x.shape[0],
                       ctypes.byref(n))
             ws = torch.empty(n.value, device=x.device)
-            _lib.call("vsa_grid_encode_bwd_binned_ld", ctypes.byref(ctx.plan), x, g_out, ctx.width,
+            _lib.call("vsa_grid_encode_bwd_binned_ld", ctypes.byref(ctx.plan), x, g_out, g_ld,
                       x.shape[0], g_tables, ws, _lib.stream_ptr())
         elif x.shape[0] >= SLICED_BWD_MIN_POINTS:
             # large batches: LDS-resident table slices instead of memory-side float atomics
             ws = torch.empty(x.shape[0] * ctx.plan.n_levels * 2 + 32, device=x.device)
-            _lib.call("vsa_grid_encode_bwd_sliced_ld", ctypes.byref(ctx.plan), x, g_out, ctx.width,
+            _lib.call("vsa_grid_encode_bwd_sliced_ld", ctypes.byref(ctx.plan), x, g_out, g_ld,
                       x.shape[0], g_tables, ws, _lib.stream_ptr())
         else:
-            _lib.call("vsa_grid_encode_bwd_ld", ctypes.byref(ctx.plan), x, g_out, ctx.width, x.shape[0],
+            _lib.call("vsa_grid_encode_bwd_ld", ctypes.byref(ctx.plan), x, g_out, g_ld, x.shape[0],
                       g_tables, _lib.stream_ptr())
         # positions carry no gradient on this path
         return (None if direct is not None else g_tables), None, None, None, None

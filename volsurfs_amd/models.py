@@ -85,6 +85,24 @@ def fused_mlp_supported(dims, x):
             and all(1 <= d <= 128 for d in dims) and all(d % 32 == 0 for d in dims[1:-1]))
 
 
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+def rows16(t):
+    """t [M, W] can be handed to the MLP / field-head kernels IN PLACE as rows of 16-byte groups: unit column stride, a
+    row stride that is a multiple of 4 floats, a 16-byte aligned base (include/volsurfs_hip.h, vsa_mlp_bwd)."""
+    return (t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.stride(0) >= t.shape[1]
+            and t.data_ptr() % 16 == 0)
+
+
+def padded_rows(M, W, device, zero=False):
+    """[M, W] view of a fresh [M, pad4(W)] buffer: the producer of a matrix the MLP kernels will read pads its rows so that
+    they move as 16-byte accesses (a 51-wide feature row, a 65-wide output row: rows of 52 / 68 floats)."""
+    buf = (torch.zeros if zero else torch.empty)(M, _pad4(W), device=device)
+    return buf[:, :W] if W % 4 else buf
+
+
 class _FusedMLP(torch.autograd.Function):
     """y = W_L(... GELU(W_1 x + b_1) ...) + b_L in ONE launch on the fp32 matrix cores
     (vsa_mlp_fwd); backward = vsa_mlp_bwd (data-gradient chain, weight gradients, bias sums).
@@ -97,7 +115,7 @@ class _FusedMLP(torch.autograd.Function):
         bs = [params[2 * l + 1] if has_bias else None for l in range(nl)]
         ws = [w.contiguous() for w in ws]
         bs = [b.contiguous() if b is not None else None for b in bs]
-        x = x.contiguous()
+        x = x if rows16(x) else x.contiguous()        # (a producer's padded rows are read in place)
         M = x.shape[0]
         plan = _mlp_plan(ws, bs)
         sizes = [ctypes.c_longlong() for _ in range(3)]
@@ -109,11 +127,14 @@ class _FusedMLP(torch.autograd.Function):
         z = torch.empty(max(sizes[1].value, 1), device=dev) if need else None
         # GELU(z), the weight gradients' other operand: only the two-kernel backward reads it (the fused backward of
         # networks up to 96 wide forms it from z: include/volsurfs_hip.h, vsa_mlp_bwd_needs_act)
-        needs_act = need and int(_lib.lib().vsa_mlp_bwd_needs_act(ctypes.byref(plan))) != 0
-        act = torch.empty_like(z) if needs_act else None
-        y = torch.empty(M, ws[-1].shape[0], device=dev)
-        _lib.call("vsa_mlp_fwd", ctypes.byref(plan), x, x.shape[1], M, y, y.shape[1], z, act, packed,
-                  _lib.stream_ptr())
+        xs = x.stride(0)
+        fused_bwd = rows16(x) and int(_lib.lib().vsa_mlp_bwd_needs_act(
+            ctypes.byref(plan), ctypes.c_int(xs), ctypes.c_int(xs if ctx.needs_input_grad[0] else 0))) == 0
+        act = torch.empty_like(z) if need and not fused_bwd else None
+        y = padded_rows(M, ws[-1].shape[0], dev)
+        _lib.call("vsa_mlp_fwd", ctypes.byref(plan), x, xs, M, y, y.stride(0), z, act,
+                  packed, _lib.stream_ptr())
+        ctx.xs = xs
         ctx.save_for_backward(x, z, act, *ws, *[b for b in bs if b is not None])
         ctx.meta = (nl, has_bias, sizes[1].value, sizes[2].value)
         return y
@@ -126,12 +147,19 @@ class _FusedMLP(torch.autograd.Function):
         bs = list(ctx.saved_tensors[3 + nl:]) if has_bias else [None] * nl
         M, dev = x.shape[0], x.device
         plan = _mlp_plan(ws, bs)
-        gy = gy.contiguous()
+        if not rows16(gy):          # (e.g. the contiguous [M, 3] gradient of a torch op: re-laid once as padded rows)
+            g_ = padded_rows(M, gy.shape[1], dev)
+            g_.copy_(gy)
+            gy = g_
         dz = torch.empty(max(act_n, 1), device=dev) if act is not None else None
         packed = torch.empty(sum(((w.shape[0] + 31) // 32) * ((w.shape[1] + 31) // 32) * 1024 for w in ws),
                              device=dev)
         partial = torch.empty(max(part_n, 1), device=dev)
-        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        xs = ctx.xs
+        dx = None
+        if ctx.needs_input_grad[0]:     # rows of x's own stride (the fused backward stores them as 16-byte groups)
+            dxb = torch.empty(M, xs, device=dev)
+            dx = dxb[:, :x.shape[1]] if xs != x.shape[1] else dxb
         # (an empty batch: the entry point returns without a launch — the gradients are zero)
         alloc = torch.zeros_like if M == 0 else torch.empty_like
         gw = [alloc(w) for w in ws]
@@ -140,8 +168,8 @@ class _FusedMLP(torch.autograd.Function):
         for l in range(nl):
             grads.dw[l] = gw[l].data_ptr()
             grads.db[l] = gb[l].data_ptr() if gb[l] is not None else None
-        _lib.call("vsa_mlp_bwd", ctypes.byref(plan), x, x.shape[1], M, gy, gy.shape[1], z, dz, act,
-                  packed, partial, dx, x.shape[1], ctypes.byref(grads), _lib.stream_ptr())
+        _lib.call("vsa_mlp_bwd", ctypes.byref(plan), x, xs, M, gy, gy.stride(0), z, dz, act,
+                  packed, partial, dx, xs, ctypes.byref(grads), _lib.stream_ptr())
         out = []
         for l in range(nl):
             out.append(gw[l])
@@ -553,12 +581,13 @@ class _FieldHead(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y1, dirs_enc):
-        y1 = _lib.check_f32(y1.contiguous())
+        y1 = y1 if rows16(y1) and y1.dtype == torch.float32 else _lib.check_f32(y1.contiguous())
         dirs_enc = _lib.check_f32(dirs_enc.contiguous(), y1.shape[0], dirs_enc.shape[1])
         n, F, E = y1.shape[0], y1.shape[1] - 1, dirs_enc.shape[1]
-        x2 = torch.empty(n, F + E, device=y1.device)
+        x2 = padded_rows(n, F + E, y1.device)
         density = torch.empty(n, 1, device=y1.device)
-        _lib.call("vsa_field_head_fwd", y1, dirs_enc, ctypes.c_longlong(n), F, E, x2, density,
+        ctx.s1 = s1 = y1.stride(0)
+        _lib.call("vsa_field_head_fwd", y1, s1, dirs_enc, ctypes.c_longlong(n), F, E, x2, density,
                   _lib.stream_ptr())
         ctx.save_for_backward(y1)
         ctx.dims = (F, E)
@@ -570,8 +599,9 @@ class _FieldHead(torch.autograd.Function):
         F, E = ctx.dims
         g_x2 = g_x2.contiguous() if g_x2 is not None else None
         g_density = g_density.contiguous() if g_density is not None else None
-        dy1 = torch.empty_like(y1)
-        _lib.call("vsa_field_head_bwd", y1, g_x2, g_density, ctypes.c_longlong(y1.shape[0]), F, E, dy1,
+        dyb = torch.empty(y1.shape[0], ctx.s1, device=y1.device)       # rows of y1's stride (padding columns: zeros)
+        dy1 = dyb[:, :1 + F] if ctx.s1 != 1 + F else dyb
+        _lib.call("vsa_field_head_bwd", y1, ctx.s1, g_x2, g_density, ctypes.c_longlong(y1.shape[0]), F, E, dy1,
                   _lib.stream_ptr())
         return dy1, None
 

@@ -28,6 +28,24 @@ GRAD_CHAIN_GAIN = 16.0
 _CAPTURE_MODE = "thread_local"
 
 
+class _no_gc:
+    """No garbage collection inside a stream capture: a cycle collected there may destroy ANOTHER pipeline's HIP graph (or a
+    signal allocation), which the runtime refuses during a capture — and a failed destroy inside a C++ destructor aborts
+    the process (seen once in a full `pytest -m gpu` run: 'Fatal Python error: Aborted ... Garbage-collecting' under
+    capture_graph, profiles/r06/README.md).  Collect first, then hold the collector off until the capture has ended."""
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self.was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        import gc
+        if self.was:
+            gc.enable()
+
+
 class StageTimer:
     def __init__(self):
         self.records = []          # (name, start_evt, end_evt)
@@ -220,12 +238,13 @@ class KShellPipeline:
             dp.on_weights_final = hook
         torch.cuda.current_stream().wait_stream(s)
         self._graph_prefix, self._graph_mid, self._graph_tail = (torch.cuda.CUDAGraph() for _ in range(3))
-        with torch.cuda.graph(self._graph_prefix, capture_error_mode=_CAPTURE_MODE):
-            self.step(part="prefix", **step_kw)
-        with torch.cuda.graph(self._graph_mid, pool=self._graph_prefix.pool(), capture_error_mode=_CAPTURE_MODE):
-            self.step(part="mid", **step_kw)
-        with torch.cuda.graph(self._graph_tail, pool=self._graph_prefix.pool(), capture_error_mode=_CAPTURE_MODE):
-            self._static_rgb = self.step(part="tail", **step_kw)
+        with _no_gc():
+            with torch.cuda.graph(self._graph_prefix, capture_error_mode=_CAPTURE_MODE):
+                self.step(part="prefix", **step_kw)
+            with torch.cuda.graph(self._graph_mid, pool=self._graph_prefix.pool(), capture_error_mode=_CAPTURE_MODE):
+                self.step(part="mid", **step_kw)
+            with torch.cuda.graph(self._graph_tail, pool=self._graph_prefix.pool(), capture_error_mode=_CAPTURE_MODE):
+                self._static_rgb = self.step(part="tail", **step_kw)
 
     def replay_prefix(self):
         self._graph_prefix.replay()
@@ -265,7 +284,7 @@ class KShellPipeline:
             dp.on_weights_final = hook
         torch.cuda.current_stream().wait_stream(s)
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph, capture_error_mode=_CAPTURE_MODE):
+        with _no_gc(), torch.cuda.graph(self._graph, capture_error_mode=_CAPTURE_MODE):
             self._static_rgb = self.step(**step_kw)
         return self._graph
 
