@@ -84,6 +84,9 @@ def parse(argv=None):
     ap.add_argument("--by-shell", action="store_true",
                     help="1 GPU: run the data-parallel step (phased hash-grid backward + device flags) "
                          "without the collectives, to price it")
+    ap.add_argument("--dp-phases-auto", type=int, default=1,
+                    help="N > 1 (or --force-dist): 1 (default) = choose the phase split from the all-reduce time, the hash-grid "
+                         "backward and the step's head measured at start-up (parallel.choose_phases); 0 = the fixed default")
     ap.add_argument("--dp-phases", default=None,
                     help="data-parallel step: shell-range ends of the hash-grid backward's phases, e.g. 3,5 "
                          "(default: parallel.default_phases — 3 phases)")
@@ -723,6 +726,11 @@ def main():
                                direct_rccl={"auto": None, "rccl": True, "torch": False}[args.dp_comm]
                                if dist is not None else False)
         ostep.active = dist is not None
+        dp_tuned = None
+        if dist is not None and phases is None and args.dp_phases_auto:
+            # the phase split from times measured on THIS group's wire (one phase when the reduction hides behind the
+            # next step's head — a one-rank group then pays nothing for the schedule; parallel.choose_phases)
+            _, dp_tuned = ostep.autotune_phases()
 
     def step(record=False):
         if ostep is not None:
@@ -799,6 +807,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 
+    # the reduced gradients of the last step, checksummed on EVERY rank: after the all-reduce they are the same bits
+    # everywhere, so the first multi-GPU run validates its own collectives (outside the timed region)
+    grad_cs = None
+    if dist is not None:
+        b = pipe.bank
+        cs = torch.stack([b.tables.grad.double().sum(), b.tables.grad.double().abs().sum(),
+                          b.weights.grad.double().sum(), b.weights.grad.double().abs().sum()])
+        got = [torch.zeros_like(cs) for _ in range(world)]
+        dist.all_gather(got, cs)
+        rows = [[float(v) for v in g.cpu()] for g in got]
+        grad_cs = {"grad_checksum_per_rank": rows, "grad_checksums_equal": all(r == rows[0] for r in rows),
+                   "grad_checksum_is": "[sum, sum |.|] of tables.grad and of weights.grad after the last step's all-reduce"}
+
     if rank == 0:
         total_rays = (pipe.loss_rays if strong else N * world) * args.steps
         value = total_rays / dt / 1e6
@@ -846,6 +867,7 @@ def main():
             "dtype": pipe.dtype_desc, "data": "synthetic",
             "config": dict(pipe.config_desc(world), launch="hip-graph replay" if use_graph else "eager",
                            **({"dp_phases": ostep.signals.phase_end,
+                               "dp_phases_chosen_from": dp_tuned if dp_tuned else "given / the fixed default",
                                "dp_reserve_cus": ostep.signals.reserve_cus,
                                "dp_comm": "rccl called directly on the side stream" if ostep.rccl is not None
                                else "torch.distributed",
@@ -879,6 +901,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], out["parity_sample"] = cpu_baseline(pipe, args.cpu_sample_rays)
         out.update(dist_info(dist, args))
+        if grad_cs is not None:
+            out.update(grad_cs)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

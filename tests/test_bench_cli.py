@@ -70,6 +70,12 @@ def test_one_rank_rccl_group_drives_the_data_parallel_schedule():
     assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["dist_backend"] == "nccl" and d["value"] > 0
     # r5: the data-parallel step is the one-GPU graph + device flags; the collectives run beside it
     assert "grad_allreduce" in d["stages_ms"] and d["config"]["launch"] == "hip-graph replay"
+    # r6: the phase split is chosen from times measured on this group's wire — a one-rank group's all-reduce hides behind
+    # the next step's head, so ONE phase (the schedule then costs what the plain step costs) — and every rank's reduced
+    # gradients are checksummed into the line (the first multi-GPU run validates its own collectives)
+    assert d["config"]["dp_phases"] == [2] and d["config"]["dp_phases_chosen_from"]["t_comm_ms"] >= 0
+    assert d["grad_checksums_equal"] is True and len(d["grad_checksum_per_rank"]) == 1
+    assert d["grad_checksum_per_rank"][0][1] > 0 and d["grad_checksum_per_rank"][0][3] > 0
 
 
 @pytest.mark.gpu

@@ -561,3 +561,22 @@ def test_default_phases_cut_the_shells_with_the_smallest_phase_last():
         sizes = [b - a for a, b in zip([0] + ends, ends)]
         assert ends[-1] == k and all(s > 0 for s in sizes) and sizes[-1] <= min(sizes[:-1] or [sizes[-1]])
     assert default_phases(5, max_phases=5) == [1, 2, 3, 4, 5] and default_phases(5, max_phases=1) == [5]
+
+
+def test_phase_count_follows_the_measured_times():
+    """parallel.choose_phases: one phase when the whole reduction hides behind the next step's head
+    (one GPU / a one-rank group: the data-parallel step then costs what the plain step costs), more phases as the wire
+    gets slower, never a cut that does not partition the shells; a phase boundary is not free."""
+    from volsurfs_amd.parallel import choose_phases
+    K = 5
+    assert choose_phases(K, 0.0, 0.6, 0.33) == [K]
+    assert choose_phases(K, 0.3, 0.6, 0.33) == [K]                 # 0.3 ms of reduction < 0.33 ms of head
+    prev = 1
+    for t_comm in (0.4, 0.6, 0.9, 1.5, 3.0):
+        ends = choose_phases(K, t_comm, 0.6, 0.33)
+        assert ends[-1] == K and all(b > a for a, b in zip([0] + ends, ends))
+        assert len(ends) >= prev                                    # a slower wire never asks for fewer phases
+        prev = len(ends)
+    assert prev > 1
+    assert choose_phases(K, 0.6, 0.6, 0.33, boundary_ms=10.0) == [K]   # a boundary that costs more than it hides
+    assert choose_phases(1, 5.0, 0.6, 0.0) == [1]

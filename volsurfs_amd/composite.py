@@ -148,15 +148,19 @@ _reduce_scratch = {}
 
 
 def reduce_scratch(device):
-    """The per-device scratch of vsa_count_hits / vsa_l1_mean (zeroed once; every call leaves it ready)."""
+    """The scratch of vsa_count_hits / vsa_l1_mean (zeroed once; every call leaves it ready): ticket + partials, a
+    last-ticket protocol that is only valid for calls SERIALISED on one stream — so there is one per (device, stream):
+    two reductions on different streams (look-ahead traversal, the alpha chain, the optimiser's side stream) never
+    share a ticket."""
     import ctypes
-    key = torch.device(device)
-    key = torch.device("cuda", torch.cuda.current_device()) if key.index is None else key
+    dev = torch.device(device)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dev.index is None else dev
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
     sc = _reduce_scratch.get(key)
     if sc is None:
         fn = _lib.lib().vsa_reduce_scratch_bytes
         fn.restype = ctypes.c_longlong
-        sc = _reduce_scratch[key] = torch.zeros(int(fn()), dtype=torch.uint8, device=key)
+        sc = _reduce_scratch[key] = torch.zeros(int(fn()), dtype=torch.uint8, device=dev)
     return sc
 
 

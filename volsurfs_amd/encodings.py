@@ -377,7 +377,8 @@ class _PermutoEncodeGrouped(torch.autograd.Function):
     def backward(ctx, g_out):
         x, window = ctx.saved_tensors
         from .optim import accumulate_into_grad
-        g_out = g_out.contiguous()
+        if not (g_out.dim() == 2 and g_out.stride(1) == 1 and g_out.stride(0) >= g_out.shape[1]):
+            g_out = g_out.contiguous()          # (a column slice of wider rows is read in place: the kernel takes the row stride)
         encs, sizes = ctx.encs, ctx.sizes
         g_values, grads = [], []
         for enc in encs:
@@ -391,7 +392,7 @@ class _PermutoEncodeGrouped(torch.autograd.Function):
             ptrs = (ctypes.c_void_p * ng)(*[v.data_ptr() for v in g_values[g0:g0 + ng]])
             cnt = (ctypes.c_int * ng)(*sizes[g0:g0 + ng])
             _lib.call("vsa_permuto_encode_bwd_grouped", ctypes.byref(run[0].plan), _plans_on_device(run, x.device),
-                      ng, cnt, x[a:a + n], window, g_out[a:a + n], g_out.shape[1], ptrs, _lib.stream_ptr())
+                      ng, cnt, x[a:a + n], window, g_out[a:a + n], g_out.stride(0), ptrs, _lib.stream_ptr())
         return (None, None, None, None, None, *grads)      # positions: no gradient here
 
 

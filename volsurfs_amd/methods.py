@@ -50,7 +50,8 @@ class _ShadeStage(torch.autograd.Function):
         # for the two parameters: no 113 MB temporary, no second pass adding it to .grad.
         bank._ensure_grads()
         opt = getattr(method, "optimizer", None)
-        zeroed = bool(getattr(opt, "_grads_clean", False))     # the fused Adam step (or zero_grad) has just cleared them
+        # the fused Adam step (or zero_grad) has just cleared them — and nothing has touched the buffers since
+        zeroed = bool(opt.grads_are_clean()) if hasattr(opt, "grads_are_clean") else bool(getattr(opt, "_grads_clean", False))
         if hasattr(opt, "mark_grads_dirty"):
             opt.mark_grads_dirty()
         # scale of the fp16 gradient chain (tcnn's loss scale).  By default a power of two that
@@ -351,14 +352,15 @@ class VolSurfs(torch.nn.Module):
                 # the autograd-free step (fused_legacy_forward): the same grouped launches called directly, their
                 # backward closures kept on the tape
                 from .encodings import permuto_hash_encode_grouped_manual
-                from .models import fused_mlp_grouped_manual
+                from .models import cat_rows16, fused_mlp_grouped_manual
                 enc, enc_bwd = permuto_hash_encode_grouped_manual(pos_encs, pts[a0:], sizes, iter_nr=iter_nr)
                 parts = [enc]
                 if m0.view_dep:
                     parts.append(m0.dir_encoder(d[a0:], iter_nr=iter_nr))
                 if m0.normal_dep:
                     parts.append(nrm[a0:])
-                y, mlp_bwd = fused_mlp_grouped_manual([mod.mlp for mod in mods], torch.cat(parts, 1), sizes)
+                # (rows padded to a multiple of 4 floats — 66 -> 68: the MLP kernels move them as 16-byte groups)
+                y, mlp_bwd = fused_mlp_grouped_manual([mod.mlp for mod in mods], cat_rows16(parts), sizes)
                 n_enc = enc.shape[1]
                 tape[typ] = lambda gy: enc_bwd(mlp_bwd(gy)[:, :n_enc])
                 return y
@@ -746,7 +748,8 @@ class VolSurfs(torch.nn.Module):
         bank = self.bank
         bank._ensure_grads()
         opt = getattr(self, "optimizer", None)
-        zeroed = bool(getattr(opt, "_grads_clean", False))     # the fused Adam step (or zero_grad) has just cleared them
+        # the fused Adam step (or zero_grad) has just cleared them — and nothing has touched the buffers since
+        zeroed = bool(opt.grads_are_clean()) if hasattr(opt, "grads_are_clean") else bool(getattr(opt, "_grads_clean", False))
         if hasattr(opt, "mark_grads_dirty"):
             opt.mark_grads_dirty()
         bank.frame_generation = getattr(bank, "frame_generation", 0) + 1

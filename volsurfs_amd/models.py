@@ -258,7 +258,7 @@ class _FusedMLPGrouped(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, sizes, has_bias, nl, *params):
-        x = x.contiguous()
+        x = x if rows16(x) else x.contiguous()        # (padded rows — cat_rows16 — are read in place: 16-byte accesses)
         G = len(sizes)
         if not all(p_.is_contiguous() for p_ in params):
             raise _lib.VolsurfsHipError("fused_mlp_grouped: contiguous parameters only")
@@ -266,7 +266,7 @@ class _FusedMLPGrouped(torch.autograd.Function):
         need = _needs_backward(x, params)
         dev = x.device
         M = x.shape[0]
-        y = torch.empty(M, out_dim, device=dev)
+        y = padded_rows(M, out_dim, dev)
         z = torch.empty(max(M * hidden, 1), device=dev) if need else None
         act = torch.empty_like(z) if need else None       # GELU(z): the weight gradients' other operand
         packed = torch.empty(max(packed_n, 1) * min(G, MLP_MAX_GROUPS), device=dev)
@@ -277,7 +277,7 @@ class _FusedMLPGrouped(torch.autograd.Function):
             if n == 0:
                 continue
             cnt = (ctypes.c_int * ng)(*sizes[g0:g0 + ng])
-            _lib.call("vsa_mlp_fwd_grouped", plans, ng, cnt, x[a:a + n], x.shape[1], y[a:a + n], out_dim,
+            _lib.call("vsa_mlp_fwd_grouped", plans, ng, cnt, x[a:a + n], x.stride(0), y[a:a + n], y.stride(0),
                       z[a * hidden:] if z is not None else None, act[a * hidden:] if act is not None else None,
                       packed, packed_bwd, _lib.stream_ptr())
         ctx.packed_bwd = packed_bwd
@@ -294,8 +294,14 @@ class _FusedMLPGrouped(torch.autograd.Function):
         params = ctx.param_objs
         G = len(sizes)
         dev = x.device
-        gy = gy.contiguous()
-        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        if not rows16(gy):
+            g_ = padded_rows(gy.shape[0], gy.shape[1], dev)
+            g_.copy_(gy)
+            gy = g_
+        dx = None
+        if ctx.needs_input_grad[0]:        # rows of x's stride
+            dxb = torch.empty(x.shape[0], x.stride(0), device=dev)
+            dx = dxb[:, :x.shape[1]] if x.stride(0) != x.shape[1] else dxb
         nmax = max(sizes) if sizes else 0
         dz = torch.empty(max(x.shape[0] * hidden, 1), device=dev)
         _, runs, _, grad_cache, _ = _FusedMLPGrouped._descriptors(params, nl, has_bias, G)
@@ -345,12 +351,23 @@ class _FusedMLPGrouped(torch.autograd.Function):
                 _lib.call("vsa_mlp_workspace", ctypes.byref(plans[0]), ctypes.c_longlong(nmax), None, None,
                           ctypes.byref(sz))
                 partial = torch.empty(max(sz.value, 1) * min(G, MLP_MAX_GROUPS), device=dev)
-            _lib.call("vsa_mlp_bwd_grouped", plans, ng, cnt, x[a:a + n], x.shape[1], gy[a:a + n], gy.shape[1],
+            _lib.call("vsa_mlp_bwd_grouped", plans, ng, cnt, x[a:a + n], x.stride(0), gy[a:a + n], gy.stride(0),
                       z[a * hidden:], dz[a * hidden:], act[a * hidden:], packed, 1 if ready else 0, partial,
-                      dx[a:a + n] if dx is not None else None, x.shape[1], grads, _lib.stream_ptr())
+                      dx[a:a + n] if dx is not None else None, x.stride(0), grads, _lib.stream_ptr())
         if direct is not None:
             return (dx, None, None, None, *([None] * len(params)))
         return (dx, None, None, None, *targets)
+
+
+def cat_rows16(parts):
+    """torch.cat(parts, 1) into rows padded to a multiple of 4 floats (a [M, W] view of a [M, pad4(W)] buffer): the MLP
+    kernels read — and write the gradient of — such rows as 16-byte groups (include/volsurfs_hip.h, vsa_mlp_fwd)."""
+    M, W = parts[0].shape[0], sum(p_.shape[1] for p_ in parts)
+    out = padded_rows(M, W, parts[0].device)
+    # (no autograd through `out=`: for the autograd-free step — fused_legacy_forward's tape — only)
+    with torch.no_grad():
+        torch.cat([p_.detach() for p_ in parts], 1, out=out)     # one launch, straight into the strided view
+    return out
 
 
 def fused_mlp_grouped(mlps, x, sizes):

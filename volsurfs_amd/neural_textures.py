@@ -425,9 +425,11 @@ class NeuralTextureBank(torch.nn.Module):
         if self.tables.grad is self._flat_t and self.weights.grad is self._flat_w:
             flat.zero_()
             self._dfsum_clean = True
+            self._tables_grad_sig = (id(self.tables.grad), self.tables.grad._version)
             return True
         self.tables.grad.zero_()
         self.weights.grad.zero_()
+        self._tables_grad_sig = (id(self.tables.grad), self.tables.grad._version)
         return False
 
     def _take_grads_zeroed(self, grads_zeroed):
@@ -435,6 +437,9 @@ class NeuralTextureBank(torch.nn.Module):
         has just cleared the gradients), else what zero_grads() left; either way the buffer holds something
         after the launch."""
         z = bool(getattr(self, "_tables_grad_zero", False) if grads_zeroed is None else grads_zeroed)
+        if grads_zeroed is None and z:       # zero_grads() said so: still the same buffer, untouched by torch since? (ADVICE r5)
+            g = self.tables.grad
+            z = g is not None and getattr(self, "_tables_grad_sig", None) == (id(g), g._version)
         # (shared models: the kernel itself keeps a shared plane's flushes atomic — K shells write it)
         self._tables_grad_zero = False
         self.plan.grads_zeroed = int(z)

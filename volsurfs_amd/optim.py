@@ -120,10 +120,26 @@ class FusedAdam(torch.optim.Optimizer):
             for p in g["params"]:
                 if p.grad is not None:
                     p.grad.zero_()
-        self._grads_clean = True
+        self._note_clean()
 
     def mark_grads_dirty(self):
         self._grads_clean = False
+
+    def _note_clean(self):
+        """The gradient buffers are all zero NOW: remember which tensor objects, at which version (a `p.grad = ...`
+        assignment or an in-place torch op on a gradient — a regulariser, a manual accumulate — bumps neither flag)."""
+        self._grads_clean = True
+        self._clean_sig = [(id(p.grad), p.grad._version) for g in self.param_groups for p in g["params"] if p.grad is not None]
+
+    def grads_are_clean(self):
+        """True iff every gradient buffer is still the all-zero buffer the last step() / zero_grad() left: what a kernel
+        that STORES instead of accumulating (vsa_nt_plan.grads_zeroed) may rely on."""
+        if not self._grads_clean:
+            return False
+        sig = [(id(p.grad), p.grad._version) for g in self.param_groups for p in g["params"] if p.grad is not None]
+        if sig != getattr(self, "_clean_sig", None):
+            self._grads_clean = False
+        return self._grads_clean
 
     def _dirty_hook(self, _param):
         self._grads_clean = False
@@ -149,7 +165,7 @@ class FusedAdam(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             _lib.call("vsa_adam_step_shared", desc, ck, n, float(group["lr"]), float(b1), float(b2),
                       float(group["eps"]), int(group["step"]), float(grad_scale), 1, bound, sp)
-        self._grads_clean = True
+        self._note_clean()
         if stream is not None:
             ev = torch.cuda.Event()
             ev.record(stream)
@@ -352,7 +368,7 @@ class ShardedFusedAdam(FusedAdam):
             whole = (h if h is not None else p.detach()).view(-1)
             mine = (h_slice if h is not None else p_slice).clone()
             self._all_gather(whole, mine)
-        self._grads_clean = True
+        self._note_clean()
         return None
 
     def _all_gather(self, whole, mine):

@@ -99,6 +99,30 @@ def default_phases(nr_shells, max_phases=3):
     return sorted({-(-nr_shells * (i + 1) // n) for i in range(n)})
 
 
+def choose_phases(nr_shells, t_comm_ms, t_bwd_ms, head_ms, boundary_ms=0.045):
+    """Phase count of the hash-grid backward from MEASURED times: t_comm_ms = the all-reduce of all
+    table gradients on this group, t_bwd_ms = the un-phased hash-grid backward, head_ms = the next step's parameter-free head
+    that runs before the wait (OverlappedStep.run_split), boundary_ms = what one more phase costs the launch (0.028 ms of
+    piece visits + 0.015 ms for the wait -> collective -> event chain, profiles/r05/dp_schedule_one_gpu.txt).
+    Phase p's slice is final at (p + 1) / n of the launch and its reduction takes its share of t_comm on the wire behind the
+    previous slice's; what is left behind the launch, minus the head, is exposed.  One phase when the whole reduction hides
+    behind the head (one GPU, a one-rank group: the step then pays nothing for being data-parallel).  Returns the ends."""
+    best = None
+    for n in range(1, max(1, int(nr_shells)) + 1):
+        ends = default_phases(nr_shells, n)
+        m = len(ends)
+        t_b = t_bwd_ms + (m - 1) * boundary_ms
+        done, prev = 0.0, 0
+        for p, e in enumerate(ends):
+            ready = t_b * (p + 1) / m
+            done = max(done, ready) + t_comm_ms * (e - prev) / nr_shells
+            prev = e
+        cost = (m - 1) * boundary_ms + max(0.0, done - t_b - head_ms)
+        if best is None or cost < best[0] - 1e-9:
+            best = (cost, ends)
+    return best[1]
+
+
 class _EventWork:
     """What GradientOverlap.wait() needs of a Work: wait() makes the current stream wait."""
 
@@ -230,6 +254,47 @@ class OverlappedStep:
 
     def eager(self, record=False):
         return self.pipe.step(record=record, dp=self.signals)
+
+    def autotune_phases(self, group=None, reps=3):
+        """Replace the default phase split by choose_phases() of times measured HERE: the all-reduce of the gradient
+        buffers on this group's wire (side stream, events), the hash-grid backward and the step's head (one recorded eager
+        step).  Collective: every rank calls it at the same point, before any graph is captured; the ranks take the
+        slowest rank's times, so they all build the same launch.  Returns (phase ends, measured times)."""
+        pipe, bank = self.pipe, self.pipe.bank
+        pipe.step()                                    # gradient buffers exist
+        torch.cuda.synchronize()
+        t_comm = 0.0
+        if self.active:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            with torch.cuda.stream(self.side):
+                for i in range(reps + 1):              # (the first run pays the channel set-up)
+                    if i == 1:
+                        ev[0].record()
+                    if self.rccl is not None:
+                        self.rccl.all_reduce_sum_(bank.tables.grad, self.side)
+                    else:
+                        self.overlap.reduce_async(bank.tables.grad)
+                        self.overlap.wait()
+                ev[1].record()
+            torch.cuda.synchronize()
+            t_comm = ev[0].elapsed_time(ev[1]) / reps
+        pipe.reset_stage_timers()
+        pipe.step(record=True)
+        st = pipe.stage_report()
+        pipe.reset_stage_timers()
+        t_bwd = float(st.get("nt_encode_bwd", {}).get("ms", 0.6))
+        head = sum(float(st.get(k, {}).get("ms", 0.0)) for k in ("ray_tile_order", "trace", "nt_mark_compact"))
+        times = torch.tensor([t_comm, t_bwd, -head], device=bank.tables.device, dtype=torch.float64)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(times, op=dist.ReduceOp.MAX, group=group)       # slowest wire, slowest launch, shortest head
+        t_comm, t_bwd, head = float(times[0]), float(times[1]), -float(times[2])
+        ends = choose_phases(pipe.K, t_comm, t_bwd, head)
+        if ends != self.signals.phase_end:
+            sg = self.signals
+            self.signals = StepSignals(pipe.K, bank.tables.device, ends, sg.wait_mode, sg.reserve_cus)
+            self.signals.on_weights_final = self._weights_final
+        return ends, {"t_comm_ms": t_comm, "t_encode_bwd_ms": t_bwd, "head_ms": head}
 
     def run_split(self, prefix, mid, tail):
         """The pipelined form (pipe.capture_graph_split; replay_prefix / replay_mid / replay_tail):

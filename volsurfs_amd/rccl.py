@@ -49,6 +49,24 @@ class RcclComm:
     def __init__(self, rank, world, group=None):
         uid = _UniqueId()
         err = None
+        # Every rank first shows that it can call the library at all and the ranks AGREE on that (MIN over the group)
+        # before anyone enters the collective ncclCommInitRank: a rank that failed to load librccl.so would raise
+        # locally while the others hang in the init for ever.
+        try:
+            lib()
+            ok = 1
+        except Exception as e:
+            ok, err = 0, e
+        if world > 1:
+            import torch.distributed as dist
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if int(flag.item()) == 0:
+                raise RcclError(f"librccl is not usable on every rank (this rank: {err or 'ok'}): no direct communicator")
+        elif not ok:
+            raise RcclError(str(err))
+        err = None
         if rank == 0:
             try:
                 _check(lib().ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
