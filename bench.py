@@ -115,7 +115,8 @@ def parse(argv=None):
     if args.steps is None:
         # frame: 200 steps = 0.64 s of back-to-back graph replays (the round-1 default of 20 was a 63 ms
         # timed region, too short for any external GPU-busy sampler to corroborate)
-        args.steps = 500 if training else (3 if args.workload == "dtu" else (50 if args.workload == "render" else 200))
+        # (render: 200 frames = 0.2 s — at 50 the eager loop's 50 ms timed region moved by +-10 % from run to run on one box)
+        args.steps = 500 if training else (3 if args.workload == "dtu" else 200)
     if args.warmup is None:
         args.warmup = 100 if training else 10
     return args
@@ -243,17 +244,20 @@ def cpu_baseline(pipe, sample_rays):
     n = min(sample_rays, pipe.nr_rays)
     idx = torch.linspace(0, pipe.nr_rays - 1, n, device=pipe.rays_o.device).long()
     fb, pipe.tracer._fb = pipe.tracer._fb, None            # (the launch-order feedback belongs to the frame's rays)
+    # (parameters: the frame's MLP weights with SPREAD hash tables, U(-1, 1) — with the tcnn initialisation the frame is
+    #  timed at, U(+-1e-4), every texel is sigmoid(~0) and the oracle's own fp16 autograd is mostly rounding noise: a
+    #  comparison that could not fail on RGB and could not pass on gradients)
     sub = KShellPipeline(pipe.meshes, pipe.rays_o[idx].contiguous(), pipe.rays_d[idx].contiguous(),
-                         pipe.gt[idx].contiguous(), tracer=pipe.tracer)
+                         pipe.gt[idx].contiguous(), tracer=pipe.tracer, init="spread", seed=5)
     with torch.no_grad():
-        sub.bank.tables.copy_(pipe.bank.tables)
         sub.bank.weights.copy_(pipe.bank.weights)
     sub.bank.refresh_half_params()
     rgb = sub.step()
     torch.cuda.synchronize()
     ref, dt = opar.oracle_step(sub, loss_scale=128.0)      # the reference's fp16 autograd runs under tcnn's loss scale
     parity = opar.compare_step(sub, rgb, ref)
-    parity["sample"] = f"{n} rays spread over the frame (every {pipe.nr_rays // n}-th), L1 mean over the sample"
+    parity["sample"] = (f"{n} rays spread over the frame (every {pipe.nr_rays // n}-th), L1 mean over the sample, full-size "
+                        "meshes and textures, hash tables U(-1, 1), the frame's MLP weights; HIP path vs oracle.pipeline.render_step")
     pipe.tracer._fb = fb
     base = {"value": n / dt / 1e6, "unit": "Mrays/s", "cores": torch.get_num_threads(), "kind": "port",
             "frame_extrapolation_s": dt * pipe.nr_rays / n,

@@ -27,7 +27,7 @@
 // MFMA work per round and SIMD: ~290 (data) + ~290 (weight) v_mfma_f32_32x32x2_f32 of 64 cycles each.
 #pragma once
 
-// FB_DIAG (timing-only builds, results WRONG; tools/_diag_mlp.sh): 1 no weight-gradient MFMAs, 2 no data-gradient
+// FB_DIAG (timing-only builds, results WRONG; tools/diag_mlp.sh): 1 no weight-gradient MFMAs, 2 no data-gradient
 // MFMAs, 4 identity instead of the GELU evaluation, 8 no staging stores, 16 no barriers
 #ifndef FB_DIAG
 #define FB_DIAG 0
