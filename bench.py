@@ -84,6 +84,9 @@ def parse(argv=None):
     ap.add_argument("--by-shell", action="store_true",
                     help="1 GPU: run the data-parallel step (phased hash-grid backward + device flags) "
                          "without the collectives, to price it")
+    ap.add_argument("--train-graph", type=int, default=1,
+                    help="train workload (neural textures, one rank): 1 (default) = also run the iteration as one replayed HIP "
+                         "graph (trainer.GraphTrainLoop) and report it as `value` beside `value_eager`; 0 = the eager loop only")
     ap.add_argument("--dp-phases-auto", type=int, default=1,
                     help="N > 1 (or --force-dist): 1 (default) = choose the phase split from the all-reduce time, the hash-grid "
                          "backward and the step's head measured at start-up (parallel.choose_phases); 0 = the fixed default")
@@ -332,6 +335,29 @@ def run_train(args, world, rank, dev, dist):
         one(True)
     barrier()
     dt = time.perf_counter() - t0
+    # r6: the same loop as ONE replayed HIP graph per iteration (trainer.GraphTrainLoop: every launch at a fixed capacity
+    # of rays, the dynamic ray count / schedule / Adam step count / sampler stream advanced on the device) — the eager
+    # loop's host side and launch gaps are as long as its kernels.  Same batches, same rays, same learning rates.
+    graph = None
+    if not legacy and world == 1 and args.train_graph:
+        from volsurfs_amd.trainer import GraphTrainLoop
+        method.grad_scale = None
+        loop = GraphTrainLoop(method, reel, state["nr_rays"], target, iter_nr=state["it"]).capture()
+        for _ in range(20):
+            loop.step()
+        barrier()
+        s0 = loop.read()
+        tg = time.perf_counter()
+        for _ in range(args.steps):
+            loop.step()
+        barrier()
+        dtg = time.perf_counter() - tg
+        s1 = loop.finish()
+        state["it"], state["nr_rays"] = int(s1["iter"]), int(s1["nr_rays"])
+        graph = {"it/s": args.steps / dtg, "ms_per_step": dtg / args.steps * 1e3,
+                 "rays_per_iter": (s1["sum_rays"] - s0["sum_rays"]) / args.steps,
+                 "hits_per_iter": (s1["sum_hits"] - s0["sum_hits"]) / args.steps,
+                 "capacity": loop.capacity, "clamped": int(s1["clamped"]), "loss": float(s1["loss"])}
     # fixed cost per iteration: the same loop on batches of 64 rays (launches, host syncs, the
     # mark / compact scan of the texel domains, LDS staging of the level tables, Adam over all
     # parameters) — what does not shrink with the batch
@@ -382,9 +408,12 @@ def run_train(args, world, rank, dev, dist):
         ms = dt / args.steps * 1e3
         nparams = sum(p.numel() for g in method.optimizer.param_groups for p in g["params"])
         out = {
-            "metric": "training iterations/s (fwd+bwd+Adam, dynamic batch)", "value": args.steps / dt,
+            "metric": "training iterations/s (fwd+bwd+Adam, dynamic batch)",
+            # the graph loop when it ran (neural textures, one rank): the same iterations, replayed; the eager loop beside it
+            "value": graph["it/s"] if graph else args.steps / dt, "value_eager": args.steps / dt,
+            "train_graph": graph,
             "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": graph["ms_per_step"] if graph else ms, "ms_per_step_eager": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32 master / f16 compute" if not legacy else "f32", "data": "synthetic",
             "Mrays/s": state["rays"] / dt / 1e6, "Mhits/s": state["hits"] / dt / 1e6,
             "rays_per_iter": state["rays"] / args.steps, "hits_per_iter": state["hits"] / args.steps,

@@ -159,6 +159,14 @@ int vsa_trace_q(const uint32_t* qnodes, const float* tris, const int32_t* mesh_r
                 const float* mesh_frames, int nr_meshes, int max_depth, const float* rays_o,
                 const float* rays_d, int nr_rays, float t_min, float* hit_t, int32_t* hit_slot,
                 float* hit_uv, void* stream);
+/* The same launch with NARROW waves: rays_per_wave (1 .. 64) rays per 64-lane wave, the other lanes idle.  For small
+ * batches of incoherent rays (a training batch: a few ten thousand random pixels of many views): a wave walks until
+ * its slowest ray is done, so fewer rays per wave mean shorter dependent chains and more waves to hide them behind —
+ * the chip is mostly empty at that size anyway.  Same hits (a ray's walk does not depend on its wave). */
+int vsa_trace_q_narrow(const uint32_t* qnodes, const float* tris, const int32_t* mesh_roots,
+                       const float* mesh_frames, int nr_meshes, int max_depth, const float* rays_o,
+                       const float* rays_d, int nr_rays, float t_min, float* hit_t, int32_t* hit_slot,
+                       float* hit_uv, int rays_per_wave, void* stream);
 /* vsa_trace_q with the launch order taken from the previous call's measured cost (identical results):
  * every wave files itself, by the trips its walk took, into one of three lists of the NEXT call's
  * order; the next call dispatches the lists first (longest walks first), then everything else in the
@@ -842,6 +850,75 @@ int vsa_reel_next_rays_batch(const float* c2w_all, const float* intrinsics_inv_a
                              uint64_t rng_state, uint64_t rng_inc, int32_t* camera_idx,
                              float* rays_o, float* rays_d, float* gt_rgb, float* gt_mask,
                              float* points_2d, void* stream);
+
+/* ------------------------------------------------------------------------
+ * The training iteration as ONE replayed HIP graph (round 6): device-side control block.
+ *
+ * The reference's loop (volsurfs_py/trainer.py:118-308) changes four things from one iteration to the next that a
+ * launch sequence would carry as kernel ARGUMENTS — the ray count of the dynamic batch (:288-304), the loss
+ * normalisation 1 / (3 n), the learning rate of the warm-up + MultiStepLR schedule (:306-308, schedulers/warmup.py,
+ * base_method.py:71-76) with Adam's step count, and the sampler's random stream (:176-190) — and reads the hit count
+ * back on the host to size the next batch.  Here they live in device memory: every kernel of the iteration runs at
+ * a fixed CAPACITY of rays, the `_ctl` entry points read what varies from this block, and a one-lane kernel at the
+ * end of the iteration (vsa_train_ctl_tick) applies the reference's rules for the next one.  The iteration is then
+ * a static graph: no host read, no host write, no launch gap inside it.
+ * Rays beyond nr_rays (up to the capacity) are DUMMY rays: the sampler points them away from the scene (they hit
+ * nothing: no texel is marked, nothing is shaded), the composite gives them no gradient, the loss does not count them. */
+typedef struct vsa_train_ctl {
+  int32_t iter;            /* 0-based number of the iteration that runs next (= times the schedule has been stepped) */
+  int32_t nr_rays;         /* active rays of that iteration, 1 .. capacity */
+  int32_t capacity;        /* rays every launch is sized for */
+  int32_t adam_step;       /* Adam updates applied or pending so far: the pending one's 1-based step count */
+  float loss_scale;        /* loss_weight / (3 nr_rays): d mean|gt - pred| / d pred, as trainer.train_step forms it */
+  float adam_lr;           /* learning rate of the pending Adam update = lr_at(iteration it belongs to) */
+  float loss;              /* mean |gt - pred| of the last finished iteration (vsa_l1_mean_ctl) */
+  int32_t clamped;         /* how often the dynamic rule asked for more than `capacity` rays (the host re-captures) */
+  uint64_t rng_state, rng_inc;   /* the sampler's PCG32 stream (advanced by 2^32 per iteration, as TensorReel does) */
+  int64_t nr_hits;         /* hits of the last finished iteration (vsa_count_hits writes here) */
+  int32_t target_hits;     /* target_nr_of_training_samples (0: the ray count stays) */
+  int32_t nr_warmup;       /* warm-up iterations of the schedule */
+  int32_t nr_milestones;   /* <= 8 */
+  int32_t milestone[8];    /* MultiStepLR milestones, sorted */
+  float lr_stage[9];       /* (float)(base_lr * gamma^k), k = 0 .. nr_milestones: formed on the host, in double */
+  int32_t adam_pending;    /* 1: an iteration has finished whose update vsa_adam_step_ctl has not applied yet (set by the tick) */
+  double lr_base;          /* base learning rate (the warm-up ramp is lr_base * (it / nr_warmup) in double, as the host's) */
+  double loss_weight;      /* 1 (a data-parallel rank: its share of the global batch) */
+  int64_t sum_rays, sum_hits;    /* running totals over the finished iterations (the tick adds; a bench reads the difference) */
+} vsa_train_ctl;
+
+/* End of an iteration (stream-ordered behind vsa_count_hits / vsa_l1_mean_ctl of that iteration): the pending Adam
+ * update becomes this iteration's (adam_step += 1, adam_lr = lr_at(iter)); nr_rays = int(nr_rays * (target_hits /
+ * nr_hits)) (trainer.py:288-304; clamped to 1 .. capacity, counted in `clamped`); loss_scale follows; iter += 1; the
+ * random stream advances by 2^32.  One lane. */
+int vsa_train_ctl_tick(vsa_train_ctl* ctl, void* stream);
+
+/* vsa_reel_next_rays_batch at a fixed launch size: `capacity` (the host's copy of ctl->capacity: it sizes the grids of
+ * the `_ctl` launches) samples are written, the first
+ * ctl->nr_rays drawn exactly as vsa_reel_next_rays_batch(batch_size = nr_rays) draws them from (ctl->rng_state,
+ * ctl->rng_inc); the rest are dummy rays: origin dummy_o[3], direction dummy_d[3] (host arrays: a ray that misses
+ * every shell), gt_rgb = dummy_rgb[3]. */
+int vsa_reel_next_rays_batch_ctl(const float* c2w_all, const float* intrinsics_inv_all, const float* rgb_all,
+                                 const float* mask_all, int nr_cameras, int height, int width, int capacity,
+                                 int nr_rays_per_pixel, int jitter_pixels, const vsa_train_ctl* ctl,
+                                 const float* dummy_o, const float* dummy_d, const float* dummy_rgb,
+                                 int32_t* camera_idx, float* rays_o, float* rays_d, float* gt_rgb,
+                                 float* gt_mask, float* points_2d, void* stream);
+
+/* vsa_composite_dense_fwd_bwd_l1 over ctl->capacity rays with loss_scale = ctl->loss_scale; rays >= ctl->nr_rays get
+ * zero gradients (their colour is still written). */
+int vsa_composite_dense_fwd_bwd_l1_ctl(const float* surfs_rgb, const float* surfs_alpha, const float* rgb_bg,
+                                       int bg_is_broadcast, const float* gt_rgb, const vsa_train_ctl* ctl,
+                                       float* out_rgb, float* g_surfs_rgb, float* g_surfs_alpha, int capacity,
+                                       int nr_shells, int carry_f16, void* stream);
+
+/* vsa_l1_mean over the first 3 * ctl->nr_rays elements of pred / gt ([capacity, 3]); the mean goes to ctl->loss. */
+int vsa_l1_mean_ctl(const float* pred, const float* gt, int capacity, void* scratch, vsa_train_ctl* ctl, void* stream);
+
+/* vsa_adam_step_shared with lr = ctl->adam_lr and step = ctl->adam_step read on the device (the bias corrections
+ * are formed there, in double); a launch that finds adam_pending == 0 (the first replay of a loop) does nothing. */
+int vsa_adam_step_ctl(const vsa_adam_tensor* tensors_dev, const int32_t* chunks_dev, int nr_chunks, float beta1,
+                      float beta2, float eps, float grad_scale, int zero_grads, int max_workgroups,
+                      const vsa_train_ctl* ctl, void* stream);
 
 /* Re-orders a row-major per-pixel array [height*width, channels] (channels 1..4, f32) into
  * 8x8-pixel-tile-major order (inverse = 0), or back (inverse = 1).  height and width must be

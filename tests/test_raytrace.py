@@ -364,3 +364,26 @@ def test_shells_built_side_by_side_equal_the_sequential_build(monkeypatch):
         assert torch.equal(a.nodes.view(torch.int32), b.nodes.view(torch.int32))          # (bit patterns: unused fields are NaN)
         assert torch.equal(a.qnodes, b.qnodes) and torch.equal(a.tris.view(torch.int32), b.tris.view(torch.int32))
         assert torch.equal(a.slot_face_id, b.slot_face_id)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rays_per_wave", [32, 16, 5])
+def test_narrow_waves_return_the_same_hits_bit_for_bit(rays_per_wave):
+    """vsa_trace_q_narrow (csrc/trace.hip): `rays_per_wave` < 64 rays per 64-lane wave — fewer rays share a wave's
+    divergent walk.  Measured on MI355X (tools/trace_narrow_ab.py): no gain at the training batch (34 000 random rays,
+    K = 5: 0.108 ms -> 0.132), 14 % at 8 000 rays, so RayTracer.NARROW_BELOW is 0 (off) unless
+    VSA_TRACE_NARROW_BELOW sets it; the hits must not depend on it."""
+    from volsurfs_amd.mesh import TensorMesh
+    from volsurfs_amd.raytrace import RayTracer
+    g = np.random.default_rng(9)
+    meshes_np = [icosphere(4, 0.3 + 0.02 * k) for k in range(3)]
+    meshes_np = [((v * (1 + 0.03 * g.standard_normal((v.shape[0], 1)))).astype(np.float32), f) for v, f in meshes_np]
+    rt = RayTracer([TensorMesh(v, f) for v, f in meshes_np], node_format="q16")
+    assert rt.narrow_rays_per_wave(2999, 3) == 64                  # the default: off
+    o, d = _rays(2999, 6)
+    o, d = torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda()
+    ref = [x.clone() for x in rt.trace_all(o, d)]
+    rt.NARROW_BELOW, rt.NARROW_RPW = 1 << 30, rays_per_wave
+    assert rt.narrow_rays_per_wave(2999, 3) == rays_per_wave
+    out = rt.trace_all(o, d)
+    assert (ref[1] >= 0).sum() > 2999 and all(torch.equal(a, b) for a, b in zip(out, ref))

@@ -74,7 +74,16 @@ __device__ __forceinline__ void adam_store4(const vsa_adam_tensor& t, long long 
 
 __global__ __launch_bounds__(ADAM_BLOCK) void adam_kernel(const vsa_adam_tensor* __restrict__ tensors,
                                                           const int2* __restrict__ chunks, AdamCoef coef,
-                                                          int zero_grads, int nr_chunks) {
+                                                          int zero_grads, int nr_chunks,
+                                                          const vsa_train_ctl* __restrict__ ctl) {
+  if (ctl) {       // the graph-replayed iteration (vsa_adam_step_ctl): lr and step count from the control block
+    const int step = ctl->adam_step;
+    if (!ctl->adam_pending || step < 1) return;       // nothing pending (the first replay)
+    const double bc1 = 1.0 - pow((double)coef.beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)coef.beta2, (double)step);
+    coef.step_size = (float)((double)ctl->adam_lr / bc1);
+    coef.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  }
   // one chunk per workgroup, or (vsa_adam_step_shared) a bounded grid whose workgroups stride over the chunks
   for (int c = blockIdx.x; c < nr_chunks; c += gridDim.x) {
     const int2 ck = chunks[c];
@@ -153,7 +162,22 @@ extern "C" int vsa_adam_step_shared(const vsa_adam_tensor* tensors_dev, const in
   const int grid = max_workgroups > 0 && max_workgroups < nr_chunks ? max_workgroups : nr_chunks;
   const AdamCoef coef = {step_size, beta1, beta2, inv_bc2_sqrt, eps, grad_scale};
   hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(ADAM_BLOCK), 0, (hipStream_t)stream,
-                     tensors_dev, reinterpret_cast<const int2*>(chunks_dev), coef, zero_grads, nr_chunks);
+                     tensors_dev, reinterpret_cast<const int2*>(chunks_dev), coef, zero_grads, nr_chunks,
+                     (const vsa_train_ctl*)nullptr);
+  VSA_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int vsa_adam_step_ctl(const vsa_adam_tensor* tensors_dev, const int32_t* chunks_dev, int nr_chunks,
+                                 float beta1, float beta2, float eps, float grad_scale, int zero_grads,
+                                 int max_workgroups, const vsa_train_ctl* ctl, void* stream) {
+  if (max_workgroups < 0 || !ctl) return VSA_ERR_ARG;
+  if (nr_chunks < 0 || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f)) return VSA_ERR_ARG;
+  if (nr_chunks == 0) return VSA_OK;
+  if (!tensors_dev || !chunks_dev) return VSA_ERR_ARG;
+  const int grid = max_workgroups > 0 && max_workgroups < nr_chunks ? max_workgroups : nr_chunks;
+  const AdamCoef coef = {0.f, beta1, beta2, 0.f, eps, grad_scale};       // step_size / inv_bc2_sqrt: formed on the device
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(ADAM_BLOCK), 0, (hipStream_t)stream, tensors_dev,
+                     reinterpret_cast<const int2*>(chunks_dev), coef, zero_grads, nr_chunks, ctl);
   VSA_RETURN_LAUNCH_STATUS();
 }
 

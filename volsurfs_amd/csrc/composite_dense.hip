@@ -204,8 +204,13 @@ __global__ __launch_bounds__(TILE) void composite_dense_bwd_kernel(
     const float* __restrict__ rgb_bg, int bg_bcast, const float* __restrict__ g_rgb,
     float* __restrict__ g_surfs_rgb, float* __restrict__ g_surfs_alpha,
     float* __restrict__ g_rgb_bg, int N, const float* __restrict__ l1_gt, float l1_scale,
-    float* __restrict__ pred_out) {
+    float* __restrict__ pred_out, const vsa_train_ctl* __restrict__ ctl) {
   using L = Lds<K>;
+  int n_active = N;
+  if (ctl) {       // the graph-replayed iteration: the loss normalisation and the active ray count live on the device
+    l1_scale = ctl->loss_scale;
+    n_active = ctl->nr_rays;
+  }
   __shared__ __attribute__((aligned(16))) float s_c[TILE * L::SC];
   __shared__ __attribute__((aligned(16))) float s_a[TILE * L::SA];
   __shared__ __attribute__((aligned(16))) float s_g[TILE * 3];
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(TILE) void composite_dense_bwd_kernel(
       }
       if (l1_gt) {   // g holds the prediction: d mean|gt - pred| / d pred = sign(pred - gt) * scale
         const float d = g[ch] - s_t[r * 3 + ch];
-        g[ch] = d > 0.f ? l1_scale : (d < 0.f ? -l1_scale : 0.f);
+        g[ch] = ray0 + r >= n_active ? 0.f : (d > 0.f ? l1_scale : (d < 0.f ? -l1_scale : 0.f));
       }
     }
     // S_{K-1} = g.bg ; walk inner -> outer side (k = 0 is the innermost shell,
@@ -310,7 +315,8 @@ static int composite_bwd_launch(const float* surfs_rgb, const float* surfs_alpha
                                 const float* rgb_bg, int bg_is_broadcast, const float* g_rgb,
                                 float* g_surfs_rgb, float* g_surfs_alpha, float* g_rgb_bg,
                                 int nr_rays, int nr_shells, int carry_f16, const float* l1_gt,
-                                float l1_scale, void* stream, float* pred_out = nullptr) {
+                                float l1_scale, void* stream, float* pred_out = nullptr,
+                                const vsa_train_ctl* ctl = nullptr) {
   if (nr_rays < 0) return VSA_ERR_ARG;
   if (nr_rays == 0) return VSA_OK;
   if (!surfs_rgb || !surfs_alpha || !rgb_bg || (!g_rgb && !pred_out) || !g_surfs_rgb || !g_surfs_alpha)
@@ -321,11 +327,11 @@ static int composite_bwd_launch(const float* surfs_rgb, const float* surfs_alpha
     if (carry_f16)
       hipLaunchKernelGGL((composite_dense_bwd_kernel<KK, true>), grid, block, 0, st, surfs_rgb,
                          surfs_alpha, rgb_bg, bg_is_broadcast, g_rgb, g_surfs_rgb, g_surfs_alpha,
-                         g_rgb_bg, nr_rays, l1_gt, l1_scale, pred_out);
+                         g_rgb_bg, nr_rays, l1_gt, l1_scale, pred_out, ctl);
     else
       hipLaunchKernelGGL((composite_dense_bwd_kernel<KK, false>), grid, block, 0, st, surfs_rgb,
                          surfs_alpha, rgb_bg, bg_is_broadcast, g_rgb, g_surfs_rgb, g_surfs_alpha,
-                         g_rgb_bg, nr_rays, l1_gt, l1_scale, pred_out);
+                         g_rgb_bg, nr_rays, l1_gt, l1_scale, pred_out, ctl);
   });
   VSA_RETURN_LAUNCH_STATUS();
 }
@@ -361,4 +367,14 @@ extern "C" int vsa_composite_dense_fwd_bwd_l1(const float* surfs_rgb, const floa
   return composite_bwd_launch(surfs_rgb, surfs_alpha, rgb_bg, bg_is_broadcast, nullptr, g_surfs_rgb,
                               g_surfs_alpha, nullptr, nr_rays, nr_shells, carry_f16, gt_rgb,
                               loss_scale, stream, out_rgb);
+}
+
+extern "C" int vsa_composite_dense_fwd_bwd_l1_ctl(const float* surfs_rgb, const float* surfs_alpha,
+                                                  const float* rgb_bg, int bg_is_broadcast, const float* gt_rgb,
+                                                  const vsa_train_ctl* ctl, float* out_rgb, float* g_surfs_rgb,
+                                                  float* g_surfs_alpha, int capacity, int nr_shells, int carry_f16,
+                                                  void* stream) {
+  if (!gt_rgb || !ctl || capacity < 1 || !out_rgb) return VSA_ERR_ARG;
+  return composite_bwd_launch(surfs_rgb, surfs_alpha, rgb_bg, bg_is_broadcast, nullptr, g_surfs_rgb, g_surfs_alpha,
+                              nullptr, capacity, nr_shells, carry_f16, gt_rgb, 0.f, stream, out_rgb, ctl);
 }

@@ -61,6 +61,10 @@ __global__ __launch_bounds__(256) void camera_rays_kernel(
   store_ray(pinhole_ray(c2w, kinv, x, y), x, y, i, rays_o, rays_d, points_2d);
 }
 
+struct ReelDummy {
+  float o[3], d[3], rgb[3];
+};
+
 // sample b: three draws pick (camera, col, row) uniformly; its R rays follow (jittered: two
 // more draws each).  Ground truth is the picked pixel's value whatever the jitter.
 __global__ __launch_bounds__(256) void reel_rays_kernel(
@@ -68,9 +72,31 @@ __global__ __launch_bounds__(256) void reel_rays_kernel(
     const float* __restrict__ rgb_all, const float* __restrict__ mask_all, int C, int H, int W,
     int B, int R, int jitter, unsigned long long rng_state, unsigned long long rng_inc,
     int* __restrict__ camera_idx, float* __restrict__ rays_o, float* __restrict__ rays_d,
-    float* __restrict__ gt_rgb, float* __restrict__ gt_mask, float* __restrict__ points_2d) {
+    float* __restrict__ gt_rgb, float* __restrict__ gt_mask, float* __restrict__ points_2d,
+    const vsa_train_ctl* __restrict__ ctl, ReelDummy dummy) {
   const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (b >= B) return;
+  if (ctl) {      // the graph-replayed iteration (vsa_reel_next_rays_batch_ctl): size and stream from the control block
+    rng_state = ctl->rng_state;
+    rng_inc = ctl->rng_inc;
+    if (b >= ctl->capacity) return;
+    if (b >= ctl->nr_rays) {          // a dummy ray: misses every shell, and no loss is taken on it
+      camera_idx[b] = 0;
+      if (gt_rgb) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gt_rgb[3 * b + c] = dummy.rgb[c];
+      }
+      if (gt_mask) gt_mask[b] = 0.f;
+      for (int s = 0; s < R; ++s) {
+        const long long i = b * R + s;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rays_o[3 * i + c] = dummy.o[c], rays_d[3 * i + c] = dummy.d[c];
+        if (points_2d) points_2d[2 * i] = points_2d[2 * i + 1] = 0.f;
+      }
+      return;
+    }
+  } else if (b >= B) {
+    return;
+  }
   Pcg32 rng{rng_state, rng_inc};
   rng.advance((unsigned long long)b * (unsigned long long)(3 + (jitter ? 2 * R : 0)));
   const int cam = min((int)(rng.next_float() * (float)C), C - 1);
@@ -212,7 +238,27 @@ extern "C" int vsa_reel_next_rays_batch(const float* c2w_all, const float* intri
                      (hipStream_t)stream, c2w_all, intrinsics_inv_all, rgb_all, mask_all, nr_cameras,
                      height, width, batch_size, nr_rays_per_pixel, jitter_pixels,
                      (unsigned long long)rng_state, (unsigned long long)rng_inc, camera_idx, rays_o,
-                     rays_d, gt_rgb, gt_mask, points_2d);
+                     rays_d, gt_rgb, gt_mask, points_2d, (const vsa_train_ctl*)nullptr, ReelDummy{});
+  VSA_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int vsa_reel_next_rays_batch_ctl(const float* c2w_all, const float* intrinsics_inv_all,
+                                            const float* rgb_all, const float* mask_all, int nr_cameras, int height,
+                                            int width, int capacity, int nr_rays_per_pixel, int jitter_pixels,
+                                            const vsa_train_ctl* ctl, const float* dummy_o, const float* dummy_d,
+                                            const float* dummy_rgb, int32_t* camera_idx, float* rays_o,
+                                            float* rays_d, float* gt_rgb, float* gt_mask, float* points_2d,
+                                            void* stream) {
+  if (capacity < 1 || nr_rays_per_pixel < 1 || nr_cameras < 1 || height < 1 || width < 1) return VSA_ERR_ARG;
+  if (!ctl || !dummy_o || !dummy_d || !dummy_rgb || !c2w_all || !intrinsics_inv_all || !camera_idx || !rays_o || !rays_d)
+    return VSA_ERR_ARG;
+  if ((gt_rgb && !rgb_all) || (gt_mask && !mask_all)) return VSA_ERR_ARG;
+  ReelDummy dm;
+  for (int c = 0; c < 3; ++c) dm.o[c] = dummy_o[c], dm.d[c] = dummy_d[c], dm.rgb[c] = dummy_rgb[c];
+  // (`capacity` sizes the grid: the host's copy of ctl->capacity — the kernel trusts the device's)
+  hipLaunchKernelGGL(reel_rays_kernel, dim3(vsa_div_up(capacity, 256)), dim3(256), 0, (hipStream_t)stream, c2w_all,
+                     intrinsics_inv_all, rgb_all, mask_all, nr_cameras, height, width, capacity, nr_rays_per_pixel,
+                     jitter_pixels, 0ull, 0ull, camera_idx, rays_o, rays_d, gt_rgb, gt_mask, points_2d, ctl, dm);
   VSA_RETURN_LAUNCH_STATUS();
 }
 

@@ -75,7 +75,12 @@ __global__ __launch_bounds__(RED_BLOCK) void count_hits_kernel(const int* __rest
 }
 
 __global__ __launch_bounds__(RED_BLOCK) void l1_mean_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                            long long n, RedScratch* sc, float* __restrict__ out) {
+                                                            long long n, RedScratch* sc, float* __restrict__ out,
+                                                            vsa_train_ctl* __restrict__ ctl) {
+  if (ctl) {        // the graph-replayed iteration: the active elements and the result live in the control block
+    n = 3ll * ctl->nr_rays;
+    out = &ctl->loss;
+  }
   double s = 0.0;
   const long long n4 = n >> 2;
   const float4* a4 = reinterpret_cast<const float4*>(a);
@@ -116,6 +121,17 @@ extern "C" int vsa_l1_mean(const float* pred, const float* gt, long long n, void
       (reinterpret_cast<uintptr_t>(scratch) & 7))
     return VSA_ERR_ARG;
   hipLaunchKernelGGL(l1_mean_kernel, dim3(red_grid(n)), dim3(RED_BLOCK), 0, (hipStream_t)stream, pred, gt, n,
-                     static_cast<RedScratch*>(scratch), out);
+                     static_cast<RedScratch*>(scratch), out, (vsa_train_ctl*)nullptr);
+  VSA_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int vsa_l1_mean_ctl(const float* pred, const float* gt, int capacity, void* scratch, vsa_train_ctl* ctl,
+                               void* stream) {
+  if (capacity < 1 || !pred || !gt || !scratch || !ctl) return VSA_ERR_ARG;
+  if (((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(gt)) & 15) ||
+      (reinterpret_cast<uintptr_t>(scratch) & 7))
+    return VSA_ERR_ARG;
+  hipLaunchKernelGGL(l1_mean_kernel, dim3(red_grid(3ll * capacity)), dim3(RED_BLOCK), 0, (hipStream_t)stream, pred, gt,
+                     3ll * capacity, static_cast<RedScratch*>(scratch), (float*)nullptr, ctl);
   VSA_RETURN_LAUNCH_STATUS();
 }

@@ -234,11 +234,16 @@ template <int STACK>
 __global__ __launch_bounds__(TRACE_BLOCK) void trace_q_kernel(
     const uint4* __restrict__ qnodes, const float4* __restrict__ tris, Roots roots, Frames frames,
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, int N, float t_min,
-    float* __restrict__ hit_t, int* __restrict__ hit_slot, float* __restrict__ hit_uv) {
+    float* __restrict__ hit_t, int* __restrict__ hit_slot, float* __restrict__ hit_uv, int rpw) {
   __shared__ int s_stack[STACK][TRACE_BLOCK];
   const int lane = threadIdx.x;
 #ifndef TRACE_SPAN
-  const long long n = (long long)blockIdx.x * TRACE_BLOCK + lane;
+  // rpw (rays per wave) < 64: NARROW waves for small batches (vsa_trace_q_narrow) — lanes >= rpw sit out.  A wave walks
+  // until its slowest ray is done, and a batch of a few ten thousand incoherent rays (a training batch) is a few
+  // waves per SIMD each carrying the maximum of 64 unrelated walks: with 16 rays per wave the chains are shorter and
+  // there are four times as many waves to hide their latency behind.  Same rays, same walks, same hits.
+  if (lane >= rpw) return;
+  const long long n = (long long)blockIdx.x * rpw + lane;
   const int mesh = blockIdx.y;
 #else
   int item = blockIdx.y * gridDim.x + blockIdx.x;
@@ -657,12 +662,14 @@ extern "C" int vsa_trace(const float* nodes, const float* tris, const int32_t* m
   VSA_RETURN_LAUNCH_STATUS();
 }
 
-extern "C" int vsa_trace_q(const uint32_t* qnodes, const float* tris, const int32_t* mesh_roots,
-                           const float* mesh_frames, int nr_meshes, int max_depth,
-                           const float* rays_o, const float* rays_d, int nr_rays, float t_min,
-                           float* hit_t, int32_t* hit_slot, float* hit_uv, void* stream) {
+extern "C" int vsa_trace_q_narrow(const uint32_t* qnodes, const float* tris, const int32_t* mesh_roots,
+                                  const float* mesh_frames, int nr_meshes, int max_depth,
+                                  const float* rays_o, const float* rays_d, int nr_rays, float t_min,
+                                  float* hit_t, int32_t* hit_slot, float* hit_uv, int rays_per_wave,
+                                  void* stream) {
   if (nr_meshes < 1 || nr_meshes > VSA_MAX_SHELLS || nr_rays < 0 || !mesh_roots || !mesh_frames)
     return VSA_ERR_ARG;
+  if (rays_per_wave < 1 || rays_per_wave > TRACE_BLOCK) return VSA_ERR_ARG;
   if (max_depth >= TRACE_STACK) return VSA_ERR_UNSUPPORTED;
   if (nr_rays == 0) return VSA_OK;
   if (!qnodes || !tris || !rays_o || !rays_d || !hit_t || !hit_slot || !hit_uv) return VSA_ERR_ARG;
@@ -672,16 +679,24 @@ extern "C" int vsa_trace_q(const uint32_t* qnodes, const float* tris, const int3
     r.root[i] = i < nr_meshes ? mesh_roots[i] : 0;
     for (int j = 0; j < 6; ++j) fr.f[i][j] = i < nr_meshes ? mesh_frames[6 * i + j] : 1.0f;
   }
-  dim3 grid(vsa_div_up(nr_rays, TRACE_BLOCK), nr_meshes), block(TRACE_BLOCK);
+  dim3 grid(vsa_div_up(nr_rays, rays_per_wave), nr_meshes), block(TRACE_BLOCK);
   if (max_depth < 24)
     hipLaunchKernelGGL(trace_q_kernel<24>, grid, block, 0, (hipStream_t)stream,
                        reinterpret_cast<const uint4*>(qnodes), reinterpret_cast<const float4*>(tris),
-                       r, fr, rays_o, rays_d, nr_rays, t_min, hit_t, hit_slot, hit_uv);
+                       r, fr, rays_o, rays_d, nr_rays, t_min, hit_t, hit_slot, hit_uv, rays_per_wave);
   else
     hipLaunchKernelGGL(trace_q_kernel<TRACE_STACK>, grid, block, 0, (hipStream_t)stream,
                        reinterpret_cast<const uint4*>(qnodes), reinterpret_cast<const float4*>(tris),
-                       r, fr, rays_o, rays_d, nr_rays, t_min, hit_t, hit_slot, hit_uv);
+                       r, fr, rays_o, rays_d, nr_rays, t_min, hit_t, hit_slot, hit_uv, rays_per_wave);
   VSA_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int vsa_trace_q(const uint32_t* qnodes, const float* tris, const int32_t* mesh_roots,
+                           const float* mesh_frames, int nr_meshes, int max_depth,
+                           const float* rays_o, const float* rays_d, int nr_rays, float t_min,
+                           float* hit_t, int32_t* hit_slot, float* hit_uv, void* stream) {
+  return vsa_trace_q_narrow(qnodes, tris, mesh_roots, mesh_frames, nr_meshes, max_depth, rays_o, rays_d, nr_rays, t_min,
+                            hit_t, hit_slot, hit_uv, TRACE_BLOCK, stream);
 }
 
 // Feedback buffer of vsa_trace_q_fb: two halves (written / read alternately) at offsets 0 and H, then

@@ -144,7 +144,15 @@ class RayTracer:
         hit_t = torch.empty(K, N, device=rays_o.device)
         hit_slot = torch.empty(K, N, dtype=torch.int32, device=rays_o.device)
         hit_uv = torch.empty(K, N, 2, device=rays_o.device)
-        if self.node_format == "q16" and self.cost_feedback and self.max_depth < 48:
+        # small batches (a training batch's few ten thousand random rays: ~2 waves per SIMD, each the maximum of 64
+        # unrelated walks): narrow waves — fewer rays per wave, more waves (vsa_trace_q_narrow; same hits).  The launch-order
+        # feedback has nothing to learn from random rays (profiles/NOTEBOOK.md round 5)
+        rpw = self.narrow_rays_per_wave(N, K) if self.node_format == "q16" else 64
+        if rpw < 64:
+            _lib.call("vsa_trace_q_narrow", self.qnodes, self.tris, self._roots, self._frames, K,
+                      self.max_depth, rays_o, rays_d, N, float(t_min), hit_t, hit_slot, hit_uv, int(rpw),
+                      _lib.stream_ptr())
+        elif self.node_format == "q16" and self.cost_feedback and self.max_depth < 48:
             if self._fb is None or self._fb[1] < N or self._fb[0].device != rays_o.device:   # grows only
                 fn = _lib.lib().vsa_trace_feedback_bytes
                 fn.restype = ctypes.c_longlong
@@ -165,6 +173,15 @@ class RayTracer:
             _lib.call("vsa_trace", self.nodes, self.tris, self._roots, K, self.max_depth, rays_o,
                       rays_d, N, float(t_min), hit_t, hit_slot, hit_uv, _lib.stream_ptr())
         return hit_t, hit_slot, hit_uv
+
+    # narrow waves (vsa_trace_q_narrow: NARROW_RPW rays per 64-lane wave) below this many (ray, shell) walks; 0 = never.
+    # Measured on MI355X (tools/trace_narrow_ab.py, profiles/r06/trace_narrow_ab.txt): 34 000 random rays x 5 shells
+    # 0.108 ms -> 0.132 (worse), 8 000 rays 0.080 -> 0.069 at 8 per wave: off by default, the hits do not depend on it
+    NARROW_BELOW = int(os.environ.get("VSA_TRACE_NARROW_BELOW", "0"))
+    NARROW_RPW = int(os.environ.get("VSA_TRACE_RPW", "16"))
+
+    def narrow_rays_per_wave(self, N, K):
+        return self.NARROW_RPW if N * K < self.NARROW_BELOW else 64
 
     def walk_stats(self, rays_o, rays_d, t_min=0.0):
         """{lane_visits, tri_tests, wave_trips, waves, max_wave_trips} of one traversal of these rays

@@ -311,3 +311,185 @@ class Profiler:
 
     def reset(self):
         self._open, self._pairs = {}, {}
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# The training iteration as ONE replayed HIP graph (round 6; include/volsurfs_hip.h: vsa_train_ctl)
+import ctypes as _ct
+
+
+class TrainCtl(_ct.Structure):
+    """Mirror of `vsa_train_ctl` (include/volsurfs_hip.h)."""
+    _fields_ = [("iter", _ct.c_int32), ("nr_rays", _ct.c_int32), ("capacity", _ct.c_int32), ("adam_step", _ct.c_int32),
+                ("loss_scale", _ct.c_float), ("adam_lr", _ct.c_float), ("loss", _ct.c_float), ("clamped", _ct.c_int32),
+                ("rng_state", _ct.c_uint64), ("rng_inc", _ct.c_uint64), ("nr_hits", _ct.c_int64),
+                ("target_hits", _ct.c_int32), ("nr_warmup", _ct.c_int32), ("nr_milestones", _ct.c_int32),
+                ("milestone", _ct.c_int32 * 8), ("lr_stage", _ct.c_float * 9), ("adam_pending", _ct.c_int32),
+                ("lr_base", _ct.c_double), ("loss_weight", _ct.c_double), ("sum_rays", _ct.c_int64), ("sum_hits", _ct.c_int64)]
+
+
+class GraphTrainLoop:
+    """trainer.py:118-308 for the neural-texture method with a constant background, as ONE HIP graph per iteration.
+
+    The eager loop (`train_step_from_reel`) issues ~20 dependent launches per iteration from Python and reads the hit
+    count back to size the next batch; at the reference's batch (49 152 hits) its host side and the launch gaps between
+    its kernels are as long as the kernels themselves (profiles/r06/train_host_floor.txt).  Here every launch runs at a
+    fixed `capacity` of rays — the sampler fills the rays beyond the iteration's count with rays that miss the scene —
+    and what changes from one iteration to the next lives in a device control block that a one-lane kernel advances by
+    the reference's own rules (vsa_train_ctl_tick: dynamic ray count, warm-up + MultiStepLR, Adam's step count, the
+    sampler's stream).  The Adam update of iteration i runs at the head of iteration i + 1's graph on a side stream,
+    beside the ray batch, traversal and texel compaction that read no parameter.  `step()` is one graph replay: no host
+    read, no host write.
+
+    Same batches, same rays, same learning rates as the eager loop from the same state (tests/test_train_graph.py);
+    parameters agree up to the order of the gradient atomics, as two eager runs do."""
+
+    def __init__(self, method, reel, nr_rays, target_nr_of_training_samples, iter_nr=0, capacity=None,
+                 jitter_pixels=True, loss_weight=1.0):
+        from . import _lib
+        from .optim import FusedAdam
+        from .schedulers import lr_at
+        if not method.supports_fused_step(None, False) or not getattr(method, "using_neural_textures", False):
+            raise _lib.VolsurfsHipError("GraphTrainLoop: neural-texture method with a constant background only")
+        opt = method.optimizer
+        if type(opt) is not FusedAdam or len(opt.param_groups) != 1:
+            raise _lib.VolsurfsHipError("GraphTrainLoop: one FusedAdam parameter group (not the sharded optimiser)")
+        if reel.masks is not None:
+            raise _lib.VolsurfsHipError("GraphTrainLoop: unmasked training only")
+        self.method, self.reel, self.jitter = method, reel, bool(jitter_pixels)
+        dev = method.bank.tables.device
+        n = int(nr_rays)
+        if capacity is None:      # headroom for the dynamic count's fluctuation; a multiple of 4 096
+            capacity = min(int(method.max_rays), (int(n * 1.25) + 4096 + 4095) // 4096 * 4096)
+        self.capacity = int(capacity)
+        if not 1 <= n <= self.capacity <= method.max_rays:
+            raise _lib.VolsurfsHipError(f"GraphTrainLoop: 1 <= nr_rays {n} <= capacity {self.capacity} <= max_rays")
+        g = opt.param_groups[0]
+        base_lr = float(g.get("initial_lr", method.lr))
+        ms = sorted(int(m) for m in method.lr_milestones)[:8]
+        gamma = float(getattr(method.scheduler_lr_decay, "gamma", 0.3))
+        c = TrainCtl()
+        c.iter, c.nr_rays, c.capacity, c.adam_step = int(iter_nr), n, self.capacity, int(g.get("step", 0))
+        c.loss_scale = float(loss_weight) / (3.0 * n)
+        c.rng_state, c.rng_inc = reel.rng.state, reel.rng.inc
+        c.target_hits = int(target_nr_of_training_samples or 0)
+        c.nr_warmup, c.nr_milestones = int(method.nr_warmup_iters), len(ms)
+        for i, m_ in enumerate(ms):
+            c.milestone[i] = m_
+        for k in range(len(ms) + 1):
+            c.lr_stage[k] = base_lr * gamma ** k           # (double -> float, as the eager loop's c_float(group["lr"]))
+        c.lr_base, c.loss_weight = base_lr, float(loss_weight)
+        self._host = c
+        self.ctl = torch.frombuffer(bytearray(bytes(c)), dtype=torch.uint8).to(dev)
+        off = TrainCtl.nr_hits.offset
+        self._hits_out = self.ctl[off:off + 8].view(torch.int64)
+        fn = _lib.lib().vsa_reduce_scratch_bytes
+        fn.restype = _ct.c_longlong
+        self._scr_hits = torch.zeros(int(fn()), dtype=torch.uint8, device=dev)
+        self._scr_loss = torch.zeros(int(fn()), dtype=torch.uint8, device=dev)
+        # a ray that misses every shell: from the first camera's centre, straight away from the scene's centre
+        o = reel.c2w[0, :, 3].detach().cpu().double()
+        d = o / o.norm() if float(o.norm()) > 0 else torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64)
+        self._dummy = [(_ct.c_float * 3)(*[float(v) for v in x]) for x in
+                       (o, d, method.bg_color.reshape(3).detach().cpu())]
+        self._side = torch.cuda.Stream(device=dev)
+        self.graph = None
+        self._lr_at = lambda it: lr_at(it, base_lr, int(method.nr_warmup_iters), ms, gamma)
+        opt._plan(0, g)                    # descriptors exist before anything is captured
+        if not opt.grads_are_clean():
+            opt.zero_grad()
+        method.bank._ensure_grads()
+
+    # -- one iteration: what a replay runs
+    def _iteration(self):
+        from . import _lib
+        m, bank, opt, cap = self.method, self.method.bank, self.method.optimizer, self.capacity
+        reel, ctl = self.reel, self.ctl
+        dev = ctl.device
+        main = torch.cuda.current_stream()
+        g = opt.param_groups[0]
+        _, desc, ck, nck, _ = opt._plan(0, g)
+        b1, b2 = g["betas"]
+        # the update of the PREVIOUS iteration beside this iteration's parameter-free head
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            _lib.call("vsa_adam_step_ctl", desc, ck, nck, float(b1), float(b2), float(g["eps"]), 1.0, 1,
+                      int(opt.shared_workgroups), ctl, _ct.c_void_p(self._side.cuda_stream))
+        cam = torch.empty(cap, dtype=torch.int32, device=dev)
+        o, d, gt = (torch.empty(cap, 3, device=dev) for _ in range(3))
+        _lib.call("vsa_reel_next_rays_batch_ctl", reel.c2w, reel.intrinsics_inv, reel.rgbs, None, reel.nr_cameras,
+                  reel.height, reel.width, cap, 1, self.jitter, ctl, self._dummy[0], self._dummy[1], self._dummy[2],
+                  cam, o, d, gt, None, None, _lib.stream_ptr())
+        hit_t, hit_slot, hit_uv = m._trace_now(o, d)
+        _lib.call("vsa_count_hits", hit_slot, _ct.c_longlong(hit_slot.numel()), self._scr_hits, self._hits_out,
+                  _lib.stream_ptr())
+        tex_uv = bank.mark_and_compact(hit_slot, hit_uv, m.face_uvs)
+        main.wait_stream(self._side)            # the parameters (and their f16 copies) are final; the gradients are zero
+        bank.evaluate()
+        act = torch.empty(m.nr_meshes, cap, 4, device=dev)
+        tris = m.raytracer.tris
+        rgb_k, alpha_k, _, _ = bank.shade(hit_slot, tex_uv, d, tris, act_out=act)
+        rgb = torch.empty(cap, 3, device=dev)
+        g_c, g_a = torch.empty_like(rgb_k), torch.empty_like(alpha_k)
+        _lib.call("vsa_composite_dense_fwd_bwd_l1_ctl", rgb_k, alpha_k, m.bg_color, True, gt, ctl, rgb, g_c, g_a, cap,
+                  m.nr_meshes, 0, _lib.stream_ptr())
+        # (the f16 gradient chain's scale is any constant the kernels divide out again: the capacity's)
+        from .pipeline import GRAD_CHAIN_GAIN
+        scale = m.grad_scale if m.grad_scale is not None else GRAD_CHAIN_GAIN * float(cap)
+        bank.backward(hit_slot, tex_uv, d, tris, g_c, g_a, scale, act, grads_zeroed=True)
+        _lib.call("vsa_l1_mean_ctl", rgb, gt, cap, self._scr_loss, ctl, _lib.stream_ptr())
+        _lib.call("vsa_train_ctl_tick", ctl, _lib.stream_ptr())
+
+    def capture(self, warm_iterations=2):
+        """`warm_iterations` real iterations run eagerly first (every lazily allocated buffer exists afterwards), then one
+        iteration is captured — a capture pass only records."""
+        from .pipeline import _CAPTURE_MODE, _no_gc
+        m = self.method
+        m.is_training = True
+        opt = m.optimizer
+        opt.mark_grads_dirty()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(int(warm_iterations)):
+                self._iteration()
+        torch.cuda.current_stream().wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        with _no_gc(), torch.cuda.graph(self.graph, capture_error_mode=_CAPTURE_MODE):
+            self._iteration()
+        return self
+
+    def step(self):
+        self.graph.replay()
+
+    def read(self):
+        """The control block as it stands on the device (synchronises): iter, nr_rays, nr_hits, loss, lr, clamped."""
+        c = TrainCtl.from_buffer_copy(bytes(self.ctl.cpu().numpy().tobytes()))
+        return {"iter": c.iter, "nr_rays": c.nr_rays, "nr_hits": c.nr_hits, "loss": c.loss, "adam_step": c.adam_step,
+                "adam_lr": c.adam_lr, "clamped": c.clamped, "capacity": c.capacity, "rng_state": c.rng_state,
+                "sum_rays": c.sum_rays, "sum_hits": c.sum_hits}
+
+    def finish(self):
+        """Apply the last iteration's pending update and hand the loop's state back to the host objects (optimiser step
+        count and lr, scheduler position, the reel's stream), so that eager training, checkpoints or another loop can go on."""
+        from . import _lib
+        m, opt = self.method, self.method.optimizer
+        g = opt.param_groups[0]
+        _, desc, ck, nck, _ = opt._plan(0, g)
+        b1, b2 = g["betas"]
+        _lib.call("vsa_adam_step_ctl", desc, ck, nck, float(b1), float(b2), float(g["eps"]), 1.0, 1, 0, self.ctl,
+                  _lib.stream_ptr())
+        off = TrainCtl.adam_pending.offset
+        self.ctl[off:off + 4].zero_()
+        st = self.read()
+        g["step"] = int(st["adam_step"])
+        sched = getattr(m, "lr_scheduler", None)
+        if sched is not None and hasattr(sched, "it"):
+            sched.it = int(st["iter"])
+            sched._apply()
+        else:
+            g["lr"] = self._lr_at(int(st["iter"]))
+        self.reel.rng.state = int(st["rng_state"])
+        opt._note_clean()
+        m.last_nr_samples = int(st["nr_hits"])
+        return st
