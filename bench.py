@@ -216,16 +216,19 @@ def trace_ceiling(pipe, trace_ms, args, nr_cus=256):
 
 
 def kernel_table(fn, iters):
-    """Per C-ABI entry point: ms per iteration and calls per iteration over `iters` calls of fn(), events directly
-    around every library launch (the torch glue in between is not in it)."""
+    """Per C-ABI entry point: ms per iteration (median call x calls per iteration) over `iters` calls of fn(), events
+    directly around every library launch (the torch glue in between is not in it)."""
     from volsurfs_amd import _lib
     _lib.kernel_events = {}
     for _ in range(iters):
         fn()
-    tot = _lib.kernel_totals()
+    tot, med = _lib.kernel_totals(), _lib.kernel_ms()
     _lib.kernel_events = None
-    return {k: {"ms_per_iter": round(ms / iters, 4), "calls_per_iter": round(n / iters, 2)}
-            for k, (ms, n) in sorted(tot.items(), key=lambda kv: -kv[1][0])}
+    # median per call x calls per iteration: over three iterations ONE call that carried a first-use cost (a lazily
+    # built descriptor, a rebalance) owned the mean — r5's training line quoted nt_mlp_bwd at 0.21 ms where the
+    # workgroups' own clocks and rocprof say 0.09-0.105 (profiles/r06/mlp_bwd_train_stamps.txt)
+    return {k: {"ms_per_iter": round(med[k] * n / iters, 4), "calls_per_iter": round(n / iters, 2)}
+            for k, (ms, n) in sorted(tot.items(), key=lambda kv: -med[kv[0]] * kv[1][1])}
 
 
 def cpu_baseline(pipe, sample_rays):

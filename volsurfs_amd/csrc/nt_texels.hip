@@ -245,6 +245,80 @@ __global__ __launch_bounds__(1024) void nt_assign_kernel(vsa_nt_plan plan,
   if (SPARSE && word) marks[vec] = 0;
 }
 
+// The SPARSE pass C with ONE WAVE per 4096-texel block (vsa_nt_compact_frame): a block is one dependent chain —
+// prefix + marks in, scan, slots out — and with a 1024-thread workgroup per block only 2 chains per CU are in
+// flight: 48 us for the 6.8 k blocks of a training batch (~115 marks per block), 3.6 us per block on a CU, all of
+// it round trips (rocprofv3, profiles/r06/train_graph_timeline.txt; several blocks per workgroup one after the
+// other: slower still).  A wave takes the block alone: lane l owns the 4-texel groups 64 k + l, k = 0 .. 15 (every
+// load a contiguous 256 B), all 16 mark words are requested up front, the slot numbers come from 16 DPP scans with a
+// running total — no LDS, no barrier, 32 chains per CU.
+__global__ __launch_bounds__(256) void nt_assign_wave_kernel(vsa_nt_plan plan, unsigned* __restrict__ marks,
+                                                             const int* __restrict__ block_prefix,
+                                                             int4* __restrict__ slot_of,
+                                                             int* __restrict__ texel_of_slot,
+                                                             float2* __restrict__ slot_xy,
+                                                             long long slot_capacity, int nr_blocks) {
+  const int lane = threadIdx.x & 63;
+  const int blk = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blk >= nr_blocks) return;
+  const int first = block_prefix[blk];
+  if (block_prefix[blk + 1] == first) return;       // untouched: nothing to clear, no slot to write
+  const long long vec0 = (long long)blk * 1024 + lane;
+  unsigned w[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) w[k] = marks[vec0 + 64 * k];
+  const long long blk0 = (long long)blk * NT_DOM_BLOCK;
+  int sd = 0;
+  const int nseg = plan.nr_shells * VSA_NT_MAX_DEG;
+  while (sd + 1 < nseg && plan.dom_off[sd + 1] <= blk0) ++sd;
+  const int R = plan.tex_res[sd % VSA_NT_MAX_DEG], W = R + 2;
+  const float Rf = (float)R, inv_R = 1.0f / Rf, inv_W = 1.0f / (float)W;
+  const bool pow2 = (R & (R - 1)) == 0;
+  const long long dom0 = plan.dom_off[sd];
+  int run = first;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const unsigned word = w[k] & 0x01010101u;
+    const int c = __popc(word);
+    const int incl = nt_wave_incl_scan(c);
+    int slot = run + incl - c;
+    run += __builtin_amdgcn_readlane(incl, 63);
+    if (!word) continue;
+    const long long vec = vec0 + 64 * k;
+    const int local0 = (int)(vec * 4 - dom0);
+    int iy, ix;
+    if (local0 < (1 << 24)) {      // exact in fp32, off by at most one row (as nt_assign_kernel)
+      iy = (int)((float)local0 * inv_W);
+      ix = local0 - iy * W;
+      if (ix < 0) --iy, ix += W;
+      else if (ix >= W) ++iy, ix -= W;
+    } else {
+      iy = local0 / W;
+      ix = local0 - iy * W;
+    }
+    int out[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool m = (word >> (8 * i)) & 1u;
+      out[i] = m ? slot : -1;
+      if (m) {
+        if (slot < slot_capacity) {
+          if (texel_of_slot) texel_of_slot[slot] = (int)(vec * 4 + i);
+          const float cx = (float)(ix - 1) + 0.5f, cy = (float)(iy - 1) + 0.5f;
+          slot_xy[slot] = pow2 ? make_float2(cx * inv_R, cy * inv_R) : make_float2(cx / Rf, cy / Rf);
+        }
+        ++slot;
+      }
+      if (++ix == W) {
+        ix = 0;
+        ++iy;
+      }
+    }
+    slot_of[vec] = make_int4(out[0], out[1], out[2], out[3]);
+    marks[vec] = 0;
+  }
+}
+
 }  // namespace
 
 static int plan_check(const vsa_nt_plan* p) {
@@ -301,9 +375,9 @@ static int nt_compact(const vsa_nt_plan* plan, uint8_t* marks, int32_t* slot_of,
   hipLaunchKernelGGL(nt_scan_blocks_kernel, dim3(sparse && plan->balance ? 1 + NT_BAL_KERNELS : 1), dim3(1024), 0, st,
                      *plan, block_scratch, nr_blocks, seg_start);
   if (sparse)
-    hipLaunchKernelGGL(nt_assign_kernel<true>, dim3(nr_blocks), dim3(1024), 0, st, *plan,
+    hipLaunchKernelGGL(nt_assign_wave_kernel, dim3(vsa_div_up(nr_blocks, 4)), dim3(256), 0, st, *plan,
                        reinterpret_cast<unsigned*>(marks), block_scratch, reinterpret_cast<int4*>(slot_of),
-                       texel_of_slot, reinterpret_cast<float2*>(slot_xy), (long long)plan->slot_capacity);
+                       texel_of_slot, reinterpret_cast<float2*>(slot_xy), (long long)plan->slot_capacity, nr_blocks);
   else
     hipLaunchKernelGGL(nt_assign_kernel<false>, dim3(nr_blocks), dim3(1024), 0, st, *plan,
                        reinterpret_cast<unsigned*>(marks), block_scratch, reinterpret_cast<int4*>(slot_of),

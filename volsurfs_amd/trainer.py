@@ -4,6 +4,8 @@ backward -> optimiser step -> dynamic ray count -> lr scheduler, and the loop ar
 the reference's callback hooks (`train`).  Logging, checkpoints and evaluation (the rest of
 trainer.py) are outside SURVEY §8 and live in the callbacks.
 """
+import os
+
 import torch
 
 
@@ -393,6 +395,7 @@ class GraphTrainLoop:
         self._dummy = [(_ct.c_float * 3)(*[float(v) for v in x]) for x in
                        (o, d, method.bg_color.reshape(3).detach().cpu())]
         self._side = torch.cuda.Stream(device=dev)
+        self.adam_beside_head = os.environ.get("VSA_TRAIN_GRAPH_ADAM_SIDE", "1") != "0"
         self.graph = None
         self._lr_at = lambda it: lr_at(it, base_lr, int(method.nr_warmup_iters), ms, gamma)
         opt._plan(0, g)                    # descriptors exist before anything is captured
@@ -411,10 +414,14 @@ class GraphTrainLoop:
         _, desc, ck, nck, _ = opt._plan(0, g)
         b1, b2 = g["betas"]
         # the update of the PREVIOUS iteration beside this iteration's parameter-free head
-        self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):
-            _lib.call("vsa_adam_step_ctl", desc, ck, nck, float(b1), float(b2), float(g["eps"]), 1.0, 1,
-                      int(opt.shared_workgroups), ctl, _ct.c_void_p(self._side.cuda_stream))
+        if self.adam_beside_head:
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                _lib.call("vsa_adam_step_ctl", desc, ck, nck, float(b1), float(b2), float(g["eps"]), 1.0, 1,
+                          int(opt.shared_workgroups), ctl, _ct.c_void_p(self._side.cuda_stream))
+        else:
+            _lib.call("vsa_adam_step_ctl", desc, ck, nck, float(b1), float(b2), float(g["eps"]), 1.0, 1, 0, ctl,
+                      _lib.stream_ptr())
         cam = torch.empty(cap, dtype=torch.int32, device=dev)
         o, d, gt = (torch.empty(cap, 3, device=dev) for _ in range(3))
         _lib.call("vsa_reel_next_rays_batch_ctl", reel.c2w, reel.intrinsics_inv, reel.rgbs, None, reel.nr_cameras,
@@ -424,7 +431,8 @@ class GraphTrainLoop:
         _lib.call("vsa_count_hits", hit_slot, _ct.c_longlong(hit_slot.numel()), self._scr_hits, self._hits_out,
                   _lib.stream_ptr())
         tex_uv = bank.mark_and_compact(hit_slot, hit_uv, m.face_uvs)
-        main.wait_stream(self._side)            # the parameters (and their f16 copies) are final; the gradients are zero
+        if self.adam_beside_head:
+            main.wait_stream(self._side)        # the parameters (and their f16 copies) are final; the gradients are zero
         bank.evaluate()
         act = torch.empty(m.nr_meshes, cap, 4, device=dev)
         tris = m.raytracer.tris
