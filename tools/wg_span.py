@@ -6,7 +6,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from volsurfs_amd import _lib
 from volsurfs_amd.pipeline import KShellPipeline
 import os
-p = KShellPipeline.synthetic(res=int(os.environ.get("SPAN_RES", "800")))
+if os.environ.get("SPAN_RAYS"):        # a training batch: that many random rays of the 800 x 800 view (tools/wg_timeline_train.py)
+    from volsurfs_amd.camera import pinhole_rays
+    from volsurfs_amd.mesh import nested_shells
+    n = int(os.environ["SPAN_RAYS"])
+    o, d = pinhole_rays(800, 800, focal=1111.1, cam_pos=(0.0, 0.0, -1.5))
+    g = torch.Generator(device="cuda").manual_seed(0)
+    idx = torch.randperm(o.shape[0], device="cuda", generator=g)[:n]
+    p = KShellPipeline(nested_shells(K=5, subdiv=6), o[idx].contiguous(), d[idx].contiguous(),
+                       torch.rand(n, 3, device="cuda", generator=g))
+else:
+    p = KShellPipeline.synthetic(res=int(os.environ.get("SPAN_RES", "800")))
 for _ in range(3):
     p.step()
 torch.cuda.synchronize()
