@@ -188,6 +188,17 @@ int vsa_trace_q_fb(const uint32_t* qnodes, const float* tris, const int32_t* mes
                    const float* mesh_frames, int nr_meshes, int max_depth, const float* rays_o,
                    const float* rays_d, int nr_rays, float t_min, float* hit_t, int32_t* hit_slot,
                    float* hit_uv, void* feedback, long long feedback_bytes, int phase, void* stream);
+/* The cooperative finish of vsa_trace_q_fb (same call site, volsurfs.py:476-485): a wave walks one ray per lane until
+ * its slowest ray is done — a grazing ray takes 100-360 trips of the walk against a median of 9, and a small launch is
+ * as long as its longest wave.  In launches of at most `max_waves` waves (nr_meshes x ceil(nr_rays / 64): training
+ * batches; larger launches keep the plain walk, whose register budget holds five waves per SIMD) a wave looks every
+ * `chunk` trips at how many of its lanes are still walking, and once they are at most `lanes` the WHOLE wave finishes
+ * those rays together: their pending subtrees go into a queue of (node, ray) entries, every lane takes one entry per
+ * round and appends the children that survive.  The hits are bit for bit those of the plain walk (the closest hit is
+ * a minimum over (t, face id); a stale bound only visits more).  Process-wide setting, defaults 16 / 24 / 4096
+ * (environment VSA_TRACE_COOP="chunk,lanes", VSA_TRACE_COOP_WAVES); lanes = 0 switches it off.  Returns
+ * VSA_ERR_ARG for chunk < 1, lanes outside 0..64 or max_waves < 0. */
+int vsa_trace_coop_config(int chunk, int lanes, long long max_waves);
 /* Measurement aid (bench.py's stage_roofline.trace; not on the product path): the walk of vsa_trace_q with
  * counters.  stats (device, 5 x u64, overwritten): lane-level node visits (one 32-byte node fetch each),
  * lane-level triangle tests (48 bytes each), wave-level trips of the walk loop summed over the waves (one trip =

@@ -387,3 +387,45 @@ def test_narrow_waves_return_the_same_hits_bit_for_bit(rays_per_wave):
     assert rt.narrow_rays_per_wave(2999, 3) == rays_per_wave
     out = rt.trace_all(o, d)
     assert (ref[1] >= 0).sum() > 2999 and all(torch.equal(a, b) for a, b in zip(out, ref))
+
+
+@pytest.mark.gpu
+def test_cooperative_finish_returns_the_same_hits_bit_for_bit():
+    """vsa_trace_coop_config / q_finish_coop (csrc/trace.hip): in small launches a wave hands the pending subtrees of
+    its last rays to all 64 lanes.  Shells with grazing rays (long walks), rays from inside and outside, every
+    setting from 'finish at once' (all 64 lanes after one trip) to off: the hits are those of the brute-force oracle
+    and of the plain walk, bit for bit, and a launch above max_waves takes the plain walk."""
+    from volsurfs_amd.mesh import TensorMesh
+    from volsurfs_amd.raytrace import RayTracer
+    g = np.random.default_rng(11)
+    meshes_np = [icosphere(5, 0.3 + 0.02 * k) for k in range(3)]
+    meshes_np = [((v * (1 + 0.05 * g.standard_normal((v.shape[0], 1)))).astype(np.float32), f) for v, f in meshes_np]
+    rt = RayTracer([TensorMesh(v, f) for v, f in meshes_np], node_format="q16")
+    assert rt.cost_feedback
+    o, d = _rays(4099, 8)
+    # grazing rays: tangent to the outer shell
+    t = g.standard_normal((600, 3)).astype(np.float32)
+    t /= np.linalg.norm(t, axis=1, keepdims=True)
+    n = np.cross(t, g.standard_normal((600, 3)).astype(np.float32))
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    o[:600] = (0.34 * n - 2.0 * t).astype(np.float32)
+    d[:600] = t
+    oc, dc = torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda()
+    try:
+        RayTracer.coop_config(lanes=0)
+        ref = [x.clone() for x in rt.trace_all(oc, dc)]
+        for k, (v, f) in enumerate(meshes_np):
+            br = oracle_rt.trace_bruteforce(v, f, o, d)
+            face = torch.where(ref[1][k] >= 0, rt.slot_face_id[ref[1][k].clamp(min=0).long()],
+                               torch.full_like(ref[1][k], -1)).cpu().numpy()
+            assert np.array_equal(face, br["tri"]) and np.array_equal(ref[0][k].cpu().numpy(), br["t"])
+        assert (ref[1] >= 0).sum() > 4099
+        for chunk, lanes, max_waves in ((16, 24, 8192), (1, 64, 8192), (3, 7, 8192), (64, 1, 8192), (16, 24, 10)):
+            RayTracer.coop_config(chunk, lanes, max_waves)
+            for _ in range(2):          # (the second call reads the launch order the first one filed)
+                out = rt.trace_all(oc, dc)
+                assert all(torch.equal(a, b) for a, b in zip(out, ref)), (chunk, lanes, max_waves)
+        with pytest.raises(Exception):
+            RayTracer.coop_config(0, 24, 8192)
+    finally:
+        RayTracer.coop_config()

@@ -17,6 +17,8 @@
 // is bit-identical to the brute-force oracle (oracle/raytrace_ref.c).
 #include "common.h"
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -397,6 +399,165 @@ __device__ __forceinline__ int q_walk(const uint4* __restrict__ qnodes, const fl
   return trips;
 }
 
+// ---- cooperative finish of a wave's LAST rays.  A wave walks until its slowest ray is done: a grazing ray takes
+// 100-360 trips of the loop above against a median of 9, and a launch is as long as its longest wave (8 000 random
+// rays take 0.077 ms where 34 000 take 0.110, tools/trace_narrow_ab.py).  Once only a few lanes of a wave are still
+// walking (checked every `chunk` trips), they hand their pending subtrees — `cur` and the stack — to the WHOLE wave:
+// a queue of (node, ray lane) entries, of which every lane takes one per round, fetches its ray's parameters from the
+// owner lane, tests the node's two boxes (or the leaf's triangles) against the ray's current closest hit and appends
+// the children that survive.  One ray's remaining walk becomes ~its tree depth in rounds instead of its node count in
+// trips.  The closest hit is the minimum of (t, face id) over every triangle whose leaf is reached, and a subtree is
+// only dropped when its box starts beyond the closest hit known AT THAT TIME: a stale (larger) bound visits more, never
+// less — the hits are the ones of the one-ray-per-lane walk bit for bit (keys: ds_min_u64 on {ordered t, id}).
+// The queue lives in the stack's own LDS: the rows above the deepest straggler's stack are free, the entries are
+// gathered there and moved down to row 0 (+ 1.8 KB for the entries' ray lanes and the rays' keys).
+#ifndef TRACE_COOP_CHUNK
+#define TRACE_COOP_CHUNK 16      /* trips between two looks at how many lanes are left */
+#endif
+#ifndef TRACE_COOP_LANES
+#define TRACE_COOP_LANES 24      /* at most this many lanes still walking: the wave finishes them together */
+#endif
+#ifndef TRACE_COOP_WAVES
+#define TRACE_COOP_WAVES 4096    /* launches of at most this many waves: four per SIMD on 256 CUs (the finish's kernel holds no
+                                    more; 65 536 rays x 5 shells = 5 120 waves already ran 0.103 -> 0.114 ms with it) */
+#endif
+constexpr int TRACE_COOP_Q = 1536;      // (the 24-row stack's own 1 536 words hold the queue)
+struct TraceCoop {
+  unsigned long long key[TRACE_BLOCK];
+  int slot[TRACE_BLOCK];
+  unsigned char qr[TRACE_COOP_Q];
+};
+__device__ __forceinline__ unsigned long long coop_key(float t, int id) {
+  const unsigned b = __float_as_uint(t);
+  const unsigned o = b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);      // order-preserving for all finite t and +inf
+  return ((unsigned long long)o << 32) | (unsigned)id;
+}
+__device__ __forceinline__ float coop_key_t(unsigned long long k) {
+  const unsigned o = (unsigned)(k >> 32);
+  return __uint_as_float(o ^ ((o >> 31) ? 0x80000000u : 0xffffffffu));
+}
+
+// Returns the rounds it took, or -1 when the pending entries do not fit the queue (the caller walks on, one ray per
+// lane).  Every lane of the wave must call it; `cur` of at least one lane is not TRACE_EMPTY.
+template <int STACK>
+__device__ __forceinline__ int q_finish_coop(const uint4* __restrict__ qnodes, const float4* __restrict__ tris,
+                                          const QRay& qr, float ox, float oy, float oz, float dx, float dy,
+                                          float dz, float t_min, int& cur, int& sp, Hit& best,
+                                          int (*s_stack)[TRACE_BLOCK], TraceCoop& L, int lane) {
+  constexpr int QCAP = STACK * TRACE_BLOCK < TRACE_COOP_Q ? STACK * TRACE_BLOCK : TRACE_COOP_Q;
+  int* const qn = &s_stack[0][0];
+  const bool strag = cur != TRACE_EMPTY;
+  const int mine = strag ? sp + 1 : 0;
+  int incl = mine, top = strag ? sp : 0;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += o;
+    top = max(top, __shfl_xor(top, off, 64));
+  }
+  int count = __shfl(incl, 63, 64);
+  const int F = top * TRACE_BLOCK;           // rows >= top hold no straggler's entry
+  if (count > QCAP / 2 || F + count > STACK * TRACE_BLOCK) return -1;
+  if (strag) {
+    const int base = incl - mine;
+    L.key[lane] = coop_key(best.t, best.id);
+    L.slot[lane] = best.slot;
+    qn[F + base] = cur;
+    L.qr[base] = (unsigned char)lane;
+    for (int k = 0; k < sp; ++k) {
+      qn[F + base + 1 + k] = s_stack[k][lane];
+      L.qr[base + 1 + k] = (unsigned char)lane;
+    }
+  }
+  if (F)
+    for (int i = lane; i < count; i += TRACE_BLOCK) {      // down to row 0: a chunk is read whole before it is written
+      const int e = qn[F + i];
+      qn[i] = e;
+    }
+  const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+  int rounds = 0;
+  while (count > 0) {
+    ++rounds;
+    // near the cap one entry per round: a depth-first walk of the top entry adds at most the tree depth
+    const int P = count > QCAP - 128 - STACK ? 1 : min(64, count);
+    const int start = count - P;
+    const bool have = lane < P;
+    const int e = have ? qn[start + lane] : TRACE_EMPTY;
+    const int r = have ? (int)L.qr[start + lane] : lane;
+    count = start;
+    const unsigned long long k0 = L.key[r];
+    bool h0 = false, h1 = false;
+    int c0 = 0, c1 = 0;
+    {
+      QRay q;
+      const float ix = __shfl(qr.ix.x, r, 64), iy = __shfl(qr.iy.x, r, 64), iz = __shfl(qr.iz.x, r, 64);
+      const float cx = __shfl(qr.cx.x, r, 64), cy = __shfl(qr.cy.x, r, 64), cz = __shfl(qr.cz.x, r, 64);
+      q.ix = f32x2_t{ix, ix}, q.iy = f32x2_t{iy, iy}, q.iz = f32x2_t{iz, iz};
+      q.cx = f32x2_t{cx, cx}, q.cy = f32x2_t{cy, cy}, q.cz = f32x2_t{cz, cz};
+      if (have && e >= 0) {
+        const uint4 a = qnodes[2 * (long long)e], b = qnodes[2 * (long long)e + 1];
+        float tn0, tn1;
+        const float tb = coop_key_t(k0);
+        h0 = qbox_test(a.x, a.y, a.z, q, t_min, tb, tn0);
+        h1 = qbox_test(a.w, b.x, b.y, q, t_min, tb, tn1);
+        c0 = (int)b.z, c1 = (int)b.w;
+      }
+    }
+    // (the two halves of a round keep to themselves: with the ray fetches of both hoisted to the top the finish
+    //  took 115 registers where the walk takes 95 — four waves per SIMD instead of five for every launch)
+    __builtin_amdgcn_sched_barrier(0);
+    Hit hb;
+    hb.t = coop_key_t(k0), hb.id = (int)(unsigned)k0, hb.u = hb.v = 0.f, hb.slot = -1;
+    {
+      const float rox = __shfl(ox, r, 64), roy = __shfl(oy, r, 64), roz = __shfl(oz, r, 64);
+      const float rdx = __shfl(dx, r, 64), rdy = __shfl(dy, r, 64), rdz = __shfl(dz, r, 64);
+      if (have && e < 0) {
+        const int code = ~e;
+        const int first = code >> 4, cnt = code & 15;
+#pragma nounroll
+        for (int i = 0; i < cnt; ++i) {
+          const long long s = first + i;
+          tri_test(tris[3 * s], tris[3 * s + 1], tris[3 * s + 2], rox, roy, roz, rdx, rdy, rdz, t_min, first + i, hb);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const bool better = hb.slot >= 0;       // a triangle of this leaf beats the bound the lane started from
+    const unsigned long long mykey = coop_key(hb.t, hb.id);
+    if (better) atomicMin(&L.key[r], mykey);
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(h0), m1 = __builtin_amdgcn_ballot_w64(h1);
+    const int n0 = __builtin_popcountll(m0);
+    if (h0) {
+      const int p = count + __builtin_popcountll(m0 & lt);
+      qn[p] = c0;
+      L.qr[p] = (unsigned char)r;
+    }
+    if (h1) {
+      const int p = count + n0 + __builtin_popcountll(m1 & lt);
+      qn[p] = c1;
+      L.qr[p] = (unsigned char)r;
+    }
+    count += n0 + __builtin_popcountll(m1);
+    // of the lanes that improved ray r this round, the one whose key stands names the triangle
+    if (better && L.key[r] == mykey) L.slot[r] = hb.slot;
+  }
+  if (strag) {
+    const unsigned long long k = L.key[lane];
+    const int slot = L.slot[lane];
+    if (slot != best.slot) {                 // the owner forms u, v (and t again) of the winning triangle itself
+      Hit w;
+      w.t = INFINITY, w.u = w.v = 0.f, w.slot = -1, w.id = 0x7fffffff;
+      tri_test(tris[3 * (long long)slot], tris[3 * (long long)slot + 1], tris[3 * (long long)slot + 2], ox, oy, oz, dx, dy,
+               dz, t_min, slot, w);
+      best = w;
+    }
+    (void)k;
+  }
+  cur = TRACE_EMPTY;
+  sp = 0;
+  return rounds;
+}
+
 __device__ __forceinline__ void write_hit(const Hit& best, long long o, float* __restrict__ hit_t,
                                           int* __restrict__ hit_slot, float* __restrict__ hit_uv) {
   hit_t[o] = best.slot >= 0 ? best.t : 0.0f;
@@ -461,11 +622,16 @@ __global__ void trace_fb_flip_kernel(int* phase_word, char* half0, char* half1) 
 constexpr int TRACE_FB_TS[3] = {TRACE_FB_T};
 constexpr int TRACE_FB_T0 = TRACE_FB_TS[0], TRACE_FB_T1 = TRACE_FB_TS[1], TRACE_FB_T2 = TRACE_FB_TS[2];   // trips: list 0 / 1 / 2
 
-template <int STACK>
+// COOP: with the cooperative finish (q_finish_coop).  Its registers come on top of the walk's (95 -> 115 VGPRs: four
+// waves per SIMD instead of five, which costs a FRAME's launch of 50 000 waves 0.185 -> 0.209 ms whether the finish is
+// ever entered or not), so it is the kernel of launches that cannot fill four waves per SIMD anyway — training
+// batches — and the plain walk stays the kernel of the large ones (vsa_trace_q_fb picks by the number of waves).
+template <int STACK, bool COOP>
 __global__ __launch_bounds__(TRACE_BLOCK) void trace_qf_kernel(
     const uint4* __restrict__ qnodes, const float4* __restrict__ tris, Roots roots, Frames frames,
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, int N, int G, int nr_items, float t_min,
-    TraceFeedbackBuf fbb, float* __restrict__ hit_t, int* __restrict__ hit_slot, float* __restrict__ hit_uv) {
+    TraceFeedbackBuf fbb, float* __restrict__ hit_t, int* __restrict__ hit_slot, float* __restrict__ hit_uv,
+    int coop_chunk, int coop_lanes) {
   __shared__ int s_stack[STACK][TRACE_BLOCK];
   const int lane = threadIdx.x;
   const TraceFeedback fb = trace_fb_select(fbb);
@@ -508,8 +674,27 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_qf_kernel(
   best.id = 0x7fffffff;
   int cur = alive ? roots.root[mesh] : TRACE_EMPTY;
   int sp = 0;
-  const int trips = q_walk<STACK, true>(qnodes, tris, qr, ox, oy, oz, dx, dy, dz, t_min, cur, sp, best, s_stack,
-                                        lane, 0x7fffffff);
+  // one ray per lane, `coop_chunk` trips at a time, until at most `coop_lanes` lanes are still walking: the whole wave
+  // finishes those together (q_finish_coop)
+  int trips = 0;
+  if constexpr (COOP) {
+    __shared__ TraceCoop s_coop;
+    for (int chunk = coop_chunk;;) {
+      trips += q_walk<STACK, true>(qnodes, tris, qr, ox, oy, oz, dx, dy, dz, t_min, cur, sp, best, s_stack, lane, chunk);
+      const unsigned long long left = __builtin_amdgcn_ballot_w64(cur != TRACE_EMPTY);
+      if (left == 0) break;
+      if (__builtin_popcountll(left) > coop_lanes) continue;
+      const int rounds = q_finish_coop<STACK>(qnodes, tris, qr, ox, oy, oz, dx, dy, dz, t_min, cur, sp, best, s_stack,
+                                              s_coop, lane);
+      if (rounds >= 0) {
+        trips += rounds;
+        break;
+      }
+      // (the pending entries did not fit the queue: another chunk one ray per lane, then another look)
+    }
+  } else {
+    trips = q_walk<STACK, true>(qnodes, tris, qr, ox, oy, oz, dx, dy, dz, t_min, cur, sp, best, s_stack, lane, 0x7fffffff);
+  }
   if (alive) write_hit(best, (long long)mesh * N + n, hit_t, hit_slot, hit_uv);
   // file this wave for the next launch
   if (lane == 0) {
@@ -715,6 +900,27 @@ extern "C" long long vsa_trace_feedback_bytes(int nr_rays, int nr_meshes) {
   return 2 * trace_fb_half_bytes((long long)vsa_div_up(nr_rays, TRACE_BLOCK) * nr_meshes, nullptr) + 256;
 }
 
+// process-wide setting of the cooperative finish (vsa_trace_coop_config)
+struct TraceCoopConfig {
+  int chunk, lanes;
+  long long max_waves;
+};
+static TraceCoopConfig& trace_coop_config() {
+  static TraceCoopConfig cfg = [] {
+    TraceCoopConfig c{TRACE_COOP_CHUNK, TRACE_COOP_LANES, TRACE_COOP_WAVES};
+    if (const char* e = getenv("VSA_TRACE_COOP")) sscanf(e, "%d,%d", &c.chunk, &c.lanes);
+    if (const char* e = getenv("VSA_TRACE_COOP_WAVES")) c.max_waves = atoll(e);
+    if (c.chunk < 1 || c.lanes < 0 || c.lanes > TRACE_BLOCK || c.max_waves < 0) c = TraceCoopConfig{TRACE_COOP_CHUNK, TRACE_COOP_LANES, TRACE_COOP_WAVES};
+    return c;
+  }();
+  return cfg;
+}
+extern "C" int vsa_trace_coop_config(int chunk, int lanes, long long max_waves) {
+  if (chunk < 1 || lanes < 0 || lanes > TRACE_BLOCK || max_waves < 0) return VSA_ERR_ARG;
+  trace_coop_config() = TraceCoopConfig{chunk, lanes, max_waves};
+  return VSA_OK;
+}
+
 extern "C" int vsa_trace_q_fb(const uint32_t* qnodes, const float* tris, const int32_t* mesh_roots,
                               const float* mesh_frames, int nr_meshes, int max_depth, const float* rays_o,
                               const float* rays_d, int nr_rays, float t_min, float* hit_t, int32_t* hit_slot,
@@ -753,12 +959,20 @@ extern "C" int vsa_trace_q_fb(const uint32_t* qnodes, const float* tris, const i
   const float4* tr = reinterpret_cast<const float4*>(tris);
   // every item once, plus room for the listed ones' second (skipped) appearance
   dim3 grid((unsigned)(items + 3ll * cap)), block(TRACE_BLOCK);
-  if (max_depth < 24)
-    hipLaunchKernelGGL(trace_qf_kernel<24>, grid, block, 0, s, qn, tr, r, fr, rays_o, rays_d, nr_rays, G, (int)items,
-                       t_min, fb, hit_t, hit_slot, hit_uv);
-  else
-    hipLaunchKernelGGL(trace_qf_kernel<TRACE_STACK>, grid, block, 0, s, qn, tr, r, fr, rays_o, rays_d, nr_rays, G,
-                       (int)items, t_min, fb, hit_t, hit_slot, hit_uv);
+  const TraceCoopConfig& cfg = trace_coop_config();
+  const int coop_chunk = cfg.chunk, coop_lanes = cfg.lanes;
+  const bool coop = coop_lanes > 0 && items <= cfg.max_waves;
+#define TRACE_QF_LAUNCH(ST, CO)                                                                                        \
+  hipLaunchKernelGGL((trace_qf_kernel<ST, CO>), grid, block, 0, s, qn, tr, r, fr, rays_o, rays_d, nr_rays, G, (int)items, \
+                     t_min, fb, hit_t, hit_slot, hit_uv, coop_chunk, coop_lanes)
+  if (max_depth < 24) {
+    if (coop) TRACE_QF_LAUNCH(24, true);
+    else TRACE_QF_LAUNCH(24, false);
+  } else {
+    if (coop) TRACE_QF_LAUNCH(TRACE_STACK, true);
+    else TRACE_QF_LAUNCH(TRACE_STACK, false);
+  }
+#undef TRACE_QF_LAUNCH
   VSA_RETURN_LAUNCH_STATUS();
 }
 

@@ -180,6 +180,13 @@ class RayTracer:
     NARROW_BELOW = int(os.environ.get("VSA_TRACE_NARROW_BELOW", "0"))
     NARROW_RPW = int(os.environ.get("VSA_TRACE_RPW", "16"))
 
+    @staticmethod
+    def coop_config(chunk=16, lanes=24, max_waves=4096):
+        """Process-wide setting of the traversal's cooperative finish (vsa_trace_coop_config: in launches of at most
+        `max_waves` waves a wave whose last `lanes` rays are still walking finishes them together; lanes = 0: never).
+        The hits do not depend on it."""
+        _lib.call("vsa_trace_coop_config", int(chunk), int(lanes), ctypes.c_longlong(int(max_waves)))
+
     def narrow_rays_per_wave(self, N, K):
         return self.NARROW_RPW if N * K < self.NARROW_BELOW else 64
 
