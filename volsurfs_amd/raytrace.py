@@ -134,16 +134,23 @@ class RayTracer:
             pass
         self._bvh = []
 
-    def trace_all(self, rays_o, rays_d, t_min=0.0):
+    def trace_all(self, rays_o, rays_d, t_min=0.0, out=None):
         """All K shells, one launch.  Returns hit_t [K,N] f32, hit_slot [K,N]
-        i32 (global index into self.tris, -1 = miss), hit_uv [K,N,2] f32."""
+        i32 (global index into self.tris, -1 = miss), hit_uv [K,N,2] f32 (written into `out` = that triple when given)."""
         N = rays_o.shape[0]
         rays_o = _lib.check_f32(rays_o.contiguous(), N, 3)
         rays_d = _lib.check_f32(rays_d.contiguous(), N, 3)
         K = self.nr_meshes
-        hit_t = torch.empty(K, N, device=rays_o.device)
-        hit_slot = torch.empty(K, N, dtype=torch.int32, device=rays_o.device)
-        hit_uv = torch.empty(K, N, 2, device=rays_o.device)
+        if out is not None:
+            hit_t, hit_slot, hit_uv = out
+            _lib.check_f32(hit_t, K, N)
+            _lib.check_f32(hit_uv, K, N, 2)
+            if hit_slot.dtype != torch.int32 or tuple(hit_slot.shape) != (K, N) or not hit_slot.is_contiguous():
+                raise _lib.VolsurfsHipError("trace_all: out[1] must be a contiguous int32 [K, N] tensor")
+        else:
+            hit_t = torch.empty(K, N, device=rays_o.device)
+            hit_slot = torch.empty(K, N, dtype=torch.int32, device=rays_o.device)
+            hit_uv = torch.empty(K, N, 2, device=rays_o.device)
         # small batches (a training batch's few ten thousand random rays: ~2 waves per SIMD, each the maximum of 64
         # unrelated walks): narrow waves — fewer rays per wave, more waves (vsa_trace_q_narrow; same hits).  The launch-order
         # feedback has nothing to learn from random rays (profiles/NOTEBOOK.md round 5)
