@@ -391,6 +391,21 @@ def run_train(args, world, rank, dev, dist):
         ktab = kernel_table(lambda: one(False), 20)
         top = next(iter(ktab))
         roof = {"kernel": top, "kernel_ms": ktab[top]["ms_per_iter"] / max(1.0, ktab[top]["calls_per_iter"])}
+        if legacy and top.startswith("vsa_mlp_"):
+            # the fp32 matrix-core MLPs of the legacy appearance models (models/rgb.py:139: 66 -> 128 -> 128 -> 64 -> C):
+            # executed FLOPs of all K shells' networks over the iteration's hits (a frac for configs[2])
+            hits = int(getattr(method, "last_nr_samples", 0))
+            fl_fwd = 0
+            for typ in ("rgb", "alpha"):
+                mods = [mm for k_, mm in method.models.items() if k_.split("_")[0] == typ and mm is not None]
+                if mods:
+                    dims = [[l.in_features, l.out_features] for l in mods[0].mlp.layers if isinstance(l, torch.nn.Linear)]
+                    fl_fwd += 2 * sum(a * b for a, b in dims) * hits
+            mult = 2 if "bwd" in top else 1
+            sec = ktab[top]["ms_per_iter"] * 1e-3
+            roof.update(bound="mfma", achieved=fl_fwd * mult / sec / 1e12, peak=157.3, unit="TFLOP/s",
+                        frac=fl_fwd * mult / sec / 1e12 / 157.3, traffic=None,
+                        units={"hits": hits, "calls_per_iter": ktab[top]["calls_per_iter"], "dtype": "f32 (v_mfma_f32_32x32x2_f32)"})
         if not legacy:        # algorithmic bytes of the neural-texture stages at THIS batch (neural_textures.stage_accounting)
             from volsurfs_amd.neural_textures import stage_accounting
             n_last = state["nr_rays"]

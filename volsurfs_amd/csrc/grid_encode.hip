@@ -11,11 +11,16 @@
 // the tables are gathered from L2 / the 256 MiB MALL (24 levels = 48 MiB): one thread per
 // (sample, level), 2^D float2 gathers, D-linear weights formed in the oracle's order.
 #include "common.h"
+#include <cstdint>
+#include <cstdlib>
 
 namespace {
 
 #ifndef GRID_FWD_PAIRS
 #define GRID_FWD_PAIRS 1
+#endif
+#ifndef GRID_FWD_LV
+#define GRID_FWD_LV 2     /* levels per thread: 1 / 2 / 4 = 1.63 / 1.47 / 1.59 ms per 2.1 M-sample batch (bench.py --workload dtu) */
 #endif
 constexpr unsigned GRID_PRIMES[3] = {1u, 2654435761u, 805459861u};
 
@@ -85,15 +90,21 @@ __device__ __forceinline__ float corner_weight(const GridCell<D>& cell, int corn
   return w;
 }
 
-template <int D>
+// LV levels per thread (blockIdx.y = group of LV levels): a thread's LV feature pairs leave as ONE 8 LV-byte store.  One
+// level per thread wrote 8 bytes per lane, 208 bytes apart (a 52-float row): every wave instruction touched 64 lines for
+// 512 bytes, 50 M such requests per 2.1 M-sample batch (what that pattern costs: profiles/r06/encode_bwd_train_diag.txt).
+template <int D, int LV>
 __global__ __launch_bounds__(256) void grid_encode_fwd_kernel(vsa_grid_plan plan,
                                                               const float2* __restrict__ tables,
                                                               const float* __restrict__ x, int B,
                                                               float* __restrict__ out, int out_stride,
                                                               int append_x) {
   const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int l = blockIdx.y;
   if (b >= B) return;
+  float res[2 * LV];
+#pragma unroll
+  for (int lv = 0; lv < LV; ++lv) {
+  const int l = blockIdx.y * LV + lv;
   const GridLevel g = grid_level(plan, l);
   const GridCell<D> cell = grid_cell<D>(g, x + b * D);
   float f0 = 0.f, f1 = 0.f;
@@ -144,17 +155,24 @@ __global__ __launch_bounds__(256) void grid_encode_fwd_kernel(vsa_grid_plan plan
     f1 = f1 + w * v.y;
   }
 #endif
+  res[2 * lv] = f0, res[2 * lv + 1] = f1;
+  }
   // out row = [2 L features | the D inputs when append_x] (GridHashEncoder's concat_points written
   // here instead of by a torch.cat over the whole feature matrix); rows of odd stride are not
   // 8-byte aligned
-  float* o = out + b * out_stride + 2 * l;
-  if ((out_stride & 1) == 0) {
-    *reinterpret_cast<float2*>(o) = make_float2(f0, f1);
+  float* o = out + b * out_stride + 2 * LV * blockIdx.y;
+  if (LV % 2 == 0 && (out_stride & 3) == 0) {       // 16-byte groups (launched only for 16-byte aligned `out`)
+#pragma unroll
+    for (int q = 0; q < LV / 2; ++q)
+      reinterpret_cast<float4*>(o)[q] = make_float4(res[4 * q], res[4 * q + 1], res[4 * q + 2], res[4 * q + 3]);
+  } else if ((out_stride & 1) == 0) {
+#pragma unroll
+    for (int lv = 0; lv < LV; ++lv) reinterpret_cast<float2*>(o)[lv] = make_float2(res[2 * lv], res[2 * lv + 1]);
   } else {
-    o[0] = f0;
-    o[1] = f1;
+#pragma unroll
+    for (int i = 0; i < 2 * LV; ++i) o[i] = res[i];
   }
-  if (append_x && l == 0) {
+  if (append_x && blockIdx.y == 0) {
 #pragma unroll
     for (int d = 0; d < D; ++d) out[b * out_stride + 2 * plan.n_levels + d] = x[b * D + d];
   }
@@ -697,13 +715,24 @@ extern "C" int vsa_grid_encode_fwd_ld(const vsa_grid_plan* plan, const float* ta
   if (nr_points < 0 || out_stride < 2 * plan->n_levels + (append_x ? plan->n_dims : 0)) return VSA_ERR_ARG;
   if (nr_points == 0) return VSA_OK;
   if (!tables || !x || !out) return VSA_ERR_ARG;
-  dim3 grid(vsa_div_up(nr_points, 256), plan->n_levels);
-  if (plan->n_dims == 2)
-    hipLaunchKernelGGL(grid_encode_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, *plan,
-                       reinterpret_cast<const float2*>(tables), x, nr_points, out, out_stride, append_x);
-  else
-    hipLaunchKernelGGL(grid_encode_fwd_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, *plan,
-                       reinterpret_cast<const float2*>(tables), x, nr_points, out, out_stride, append_x);
+  // levels per thread: 4 (32-byte stores) / 2 where the level count divides and the rows are 16-byte groups
+  static const int lv_env = getenv("VSA_GRID_FWD_LV") ? atoi(getenv("VSA_GRID_FWD_LV")) : GRID_FWD_LV;
+  const bool wide = (out_stride & 3) == 0 && ((uintptr_t)out & 15) == 0;
+  const int lv = wide && lv_env >= 4 && plan->n_levels % 4 == 0 ? 4 : wide && lv_env >= 2 && plan->n_levels % 2 == 0 ? 2 : 1;
+  dim3 grid(vsa_div_up(nr_points, 256), plan->n_levels / lv);
+#define GRID_FWD_LAUNCH(DD, LL)                                                                                  \
+  hipLaunchKernelGGL((grid_encode_fwd_kernel<DD, LL>), grid, dim3(256), 0, (hipStream_t)stream, *plan,          \
+                     reinterpret_cast<const float2*>(tables), x, nr_points, out, out_stride, append_x)
+  if (plan->n_dims == 2) {
+    if (lv == 4) GRID_FWD_LAUNCH(2, 4);
+    else if (lv == 2) GRID_FWD_LAUNCH(2, 2);
+    else GRID_FWD_LAUNCH(2, 1);
+  } else {
+    if (lv == 4) GRID_FWD_LAUNCH(3, 4);
+    else if (lv == 2) GRID_FWD_LAUNCH(3, 2);
+    else GRID_FWD_LAUNCH(3, 1);
+  }
+#undef GRID_FWD_LAUNCH
   VSA_RETURN_LAUNCH_STATUS();
 }
 
