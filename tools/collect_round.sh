@@ -6,7 +6,7 @@ cd $root; export TMPDIR=/tmp
 mkdir -p gpurun_out
 if [ "$2" != "notests" ]; then
   rm -f gpurun_out/parity_report.json
-  python -m pytest tests -m gpu -q 2>&1 | tail -6 > gpurun_out/${tag}_tests.log; tail -3 gpurun_out/${tag}_tests.log
+  python -m pytest tests -m gpu -q --durations=25 2>&1 | tail -40 > gpurun_out/${tag}_tests.log; tail -3 gpurun_out/${tag}_tests.log
 fi
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/${tag}_smoke.log
 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -2 gpurun_out/${tag}_bench.err
@@ -21,6 +21,8 @@ python bench.py --gpus 1 --force-dist --dist-backend nccl --no-cpu-baseline --no
 bash tools/prof.sh ${tag}_prof_frame --steps 20 --warmup 5 --no-noisy | tail -3
 bash tools/prof.sh ${tag}_prof_render --workload render --steps 20 --warmup 5 | tail -3
 bash tools/prof.sh ${tag}_prof_train --workload train --steps 100 --warmup 30 | tail -3
+bash tools/prof.sh ${tag}_prof_trainp --workload train-permuto --steps 100 --warmup 30 | tail -3
+bash tools/prof.sh ${tag}_prof_dtu --workload dtu --steps 1 --warmup 1 | tail -3
 bash tools/traffic.sh frame | tail -12
 bash tools/traffic.sh k7 --res 1080 --width 1920 --shells 7 --subdiv 8 | tail -12
 P="--steps 3 --warmup 1 --no-noisy"

@@ -26,7 +26,8 @@ pr = os.path.join(root, "gpurun_out", "parity_report.json")
 if os.path.exists(pr):
     shutil.copy(pr, os.path.join(R, "parity_report.json"))
 for t, name in (("prof_frame", "kernel_stats_frame.csv"), ("prof_k7", "kernel_stats_1080p_K7_subdiv8.csv"),
-                ("prof_render", "kernel_stats_render.csv"), ("prof_train", "kernel_stats_train.csv")):
+                ("prof_render", "kernel_stats_render.csv"), ("prof_train", "kernel_stats_train.csv"),
+                ("prof_trainp", "kernel_stats_train_permuto.csv"), ("prof_dtu", "kernel_stats_dtu.csv")):
     fs = sorted(glob.glob(os.path.join(root, "gpurun_out", f"{tag}_{t}", "*", "*kernel_stats.csv")), key=os.path.getmtime)
     if fs:
         shutil.copy(fs[-1], os.path.join(R, name))
