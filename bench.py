@@ -422,6 +422,12 @@ def run_train(args, world, rank, dev, dist):
                     roof.update(bound="hbm", achieved=acct[key] / sec / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                                 frac=acct[key] / sec / 1e9 / HBM_PEAK_GBS, traffic=None)
                 roof["units"] = {"rays": n_last, "hits": hits, "unique_texels": slots}
+                # (events around ONE launch of a host-driven loop read 0.16-0.18 ms for this kernel where rocprofv3's
+                #  average over the same loop and the workgroups' own clocks read 0.09-0.105: profiles/r06/
+                #  kernel_stats_train.csv, mlp_bwd_train_stamps.txt — the frame line's kernel_ms, taken on 11 M pairs, agrees
+                #  with rocprofv3)
+                roof["kernel_ms_note"] = ("events around a single launch in the host-driven loop; rocprofv3 averages the same "
+                                          "kernel at 0.09-0.105 ms at this batch (profiles/r06/kernel_stats_train.csv)")
     if rank == 0:
         ms = dt / args.steps * 1e3
         nparams = sum(p.numel() for g in method.optimizer.param_groups for p in g["params"])
