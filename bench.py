@@ -833,7 +833,10 @@ def main():
                 pipe.capture_graph_split(dp=ostep.signals)
             else:
                 pipe.capture_graph()
-            for _ in range(2):
+            # (the capture is ~0.1 s of host work with the GPU idle: untimed replays before the timed region, so that a
+            #  short timed region — 20 steps = 50 ms — does not start on a device that has clocked down.  Same box, 20 timed
+            #  steps: 2 replays 260.0 / 260.2 Mrays/s, 12: 263.3 / 265.3, 40: 267.1 = what 200 timed steps read)
+            for _ in range(int(os.environ.get("VSA_BENCH_POST_CAPTURE_REPLAYS", "40"))):
                 ostep.run_split(pipe.replay_prefix, pipe.replay_mid, pipe.replay_tail) if ostep is not None else pipe.replay()
             if ostep is not None:
                 ostep.finish()
