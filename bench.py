@@ -641,7 +641,7 @@ def extra_scene(args, dev, use_graph, tag, steps=50, cold=False, orbit_deg=0.0, 
             pipe.rays_o.copy_(views[i % len(views)][0])
             pipe.rays_d.copy_(views[i % len(views)][1])
         run()
-    for i in range(3):
+    for i in range(24 if use_graph else 3):      # (untimed: the device clocks down during the capture, see the main line)
         frame(i)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
